@@ -1,0 +1,169 @@
+/*
+ * mvs_hip.h -- C ABI of libmvs_hip.so: the MI355X (gfx950) implementation of the reference's
+ * random-projection sketching + all-vs-all sketch comparison hot path.
+ *
+ * The reference (RolandFaure/metagenome_vector_sketches) has no FFI seam on this path: the
+ * functions below are what its two executables would bind if the hot loops were moved behind one.
+ * Each entry point cites the reference code it replaces (paths relative to the reference root).
+ * INTEGRATION.md shows the call sites a maintainer would change.
+ *
+ * Conventions
+ *   - plain C types only; the caller owns every buffer it passes in; the library never frees
+ *     caller memory and never keeps a caller pointer after the call returns (except the non-owning
+ *     views documented at mvs_sketch_set_from_planes);
+ *   - every function returns MVS_OK (0) or an MVS_E_* code; mvs_last_error() gives the message of the
+ *     last failure on the calling thread; no C++ exception crosses this boundary;
+ *   - `mem` arguments say where a buffer lives: MVS_MEM_HOST (pageable or pinned host memory) or
+ *     MVS_MEM_DEVICE (HBM of the context's device);
+ *   - all work of a context is issued on ONE HIP stream (its own, or the one given to
+ *     mvs_ctx_set_stream); calls with only device buffers are asynchronous on that stream unless
+ *     stated otherwise; a context is thread-compatible, not thread-safe;
+ *   - there is no CPU fallback: if no gfx950 device is usable every call fails with MVS_E_HIP.
+ */
+#ifndef MVS_HIP_H
+#define MVS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MVS_OK           0
+#define MVS_E_INVALID    1   /* bad argument */
+#define MVS_E_HIP        2   /* HIP runtime / device failure */
+#define MVS_E_CAPACITY   3   /* output buffer too small; the needed size is reported */
+#define MVS_E_NOMEM      4   /* host or device allocation failed */
+#define MVS_E_RANGE      5   /* input outside the supported numeric range */
+
+#define MVS_MEM_HOST     0
+#define MVS_MEM_DEVICE   1
+
+/* keep test variants */
+#define MVS_KEEP_INT32   0   /* src/pairwise_comp_optimized.cpp:139-141  (int64 dot / d truncates) */
+#define MVS_KEEP_INT16   1   /* src/pairwise_comp_optimized_16bits.cpp:211-218 (double(dot)/d)    */
+
+typedef struct mvs_ctx mvs_ctx;
+typedef struct mvs_sketch_set mvs_sketch_set;
+
+/* One kept cell of the comparison matrix: what the reference appends to `all_results`
+ * (src/pairwise_comp_optimized.cpp:974-980) plus the quantised Jaccard its writer derives from it
+ * (:658-665). */
+typedef struct {
+    int32_t row;   /* global sample index of the row                              */
+    int32_t col;   /* global sample index of the column                           */
+    int32_t dot;   /* int32 dot product, wrapped mod 2^32 (MatrixXi product, :135) */
+    int32_t q;     /* uint16_t(round(min(J,1)*255)), J = (dot/d)/(n2r+n2c-dot/d)   */
+} mvs_cell;
+
+/* ---- library / context ------------------------------------------------------------------------ */
+const char* mvs_version(void);
+const char* mvs_last_error(void);
+int mvs_device_count(int* count);
+
+int mvs_ctx_create(int device, mvs_ctx** ctx);
+int mvs_ctx_destroy(mvs_ctx* ctx);
+/* Issue all later work on `hip_stream` (a hipStream_t of the same device, e.g. the caller's
+ * framework stream).  NULL switches back to the context's own stream. */
+int mvs_ctx_set_stream(mvs_ctx* ctx, void* hip_stream);
+int mvs_ctx_synchronize(mvs_ctx* ctx);
+/* Optional kernel timing: when enabled, HIP events are recorded on the context's stream around the
+ * dominant kernel of mvs_project_csr (which = 0) and of mvs_pairwise_rows (which = 1);
+ * mvs_ctx_kernel_ms returns the duration of the most recent such launch in milliseconds. */
+int mvs_ctx_set_timing(mvs_ctx* ctx, int enabled);
+int mvs_ctx_kernel_ms(mvs_ctx* ctx, int which, float* ms);
+
+/* ---- projection ----------------------------------------------------------------------------------
+ * Replaces transform_set_into_vector() (src/random_projection.cpp:9-26) called once per sample from
+ * the OpenMP loop of sketch() (src/project_everything.cpp:289-298) and from standalone_projection
+ * (src/standalone_projection.cpp:37).
+ *
+ * hashes  : concatenated per-sample hash lists (CSR values), `mem_hashes` says where they live.
+ *           Precondition: hashes of one sample are unique (the reference holds them in an
+ *           std::unordered_set); order is irrelevant.
+ * offsets : n_samples+1 HOST int64, offsets[s]..offsets[s+1] is sample s; a sample may be empty.
+ *           Each sample must hold < 2^31 hashes.
+ * out     : n_samples x d int32, row-major by sample (the vectors.bin record layout,
+ *           src/project_everything.cpp:349-353), `mem_out` says where.
+ * out[s][k] = sum over hashes h of (1 - 2*bit_{k%64}(splitmix64(h + 64*(k/64)))), exact.
+ */
+int mvs_project_csr(mvs_ctx* ctx, const uint64_t* hashes, int mem_hashes, const int64_t* offsets,
+                    int64_t n_samples, int d, int32_t* out, int mem_out);
+
+/* Sum of squares of each sketch (exact int64): the integer the norm of
+ * src/project_everything.cpp:328-329 is derived from (norm = sqrt(sumsq / d)). */
+int mvs_sketch_sumsq(mvs_ctx* ctx, const int32_t* sketches, int mem_in, int64_t n, int d,
+                     int64_t* sumsq, int mem_out);
+
+/* Saturating int32 -> int16 store of the --int16 mode (src/project_everything.cpp:332-347). */
+int mvs_sketch_saturate_i16(mvs_ctx* ctx, const int32_t* sketches, int mem_in, int64_t n_elems,
+                            int16_t* out, int mem_out);
+
+/* ---- pairwise comparison --------------------------------------------------------------------------
+ * Replaces load_matrix_block() + compute_sparse_dot_products_optimized() + the tiling loop of
+ * main() (src/pairwise_comp_optimized.cpp:33-54, :57-160, :949-982) and the per-cell arithmetic of
+ * write_sparse_results_jaccard_wo_sort() (:658-665); for elem_bytes == 2 also
+ * compute_sparse_dot_products_optimized_16() (src/pairwise_comp_optimized_16bits.cpp:96-244).
+ *
+ * The sketches are first re-coded into signed base-256 int8 "limb planes" kept in HBM (exact:
+ * v == sum_a limb_a * 256^a mod 2^32); the comparison kernel multiplies limb planes on the int8
+ * matrix cores with int32 accumulation and recombines them mod 2^32, so `dot` carries exactly the
+ * bits of the reference's int32 Eigen product.
+ */
+
+/* Largest |v| over n*d sketch entries (elem_bytes 4: int32, 2: int16); synchronous. */
+int mvs_sketch_max_abs(mvs_ctx* ctx, const void* sketches, int elem_bytes, int mem, int64_t n_elems,
+                       int64_t* max_abs);
+/* Number of limbs needed for entries up to max_abs (1..4). */
+int mvs_limbs_for_max_abs(int64_t max_abs);
+/* Geometry of the limb-plane buffer for n samples: rows are padded to n_alloc (multiple of 128,
+ * plus one spare tile), the dimension to d_pad (multiple of 128); layout is
+ * planes[(row * limbs + limb) * d_pad + k], zero filled outside n x d. */
+int mvs_limb_geometry(int64_t n, int d, int limbs, int64_t* n_alloc, int* d_pad, size_t* bytes);
+/* Re-code rows [0, n_rows) of `sketches` into rows [row_offset, row_offset + n_rows) of a
+ * caller-owned DEVICE plane buffer that has been zero-filled (so several producers -- e.g. the
+ * ranks of an all-gather -- can fill disjoint row ranges of one buffer). */
+int mvs_limb_split(mvs_ctx* ctx, const void* sketches, int elem_bytes, int mem, int64_t n_rows, int d,
+                   int limbs, int8_t* planes, int d_pad, int64_t row_offset);
+
+/* A sketch set = limb planes of N samples resident in HBM.
+ * mvs_sketch_set_create : allocates the planes, re-codes `sketches` (chooses the limb count itself).
+ * mvs_sketch_set_from_planes : NON-owning view of a caller-owned device buffer filled by
+ *   mvs_limb_split (and, across GPUs, by an all-gather of per-rank row blocks); the buffer must
+ *   outlive the set. */
+int mvs_sketch_set_create(mvs_ctx* ctx, const void* sketches, int elem_bytes, int mem, int64_t n, int d,
+                          mvs_sketch_set** set);
+int mvs_sketch_set_from_planes(mvs_ctx* ctx, const int8_t* planes, int64_t n, int64_t n_alloc, int d,
+                               int d_pad, int limbs, mvs_sketch_set** set);
+int mvs_sketch_set_info(const mvs_sketch_set* set, int64_t* n, int* d, int* limbs, int64_t* n_alloc,
+                        int* d_pad);
+int mvs_sketch_set_destroy(mvs_sketch_set* set);
+
+/* All-vs-all for the row range [row_begin, row_end) against ALL n columns -- one shard of
+ * src/pairwise_comp_optimized.cpp:938-982.
+ *   norms_sq : n doubles, (parsed norm)^2 as built at :893-901 (`mem_norms` says where).
+ *   keep_mode: MVS_KEEP_INT32 or MVS_KEEP_INT16.
+ *   cells    : capacity entries (`mem_cells`); on success holds *n_cells kept cells sorted by
+ *              (row, col) -- the per-row, ascending-column order the reference's writer relies on
+ *              (:718-722).  If more than `capacity` cells are kept the call returns MVS_E_CAPACITY
+ *              and *n_cells is the number needed (retry with a larger buffer or fewer rows).
+ * Synchronous (returns after the count is known). */
+int mvs_pairwise_rows(mvs_ctx* ctx, const mvs_sketch_set* set, const double* norms_sq, int mem_norms,
+                      int keep_mode, int64_t row_begin, int64_t row_end, mvs_cell* cells,
+                      int64_t capacity, int mem_cells, int64_t* n_cells);
+
+/* Dense int32 dot products of rows [r0,r1) x cols [c0,c1) (row-major, leading dimension c1-c0):
+ * the bare `block_i.transpose() * block_j` of src/pairwise_comp_optimized.cpp:135.  For validation
+ * and small problems.  `algo` 0 = matrix-core path, 1 = plain vector-ALU path (independent check). */
+int mvs_pairwise_dots(mvs_ctx* ctx, const mvs_sketch_set* set, int64_t r0, int64_t r1, int64_t c0,
+                      int64_t c1, int32_t* out, int mem_out, int algo);
+
+/* src/pairwise_comp_optimized.cpp:903-906 and :938-940, for drivers that keep the reference CLI */
+int64_t mvs_chunk_size(double max_memory_gb, int d);
+void mvs_shard_rows(int64_t n, int num_shards, int shard_idx, int64_t* begin, int64_t* end);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MVS_HIP_H */

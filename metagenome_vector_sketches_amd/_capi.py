@@ -1,0 +1,298 @@
+"""ctypes binding of libmvs_hip.so (include/mvs_hip.h).
+
+The library is the product: if it is missing or cannot be loaded this module raises -- there is no
+Python or CPU fallback for the hot path.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmvs_hip.so")
+
+MVS_OK, MVS_E_INVALID, MVS_E_HIP, MVS_E_CAPACITY, MVS_E_NOMEM, MVS_E_RANGE = 0, 1, 2, 3, 4, 5
+MEM_HOST, MEM_DEVICE = 0, 1
+KEEP_INT32, KEEP_INT16 = 0, 1
+
+CELL_DTYPE = np.dtype([("row", "<i4"), ("col", "<i4"), ("dot", "<i4"), ("q", "<i4")])
+
+# every symbol include/mvs_hip.h declares: (name, restype, argtypes)
+_c = ctypes
+_P = _c.c_void_p
+SYMBOLS = [
+    ("mvs_version", _c.c_char_p, []),
+    ("mvs_last_error", _c.c_char_p, []),
+    ("mvs_device_count", _c.c_int, [_c.POINTER(_c.c_int)]),
+    ("mvs_ctx_create", _c.c_int, [_c.c_int, _c.POINTER(_P)]),
+    ("mvs_ctx_destroy", _c.c_int, [_P]),
+    ("mvs_ctx_set_stream", _c.c_int, [_P, _P]),
+    ("mvs_ctx_synchronize", _c.c_int, [_P]),
+    ("mvs_ctx_set_timing", _c.c_int, [_P, _c.c_int]),
+    ("mvs_ctx_kernel_ms", _c.c_int, [_P, _c.c_int, _c.POINTER(_c.c_float)]),
+    ("mvs_project_csr", _c.c_int, [_P, _P, _c.c_int, _P, _c.c_int64, _c.c_int, _P, _c.c_int]),
+    ("mvs_sketch_sumsq", _c.c_int, [_P, _P, _c.c_int, _c.c_int64, _c.c_int, _P, _c.c_int]),
+    ("mvs_sketch_saturate_i16", _c.c_int, [_P, _P, _c.c_int, _c.c_int64, _P, _c.c_int]),
+    ("mvs_sketch_max_abs", _c.c_int, [_P, _P, _c.c_int, _c.c_int, _c.c_int64, _c.POINTER(_c.c_int64)]),
+    ("mvs_limbs_for_max_abs", _c.c_int, [_c.c_int64]),
+    ("mvs_limb_geometry", _c.c_int, [_c.c_int64, _c.c_int, _c.c_int, _c.POINTER(_c.c_int64),
+                                      _c.POINTER(_c.c_int), _c.POINTER(_c.c_size_t)]),
+    ("mvs_limb_split", _c.c_int, [_P, _P, _c.c_int, _c.c_int, _c.c_int64, _c.c_int, _c.c_int, _P, _c.c_int,
+                                   _c.c_int64]),
+    ("mvs_sketch_set_create", _c.c_int, [_P, _P, _c.c_int, _c.c_int, _c.c_int64, _c.c_int, _c.POINTER(_P)]),
+    ("mvs_sketch_set_from_planes", _c.c_int, [_P, _P, _c.c_int64, _c.c_int64, _c.c_int, _c.c_int, _c.c_int,
+                                               _c.POINTER(_P)]),
+    ("mvs_sketch_set_info", _c.c_int, [_P, _c.POINTER(_c.c_int64), _c.POINTER(_c.c_int), _c.POINTER(_c.c_int),
+                                        _c.POINTER(_c.c_int64), _c.POINTER(_c.c_int)]),
+    ("mvs_sketch_set_destroy", _c.c_int, [_P]),
+    ("mvs_pairwise_rows", _c.c_int, [_P, _P, _P, _c.c_int, _c.c_int, _c.c_int64, _c.c_int64, _P, _c.c_int64,
+                                      _c.c_int, _c.POINTER(_c.c_int64)]),
+    ("mvs_pairwise_dots", _c.c_int, [_P, _P, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _P, _c.c_int,
+                                      _c.c_int]),
+    ("mvs_chunk_size", _c.c_int64, [_c.c_double, _c.c_int]),
+    ("mvs_shard_rows", None, [_c.c_int64, _c.c_int, _c.c_int, _c.POINTER(_c.c_int64), _c.POINTER(_c.c_int64)]),
+]
+
+_lib = None
+
+
+class MvsError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("libmvs_hip error %d: %s" % (code, message))
+        self.code = code
+
+
+def load_library():
+    """Load libmvs_hip.so (once).  torch, when present, is imported first so that the process uses a
+    single HIP runtime (torch's bundled libamdhip64 has the same SONAME as the system one)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "libmvs_hip.so not found at %s -- build it with `make -C metagenome_vector_sketches_amd/csrc` "
+            "(or __graft_entry__.build()); there is no CPU fallback" % LIB_PATH)
+    try:
+        import torch  # noqa: F401  (side effect: loads the HIP runtime torch ships)
+    except Exception:  # torch is plumbing for tests/bench, not a requirement of the library
+        pass
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, restype, argtypes in SYMBOLS:
+        fn = getattr(lib, name)  # AttributeError if the ABI is incomplete
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def _check(rc):
+    if rc != MVS_OK:
+        raise MvsError(rc, load_library().mvs_last_error().decode("utf-8", "replace"))
+
+
+def _is_torch(x):
+    return type(x).__module__.startswith("torch")
+
+
+def _buf(x, dtype=None, writable=False):
+    """-> (pointer, mem flag, keepalive).  numpy arrays are host buffers, torch CUDA tensors device."""
+    if x is None:
+        return None, MEM_HOST, None
+    if _is_torch(x):
+        if not x.is_contiguous():
+            raise ValueError("tensor must be contiguous")
+        return x.data_ptr(), (MEM_DEVICE if x.is_cuda else MEM_HOST), x
+    a = np.ascontiguousarray(x, dtype=dtype) if not writable else x
+    if writable and (not a.flags["C_CONTIGUOUS"] or (dtype is not None and a.dtype != np.dtype(dtype))):
+        raise ValueError("output array must be C-contiguous %s" % dtype)
+    return a.ctypes.data, MEM_HOST, a
+
+
+class SketchSet:
+    """Limb planes of N samples resident in HBM (mvs_sketch_set)."""
+
+    def __init__(self, ctx, handle, keep=None):
+        self.ctx, self._h, self._keep = ctx, handle, keep
+        n, d, limbs, n_alloc, d_pad = (_c.c_int64(), _c.c_int(), _c.c_int(), _c.c_int64(), _c.c_int())
+        _check(ctx.lib.mvs_sketch_set_info(handle, n, d, limbs, n_alloc, d_pad))
+        self.n, self.d, self.limbs, self.n_alloc, self.d_pad = n.value, d.value, limbs.value, n_alloc.value, d_pad.value
+
+    def close(self):
+        if self._h:
+            self.ctx.lib.mvs_sketch_set_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Context:
+    """One device + one stream (mvs_ctx)."""
+
+    def __init__(self, device=0, stream=None):
+        self.lib = load_library()
+        h = _P()
+        _check(self.lib.mvs_ctx_create(int(device), ctypes.byref(h)))
+        self._h = h
+        self.device = device
+        if stream is not None:
+            self.set_stream(stream)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.mvs_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, stream):
+        """stream: raw hipStream_t value (int), a torch.cuda.Stream, or None for the context's own."""
+        if stream is not None and hasattr(stream, "cuda_stream"):
+            stream = stream.cuda_stream
+        _check(self.lib.mvs_ctx_set_stream(self._h, _P(stream) if stream else None))
+
+    def synchronize(self):
+        _check(self.lib.mvs_ctx_synchronize(self._h))
+
+    def set_timing(self, enabled=True):
+        _check(self.lib.mvs_ctx_set_timing(self._h, 1 if enabled else 0))
+
+    def kernel_ms(self, which):
+        ms = _c.c_float()
+        _check(self.lib.mvs_ctx_kernel_ms(self._h, which, ctypes.byref(ms)))
+        return ms.value
+
+    # ---- projection ----
+    def project_csr(self, hashes, offsets, d, out=None):
+        """hashes: uint64 numpy array or torch CUDA tensor (int64 view of the bits is accepted);
+        offsets: host int64 array (n_samples+1).  Returns out (numpy unless `out` is given)."""
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        n = len(offsets) - 1
+        if _is_torch(hashes):
+            hp, hm, hk = _buf(hashes)
+        else:
+            hp, hm, hk = _buf(hashes, np.uint64)
+        if out is None:
+            out = np.empty((n, d), dtype=np.int32)
+        op, om, ok = _buf(out, np.int32, writable=True)
+        _check(self.lib.mvs_project_csr(self._h, hp, hm, offsets.ctypes.data, n, int(d), op, om))
+        return out
+
+    def sumsq(self, sketches, out=None):
+        n, d = sketches.shape
+        ip, im, ik = _buf(sketches, np.int32)
+        if out is None:
+            out = np.empty(n, dtype=np.int64)
+        op, om, ok = _buf(out, np.int64, writable=True)
+        _check(self.lib.mvs_sketch_sumsq(self._h, ip, im, n, d, op, om))
+        return out
+
+    def saturate_i16(self, sketches, out=None):
+        ip, im, ik = _buf(sketches, np.int32)
+        n_elems = int(np.prod(sketches.shape))
+        if out is None:
+            out = np.empty(tuple(sketches.shape), dtype=np.int16)
+        op, om, ok = _buf(out, np.int16, writable=True)
+        _check(self.lib.mvs_sketch_saturate_i16(self._h, ip, im, n_elems, op, om))
+        return out
+
+    # ---- pairwise ----
+    @staticmethod
+    def _elem_bytes(sketches):
+        if _is_torch(sketches):
+            return sketches.element_size()
+        return np.asarray(sketches).dtype.itemsize
+
+    def max_abs(self, sketches):
+        eb = self._elem_bytes(sketches)
+        p, m, k = _buf(sketches)
+        out = _c.c_int64()
+        _check(self.lib.mvs_sketch_max_abs(self._h, p, eb, m, int(np.prod(sketches.shape)), ctypes.byref(out)))
+        return out.value
+
+    def limb_geometry(self, n, d, limbs):
+        n_alloc, d_pad, nbytes = _c.c_int64(), _c.c_int(), _c.c_size_t()
+        _check(self.lib.mvs_limb_geometry(n, d, limbs, n_alloc, d_pad, nbytes))
+        return n_alloc.value, d_pad.value, nbytes.value
+
+    def limb_split(self, sketches, limbs, planes, d_pad, row_offset=0):
+        n, d = sketches.shape
+        eb = self._elem_bytes(sketches)
+        p, m, k = _buf(sketches)
+        pp, pm, pk = _buf(planes)
+        if pm != MEM_DEVICE:
+            raise ValueError("planes must be a device buffer")
+        _check(self.lib.mvs_limb_split(self._h, p, eb, m, n, d, limbs, pp, d_pad, row_offset))
+
+    def sketch_set(self, sketches):
+        n, d = sketches.shape
+        eb = self._elem_bytes(sketches)
+        if eb not in (2, 4):
+            raise ValueError("sketches must be int32 or int16")
+        p, m, k = _buf(sketches)
+        h = _P()
+        _check(self.lib.mvs_sketch_set_create(self._h, p, eb, m, n, d, ctypes.byref(h)))
+        return SketchSet(self, h)
+
+    def sketch_set_from_planes(self, planes, n, n_alloc, d, d_pad, limbs):
+        pp, pm, pk = _buf(planes)
+        if pm != MEM_DEVICE:
+            raise ValueError("planes must be a device buffer")
+        h = _P()
+        _check(self.lib.mvs_sketch_set_from_planes(self._h, pp, n, n_alloc, d, d_pad, limbs, ctypes.byref(h)))
+        return SketchSet(self, h, keep=planes)
+
+    def pairwise_rows(self, sset, norms_sq, row_begin=0, row_end=None, keep_mode=KEEP_INT32, capacity=None,
+                      cells_out=None):
+        """Returns (cells, n_cells).  cells is a numpy structured array (CELL_DTYPE) unless a device
+        buffer `cells_out` (torch int32 tensor of shape [capacity, 4]) is given.  Grows the host buffer
+        and retries on MVS_E_CAPACITY."""
+        if row_end is None:
+            row_end = sset.n
+        np_, nm, nk = _buf(norms_sq) if _is_torch(norms_sq) else _buf(norms_sq, np.float64)
+        count = _c.c_int64()
+        if cells_out is not None:
+            cp, cm, ck = _buf(cells_out)
+            cap = cells_out.shape[0]
+            rc = self.lib.mvs_pairwise_rows(self._h, sset._h, np_, nm, keep_mode, row_begin, row_end, cp, cap, cm,
+                                            ctypes.byref(count))
+            _check(rc)
+            return cells_out, count.value
+        cap = capacity if capacity is not None else max(1024, 64 * (row_end - row_begin))
+        while True:
+            cells = np.empty(cap, dtype=CELL_DTYPE)
+            rc = self.lib.mvs_pairwise_rows(self._h, sset._h, np_, nm, keep_mode, row_begin, row_end,
+                                            cells.ctypes.data, cap, MEM_HOST, ctypes.byref(count))
+            if rc == MVS_E_CAPACITY and capacity is None:
+                cap = count.value
+                continue
+            _check(rc)
+            return cells[:count.value], count.value
+
+    def pairwise_dots(self, sset, r0, r1, c0, c1, algo=0, out=None):
+        if out is None:
+            out = np.empty((r1 - r0, c1 - c0), dtype=np.int32)
+        op, om, ok = _buf(out, np.int32, writable=True)
+        _check(self.lib.mvs_pairwise_dots(self._h, sset._h, r0, r1, c0, c1, op, om, algo))
+        return out
+
+
+def chunk_size(max_memory_gb, d):
+    return load_library().mvs_chunk_size(float(max_memory_gb), int(d))
+
+
+def shard_rows(n, num_shards, shard_idx):
+    b, e = _c.c_int64(), _c.c_int64()
+    load_library().mvs_shard_rows(n, num_shards, shard_idx, ctypes.byref(b), ctypes.byref(e))
+    return b.value, e.value
+
+
+def limbs_for_max_abs(max_abs):
+    return load_library().mvs_limbs_for_max_abs(int(max_abs))

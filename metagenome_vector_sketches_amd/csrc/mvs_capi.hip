@@ -1,0 +1,663 @@
+// mvs_capi.hip -- the C ABI of libmvs_hip.so (include/mvs_hip.h): contexts, buffer staging and
+// kernel orchestration.  No compute happens on the host here and there is no CPU fallback.
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "mvs_internal.h"
+
+struct mvs_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    // timing of the dominant kernels (optional)
+    bool timing = false;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // project start/stop, pairwise start/stop
+    bool ev_valid[2] = {false, false};
+    // reusable device scratch
+    void* scratch = nullptr;
+    size_t scratch_bytes = 0;
+    unsigned long long* d_counter = nullptr;   // 8-byte slot for counters / max
+    // pinned host staging for small metadata uploads (projection unit lists)
+    void* pinned = nullptr;
+    size_t pinned_bytes = 0;
+    hipEvent_t pinned_ev = nullptr;
+    bool pinned_busy = false;
+};
+
+struct mvs_sketch_set {
+    mvs_ctx* ctx = nullptr;
+    const int8_t* planes = nullptr;
+    int8_t* owned = nullptr;
+    int64_t n = 0, n_alloc = 0;
+    int d = 0, d_pad = 0, limbs = 0;
+};
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) return fail(MVS_E_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+bool mem_ok(int m) { return m == MVS_MEM_HOST || m == MVS_MEM_DEVICE; }
+
+// RAII device buffer used for staging host inputs / outputs
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() {
+        if (p) (void)hipFree(p);
+    }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
+};
+
+int ensure_scratch(mvs_ctx* c, size_t bytes) {
+    if (c->scratch_bytes >= bytes) return MVS_OK;
+    if (c->scratch) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipFree(c->scratch));
+        c->scratch = nullptr;
+        c->scratch_bytes = 0;
+    }
+    HIP_TRY(hipMalloc(&c->scratch, bytes));
+    c->scratch_bytes = bytes;
+    return MVS_OK;
+}
+
+// pinned host buffer whose previous upload has completed
+int acquire_pinned(mvs_ctx* c, size_t bytes) {
+    if (c->pinned_busy) {
+        HIP_TRY(hipEventSynchronize(c->pinned_ev));
+        c->pinned_busy = false;
+    }
+    if (c->pinned_bytes >= bytes) return MVS_OK;
+    if (c->pinned) {
+        HIP_TRY(hipHostFree(c->pinned));
+        c->pinned = nullptr;
+        c->pinned_bytes = 0;
+    }
+    const size_t want = bytes < (1u << 20) ? (1u << 20) : bytes;
+    HIP_TRY(hipHostMalloc(&c->pinned, want, hipHostMallocDefault));
+    c->pinned_bytes = want;
+    return MVS_OK;
+}
+
+int check_kernel(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(MVS_E_HIP, "%s launch: %s", what, hipGetErrorString(e));
+    return MVS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* mvs_version(void) { return "mvs_hip 0.1 (gfx950)"; }
+const char* mvs_last_error(void) { return g_err.c_str(); }
+
+int mvs_device_count(int* count) {
+    if (!count) return fail(MVS_E_INVALID, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        return fail(MVS_E_HIP, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    }
+    *count = n;
+    return MVS_OK;
+}
+
+int mvs_ctx_create(int device, mvs_ctx** out) {
+    if (!out) return fail(MVS_E_INVALID, "ctx out pointer is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(MVS_E_HIP, "no HIP device available (%s); libmvs_hip has no CPU fallback",
+                    e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+    if (device < 0 || device >= n) return fail(MVS_E_INVALID, "device %d out of range [0,%d)", device, n);
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(MVS_E_HIP, "device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
+    mvs_ctx* c = new (std::nothrow) mvs_ctx();
+    if (!c) return fail(MVS_E_NOMEM, "out of host memory");
+    c->device = device;
+    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return fail(MVS_E_HIP, "hipStreamCreate failed");
+    }
+    c->stream = c->own_stream;
+    for (auto& ev : c->ev) {
+        if (hipEventCreate(&ev) != hipSuccess) {
+            mvs_ctx_destroy(c);
+            return fail(MVS_E_HIP, "hipEventCreate failed");
+        }
+    }
+    if (hipEventCreateWithFlags(&c->pinned_ev, hipEventDisableTiming) != hipSuccess) {
+        mvs_ctx_destroy(c);
+        return fail(MVS_E_HIP, "hipEventCreate failed");
+    }
+    if (hipMalloc((void**)&c->d_counter, 64) != hipSuccess) {
+        mvs_ctx_destroy(c);
+        return fail(MVS_E_HIP, "hipMalloc failed");
+    }
+    *out = c;
+    return MVS_OK;
+}
+
+int mvs_ctx_destroy(mvs_ctx* c) {
+    if (!c) return MVS_OK;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->scratch) (void)hipFree(c->scratch);
+    if (c->d_counter) (void)hipFree(c->d_counter);
+    if (c->pinned) (void)hipHostFree(c->pinned);
+    if (c->pinned_ev) (void)hipEventDestroy(c->pinned_ev);
+    for (auto& ev : c->ev)
+        if (ev) (void)hipEventDestroy(ev);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+    return MVS_OK;
+}
+
+int mvs_ctx_set_stream(mvs_ctx* c, void* hip_stream) {
+    if (!c) return fail(MVS_E_INVALID, "ctx is NULL");
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return MVS_OK;
+}
+
+int mvs_ctx_synchronize(mvs_ctx* c) {
+    if (!c) return fail(MVS_E_INVALID, "ctx is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return MVS_OK;
+}
+
+int mvs_ctx_set_timing(mvs_ctx* c, int enabled) {
+    if (!c) return fail(MVS_E_INVALID, "ctx is NULL");
+    c->timing = enabled != 0;
+    c->ev_valid[0] = c->ev_valid[1] = false;
+    return MVS_OK;
+}
+
+int mvs_ctx_kernel_ms(mvs_ctx* c, int which, float* ms) {
+    if (!c || !ms || which < 0 || which > 1) return fail(MVS_E_INVALID, "bad argument");
+    if (!c->ev_valid[which]) return fail(MVS_E_INVALID, "no timing recorded for kernel %d", which);
+    HIP_TRY(hipEventSynchronize(c->ev[2 * which + 1]));
+    HIP_TRY(hipEventElapsedTime(ms, c->ev[2 * which], c->ev[2 * which + 1]));
+    return MVS_OK;
+}
+
+// -------------------------------------------------------------------------------------------------
+// projection
+// -------------------------------------------------------------------------------------------------
+int mvs_project_csr(mvs_ctx* c, const uint64_t* hashes, int mem_hashes, const int64_t* offsets,
+                    int64_t n_samples, int d, int32_t* out, int mem_out) {
+    if (!c) return fail(MVS_E_INVALID, "ctx is NULL");
+    if (n_samples < 0 || d <= 0) return fail(MVS_E_INVALID, "n_samples=%lld d=%d", (long long)n_samples, d);
+    if (!mem_ok(mem_hashes) || !mem_ok(mem_out)) return fail(MVS_E_INVALID, "bad mem flag");
+    if (n_samples == 0) return MVS_OK;
+    if (!offsets || !out) return fail(MVS_E_INVALID, "offsets/out is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+
+    // units: runs of <= kProjUnitMax hashes, written straight into pinned memory
+    if (n_samples >= (1LL << 31)) return fail(MVS_E_RANGE, "too many samples");
+    size_t n_units = 0;
+    for (int64_t s = 0; s < n_samples; ++s) {
+        const int64_t b = offsets[s], e = offsets[s + 1];
+        if (e < b) return fail(MVS_E_INVALID, "offsets not monotone at sample %lld", (long long)s);
+        if (e - b >= (1LL << 31)) return fail(MVS_E_RANGE, "sample %lld has >= 2^31 hashes", (long long)s);
+        n_units += (size_t)((e - b + mvs::kProjUnitMax - 1) / mvs::kProjUnitMax);
+    }
+    int rc = acquire_pinned(c, std::max<size_t>(n_units * sizeof(mvs::ProjUnit), 256));
+    if (rc) return rc;
+    mvs::ProjUnit* units = (mvs::ProjUnit*)c->pinned;
+    {
+        size_t w = 0;
+        for (int64_t s = 0; s < n_samples; ++s) {
+            const int64_t b = offsets[s], e = offsets[s + 1];
+            const bool single = (e - b) <= mvs::kProjUnitMax;
+            for (int64_t p = b; p < e; p += mvs::kProjUnitMax) {
+                mvs::ProjUnit u;
+                u.begin = p;
+                u.count = (int32_t)std::min<int64_t>(mvs::kProjUnitMax, e - p);
+                u.sample = (int32_t)s;
+                u.single = single ? 1 : 0;
+                u.pad = 0;
+                units[w++] = u;
+            }
+        }
+    }
+    const int64_t total = offsets[n_samples];
+    if (total > 0 && !hashes) return fail(MVS_E_INVALID, "hashes is NULL");
+
+    DevBuf dh, dout;
+    const uint64_t* d_hashes = hashes;
+    if (mem_hashes == MVS_MEM_HOST) {
+        HIP_TRY(dh.alloc((size_t)total * 8));
+        HIP_TRY(hipMemcpyAsync(dh.p, hashes, (size_t)total * 8, hipMemcpyHostToDevice, c->stream));
+        d_hashes = (const uint64_t*)dh.p;
+    }
+    int32_t* d_out = out;
+    const size_t out_bytes = (size_t)n_samples * (size_t)d * 4;
+    if (mem_out == MVS_MEM_HOST) {
+        HIP_TRY(dout.alloc(out_bytes));
+        d_out = (int32_t*)dout.p;
+    }
+    const size_t ubytes = n_units * sizeof(mvs::ProjUnit);
+    rc = ensure_scratch(c, std::max<size_t>(ubytes, 256));
+    if (rc) return rc;
+    if (n_units) {
+        HIP_TRY(hipMemcpyAsync(c->scratch, units, ubytes, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipEventRecord(c->pinned_ev, c->stream));
+        c->pinned_busy = true;
+    }
+
+    HIP_TRY(hipMemsetAsync(d_out, 0, out_bytes, c->stream));   // empty samples, atomically combined units
+    if (c->timing) HIP_TRY(hipEventRecord(c->ev[0], c->stream));
+    const int nblk = (d + 63) / 64;
+    const int bpw = nblk >= 2 ? 2 : 1;
+    mvs::launch_project(c->stream, d_hashes, (const mvs::ProjUnit*)c->scratch, (int64_t)n_units, d, d_out, bpw);
+    rc = check_kernel("k_project");
+    if (rc) return rc;
+    if (c->timing) {
+        HIP_TRY(hipEventRecord(c->ev[1], c->stream));
+        c->ev_valid[0] = true;
+    }
+    if (mem_out == MVS_MEM_HOST) {
+        HIP_TRY(hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    } else if (mem_hashes == MVS_MEM_HOST) {
+        HIP_TRY(hipStreamSynchronize(c->stream));   // staging buffer is freed on return
+    } else {
+        // the unit list lives in ctx scratch, which stays valid; nothing to wait for
+    }
+    return MVS_OK;
+}
+
+int mvs_sketch_sumsq(mvs_ctx* c, const int32_t* sketches, int mem_in, int64_t n, int d, int64_t* sumsq,
+                     int mem_out) {
+    if (!c) return fail(MVS_E_INVALID, "ctx is NULL");
+    if (n < 0 || d <= 0 || !mem_ok(mem_in) || !mem_ok(mem_out)) return fail(MVS_E_INVALID, "bad argument");
+    if (n == 0) return MVS_OK;
+    if (!sketches || !sumsq) return fail(MVS_E_INVALID, "NULL buffer");
+    HIP_TRY(hipSetDevice(c->device));
+    DevBuf din, dout;
+    const int32_t* d_in = sketches;
+    if (mem_in == MVS_MEM_HOST) {
+        HIP_TRY(din.alloc((size_t)n * d * 4));
+        HIP_TRY(hipMemcpyAsync(din.p, sketches, (size_t)n * d * 4, hipMemcpyHostToDevice, c->stream));
+        d_in = (const int32_t*)din.p;
+    }
+    int64_t* d_out = sumsq;
+    if (mem_out == MVS_MEM_HOST) {
+        HIP_TRY(dout.alloc((size_t)n * 8));
+        d_out = (int64_t*)dout.p;
+    }
+    mvs::launch_sumsq(c->stream, d_in, n, d, d_out);
+    int rc = check_kernel("k_sumsq");
+    if (rc) return rc;
+    if (mem_out == MVS_MEM_HOST)
+        HIP_TRY(hipMemcpyAsync(sumsq, d_out, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+    if (mem_out == MVS_MEM_HOST || mem_in == MVS_MEM_HOST) HIP_TRY(hipStreamSynchronize(c->stream));
+    return MVS_OK;
+}
+
+int mvs_sketch_saturate_i16(mvs_ctx* c, const int32_t* sketches, int mem_in, int64_t n_elems, int16_t* out,
+                            int mem_out) {
+    if (!c) return fail(MVS_E_INVALID, "ctx is NULL");
+    if (n_elems < 0 || !mem_ok(mem_in) || !mem_ok(mem_out)) return fail(MVS_E_INVALID, "bad argument");
+    if (n_elems == 0) return MVS_OK;
+    if (!sketches || !out) return fail(MVS_E_INVALID, "NULL buffer");
+    HIP_TRY(hipSetDevice(c->device));
+    DevBuf din, dout;
+    const int32_t* d_in = sketches;
+    if (mem_in == MVS_MEM_HOST) {
+        HIP_TRY(din.alloc((size_t)n_elems * 4));
+        HIP_TRY(hipMemcpyAsync(din.p, sketches, (size_t)n_elems * 4, hipMemcpyHostToDevice, c->stream));
+        d_in = (const int32_t*)din.p;
+    }
+    int16_t* d_out = out;
+    if (mem_out == MVS_MEM_HOST) {
+        HIP_TRY(dout.alloc((size_t)n_elems * 2));
+        d_out = (int16_t*)dout.p;
+    }
+    mvs::launch_saturate_i16(c->stream, d_in, n_elems, d_out);
+    int rc = check_kernel("k_saturate_i16");
+    if (rc) return rc;
+    if (mem_out == MVS_MEM_HOST)
+        HIP_TRY(hipMemcpyAsync(out, d_out, (size_t)n_elems * 2, hipMemcpyDeviceToHost, c->stream));
+    if (mem_out == MVS_MEM_HOST || mem_in == MVS_MEM_HOST) HIP_TRY(hipStreamSynchronize(c->stream));
+    return MVS_OK;
+}
+
+// -------------------------------------------------------------------------------------------------
+// pairwise
+// -------------------------------------------------------------------------------------------------
+int mvs_sketch_max_abs(mvs_ctx* c, const void* sketches, int elem_bytes, int mem, int64_t n_elems,
+                       int64_t* max_abs) {
+    if (!c || !max_abs) return fail(MVS_E_INVALID, "NULL argument");
+    if ((elem_bytes != 4 && elem_bytes != 2) || !mem_ok(mem) || n_elems < 0)
+        return fail(MVS_E_INVALID, "bad argument");
+    *max_abs = 0;
+    if (n_elems == 0) return MVS_OK;
+    if (!sketches) return fail(MVS_E_INVALID, "sketches is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    DevBuf din;
+    const void* d_in = sketches;
+    if (mem == MVS_MEM_HOST) {
+        HIP_TRY(din.alloc((size_t)n_elems * elem_bytes));
+        HIP_TRY(hipMemcpyAsync(din.p, sketches, (size_t)n_elems * elem_bytes, hipMemcpyHostToDevice, c->stream));
+        d_in = din.p;
+    }
+    HIP_TRY(hipMemsetAsync(c->d_counter, 0, 8, c->stream));
+    mvs::launch_max_abs(c->stream, d_in, elem_bytes, n_elems, c->d_counter);
+    int rc = check_kernel("k_max_abs");
+    if (rc) return rc;
+    unsigned long long m = 0;
+    HIP_TRY(hipMemcpyAsync(&m, c->d_counter, 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    *max_abs = (int64_t)m;
+    return MVS_OK;
+}
+
+int mvs_limbs_for_max_abs(int64_t max_abs) {
+    if (max_abs < 0) max_abs = -max_abs;
+    if (max_abs <= 127) return 1;
+    if (max_abs <= 32639) return 2;      // 127 * (1 + 256)
+    if (max_abs <= 8355711) return 3;    // 127 * (1 + 256 + 65536)
+    return 4;                            // exact mod 2^32 for every int32
+}
+
+int mvs_limb_geometry(int64_t n, int d, int limbs, int64_t* n_alloc, int* d_pad, size_t* bytes) {
+    if (n < 0 || d <= 0 || limbs < 1 || limbs > mvs::kMaxLimbs) return fail(MVS_E_INVALID, "bad argument");
+    const int64_t na = (n + mvs::kTile - 1) / mvs::kTile * mvs::kTile + mvs::kTile;
+    const int dp = (d + mvs::kBK - 1) / mvs::kBK * mvs::kBK;
+    if (n_alloc) *n_alloc = na;
+    if (d_pad) *d_pad = dp;
+    if (bytes) *bytes = (size_t)na * (size_t)limbs * (size_t)dp;
+    return MVS_OK;
+}
+
+int mvs_limb_split(mvs_ctx* c, const void* sketches, int elem_bytes, int mem, int64_t n_rows, int d, int limbs,
+                   int8_t* planes, int d_pad, int64_t row_offset) {
+    if (!c) return fail(MVS_E_INVALID, "ctx is NULL");
+    if ((elem_bytes != 4 && elem_bytes != 2) || !mem_ok(mem) || n_rows < 0 || d <= 0 || limbs < 1 ||
+        limbs > mvs::kMaxLimbs || d_pad < d || d_pad % mvs::kBK != 0 || row_offset < 0)
+        return fail(MVS_E_INVALID, "bad argument");
+    if (n_rows == 0) return MVS_OK;
+    if (!sketches || !planes) return fail(MVS_E_INVALID, "NULL buffer");
+    HIP_TRY(hipSetDevice(c->device));
+    DevBuf din;
+    const void* d_in = sketches;
+    if (mem == MVS_MEM_HOST) {
+        HIP_TRY(din.alloc((size_t)n_rows * d * elem_bytes));
+        HIP_TRY(hipMemcpyAsync(din.p, sketches, (size_t)n_rows * d * elem_bytes, hipMemcpyHostToDevice, c->stream));
+        d_in = din.p;
+    }
+    mvs::launch_limb_split(c->stream, d_in, elem_bytes, n_rows, d, limbs, planes, d_pad, row_offset);
+    int rc = check_kernel("k_limb_split");
+    if (rc) return rc;
+    if (mem == MVS_MEM_HOST) HIP_TRY(hipStreamSynchronize(c->stream));
+    return MVS_OK;
+}
+
+int mvs_sketch_set_create(mvs_ctx* c, const void* sketches, int elem_bytes, int mem, int64_t n, int d,
+                          mvs_sketch_set** out) {
+    if (!c || !out) return fail(MVS_E_INVALID, "NULL argument");
+    *out = nullptr;
+    if ((elem_bytes != 4 && elem_bytes != 2) || !mem_ok(mem) || n < 0 || d <= 0)
+        return fail(MVS_E_INVALID, "bad argument");
+    if (n >= (1LL << 31) - 256) return fail(MVS_E_RANGE, "n too large for int32 row/col indices");
+    if (n > 0 && !sketches) return fail(MVS_E_INVALID, "sketches is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    // stage once if the input is on the host
+    DevBuf din;
+    const void* d_in = sketches;
+    if (mem == MVS_MEM_HOST && n > 0) {
+        HIP_TRY(din.alloc((size_t)n * d * elem_bytes));
+        HIP_TRY(hipMemcpyAsync(din.p, sketches, (size_t)n * d * elem_bytes, hipMemcpyHostToDevice, c->stream));
+        d_in = din.p;
+    }
+    int64_t max_abs = 0;
+    int rc = mvs_sketch_max_abs(c, d_in, elem_bytes, MVS_MEM_DEVICE, n * d, &max_abs);
+    if (rc) return rc;
+    const int limbs = mvs_limbs_for_max_abs(max_abs);
+    int64_t n_alloc = 0;
+    int d_pad = 0;
+    size_t bytes = 0;
+    mvs_limb_geometry(n, d, limbs, &n_alloc, &d_pad, &bytes);
+    mvs_sketch_set* s = new (std::nothrow) mvs_sketch_set();
+    if (!s) return fail(MVS_E_NOMEM, "out of host memory");
+    if (hipMalloc((void**)&s->owned, bytes) != hipSuccess) {
+        delete s;
+        return fail(MVS_E_NOMEM, "hipMalloc of %zu bytes of limb planes failed", bytes);
+    }
+    s->ctx = c;
+    s->planes = s->owned;
+    s->n = n;
+    s->n_alloc = n_alloc;
+    s->d = d;
+    s->d_pad = d_pad;
+    s->limbs = limbs;
+    hipError_t e = hipMemsetAsync(s->owned, 0, bytes, c->stream);
+    if (e == hipSuccess) {
+        rc = mvs_limb_split(c, d_in, elem_bytes, MVS_MEM_DEVICE, n, d, limbs, s->owned, d_pad, 0);
+        if (rc == MVS_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(MVS_E_HIP, "sync failed");
+    } else {
+        rc = fail(MVS_E_HIP, "hipMemsetAsync: %s", hipGetErrorString(e));
+    }
+    if (rc) {
+        mvs_sketch_set_destroy(s);
+        return rc;
+    }
+    *out = s;
+    return MVS_OK;
+}
+
+int mvs_sketch_set_from_planes(mvs_ctx* c, const int8_t* planes, int64_t n, int64_t n_alloc, int d, int d_pad,
+                               int limbs, mvs_sketch_set** out) {
+    if (!c || !out || !planes) return fail(MVS_E_INVALID, "NULL argument");
+    *out = nullptr;
+    int64_t need_alloc = 0;
+    int need_pad = 0;
+    if (mvs_limb_geometry(n, d, limbs, &need_alloc, &need_pad, nullptr)) return MVS_E_INVALID;
+    if (n_alloc < need_alloc || d_pad != need_pad)
+        return fail(MVS_E_INVALID, "plane buffer geometry: need n_alloc >= %lld and d_pad == %d",
+                    (long long)need_alloc, need_pad);
+    if (n >= (1LL << 31) - 256) return fail(MVS_E_RANGE, "n too large for int32 row/col indices");
+    mvs_sketch_set* s = new (std::nothrow) mvs_sketch_set();
+    if (!s) return fail(MVS_E_NOMEM, "out of host memory");
+    s->ctx = c;
+    s->planes = planes;
+    s->n = n;
+    s->n_alloc = n_alloc;
+    s->d = d;
+    s->d_pad = d_pad;
+    s->limbs = limbs;
+    *out = s;
+    return MVS_OK;
+}
+
+int mvs_sketch_set_info(const mvs_sketch_set* s, int64_t* n, int* d, int* limbs, int64_t* n_alloc, int* d_pad) {
+    if (!s) return fail(MVS_E_INVALID, "set is NULL");
+    if (n) *n = s->n;
+    if (d) *d = s->d;
+    if (limbs) *limbs = s->limbs;
+    if (n_alloc) *n_alloc = s->n_alloc;
+    if (d_pad) *d_pad = s->d_pad;
+    return MVS_OK;
+}
+
+int mvs_sketch_set_destroy(mvs_sketch_set* s) {
+    if (!s) return MVS_OK;
+    if (s->owned) {
+        (void)hipSetDevice(s->ctx->device);
+        (void)hipStreamSynchronize(s->ctx->stream);
+        (void)hipFree(s->owned);
+    }
+    delete s;
+    return MVS_OK;
+}
+
+int mvs_pairwise_rows(mvs_ctx* c, const mvs_sketch_set* s, const double* norms_sq, int mem_norms, int keep_mode,
+                      int64_t row_begin, int64_t row_end, mvs_cell* cells, int64_t capacity, int mem_cells,
+                      int64_t* n_cells) {
+    if (!c || !s || !n_cells) return fail(MVS_E_INVALID, "NULL argument");
+    *n_cells = 0;
+    if (!mem_ok(mem_norms) || !mem_ok(mem_cells) || capacity < 0 ||
+        (keep_mode != MVS_KEEP_INT32 && keep_mode != MVS_KEEP_INT16))
+        return fail(MVS_E_INVALID, "bad argument");
+    if (row_begin < 0 || row_end > s->n || row_begin > row_end)
+        return fail(MVS_E_INVALID, "row range [%lld,%lld) outside [0,%lld)", (long long)row_begin,
+                    (long long)row_end, (long long)s->n);
+    if (row_begin == row_end || s->n == 0) return MVS_OK;
+    if (!norms_sq) return fail(MVS_E_INVALID, "norms_sq is NULL");
+    if (capacity > 0 && !cells) return fail(MVS_E_INVALID, "cells is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+
+    DevBuf dn, dcells, dtmp, dthr, dsort;
+    const double* d_n2 = norms_sq;
+    if (mem_norms == MVS_MEM_HOST) {
+        HIP_TRY(dn.alloc((size_t)s->n * 8));
+        HIP_TRY(hipMemcpyAsync(dn.p, norms_sq, (size_t)s->n * 8, hipMemcpyHostToDevice, c->stream));
+        d_n2 = (const double*)dn.p;
+    }
+    mvs_cell* d_cells = cells;
+    if (mem_cells == MVS_MEM_HOST) {
+        HIP_TRY(dcells.alloc((size_t)capacity * sizeof(mvs_cell)));
+        d_cells = (mvs_cell*)dcells.p;
+    }
+    HIP_TRY(dthr.alloc((size_t)s->n_alloc * 4));
+    mvs::launch_cand_thr(c->stream, d_n2, s->n, s->n_alloc, s->d, (int32_t*)dthr.p);
+    int rc = check_kernel("k_cand_thr");
+    if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(c->d_counter, 0, 8, c->stream));
+
+    mvs::PairwiseArgs a{};
+    a.planes = s->planes;
+    a.n = s->n;
+    a.n_alloc = s->n_alloc;
+    a.d = s->d;
+    a.d_pad = s->d_pad;
+    a.limbs = s->limbs;
+    a.row_begin = row_begin;
+    a.row_end = row_end;
+    a.col_begin = 0;
+    a.col_end = s->n;
+    a.norms_sq = d_n2;
+    a.cand_thr = (const int32_t*)dthr.p;
+    a.keep_mode = keep_mode;
+    a.cells = d_cells;
+    a.capacity = (unsigned long long)capacity;
+    a.counter = c->d_counter;
+    a.dots = nullptr;
+    if (c->timing) HIP_TRY(hipEventRecord(c->ev[2], c->stream));
+    rc = mvs::launch_pairwise(c->stream, a, 0, 0);
+    if (rc) return fail(rc, "pairwise launch rejected");
+    rc = check_kernel("k_pairwise");
+    if (rc) return rc;
+    if (c->timing) {
+        HIP_TRY(hipEventRecord(c->ev[3], c->stream));
+        c->ev_valid[1] = true;
+    }
+    unsigned long long count = 0;
+    HIP_TRY(hipMemcpyAsync(&count, c->d_counter, 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    *n_cells = (int64_t)count;
+    if ((int64_t)count > capacity)
+        return fail(MVS_E_CAPACITY, "%llu cells kept but capacity is %lld", count, (long long)capacity);
+    if (count == 0) return MVS_OK;
+
+    // order by (row, col): the per-row ascending-column order of the reference's result list
+    HIP_TRY(dtmp.alloc((size_t)count * sizeof(mvs_cell)));
+    size_t need = 0;
+    rc = mvs::sort_cells(c->stream, d_cells, (mvs_cell*)dtmp.p, (int64_t)count, nullptr, 0, &need);
+    if (rc) return fail(rc, "sort sizing failed");
+    HIP_TRY(dsort.alloc(need));
+    rc = mvs::sort_cells(c->stream, d_cells, (mvs_cell*)dtmp.p, (int64_t)count, dsort.p, need, nullptr);
+    if (rc) return fail(rc, "sort failed");
+    if (mem_cells == MVS_MEM_HOST)
+        HIP_TRY(hipMemcpyAsync(cells, dtmp.p, (size_t)count * sizeof(mvs_cell), hipMemcpyDeviceToHost, c->stream));
+    else
+        HIP_TRY(hipMemcpyAsync(cells, dtmp.p, (size_t)count * sizeof(mvs_cell), hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return MVS_OK;
+}
+
+int mvs_pairwise_dots(mvs_ctx* c, const mvs_sketch_set* s, int64_t r0, int64_t r1, int64_t c0, int64_t c1,
+                      int32_t* out, int mem_out, int algo) {
+    if (!c || !s) return fail(MVS_E_INVALID, "NULL argument");
+    if (!mem_ok(mem_out) || r0 < 0 || r1 > s->n || r0 > r1 || c0 < 0 || c1 > s->n || c0 > c1 ||
+        (algo != 0 && algo != 1))
+        return fail(MVS_E_INVALID, "bad argument");
+    if (r0 == r1 || c0 == c1) return MVS_OK;
+    if (!out) return fail(MVS_E_INVALID, "out is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t bytes = (size_t)(r1 - r0) * (size_t)(c1 - c0) * 4;
+    DevBuf dout;
+    int32_t* d_out = out;
+    if (mem_out == MVS_MEM_HOST) {
+        HIP_TRY(dout.alloc(bytes));
+        d_out = (int32_t*)dout.p;
+    }
+    mvs::PairwiseArgs a{};
+    a.planes = s->planes;
+    a.n = s->n;
+    a.n_alloc = s->n_alloc;
+    a.d = s->d;
+    a.d_pad = s->d_pad;
+    a.limbs = s->limbs;
+    a.row_begin = r0;
+    a.row_end = r1;
+    a.col_begin = c0;
+    a.col_end = c1;
+    a.dots = d_out;
+    int rc = mvs::launch_pairwise(c->stream, a, 1, algo);
+    if (rc) return fail(rc, "pairwise launch rejected");
+    rc = check_kernel("k_pairwise(dots)");
+    if (rc) return rc;
+    if (mem_out == MVS_MEM_HOST) {
+        HIP_TRY(hipMemcpyAsync(out, d_out, bytes, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    return MVS_OK;
+}
+
+int64_t mvs_chunk_size(double max_memory_gb, int d) {
+    const int64_t bytes_per_vector = (int64_t)d * 4;
+    const int64_t max_bytes = (int64_t)(max_memory_gb * 1024 * 1024 * 1024);
+    return bytes_per_vector > 0 ? max_bytes / (bytes_per_vector * bytes_per_vector) : 0;
+}
+
+void mvs_shard_rows(int64_t n, int num_shards, int shard_idx, int64_t* begin, int64_t* end) {
+    if (num_shards < 1) num_shards = 1;
+    const int64_t rps = (n + num_shards - 1) / num_shards;
+    int64_t b = (int64_t)shard_idx * rps;
+    int64_t e = std::min(b + rps, n);
+    if (b > n) b = n;
+    if (e < b) e = b;
+    if (begin) *begin = b;
+    if (end) *end = e;
+}
+
+}  // extern "C"

@@ -1,0 +1,66 @@
+// mvs_internal.h -- declarations shared by the translation units of libmvs_hip.so (not installed).
+#ifndef MVS_INTERNAL_H
+#define MVS_INTERNAL_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mvs_hip.h"
+
+namespace mvs {
+
+// One unit of projection work: a run of <= 65536 hashes of one sample.
+struct ProjUnit {
+    int64_t begin;    // index of the unit's first hash in the CSR value array
+    int32_t count;    // hashes in the unit
+    int32_t sample;   // output row
+    int32_t single;   // 1: the unit is the whole sample -> plain store; 0: combine with atomics
+    int32_t pad;
+};
+constexpr int kProjUnitMax = 65536;
+
+// ---- geometry of the pairwise kernel (mvs_pairwise.hip) ----
+constexpr int kTile = 128;      // samples per workgroup tile edge (rows and cols)
+constexpr int kBK = 128;        // bytes (= int8 k values) per staged k-slice
+constexpr int kMaxLimbs = 4;
+
+struct PairwiseArgs {
+    const int8_t* planes;   // [(row*limbs + limb) * d_pad + k]
+    int64_t n;              // samples
+    int64_t n_alloc;        // allocated (zero padded) rows
+    int d;
+    int d_pad;
+    int limbs;
+    int64_t row_begin, row_end;   // row range of this call
+    int64_t col_begin, col_end;   // column range (dots) / [0,n) for the comparison
+    // comparison outputs
+    const double* norms_sq;       // n
+    const int32_t* cand_thr;      // n_alloc: conservative integer per-sample threshold part
+    int keep_mode;
+    mvs_cell* cells;
+    unsigned long long capacity;
+    unsigned long long* counter;  // number of kept cells (may exceed capacity)
+    // dense outputs (dots mode)
+    int32_t* dots;                // (row_end-row_begin) x (col_end-col_begin)
+};
+
+int launch_project(hipStream_t stream, const uint64_t* d_hashes, const ProjUnit* d_units, int64_t n_units,
+                   int d, int32_t* d_out, int bpw);
+int launch_sumsq(hipStream_t stream, const int32_t* d_sk, int64_t n, int d, int64_t* d_out);
+int launch_saturate_i16(hipStream_t stream, const int32_t* d_in, int64_t n, int16_t* d_out);
+
+int launch_max_abs(hipStream_t stream, const void* d_sk, int elem_bytes, int64_t n_elems,
+                   unsigned long long* d_out);
+int launch_limb_split(hipStream_t stream, const void* d_sk, int elem_bytes, int64_t n_rows, int d, int limbs,
+                      int8_t* d_planes, int d_pad, int64_t row_offset);
+int launch_cand_thr(hipStream_t stream, const double* d_norms_sq, int64_t n, int64_t n_alloc, int d,
+                    int32_t* d_thr);
+// mode 0: comparison (kept cells), mode 1: dense dots.  algo 0: MFMA, 1: vector ALU.
+int launch_pairwise(hipStream_t stream, const PairwiseArgs& a, int mode, int algo);
+// sort cells by (row, col); tmp buffers owned by the caller
+int sort_cells(hipStream_t stream, mvs_cell* d_cells, mvs_cell* d_tmp, int64_t n, void* d_scratch,
+               size_t scratch_bytes, size_t* scratch_needed);
+
+}  // namespace mvs
+
+#endif

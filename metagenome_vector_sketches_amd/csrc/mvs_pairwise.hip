@@ -1,0 +1,438 @@
+// mvs_pairwise.hip -- all-vs-all sketch comparison kernels (gfx950 / CDNA4).
+//
+// Reference semantics (src/pairwise_comp_optimized.cpp):
+//   :135      P = block_i^T * block_j   as int32 (wraps mod 2^32)
+//   :139-141  keep (i,j) iff int64(P)/d (truncating) > 0.05*(n2_i + n2_j)        [int32 path]
+//             (_16bits.cpp:211-218: keep iff double(P)/d > 0.05*(n2_i + n2_j))   [int16 path]
+//   :658-665  J = (P/d) / (n2_r + n2_c - P/d); J = min(J,1); q = uint16(round(J*255))
+//
+// MI355X design (DESIGN.md "K2"):
+//   * sketches live in HBM as signed base-256 int8 limb planes, planes[(row*L + limb)*d_pad + k];
+//     v == sum_a limb_a*256^a (mod 2^32), so P == sum_{a+b<=3} 256^(a+b) * <limb_a(i), limb_b(j)> (mod 2^32);
+//   * each limb-pair product runs on the int8 matrix cores (v_mfma_i32_32x32x32_i8, exact int32
+//     accumulation: |sum| <= 2 * 128*128*d_pad < 2^31 for d_pad <= 32768);
+//   * workgroup = 512 threads = 8 waves (2 x 4), tile = 128 x 128 samples, k-slices of 128 bytes are
+//     copied HBM -> LDS with global_load_lds (16 B per lane, no VGPR round trip) into a two-stage ring;
+//     the LDS image is [limb][sample][128 B] with the 16-byte chunks XOR-swizzled by (sample>>1)&7 on the
+//     SOURCE address side so that the ds_read_b128 fragment reads are bank-conflict free;
+//   * the epilogue recombines the limb products, rejects almost every cell with one integer compare
+//     against a conservative per-sample threshold sum, and runs the reference's fp64 keep test / Jaccard
+//     only on the survivors, which are appended (wave-aggregated atomic) to the kept-cell list;
+//   * workgroup -> tile mapping walks 16 x 16-tile super-patches, each of the 8 XCDs (blockIdx % 8)
+//     taking a 4 x 8 sub-patch, so that one XCD's L2 serves 12 operand panels to 32 tiles.
+#include "mvs_internal.h"
+
+#include <cstring>
+
+#include <rocprim/device/device_merge_sort.hpp>
+
+namespace mvs {
+
+namespace {
+
+using v4i = __attribute__((ext_vector_type(4))) int;
+using v16i = __attribute__((ext_vector_type(16))) int;
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+
+constexpr int kWaves = 8;
+constexpr int kThreads = kWaves * 64;
+
+__host__ __device__ constexpr int num_acc_sets(int L) { return L == 1 ? 1 : (L == 2 ? 3 : 4); }
+
+struct TileCoord {
+    int tr, tc;
+    bool valid;
+};
+
+// blockIdx.x -> tile.  16x16 super-patches in row-major order; inside one, the XCD label (b % 8)
+// picks a 4-row x 8-col sub-patch and b / 8 walks it.  Placement only affects speed.
+__device__ __forceinline__ TileCoord map_tile(unsigned b, int n_tr, int n_tc, int n_spc) {
+    const unsigned x = b & 7u;
+    const unsigned q = b >> 3;
+    const unsigned sp = q >> 5;
+    const unsigned ql = q & 31u;
+    const int spr = (int)(sp / (unsigned)n_spc), spc = (int)(sp % (unsigned)n_spc);
+    TileCoord t;
+    t.tr = spr * 16 + (int)(x >> 1) * 4 + (int)(ql >> 3);
+    t.tc = spc * 16 + (int)(x & 1u) * 8 + (int)(ql & 7u);
+    t.valid = t.tr < n_tr && t.tc < n_tc;
+    return t;
+}
+
+// exact per-cell decision + quantisation, identical operation order to the reference
+__device__ __forceinline__ bool keep_cell(int32_t P, int d, double n2r, double n2c, int keep_mode) {
+    const double threshold = 0.05 * (n2r + n2c);                       // :139
+    if (keep_mode == MVS_KEEP_INT32) {
+        const long long q = (long long)P / (long long)d;               // :140-141 truncating
+        return (double)q > threshold;
+    }
+    return (double)P / (double)d > threshold;                          // _16bits.cpp:218
+}
+
+__device__ __forceinline__ int32_t quantize_cell(int32_t P, int d, double n2r, double n2c) {
+    const double inter = (double)P / (double)d;                        // :661
+    double jac = inter / (n2r + n2c - inter);                          // :662
+    if (jac > 1) jac = 1;                                              // :663
+    const double r = round(jac * 255.0);                               // :664
+    if (!(r == r)) return 0;
+    return (int32_t)(uint16_t)(long long)r;
+}
+
+__device__ __forceinline__ void emit_cell(const PairwiseArgs& a, bool keep, int32_t row, int32_t col,
+                                          int32_t P, int lane) {
+    const unsigned long long mask = __ballot(keep);
+    if (mask == 0ULL) return;
+    unsigned long long base = 0;
+    const int leader = __ffsll((long long)mask) - 1;
+    if (lane == leader) base = atomicAdd(a.counter, (unsigned long long)__popcll(mask));
+    base = __shfl(base, leader, 64);
+    if (keep) {
+        const unsigned long long slot = base + (unsigned long long)__popcll(mask & ((1ULL << lane) - 1ULL));
+        if (slot < a.capacity) {
+            mvs_cell c;
+            c.row = row;
+            c.col = col;
+            c.dot = P;
+            c.q = quantize_cell(P, a.d, a.norms_sq[row], a.norms_sq[col]);
+            a.cells[slot] = c;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// MFMA kernel.  L = limbs (1 or 2).  MODE 0: comparison, 1: dense dots.
+// LDS: 2 stages x [A region | B region], region = [L][128 samples][128 B].
+// ---------------------------------------------------------------------------------------------------
+template <int L, int MODE>
+__global__ __launch_bounds__(kThreads, 2) void k_pairwise_mfma(const PairwiseArgs a, int n_tr, int n_tc,
+                                                               int n_spc) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int kRegion = L * kTile * kBK;     // bytes of one operand region
+    constexpr int kStage = 2 * kRegion;          // bytes of one stage
+    constexpr int kPieces = kStage / 1024;       // 1 KiB pieces per stage
+    constexpr int kPPW = kPieces / kWaves;       // pieces per wave per stage
+    constexpr int NS = num_acc_sets(L);
+
+    const TileCoord tc = map_tile(blockIdx.x, n_tr, n_tc, n_spc);
+    if (!tc.valid) return;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2;   // 0..1 : 64-row half of the tile
+    const int wn = wave & 3;    // 0..3 : 32-col quarter of the tile
+
+    const int64_t i0 = a.row_begin + (int64_t)tc.tr * kTile;   // first A sample of the tile
+    const int64_t j0 = a.col_begin + (int64_t)tc.tc * kTile;   // first B sample of the tile
+
+    // ---- per-lane source pointers of this wave's pieces (k0 = 0) ----
+    const int8_t* src[kPPW];
+#pragma unroll
+    for (int p = 0; p < kPPW; ++p) {
+        const int piece = wave * kPPW + p;
+        const int row = piece * 8 + (lane >> 3);          // 128-byte LDS row inside the stage
+        const int region = row / (L * kTile);
+        const int rr = row % (L * kTile);
+        const int limb = rr / kTile;
+        const int s = rr % kTile;
+        const int c = (lane & 7) ^ ((s >> 1) & 7);        // logical 16-byte chunk stored at slot lane&7
+        const int64_t sample = (region == 0 ? i0 : j0) + s;
+        src[p] = a.planes + (sample * L + limb) * (int64_t)a.d_pad + c * 16;
+    }
+
+    auto stage_copy = [&](int stage, int k0) {
+#pragma unroll
+        for (int p = 0; p < kPPW; ++p) {
+            const int piece = wave * kPPW + p;
+            char* dst = smem + stage * kStage + piece * 1024;   // wave-uniform; lane data lands at +lane*16
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src[p] + k0), (lds_ptr_t)dst, 16, 0, 0);
+        }
+    };
+
+    // ---- fragment addressing ----
+    const int fr = lane & 31;          // row (A) / col (B) inside a 32x32 MFMA tile
+    const int fh = lane >> 5;          // k half
+    const int key = (fr >> 1) & 7;     // swizzle key (tile bases are multiples of 16 samples)
+    const int a_row0 = (wm * 64 + fr) * kBK;                   // + t*32*kBK + limb*kTile*kBK
+    const int b_row0 = kRegion + (wn * 32 + fr) * kBK;         // + limb*kTile*kBK
+
+    v16i acc[2][NS];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][s][r] = 0;
+
+    const int nk = a.d_pad / kBK;
+    stage_copy(0, 0);
+    __syncthreads();   // drains the LDS-DMA (vmcnt(0)) and publishes stage 0
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) stage_copy(cur ^ 1, (kt + 1) * kBK);   // in flight during the MFMAs below
+        const char* sb = smem + cur * kStage;
+#pragma unroll
+        for (int kk = 0; kk < kBK / 32; ++kk) {
+            const int coff = (((kk * 2 + fh) ^ key) << 4);
+            v4i fa[2][L], fb[L];
+#pragma unroll
+            for (int l = 0; l < L; ++l) {
+                fb[l] = *reinterpret_cast<const v4i*>(sb + b_row0 + l * kTile * kBK + coff);
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+                    fa[t][l] = *reinterpret_cast<const v4i*>(sb + a_row0 + t * 32 * kBK + l * kTile * kBK + coff);
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int la = 0; la < L; ++la)
+#pragma unroll
+                    for (int lb = 0; lb < L; ++lb) {
+                        if (la + lb > 3) continue;   // 256^4 == 0 (mod 2^32)
+                        acc[t][la + lb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[t][la], fb[lb], acc[t][la + lb], 0, 0, 0);
+                    }
+        }
+        __syncthreads();   // next stage landed (vmcnt(0)) and everyone is done reading `cur`
+    }
+
+    // ---- epilogue ----
+    int32_t* thr = reinterpret_cast<int32_t*>(smem);   // [0,128): rows, [128,256): cols
+    if (MODE == 0) {
+        if (tid < 2 * kTile) {
+            const int64_t g = (tid < kTile ? i0 : j0 - kTile) + tid;
+            thr[tid] = a.cand_thr[g];
+        }
+        __syncthreads();
+    }
+    const int col_l = wn * 32 + fr;
+    const int64_t col = j0 + col_l;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row_l = wm * 64 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+            const int64_t row = i0 + row_l;
+            uint32_t Pu = (uint32_t)acc[t][0][r];
+#pragma unroll
+            for (int s = 1; s < NS; ++s) Pu += (uint32_t)acc[t][s][r] << (8 * s);
+            const int32_t P = (int32_t)Pu;
+            if (MODE == 1) {
+                if (row < a.row_end && col < a.col_end)
+                    a.dots[(row - a.row_begin) * (a.col_end - a.col_begin) + (col - a.col_begin)] = P;
+            } else {
+                const bool cand = P >= thr[row_l] + thr[kTile + col_l];
+                if (__any(cand)) {
+                    bool keep = false;
+                    if (cand && row < a.row_end && col < a.col_end)
+                        keep = keep_cell(P, a.d, a.norms_sq[row], a.norms_sq[col], a.keep_mode);
+                    emit_cell(a, keep, (int32_t)row, (int32_t)col, P, lane);
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Vector-ALU kernel: one thread per cell, v_dot4_i32_i8 over the limb planes.  Any limb count.
+// Independent of the MFMA path (no LDS, no matrix cores): used for limbs > 2 and as a cross-check.
+// ---------------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(256) void k_pairwise_valu(const PairwiseArgs a) {
+    const int64_t col = a.col_begin + (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
+    const int64_t row = a.row_begin + (int64_t)blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const bool in = row < a.row_end && col < a.col_end;
+    const int L = a.limbs;
+    uint32_t acc[4] = {0u, 0u, 0u, 0u};
+    if (in) {
+        const int8_t* pa = a.planes + row * L * (int64_t)a.d_pad;
+        const int8_t* pb = a.planes + col * L * (int64_t)a.d_pad;
+        for (int k = 0; k < a.d_pad; k += 4) {
+            int wa[kMaxLimbs], wb[kMaxLimbs];
+            for (int l = 0; l < L; ++l) {
+                wa[l] = *reinterpret_cast<const int*>(pa + (int64_t)l * a.d_pad + k);
+                wb[l] = *reinterpret_cast<const int*>(pb + (int64_t)l * a.d_pad + k);
+            }
+            for (int la = 0; la < L; ++la)
+                for (int lb = 0; lb < L; ++lb)
+                    if (la + lb <= 3)
+                        acc[la + lb] = (uint32_t)__builtin_amdgcn_sdot4(wa[la], wb[lb], (int)acc[la + lb], false);
+        }
+    }
+    const int32_t P = (int32_t)(acc[0] + (acc[1] << 8) + (acc[2] << 16) + (acc[3] << 24));
+    if (MODE == 1) {
+        if (in) a.dots[(row - a.row_begin) * (a.col_end - a.col_begin) + (col - a.col_begin)] = P;
+    } else {
+        bool keep = false;
+        if (in) keep = keep_cell(P, a.d, a.norms_sq[row], a.norms_sq[col], a.keep_mode);
+        emit_cell(a, keep, (int32_t)row, (int32_t)col, P, lane);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// helpers: max |v|, limb split, candidate thresholds
+// ---------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_max_abs(const T* __restrict__ v, int64_t n,
+                                                 unsigned long long* __restrict__ out) {
+    unsigned long long m = 0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const long long x = (long long)v[i];
+        const unsigned long long ax = (unsigned long long)(x < 0 ? -x : x);
+        m = ax > m ? ax : m;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long other = __shfl_xor(m, o, 64);
+        m = other > m ? other : m;
+    }
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+
+// signed base-256 digits: v = l0 + 256*l1 + ... (mod 2^32), every digit in [-128, 127]
+template <typename T>
+__global__ __launch_bounds__(256) void k_limb_split(const T* __restrict__ sk, int64_t n_rows, int d, int limbs,
+                                                    int8_t* __restrict__ planes, int d_pad, int64_t row_offset) {
+    const int words = d_pad / 4;
+    const int64_t total = n_rows * words;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+        const int64_t row = idx / words;
+        const int k = (int)(idx % words) * 4;
+        if (k >= d) continue;   // pad words stay zero
+        int32_t v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (k + e < d) ? (int32_t)sk[row * d + k + e] : 0;
+        int8_t* dst = planes + (row_offset + row) * limbs * (int64_t)d_pad + k;
+        for (int l = 0; l < limbs; ++l) {
+            uint32_t packed = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int32_t digit = (int32_t)(int8_t)(v[e] & 0xff);
+                packed |= (uint32_t)(uint8_t)digit << (8 * e);
+                // v - digit is a multiple of 256; unsigned subtract so that the one wrapping case
+                // (v near INT32_MAX, 4 limbs) stays defined and congruent mod 2^32
+                v[e] = (int32_t)((uint32_t)v[e] - (uint32_t)digit) >> 8;
+            }
+            *reinterpret_cast<uint32_t*>(dst + (int64_t)l * d_pad) = packed;
+        }
+    }
+}
+
+// conservative integer part of the keep threshold: keep(i,j) implies P >= thr[i] + thr[j]
+__global__ __launch_bounds__(256) void k_cand_thr(const double* __restrict__ n2, int64_t n, int64_t n_alloc,
+                                                  int d, int32_t* __restrict__ thr) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_alloc) return;
+    int32_t t = (1 << 30) - 1;   // padding rows: never a candidate
+    if (i < n) {
+        const double x = n2[i];
+        t = -1;
+        if (x >= 0.0) {
+            const double f = floor(0.05 * (double)d * x * (1.0 - 1.0 / 1048576.0)) - 1.0;
+            t = f >= 1073741823.0 ? (1 << 30) - 1 : (f < -1.0 ? -1 : (int32_t)f);
+        }
+    }
+    thr[i] = t;
+}
+
+struct CellLess {
+    __host__ __device__ bool operator()(const mvs_cell& x, const mvs_cell& y) const {
+        return x.row < y.row || (x.row == y.row && x.col < y.col);
+    }
+};
+
+template <int L, int MODE>
+int launch_mfma(hipStream_t stream, const PairwiseArgs& a) {
+    const int64_t rows = a.row_end - a.row_begin, cols = a.col_end - a.col_begin;
+    if (rows <= 0 || cols <= 0) return 0;
+    const int n_tr = (int)((rows + kTile - 1) / kTile), n_tc = (int)((cols + kTile - 1) / kTile);
+    const int n_spr = (n_tr + 15) / 16, n_spc = (n_tc + 15) / 16;
+    const int64_t blocks = (int64_t)n_spr * n_spc * 256;
+    if (blocks > 0x7fffffffLL) return MVS_E_INVALID;
+    const size_t lds = (size_t)2 * 2 * L * kTile * kBK;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pairwise_mfma<L, MODE>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return MVS_E_HIP;
+    hipLaunchKernelGGL((k_pairwise_mfma<L, MODE>), dim3((unsigned)blocks), dim3(kThreads), lds, stream, a, n_tr,
+                       n_tc, n_spc);
+    return 0;
+}
+
+}  // namespace
+
+int launch_max_abs(hipStream_t stream, const void* d_sk, int elem_bytes, int64_t n_elems,
+                   unsigned long long* d_out) {
+    if (n_elems == 0) return 0;
+    int64_t blocks = (n_elems + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (elem_bytes == 4)
+        hipLaunchKernelGGL(k_max_abs<int32_t>, dim3((unsigned)blocks), dim3(256), 0, stream,
+                           (const int32_t*)d_sk, n_elems, d_out);
+    else
+        hipLaunchKernelGGL(k_max_abs<int16_t>, dim3((unsigned)blocks), dim3(256), 0, stream,
+                           (const int16_t*)d_sk, n_elems, d_out);
+    return 0;
+}
+
+int launch_limb_split(hipStream_t stream, const void* d_sk, int elem_bytes, int64_t n_rows, int d, int limbs,
+                      int8_t* d_planes, int d_pad, int64_t row_offset) {
+    if (n_rows == 0) return 0;
+    const int64_t total = n_rows * (d_pad / 4);
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    if (elem_bytes == 4)
+        hipLaunchKernelGGL(k_limb_split<int32_t>, dim3((unsigned)blocks), dim3(256), 0, stream,
+                           (const int32_t*)d_sk, n_rows, d, limbs, d_planes, d_pad, row_offset);
+    else
+        hipLaunchKernelGGL(k_limb_split<int16_t>, dim3((unsigned)blocks), dim3(256), 0, stream,
+                           (const int16_t*)d_sk, n_rows, d, limbs, d_planes, d_pad, row_offset);
+    return 0;
+}
+
+int launch_cand_thr(hipStream_t stream, const double* d_norms_sq, int64_t n, int64_t n_alloc, int d,
+                    int32_t* d_thr) {
+    hipLaunchKernelGGL(k_cand_thr, dim3((unsigned)((n_alloc + 255) / 256)), dim3(256), 0, stream, d_norms_sq, n,
+                       n_alloc, d, d_thr);
+    return 0;
+}
+
+int launch_pairwise(hipStream_t stream, const PairwiseArgs& a, int mode, int algo) {
+    if (algo == 0 && a.limbs <= 2) {
+        if (a.limbs == 1) return mode == 0 ? launch_mfma<1, 0>(stream, a) : launch_mfma<1, 1>(stream, a);
+        return mode == 0 ? launch_mfma<2, 0>(stream, a) : launch_mfma<2, 1>(stream, a);
+    }
+    const int64_t rows = a.row_end - a.row_begin, cols = a.col_end - a.col_begin;
+    if (rows <= 0 || cols <= 0) return 0;
+    const int64_t gx = (cols + 63) / 64, gy = (rows + 3) / 4;
+    // grid.y is limited to 65535: walk the rows in slabs
+    for (int64_t y0 = 0; y0 < gy; y0 += 65535) {
+        PairwiseArgs s = a;
+        s.row_begin = a.row_begin + y0 * 4;
+        const int64_t ny = gy - y0 < 65535 ? gy - y0 : 65535;
+        if (mode == 1) s.dots = a.dots + (s.row_begin - a.row_begin) * cols;
+        dim3 grid((unsigned)gx, (unsigned)ny);
+        if (mode == 0)
+            hipLaunchKernelGGL(k_pairwise_valu<0>, grid, dim3(256), 0, stream, s);
+        else
+            hipLaunchKernelGGL(k_pairwise_valu<1>, grid, dim3(256), 0, stream, s);
+    }
+    return 0;
+}
+
+int sort_cells(hipStream_t stream, mvs_cell* d_cells, mvs_cell* d_tmp, int64_t n, void* d_scratch,
+               size_t scratch_bytes, size_t* scratch_needed) {
+    size_t need = 0;
+    hipError_t e = rocprim::merge_sort(nullptr, need, d_cells, d_tmp, (size_t)n, CellLess(), stream);
+    if (e != hipSuccess) return MVS_E_HIP;
+    if (scratch_needed) *scratch_needed = need;
+    if (d_scratch == nullptr) return 0;
+    if (scratch_bytes < need) return MVS_E_CAPACITY;
+    e = rocprim::merge_sort(d_scratch, need, d_cells, d_tmp, (size_t)n, CellLess(), stream);
+    return e == hipSuccess ? 0 : MVS_E_HIP;
+}
+
+}  // namespace mvs

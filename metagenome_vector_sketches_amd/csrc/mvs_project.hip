@@ -1,0 +1,272 @@
+// mvs_project.hip -- projection kernels (gfx950 / CDNA4).
+//
+// Reference semantics: transform_set_into_vector(), src/random_projection.cpp:9-26
+//   v[k] = sum_h (1 - 2*bit_{k%64}(SM(h + 64*(k/64))))  ==  n - 2*count_k
+// where count_k = number of hashes whose bit k%64 of SM(h + 64*(k/64)) is set.
+//
+// MI355X design (see DESIGN.md "K1"):
+//   * the +-1 matrix is implicit (hash generated), so there is nothing to stage from HBM; the kernel
+//     is integer-VALU bound (19 VALU per splitmix64, 6 of them 32-bit multiplies);
+//   * each LANE hashes its own stream of hashes (coalesced 8-byte loads, 512 B per wave load) and
+//     counts set bits per position with BIT-SLICED counters: a Harley-Seal carry-save tree built from
+//     v_bitop3_b32 full adders (xor3 / majority), ~4.6 VALU per (hash, 64-dim block) instead of 128
+//     extract+add;
+//   * one wave owns BPW 64-dim blocks of one (sample, hash-chunk) unit; at the end the 64 lanes'
+//     bit-sliced counters are summed by a butterfly of bit-sliced ripple adders (ds_bpermute) and
+//     lane k extracts count_k;
+//   * samples are cut into units of <= 65536 hashes so that long samples spread over many
+//     workgroups; units of one sample combine with int32 atomics (order independent => exact).
+#include "mvs_internal.h"
+
+namespace mvs {
+
+namespace {
+
+constexpr int kLV = 11;            // bit-sliced counter depth per lane: counts up to 2047
+constexpr int kRedLV = kLV + 6;    // after summing 64 lanes
+constexpr uint64_t kGolden = 0x9e3779b97f4a7c15ULL;
+
+__device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) {
+    return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);
+}
+__device__ __forceinline__ uint32_t maj3(uint32_t a, uint32_t b, uint32_t c) {
+    return __builtin_amdgcn_bitop3_b32(a, b, c, 0xE8);
+}
+
+// src/random_projection.cpp:14-17 applied to z = hash + i + 0x9e37... (the adds of :13-14 are folded
+// into one 64-bit add by the caller)
+__device__ __forceinline__ uint64_t splitmix_tail(uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
+    return z ^ (z >> 31);
+}
+
+template <int BPW>
+struct Acc {
+    uint32_t lo[BPW][kLV];
+    uint32_t hi[BPW][kLV];
+};
+
+// Harley-Seal: absorb 2^LEVEL inputs into the persistent bit-sliced digits s[0..LEVEL-1]; returns
+// (in clo/chi) the carry word of weight 2^LEVEL.  2^LEVEL - 1 full adders per 2^LEVEL inputs.
+template <int LEVEL, int BPW, class Gen>
+__device__ __forceinline__ void absorb(Acc<BPW>& s, Gen& g, uint32_t (&clo)[BPW], uint32_t (&chi)[BPW]) {
+    if constexpr (LEVEL == 0) {
+        g.next(clo, chi);
+    } else {
+        uint32_t alo[BPW], ahi[BPW], blo[BPW], bhi[BPW];
+        absorb<LEVEL - 1, BPW>(s, g, alo, ahi);
+        absorb<LEVEL - 1, BPW>(s, g, blo, bhi);
+#pragma unroll
+        for (int b = 0; b < BPW; ++b) {
+            const uint32_t tl = s.lo[b][LEVEL - 1], th = s.hi[b][LEVEL - 1];
+            clo[b] = maj3(tl, alo[b], blo[b]);
+            chi[b] = maj3(th, ahi[b], bhi[b]);
+            s.lo[b][LEVEL - 1] = xor3(tl, alo[b], blo[b]);
+            s.hi[b][LEVEL - 1] = xor3(th, ahi[b], bhi[b]);
+        }
+    }
+}
+
+// add a carry word of weight 2^FROM into digits FROM..kLV-1 (half adders)
+template <int FROM, int BPW>
+__device__ __forceinline__ void ripple(Acc<BPW>& s, uint32_t (&clo)[BPW], uint32_t (&chi)[BPW]) {
+#pragma unroll
+    for (int l = FROM; l < kLV; ++l) {
+#pragma unroll
+        for (int b = 0; b < BPW; ++b) {
+            const uint32_t tl = s.lo[b][l] & clo[b], th = s.hi[b][l] & chi[b];
+            s.lo[b][l] ^= clo[b];
+            s.hi[b][l] ^= chi[b];
+            clo[b] = tl;
+            chi[b] = th;
+        }
+    }
+}
+
+// yields SM(h + 64*block) for the next hash of this lane's stream, for each of the wave's BPW blocks
+template <int BPW, bool MASKED>
+struct HashGen {
+    const uint64_t* p;     // this lane's first hash of the current batch
+    int64_t remaining;     // hashes left from p (MASKED only), counted in lane strides of 64
+    uint64_t cb[BPW];      // 64*block + golden
+    int j = 0;
+    __device__ __forceinline__ void next(uint32_t (&lo)[BPW], uint32_t (&hi)[BPW]) {
+        bool valid = true;
+        uint64_t h = 0;
+        if constexpr (MASKED) {
+            valid = (int64_t)j * 64 < remaining;
+            if (valid) h = p[(int64_t)j * 64];
+        } else {
+            h = p[(int64_t)j * 64];
+        }
+        ++j;
+#pragma unroll
+        for (int b = 0; b < BPW; ++b) {
+            uint64_t x = splitmix_tail(h + cb[b]);
+            if constexpr (MASKED) x = valid ? x : 0ULL;
+            lo[b] = (uint32_t)x;
+            hi[b] = (uint32_t)(x >> 32);
+        }
+    }
+};
+
+// Sum the 64 lanes' bit-sliced counters and return, in lane k, the count for bit position k.
+__device__ __forceinline__ int32_t reduce_counts(const uint32_t (&lo_in)[kLV], const uint32_t (&hi_in)[kLV],
+                                                 int lane) {
+    uint32_t lo[kRedLV], hi[kRedLV];
+#pragma unroll
+    for (int l = 0; l < kRedLV; ++l) {
+        lo[l] = l < kLV ? lo_in[l] : 0u;
+        hi[l] = l < kLV ? hi_in[l] : 0u;
+    }
+#pragma unroll
+    for (int s = 0; s < 6; ++s) {
+        uint32_t cl = 0, ch = 0;
+#pragma unroll
+        for (int l = 0; l < kLV + s + 1; ++l) {
+            const uint32_t pl = (uint32_t)__shfl_xor((int)lo[l], 1 << s, 64);
+            const uint32_t ph = (uint32_t)__shfl_xor((int)hi[l], 1 << s, 64);
+            const uint32_t sl = xor3(lo[l], pl, cl), sh = xor3(hi[l], ph, ch);
+            cl = maj3(lo[l], pl, cl);
+            ch = maj3(hi[l], ph, ch);
+            lo[l] = sl;
+            hi[l] = sh;
+        }
+    }
+    int32_t cnt = 0;
+    const int sh = lane & 31;
+#pragma unroll
+    for (int l = 0; l < kRedLV; ++l) {
+        const uint32_t w = lane < 32 ? lo[l] : hi[l];
+        cnt += (int32_t)((w >> sh) & 1u) << l;
+    }
+    return cnt;
+}
+
+// grid.x = unit, grid.y = group of kWaves*BPW 64-dim blocks; 256 threads = 4 waves, each wave owns
+// BPW consecutive blocks and streams over all hashes of the unit.
+template <int BPW>
+__global__ __launch_bounds__(256) void k_project(const uint64_t* __restrict__ hashes,
+                                                 const ProjUnit* __restrict__ units, int d, int nblk,
+                                                 int32_t* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b0 = (blockIdx.y * 4 + wave) * BPW;
+    if (b0 >= nblk) return;
+    const ProjUnit u = units[blockIdx.x];
+    const uint64_t* base = hashes + u.begin;
+    const int64_t count = u.count;
+
+    Acc<BPW> s;
+#pragma unroll
+    for (int b = 0; b < BPW; ++b)
+#pragma unroll
+        for (int l = 0; l < kLV; ++l) s.lo[b][l] = s.hi[b][l] = 0u;
+
+    uint64_t cb[BPW];
+#pragma unroll
+    for (int b = 0; b < BPW; ++b) cb[b] = (uint64_t)(b0 + b) * 64ULL + kGolden;
+
+    // main loop: 32 hashes per lane per iteration (2048 per wave), no masking
+    int64_t pos = 0;
+    for (; pos + 2048 <= count; pos += 2048) {
+        HashGen<BPW, false> g;
+        g.p = base + pos + lane;
+        g.remaining = 0;
+#pragma unroll
+        for (int b = 0; b < BPW; ++b) g.cb[b] = cb[b];
+        uint32_t clo[BPW], chi[BPW];
+        absorb<5, BPW>(s, g, clo, chi);
+        ripple<5, BPW>(s, clo, chi);
+    }
+    // tail: 4 hashes per lane per step (256 per wave), masked
+    for (; pos < count; pos += 256) {
+        HashGen<BPW, true> g;
+        g.p = base + pos + lane;
+        g.remaining = count - pos - lane;
+#pragma unroll
+        for (int b = 0; b < BPW; ++b) g.cb[b] = cb[b];
+        uint32_t clo[BPW], chi[BPW];
+        absorb<2, BPW>(s, g, clo, chi);
+        ripple<2, BPW>(s, clo, chi);
+    }
+
+#pragma unroll
+    for (int b = 0; b < BPW; ++b) {
+        if (b0 + b >= nblk) break;
+        const int32_t cnt = reduce_counts(s.lo[b], s.hi[b], lane);
+        const int k = (b0 + b) * 64 + lane;
+        if (k < d) {
+            const int32_t v = (int32_t)count - 2 * cnt;
+            int32_t* dst = out + (int64_t)u.sample * d + k;
+            if (u.single)
+                *dst = v;
+            else
+                atomicAdd(dst, v);
+        }
+    }
+}
+
+// one wave per sketch row: exact int64 sum of squares
+__global__ __launch_bounds__(256) void k_sumsq(const int32_t* __restrict__ sk, int64_t n, int d,
+                                               int64_t* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const int32_t* p = sk + row * d;
+    long long acc = 0;
+    for (int k = lane; k < d; k += 64) {
+        const long long v = p[k];
+        acc += v * v;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (lane == 0) out[row] = acc;
+}
+
+__global__ __launch_bounds__(256) void k_saturate_i16(const int32_t* __restrict__ in, int64_t n,
+                                                      int16_t* __restrict__ out) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int32_t v = in[i];
+        out[i] = (int16_t)(v > 32767 ? 32767 : (v < -32768 ? -32768 : v));
+    }
+}
+
+}  // namespace
+
+int launch_project(hipStream_t stream, const uint64_t* d_hashes, const ProjUnit* d_units, int64_t n_units,
+                   int d, int32_t* d_out, int bpw) {
+    if (n_units == 0) return 0;
+    const int nblk = (d + 63) / 64;
+    // grid.x is limited to 2^31-1, plenty; launch in slabs anyway to keep blockIdx.x an int
+    const int64_t kMaxUnits = 1 << 30;
+    for (int64_t u0 = 0; u0 < n_units; u0 += kMaxUnits) {
+        const int64_t nu = n_units - u0 < kMaxUnits ? n_units - u0 : kMaxUnits;
+        if (bpw == 1) {
+            dim3 grid((unsigned)nu, (unsigned)((nblk + 3) / 4));
+            hipLaunchKernelGGL(k_project<1>, grid, dim3(256), 0, stream, d_hashes, d_units + u0, d, nblk, d_out);
+        } else {
+            dim3 grid((unsigned)nu, (unsigned)((nblk + 7) / 8));
+            hipLaunchKernelGGL(k_project<2>, grid, dim3(256), 0, stream, d_hashes, d_units + u0, d, nblk, d_out);
+        }
+    }
+    return 0;
+}
+
+int launch_sumsq(hipStream_t stream, const int32_t* d_sk, int64_t n, int d, int64_t* d_out) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_sumsq, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, d_sk, n, d, d_out);
+    return 0;
+}
+
+int launch_saturate_i16(hipStream_t stream, const int32_t* d_in, int64_t n, int16_t* d_out) {
+    if (n == 0) return 0;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_saturate_i16, dim3((unsigned)blocks), dim3(256), 0, stream, d_in, n, d_out);
+    return 0;
+}
+
+}  // namespace mvs

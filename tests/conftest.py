@@ -1,0 +1,68 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+class Golden:
+    """Committed fixtures (tests/golden/, produced by tests/golden/make_golden.py from the reference)."""
+
+    def __init__(self):
+        with open(os.path.join(GOLD, "kat.json")) as f:
+            self.kat = json.load(f)
+        with open(os.path.join(GOLD, "toy_sketch_digests.json")) as f:
+            self.digests = json.load(f)
+        db = np.load(os.path.join(GOLD, "toy_db.npz"))
+        self.names = [str(x) for x in db["names"]]
+        self.vectors = db["vectors"]
+        with open(os.path.join(GOLD, "toy_vector_norms.txt")) as f:
+            self.norms_txt = f.read()
+        h = np.load(os.path.join(GOLD, "toy_hashes.npz"))
+        assert [str(x) for x in h["names"]] == self.names
+        self.offsets = h["offsets"].astype(np.int64)
+        deltas = h["deltas"].astype(np.uint64)
+        hashes = deltas.copy()
+        for i in range(len(self.names)):
+            b, e = self.offsets[i], self.offsets[i + 1]
+            hashes[b:e] = np.cumsum(deltas[b:e], dtype=np.uint64)
+        self.hashes = hashes
+
+    def cells(self, int16=False):
+        fn = "toy_pairwise_cells_int16.txt" if int16 else "toy_pairwise_cells.txt"
+        idx = {n: i for i, n in enumerate(self.names)}
+        out = []
+        with open(os.path.join(GOLD, fn)) as f:
+            for line in f:
+                if line.startswith("#"):
+                    continue
+                r, c, dot, q = line.split()
+                out.append((idx[r], idx[c], int(dot), int(q)))
+        return out
+
+    def norm_lines(self):
+        return [l for l in self.norms_txt.split("\n") if l]
+
+
+@pytest.fixture(scope="session")
+def gold():
+    return Golden()
+
+
+@pytest.fixture(scope="session")
+def ctx():
+    """GPU context through the C ABI; only -m gpu tests use it."""
+    from metagenome_vector_sketches_amd import Context
+    c = Context(0)
+    yield c
+    c.close()

@@ -1,0 +1,140 @@
+"""CPU: the oracle (oracle/mvs_oracle.c) against the committed reference fixtures.
+
+Fixtures come from the reference binaries (oracle/_ref, built from /root/reference/src) run by
+tests/golden/make_golden.py, and from the values SURVEY.md section 4 recorded."""
+import hashlib
+
+import numpy as np
+
+from oracle import pyoracle as orc
+
+
+def test_splitmix_kat(gold):
+    # splitmix64 finaliser as used by src/random_projection.cpp:13-17, x = 1
+    assert orc.splitmix64(1) == int(gold.kat["splitmix64_of_1"], 16)
+
+
+def _parse_sp(stdout):
+    return [np.array([float(t) for t in line.split(" ")], dtype=np.float64) if line else np.zeros(0)
+            for line in stdout.split("\n")[:-1]]
+
+
+def test_standalone_projection_cases(gold):
+    """src/standalone_projection.cpp:28-43: one line of d floats per input line."""
+    for key, case in gold.kat["standalone_projection"].items():
+        d = case["d"]
+        lines = case["input"].split("\n")[:-1]
+        want = _parse_sp(case["stdout"])
+        assert len(want) == len(lines), key
+        for line, w in zip(lines, want):
+            hashes = sorted(set(int(t) for t in line.split()))  # unordered_set dedups
+            got = orc.project(np.array(hashes, dtype=np.uint64), d)
+            assert len(w) == d, key
+            assert np.array_equal(got.astype(np.float64), w), key
+
+
+def test_toy_projection_bit_exact(gold):
+    """all 61 toy samples, d=2048, against the reference's vectors.bin"""
+    got = orc.project_csr(gold.hashes, gold.offsets, 2048, threads=4)
+    assert np.array_equal(got, gold.vectors)
+    fast = orc.project_csr(gold.hashes, gold.offsets, 2048, threads=4, fast=True)
+    assert np.array_equal(fast, gold.vectors)
+    assert hashlib.sha256(got.tobytes()).hexdigest() == gold.kat["toy_vectors_sha256_sorted_by_name"]
+    for i, n in enumerate(gold.names):
+        dg = gold.digests[n]
+        assert hashlib.sha256(got[i].tobytes()).hexdigest() == dg["sha256"]
+        assert int(got[i].sum()) == dg["sum"] and orc.sumsq(got[i]) == dg["sumsq"]
+        assert gold.offsets[i + 1] - gold.offsets[i] == dg["n_hashes"]
+
+
+def test_toy_norms_within_tolerance(gold):
+    """vector_norms.txt is float32 + -ffast-math in the reference and not bit-reproducible
+    (SURVEY.md 8c): tolerance 1e-5 relative, i.e. <= 1 unit in the 6th significant digit."""
+    exact_match = 0
+    for i, line in enumerate(gold.norm_lines()):
+        name, txt = line.split(" ")
+        assert name == gold.names[i]
+        ref = float(txt)
+        for mine in (orc.norm(gold.vectors[i]), orc.norm_f32path(gold.vectors[i])):
+            assert abs(mine - ref) <= 1e-5 * max(ref, 1e-30) + 1e-12
+        exact_match += orc.format_norm(orc.norm(gold.vectors[i])) == txt
+    assert exact_match >= len(gold.names) - 3
+
+
+def test_toy_pairwise_cells(gold):
+    """int32 path, chunk 192, one shard: 1291 of 3721 cells."""
+    n2 = np.array([orc.norm_sq_from_text(l.split(" ")[1]) for l in gold.norm_lines()])
+    cells = orc.pairwise_rows(gold.vectors, n2, chunk=192, threads=4)
+    want = gold.cells()
+    assert len(cells) == gold.kat["survey_kept_cells"]["int32"] == len(want)
+    got = [(int(c["row"]), int(c["col"]), int(c["dot"]), int(c["q"])) for c in cells]
+    assert got == want
+    # the rows SURVEY.md recorded from the reference binary itself
+    by_row = {}
+    for r, c, dot, q in got:
+        by_row.setdefault(gold.names[r], []).append((gold.names[c], q))
+    # SURVEY listed them in readdir order; compare as sets of (col, q) prefixes by name
+    for rname, pin in gold.kat["survey_pairwise_pins"].items():
+        have = dict(by_row[rname])
+        for cname, q in zip(pin["cols"], pin["q"]):
+            assert have[cname] == q
+
+
+def test_toy_pairwise_cells_int16(gold):
+    n2 = np.array([orc.norm_sq_from_text(l.split(" ")[1]) for l in gold.norm_lines()])
+    v16 = orc.saturate_i16(gold.vectors)
+    assert np.array_equal(v16.astype(np.int32), gold.vectors)  # toy max |v| = 1263
+    cells = orc.pairwise_rows(v16, n2, chunk=2048, threads=4)
+    got = sorted((int(c["row"]), int(c["col"]), int(c["dot"]), int(c["q"])) for c in cells)
+    assert len(got) == gold.kat["survey_kept_cells"]["int16"]
+    assert got == sorted(gold.cells(int16=True))
+
+
+def test_pairwise_order_and_shards(gold):
+    """order = (i-chunk, j-chunk, i, j); shards = row ranges (src/pairwise_comp_optimized.cpp:938-980)"""
+    n2 = np.array([orc.norm_sq_from_text(l.split(" ")[1]) for l in gold.norm_lines()])
+    full = orc.pairwise_rows(gold.vectors, n2, chunk=192)
+    parts = []
+    for k in range(2):
+        b, e = orc.shard_rows(len(gold.names), 2, k)
+        parts.append(orc.pairwise_rows(gold.vectors, n2, row_begin=b, row_end=e, chunk=192))
+    assert (b, e) == (31, 61)
+    assert np.array_equal(np.concatenate(parts), full)
+    small = orc.pairwise_rows(gold.vectors, n2, chunk=7)  # different tiling -> different order, same set
+    assert sorted(map(tuple, small.tolist())) == sorted(map(tuple, full.tolist()))
+    assert not np.array_equal(small, full)
+
+
+def test_chunk_formula():
+    assert orc.chunk_size(12, 2048) == 192
+    assert orc.chunk_size(12, 4096) == 48
+    assert orc.chunk_size(64, 2048) == 1024
+
+
+def test_keep_and_quantize_edge_cases():
+    lib = orc.load()
+    # truncation toward zero: -2047/2048 -> 0, not -1; 0 > 0 is false
+    assert lib.mvs_oracle_keep_i32(-2047, 2048, 0.0, 0.0) == 0
+    assert lib.mvs_oracle_keep_i32(2047, 2048, 0.0, 0.0) == 0          # trunc(0.9995) = 0
+    assert lib.mvs_oracle_keep_i16(2047, 2048, 0.0, 0.0) == 1          # floating division keeps it
+    assert lib.mvs_oracle_keep_i32(2048, 2048, 0.0, 0.0) == 1
+    # self pair: J = 1 -> 255
+    assert lib.mvs_oracle_quantize(2048 * 100, 2048, 100.0, 100.0) == 255
+    # J slightly above 1 clamps
+    assert lib.mvs_oracle_quantize(2048 * 101, 2048, 100.0, 100.0) == 255
+    # round half away from zero: J*255 = 0.5 -> 1
+    assert lib.mvs_oracle_quantize(1, 1, 255.0, 255.0 + 1.0) == 1
+
+
+def test_dot_wraps_mod_2_32():
+    a = np.full(2048, 70000, dtype=np.int32)
+    lib = orc.load()
+    got = lib.mvs_oracle_dot_i32(a.ctypes.data, a.ctypes.data, 2048)
+    want = (70000 * 70000 * 2048) % (1 << 32)
+    want = want - (1 << 32) if want >= (1 << 31) else want
+    assert got == want
+
+
+def test_saturate_i16():
+    v = np.array([0, 1, -1, 32767, 32768, -32768, -32769, 2**31 - 1, -2**31], dtype=np.int32)
+    assert orc.saturate_i16(v).tolist() == [0, 1, -1, 32767, 32767, -32768, -32768, 32767, -32768]

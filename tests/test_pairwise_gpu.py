@@ -1,0 +1,164 @@
+"""GPU: the pairwise kernels (through the C ABI) against the oracle and the reference fixtures.
+Bit-exact: dot products are int32 mod 2^32, the keep test and the 8-bit Jaccard are evaluated in the
+reference's own operation order in fp64."""
+import numpy as np
+import pytest
+
+from metagenome_vector_sketches_amd import _capi, synth
+from oracle import pyoracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _n2_from_sketches(sk):
+    """norms as the DB would carry them: '%g' text of sqrt(sumsq/d), squared (pairwise_comp_optimized.cpp:893-901)"""
+    return np.array([orc.norm_sq_from_text(orc.format_norm(orc.norm(row))) for row in sk.astype(np.int32)])
+
+
+def _cells_tuple(cells):
+    return [(int(c["row"]), int(c["col"]), int(c["dot"]), int(c["q"])) for c in cells]
+
+
+def _oracle_sorted(sk, n2, **kw):
+    return sorted(_cells_tuple(orc.pairwise_rows(sk, n2, threads=8, **kw)))
+
+
+@pytest.mark.parametrize("n,d", [(61, 2048), (300, 2048), (257, 100), (130, 4096), (5, 64), (129, 2048 + 64)])
+def test_dots_mfma_and_valu_vs_oracle(ctx, n, d):
+    rng = np.random.default_rng(n * 7 + d)
+    sk = rng.integers(-1500, 1500, size=(n, d), dtype=np.int32)   # asymmetric, 2 limbs
+    sk[0] = 0
+    ss = ctx.sketch_set(sk)
+    assert ss.limbs == 2
+    want = orc.dots_dense(sk, 0, n, 0, n, threads=8)
+    assert np.array_equal(ctx.pairwise_dots(ss, 0, n, 0, n, algo=0), want)
+    assert np.array_equal(ctx.pairwise_dots(ss, 0, n, 0, n, algo=1), want)
+    # off-diagonal rectangular block (row/col tiles differ; catches a transposed C/D mapping)
+    r0, r1, c0, c1 = n // 3, n, 0, n // 2 + 1
+    assert np.array_equal(ctx.pairwise_dots(ss, r0, r1, c0, c1, algo=0), want[r0:r1, c0:c1])
+    ss.close()
+
+
+def test_dots_single_limb(ctx):
+    rng = np.random.default_rng(3)
+    sk = rng.integers(-128, 128, size=(200, 2048), dtype=np.int32)
+    sk[sk == -128] = -127
+    ss = ctx.sketch_set(sk)
+    assert ss.limbs == 1
+    assert np.array_equal(ctx.pairwise_dots(ss, 0, 200, 0, 200), orc.dots_dense(sk, 0, 200, 0, 200, threads=8))
+    ss.close()
+
+
+@pytest.mark.parametrize("hi,limbs", [(32639, 2), (40000, 3), (8355711, 3), (9_000_000, 4), (2**31 - 1, 4)])
+def test_dots_wrap_and_many_limbs(ctx, hi, limbs):
+    """large entries: products overflow int32 and must wrap exactly like the reference's MatrixXi product"""
+    rng = np.random.default_rng(hi % 1000)
+    sk = rng.integers(-hi, hi, size=(70, 256), dtype=np.int64).astype(np.int32)
+    sk[0, 0], sk[1, 1] = hi, -hi
+    if hi == 2**31 - 1:
+        sk[2, 2] = -2**31
+    ss = ctx.sketch_set(sk)
+    assert ss.limbs == limbs
+    want = orc.dots_dense(sk, 0, 70, 0, 70, threads=8)
+    assert np.array_equal(ctx.pairwise_dots(ss, 0, 70, 0, 70, algo=0), want)
+    assert np.array_equal(ctx.pairwise_dots(ss, 0, 70, 0, 70, algo=1), want)
+    ss.close()
+
+
+def test_toy_cells_reference_db(ctx, gold):
+    """config 1: the reference-built toy DB (vectors.bin + vector_norms.txt) -> 1291 kept cells, the rows
+    SURVEY.md recorded, every (row, col, dot, q) equal to the fixture"""
+    n2 = np.array([orc.norm_sq_from_text(l.split(" ")[1]) for l in gold.norm_lines()])
+    ss = ctx.sketch_set(gold.vectors)
+    cells, cnt = ctx.pairwise_rows(ss, n2)
+    got = _cells_tuple(cells)
+    assert cnt == 1291 == gold.kat["survey_kept_cells"]["int32"]
+    assert got == sorted(gold.cells())            # library order is (row, col)
+    by_row = {}
+    for r, c, dot, q in got:
+        by_row.setdefault(gold.names[r], {})[gold.names[c]] = q
+    for rname, pin in gold.kat["survey_pairwise_pins"].items():
+        for cname, q in zip(pin["cols"], pin["q"]):
+            assert by_row[rname][cname] == q
+    # int16 DB + floating keep test -> 1293 cells
+    ss16 = ctx.sketch_set(gold.vectors.astype(np.int16))
+    cells16, cnt16 = ctx.pairwise_rows(ss16, n2, keep_mode=_capi.KEEP_INT16)
+    assert cnt16 == 1293 and _cells_tuple(cells16) == sorted(gold.cells(int16=True))
+    ss.close()
+    ss16.close()
+
+
+def test_clustered_synthetic_vs_oracle(ctx):
+    """sketches of real (synthetic) hash sets: clusters of 16 with Jaccard ~0.25 -> ~16 kept cells per row"""
+    hashes, offsets = synth.make_csr_numpy(400, 3000, seed=5, cluster=16, shared=0.4, lognormal_sigma=0.8)
+    sk = ctx.project_csr(hashes, offsets, 2048)
+    n2 = _n2_from_sketches(sk)
+    ss = ctx.sketch_set(sk)
+    cells, cnt = ctx.pairwise_rows(ss, n2)
+    want = _oracle_sorted(sk, n2, chunk=192)
+    assert cnt == len(want) and cnt > 400 * 8
+    assert _cells_tuple(cells) == want
+    # shards = row ranges; union of shards == whole (src/pairwise_comp_optimized.cpp:938-940)
+    parts = []
+    for k in range(3):
+        b, e = _capi.shard_rows(400, 3, k)
+        c, _ = ctx.pairwise_rows(ss, n2, row_begin=b, row_end=e)
+        assert all(b <= x["row"] < e for x in c)
+        parts += _cells_tuple(c)
+    assert parts == want
+    ss.close()
+
+
+def test_keep_threshold_edges(ctx):
+    """cells sitting exactly on the keep threshold: truncating vs floating division"""
+    d = 64
+    sk = np.zeros((4, d), dtype=np.int32)
+    sk[0, :] = 1                      # dot(0,0) = 64 -> 64/64 = 1
+    sk[1, :63] = 1                    # dot(0,1) = 63 -> trunc 0 / float 0.98
+    sk[2, :] = -1                     # negative dots: trunc toward zero
+    sk[3, 0] = 1
+    n2 = np.array([1.0, 0.5, 1.0, 0.0])
+    ss = ctx.sketch_set(sk)
+    for mode in (_capi.KEEP_INT32, _capi.KEEP_INT16):
+        cells, _ = ctx.pairwise_rows(ss, n2, keep_mode=mode)
+        skx = sk if mode == _capi.KEEP_INT32 else sk.astype(np.int16)
+        want = sorted(_cells_tuple(orc.pairwise_rows(skx, n2, chunk=192)))
+        assert _cells_tuple(cells) == want
+    ss.close()
+
+
+def test_capacity_error_reports_needed(ctx, gold):
+    n2 = np.array([orc.norm_sq_from_text(l.split(" ")[1]) for l in gold.norm_lines()])
+    ss = ctx.sketch_set(gold.vectors)
+    with pytest.raises(_capi.MvsError) as ei:
+        ctx.pairwise_rows(ss, n2, capacity=100)
+    assert ei.value.code == _capi.MVS_E_CAPACITY and "1291" in str(ei.value)
+    ss.close()
+
+
+def test_full_width_properties(ctx):
+    """N = 4096, d = 2048 (sketch magnitudes of 50k-hash samples): no oracle for the whole matrix --
+    symmetry of the kept set, diagonal = 255, checksum of dots vs the VALU path on a stripe, and an
+    oracle check of 64 rows."""
+    import torch
+    n, d = 4096, 2048
+    sk_t = synth.make_sketches_torch(n, d, 50_000, seed=2345, device="cuda")
+    sk = sk_t.cpu().numpy()
+    n2 = _n2_from_sketches(sk)
+    ss = ctx.sketch_set(sk_t)
+    assert ss.limbs == 2
+    cells, cnt = ctx.pairwise_rows(ss, n2)
+    got = _cells_tuple(cells)
+    s = set((r, c) for r, c, _, _ in got)
+    assert all((c, r) in s for r, c in s)                         # symmetric
+    dq = {(r, c): (dot, q) for r, c, dot, q in got}
+    assert all(dq[(i, i)][1] == 255 for i in range(n))            # self pairs kept with J = 1
+    assert all(dq[(r, c)] == dq[(c, r)] for r, c in s)
+    assert cnt >= n * 12                                          # ~16 cluster mates per row
+    rows = slice(1000, 1064)
+    want = _oracle_sorted(sk, n2, row_begin=rows.start, row_end=rows.stop, chunk=192)
+    assert [t for t in got if rows.start <= t[0] < rows.stop] == want
+    a = ctx.pairwise_dots(ss, 2048, 2048 + 256, 0, n, algo=0)
+    b = ctx.pairwise_dots(ss, 2048, 2048 + 256, 0, n, algo=1)
+    assert np.array_equal(a, b)
+    ss.close()

@@ -1,0 +1,123 @@
+"""GPU: the HIP projection kernel (through the C ABI) against the oracle, the reference fixtures and
+size-independent properties.  Bit-exact: the sketch is integer work."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from metagenome_vector_sketches_amd import synth
+from oracle import pyoracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _csr(lists):
+    offs = np.zeros(len(lists) + 1, dtype=np.int64)
+    offs[1:] = np.cumsum([len(x) for x in lists])
+    flat = np.concatenate([np.asarray(x, dtype=np.uint64) for x in lists]) if offs[-1] else np.zeros(0, np.uint64)
+    return flat, offs
+
+
+def test_kat(ctx, gold):
+    # hashes {1,2,3}, d=8 -> -1 1 -1 -1 3 1 -3 -3
+    h, o = _csr([[1, 2, 3]])
+    assert ctx.project_csr(h, o, 8).tolist() == [[-1, 1, -1, -1, 3, 1, -3, -3]]
+
+
+def test_standalone_projection_fixtures(ctx, gold):
+    for key, case in gold.kat["standalone_projection"].items():
+        d = case["d"]
+        lines = case["input"].split("\n")[:-1]
+        want = [[float(t) for t in l.split(" ")] for l in case["stdout"].split("\n")[:-1]]
+        lists = [sorted(set(int(t) for t in line.split())) for line in lines]
+        h, o = _csr(lists)
+        got = ctx.project_csr(h, o, d)
+        assert got.shape == (len(lines), d)
+        assert np.array_equal(got.astype(np.float64), np.array(want)), key
+
+
+def test_toy_set_bit_exact(ctx, gold):
+    """config 1 of BASELINE.json: the 61 toy samples (3 ... 80772 hashes), d=2048, against the
+    reference's own vectors.bin"""
+    got = ctx.project_csr(gold.hashes, gold.offsets, 2048)
+    assert np.array_equal(got, gold.vectors)
+    assert hashlib.sha256(got.tobytes()).hexdigest() == gold.kat["toy_vectors_sha256_sorted_by_name"]
+
+
+@pytest.mark.parametrize("d", [64, 100, 2048, 4096, 2048 + 64])
+def test_ragged_vs_oracle(ctx, d):
+    rng = np.random.default_rng(d)
+    sizes = [0, 1, 2, 63, 64, 65, 255, 256, 257, 2047, 2048, 2049, 4096 + 300, 0, 7000, 65535, 65536, 65537,
+             131072 + 5]
+    lists = [rng.integers(0, synth.MAX_HASH, size=s, dtype=np.uint64) for s in sizes]
+    h, o = _csr(lists)
+    got = ctx.project_csr(h, o, d)
+    want = orc.project_csr(h, o, d, threads=8, fast=True)
+    assert np.array_equal(got, want)
+
+
+def test_u64_wraparound(ctx):
+    # hash + 64*block wraps mod 2^64 (src/random_projection.cpp:13)
+    lists = [[2**64 - 1, 2**64 - 64, 2**64 - 2048, 5], [2**63, 2**63 - 1]]
+    h, o = _csr(lists)
+    assert np.array_equal(ctx.project_csr(h, o, 4096), orc.project_csr(h, o, 4096))
+
+
+def test_device_resident_io(ctx):
+    import torch
+    hashes, offsets = synth.make_csr_torch(96, 5000, seed=7, device="cuda")
+    out = torch.empty((96, 2048), dtype=torch.int32, device="cuda")
+    ctx.set_stream(torch.cuda.current_stream())
+    ctx.project_csr(hashes, offsets, 2048, out=out)
+    torch.cuda.synchronize()
+    ctx.set_stream(None)
+    want = orc.project_csr(hashes.cpu().numpy().view(np.uint64), offsets, 2048, threads=8, fast=True)
+    assert np.array_equal(out.cpu().numpy(), want)
+
+
+def test_full_size_properties(ctx):
+    """BASELINE config-2 sample size (50k hashes): properties that need no oracle.
+    - parity: v[k] == n (mod 2) and |v[k]| <= n
+    - additivity: sketch(A u B) == sketch(A) + sketch(B) for disjoint A, B
+    - order independence"""
+    import torch
+    n, d = 50_000, 2048
+    hashes, offsets = synth.make_csr_torch(64, n, seed=11, device="cuda", cluster=1, shared=0.0)
+    out = torch.empty((64, d), dtype=torch.int32, device="cuda")
+    ctx.project_csr(hashes, offsets, d, out=out)
+    ctx.synchronize()
+    v = out.cpu().numpy()
+    assert np.all((v - n) % 2 == 0) and np.all(np.abs(v) <= n)
+    assert np.abs(v).max() < 8 * np.sqrt(n)            # +-1 sums: 8 sigma
+    # pairs of consecutive samples as one 100k-hash sample (exercises the multi-unit atomic path)
+    out2 = torch.empty((32, d), dtype=torch.int32, device="cuda")
+    ctx.project_csr(hashes, offsets[::2].copy(), d, out=out2)
+    ctx.synchronize()
+    assert np.array_equal(out2.cpu().numpy(), v[0::2] + v[1::2])
+    # permute the hashes inside each sample
+    perm = torch.randperm(n, device="cuda")
+    shuffled = hashes.view(64, n)[:, perm].contiguous().view(-1)
+    out3 = torch.empty_like(out)
+    ctx.project_csr(shuffled, offsets, d, out=out3)
+    ctx.synchronize()
+    assert torch.equal(out3, out)
+    # spot-check two rows against the oracle
+    hh = hashes.cpu().numpy().view(np.uint64)
+    for s in (0, 63):
+        assert np.array_equal(v[s], orc.project(hh[offsets[s]:offsets[s + 1]], d))
+
+
+def test_sumsq_and_saturate(ctx, gold):
+    got = ctx.sumsq(gold.vectors)
+    assert got.tolist() == [gold.digests[n]["sumsq"] for n in gold.names]
+    v = np.array([[0, 1, -1, 32767, 32768, -32768, -32769, 2**31 - 1, -2**31, 5]], dtype=np.int32)
+    assert np.array_equal(ctx.saturate_i16(v), orc.saturate_i16(v))
+
+
+def test_bad_arguments(ctx):
+    from metagenome_vector_sketches_amd import MvsError
+    h, o = _csr([[1, 2, 3]])
+    with pytest.raises(MvsError):
+        ctx.project_csr(h, o, 0)
+    with pytest.raises(MvsError):
+        ctx.project_csr(h, np.array([0, 3, 2], dtype=np.int64), 64)
