@@ -64,9 +64,11 @@ int mvs_device_count(int* count);
 
 int mvs_ctx_create(int device, mvs_ctx** ctx);
 int mvs_ctx_destroy(mvs_ctx* ctx);
-/* Issue all later work on `hip_stream` (a hipStream_t of the same device, e.g. the caller's
- * framework stream).  NULL switches back to the context's own stream. */
+/* Issue all later work on `hip_stream`, a hipStream_t of the same device (e.g. the caller's framework
+ * stream); NULL is HIP's default ("null") stream.  mvs_ctx_use_own_stream switches back to the
+ * non-blocking stream the context created for itself (the initial state). */
 int mvs_ctx_set_stream(mvs_ctx* ctx, void* hip_stream);
+int mvs_ctx_use_own_stream(mvs_ctx* ctx);
 int mvs_ctx_synchronize(mvs_ctx* ctx);
 /* Optional kernel timing: when enabled, HIP events are recorded on the context's stream around the
  * dominant kernel of mvs_project_csr (which = 0) and of mvs_pairwise_rows (which = 1);

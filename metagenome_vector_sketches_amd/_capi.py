@@ -27,6 +27,7 @@ SYMBOLS = [
     ("mvs_ctx_create", _c.c_int, [_c.c_int, _c.POINTER(_P)]),
     ("mvs_ctx_destroy", _c.c_int, [_P]),
     ("mvs_ctx_set_stream", _c.c_int, [_P, _P]),
+    ("mvs_ctx_use_own_stream", _c.c_int, [_P]),
     ("mvs_ctx_synchronize", _c.c_int, [_P]),
     ("mvs_ctx_set_timing", _c.c_int, [_P, _c.c_int]),
     ("mvs_ctx_kernel_ms", _c.c_int, [_P, _c.c_int, _c.POINTER(_c.c_float)]),
@@ -153,10 +154,14 @@ class Context:
             pass
 
     def set_stream(self, stream):
-        """stream: raw hipStream_t value (int), a torch.cuda.Stream, or None for the context's own."""
-        if stream is not None and hasattr(stream, "cuda_stream"):
+        """stream: a torch.cuda.Stream or a raw hipStream_t value (0 = HIP's default stream);
+        None switches back to the context's own non-blocking stream."""
+        if stream is None:
+            _check(self.lib.mvs_ctx_use_own_stream(self._h))
+            return
+        if hasattr(stream, "cuda_stream"):
             stream = stream.cuda_stream
-        _check(self.lib.mvs_ctx_set_stream(self._h, _P(stream) if stream else None))
+        _check(self.lib.mvs_ctx_set_stream(self._h, _P(int(stream)) if int(stream) else None))
 
     def synchronize(self):
         _check(self.lib.mvs_ctx_synchronize(self._h))

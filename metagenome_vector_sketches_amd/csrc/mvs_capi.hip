@@ -167,7 +167,7 @@ int mvs_ctx_create(int device, mvs_ctx** out) {
 int mvs_ctx_destroy(mvs_ctx* c) {
     if (!c) return MVS_OK;
     (void)hipSetDevice(c->device);
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    (void)hipStreamSynchronize(c->stream);
     if (c->scratch) (void)hipFree(c->scratch);
     if (c->d_counter) (void)hipFree(c->d_counter);
     if (c->pinned) (void)hipHostFree(c->pinned);
@@ -181,7 +181,13 @@ int mvs_ctx_destroy(mvs_ctx* c) {
 
 int mvs_ctx_set_stream(mvs_ctx* c, void* hip_stream) {
     if (!c) return fail(MVS_E_INVALID, "ctx is NULL");
-    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    c->stream = (hipStream_t)hip_stream;
+    return MVS_OK;
+}
+
+int mvs_ctx_use_own_stream(mvs_ctx* c) {
+    if (!c) return fail(MVS_E_INVALID, "ctx is NULL");
+    c->stream = c->own_stream;
     return MVS_OK;
 }
 
