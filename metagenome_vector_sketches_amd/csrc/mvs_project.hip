@@ -84,32 +84,49 @@ __device__ __forceinline__ void ripple(Acc<BPW>& s, uint32_t (&clo)[BPW], uint32
     }
 }
 
-// yields SM(h + 64*block) for the next hash of this lane's stream, for each of the wave's BPW blocks
+// yields SM(h + 64*block) for the next hash of a register-resident batch, for each of the wave's BPW
+// blocks.  The batch (8 hashes per lane = 512 per wave) was loaded one batch ahead of its use.
 template <int BPW, bool MASKED>
-struct HashGen {
-    const uint64_t* p;     // this lane's first hash of the current batch
-    int64_t remaining;     // hashes left from p (MASKED only), counted in lane strides of 64
-    uint64_t cb[BPW];      // 64*block + golden
+struct BatchGen {
+    const uint64_t (&h)[8];
+    const uint64_t (&cb)[BPW];   // 64*block + golden
+    int64_t remaining;           // MASKED: hashes left from this lane's first hash of the batch
     int j = 0;
+    __device__ __forceinline__ BatchGen(const uint64_t (&h_)[8], const uint64_t (&cb_)[BPW], int64_t rem)
+        : h(h_), cb(cb_), remaining(rem) {}
     __device__ __forceinline__ void next(uint32_t (&lo)[BPW], uint32_t (&hi)[BPW]) {
+        const uint64_t hv = h[j];
         bool valid = true;
-        uint64_t h = 0;
-        if constexpr (MASKED) {
-            valid = (int64_t)j * 64 < remaining;
-            if (valid) h = p[(int64_t)j * 64];
-        } else {
-            h = p[(int64_t)j * 64];
-        }
+        if constexpr (MASKED) valid = (int64_t)j * 64 < remaining;
         ++j;
 #pragma unroll
         for (int b = 0; b < BPW; ++b) {
-            uint64_t x = splitmix_tail(h + cb[b]);
+            uint64_t x = splitmix_tail(hv + cb[b]);
             if constexpr (MASKED) x = valid ? x : 0ULL;
             lo[b] = (uint32_t)x;
             hi[b] = (uint32_t)(x >> 32);
         }
     }
 };
+
+// load the batch that starts at hash index `pos` of the unit; indices are clamped into the unit so the
+// prefetch of a batch that does not exist (or the tail of a partial one) stays in bounds
+template <bool CLAMP>
+__device__ __forceinline__ void load_batch(uint64_t (&h)[8], const uint64_t* base, int64_t pos, int lane,
+                                           int64_t last) {
+    if constexpr (CLAMP) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            int64_t idx = pos + j * 64 + lane;
+            idx = idx < last ? idx : last;
+            h[j] = base[idx];
+        }
+    } else {
+        const uint64_t* p = base + pos + lane;   // whole batch known to be inside the unit
+#pragma unroll
+        for (int j = 0; j < 8; ++j) h[j] = p[j * 64];
+    }
+}
 
 // Sum the 64 lanes' bit-sliced counters and return, in lane k, the count for bit position k.
 __device__ __forceinline__ int32_t reduce_counts(const uint32_t (&lo_in)[kLV], const uint32_t (&hi_in)[kLV],
@@ -168,28 +185,63 @@ __global__ __launch_bounds__(256) void k_project(const uint64_t* __restrict__ ha
 #pragma unroll
     for (int b = 0; b < BPW; ++b) cb[b] = (uint64_t)(b0 + b) * 64ULL + kGolden;
 
-    // main loop: 32 hashes per lane per iteration (2048 per wave), no masking
-    int64_t pos = 0;
-    for (; pos + 2048 <= count; pos += 2048) {
-        HashGen<BPW, false> g;
-        g.p = base + pos + lane;
-        g.remaining = 0;
+    // Batches of 8 hashes per lane (512 per wave); batch i+1 is loaded while batch i is hashed.
+    if (count > 0) {
+        const int64_t last = count - 1;
+        const int64_t nfull = count >> 9;
+        uint64_t hv[8], hn[8];
+        load_batch<true>(hv, base, 0, lane, last);
+        int64_t b = 0;
+        // four batches = 32 hashes per lane: Harley-Seal tree of depth 5, then one ripple.  The loop
+        // runs while the NEXT four batches are full too, so its prefetches need no bounds handling.
+        for (; b + 4 < nfull; b += 4) {
+            uint32_t c8lo[4][BPW], c8hi[4][BPW];
 #pragma unroll
-        for (int b = 0; b < BPW; ++b) g.cb[b] = cb[b];
-        uint32_t clo[BPW], chi[BPW];
-        absorb<5, BPW>(s, g, clo, chi);
-        ripple<5, BPW>(s, clo, chi);
-    }
-    // tail: 4 hashes per lane per step (256 per wave), masked
-    for (; pos < count; pos += 256) {
-        HashGen<BPW, true> g;
-        g.p = base + pos + lane;
-        g.remaining = count - pos - lane;
+            for (int sb = 0; sb < 4; ++sb) {
+                load_batch<false>(hn, base, (b + sb + 1) << 9, lane, last);
+                BatchGen<BPW, false> g(hv, cb, 0);
+                absorb<3, BPW>(s, g, c8lo[sb], c8hi[sb]);
 #pragma unroll
-        for (int b = 0; b < BPW; ++b) g.cb[b] = cb[b];
-        uint32_t clo[BPW], chi[BPW];
-        absorb<2, BPW>(s, g, clo, chi);
-        ripple<2, BPW>(s, clo, chi);
+                for (int j = 0; j < 8; ++j) hv[j] = hn[j];
+            }
+            uint32_t c16lo[2][BPW], c16hi[2][BPW], c32lo[BPW], c32hi[BPW];
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+                for (int q = 0; q < BPW; ++q) {
+                    const uint32_t tl = s.lo[q][3], th = s.hi[q][3];
+                    c16lo[h2][q] = maj3(tl, c8lo[2 * h2][q], c8lo[2 * h2 + 1][q]);
+                    c16hi[h2][q] = maj3(th, c8hi[2 * h2][q], c8hi[2 * h2 + 1][q]);
+                    s.lo[q][3] = xor3(tl, c8lo[2 * h2][q], c8lo[2 * h2 + 1][q]);
+                    s.hi[q][3] = xor3(th, c8hi[2 * h2][q], c8hi[2 * h2 + 1][q]);
+                }
+#pragma unroll
+            for (int q = 0; q < BPW; ++q) {
+                const uint32_t tl = s.lo[q][4], th = s.hi[q][4];
+                c32lo[q] = maj3(tl, c16lo[0][q], c16lo[1][q]);
+                c32hi[q] = maj3(th, c16hi[0][q], c16hi[1][q]);
+                s.lo[q][4] = xor3(tl, c16lo[0][q], c16lo[1][q]);
+                s.hi[q][4] = xor3(th, c16hi[0][q], c16hi[1][q]);
+            }
+            ripple<5, BPW>(s, c32lo, c32hi);
+        }
+        // leftover full batches
+        for (; b < nfull; ++b) {
+            load_batch<true>(hn, base, (b + 1) << 9, lane, last);
+            BatchGen<BPW, false> g(hv, cb, 0);
+            uint32_t clo[BPW], chi[BPW];
+            absorb<3, BPW>(s, g, clo, chi);
+            ripple<3, BPW>(s, clo, chi);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) hv[j] = hn[j];
+        }
+        // partial last batch, masked
+        if ((count & 511) != 0) {
+            BatchGen<BPW, true> g(hv, cb, count - (nfull << 9) - lane);
+            uint32_t clo[BPW], chi[BPW];
+            absorb<3, BPW>(s, g, clo, chi);
+            ripple<3, BPW>(s, clo, chi);
+        }
     }
 
 #pragma unroll
