@@ -138,6 +138,11 @@ int mvs_sketch_set_create(mvs_ctx* ctx, const void* sketches, int elem_bytes, in
                           mvs_sketch_set** set);
 int mvs_sketch_set_from_planes(mvs_ctx* ctx, const int8_t* planes, int64_t n, int64_t n_alloc, int d,
                                int d_pad, int limbs, mvs_sketch_set** set);
+/* For databases streamed from disk in row chunks (load_matrix_block, src/pairwise_comp_optimized.cpp:33-54):
+ * allocate zeroed planes for n samples with a given limb count, then fill row ranges. */
+int mvs_sketch_set_alloc(mvs_ctx* ctx, int64_t n, int d, int limbs, mvs_sketch_set** set);
+int mvs_sketch_set_fill(mvs_sketch_set* set, const void* sketches, int elem_bytes, int mem, int64_t row_offset,
+                        int64_t n_rows);
 int mvs_sketch_set_info(const mvs_sketch_set* set, int64_t* n, int* d, int* limbs, int64_t* n_alloc,
                         int* d_pad);
 int mvs_sketch_set_destroy(mvs_sketch_set* set);

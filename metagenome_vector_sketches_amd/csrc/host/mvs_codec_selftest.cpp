@@ -1,0 +1,116 @@
+// mvs_codec_selftest -- CPU-only round-trip checks of mvs_codec.hpp and of the shard writer/reader in
+// mvs_host.hpp (no device needed).  Exit code 0 = all good.
+#include <random>
+#include <sstream>
+
+#include "mvs_host.hpp"
+
+#define CHECK(cond)                                                                  \
+    do {                                                                             \
+        if (!(cond)) {                                                               \
+            std::cerr << "FAILED: " #cond " at line " << __LINE__ << std::endl;      \
+            return 1;                                                                \
+        }                                                                            \
+    } while (0)
+
+int main(int argc, char* argv[]) {
+    std::mt19937_64 rng(12345);
+    // compact_vector: widths 1..64, sizes incl. 0 and 1
+    for (int width = 1; width <= 64; ++width) {
+        for (size_t n : {size_t(0), size_t(1), size_t(2), size_t(63), size_t(64), size_t(65), size_t(1000)}) {
+            std::vector<uint64_t> v(n);
+            const uint64_t mask = width == 64 ? ~0ULL : ((1ULL << width) - 1);
+            for (auto& x : v) x = rng() & mask;
+            if (n) v[n / 2] = mask;   // force the width
+            mvs_codec::compact_vector cv;
+            cv.build(v.begin(), v.size());
+            std::stringstream ss;
+            cv.save(ss);
+            CHECK((uint64_t)ss.str().size() == cv.num_bytes());
+            mvs_codec::compact_vector back;
+            back.load(ss);
+            CHECK(back.size() == n);
+            for (size_t i = 0; i < n; ++i) CHECK(back[i] == v[i]);
+        }
+    }
+    // rice_sequence: small deltas, large values, zeros, unsorted, single element
+    for (int mode = 0; mode < 6; ++mode) {
+        for (size_t n : {size_t(0), size_t(1), size_t(2), size_t(64), size_t(65), size_t(129), size_t(5000)}) {
+            std::vector<uint64_t> v(n);
+            for (auto& x : v) {
+                switch (mode) {
+                    case 0: x = rng() % 4; break;
+                    case 1: x = rng() % 1000; break;
+                    case 2: x = 0; break;
+                    case 3: x = rng() % (1ULL << 40); break;
+                    case 4: x = (rng() % 100 == 0) ? (rng() % (1ULL << 30)) : (rng() % 3); break;
+                    default: x = 1 + rng() % 100000; break;
+                }
+            }
+            mvs_codec::rice_sequence rs;
+            rs.encode(v.begin(), v.size());
+            std::stringstream ss;
+            rs.save(ss);
+            CHECK((uint64_t)ss.str().size() == rs.num_bytes());
+            mvs_codec::rice_sequence back;
+            back.load(ss);
+            CHECK(back.size() == n);
+            std::vector<uint64_t> dec;
+            back.decode(dec);
+            CHECK(dec == v);
+            for (size_t i = 0; i < n; i += (n > 100 ? 37 : 1)) CHECK(back.access(i) == v[i]);
+            if (n) CHECK(back.access(n - 1) == v[n - 1]);
+        }
+    }
+    // shard writer/reader: rows with 1 entry, many entries, gaps; empty shard
+    const std::string dir = argc > 1 ? std::string(argv[1]) : std::string("/tmp/mvs_codec_selftest/");
+    std::filesystem::remove_all(dir);
+    for (int variant = 0; variant < 3; ++variant) {
+        std::vector<mvs_cell> cells;
+        if (variant > 0) {
+            const int rows = variant == 1 ? 1 : 500;
+            for (int r = 0; r < rows; ++r) {
+                if (variant == 2 && r % 7 == 3) continue;   // absent rows
+                const int cnt = variant == 1 ? 1 : (r % 5 == 0 ? 1 : 1 + (int)(rng() % 40));
+                int col = (int)(rng() % 50);
+                for (int k = 0; k < cnt; ++k) {
+                    mvs_cell c{r * 3 + 10, col, 0, (int32_t)(13 + rng() % 243)};
+                    cells.push_back(c);
+                    col += 1 + (int)(rng() % (k % 3 == 0 ? 100000 : 5));
+                }
+            }
+        }
+        const std::string sub = dir + "shard_" + std::to_string(variant) + "/";
+        mvs_host::write_shard(sub, cells.data(), cells.size());
+        std::vector<mvs_cell> back;
+        CHECK(mvs_host::read_shard(sub, back));
+        CHECK(back.size() == cells.size());
+        for (size_t i = 0; i < cells.size(); ++i)
+            CHECK(back[i].row == cells[i].row && back[i].col == cells[i].col && back[i].q == cells[i].q);
+    }
+    std::filesystem::remove_all(dir);
+    // hash text parsing: dedup, stop at the first bad token, lines without ':' skipped
+    {
+        const std::string p = "/tmp/mvs_codec_selftest_hashes.txt";
+        {
+            std::ofstream f(p);
+            f << "a: 3 1 2 3 3\nno colon here\nb:\nc: 18446744073709551615 7 18446744073709551616 9\nd: 5 x 6\ne: 12abc 4\r\n";
+        }
+        mvs_host::HashSets hs;
+        CHECK(mvs_host::read_hash_file(p, true, hs, 2));
+        CHECK(hs.names.size() == 5 && hs.names[0] == "a" && hs.names[1] == "b" && hs.names[4] == "e");
+        CHECK(hs.offsets[1] - hs.offsets[0] == 3 && hs.hashes[0] == 1 && hs.hashes[2] == 3);
+        CHECK(hs.offsets[2] - hs.offsets[1] == 0);
+        CHECK(hs.offsets[3] - hs.offsets[2] == 2 && hs.hashes[(size_t)hs.offsets[3] - 1] == 18446744073709551615ULL);
+        CHECK(hs.offsets[4] - hs.offsets[3] == 1 && hs.hashes[(size_t)hs.offsets[3]] == 5);
+        CHECK(hs.offsets[5] - hs.offsets[4] == 1 && hs.hashes[(size_t)hs.offsets[4]] == 12);
+        mvs_host::HashSets hl;
+        CHECK(mvs_host::read_hash_file(p, false, hl, 1));
+        CHECK(hl.offsets.size() == 7);   // six lines, every one a record
+        std::remove(p.c_str());
+    }
+    CHECK(mvs_host::format_g(56.46254) == "56.4625" && mvs_host::format_g(1234567.0) == "1.23457e+06");
+    CHECK(mvs_host::format_g_float(-3.0f) == "-3" && mvs_host::format_g(0.0) == "0");
+    std::cout << "mvs_codec_selftest ok" << std::endl;
+    return 0;
+}

@@ -1,0 +1,274 @@
+// mvs_host.hpp -- host-side pieces shared by the drop-in executables: the reference's text/binary
+// formats on both sides of the hot path.  Everything numeric is done by libmvs_hip.so (include/mvs_hip.h).
+//
+// Citations are relative to the reference root.
+#ifndef MVS_HOST_HPP
+#define MVS_HOST_HPP
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <filesystem>
+#include <fstream>
+#include <iostream>
+#include <sstream>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../../include/mvs_hip.h"
+#include "mvs_codec.hpp"
+
+namespace mvs_host {
+
+namespace fs = std::filesystem;
+
+// ---------------------------------------------------------------------------------------------------
+// hash text -> CSR
+// ---------------------------------------------------------------------------------------------------
+struct HashSets {
+    std::vector<std::string> names;
+    std::vector<uint64_t> hashes;    // concatenated, unique within a sample (sorted)
+    std::vector<int64_t> offsets;    // names.size() + 1
+};
+
+// Parse whitespace separated unsigned 64-bit integers the way `while (iss >> hash)` does
+// (src/project_everything.cpp:275-279, src/standalone_projection.cpp:32-35): stop at the first token
+// that is not a number in range.  The reference collects them in an unordered_set; sort + unique gives
+// the same set.
+inline void parse_u64_tokens(const char* p, const char* end, std::vector<uint64_t>& out) {
+    while (true) {
+        while (p < end && (*p == ' ' || *p == '\t' || *p == '\r' || *p == '\v' || *p == '\f')) ++p;
+        if (p >= end) break;
+        if (*p == '+') ++p;
+        if (p >= end || *p < '0' || *p > '9') break;
+        uint64_t v = 0;
+        bool overflow = false;
+        while (p < end && *p >= '0' && *p <= '9') {
+            const uint64_t dgt = (uint64_t)(*p - '0');
+            if (v > (UINT64_MAX - dgt) / 10) overflow = true;
+            v = v * 10 + dgt;
+            ++p;
+        }
+        if (overflow) break;                                   // failbit in the reference
+        if (p < end && !(*p == ' ' || *p == '\t' || *p == '\r' || *p == '\v' || *p == '\f')) {
+            out.push_back(v);                                  // "12abc": 12 is extracted, then the stream fails
+            break;
+        }
+        out.push_back(v);
+    }
+    std::sort(out.begin(), out.end());
+    out.erase(std::unique(out.begin(), out.end()), out.end());
+}
+
+// One record per line.  with_names: "name: h1 h2 ..." (lines without ':' are skipped,
+// src/project_everything.cpp:267-270); otherwise every line is a hash list
+// (src/standalone_projection.cpp:28-35).
+inline bool read_hash_file(const std::string& path, bool with_names, HashSets& out, unsigned threads = 0) {
+    std::ifstream in(path, std::ios::binary | std::ios::ate);
+    if (!in) return false;
+    const std::streamoff size = in.tellg();
+    std::string buf((size_t)size, '\0');
+    in.seekg(0);
+    if (size) in.read(&buf[0], size);
+    // line table
+    struct Line { size_t b, e; };
+    std::vector<Line> lines;
+    size_t pos = 0;
+    while (pos < buf.size()) {
+        const char* nl = (const char*)memchr(buf.data() + pos, '\n', buf.size() - pos);
+        const size_t e = nl ? (size_t)(nl - buf.data()) : buf.size();
+        lines.push_back({pos, e});
+        pos = e + 1;
+    }
+    // std::getline yields a final empty line only if the file ends without '\n' after text; a trailing
+    // "\n" does not produce an extra record -- the loop above matches that.
+    std::vector<Line> recs;
+    std::vector<size_t> colon;
+    for (const Line& l : lines) {
+        if (with_names) {
+            const char* c = (const char*)memchr(buf.data() + l.b, ':', l.e - l.b);
+            if (!c) continue;
+            recs.push_back(l);
+            colon.push_back((size_t)(c - buf.data()));
+        } else {
+            recs.push_back(l);
+            colon.push_back(l.b - 1);
+        }
+    }
+    const size_t n = recs.size();
+    std::vector<std::vector<uint64_t>> sets(n);
+    if (threads == 0) threads = std::max(1u, std::thread::hardware_concurrency());
+    threads = (unsigned)std::min<size_t>(threads, std::max<size_t>(1, n));
+    std::vector<std::thread> pool;
+    for (unsigned t = 0; t < threads; ++t)
+        pool.emplace_back([&, t]() {
+            for (size_t i = t; i < n; i += threads)
+                parse_u64_tokens(buf.data() + colon[i] + 1, buf.data() + recs[i].e, sets[i]);
+        });
+    for (auto& th : pool) th.join();
+    out.names.clear();
+    out.offsets.assign(1, 0);
+    size_t total = 0;
+    for (auto& s : sets) total += s.size();
+    out.hashes.clear();
+    out.hashes.reserve(total);
+    for (size_t i = 0; i < n; ++i) {
+        out.names.push_back(with_names ? buf.substr(recs[i].b, colon[i] - recs[i].b) : std::string());
+        out.hashes.insert(out.hashes.end(), sets[i].begin(), sets[i].end());
+        out.offsets.push_back((int64_t)out.hashes.size());
+    }
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// DB folder (src/project_everything.cpp:306-361 writes it, src/pairwise_comp_optimized.cpp:852-914 reads it)
+// ---------------------------------------------------------------------------------------------------
+// `os << double` with default precision / flags == "%g"
+inline std::string format_g(double v) {
+    char b[64];
+    snprintf(b, sizeof b, "%g", v);
+    return b;
+}
+// `os << float` likewise (src/standalone_projection.cpp:40)
+inline std::string format_g_float(float v) { return format_g((double)v); }
+
+// norm of one sketch: the reference takes the float32 path (cast / sqrt(float d), Eigen norm) whose
+// last digit is not reproducible; this build defines it as sqrt(double(sumsq) / d).
+inline double norm_from_sumsq(int64_t sumsq, int d) { return std::sqrt((double)sumsq / (double)d); }
+
+struct DbInfo {
+    std::string dtype = "int32";
+    int dimension = 0;
+    int64_t total_vectors = 0;
+    std::vector<std::string> names;
+    std::vector<double> norms_sq;   // stod(text)^2, src/pairwise_comp_optimized.cpp:893-901
+};
+
+inline bool read_norms(const std::string& norms_file, DbInfo& db) {
+    std::ifstream in(norms_file);
+    if (!in) return false;
+    std::string line;
+    while (std::getline(in, line)) {
+        const size_t pos = line.find(' ');
+        if (pos == std::string::npos) continue;
+        const double norm = std::stod(line.substr(pos + 1));
+        db.names.push_back(line.substr(0, pos));
+        db.norms_sq.push_back(norm * norm);
+    }
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// matrix shard folder, active format (writer src/pairwise_comp_optimized.cpp:645-817)
+// ---------------------------------------------------------------------------------------------------
+struct ShardStats {
+    uint64_t jac_space = 0, ngh_space = 0, rows = 0;
+};
+
+// cells must be grouped by row with ascending columns inside a row (mvs_pairwise_rows order).
+// Rows are written in ascending order (the reference iterates a std::unordered_map, i.e. in an
+// unspecified order; its reader builds a map and accepts any order).
+inline ShardStats write_shard(const std::string& folder, const mvs_cell* cells, size_t n_cells) {
+    if (!fs::exists(folder)) fs::create_directories(folder);
+    std::ofstream bin_out(folder + "matrix.bin", std::ios::binary);
+    std::ofstream index_out(folder + "row_index.bin", std::ios::binary);
+    std::vector<uint32_t> row_vec, start_neighbor;
+    std::vector<uint64_t> curr_pos_vec;
+    ShardStats st;
+    size_t i = 0;
+    while (i < n_cells) {
+        size_t j = i;
+        while (j < n_cells && cells[j].row == cells[i].row) ++j;
+        row_vec.push_back((uint32_t)cells[i].row);
+        curr_pos_vec.push_back((uint64_t)bin_out.tellp());
+        start_neighbor.push_back((uint32_t)cells[i].col);
+        std::vector<uint16_t> jac(j - i);
+        std::vector<uint64_t> delta(j - i - 1);
+        for (size_t k = i; k < j; ++k) {
+            jac[k - i] = (uint16_t)cells[k].q;
+            if (k > i) {
+                if (cells[k].col <= cells[k - 1].col) throw std::runtime_error("write_shard: columns not ascending");
+                delta[k - i - 1] = (uint64_t)(cells[k].col - cells[k - 1].col);
+            }
+        }
+        mvs_codec::compact_vector cv_jc;
+        cv_jc.build(jac.begin(), jac.size());
+        cv_jc.save(bin_out);
+        st.jac_space += cv_jc.num_bytes();
+        if (jac.size() > 1) {                     // :732 a single-entry row has no delta sequence
+            mvs_codec::rice_sequence rs_delta;
+            rs_delta.encode(delta.begin(), delta.size());
+            rs_delta.save(bin_out);
+            st.ngh_space += rs_delta.num_bytes();
+        }
+        i = j;
+    }
+    bin_out.close();
+    st.rows = row_vec.size();
+    // row ids, then byte-offset deltas between consecutive rows (:769-783)
+    mvs_codec::compact_vector cv_rows;
+    cv_rows.build(row_vec.begin(), row_vec.size());
+    cv_rows.save(index_out);
+    std::vector<uint64_t> pos_delta(curr_pos_vec.empty() ? 0 : curr_pos_vec.size() - 1);
+    for (size_t k = 1; k < curr_pos_vec.size(); ++k) pos_delta[k - 1] = curr_pos_vec[k] - curr_pos_vec[k - 1];
+    mvs_codec::compact_vector cv_cps;
+    cv_cps.build(pos_delta.begin(), pos_delta.size());
+    cv_cps.save(index_out);
+    index_out.close();
+    std::ofstream ngh_out(folder + "neighbor_start.bin", std::ios::binary);
+    mvs_codec::rice_sequence rs_start;
+    rs_start.encode(start_neighbor.begin(), start_neighbor.size());
+    rs_start.save(ngh_out);
+    st.ngh_space += rs_start.num_bytes();
+    return st;
+}
+
+// decode a shard folder back into (row, col, q) triples in file order -- what the reader's
+// load_neighbors_for_rows_jaccard_wo_sort (src/read_pc_mat_cmp.cpp:597-671) reconstructs
+inline bool read_shard(const std::string& folder, std::vector<mvs_cell>& out) {
+    std::ifstream index_in(folder + "row_index.bin", std::ios::binary);
+    std::ifstream bin_in(folder + "matrix.bin", std::ios::binary);
+    std::ifstream ngh_in(folder + "neighbor_start.bin", std::ios::binary);
+    if (!index_in || !bin_in || !ngh_in) return false;
+    mvs_codec::compact_vector cv_rows, cv_cps;
+    cv_rows.load(index_in);
+    cv_cps.load(index_in);
+    mvs_codec::rice_sequence rs_start;
+    rs_start.load(ngh_in);
+    uint64_t addr = 0;
+    for (uint64_t r = 0; r < cv_rows.size(); ++r) {
+        if (r > 0) addr += cv_cps.access(r - 1);
+        bin_in.seekg((std::streamoff)addr);
+        mvs_codec::compact_vector jac;
+        jac.load(bin_in);
+        std::vector<uint64_t> delta;
+        if (jac.size() > 1) {
+            mvs_codec::rice_sequence rs;
+            rs.load(bin_in);
+            rs.decode(delta);
+        }
+        uint64_t col = rs_start.access(r);
+        for (uint64_t k = 0; k < jac.size(); ++k) {
+            if (k > 0) col += delta[k - 1];
+            mvs_cell c;
+            c.row = (int32_t)cv_rows.access(r);
+            c.col = (int32_t)col;
+            c.dot = 0;
+            c.q = (int32_t)jac.access(k);
+            out.push_back(c);
+        }
+    }
+    return true;
+}
+
+inline int pick_device() {
+    const char* e = getenv("MVS_DEVICE");
+    return e ? atoi(e) : 0;
+}
+
+}  // namespace mvs_host
+
+#endif

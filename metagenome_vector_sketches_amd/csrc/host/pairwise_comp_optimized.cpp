@@ -1,0 +1,245 @@
+// pairwise_comp_optimized -- drop-in for the reference executable of the same name
+// (src/pairwise_comp_optimized.cpp + src/pairwise_comp_optimized_16bits.cpp): same six required flags,
+// same DB folder in, same shard folder out; the all-vs-all comparison runs on the MI355X.
+//
+//   pairwise_comp_optimized --db D/ --max_memory_gb G --num_threads T --output_folder O
+//                           --num_shards S --shard_idx k [--start_shard a] [--end_shard b] [--help]
+//
+// Differences a user can observe (all listed in DESIGN.md): tiles are sized by the kernel, not by
+// --max_memory_gb (the "Using chunks of size" line still prints the reference's formula; the flag bounds
+// the kept-cell staging buffer instead); rows are written in ascending order; the codec bytes are this
+// build's own (the reference's `bits` library is not available); the int16 DB path writes the active
+// shard format instead of the legacy EF+zstd one.
+#include <chrono>
+
+#include "mvs_host.hpp"
+
+namespace fs = std::filesystem;
+using namespace mvs_host;
+
+struct Options {
+    std::string db_folder, output_folder;
+    double max_memory_gb = 0.0;
+    int num_threads = 1, num_shards = 1, shard_idx = 0, start_shard = 0, end_shard = 1;
+    bool show_help = false;
+};
+
+static void print_usage(const char* argv0) {
+    std::cout << "Usage:\n"
+              << "        " << argv0
+              << " --db <folder> --max_memory_gb <float> --num_threads <int> --output_folder <folder>"
+                 " --num_shards <int> --shard_idx <int> [--start_shard <int>] [--end_shard <int>] [--help]"
+              << std::endl;
+}
+
+static bool parse(int argc, char* argv[], Options& o) {
+    bool have[6] = {false, false, false, false, false, false};
+    for (int i = 1; i < argc; ++i) {
+        const std::string a = argv[i];
+        auto value = [&](std::string& dst) {
+            if (i + 1 >= argc) return false;
+            dst = argv[++i];
+            return true;
+        };
+        std::string v;
+        char* end = nullptr;
+        if (a == "--help") {
+            o.show_help = true;
+        } else if (a == "--db") {
+            if (!value(o.db_folder)) return false;
+            have[0] = true;
+        } else if (a == "--max_memory_gb") {
+            if (!value(v)) return false;
+            o.max_memory_gb = strtod(v.c_str(), &end);
+            if (end == v.c_str() || *end) return false;
+            have[1] = true;
+        } else if (a == "--output_folder") {
+            if (!value(o.output_folder)) return false;
+            have[3] = true;
+        } else if (a == "--num_threads" || a == "--num_shards" || a == "--shard_idx" || a == "--start_shard" ||
+                   a == "--end_shard") {
+            if (!value(v)) return false;
+            const long x = strtol(v.c_str(), &end, 10);
+            if (end == v.c_str() || *end) return false;
+            if (a == "--num_threads") { o.num_threads = (int)x; have[2] = true; }
+            else if (a == "--num_shards") { o.num_shards = (int)x; have[4] = true; }
+            else if (a == "--shard_idx") { o.shard_idx = (int)x; have[5] = true; }
+            else if (a == "--start_shard") o.start_shard = (int)x;
+            else o.end_shard = (int)x;
+        } else {
+            return false;
+        }
+    }
+    for (bool h : have)
+        if (!h) return false;
+    return true;
+}
+
+struct Gpu {
+    mvs_ctx* ctx = nullptr;
+    mvs_sketch_set* set = nullptr;
+    ~Gpu() {
+        if (set) mvs_sketch_set_destroy(set);
+        if (ctx) mvs_ctx_destroy(ctx);
+    }
+};
+
+static int gpu_fail(const char* what) {
+    std::cerr << "pairwise_comp_optimized: " << what << ": " << mvs_last_error() << std::endl;
+    return 2;
+}
+
+// stream vectors.bin through the device in row chunks: pass 1 finds the limb count, pass 2 re-codes
+static int load_db(Gpu& g, const std::string& matrix_file, int elem_bytes, int64_t n, int d) {
+    const int64_t row_bytes = (int64_t)d * elem_bytes;
+    const int64_t chunk_rows = std::max<int64_t>(1, (1LL << 30) / row_bytes);
+    std::vector<char> buf((size_t)(std::min(chunk_rows, std::max<int64_t>(n, 1)) * row_bytes));
+    int64_t max_abs = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+        std::ifstream file(matrix_file, std::ios::binary);
+        if (!file) {
+            std::cerr << "Error opening file: " << matrix_file << std::endl;   // :35-38
+            return 1;
+        }
+        if (pass == 1 && mvs_sketch_set_alloc(g.ctx, n, d, mvs_limbs_for_max_abs(max_abs), &g.set) != MVS_OK)
+            return gpu_fail("allocating sketch set");
+        for (int64_t r0 = 0; r0 < n; r0 += chunk_rows) {
+            const int64_t rows = std::min(chunk_rows, n - r0);
+            file.read(buf.data(), (std::streamsize)(rows * row_bytes));
+            if (!file) {
+                std::cerr << "Error reading file: " << matrix_file << std::endl;
+                return 1;
+            }
+            if (pass == 0) {
+                int64_t m = 0;
+                if (mvs_sketch_max_abs(g.ctx, buf.data(), elem_bytes, MVS_MEM_HOST, rows * d, &m) != MVS_OK)
+                    return gpu_fail("scanning vectors.bin");
+                max_abs = std::max(max_abs, m);
+            } else if (mvs_sketch_set_fill(g.set, buf.data(), elem_bytes, MVS_MEM_HOST, r0, rows) != MVS_OK) {
+                return gpu_fail("re-coding vectors.bin");
+            }
+        }
+    }
+    return 0;
+}
+
+// rows [b, e) against all columns; halves the range when the staging buffer is too small
+static int compare_rows(Gpu& g, const std::vector<double>& n2, int keep_mode, int64_t b, int64_t e,
+                        std::vector<mvs_cell>& staging, std::vector<mvs_cell>& all) {
+    if (b >= e) return 0;
+    int64_t cnt = 0;
+    const int rc = mvs_pairwise_rows(g.ctx, g.set, n2.data(), MVS_MEM_HOST, keep_mode, b, e, staging.data(),
+                                     (int64_t)staging.size(), MVS_MEM_HOST, &cnt);
+    if (rc == MVS_E_CAPACITY) {
+        if (e - b == 1) {
+            staging.resize((size_t)cnt);
+            return compare_rows(g, n2, keep_mode, b, e, staging, all);
+        }
+        const int64_t mid = b + (e - b) / 2;
+        int r = compare_rows(g, n2, keep_mode, b, mid, staging, all);
+        return r ? r : compare_rows(g, n2, keep_mode, mid, e, staging, all);
+    }
+    if (rc != MVS_OK) return gpu_fail("pairwise comparison");
+    all.insert(all.end(), staging.begin(), staging.begin() + cnt);
+    return 0;
+}
+
+int main(int argc, char* argv[]) {
+    Options o;
+    if (!parse(argc, argv, o) || o.show_help) {                                   // :846-850
+        print_usage(argv[0]);
+        return o.show_help ? 0 : 1;
+    }
+    std::string db_folder = o.db_folder, output_folder = o.output_folder;
+    std::string dtype = "int32";
+    const std::string dtype_file = db_folder + "dtype.txt";                       // :853 raw concatenation
+    std::string norms_file = db_folder + "vector_norms.txt";
+    if (!fs::exists(norms_file)) {                                                // :855-858
+        std::cerr << "Error: Required file 'vector_norms.txt' not found in output folder: " << db_folder << std::endl;
+        return 1;
+    }
+    {
+        std::ifstream dtype_in(dtype_file);                                       // :859-865
+        if (dtype_in) std::getline(dtype_in, dtype);
+    }
+    int dimension = 0;
+    {
+        std::ifstream dim_in(db_folder + "dimension.txt");                        // :866-873
+        if (dim_in) dim_in >> dimension;
+    }
+    std::cout << "dtypeqs: " << dtype << std::endl;                               // :874
+    const bool int16 = dtype == "int16";
+    if (int16) std::cout << "dtyeom" << std::endl;                                // :877
+    if (dimension <= 0) {
+        std::cerr << "Error: could not read a positive dimension from " << db_folder << "dimension.txt" << std::endl;
+        return 1;
+    }
+    if (!output_folder.empty() && output_folder.back() != '/' && output_folder.back() != '\\') output_folder += '/';
+    if (int16) {
+        // _16bits.cpp:334 reads the norms from the OUTPUT folder; fall back to the DB folder, where
+        // sketch() actually writes them
+        const std::string alt = output_folder + "vector_norms.txt";
+        if (fs::exists(alt)) norms_file = alt;
+    }
+    const std::string matrix_file = db_folder + "vectors.bin";                    // :891
+    DbInfo db;
+    read_norms(norms_file, db);                                                   // :893-901
+    const int elem_bytes = int16 ? 2 : 4;
+    const int64_t bytes_per_vector = (int64_t)dimension * elem_bytes;
+    if (!int16) {
+        const int64_t max_bytes = (int64_t)(o.max_memory_gb * 1024 * 1024 * 1024);   // :904-908
+        std::cout << "max bytes " << max_bytes << " " << o.max_memory_gb << std::endl;
+        std::cout << "Using chunks of size " << mvs_chunk_size(o.max_memory_gb, dimension) << std::endl;
+    }
+    int64_t file_size = 0;
+    {
+        std::ifstream file(matrix_file, std::ios::ate | std::ios::binary);        // :911-914
+        file_size = file ? (int64_t)file.tellg() : 0;
+    }
+    const int64_t total_vectors = file_size / bytes_per_vector;
+    std::cout << "Total vectors: " << total_vectors << std::endl;                 // :916
+    if ((int64_t)db.norms_sq.size() < total_vectors) {
+        std::cerr << "Error: vector_norms.txt has " << db.norms_sq.size() << " entries for " << total_vectors
+                  << " vectors" << std::endl;
+        return 1;
+    }
+    auto start_time = std::chrono::high_resolution_clock::now();                  // :918
+
+    const std::string shard_folder = output_folder + "shard_" + std::to_string(o.shard_idx) + "/";   // :932-935
+    if (!fs::exists(shard_folder)) fs::create_directories(shard_folder);
+    int64_t begin_row = 0, end_row = 0;
+    mvs_shard_rows(total_vectors, o.num_shards, o.shard_idx, &begin_row, &end_row);                   // :938-940
+    std::cout << "Shard " << o.shard_idx << " processing rows " << begin_row << " to " << end_row << std::endl;
+
+    Gpu g;
+    int device = 0, ndev = 0;
+    if (getenv("MVS_DEVICE")) device = pick_device();
+    else if (mvs_device_count(&ndev) == MVS_OK && ndev > 0) device = o.shard_idx % ndev;
+    if (mvs_ctx_create(device, &g.ctx) != MVS_OK) return gpu_fail("creating context");
+    int rc = load_db(g, matrix_file, elem_bytes, total_vectors, dimension);
+    if (rc) return rc;
+
+    // kept-cell staging: --max_memory_gb bounds it (16 bytes per cell), at least 1M cells
+    double budget = o.max_memory_gb > 0 ? o.max_memory_gb : 1.0;
+    size_t cap = (size_t)std::min<double>(budget * 1024.0 * 1024.0 * 1024.0 / 16.0 / 4.0, 256e6);
+    cap = std::max<size_t>(cap, 1u << 20);
+    std::vector<mvs_cell> staging(cap), all_results;
+    db.norms_sq.resize((size_t)total_vectors);
+    rc = compare_rows(g, db.norms_sq, int16 ? MVS_KEEP_INT16 : MVS_KEEP_INT32, begin_row, end_row, staging,
+                      all_results);
+    if (rc) return rc;
+    if (int16) {                                                                  // _16bits.cpp:419-423
+        auto end_time = std::chrono::high_resolution_clock::now();
+        auto duration = std::chrono::duration_cast<std::chrono::milliseconds>(end_time - start_time);
+        std::cout << "Total computation time: " << duration.count() << " ms" << std::endl;
+        std::cout << "Total results: " << all_results.size() << std::endl;
+    }
+    const ShardStats st = write_shard(shard_folder, all_results.data(), all_results.size());          // :990
+    std::cout << "Jac space: " << st.jac_space << " ngh space: " << st.ngh_space << std::endl;        // :808
+    if (!int16) {                                                                 // :993-996
+        auto end_time = std::chrono::high_resolution_clock::now();
+        auto duration = std::chrono::duration_cast<std::chrono::milliseconds>(end_time - start_time);
+        std::cout << "Total computation time: " << duration.count() << " ms" << std::endl;
+    }
+    return 0;
+}

@@ -1,0 +1,164 @@
+// project_everything -- drop-in for the reference executable of the same name
+// (src/project_everything.cpp).  `sketch` runs the projection on the MI355X through libmvs_hip.so;
+// the command line, stdout lines and the four DB files are the reference's.
+//
+//   project_everything sketch  <hash_file> <index_folder> [-t/--threads N] [-d/--dimension D] [--int16]
+//   project_everything convert <signature_folder> <hash_file> [-t/--threads N]      (not in this build)
+#include <chrono>
+
+#include "mvs_host.hpp"
+
+namespace fs = std::filesystem;
+using namespace mvs_host;
+
+static void usage(const char* argv0) {   // src/project_everything.cpp:394-407, verbatim layout
+    std::cerr << "Usage:\n";
+    std::cerr << "  Convert mode:\n";
+    std::cerr << "    " << argv0 << " convert <signature_folder> <hash_file> [-t threads]\n";
+    std::cerr << "      signature_folder : Path to folder containing signature files\n";
+    std::cerr << "      hash_file        : Output hash file path\n";
+    std::cerr << "      -t, --threads    : Number of threads (default: 1)\n\n";
+    std::cerr << "  Sketch mode:\n";
+    std::cerr << "    " << argv0 << " sketch <hash_file> <index_folder> [-t threads] [-d dimension] [--int16]\n";
+    std::cerr << "      hash_file        : Input hash file path\n";
+    std::cerr << "      index_folder     : Output folder for index files\n";
+    std::cerr << "      -t, --threads    : Number of threads (default: 1)\n";
+    std::cerr << "      -d, --dimension  : Vector dimension (default: 2048)\n";
+    std::cerr << "      --int16          : Use int16 instead of int32 for vector storage\n";
+}
+
+static bool parse_int(const char* s, int& out) {
+    char* end = nullptr;
+    const long v = strtol(s, &end, 10);
+    if (end == s || *end != '\0') return false;
+    out = (int)v;
+    return true;
+}
+
+// src/project_everything.cpp:238-362
+static int sketch(const std::string& hash_file, std::string index_folder, int dimension, bool use_int16) {
+    if (index_folder.empty() || index_folder[index_folder.size() - 1] != '/') index_folder += '/';   // :239-241
+    if (fs::exists(index_folder)) {                                                                    // :244-252
+        for (const auto& entry : fs::directory_iterator(index_folder)) fs::remove_all(entry.path());
+    } else {
+        fs::create_directories(index_folder);
+    }
+    auto start = std::chrono::high_resolution_clock::now();                                            // :255
+
+    HashSets sets;
+    if (!read_hash_file(hash_file, true, sets)) {                                                      // :258-262
+        std::cerr << "Error opening " << hash_file << " for reading." << std::endl;
+        return 0;   // the reference returns from sketch() and exits 0
+    }
+    const int64_t n = (int64_t)sets.names.size();
+    std::cout << "Loaded " << n << " hash sets from " << hash_file << std::endl;                       // :284
+
+    mvs_ctx* ctx = nullptr;
+    if (mvs_ctx_create(pick_device(), &ctx) != MVS_OK) {
+        std::cerr << "project_everything: " << mvs_last_error() << std::endl;
+        return 2;
+    }
+    std::vector<int32_t> vectors((size_t)n * (size_t)dimension);
+    std::vector<int64_t> sumsq((size_t)n);
+    // batches bound the device footprint (hash lists of ~1M-hash samples x thousands of samples)
+    const int64_t kMaxBatchHashes = 1LL << 28;   // 2 GiB of hashes per launch
+    for (int64_t s0 = 0; s0 < n;) {
+        int64_t s1 = s0 + 1;
+        while (s1 < n && sets.offsets[s1 + 1] - sets.offsets[s0] <= kMaxBatchHashes) ++s1;
+        std::vector<int64_t> offs((size_t)(s1 - s0 + 1));
+        for (int64_t s = s0; s <= s1; ++s) offs[(size_t)(s - s0)] = sets.offsets[s] - sets.offsets[s0];
+        int rc = mvs_project_csr(ctx, sets.hashes.data() + sets.offsets[s0], MVS_MEM_HOST, offs.data(), s1 - s0,
+                                 dimension, vectors.data() + (size_t)s0 * dimension, MVS_MEM_HOST);
+        if (rc == MVS_OK)
+            rc = mvs_sketch_sumsq(ctx, vectors.data() + (size_t)s0 * dimension, MVS_MEM_HOST, s1 - s0, dimension,
+                                  sumsq.data() + s0, MVS_MEM_HOST);
+        if (rc != MVS_OK) {
+            std::cerr << "project_everything: " << mvs_last_error() << std::endl;
+            mvs_ctx_destroy(ctx);
+            return 2;
+        }
+        s0 = s1;
+    }
+    for (int64_t i = 0; i < n; ++i)                                                                    // :294-297
+        std::cout << "Projected " << sets.names[(size_t)i] << ", vector dimension " << dimension << ", index " << i
+                  << "\n";
+    std::cout.flush();
+
+    auto end = std::chrono::high_resolution_clock::now();                                              // :301-303
+    std::chrono::duration<double> elapsed = end - start;
+    std::cout << "Time to compute all projected vectors: " << elapsed.count() << " seconds" << std::endl;
+
+    std::ofstream norm_out(index_folder + "vector_norms.txt");                                         // :306-309
+    std::ofstream dim_out(index_folder + "dimension.txt");
+    std::ofstream dtype_out(index_folder + "dtype.txt");
+    std::ofstream bin_out(index_folder + "vectors.bin", std::ios::binary);
+    if (!norm_out) std::cerr << "Error opening vector_norms.txt for writing." << std::endl;
+    if (!bin_out) std::cerr << "Error opening vectors.bin for writing." << std::endl;
+    int status = 0;
+    if (norm_out && bin_out && dim_out && dtype_out) {
+        dim_out << dimension << "\n";                                                                  // :319
+        dtype_out << (use_int16 ? "int16" : "int32") << "\n";                                          // :320
+        for (int64_t i = 0; i < n; ++i)                                                                // :328-330
+            norm_out << sets.names[(size_t)i] << " " << format_g(norm_from_sumsq(sumsq[(size_t)i], dimension)) << "\n";
+        if (use_int16) {                                                                               // :332-347
+            std::vector<int16_t> v16(vectors.size());
+            if (mvs_sketch_saturate_i16(ctx, vectors.data(), MVS_MEM_HOST, (int64_t)vectors.size(), v16.data(),
+                                        MVS_MEM_HOST) != MVS_OK) {
+                std::cerr << "project_everything: " << mvs_last_error() << std::endl;
+                status = 2;
+            } else {
+                bin_out.write(reinterpret_cast<const char*>(v16.data()), (std::streamsize)(v16.size() * 2));
+            }
+        } else {                                                                                       // :348-354
+            bin_out.write(reinterpret_cast<const char*>(vectors.data()), (std::streamsize)(vectors.size() * 4));
+        }
+    }
+    mvs_ctx_destroy(ctx);
+    return status;
+}
+
+int main(int argc, char* argv[]) {
+    bool is_convert = false, is_sketch = false, use_int16 = false, ok = argc >= 2;
+    std::string input_path, output_path;
+    int t = 1, d = 2048;
+    if (ok) {
+        const std::string cmd = argv[1];
+        is_convert = cmd == "convert";
+        is_sketch = cmd == "sketch";
+        ok = is_convert || is_sketch;
+    }
+    int positional = 0;
+    for (int i = 2; ok && i < argc; ++i) {
+        const std::string a = argv[i];
+        if (a == "-t" || a == "--threads") {
+            ok = i + 1 < argc && parse_int(argv[++i], t);
+        } else if (is_sketch && (a == "-d" || a == "--dimension")) {
+            ok = i + 1 < argc && parse_int(argv[++i], d);
+        } else if (is_sketch && a == "--int16") {
+            use_int16 = true;
+        } else if (positional == 0) {
+            input_path = a;
+            ++positional;
+        } else if (positional == 1) {
+            output_path = a;
+            ++positional;
+        } else {
+            ok = false;
+        }
+    }
+    if (!ok || positional != 2) {   // src/project_everything.cpp:393-408
+        usage(argv[0]);
+        return 1;
+    }
+    (void)t;   // the reference parses -t for sketch but never applies it (:384 vs :238)
+    if (is_convert) {
+        std::cerr << "convert: signature ingest is not part of this build (hot-path scope, DESIGN.md); "
+                     "use the reference's convert to produce the hash file" << std::endl;
+        return 3;
+    }
+    if (d <= 0) {
+        std::cerr << "dimension must be positive" << std::endl;
+        return 1;
+    }
+    return sketch(input_path, output_path, d, use_int16);
+}

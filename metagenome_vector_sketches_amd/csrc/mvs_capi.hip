@@ -504,6 +504,46 @@ int mvs_sketch_set_from_planes(mvs_ctx* c, const int8_t* planes, int64_t n, int6
     return MVS_OK;
 }
 
+int mvs_sketch_set_alloc(mvs_ctx* c, int64_t n, int d, int limbs, mvs_sketch_set** out) {
+    if (!c || !out) return fail(MVS_E_INVALID, "NULL argument");
+    *out = nullptr;
+    if (n < 0 || d <= 0 || limbs < 1 || limbs > mvs::kMaxLimbs) return fail(MVS_E_INVALID, "bad argument");
+    if (n >= (1LL << 31) - 256) return fail(MVS_E_RANGE, "n too large for int32 row/col indices");
+    HIP_TRY(hipSetDevice(c->device));
+    int64_t n_alloc = 0;
+    int d_pad = 0;
+    size_t bytes = 0;
+    mvs_limb_geometry(n, d, limbs, &n_alloc, &d_pad, &bytes);
+    mvs_sketch_set* s = new (std::nothrow) mvs_sketch_set();
+    if (!s) return fail(MVS_E_NOMEM, "out of host memory");
+    if (hipMalloc((void**)&s->owned, bytes) != hipSuccess) {
+        delete s;
+        return fail(MVS_E_NOMEM, "hipMalloc of %zu bytes of limb planes failed", bytes);
+    }
+    s->ctx = c;
+    s->planes = s->owned;
+    s->n = n;
+    s->n_alloc = n_alloc;
+    s->d = d;
+    s->d_pad = d_pad;
+    s->limbs = limbs;
+    if (hipMemsetAsync(s->owned, 0, bytes, c->stream) != hipSuccess) {
+        mvs_sketch_set_destroy(s);
+        return fail(MVS_E_HIP, "hipMemsetAsync failed");
+    }
+    *out = s;
+    return MVS_OK;
+}
+
+int mvs_sketch_set_fill(mvs_sketch_set* s, const void* sketches, int elem_bytes, int mem, int64_t row_offset,
+                        int64_t n_rows) {
+    if (!s || !s->owned) return fail(MVS_E_INVALID, "set is NULL or not owned by the library");
+    if (row_offset < 0 || n_rows < 0 || row_offset + n_rows > s->n)
+        return fail(MVS_E_INVALID, "rows [%lld,%lld) outside the set", (long long)row_offset,
+                    (long long)(row_offset + n_rows));
+    return mvs_limb_split(s->ctx, sketches, elem_bytes, mem, n_rows, s->d, s->limbs, s->owned, s->d_pad, row_offset);
+}
+
 int mvs_sketch_set_info(const mvs_sketch_set* s, int64_t* n, int* d, int* limbs, int64_t* n_alloc, int* d_pad) {
     if (!s) return fail(MVS_E_INVALID, "set is NULL");
     if (n) *n = s->n;

@@ -1,0 +1,61 @@
+"""CPU: command-line contracts of the drop-in executables (usage / exit codes as the reference's
+clipp parsers give them) and the codec round trips.  No device needed."""
+import os
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "metagenome_vector_sketches_amd", "bin")
+
+
+def run(*args):
+    return subprocess.run(list(args), capture_output=True, text=True)
+
+
+def test_codec_and_text_parsing_selftest(tmp_path):
+    r = run(os.path.join(BIN, "mvs_codec_selftest"), str(tmp_path) + "/")
+    assert r.returncode == 0, r.stderr
+    assert "ok" in r.stdout
+
+
+def test_project_everything_usage_errors():
+    exe = os.path.join(BIN, "project_everything")
+    for args in ([], ["sketch"], ["sketch", "a"], ["frobnicate", "a", "b"], ["sketch", "a", "b", "-d"],
+                 ["sketch", "a", "b", "--dimension", "x"], ["sketch", "a", "b", "c"],
+                 # the README's stale spelling is rejected by the real parser too
+                 ["toy", "toy_db/", "-t", "8", "-d", "2048", "-s", "0"]):
+        r = run(exe, *args)
+        assert r.returncode == 1, args
+        assert r.stderr.startswith("Usage:\n  Convert mode:\n") and "Sketch mode:" in r.stderr
+        assert r.stdout == ""
+
+
+def test_pairwise_usage_errors():
+    exe = os.path.join(BIN, "pairwise_comp_optimized")
+    r = run(exe, "--help")
+    assert r.returncode == 0 and r.stdout.startswith("Usage:")
+    full = ["--db", "x/", "--max_memory_gb", "12", "--num_threads", "8", "--output_folder", "o", "--num_shards", "1",
+            "--shard_idx", "0"]
+    for i in range(0, len(full), 2):          # every one of the six flags is required
+        r = run(exe, *(full[:i] + full[i + 2:]))
+        assert r.returncode == 1 and r.stdout.startswith("Usage:"), full[i]
+    r = run(exe, *(full[:3] + ["abc"] + full[4:]))
+    assert r.returncode == 1
+    # README spelling (--dimension/--strategy) is rejected
+    r = run(exe, *full, "--dimension", "2048")
+    assert r.returncode == 1
+
+
+def test_pairwise_missing_db(tmp_path):
+    exe = os.path.join(BIN, "pairwise_comp_optimized")
+    r = run(exe, "--db", str(tmp_path) + "/nodb/", "--max_memory_gb", "12", "--num_threads", "8", "--output_folder",
+            str(tmp_path) + "/out", "--num_shards", "1", "--shard_idx", "0")
+    assert r.returncode == 1
+    assert "Required file 'vector_norms.txt' not found" in r.stderr
+
+
+def test_standalone_projection_usage():
+    exe = os.path.join(BIN, "standalone_projection")
+    r = run(exe)
+    assert r.returncode == 1 and r.stderr.startswith("Usage: ")
+    r = run(exe, "/nonexistent/file", "8")
+    assert r.returncode == 1 and "Error opening file: /nonexistent/file" in r.stderr
