@@ -101,40 +101,18 @@ def main():
     cells = torch.empty((cap, 4), dtype=torch.int32, device=dev)
     torch.cuda.synchronize()
 
+    from metagenome_vector_sketches_amd import parallel
+    sc = parallel.ShardedComparison(parallel.GpuOps(ctx, dev), rank, world, dist if world > 1 else None)
     state = {}
 
     def step():
         ctx.project_csr(hashes, offsets, D, out=sketches)                 # K1
         ctx.sumsq(sketches, out=sumsq)
         n2_local = fast_norm_sq(sumsq.cpu().numpy(), D)                    # text round trip of the norms
-        max_abs = ctx.max_abs(sketches)
-        if world > 1:
-            t = torch.tensor([max_abs], dtype=torch.int64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            max_abs = int(t.item())
-        limbs = pkg._capi.limbs_for_max_abs(max_abs)
-        n_alloc, d_pad, nbytes = ctx.limb_geometry(N_total, D, limbs)
-        key = (limbs, n_alloc, d_pad)
-        if state.get("key") != key:
-            state["planes"] = torch.zeros(nbytes, dtype=torch.int8, device=dev)
-            state["key"] = key
-        planes = state["planes"]
-        ctx.limb_split(sketches, limbs, planes, d_pad, row_offset=rank * S)
-        if world > 1:
-            blk = S * limbs * d_pad
-            body = planes[:world * blk]
-            dist.all_gather_into_tensor(body, planes[rank * blk:(rank + 1) * blk].clone())
-            n2_all = torch.empty(N_total, dtype=torch.float64, device=dev)
-            dist.all_gather_into_tensor(n2_all, torch.from_numpy(n2_local).to(dev))
-            torch.cuda.current_stream().synchronize()
-            n2 = n2_all
-        else:
-            n2 = torch.from_numpy(n2_local).to(dev)
-        sset = ctx.sketch_set_from_planes(planes, N_total, n_alloc, D, d_pad, limbs)
-        _, cnt = ctx.pairwise_rows(sset, n2, row_begin=rank * S, row_end=(rank + 1) * S, cells_out=cells)   # K2
-        sset.close()
+        # limb split, [all-gather of plane row blocks + norms], K2 on this rank's rows x all columns
+        _, cnt, info = sc.run(sketches, n2_local, N_total, cells_out=cells)
         state["cnt"] = cnt
-        state["limbs"] = limbs
+        state["limbs"] = info["limbs"]
 
     def sync_all():
         if world > 1:

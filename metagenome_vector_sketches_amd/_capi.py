@@ -5,6 +5,7 @@ Python or CPU fallback for the hot path.
 """
 import ctypes
 import os
+import weakref
 
 import numpy as np
 
@@ -116,6 +117,7 @@ class SketchSet:
 
     def __init__(self, ctx, handle, keep=None):
         self.ctx, self._h, self._keep = ctx, handle, keep
+        ctx._sets.add(self)
         n, d, limbs, n_alloc, d_pad = (_c.c_int64(), _c.c_int(), _c.c_int(), _c.c_int64(), _c.c_int())
         _check(ctx.lib.mvs_sketch_set_info(handle, n, d, limbs, n_alloc, d_pad))
         self.n, self.d, self.limbs, self.n_alloc, self.d_pad = n.value, d.value, limbs.value, n_alloc.value, d_pad.value
@@ -141,11 +143,14 @@ class Context:
         _check(self.lib.mvs_ctx_create(int(device), ctypes.byref(h)))
         self._h = h
         self.device = device
+        self._sets = weakref.WeakSet()   # sketch sets hold a pointer to the context: close them first
         if stream is not None:
             self.set_stream(stream)
 
     def close(self):
         if getattr(self, "_h", None):
+            for s in list(self._sets):
+                s.close()
             self.lib.mvs_ctx_destroy(self._h)
             self._h = None
 

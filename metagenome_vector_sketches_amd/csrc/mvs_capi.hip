@@ -617,6 +617,10 @@ int mvs_pairwise_rows(mvs_ctx* c, const mvs_sketch_set* s, const double* norms_s
     a.capacity = (unsigned long long)capacity;
     a.counter = c->d_counter;
     a.dots = nullptr;
+    {
+        const char* dbg = getenv("MVS_PAIRWISE_DEBUG");
+        a.debug_flags = dbg ? atoi(dbg) : 0;
+    }
     if (c->timing) HIP_TRY(hipEventRecord(c->ev[2], c->stream));
     rc = mvs::launch_pairwise(c->stream, a, 0, 0);
     if (rc) return fail(rc, "pairwise launch rejected");

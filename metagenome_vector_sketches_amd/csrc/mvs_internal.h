@@ -42,6 +42,7 @@ struct PairwiseArgs {
     unsigned long long* counter;  // number of kept cells (may exceed capacity)
     // dense outputs (dots mode)
     int32_t* dots;                // (row_end-row_begin) x (col_end-col_begin)
+    int debug_flags;              // profiling ablations (MVS_PAIRWISE_DEBUG): 1 skip k-loop, 2 skip epilogue
 };
 
 int launch_project(hipStream_t stream, const uint64_t* d_hashes, const ProjUnit* d_units, int64_t n_units,

@@ -35,8 +35,6 @@ using v16i = __attribute__((ext_vector_type(16))) int;
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
-constexpr int kWaves = 8;
-constexpr int kThreads = kWaves * 64;
 
 __host__ __device__ constexpr int num_acc_sets(int L) { return L == 1 ? 1 : (L == 2 ? 3 : 4); }
 
@@ -101,18 +99,41 @@ __device__ __forceinline__ void emit_cell(const PairwiseArgs& a, bool keep, int3
 }
 
 // ---------------------------------------------------------------------------------------------------
-// MFMA kernel.  L = limbs (1 or 2).  MODE 0: comparison, 1: dense dots.
-// LDS: 2 stages x [A region | B region], region = [L][128 samples][128 B].
+// MFMA kernel.  L = limbs (1 or 2).  MODE 0: comparison, 1: dense dots.  NST = LDS ring depth.
+// LDS: NST stages x [A region | B region], region = [L][128 samples][64 B] (one 64-byte k-slice).
+// The ring keeps NST-1 slices in flight: the kernel is bound by the latency of the HBM/L2 -> LDS
+// copies (about 1-2 us under load), so what matters is the number of bytes in flight per CU.
 // ---------------------------------------------------------------------------------------------------
-template <int L, int MODE>
-__global__ __launch_bounds__(kThreads, 2) void k_pairwise_mfma(const PairwiseArgs a, int n_tr, int n_tc,
-                                                               int n_spc) {
+constexpr int kSK = 64;   // bytes (= int8 k values) per ring stage
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    static_assert(N >= 0 && N <= 24, "unsupported vmcnt");
+#define MVS_VMCNT_CASE(n) else if constexpr (N == n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory");
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    MVS_VMCNT_CASE(1) MVS_VMCNT_CASE(2) MVS_VMCNT_CASE(3) MVS_VMCNT_CASE(4) MVS_VMCNT_CASE(5) MVS_VMCNT_CASE(6)
+    MVS_VMCNT_CASE(7) MVS_VMCNT_CASE(8) MVS_VMCNT_CASE(9) MVS_VMCNT_CASE(10) MVS_VMCNT_CASE(11) MVS_VMCNT_CASE(12)
+    MVS_VMCNT_CASE(13) MVS_VMCNT_CASE(14) MVS_VMCNT_CASE(15) MVS_VMCNT_CASE(16) MVS_VMCNT_CASE(17) MVS_VMCNT_CASE(18)
+    MVS_VMCNT_CASE(19) MVS_VMCNT_CASE(20) MVS_VMCNT_CASE(21) MVS_VMCNT_CASE(22) MVS_VMCNT_CASE(23) MVS_VMCNT_CASE(24)
+#undef MVS_VMCNT_CASE
+}
+
+// WN = waves along the column axis: 4 -> 8 waves, tile 128 x 128 samples (one workgroup per CU);
+//                                    2 -> 4 waves, tile 128 x 64 samples (two workgroups per CU, so
+//                                         one's barrier/copy waits overlap the other's MFMAs).
+template <int L, int MODE, int NST, int WN>
+__global__ __launch_bounds__(2 * WN * 64, 2) void k_pairwise_mfma(const PairwiseArgs a, int n_tr, int n_tc,
+                                                                  int n_spc) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int kRegion = L * kTile * kBK;     // bytes of one operand region
-    constexpr int kStage = 2 * kRegion;          // bytes of one stage
+    constexpr int kWavesT = 2 * WN;
+    constexpr int TN = WN * 32;                  // columns (B samples) per tile
+    constexpr int kRegion = L * kTile * kSK;     // bytes of the A operand region (128 samples)
+    constexpr int kRegionB = L * TN * kSK;       // bytes of the B operand region (TN samples)
+    constexpr int kStage = kRegion + kRegionB;   // bytes of one stage
     constexpr int kPieces = kStage / 1024;       // 1 KiB pieces per stage
-    constexpr int kPPW = kPieces / kWaves;       // pieces per wave per stage
+    constexpr int kPPW = kPieces / kWavesT;      // pieces per wave per stage
     constexpr int NS = num_acc_sets(L);
+    static_assert(kPieces % kWavesT == 0, "stage must split evenly over the waves");
 
     const TileCoord tc = map_tile(blockIdx.x, n_tr, n_tc, n_spc);
     if (!tc.valid) return;
@@ -120,32 +141,32 @@ __global__ __launch_bounds__(kThreads, 2) void k_pairwise_mfma(const PairwiseArg
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2;   // 0..1 : 64-row half of the tile
-    const int wn = wave & 3;    // 0..3 : 32-col quarter of the tile
+    const int wm = wave / WN;   // 0..1 : 64-row half of the tile
+    const int wn = wave % WN;   // 32-col slice of the tile
 
     const int64_t i0 = a.row_begin + (int64_t)tc.tr * kTile;   // first A sample of the tile
-    const int64_t j0 = a.col_begin + (int64_t)tc.tc * kTile;   // first B sample of the tile
+    const int64_t j0 = a.col_begin + (int64_t)tc.tc * TN;      // first B sample of the tile
 
-    // ---- per-lane source pointers of this wave's pieces (k0 = 0) ----
+    // ---- per-lane source pointers of this wave's pieces (k0 = 0).  One piece = 16 LDS rows of 64 B;
+    //      lane -> row piece*16 + lane/4, 16-byte slot lane%4 holding logical chunk slot ^ ((s>>2)&3).
     const int8_t* src[kPPW];
 #pragma unroll
     for (int p = 0; p < kPPW; ++p) {
         const int piece = wave * kPPW + p;
-        const int row = piece * 8 + (lane >> 3);          // 128-byte LDS row inside the stage
-        const int region = row / (L * kTile);
-        const int rr = row % (L * kTile);
-        const int limb = rr / kTile;
-        const int s = rr % kTile;
-        const int c = (lane & 7) ^ ((s >> 1) & 7);        // logical 16-byte chunk stored at slot lane&7
-        const int64_t sample = (region == 0 ? i0 : j0) + s;
+        const int row = piece * 16 + (lane >> 2);
+        const bool is_b = row >= L * kTile;
+        const int rr = is_b ? row - L * kTile : row;
+        const int limb = is_b ? rr / TN : rr / kTile;
+        const int s = is_b ? rr % TN : rr % kTile;
+        const int c = (lane & 3) ^ ((s >> 2) & 3);
+        const int64_t sample = (is_b ? j0 : i0) + s;
         src[p] = a.planes + (sample * L + limb) * (int64_t)a.d_pad + c * 16;
     }
-
-    auto stage_copy = [&](int stage, int k0) {
+    auto stage_copy = [&](int slot, int k0) {
 #pragma unroll
         for (int p = 0; p < kPPW; ++p) {
             const int piece = wave * kPPW + p;
-            char* dst = smem + stage * kStage + piece * 1024;   // wave-uniform; lane data lands at +lane*16
+            char* dst = smem + slot * kStage + piece * 1024;   // wave-uniform; lane data lands at +lane*16
             __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src[p] + k0), (lds_ptr_t)dst, 16, 0, 0);
         }
     };
@@ -153,9 +174,9 @@ __global__ __launch_bounds__(kThreads, 2) void k_pairwise_mfma(const PairwiseArg
     // ---- fragment addressing ----
     const int fr = lane & 31;          // row (A) / col (B) inside a 32x32 MFMA tile
     const int fh = lane >> 5;          // k half
-    const int key = (fr >> 1) & 7;     // swizzle key (tile bases are multiples of 16 samples)
-    const int a_row0 = (wm * 64 + fr) * kBK;                   // + t*32*kBK + limb*kTile*kBK
-    const int b_row0 = kRegion + (wn * 32 + fr) * kBK;         // + limb*kTile*kBK
+    const int key = (fr >> 2) & 3;     // swizzle key (tile bases are multiples of 16 samples)
+    const int a_row0 = (wm * 64 + fr) * kSK;                   // + t*32*kSK + limb*kTile*kSK
+    const int b_row0 = kRegion + (wn * 32 + fr) * kSK;         // + limb*kTile*kSK
 
     v16i acc[2][NS];
 #pragma unroll
@@ -165,44 +186,93 @@ __global__ __launch_bounds__(kThreads, 2) void k_pairwise_mfma(const PairwiseArg
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][s][r] = 0;
 
-    const int nk = a.d_pad / kBK;
-    stage_copy(0, 0);
-    __syncthreads();   // drains the LDS-DMA (vmcnt(0)) and publishes stage 0
-
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) stage_copy(cur ^ 1, (kt + 1) * kBK);   // in flight during the MFMAs below
-        const char* sb = smem + cur * kStage;
+    // Fragments are double buffered in registers: the ds_reads of k-step kk+1 are issued before the
+    // MFMAs of k-step kk, so the matrix pipe never waits for LDS.
+    v4i fa[2][2][L], fb[2][L];
+    auto load_frags = [&](int buf, const char* sb, int kk) {
+        const int coff = (((kk * 2 + fh) ^ key) << 4);
 #pragma unroll
-        for (int kk = 0; kk < kBK / 32; ++kk) {
-            const int coff = (((kk * 2 + fh) ^ key) << 4);
-            v4i fa[2][L], fb[L];
-#pragma unroll
-            for (int l = 0; l < L; ++l) {
-                fb[l] = *reinterpret_cast<const v4i*>(sb + b_row0 + l * kTile * kBK + coff);
-#pragma unroll
-                for (int t = 0; t < 2; ++t)
-                    fa[t][l] = *reinterpret_cast<const v4i*>(sb + a_row0 + t * 32 * kBK + l * kTile * kBK + coff);
-            }
+        for (int l = 0; l < L; ++l) {
+            fb[buf][l] = *reinterpret_cast<const v4i*>(sb + b_row0 + l * TN * kSK + coff);
 #pragma unroll
             for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int la = 0; la < L; ++la)
-#pragma unroll
-                    for (int lb = 0; lb < L; ++lb) {
-                        if (la + lb > 3) continue;   // 256^4 == 0 (mod 2^32)
-                        acc[t][la + lb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[t][la], fb[lb], acc[t][la + lb], 0, 0, 0);
-                    }
+                fa[buf][t][l] = *reinterpret_cast<const v4i*>(sb + a_row0 + t * 32 * kSK + l * kTile * kSK + coff);
         }
-        __syncthreads();   // next stage landed (vmcnt(0)) and everyone is done reading `cur`
+    };
+    auto mfma_group = [&](int buf) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int la = 0; la < L; ++la)
+#pragma unroll
+                for (int lb = 0; lb < L; ++lb) {
+                    if (la + lb > 3) continue;   // 256^4 == 0 (mod 2^32)
+                    acc[t][la + lb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[buf][t][la], fb[buf][lb],
+                                                                           acc[t][la + lb], 0, 0, 0);
+                }
+    };
+
+    // ---- main loop over 64-byte k-slices ----
+    // Completion of the LDS-DMA copies is tracked by hand with counted s_waitcnt vmcnt(N) (each wave has
+    // kPPW copies per slice in flight, oldest first) followed by a raw s_barrier; hipcc's own waitcnt
+    // insertion is not relied on for global_load_lds (it was seen to drop the wait, and a plain
+    // __syncthreads() would drain the whole ring).
+    const int nk = (a.debug_flags & 1) ? 0 : a.d_pad / kSK;
+#pragma unroll
+    for (int st = 0; st < NST - 1; ++st)
+        if (st < nk) stage_copy(st, st * kSK);
+    // slice 0 landed <=> at most (slices issued after it) * kPPW copies outstanding
+    if (nk >= NST - 1) wait_vmcnt<(NST - 2) * kPPW>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    load_frags(0, smem, 0);
+
+    int slot = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        const char* sb = smem + slot * kStage;
+        // refill the slot that slice kt-1 used (its readers passed the previous barrier)
+        {
+            const int nslot = slot == 0 ? NST - 1 : slot - 1;
+            if (kt + NST - 1 < nk) stage_copy(nslot, (kt + NST - 1) * kSK);
+        }
+        load_frags(1, sb, 1);
+        __builtin_amdgcn_sched_barrier(0);   // keep the reads of the next k-step ahead of these MFMAs
+        mfma_group(0);
+        __builtin_amdgcn_sched_barrier(0);
+        // slice kt+1 must have landed: allow only the copies of younger slices to be outstanding
+        {
+            const int younger = nk - kt - 2;   // slices issued after kt+1
+            if (younger >= NST - 2) wait_vmcnt<(NST - 2) * kPPW>();
+            else if (NST >= 4 && younger == NST - 3) wait_vmcnt<(NST >= 4 ? (NST - 3) : 0) * kPPW>();
+            else if (NST >= 5 && younger == NST - 4) wait_vmcnt<(NST >= 5 ? (NST - 4) : 0) * kPPW>();
+            else wait_vmcnt<0>();
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's reads of slice kt are done
+        __builtin_amdgcn_s_barrier();
+        slot = slot == NST - 1 ? 0 : slot + 1;
+        load_frags(0, smem + slot * kStage, 0);   // unconditional: after the last slice this reads a stale
+                                                 // (in-bounds) slot and the values are never used
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_group(1);
+        __builtin_amdgcn_sched_barrier(0);
     }
+    __syncthreads();
 
     // ---- epilogue ----
+    if (a.debug_flags & 2) {   // ablation: keep the accumulators alive, skip the epilogue
+        int x = 0;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int sset = 0; sset < NS; ++sset) x ^= acc[t][sset][0] ^ acc[t][sset][15];
+        if (x == 0x7fffffff) a.counter[1] = 1;
+        return;
+    }
     int32_t* thr = reinterpret_cast<int32_t*>(smem);   // [0,128): rows, [128,256): cols
     if (MODE == 0) {
-        if (tid < 2 * kTile) {
-            const int64_t g = (tid < kTile ? i0 : j0 - kTile) + tid;
-            thr[tid] = a.cand_thr[g];
+        for (int x = tid; x < kTile + TN; x += kWavesT * 64) {
+            const int64_t g = (x < kTile ? i0 : j0 - kTile) + x;
+            thr[x] = a.cand_thr[g];
         }
         __syncthreads();
     }
@@ -345,21 +415,46 @@ struct CellLess {
     }
 };
 
-template <int L, int MODE>
-int launch_mfma(hipStream_t stream, const PairwiseArgs& a) {
+// Kernel variant: MVS_PAIRWISE_VARIANT=0 -> 8 waves, 128x128 tile, 4-stage ring (default)
+//                                      1 -> 4 waves, 128x64 tile, 3-stage ring, two workgroups per CU
+//                                      2 -> 8 waves, 128x128 tile, 5-stage ring
+//                                      3 -> 4 waves, 128x64 tile, 2-stage ring
+int pairwise_variant() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("MVS_PAIRWISE_VARIANT");
+        v = e ? atoi(e) : 0;
+        if (v < 0 || v > 3) v = 0;
+    }
+    return v;
+}
+
+template <int L, int MODE, int NST, int WN>
+int launch_mfma_variant(hipStream_t stream, const PairwiseArgs& a) {
+    constexpr int TN = WN * 32;
     const int64_t rows = a.row_end - a.row_begin, cols = a.col_end - a.col_begin;
     if (rows <= 0 || cols <= 0) return 0;
-    const int n_tr = (int)((rows + kTile - 1) / kTile), n_tc = (int)((cols + kTile - 1) / kTile);
+    const int n_tr = (int)((rows + kTile - 1) / kTile), n_tc = (int)((cols + TN - 1) / TN);
     const int n_spr = (n_tr + 15) / 16, n_spc = (n_tc + 15) / 16;
     const int64_t blocks = (int64_t)n_spr * n_spc * 256;
     if (blocks > 0x7fffffffLL) return MVS_E_INVALID;
-    const size_t lds = (size_t)2 * 2 * L * kTile * kBK;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pairwise_mfma<L, MODE>),
+    const size_t lds = (size_t)NST * L * (kTile + TN) * kSK;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pairwise_mfma<L, MODE, NST, WN>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return MVS_E_HIP;
-    hipLaunchKernelGGL((k_pairwise_mfma<L, MODE>), dim3((unsigned)blocks), dim3(kThreads), lds, stream, a, n_tr,
-                       n_tc, n_spc);
+    hipLaunchKernelGGL((k_pairwise_mfma<L, MODE, NST, WN>), dim3((unsigned)blocks), dim3(2 * WN * 64), lds, stream,
+                       a, n_tr, n_tc, n_spc);
     return 0;
+}
+
+template <int L, int MODE>
+int launch_mfma(hipStream_t stream, const PairwiseArgs& a) {
+    switch (pairwise_variant()) {
+        case 1: return launch_mfma_variant<L, MODE, 3, 2>(stream, a);
+        case 2: return launch_mfma_variant<L, MODE, 5, 4>(stream, a);
+        case 3: return launch_mfma_variant<L, MODE, 2, 2>(stream, a);
+        default: return launch_mfma_variant<L, MODE, 4, 4>(stream, a);
+    }
 }
 
 }  // namespace

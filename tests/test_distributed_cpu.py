@@ -1,0 +1,109 @@
+"""CPU, world_size 2, gloo: the row-sharded comparison (metagenome_vector_sketches_amd/parallel.py).
+
+The orchestration code is the product's; the numeric back end is replaced by a stand-in built on the
+oracle (tests may use the oracle; the product may not), so what is verified here is the sharding, the
+plane-buffer layout that the all-gather assembles, the padding of an uneven last shard and the norms
+exchange: the union of the ranks' shards must equal the single-process result cell for cell."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+class OracleOps:
+    """CPU stand-in for parallel.GpuOps with the same plane layout as the HIP limb-split kernel:
+    planes[(row*limbs + limb)*d_pad + k], signed base-256 digits."""
+
+    def __init__(self):
+        from oracle import pyoracle
+        self.orc = pyoracle
+
+    def max_abs(self, sk):
+        return int(np.abs(np.asarray(sk, dtype=np.int64)).max()) if sk.size else 0
+
+    def limbs_for(self, m):
+        return 1 if m <= 127 else 2 if m <= 32639 else 3 if m <= 8355711 else 4
+
+    def limb_geometry(self, n, d, limbs):
+        n_alloc = (n + 127) // 128 * 128 + 128
+        d_pad = (d + 127) // 128 * 128
+        return n_alloc, d_pad, n_alloc * limbs * d_pad
+
+    def new_planes(self, nbytes):
+        return torch.zeros(nbytes, dtype=torch.int8)
+
+    def limb_split(self, sk, limbs, planes, d_pad, row_offset):
+        v = np.asarray(sk, dtype=np.int64).copy()
+        n, d = v.shape
+        view = planes.numpy().reshape(-1, limbs, d_pad)
+        for l in range(limbs):
+            digit = ((v + 128) % 256) - 128
+            view[row_offset:row_offset + n, l, :d] = digit.astype(np.int8)
+            v = (v - digit) // 256
+
+    def to_device(self, a):
+        return torch.from_numpy(np.ascontiguousarray(a))
+
+    def compare(self, planes, n, n_alloc, d, d_pad, limbs, norms_sq, rb, re, keep_mode, cells_out):
+        view = planes.numpy().reshape(-1, limbs, d_pad).astype(np.int64)
+        sk = sum(view[:n, l, :d] * (256 ** l) for l in range(limbs)).astype(np.int32)
+        cells = self.orc.pairwise_rows(sk, norms_sq.numpy(), row_begin=rb, row_end=re, chunk=192, threads=2)
+        order = np.lexsort((cells["col"], cells["row"]))
+        return cells[order], len(cells)
+
+
+def _make(n, d, seed):
+    from metagenome_vector_sketches_amd import synth
+    from oracle import pyoracle as orc
+    sk = synth.make_sketches_numpy(n, d, 3000, seed=seed, cluster=8)
+    n2 = np.array([orc.norm_sq_from_text(orc.format_norm(orc.norm(r))) for r in sk])
+    return sk, n2
+
+
+def _worker(rank, world, port, n, d, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from metagenome_vector_sketches_amd import parallel
+    sk, n2 = _make(n, d, seed=99)
+    b, e = parallel.shard_rows(n, world, rank)
+    sc = parallel.ShardedComparison(OracleOps(), rank, world, dist)
+    cells, cnt, info = sc.run(sk[b:e], n2[b:e], n)
+    cells2, cnt2, _ = sc.run(sk[b:e], n2[b:e], n)          # second step reuses the plane buffer
+    assert cnt == cnt2 and np.array_equal(cells, cells2)
+    np.save(os.path.join(out_dir, "cells_%d.npy" % rank), cells)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [96, 101])     # 101: uneven last shard (51 + 50) -> padded block
+def test_two_rank_shards_equal_single_process(tmp_path, n):
+    d, world, port = 256, 2, 29500 + (os.getpid() + n) % 2000
+    mp.spawn(_worker, args=(world, port, n, d, str(tmp_path)), nprocs=world, join=True)
+    from metagenome_vector_sketches_amd import parallel
+    from oracle import pyoracle as orc
+    sk, n2 = _make(n, d, seed=99)
+    want = orc.pairwise_rows(sk, n2, chunk=192)
+    want = want[np.lexsort((want["col"], want["row"]))]
+    got = np.concatenate([np.load(os.path.join(str(tmp_path), "cells_%d.npy" % r)) for r in range(world)])
+    assert len(want) > n * 4
+    assert np.array_equal(got, want)
+    for r in range(world):
+        b, e = parallel.shard_rows(n, world, r)
+        part = np.load(os.path.join(str(tmp_path), "cells_%d.npy" % r))
+        assert np.all((part["row"] >= b) & (part["row"] < e))
+
+
+def test_shard_rows_matches_reference_formula():
+    from metagenome_vector_sketches_amd import parallel
+    from oracle import pyoracle as orc
+    for n, s in [(61, 2), (100, 8), (3, 8), (1000, 7), (0, 4)]:
+        for k in range(s):
+            assert parallel.shard_rows(n, s, k) == orc.shard_rows(n, s, k)

@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Run the pairwise comparison alone on synthesised sketches (profiling helper).
+   python tools/run_pairwise.py [N] [d] [reps]"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+import metagenome_vector_sketches_amd as pkg
+from metagenome_vector_sketches_amd import synth
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
+d = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
+reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+ctx = pkg.Context(0)
+ctx.set_stream(torch.cuda.current_stream())
+ctx.set_timing(True)
+sk = synth.make_sketches_torch(n, d, 50_000, seed=2345, device="cuda")
+ss = torch.empty(n, dtype=torch.int64, device="cuda")
+ctx.sumsq(sk, out=ss)
+n2 = torch.from_numpy(np.sqrt(ss.cpu().numpy() / d) ** 2).to("cuda")
+sset = ctx.sketch_set(sk)
+cells = torch.empty((max(1 << 22, 64 * n), 4), dtype=torch.int32, device="cuda")
+for r in range(reps):
+    t0 = time.perf_counter()
+    _, cnt = ctx.pairwise_rows(sset, n2, cells_out=cells)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ms = ctx.kernel_ms(1)
+    print("N=%d d=%d limbs=%d kept=%d wall %.3f ms kernel %.3f ms -> %.3g cells/s, %.1f algorithmic TFLOP/s, MFMA issue %.1f%%"
+          % (n, d, sset.limbs, cnt, dt * 1e3, ms, n * n / (ms * 1e-3), 2.0 * d * n * n / (ms * 1e-3) / 1e12,
+             2.0 * d * n * n * sset.limbs ** 2 / (ms * 1e-3) / 5e15 * 100))
