@@ -157,6 +157,16 @@ def main():
     k1_gbs = k1_bytes / (k1 * 1e-3) / 1e9
     k1_intops = S * float(NH) * D            # sign accumulations
     k2_flops = 2.0 * D * S * N_total         # this rank's rows x all columns
+    # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 cannot run inside
+    # this process); only valid for the default workload on one GPU
+    traffic = {"k_project": None, "k_pairwise_mfma": None}
+    try:
+        if (S, NH, D, world) == (10_000, 50_000, 2048, 1):
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+                pmc = json.load(f)
+            traffic = {k: pmc[k]["hbm_bytes_per_launch_corrected"] for k in traffic}
+    except Exception:
+        pass
     res = {
         "metric": "samples projected/sec + pairwise Jaccard cells/sec, d=2048, 1/2/4/8 GPUs",
         "value": samples_per_s,
@@ -179,7 +189,8 @@ def main():
                    "pairwise_kernel_ms": k2, "pairwise_cells_per_s_per_gpu": S * float(N_total) / (k2 * 1e-3),
                    "other_ms": ms_per_step - k1 - k2},
         "roofline": {"kernel": "k_project", "bound": "hbm", "achieved": k1_gbs, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": k1_gbs / HBM_PEAK_GBS, "traffic": None,
+                     "unit": "GB/s", "frac": k1_gbs / HBM_PEAK_GBS, "traffic": traffic["k_project"],
+                     "algorithmic_bytes": k1_bytes,
                      "note": "integer-VALU bound by construction (implicit hash-generated matrix): see valu"},
         "roofline_valu": {"kernel": "k_project", "achieved": k1_intops / (k1 * 1e-3) / 1e12,
                           "peak": VALU_INT_PEAK_TOPS, "unit": "T sign-accumulations/s vs T int32-op/s",
@@ -188,7 +199,7 @@ def main():
                               "achieved": k2_flops / (k2 * 1e-3) / 1e12, "peak": INT8_MFMA_PEAK_TOPS,
                               "unit": "TFLOP/s", "frac": k2_flops / (k2 * 1e-3) / 1e12 / INT8_MFMA_PEAK_TOPS,
                               "issued_frac": k2_flops * limbs * limbs / (k2 * 1e-3) / 1e12 / INT8_MFMA_PEAK_TOPS,
-                              "traffic": None},
+                              "traffic": traffic["k_pairwise_mfma"]},
     }
 
     if args.pairwise_extra and world == 1:

@@ -161,17 +161,25 @@ __device__ __forceinline__ int32_t reduce_counts(const uint32_t (&lo_in)[kLV], c
     return cnt;
 }
 
-// grid.x = unit, grid.y = group of kWaves*BPW 64-dim blocks; 256 threads = 4 waves, each wave owns
-// BPW consecutive blocks and streams over all hashes of the unit.
+// 256 threads = 4 waves, each wave owns BPW consecutive 64-dim blocks and streams over all hashes of
+// one unit; a unit needs ny = ceil(nblk / (4*BPW)) workgroups.  1-D grid, XCD aware: workgroups are
+// dealt round-robin over the 8 XCDs, so the ny workgroups of one unit are given linear ids 8 apart
+// (same XCD, dispatched together) and share the unit's hashes through that XCD's L2:
+//   id = (unit/8) * 8*ny + y*8 + unit%8.   Placement only affects HBM traffic, never results.
 template <int BPW>
 __global__ __launch_bounds__(256) void k_project(const uint64_t* __restrict__ hashes,
-                                                 const ProjUnit* __restrict__ units, int d, int nblk,
-                                                 int32_t* __restrict__ out) {
+                                                 const ProjUnit* __restrict__ units, long long n_units, int ny,
+                                                 int d, int nblk, int32_t* __restrict__ out) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int b0 = (blockIdx.y * 4 + wave) * BPW;
+    const long long grp = (long long)blockIdx.x / (8 * ny);
+    const int rem = (int)((long long)blockIdx.x % (8 * ny));
+    const long long unit = grp * 8 + (rem & 7);
+    const int y = rem >> 3;
+    if (unit >= n_units) return;
+    const int b0 = (y * 4 + wave) * BPW;
     if (b0 >= nblk) return;
-    const ProjUnit u = units[blockIdx.x];
+    const ProjUnit u = units[unit];
     const uint64_t* base = hashes + u.begin;
     const int64_t count = u.count;
 
@@ -293,16 +301,18 @@ int launch_project(hipStream_t stream, const uint64_t* d_hashes, const ProjUnit*
     if (n_units == 0) return 0;
     const int nblk = (d + 63) / 64;
     // grid.x is limited to 2^31-1, plenty; launch in slabs anyway to keep blockIdx.x an int
-    const int64_t kMaxUnits = 1 << 30;
+    const int ny = bpw == 1 ? (nblk + 3) / 4 : (nblk + 7) / 8;
+    // slabs keep the 1-D grid below 2^31 workgroups
+    const int64_t kMaxUnits = ((int64_t)0x7fffffff / (8 * ny) - 1) * 8;
     for (int64_t u0 = 0; u0 < n_units; u0 += kMaxUnits) {
         const int64_t nu = n_units - u0 < kMaxUnits ? n_units - u0 : kMaxUnits;
-        if (bpw == 1) {
-            dim3 grid((unsigned)nu, (unsigned)((nblk + 3) / 4));
-            hipLaunchKernelGGL(k_project<1>, grid, dim3(256), 0, stream, d_hashes, d_units + u0, d, nblk, d_out);
-        } else {
-            dim3 grid((unsigned)nu, (unsigned)((nblk + 7) / 8));
-            hipLaunchKernelGGL(k_project<2>, grid, dim3(256), 0, stream, d_hashes, d_units + u0, d, nblk, d_out);
-        }
+        const unsigned grid = (unsigned)(((nu + 7) / 8) * 8 * ny);
+        if (bpw == 1)
+            hipLaunchKernelGGL(k_project<1>, dim3(grid), dim3(256), 0, stream, d_hashes, d_units + u0, (long long)nu,
+                               ny, d, nblk, d_out);
+        else
+            hipLaunchKernelGGL(k_project<2>, dim3(grid), dim3(256), 0, stream, d_hashes, d_units + u0, (long long)nu,
+                               ny, d, nblk, d_out);
     }
     return 0;
 }
