@@ -620,6 +620,8 @@ int mvs_pairwise_rows(mvs_ctx* c, const mvs_sketch_set* s, const double* norms_s
     {
         const char* dbg = getenv("MVS_PAIRWISE_DEBUG");
         a.debug_flags = dbg ? atoi(dbg) : 0;
+        const char* sym = getenv("MVS_PAIRWISE_SYMMETRIC");   // default on; 0 computes every tile
+        a.symmetric = (row_begin % mvs::kTile == 0 && !(sym && atoi(sym) == 0)) ? 1 : 0;
     }
     if (c->timing) HIP_TRY(hipEventRecord(c->ev[2], c->stream));
     rc = mvs::launch_pairwise(c->stream, a, 0, 0);

@@ -42,6 +42,8 @@ struct PairwiseArgs {
     unsigned long long* counter;  // number of kept cells (may exceed capacity)
     // dense outputs (dots mode)
     int32_t* dots;                // (row_end-row_begin) x (col_end-col_begin)
+    int symmetric;                // 1: tiles strictly below the diagonal of the row range are skipped and
+                                  //    produced by mirroring the kept cells of their transposes
     int debug_flags;              // profiling ablations (MVS_PAIRWISE_DEBUG): 1 skip k-loop, 2 skip epilogue
 };
 

@@ -77,23 +77,30 @@ __device__ __forceinline__ int32_t quantize_cell(int32_t P, int d, double n2r, d
     return (int32_t)(uint16_t)(long long)r;
 }
 
-__device__ __forceinline__ void emit_cell(const PairwiseArgs& a, bool keep, int32_t row, int32_t col,
+// Append the kept cells of one wave (one atomic per wave).  mirror: the cell (col, row) is appended too --
+// dot, keep test and quantised Jaccard are symmetric in (row, col) bit for bit (fp add commutes).
+__device__ __forceinline__ void emit_cell(const PairwiseArgs& a, bool keep, bool mirror, int32_t row, int32_t col,
                                           int32_t P, int lane) {
     const unsigned long long mask = __ballot(keep);
     if (mask == 0ULL) return;
+    const unsigned long long mmask = __ballot(keep && mirror);
     unsigned long long base = 0;
     const int leader = __ffsll((long long)mask) - 1;
-    if (lane == leader) base = atomicAdd(a.counter, (unsigned long long)__popcll(mask));
+    if (lane == leader) base = atomicAdd(a.counter, (unsigned long long)(__popcll(mask) + __popcll(mmask)));
     base = __shfl(base, leader, 64);
     if (keep) {
-        const unsigned long long slot = base + (unsigned long long)__popcll(mask & ((1ULL << lane) - 1ULL));
-        if (slot < a.capacity) {
-            mvs_cell c;
-            c.row = row;
-            c.col = col;
-            c.dot = P;
-            c.q = quantize_cell(P, a.d, a.norms_sq[row], a.norms_sq[col]);
-            a.cells[slot] = c;
+        const unsigned long long below = (1ULL << lane) - 1ULL;
+        const unsigned long long slot = base + (unsigned long long)(__popcll(mask & below) + __popcll(mmask & below));
+        mvs_cell c;
+        c.row = row;
+        c.col = col;
+        c.dot = P;
+        c.q = quantize_cell(P, a.d, a.norms_sq[row], a.norms_sq[col]);
+        if (slot < a.capacity) a.cells[slot] = c;
+        if (mirror && slot + 1 < a.capacity) {
+            c.row = col;
+            c.col = row;
+            a.cells[slot + 1] = c;
         }
     }
 }
@@ -146,6 +153,15 @@ __global__ __launch_bounds__(2 * WN * 64, 2) void k_pairwise_mfma(const Pairwise
 
     const int64_t i0 = a.row_begin + (int64_t)tc.tr * kTile;   // first A sample of the tile
     const int64_t j0 = a.col_begin + (int64_t)tc.tc * TN;      // first B sample of the tile
+
+    // Symmetric schedule (row_begin % 128 == 0, col_begin == 0): inside the square [row_begin,row_end)^2 a
+    // tile strictly below the diagonal is skipped; its cells come from the tile strictly above the
+    // diagonal that holds their transposes (see DESIGN.md K2 for the covering argument).
+    bool mirror_tile = false;
+    if (MODE == 0 && a.symmetric) {
+        if (j0 >= a.row_begin && j0 + TN <= i0) return;
+        mirror_tile = j0 >= i0 + kTile && j0 < a.row_end;
+    }
 
     // ---- per-lane source pointers of this wave's pieces (k0 = 0).  One piece = 16 LDS rows of 64 B;
     //      lane -> row piece*16 + lane/4, 16-byte slot lane%4 holding logical chunk slot ^ ((s>>2)&3).
@@ -297,7 +313,7 @@ __global__ __launch_bounds__(2 * WN * 64, 2) void k_pairwise_mfma(const Pairwise
                     bool keep = false;
                     if (cand && row < a.row_end && col < a.col_end)
                         keep = keep_cell(P, a.d, a.norms_sq[row], a.norms_sq[col], a.keep_mode);
-                    emit_cell(a, keep, (int32_t)row, (int32_t)col, P, lane);
+                    emit_cell(a, keep, mirror_tile && col < a.row_end, (int32_t)row, (int32_t)col, P, lane);
                 }
             }
         }
@@ -337,7 +353,7 @@ __global__ __launch_bounds__(256) void k_pairwise_valu(const PairwiseArgs a) {
     } else {
         bool keep = false;
         if (in) keep = keep_cell(P, a.d, a.norms_sq[row], a.norms_sq[col], a.keep_mode);
-        emit_cell(a, keep, (int32_t)row, (int32_t)col, P, lane);
+        emit_cell(a, keep, false, (int32_t)row, (int32_t)col, P, lane);
     }
 }
 
