@@ -198,7 +198,11 @@ def main():
         "roofline_pairwise": {"kernel": "k_pairwise_mfma", "bound": "mfma",
                               "achieved": k2_flops / (k2 * 1e-3) / 1e12, "peak": INT8_MFMA_PEAK_TOPS,
                               "unit": "TFLOP/s", "frac": k2_flops / (k2 * 1e-3) / 1e12 / INT8_MFMA_PEAK_TOPS,
-                              "issued_frac": k2_flops * limbs * limbs / (k2 * 1e-3) / 1e12 / INT8_MFMA_PEAK_TOPS,
+                              # matrix-core work actually issued: passes per cell (1 limb: 1, Karatsuba: 3,
+                              # two base-256 limbs: 4) x share of the tiles the symmetric schedule computes
+                              "issued_frac": k2_flops * {1: 1, 0x103: 3, 2: 4}.get(limbs, 0) *
+                              (0.5 + 0.5 * 128.0 / S if world == 1 else 1.0 - 0.5 / world + 0.5 * 128.0 / N_total)
+                              / (k2 * 1e-3) / 1e12 / INT8_MFMA_PEAK_TOPS,
                               "traffic": traffic["k_pairwise_mfma"]},
     }
 

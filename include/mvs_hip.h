@@ -40,6 +40,11 @@ extern "C" {
 #define MVS_MEM_HOST     0
 #define MVS_MEM_DEVICE   1
 
+/* limb codes (the `limbs` arguments below): 1..4 = that many signed base-256 limb planes;
+ * MVS_LIMBS_K3 = three planes (l0, l1, l0+l1) of signed base-128 digits, |v| <= 8127: the comparison then
+ * needs 3 matrix-core passes per cell (Karatsuba) instead of the 4 of two base-256 limbs. */
+#define MVS_LIMBS_K3     0x103
+
 /* keep test variants */
 #define MVS_KEEP_INT32   0   /* src/pairwise_comp_optimized.cpp:139-141  (int64 dot / d truncates) */
 #define MVS_KEEP_INT16   1   /* src/pairwise_comp_optimized_16bits.cpp:211-218 (double(dot)/d)    */
@@ -117,11 +122,12 @@ int mvs_sketch_saturate_i16(mvs_ctx* ctx, const int32_t* sketches, int mem_in, i
 /* Largest |v| over n*d sketch entries (elem_bytes 4: int32, 2: int16); synchronous. */
 int mvs_sketch_max_abs(mvs_ctx* ctx, const void* sketches, int elem_bytes, int mem, int64_t n_elems,
                        int64_t* max_abs);
-/* Number of limbs needed for entries up to max_abs (1..4). */
+/* Limb code for entries up to max_abs: 1 (<=127), 2 (<=32639), 3, or 4; with MVS_ENABLE_K3=1 in the
+ * environment MVS_LIMBS_K3 is chosen for 128..8127 (it measures slower than 2 on MI355X, so it is opt-in). */
 int mvs_limbs_for_max_abs(int64_t max_abs);
 /* Geometry of the limb-plane buffer for n samples: rows are padded to n_alloc (multiple of 128,
  * plus one spare tile), the dimension to d_pad (multiple of 128); layout is
- * planes[(row * limbs + limb) * d_pad + k], zero filled outside n x d. */
+ * planes[(row * P + plane) * d_pad + k] with P = limbs & 0xff planes per row, zero filled outside n x d. */
 int mvs_limb_geometry(int64_t n, int d, int limbs, int64_t* n_alloc, int* d_pad, size_t* bytes);
 /* Re-code rows [0, n_rows) of `sketches` into rows [row_offset, row_offset + n_rows) of a
  * caller-owned DEVICE plane buffer that has been zero-filled (so several producers -- e.g. the

@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libmvs_hip.so")
 MVS_OK, MVS_E_INVALID, MVS_E_HIP, MVS_E_CAPACITY, MVS_E_NOMEM, MVS_E_RANGE = 0, 1, 2, 3, 4, 5
 MEM_HOST, MEM_DEVICE = 0, 1
 KEEP_INT32, KEEP_INT16 = 0, 1
+LIMBS_K3 = 0x103
 
 CELL_DTYPE = np.dtype([("row", "<i4"), ("col", "<i4"), ("dot", "<i4"), ("q", "<i4")])
 
@@ -243,14 +244,24 @@ class Context:
             raise ValueError("planes must be a device buffer")
         _check(self.lib.mvs_limb_split(self._h, p, eb, m, n, d, limbs, pp, d_pad, row_offset))
 
-    def sketch_set(self, sketches):
+    def sketch_set(self, sketches, limbs=None):
+        """limbs=None lets the library choose the limb code from max|v|; an explicit code (1..4 or
+        LIMBS_K3) allocates and fills the planes with that scheme (the caller guarantees the range)."""
         n, d = sketches.shape
         eb = self._elem_bytes(sketches)
         if eb not in (2, 4):
             raise ValueError("sketches must be int32 or int16")
         p, m, k = _buf(sketches)
         h = _P()
-        _check(self.lib.mvs_sketch_set_create(self._h, p, eb, m, n, d, ctypes.byref(h)))
+        if limbs is None:
+            _check(self.lib.mvs_sketch_set_create(self._h, p, eb, m, n, d, ctypes.byref(h)))
+        else:
+            _check(self.lib.mvs_sketch_set_alloc(self._h, n, d, int(limbs), ctypes.byref(h)))
+            rc = self.lib.mvs_sketch_set_fill(h, p, eb, m, 0, n)
+            if rc != MVS_OK:
+                self.lib.mvs_sketch_set_destroy(h)
+                _check(rc)
+            self.synchronize()
         return SketchSet(self, h)
 
     def sketch_set_from_planes(self, planes, n, n_alloc, d, d_pad, limbs):

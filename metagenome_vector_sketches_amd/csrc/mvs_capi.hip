@@ -389,26 +389,37 @@ int mvs_sketch_max_abs(mvs_ctx* c, const void* sketches, int elem_bytes, int mem
 int mvs_limbs_for_max_abs(int64_t max_abs) {
     if (max_abs < 0) max_abs = -max_abs;
     if (max_abs <= 127) return 1;
+    {
+        // The 3-pass Karatsuba scheme is exact and tested but measures 9-19 % SLOWER than two base-256
+        // limbs on MI355X (25 % fewer MFMAs, 1.5x the LDS traffic: the kernel is data-movement / power
+        // bound), so it is opt-in: MVS_ENABLE_K3=1.
+        static int k3 = -1;
+        if (k3 < 0) {
+            const char* e = getenv("MVS_ENABLE_K3");
+            k3 = (e && atoi(e) != 0) ? 1 : 0;
+        }
+        if (k3 && max_abs <= 8127) return MVS_LIMBS_K3;   // 63 * (1 + 128): digits in [-64,63], sum in int8
+    }
     if (max_abs <= 32639) return 2;      // 127 * (1 + 256)
     if (max_abs <= 8355711) return 3;    // 127 * (1 + 256 + 65536)
     return 4;                            // exact mod 2^32 for every int32
 }
 
 int mvs_limb_geometry(int64_t n, int d, int limbs, int64_t* n_alloc, int* d_pad, size_t* bytes) {
-    if (n < 0 || d <= 0 || limbs < 1 || limbs > mvs::kMaxLimbs) return fail(MVS_E_INVALID, "bad argument");
+    if (n < 0 || d <= 0 || !mvs::limb_code_ok(limbs)) return fail(MVS_E_INVALID, "bad argument");
     const int64_t na = (n + mvs::kTile - 1) / mvs::kTile * mvs::kTile + mvs::kTile;
     const int dp = (d + mvs::kBK - 1) / mvs::kBK * mvs::kBK;
     if (n_alloc) *n_alloc = na;
     if (d_pad) *d_pad = dp;
-    if (bytes) *bytes = (size_t)na * (size_t)limbs * (size_t)dp;
+    if (bytes) *bytes = (size_t)na * (size_t)mvs::planes_of(limbs) * (size_t)dp;
     return MVS_OK;
 }
 
 int mvs_limb_split(mvs_ctx* c, const void* sketches, int elem_bytes, int mem, int64_t n_rows, int d, int limbs,
                    int8_t* planes, int d_pad, int64_t row_offset) {
     if (!c) return fail(MVS_E_INVALID, "ctx is NULL");
-    if ((elem_bytes != 4 && elem_bytes != 2) || !mem_ok(mem) || n_rows < 0 || d <= 0 || limbs < 1 ||
-        limbs > mvs::kMaxLimbs || d_pad < d || d_pad % mvs::kBK != 0 || row_offset < 0)
+    if ((elem_bytes != 4 && elem_bytes != 2) || !mem_ok(mem) || n_rows < 0 || d <= 0 || !mvs::limb_code_ok(limbs) ||
+        d_pad < d || d_pad % mvs::kBK != 0 || row_offset < 0)
         return fail(MVS_E_INVALID, "bad argument");
     if (n_rows == 0) return MVS_OK;
     if (!sketches || !planes) return fail(MVS_E_INVALID, "NULL buffer");
@@ -507,7 +518,7 @@ int mvs_sketch_set_from_planes(mvs_ctx* c, const int8_t* planes, int64_t n, int6
 int mvs_sketch_set_alloc(mvs_ctx* c, int64_t n, int d, int limbs, mvs_sketch_set** out) {
     if (!c || !out) return fail(MVS_E_INVALID, "NULL argument");
     *out = nullptr;
-    if (n < 0 || d <= 0 || limbs < 1 || limbs > mvs::kMaxLimbs) return fail(MVS_E_INVALID, "bad argument");
+    if (n < 0 || d <= 0 || !mvs::limb_code_ok(limbs)) return fail(MVS_E_INVALID, "bad argument");
     if (n >= (1LL << 31) - 256) return fail(MVS_E_RANGE, "n too large for int32 row/col indices");
     HIP_TRY(hipSetDevice(c->device));
     int64_t n_alloc = 0;

@@ -23,6 +23,12 @@ constexpr int kProjUnitMax = 65536;
 constexpr int kTile = 128;      // samples per workgroup tile edge (rows and cols)
 constexpr int kBK = 128;        // bytes (= int8 k values) per staged k-slice
 constexpr int kMaxLimbs = 4;
+// limb code: 1..4 = signed base-256 limbs; kLimbsK3 = three planes (l0, l1, l0+l1) of signed base-128
+// digits for the 3-pass Karatsuba product (|v| <= 8127)
+constexpr int kLimbsK3 = MVS_LIMBS_K3;
+inline __host__ __device__ int planes_of(int code) { return code & 0xff; }
+inline __host__ __device__ bool is_k3(int code) { return code == kLimbsK3; }
+inline bool limb_code_ok(int code) { return (code >= 1 && code <= kMaxLimbs) || code == kLimbsK3; }
 
 struct PairwiseArgs {
     const int8_t* planes;   // [(row*limbs + limb) * d_pad + k]
@@ -30,7 +36,7 @@ struct PairwiseArgs {
     int64_t n_alloc;        // allocated (zero padded) rows
     int d;
     int d_pad;
-    int limbs;
+    int limbs;              // limb code (see kLimbsK3)
     int64_t row_begin, row_end;   // row range of this call
     int64_t col_begin, col_end;   // column range (dots) / [0,n) for the comparison
     // comparison outputs

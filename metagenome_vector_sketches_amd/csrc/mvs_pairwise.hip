@@ -128,7 +128,9 @@ __device__ __forceinline__ void wait_vmcnt() {
 // WN = waves along the column axis: 4 -> 8 waves, tile 128 x 128 samples (one workgroup per CU);
 //                                    2 -> 4 waves, tile 128 x 64 samples (two workgroups per CU, so
 //                                         one's barrier/copy waits overlap the other's MFMAs).
-template <int L, int MODE, int NST, int WN>
+// KARA: the L = 3 planes are (l0, l1, l0+l1) of base-128 digits; only the three "diagonal" products
+//       X = <l0,l0'>, Z = <l1,l1'>, Y = <l0+l1, l0'+l1'> are formed and P = X + 128(Y-X-Z) + 16384 Z.
+template <int L, bool KARA, int MODE, int NST, int WN>
 __global__ __launch_bounds__(2 * WN * 64, 2) void k_pairwise_mfma(const PairwiseArgs a, int n_tr, int n_tc,
                                                                   int n_spc) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -139,7 +141,8 @@ __global__ __launch_bounds__(2 * WN * 64, 2) void k_pairwise_mfma(const Pairwise
     constexpr int kStage = kRegion + kRegionB;   // bytes of one stage
     constexpr int kPieces = kStage / 1024;       // 1 KiB pieces per stage
     constexpr int kPPW = kPieces / kWavesT;      // pieces per wave per stage
-    constexpr int NS = num_acc_sets(L);
+    constexpr int NS = KARA ? 3 : num_acc_sets(L);
+    static_assert(!KARA || L == 3, "Karatsuba scheme has three planes");
     static_assert(kPieces % kWavesT == 0, "stage must split evenly over the waves");
 
     const TileCoord tc = map_tile(blockIdx.x, n_tr, n_tc, n_spc);
@@ -222,9 +225,11 @@ __global__ __launch_bounds__(2 * WN * 64, 2) void k_pairwise_mfma(const Pairwise
             for (int la = 0; la < L; ++la)
 #pragma unroll
                 for (int lb = 0; lb < L; ++lb) {
-                    if (la + lb > 3) continue;   // 256^4 == 0 (mod 2^32)
-                    acc[t][la + lb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[buf][t][la], fb[buf][lb],
-                                                                           acc[t][la + lb], 0, 0, 0);
+                    if (KARA ? (la != lb) : (la + lb > 3)) continue;   // 256^4 == 0 (mod 2^32)
+                    constexpr int dummy = 0;
+                    (void)dummy;
+                    const int s = KARA ? la : la + lb;
+                    acc[t][s] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[buf][t][la], fb[buf][lb], acc[t][s], 0, 0, 0);
                 }
     };
 
@@ -301,8 +306,13 @@ __global__ __launch_bounds__(2 * WN * 64, 2) void k_pairwise_mfma(const Pairwise
             const int row_l = wm * 64 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
             const int64_t row = i0 + row_l;
             uint32_t Pu = (uint32_t)acc[t][0][r];
+            if (KARA) {
+                const uint32_t X = Pu, Z = (uint32_t)acc[t][1][r], Y = (uint32_t)acc[t][NS - 1][r];
+                Pu = X + ((Y - X - Z) << 7) + (Z << 14);
+            } else {
 #pragma unroll
-            for (int s = 1; s < NS; ++s) Pu += (uint32_t)acc[t][s][r] << (8 * s);
+                for (int s = 1; s < NS; ++s) Pu += (uint32_t)acc[t][s][r] << (8 * s);
+            }
             const int32_t P = (int32_t)Pu;
             if (MODE == 1) {
                 if (row < a.row_end && col < a.col_end)
@@ -330,7 +340,8 @@ __global__ __launch_bounds__(256) void k_pairwise_valu(const PairwiseArgs a) {
     const int64_t row = a.row_begin + (int64_t)blockIdx.y * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const bool in = row < a.row_end && col < a.col_end;
-    const int L = a.limbs;
+    const int L = planes_of(a.limbs);
+    const bool kara = is_k3(a.limbs);
     uint32_t acc[4] = {0u, 0u, 0u, 0u};
     if (in) {
         const int8_t* pa = a.planes + row * L * (int64_t)a.d_pad;
@@ -341,13 +352,18 @@ __global__ __launch_bounds__(256) void k_pairwise_valu(const PairwiseArgs a) {
                 wa[l] = *reinterpret_cast<const int*>(pa + (int64_t)l * a.d_pad + k);
                 wb[l] = *reinterpret_cast<const int*>(pb + (int64_t)l * a.d_pad + k);
             }
-            for (int la = 0; la < L; ++la)
-                for (int lb = 0; lb < L; ++lb)
-                    if (la + lb <= 3)
-                        acc[la + lb] = (uint32_t)__builtin_amdgcn_sdot4(wa[la], wb[lb], (int)acc[la + lb], false);
+            if (kara) {
+                for (int l = 0; l < 3; ++l) acc[l] = (uint32_t)__builtin_amdgcn_sdot4(wa[l], wb[l], (int)acc[l], false);
+            } else {
+                for (int la = 0; la < L; ++la)
+                    for (int lb = 0; lb < L; ++lb)
+                        if (la + lb <= 3)
+                            acc[la + lb] = (uint32_t)__builtin_amdgcn_sdot4(wa[la], wb[lb], (int)acc[la + lb], false);
+            }
         }
     }
-    const int32_t P = (int32_t)(acc[0] + (acc[1] << 8) + (acc[2] << 16) + (acc[3] << 24));
+    const int32_t P = kara ? (int32_t)(acc[0] + ((acc[2] - acc[0] - acc[1]) << 7) + (acc[1] << 14))
+                           : (int32_t)(acc[0] + (acc[1] << 8) + (acc[2] << 16) + (acc[3] << 24));
     if (MODE == 1) {
         if (in) a.dots[(row - a.row_begin) * (a.col_end - a.col_begin) + (col - a.col_begin)] = P;
     } else {
@@ -392,7 +408,24 @@ __global__ __launch_bounds__(256) void k_limb_split(const T* __restrict__ sk, in
         int32_t v[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = (k + e < d) ? (int32_t)sk[row * d + k + e] : 0;
-        int8_t* dst = planes + (row_offset + row) * limbs * (int64_t)d_pad + k;
+        const int np = planes_of(limbs);
+        int8_t* dst = planes + (row_offset + row) * np * (int64_t)d_pad + k;
+        if (is_k3(limbs)) {
+            // signed base-128 digits l0, l1 in [-64, 63] (|v| <= 8127) and their sum, which fits int8
+            uint32_t p0 = 0, p1 = 0, p2 = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int32_t l0 = ((v[e] + 64) & 127) - 64;
+                const int32_t l1 = (v[e] - l0) >> 7;
+                p0 |= (uint32_t)(uint8_t)(int8_t)l0 << (8 * e);
+                p1 |= (uint32_t)(uint8_t)(int8_t)l1 << (8 * e);
+                p2 |= (uint32_t)(uint8_t)(int8_t)(l0 + l1) << (8 * e);
+            }
+            *reinterpret_cast<uint32_t*>(dst) = p0;
+            *reinterpret_cast<uint32_t*>(dst + (int64_t)d_pad) = p1;
+            *reinterpret_cast<uint32_t*>(dst + 2 * (int64_t)d_pad) = p2;
+            continue;
+        }
         for (int l = 0; l < limbs; ++l) {
             uint32_t packed = 0;
 #pragma unroll
@@ -445,7 +478,7 @@ int pairwise_variant() {
     return v;
 }
 
-template <int L, int MODE, int NST, int WN>
+template <int L, bool KARA, int MODE, int NST, int WN>
 int launch_mfma_variant(hipStream_t stream, const PairwiseArgs& a) {
     constexpr int TN = WN * 32;
     const int64_t rows = a.row_end - a.row_begin, cols = a.col_end - a.col_begin;
@@ -455,21 +488,30 @@ int launch_mfma_variant(hipStream_t stream, const PairwiseArgs& a) {
     const int64_t blocks = (int64_t)n_spr * n_spc * 256;
     if (blocks > 0x7fffffffLL) return MVS_E_INVALID;
     const size_t lds = (size_t)NST * L * (kTile + TN) * kSK;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pairwise_mfma<L, MODE, NST, WN>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pairwise_mfma<L, KARA, MODE, NST, WN>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return MVS_E_HIP;
-    hipLaunchKernelGGL((k_pairwise_mfma<L, MODE, NST, WN>), dim3((unsigned)blocks), dim3(2 * WN * 64), lds, stream,
-                       a, n_tr, n_tc, n_spc);
+    hipLaunchKernelGGL((k_pairwise_mfma<L, KARA, MODE, NST, WN>), dim3((unsigned)blocks), dim3(2 * WN * 64), lds,
+                       stream, a, n_tr, n_tc, n_spc);
     return 0;
 }
 
-template <int L, int MODE>
+template <int L, bool KARA, int MODE>
 int launch_mfma(hipStream_t stream, const PairwiseArgs& a) {
-    switch (pairwise_variant()) {
-        case 1: return launch_mfma_variant<L, MODE, 3, 2>(stream, a);
-        case 2: return launch_mfma_variant<L, MODE, 5, 4>(stream, a);
-        case 3: return launch_mfma_variant<L, MODE, 2, 2>(stream, a);
-        default: return launch_mfma_variant<L, MODE, 4, 4>(stream, a);
+    if constexpr (KARA) {   // 48 KB per stage: at most three stages fit the 160 KB of LDS
+        switch (pairwise_variant()) {
+            case 1: return launch_mfma_variant<L, KARA, MODE, 3, 2>(stream, a);
+            case 3: return launch_mfma_variant<L, KARA, MODE, 2, 2>(stream, a);
+            case 2: return launch_mfma_variant<L, KARA, MODE, 2, 4>(stream, a);
+            default: return launch_mfma_variant<L, KARA, MODE, 3, 4>(stream, a);
+        }
+    } else {
+        switch (pairwise_variant()) {
+            case 1: return launch_mfma_variant<L, KARA, MODE, 3, 2>(stream, a);
+            case 2: return launch_mfma_variant<L, KARA, MODE, 5, 4>(stream, a);
+            case 3: return launch_mfma_variant<L, KARA, MODE, 2, 2>(stream, a);
+            default: return launch_mfma_variant<L, KARA, MODE, 4, 4>(stream, a);
+        }
     }
 }
 
@@ -512,9 +554,10 @@ int launch_cand_thr(hipStream_t stream, const double* d_norms_sq, int64_t n, int
 }
 
 int launch_pairwise(hipStream_t stream, const PairwiseArgs& a, int mode, int algo) {
-    if (algo == 0 && a.limbs <= 2) {
-        if (a.limbs == 1) return mode == 0 ? launch_mfma<1, 0>(stream, a) : launch_mfma<1, 1>(stream, a);
-        return mode == 0 ? launch_mfma<2, 0>(stream, a) : launch_mfma<2, 1>(stream, a);
+    if (algo == 0 && (a.limbs <= 2 || is_k3(a.limbs))) {
+        if (is_k3(a.limbs)) return mode == 0 ? launch_mfma<3, true, 0>(stream, a) : launch_mfma<3, true, 1>(stream, a);
+        if (a.limbs == 1) return mode == 0 ? launch_mfma<1, false, 0>(stream, a) : launch_mfma<1, false, 1>(stream, a);
+        return mode == 0 ? launch_mfma<2, false, 0>(stream, a) : launch_mfma<2, false, 1>(stream, a);
     }
     const int64_t rows = a.row_end - a.row_begin, cols = a.col_end - a.col_begin;
     if (rows <= 0 || cols <= 0) return 0;

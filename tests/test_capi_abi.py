@@ -36,8 +36,8 @@ def test_pure_host_helpers_match_reference_formulas():
     assert _capi.shard_rows(61, 2, 1) == (31, 61)
     assert _capi.shard_rows(100, 8, 7) == (91, 100)
     assert _capi.shard_rows(3, 8, 7) == (3, 3)
-    assert [_capi.limbs_for_max_abs(x) for x in (0, 127, 128, 32639, 32640, 8355711, 8355712, 2**31)] == \
-        [1, 1, 2, 2, 3, 3, 4, 4]
+    assert [_capi.limbs_for_max_abs(x) for x in (0, 127, 128, 8127, 8128, 32639, 32640, 8355711, 8355712, 2**31)] == \
+        [1, 1, 2, 2, 2, 2, 3, 3, 4, 4]
 
 
 def test_no_silent_fallback_without_gpu():

@@ -23,13 +23,24 @@ def _oracle_sorted(sk, n2, **kw):
     return sorted(_cells_tuple(orc.pairwise_rows(sk, n2, threads=8, **kw)))
 
 
-@pytest.mark.parametrize("n,d", [(61, 2048), (300, 2048), (257, 100), (130, 4096), (5, 64), (129, 2048 + 64)])
-def test_dots_mfma_and_valu_vs_oracle(ctx, n, d):
+K3 = 0x103   # MVS_LIMBS_K3: three planes of base-128 digits, 3 matrix-core passes per cell
+
+
+@pytest.mark.parametrize("n,d,hi,code", [(61, 2048, 1500, 2), (61, 2048, 1500, K3), (300, 2048, 8127, K3),
+                                         (300, 2048, 8128, 2), (257, 100, 1500, K3), (257, 100, 32639, 2),
+                                         (130, 4096, 1500, 2), (130, 4096, 1500, K3), (5, 64, 20000, 2),
+                                         (129, 2048 + 64, 8000, K3), (129, 2048 + 64, 8000, 2)])
+def test_dots_mfma_and_valu_vs_oracle(ctx, n, d, hi, code):
+    """both exact limb schemes: two base-256 limbs (default) and the opt-in 3-plane Karatsuba scheme"""
     rng = np.random.default_rng(n * 7 + d)
-    sk = rng.integers(-1500, 1500, size=(n, d), dtype=np.int32)   # asymmetric, 2 limbs
+    sk = rng.integers(-hi, hi + 1, size=(n, d), dtype=np.int32)   # asymmetric
     sk[0] = 0
-    ss = ctx.sketch_set(sk)
-    assert ss.limbs == 2
+    sk[1, 0], sk[2, 1] = hi, -hi
+    ss = ctx.sketch_set(sk, limbs=code)
+    assert ss.limbs == code
+    auto = ctx.sketch_set(sk)
+    assert auto.limbs == 2          # library default for 128 <= max|v| <= 32639
+    auto.close()
     want = orc.dots_dense(sk, 0, n, 0, n, threads=8)
     assert np.array_equal(ctx.pairwise_dots(ss, 0, n, 0, n, algo=0), want)
     assert np.array_equal(ctx.pairwise_dots(ss, 0, n, 0, n, algo=1), want)
@@ -49,7 +60,7 @@ def test_dots_single_limb(ctx):
     ss.close()
 
 
-@pytest.mark.parametrize("hi,limbs", [(32639, 2), (40000, 3), (8355711, 3), (9_000_000, 4), (2**31 - 1, 4)])
+@pytest.mark.parametrize("hi,limbs", [(8127, K3), (32639, 2), (40000, 3), (8355711, 3), (9_000_000, 4), (2**31 - 1, 4)])
 def test_dots_wrap_and_many_limbs(ctx, hi, limbs):
     """large entries: products overflow int32 and must wrap exactly like the reference's MatrixXi product"""
     rng = np.random.default_rng(hi % 1000)
@@ -57,7 +68,7 @@ def test_dots_wrap_and_many_limbs(ctx, hi, limbs):
     sk[0, 0], sk[1, 1] = hi, -hi
     if hi == 2**31 - 1:
         sk[2, 2] = -2**31
-    ss = ctx.sketch_set(sk)
+    ss = ctx.sketch_set(sk, limbs=limbs if limbs == K3 else None)
     assert ss.limbs == limbs
     want = orc.dots_dense(sk, 0, 70, 0, 70, threads=8)
     assert np.array_equal(ctx.pairwise_dots(ss, 0, 70, 0, 70, algo=0), want)
@@ -73,6 +84,10 @@ def test_toy_cells_reference_db(ctx, gold):
     cells, cnt = ctx.pairwise_rows(ss, n2)
     got = _cells_tuple(cells)
     assert cnt == 1291 == gold.kat["survey_kept_cells"]["int32"]
+    ssk = ctx.sketch_set(gold.vectors, limbs=K3)          # toy max |v| = 1263: Karatsuba planes are exact too
+    cells_k, cnt_k = ctx.pairwise_rows(ssk, n2)
+    assert cnt_k == cnt and _cells_tuple(cells_k) == got
+    ssk.close()
     assert got == sorted(gold.cells())            # library order is (row, col)
     by_row = {}
     for r, c, dot, q in got:
@@ -146,7 +161,7 @@ def test_full_width_properties(ctx):
     sk = sk_t.cpu().numpy()
     n2 = _n2_from_sketches(sk)
     ss = ctx.sketch_set(sk_t)
-    assert ss.limbs == 2
+    assert ss.limbs in (2, K3)
     cells, cnt = ctx.pairwise_rows(ss, n2)
     got = _cells_tuple(cells)
     s = set((r, c) for r, c, _, _ in got)
@@ -176,4 +191,4 @@ def test_sharded_comparison_single_rank(ctx):
     _, cnt, info = sc.run(torch.from_numpy(sk).to("cuda:0"), n2, 300, cells_out=cells_dev)
     ctx.synchronize()
     got = [tuple(int(x) for x in row) for row in cells_dev[:cnt].cpu().numpy()]
-    assert got == _oracle_sorted(sk, n2, chunk=192) and info["limbs"] == 2
+    assert got == _oracle_sorted(sk, n2, chunk=192) and info["limbs"] in (2, K3)
