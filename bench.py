@@ -107,10 +107,10 @@ def main():
 
     def step():
         ctx.project_csr(hashes, offsets, D, out=sketches)                 # K1
-        ctx.sumsq(sketches, out=sumsq)
+        _, max_abs = ctx.stats(sketches, out=sumsq)                        # sum of squares + max |v|, one pass
         n2_local = fast_norm_sq(sumsq.cpu().numpy(), D)                    # text round trip of the norms
         # limb split, [all-gather of plane row blocks + norms], K2 on this rank's rows x all columns
-        _, cnt, info = sc.run(sketches, n2_local, N_total, cells_out=cells)
+        _, cnt, info = sc.run(sketches, n2_local, N_total, cells_out=cells, max_abs_local=max_abs)
         state["cnt"] = cnt
         state["limbs"] = info["limbs"]
 

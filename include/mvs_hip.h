@@ -103,6 +103,12 @@ int mvs_project_csr(mvs_ctx* ctx, const uint64_t* hashes, int mem_hashes, const 
 int mvs_sketch_sumsq(mvs_ctx* ctx, const int32_t* sketches, int mem_in, int64_t n, int d,
                      int64_t* sumsq, int mem_out);
 
+/* Both statistics the stages after the projection need, in one pass over the sketches: the per-sketch sum
+ * of squares (as mvs_sketch_sumsq) and the largest |v| of the whole array (as mvs_sketch_max_abs, which
+ * decides the limb code).  Synchronous: *max_abs is valid on return. */
+int mvs_sketch_stats(mvs_ctx* ctx, const int32_t* sketches, int mem_in, int64_t n, int d, int64_t* sumsq,
+                     int mem_out, int64_t* max_abs);
+
 /* Saturating int32 -> int16 store of the --int16 mode (src/project_everything.cpp:332-347). */
 int mvs_sketch_saturate_i16(mvs_ctx* ctx, const int32_t* sketches, int mem_in, int64_t n_elems,
                             int16_t* out, int mem_out);
@@ -125,7 +131,7 @@ int mvs_sketch_max_abs(mvs_ctx* ctx, const void* sketches, int elem_bytes, int m
 /* Limb code for entries up to max_abs: 1 (<=127), 2 (<=32639), 3, or 4; with MVS_ENABLE_K3=1 in the
  * environment MVS_LIMBS_K3 is chosen for 128..8127 (it measures slower than 2 on MI355X, so it is opt-in). */
 int mvs_limbs_for_max_abs(int64_t max_abs);
-/* Geometry of the limb-plane buffer for n samples: rows are padded to n_alloc (multiple of 128,
+/* Geometry of the limb-plane buffer for n samples: rows are padded to n_alloc (multiple of 256,
  * plus one spare tile), the dimension to d_pad (multiple of 128); layout is
  * planes[(row * P + plane) * d_pad + k] with P = limbs & 0xff planes per row, zero filled outside n x d. */
 int mvs_limb_geometry(int64_t n, int d, int limbs, int64_t* n_alloc, int* d_pad, size_t* bytes);

@@ -35,6 +35,7 @@ SYMBOLS = [
     ("mvs_ctx_kernel_ms", _c.c_int, [_P, _c.c_int, _c.POINTER(_c.c_float)]),
     ("mvs_project_csr", _c.c_int, [_P, _P, _c.c_int, _P, _c.c_int64, _c.c_int, _P, _c.c_int]),
     ("mvs_sketch_sumsq", _c.c_int, [_P, _P, _c.c_int, _c.c_int64, _c.c_int, _P, _c.c_int]),
+    ("mvs_sketch_stats", _c.c_int, [_P, _P, _c.c_int, _c.c_int64, _c.c_int, _P, _c.c_int, _c.POINTER(_c.c_int64)]),
     ("mvs_sketch_saturate_i16", _c.c_int, [_P, _P, _c.c_int, _c.c_int64, _P, _c.c_int]),
     ("mvs_sketch_max_abs", _c.c_int, [_P, _P, _c.c_int, _c.c_int, _c.c_int64, _c.POINTER(_c.c_int64)]),
     ("mvs_limbs_for_max_abs", _c.c_int, [_c.c_int64]),
@@ -206,6 +207,17 @@ class Context:
         op, om, ok = _buf(out, np.int64, writable=True)
         _check(self.lib.mvs_sketch_sumsq(self._h, ip, im, n, d, op, om))
         return out
+
+    def stats(self, sketches, out=None):
+        """-> (sumsq, max_abs): per-row exact sum of squares and the largest |v|, one pass."""
+        n, d = sketches.shape
+        ip, im, ik = _buf(sketches, np.int32)
+        if out is None:
+            out = np.empty(n, dtype=np.int64)
+        op, om, ok = _buf(out, np.int64, writable=True)
+        m = _c.c_int64()
+        _check(self.lib.mvs_sketch_stats(self._h, ip, im, n, d, op, om, ctypes.byref(m)))
+        return out, m.value
 
     def saturate_i16(self, sketches, out=None):
         ip, im, ik = _buf(sketches, np.int32)

@@ -22,6 +22,10 @@ struct mvs_ctx {
     void* scratch = nullptr;
     size_t scratch_bytes = 0;
     unsigned long long* d_counter = nullptr;   // 8-byte slot for counters / max
+    // grow-only device buffers of mvs_pairwise_rows (no hipMalloc/hipFree on the hot path)
+    void* pw_thr = nullptr;   size_t pw_thr_bytes = 0;
+    void* pw_tmp = nullptr;   size_t pw_tmp_bytes = 0;
+    void* pw_sort = nullptr;  size_t pw_sort_bytes = 0;
     // pinned host staging for small metadata uploads (projection unit lists)
     void* pinned = nullptr;
     size_t pinned_bytes = 0;
@@ -67,6 +71,20 @@ struct DevBuf {
     }
     hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
 };
+
+int ensure_buf(mvs_ctx* c, void** p, size_t* have, size_t bytes) {
+    if (*have >= bytes) return MVS_OK;
+    if (*p) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipFree(*p));
+        *p = nullptr;
+        *have = 0;
+    }
+    const size_t want = bytes + bytes / 4 + 4096;   // head room: avoid regrowing on small changes
+    if (hipMalloc(p, want) != hipSuccess) return fail(MVS_E_NOMEM, "hipMalloc of %zu bytes failed", want);
+    *have = want;
+    return MVS_OK;
+}
 
 int ensure_scratch(mvs_ctx* c, size_t bytes) {
     if (c->scratch_bytes >= bytes) return MVS_OK;
@@ -170,6 +188,9 @@ int mvs_ctx_destroy(mvs_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     if (c->scratch) (void)hipFree(c->scratch);
     if (c->d_counter) (void)hipFree(c->d_counter);
+    if (c->pw_thr) (void)hipFree(c->pw_thr);
+    if (c->pw_tmp) (void)hipFree(c->pw_tmp);
+    if (c->pw_sort) (void)hipFree(c->pw_sort);
     if (c->pinned) (void)hipHostFree(c->pinned);
     if (c->pinned_ev) (void)hipEventDestroy(c->pinned_ev);
     for (auto& ev : c->ev)
@@ -328,6 +349,39 @@ int mvs_sketch_sumsq(mvs_ctx* c, const int32_t* sketches, int mem_in, int64_t n,
     return MVS_OK;
 }
 
+int mvs_sketch_stats(mvs_ctx* c, const int32_t* sketches, int mem_in, int64_t n, int d, int64_t* sumsq, int mem_out,
+                     int64_t* max_abs) {
+    if (!c || !max_abs) return fail(MVS_E_INVALID, "NULL argument");
+    *max_abs = 0;
+    if (n < 0 || d <= 0 || !mem_ok(mem_in) || !mem_ok(mem_out)) return fail(MVS_E_INVALID, "bad argument");
+    if (n == 0) return MVS_OK;
+    if (!sketches || !sumsq) return fail(MVS_E_INVALID, "NULL buffer");
+    HIP_TRY(hipSetDevice(c->device));
+    DevBuf din, dout;
+    const int32_t* d_in = sketches;
+    if (mem_in == MVS_MEM_HOST) {
+        HIP_TRY(din.alloc((size_t)n * d * 4));
+        HIP_TRY(hipMemcpyAsync(din.p, sketches, (size_t)n * d * 4, hipMemcpyHostToDevice, c->stream));
+        d_in = (const int32_t*)din.p;
+    }
+    int64_t* d_out = sumsq;
+    if (mem_out == MVS_MEM_HOST) {
+        HIP_TRY(dout.alloc((size_t)n * 8));
+        d_out = (int64_t*)dout.p;
+    }
+    HIP_TRY(hipMemsetAsync(c->d_counter, 0, 8, c->stream));
+    mvs::launch_stats(c->stream, d_in, n, d, d_out, c->d_counter);
+    int rc = check_kernel("k_stats");
+    if (rc) return rc;
+    if (mem_out == MVS_MEM_HOST)
+        HIP_TRY(hipMemcpyAsync(sumsq, d_out, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+    unsigned long long m = 0;
+    HIP_TRY(hipMemcpyAsync(&m, c->d_counter, 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    *max_abs = (int64_t)m;
+    return MVS_OK;
+}
+
 int mvs_sketch_saturate_i16(mvs_ctx* c, const int32_t* sketches, int mem_in, int64_t n_elems, int16_t* out,
                             int mem_out) {
     if (!c) return fail(MVS_E_INVALID, "ctx is NULL");
@@ -407,7 +461,8 @@ int mvs_limbs_for_max_abs(int64_t max_abs) {
 
 int mvs_limb_geometry(int64_t n, int d, int limbs, int64_t* n_alloc, int* d_pad, size_t* bytes) {
     if (n < 0 || d <= 0 || !mvs::limb_code_ok(limbs)) return fail(MVS_E_INVALID, "bad argument");
-    const int64_t na = (n + mvs::kTile - 1) / mvs::kTile * mvs::kTile + mvs::kTile;
+    // tiles are up to 256 rows: pad to a multiple of 256 plus one spare tile
+    const int64_t na = (n + 255) / 256 * 256 + 256;
     const int dp = (d + mvs::kBK - 1) / mvs::kBK * mvs::kBK;
     if (n_alloc) *n_alloc = na;
     if (d_pad) *d_pad = dp;
@@ -592,7 +647,7 @@ int mvs_pairwise_rows(mvs_ctx* c, const mvs_sketch_set* s, const double* norms_s
     if (capacity > 0 && !cells) return fail(MVS_E_INVALID, "cells is NULL");
     HIP_TRY(hipSetDevice(c->device));
 
-    DevBuf dn, dcells, dtmp, dthr, dsort;
+    DevBuf dn, dcells;
     const double* d_n2 = norms_sq;
     if (mem_norms == MVS_MEM_HOST) {
         HIP_TRY(dn.alloc((size_t)s->n * 8));
@@ -604,9 +659,13 @@ int mvs_pairwise_rows(mvs_ctx* c, const mvs_sketch_set* s, const double* norms_s
         HIP_TRY(dcells.alloc((size_t)capacity * sizeof(mvs_cell)));
         d_cells = (mvs_cell*)dcells.p;
     }
-    HIP_TRY(dthr.alloc((size_t)s->n_alloc * 4));
-    mvs::launch_cand_thr(c->stream, d_n2, s->n, s->n_alloc, s->d, (int32_t*)dthr.p);
-    int rc = check_kernel("k_cand_thr");
+    int rc = ensure_buf(c, &c->pw_thr, &c->pw_thr_bytes, (size_t)s->n_alloc * 4);
+    if (rc) return rc;
+    // kept cells are appended (unordered) to a staging buffer and merge-sorted into the caller's
+    rc = ensure_buf(c, &c->pw_tmp, &c->pw_tmp_bytes, (size_t)std::max<int64_t>(capacity, 1) * sizeof(mvs_cell));
+    if (rc) return rc;
+    mvs::launch_cand_thr(c->stream, d_n2, s->n, s->n_alloc, s->d, (int32_t*)c->pw_thr);
+    rc = check_kernel("k_cand_thr");
     if (rc) return rc;
     HIP_TRY(hipMemsetAsync(c->d_counter, 0, 8, c->stream));
 
@@ -622,9 +681,9 @@ int mvs_pairwise_rows(mvs_ctx* c, const mvs_sketch_set* s, const double* norms_s
     a.col_begin = 0;
     a.col_end = s->n;
     a.norms_sq = d_n2;
-    a.cand_thr = (const int32_t*)dthr.p;
+    a.cand_thr = (const int32_t*)c->pw_thr;
     a.keep_mode = keep_mode;
-    a.cells = d_cells;
+    a.cells = (mvs_cell*)c->pw_tmp;
     a.capacity = (unsigned long long)capacity;
     a.counter = c->d_counter;
     a.dots = nullptr;
@@ -632,7 +691,7 @@ int mvs_pairwise_rows(mvs_ctx* c, const mvs_sketch_set* s, const double* norms_s
         const char* dbg = getenv("MVS_PAIRWISE_DEBUG");
         a.debug_flags = dbg ? atoi(dbg) : 0;
         const char* sym = getenv("MVS_PAIRWISE_SYMMETRIC");   // default on; 0 computes every tile
-        a.symmetric = (row_begin % mvs::kTile == 0 && !(sym && atoi(sym) == 0)) ? 1 : 0;
+        a.symmetric = !(sym && atoi(sym) == 0) ? 1 : 0;   // the launcher also requires row_begin % tile == 0
     }
     if (c->timing) HIP_TRY(hipEventRecord(c->ev[2], c->stream));
     rc = mvs::launch_pairwise(c->stream, a, 0, 0);
@@ -652,18 +711,19 @@ int mvs_pairwise_rows(mvs_ctx* c, const mvs_sketch_set* s, const double* norms_s
     if (count == 0) return MVS_OK;
 
     // order by (row, col): the per-row ascending-column order of the reference's result list
-    HIP_TRY(dtmp.alloc((size_t)count * sizeof(mvs_cell)));
     size_t need = 0;
-    rc = mvs::sort_cells(c->stream, d_cells, (mvs_cell*)dtmp.p, (int64_t)count, nullptr, 0, &need);
+    rc = mvs::sort_cells(c->stream, (mvs_cell*)c->pw_tmp, d_cells, (int64_t)count, nullptr, 0, &need);
     if (rc) return fail(rc, "sort sizing failed");
-    HIP_TRY(dsort.alloc(need));
-    rc = mvs::sort_cells(c->stream, d_cells, (mvs_cell*)dtmp.p, (int64_t)count, dsort.p, need, nullptr);
+    rc = ensure_buf(c, &c->pw_sort, &c->pw_sort_bytes, need);
+    if (rc) return rc;
+    rc = mvs::sort_cells(c->stream, (mvs_cell*)c->pw_tmp, d_cells, (int64_t)count, c->pw_sort, c->pw_sort_bytes,
+                         nullptr);
     if (rc) return fail(rc, "sort failed");
-    if (mem_cells == MVS_MEM_HOST)
-        HIP_TRY(hipMemcpyAsync(cells, dtmp.p, (size_t)count * sizeof(mvs_cell), hipMemcpyDeviceToHost, c->stream));
-    else
-        HIP_TRY(hipMemcpyAsync(cells, dtmp.p, (size_t)count * sizeof(mvs_cell), hipMemcpyDeviceToDevice, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (mem_cells == MVS_MEM_HOST) {
+        HIP_TRY(hipMemcpyAsync(cells, d_cells, (size_t)count * sizeof(mvs_cell), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    // device output: the sort is queued on the context's stream; *n_cells is already final
     return MVS_OK;
 }
 

@@ -57,6 +57,8 @@ int launch_project(hipStream_t stream, const uint64_t* d_hashes, const ProjUnit*
                    int d, int32_t* d_out, int bpw);
 int launch_sumsq(hipStream_t stream, const int32_t* d_sk, int64_t n, int d, int64_t* d_out);
 int launch_saturate_i16(hipStream_t stream, const int32_t* d_in, int64_t n, int16_t* d_out);
+int launch_stats(hipStream_t stream, const int32_t* d_sk, int64_t n, int d, int64_t* d_sumsq,
+                 unsigned long long* d_max_abs);
 
 int launch_max_abs(hipStream_t stream, const void* d_sk, int elem_bytes, int64_t n_elems,
                    unsigned long long* d_out);

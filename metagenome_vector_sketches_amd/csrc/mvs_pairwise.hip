@@ -125,25 +125,31 @@ __device__ __forceinline__ void wait_vmcnt() {
 #undef MVS_VMCNT_CASE
 }
 
-// WN = waves along the column axis: 4 -> 8 waves, tile 128 x 128 samples (one workgroup per CU);
-//                                    2 -> 4 waves, tile 128 x 64 samples (two workgroups per CU, so
-//                                         one's barrier/copy waits overlap the other's MFMAs).
+// Geometry (template parameters):
+//   WM x WN waves; every wave owns 64 rows (two 32-row MFMA tiles) x BT*32 columns of the tile, so the
+//   workgroup tile is TM = WM*64 rows x TN = WN*BT*32 columns.  DBUF: fragments double buffered in
+//   registers (BT = 1); with BT = 2 the wave's 16 MFMAs per k-step are long enough for the SIMD's other
+//   wave to hide the fragment reads, and the 192 accumulator registers leave no room for a second buffer.
 // KARA: the L = 3 planes are (l0, l1, l0+l1) of base-128 digits; only the three "diagonal" products
 //       X = <l0,l0'>, Z = <l1,l1'>, Y = <l0+l1, l0'+l1'> are formed and P = X + 128(Y-X-Z) + 16384 Z.
-template <int L, bool KARA, int MODE, int NST, int WN>
-__global__ __launch_bounds__(2 * WN * 64, 2) void k_pairwise_mfma(const PairwiseArgs a, int n_tr, int n_tc,
-                                                                  int n_spc) {
+template <int L, bool KARA, int MODE, int NST, int WM, int WN, int BT>
+__global__ __launch_bounds__(WM * WN * 64, 2) void k_pairwise_mfma(const PairwiseArgs a, int n_tr, int n_tc,
+                                                                   int n_spc) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int kWavesT = 2 * WN;
-    constexpr int TN = WN * 32;                  // columns (B samples) per tile
-    constexpr int kRegion = L * kTile * kSK;     // bytes of the A operand region (128 samples)
-    constexpr int kRegionB = L * TN * kSK;       // bytes of the B operand region (TN samples)
+    constexpr int kWavesT = WM * WN;
+    constexpr int TM = WM * 64;                  // rows (A samples) per tile
+    constexpr int TN = WN * BT * 32;             // columns (B samples) per tile
+    constexpr bool DBUF = BT == 1;
+    constexpr int NB = DBUF ? 2 : 1;             // fragment register buffers
+    constexpr int kRegion = L * TM * kSK;        // bytes of the A operand region
+    constexpr int kRegionB = L * TN * kSK;       // bytes of the B operand region
     constexpr int kStage = kRegion + kRegionB;   // bytes of one stage
     constexpr int kPieces = kStage / 1024;       // 1 KiB pieces per stage
     constexpr int kPPW = kPieces / kWavesT;      // pieces per wave per stage
     constexpr int NS = KARA ? 3 : num_acc_sets(L);
     static_assert(!KARA || L == 3, "Karatsuba scheme has three planes");
     static_assert(kPieces % kWavesT == 0, "stage must split evenly over the waves");
+    static_assert(TM % TN == 0 || TN % TM == 0, "tile edges must nest");
 
     const TileCoord tc = map_tile(blockIdx.x, n_tr, n_tc, n_spc);
     if (!tc.valid) return;
@@ -151,19 +157,19 @@ __global__ __launch_bounds__(2 * WN * 64, 2) void k_pairwise_mfma(const Pairwise
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WN;   // 0..1 : 64-row half of the tile
-    const int wn = wave % WN;   // 32-col slice of the tile
+    const int wm = wave / WN;   // 64-row slice of the tile
+    const int wn = wave % WN;   // BT*32-column slice of the tile
 
-    const int64_t i0 = a.row_begin + (int64_t)tc.tr * kTile;   // first A sample of the tile
-    const int64_t j0 = a.col_begin + (int64_t)tc.tc * TN;      // first B sample of the tile
+    const int64_t i0 = a.row_begin + (int64_t)tc.tr * TM;   // first A sample of the tile
+    const int64_t j0 = a.col_begin + (int64_t)tc.tc * TN;   // first B sample of the tile
 
-    // Symmetric schedule (row_begin % 128 == 0, col_begin == 0): inside the square [row_begin,row_end)^2 a
-    // tile strictly below the diagonal is skipped; its cells come from the tile strictly above the
-    // diagonal that holds their transposes (see DESIGN.md K2 for the covering argument).
+    // Symmetric schedule (row_begin % TM == 0, col_begin == 0, TN | TM): inside the square
+    // [row_begin,row_end)^2 a tile strictly below the diagonal is skipped; its cells come from the tile
+    // strictly above the diagonal that holds their transposes (DESIGN.md K2 has the covering argument).
     bool mirror_tile = false;
     if (MODE == 0 && a.symmetric) {
         if (j0 >= a.row_begin && j0 + TN <= i0) return;
-        mirror_tile = j0 >= i0 + kTile && j0 < a.row_end;
+        mirror_tile = j0 >= i0 + TM && j0 < a.row_end;
     }
 
     // ---- per-lane source pointers of this wave's pieces (k0 = 0).  One piece = 16 LDS rows of 64 B;
@@ -173,10 +179,10 @@ __global__ __launch_bounds__(2 * WN * 64, 2) void k_pairwise_mfma(const Pairwise
     for (int p = 0; p < kPPW; ++p) {
         const int piece = wave * kPPW + p;
         const int row = piece * 16 + (lane >> 2);
-        const bool is_b = row >= L * kTile;
-        const int rr = is_b ? row - L * kTile : row;
-        const int limb = is_b ? rr / TN : rr / kTile;
-        const int s = is_b ? rr % TN : rr % kTile;
+        const bool is_b = row >= L * TM;
+        const int rr = is_b ? row - L * TM : row;
+        const int limb = is_b ? rr / TN : rr / TM;
+        const int s = is_b ? rr % TN : rr % TM;
         const int c = (lane & 3) ^ ((s >> 2) & 3);
         const int64_t sample = (is_b ? j0 : i0) + s;
         src[p] = a.planes + (sample * L + limb) * (int64_t)a.d_pad + c * 16;
@@ -194,43 +200,51 @@ __global__ __launch_bounds__(2 * WN * 64, 2) void k_pairwise_mfma(const Pairwise
     const int fr = lane & 31;          // row (A) / col (B) inside a 32x32 MFMA tile
     const int fh = lane >> 5;          // k half
     const int key = (fr >> 2) & 3;     // swizzle key (tile bases are multiples of 16 samples)
-    const int a_row0 = (wm * 64 + fr) * kSK;                   // + t*32*kSK + limb*kTile*kSK
-    const int b_row0 = kRegion + (wn * 32 + fr) * kSK;         // + limb*kTile*kSK
+    const int a_row0 = (wm * 64 + fr) * kSK;                         // + t*32*kSK + limb*TM*kSK
+    const int b_row0 = kRegion + (wn * BT * 32 + fr) * kSK;          // + u*32*kSK + limb*TN*kSK
 
-    v16i acc[2][NS];
+    v16i acc[2][BT][NS];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int s = 0; s < NS; ++s)
+        for (int u = 0; u < BT; ++u)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[t][s][r] = 0;
+            for (int s = 0; s < NS; ++s)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][u][s][r] = 0;
 
-    // Fragments are double buffered in registers: the ds_reads of k-step kk+1 are issued before the
-    // MFMAs of k-step kk, so the matrix pipe never waits for LDS.
-    v4i fa[2][2][L], fb[2][L];
+    v4i fa[NB][2][L], fb[NB][BT][L];
     auto load_frags = [&](int buf, const char* sb, int kk) {
         const int coff = (((kk * 2 + fh) ^ key) << 4);
 #pragma unroll
         for (int l = 0; l < L; ++l) {
-            fb[buf][l] = *reinterpret_cast<const v4i*>(sb + b_row0 + l * TN * kSK + coff);
+#pragma unroll
+            for (int u = 0; u < BT; ++u)
+                fb[buf][u][l] = *reinterpret_cast<const v4i*>(sb + b_row0 + u * 32 * kSK + l * TN * kSK + coff);
 #pragma unroll
             for (int t = 0; t < 2; ++t)
-                fa[buf][t][l] = *reinterpret_cast<const v4i*>(sb + a_row0 + t * 32 * kSK + l * kTile * kSK + coff);
+                fa[buf][t][l] = *reinterpret_cast<const v4i*>(sb + a_row0 + t * 32 * kSK + l * TM * kSK + coff);
         }
     };
-    auto mfma_group = [&](int buf) {
+    // part 0: the group's first MFMA, part 1: the rest, part 2: all.  Splitting lets the loop put the
+    // fragment reads of the NEXT k-step between them: hipcc waits lgkmcnt(0) in front of the first MFMA
+    // after the loop back-edge, and that wait must not cover reads issued for the next step.
+    auto mfma_group = [&](int buf, int part) {
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int la = 0; la < L; ++la)
+            for (int u = 0; u < BT; ++u)
 #pragma unroll
-                for (int lb = 0; lb < L; ++lb) {
-                    if (KARA ? (la != lb) : (la + lb > 3)) continue;   // 256^4 == 0 (mod 2^32)
-                    constexpr int dummy = 0;
-                    (void)dummy;
-                    const int s = KARA ? la : la + lb;
-                    acc[t][s] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[buf][t][la], fb[buf][lb], acc[t][s], 0, 0, 0);
-                }
+                for (int la = 0; la < L; ++la)
+#pragma unroll
+                    for (int lb = 0; lb < L; ++lb) {
+                        if (KARA ? (la != lb) : (la + lb > 3)) continue;   // 256^4 == 0 (mod 2^32)
+                        const bool first = t == 0 && u == 0 && la == 0 && lb == 0;
+                        if ((part == 0 && !first) || (part == 1 && first)) continue;
+                        const int s = KARA ? la : la + lb;
+                        acc[t][u][s] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[buf][t][la], fb[buf][u][lb],
+                                                                            acc[t][u][s], 0, 0, 0);
+                    }
     };
 
     // ---- main loop over 64-byte k-slices ----
@@ -246,7 +260,7 @@ __global__ __launch_bounds__(2 * WN * 64, 2) void k_pairwise_mfma(const Pairwise
     if (nk >= NST - 1) wait_vmcnt<(NST - 2) * kPPW>();
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
-    load_frags(0, smem, 0);
+    if (DBUF) load_frags(0, smem, 0);
 
     int slot = 0;
     for (int kt = 0; kt < nk; ++kt) {
@@ -256,10 +270,21 @@ __global__ __launch_bounds__(2 * WN * 64, 2) void k_pairwise_mfma(const Pairwise
             const int nslot = slot == 0 ? NST - 1 : slot - 1;
             if (kt + NST - 1 < nk) stage_copy(nslot, (kt + NST - 1) * kSK);
         }
-        load_frags(1, sb, 1);
-        __builtin_amdgcn_sched_barrier(0);   // keep the reads of the next k-step ahead of these MFMAs
-        mfma_group(0);
-        __builtin_amdgcn_sched_barrier(0);
+        if (DBUF) {
+            mfma_group(0, 0);                    // needs only fragments read before the back-edge
+            __builtin_amdgcn_sched_barrier(0);
+            load_frags(1, sb, 1);                // in flight during the rest of this group
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_group(0, 1);
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
+            load_frags(0, sb, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_group(0, 2);
+            __builtin_amdgcn_sched_barrier(0);
+            load_frags(0, sb, 1);                // last reads of this slice
+            __builtin_amdgcn_sched_barrier(0);
+        }
         // slice kt+1 must have landed: allow only the copies of younger slices to be outstanding
         {
             const int younger = nk - kt - 2;   // slices issued after kt+1
@@ -271,10 +296,14 @@ __global__ __launch_bounds__(2 * WN * 64, 2) void k_pairwise_mfma(const Pairwise
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's reads of slice kt are done
         __builtin_amdgcn_s_barrier();
         slot = slot == NST - 1 ? 0 : slot + 1;
-        load_frags(0, smem + slot * kStage, 0);   // unconditional: after the last slice this reads a stale
-                                                 // (in-bounds) slot and the values are never used
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_group(1);
+        if (DBUF) {
+            load_frags(0, smem + slot * kStage, 0);   // unconditional: after the last slice this reads a
+                                                     // stale (in-bounds) slot and the values are never used
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_group(1, 2);
+        } else {
+            mfma_group(0, 2);
+        }
         __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
@@ -285,45 +314,50 @@ __global__ __launch_bounds__(2 * WN * 64, 2) void k_pairwise_mfma(const Pairwise
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int sset = 0; sset < NS; ++sset) x ^= acc[t][sset][0] ^ acc[t][sset][15];
+            for (int u = 0; u < BT; ++u)
+#pragma unroll
+                for (int sset = 0; sset < NS; ++sset) x ^= acc[t][u][sset][0] ^ acc[t][u][sset][15];
         if (x == 0x7fffffff) a.counter[1] = 1;
         return;
     }
-    int32_t* thr = reinterpret_cast<int32_t*>(smem);   // [0,128): rows, [128,256): cols
+    int32_t* thr = reinterpret_cast<int32_t*>(smem);   // [0,TM): rows, [TM,TM+TN): cols
     if (MODE == 0) {
-        for (int x = tid; x < kTile + TN; x += kWavesT * 64) {
-            const int64_t g = (x < kTile ? i0 : j0 - kTile) + x;
+        for (int x = tid; x < TM + TN; x += kWavesT * 64) {
+            const int64_t g = (x < TM ? i0 : j0 - TM) + x;
             thr[x] = a.cand_thr[g];
         }
         __syncthreads();
     }
-    const int col_l = wn * 32 + fr;
-    const int64_t col = j0 + col_l;
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int u = 0; u < BT; ++u) {
+        const int col_l = (wn * BT + u) * 32 + fr;
+        const int64_t col = j0 + col_l;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row_l = wm * 64 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-            const int64_t row = i0 + row_l;
-            uint32_t Pu = (uint32_t)acc[t][0][r];
-            if (KARA) {
-                const uint32_t X = Pu, Z = (uint32_t)acc[t][1][r], Y = (uint32_t)acc[t][NS - 1][r];
-                Pu = X + ((Y - X - Z) << 7) + (Z << 14);
-            } else {
+        for (int t = 0; t < 2; ++t) {
 #pragma unroll
-                for (int s = 1; s < NS; ++s) Pu += (uint32_t)acc[t][s][r] << (8 * s);
-            }
-            const int32_t P = (int32_t)Pu;
-            if (MODE == 1) {
-                if (row < a.row_end && col < a.col_end)
-                    a.dots[(row - a.row_begin) * (a.col_end - a.col_begin) + (col - a.col_begin)] = P;
-            } else {
-                const bool cand = P >= thr[row_l] + thr[kTile + col_l];
-                if (__any(cand)) {
-                    bool keep = false;
-                    if (cand && row < a.row_end && col < a.col_end)
-                        keep = keep_cell(P, a.d, a.norms_sq[row], a.norms_sq[col], a.keep_mode);
-                    emit_cell(a, keep, mirror_tile && col < a.row_end, (int32_t)row, (int32_t)col, P, lane);
+            for (int r = 0; r < 16; ++r) {
+                const int row_l = wm * 64 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                const int64_t row = i0 + row_l;
+                uint32_t Pu = (uint32_t)acc[t][u][0][r];
+                if (KARA) {
+                    const uint32_t X = Pu, Z = (uint32_t)acc[t][u][1][r], Y = (uint32_t)acc[t][u][NS - 1][r];
+                    Pu = X + ((Y - X - Z) << 7) + (Z << 14);
+                } else {
+#pragma unroll
+                    for (int s = 1; s < NS; ++s) Pu += (uint32_t)acc[t][u][s][r] << (8 * s);
+                }
+                const int32_t P = (int32_t)Pu;
+                if (MODE == 1) {
+                    if (row < a.row_end && col < a.col_end)
+                        a.dots[(row - a.row_begin) * (a.col_end - a.col_begin) + (col - a.col_begin)] = P;
+                } else {
+                    const bool cand = P >= thr[row_l] + thr[TM + col_l];
+                    if (__any(cand)) {
+                        bool keep = false;
+                        if (cand && row < a.row_end && col < a.col_end)
+                            keep = keep_cell(P, a.d, a.norms_sq[row], a.norms_sq[col], a.keep_mode);
+                        emit_cell(a, keep, mirror_tile && col < a.row_end, (int32_t)row, (int32_t)col, P, lane);
+                    }
                 }
             }
         }
@@ -464,53 +498,60 @@ struct CellLess {
     }
 };
 
-// Kernel variant: MVS_PAIRWISE_VARIANT=0 -> 8 waves, 128x128 tile, 4-stage ring (default)
-//                                      1 -> 4 waves, 128x64 tile, 3-stage ring, two workgroups per CU
-//                                      2 -> 8 waves, 128x128 tile, 5-stage ring
-//                                      3 -> 4 waves, 128x64 tile, 2-stage ring
+// Kernel variant (MVS_PAIRWISE_VARIANT):
+//   0 -> 8 waves 2x4, wave tile 64x32, tile 128x128, 4-stage ring          (double-buffered fragments)
+//   1 -> 4 waves 2x2, wave tile 64x32, tile 128x64,  3-stage ring, two workgroups per CU
+//   2 -> 8 waves 2x4, wave tile 64x32, tile 128x128, 5-stage ring
+//   3 -> 4 waves 2x2, wave tile 64x32, tile 128x64,  2-stage ring
+//   4 -> 8 waves 4x2, wave tile 64x64, tile 256x128, 3-stage ring          (fewer LDS/L2 bytes per MFMA)
+//   5 -> 8 waves 2x4, wave tile 64x64, tile 128x256, 3-stage ring
 int pairwise_variant() {
     static int v = -1;
     if (v < 0) {
         const char* e = getenv("MVS_PAIRWISE_VARIANT");
         v = e ? atoi(e) : 0;
-        if (v < 0 || v > 3) v = 0;
+        if (v < 0 || v > 5) v = 0;
     }
     return v;
 }
 
-template <int L, bool KARA, int MODE, int NST, int WN>
+template <int L, bool KARA, int MODE, int NST, int WM, int WN, int BT>
 int launch_mfma_variant(hipStream_t stream, const PairwiseArgs& a) {
-    constexpr int TN = WN * 32;
+    constexpr int TM = WM * 64, TN = WN * BT * 32;
     const int64_t rows = a.row_end - a.row_begin, cols = a.col_end - a.col_begin;
     if (rows <= 0 || cols <= 0) return 0;
-    const int n_tr = (int)((rows + kTile - 1) / kTile), n_tc = (int)((cols + TN - 1) / TN);
+    const int n_tr = (int)((rows + TM - 1) / TM), n_tc = (int)((cols + TN - 1) / TN);
     const int n_spr = (n_tr + 15) / 16, n_spc = (n_tc + 15) / 16;
     const int64_t blocks = (int64_t)n_spr * n_spc * 256;
     if (blocks > 0x7fffffffLL) return MVS_E_INVALID;
-    const size_t lds = (size_t)NST * L * (kTile + TN) * kSK;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pairwise_mfma<L, KARA, MODE, NST, WN>),
+    const size_t lds = (size_t)NST * L * (TM + TN) * kSK;
+    PairwiseArgs b = a;
+    if (b.symmetric && (a.row_begin % TM != 0 || TM % TN != 0)) b.symmetric = 0;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pairwise_mfma<L, KARA, MODE, NST, WM, WN, BT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return MVS_E_HIP;
-    hipLaunchKernelGGL((k_pairwise_mfma<L, KARA, MODE, NST, WN>), dim3((unsigned)blocks), dim3(2 * WN * 64), lds,
-                       stream, a, n_tr, n_tc, n_spc);
+    hipLaunchKernelGGL((k_pairwise_mfma<L, KARA, MODE, NST, WM, WN, BT>), dim3((unsigned)blocks), dim3(WM * WN * 64),
+                       lds, stream, b, n_tr, n_tc, n_spc);
     return 0;
 }
 
 template <int L, bool KARA, int MODE>
 int launch_mfma(hipStream_t stream, const PairwiseArgs& a) {
-    if constexpr (KARA) {   // 48 KB per stage: at most three stages fit the 160 KB of LDS
+    if constexpr (KARA) {   // 48 KB per 128x128 stage: at most three stages fit the 160 KB of LDS
         switch (pairwise_variant()) {
-            case 1: return launch_mfma_variant<L, KARA, MODE, 3, 2>(stream, a);
-            case 3: return launch_mfma_variant<L, KARA, MODE, 2, 2>(stream, a);
-            case 2: return launch_mfma_variant<L, KARA, MODE, 2, 4>(stream, a);
-            default: return launch_mfma_variant<L, KARA, MODE, 3, 4>(stream, a);
+            case 1: return launch_mfma_variant<L, KARA, MODE, 3, 2, 2, 1>(stream, a);
+            case 3: return launch_mfma_variant<L, KARA, MODE, 2, 2, 2, 1>(stream, a);
+            case 2: return launch_mfma_variant<L, KARA, MODE, 2, 2, 4, 1>(stream, a);
+            default: return launch_mfma_variant<L, KARA, MODE, 3, 2, 4, 1>(stream, a);
         }
     } else {
         switch (pairwise_variant()) {
-            case 1: return launch_mfma_variant<L, KARA, MODE, 3, 2>(stream, a);
-            case 2: return launch_mfma_variant<L, KARA, MODE, 5, 4>(stream, a);
-            case 3: return launch_mfma_variant<L, KARA, MODE, 2, 2>(stream, a);
-            default: return launch_mfma_variant<L, KARA, MODE, 4, 4>(stream, a);
+            case 1: return launch_mfma_variant<L, KARA, MODE, 3, 2, 2, 1>(stream, a);
+            case 2: return launch_mfma_variant<L, KARA, MODE, 5, 2, 4, 1>(stream, a);
+            case 3: return launch_mfma_variant<L, KARA, MODE, 2, 2, 2, 1>(stream, a);
+            case 4: return launch_mfma_variant<L, KARA, MODE, 3, 4, 2, 2>(stream, a);
+            case 5: return launch_mfma_variant<L, KARA, MODE, 3, 2, 4, 2>(stream, a);
+            default: return launch_mfma_variant<L, KARA, MODE, 4, 2, 4, 1>(stream, a);
         }
     }
 }

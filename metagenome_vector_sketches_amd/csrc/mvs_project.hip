@@ -285,6 +285,43 @@ __global__ __launch_bounds__(256) void k_sumsq(const int32_t* __restrict__ sk, i
     if (lane == 0) out[row] = acc;
 }
 
+// one wave per sketch row: exact int64 sum of squares AND the largest |v| of the whole array (one pass)
+__global__ __launch_bounds__(256) void k_stats(const int32_t* __restrict__ sk, int64_t n, int d,
+                                               int64_t* __restrict__ sumsq, unsigned long long* __restrict__ max_abs) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const int32_t* p = sk + row * d;
+    long long acc = 0;
+    unsigned int m = 0;
+    if ((d & 3) == 0 && ((uintptr_t)p & 15) == 0) {
+        const int4* p4 = reinterpret_cast<const int4*>(p);
+        for (int k = lane; k < d / 4; k += 64) {
+            const int4 v = p4[k];
+            const long long a = v.x, b = v.y, c = v.z, e = v.w;
+            acc += a * a + b * b + c * c + e * e;
+            const unsigned int ma = (unsigned int)(a < 0 ? -a : a), mb = (unsigned int)(b < 0 ? -b : b);
+            const unsigned int mc = (unsigned int)(c < 0 ? -c : c), me = (unsigned int)(e < 0 ? -e : e);
+            m = max(max(m, max(ma, mb)), max(mc, me));
+        }
+    } else {
+        for (int k = lane; k < d; k += 64) {
+            const long long v = p[k];
+            acc += v * v;
+            m = max(m, (unsigned int)(v < 0 ? -v : v));
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        acc += __shfl_xor(acc, o, 64);
+        m = max(m, (unsigned int)__shfl_xor((int)m, o, 64));
+    }
+    if (lane == 0) {
+        sumsq[row] = acc;
+        if (m) atomicMax(max_abs, (unsigned long long)m);
+    }
+}
+
 __global__ __launch_bounds__(256) void k_saturate_i16(const int32_t* __restrict__ in, int64_t n,
                                                       int16_t* __restrict__ out) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -320,6 +357,13 @@ int launch_project(hipStream_t stream, const uint64_t* d_hashes, const ProjUnit*
 int launch_sumsq(hipStream_t stream, const int32_t* d_sk, int64_t n, int d, int64_t* d_out) {
     if (n == 0) return 0;
     hipLaunchKernelGGL(k_sumsq, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, d_sk, n, d, d_out);
+    return 0;
+}
+
+int launch_stats(hipStream_t stream, const int32_t* d_sk, int64_t n, int d, int64_t* d_sumsq,
+                 unsigned long long* d_max_abs) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_stats, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, d_sk, n, d, d_sumsq, d_max_abs);
     return 0;
 }
 

@@ -68,16 +68,21 @@ class ShardedComparison:
         if world > 1 and dist is None:
             raise ValueError("world > 1 needs torch.distributed")
 
-    def run(self, sketches_local, norms_sq_local, n_total, keep_mode=_capi.KEEP_INT32, cells_out=None):
+    def run(self, sketches_local, norms_sq_local, n_total, keep_mode=_capi.KEEP_INT32, cells_out=None,
+            max_abs_local=None):
         """sketches_local: this rank's rows (int32/int16 [n_local, d]); norms_sq_local: host float64
-        [n_local].  Returns (cells, n_cells, info) for this rank's shard."""
+        [n_local]; max_abs_local: largest |v| of sketches_local if the caller already has it
+        (Context.stats).  Returns (cells, n_cells, info) for this rank's shard."""
         ops, dist, rank, world = self.ops, self.dist, self.rank, self.world
         n_local, d = sketches_local.shape
         rb, re = shard_rows(n_total, world, rank)
         if re - rb != n_local:
             raise ValueError("rank %d holds %d rows but its shard is [%d,%d)" % (rank, n_local, rb, re))
         rps = (n_total + world - 1) // world            # rows per shard = block size of the all-gather
-        max_abs = ops.max_abs(sketches_local) if n_local else 0
+        if max_abs_local is not None:
+            max_abs = int(max_abs_local)
+        else:
+            max_abs = ops.max_abs(sketches_local) if n_local else 0
         if world > 1:
             import torch
             t = ops.to_device(np.array([max_abs], dtype=np.int64))

@@ -121,3 +121,12 @@ def test_bad_arguments(ctx):
         ctx.project_csr(h, o, 0)
     with pytest.raises(MvsError):
         ctx.project_csr(h, np.array([0, 3, 2], dtype=np.int64), 64)
+
+
+def test_stats_one_pass(ctx, gold):
+    ss, m = ctx.stats(gold.vectors)
+    assert ss.tolist() == [gold.digests[n]["sumsq"] for n in gold.names]
+    assert m == int(np.abs(gold.vectors).max())
+    v = np.array([[-2**31, 5, 0], [7, -9, 1]], dtype=np.int32)      # d % 4 != 0 path, INT32_MIN
+    ss, m = ctx.stats(v)
+    assert ss.tolist() == [2**62 + 25, 131] and m == 2**31

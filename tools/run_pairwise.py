@@ -19,6 +19,9 @@ ctx = pkg.Context(0)
 ctx.set_stream(torch.cuda.current_stream())
 ctx.set_timing(True)
 sk = synth.make_sketches_torch(n, d, 50_000, seed=2345, device="cuda")
+if os.environ.get("ZERO_DATA") == "1":       # power experiment: same instruction stream on all-zero operands
+    sk.zero_()
+    sk[:, 0] = 200                            # keeps limbs == 2 (max |v| > 127)
 ss = torch.empty(n, dtype=torch.int64, device="cuda")
 ctx.sumsq(sk, out=ss)
 n2 = torch.from_numpy(np.sqrt(ss.cpu().numpy() / d) ** 2).to("cuda")
