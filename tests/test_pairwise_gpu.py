@@ -192,3 +192,49 @@ def test_sharded_comparison_single_rank(ctx):
     ctx.synchronize()
     got = [tuple(int(x) for x in row) for row in cells_dev[:cnt].cpu().numpy()]
     assert got == _oracle_sorted(sk, n2, chunk=192) and info["limbs"] in (2, K3)
+
+
+def test_baseline_config2_full_size(ctx):
+    """BASELINE.json configs[1] at full size (10 000 samples x 50 000 hashes, d = 2048) through the same
+    calls bench.py makes: too big for the oracle as a whole, so size-independent properties + oracle spot
+    checks.  Projection: parity/bounds of every entry, cluster structure visible in the norms; pairwise:
+    symmetric kept set, diagonal q = 255, ~16 mates per row, 48 rows and 3 sketches against the oracle."""
+    import torch
+    from metagenome_vector_sketches_amd import parallel
+    S, NH, D = 10_000, 50_000, 2048
+    hashes, offsets = synth.make_csr_torch(S, NH, seed=1234, device="cuda", cluster=16, shared=0.4)
+    sk_t = torch.empty((S, D), dtype=torch.int32, device="cuda")
+    ctx.set_stream(torch.cuda.current_stream())
+    try:
+        ctx.project_csr(hashes, offsets, D, out=sk_t)
+        sumsq_t = torch.empty(S, dtype=torch.int64, device="cuda")
+        _, max_abs = ctx.stats(sk_t, out=sumsq_t)
+        sk = sk_t.cpu().numpy()
+        assert np.all((sk - NH) % 2 == 0) and max_abs == int(np.abs(sk).max()) < 8 * NH ** 0.5
+        hh = hashes.cpu().numpy().view(np.uint64)
+        for s in (0, 4999, 9999):
+            assert np.array_equal(sk[s], orc.project(hh[offsets[s]:offsets[s + 1]], D))
+        sumsq = sumsq_t.cpu().numpy()
+        assert np.array_equal(sumsq[:64], (sk[:64].astype(np.int64) ** 2).sum(1))
+        n2 = _n2_from_sketches(sk)
+        assert np.allclose(n2, NH, rtol=0.2)                        # E[sum v^2 / d] = n
+        sc = parallel.ShardedComparison(parallel.GpuOps(ctx, "cuda:0"), 0, 1, None)
+        cells_dev = torch.empty((1 << 20, 4), dtype=torch.int32, device="cuda")
+        _, cnt, info = sc.run(sk_t, n2, S, cells_out=cells_dev, max_abs_local=max_abs)
+        ctx.synchronize()
+        cells = cells_dev[:cnt].cpu().numpy()
+    finally:
+        ctx.set_stream(None)
+    rows, cols, q = cells[:, 0], cells[:, 1], cells[:, 3]
+    key = rows.astype(np.int64) * S + cols
+    assert np.all(np.diff(key) > 0)                                  # sorted by (row, col), no duplicates
+    assert np.array_equal(np.sort(cols.astype(np.int64) * S + rows), key)   # symmetric kept set
+    diag = cells[rows == cols]
+    assert len(diag) == S and np.all(diag[:, 3] == 255)
+    per_row = np.bincount(rows, minlength=S)
+    assert per_row.min() >= 16 and per_row.mean() < 17.5             # 16 cluster members (incl. self) + rare chance hits
+    same_cluster = (rows // 16) == (cols // 16)
+    assert same_cluster.sum() == S * 16
+    want = _oracle_sorted(sk, n2, row_begin=5000, row_end=5048, chunk=192)
+    got = [tuple(int(x) for x in c) for c in cells[(rows >= 5000) & (rows < 5048)]]
+    assert got == want
