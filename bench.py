@@ -81,13 +81,20 @@ def main():
         if rank == 0:
             print("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus), file=sys.stderr)
         sys.exit(2)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # rehearsal on a one-GPU box: MVS_BENCH_REHEARSAL=1 puts every rank on device 0 and uses gloo for the
+    # collectives (RCCL refuses two ranks on one device); the driver's multi-GPU runs use nccl (= RCCL)
+    rehearsal = os.environ.get("MVS_BENCH_REHEARSAL") == "1"
+    dev_index = 0 if rehearsal else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     S, NH, D = args.samples, args.hashes, args.dim
-    ctx = pkg.Context(local_rank)
+    ctx = pkg.Context(dev_index)
     stream = torch.cuda.current_stream()
     ctx.set_stream(stream)
     ctx.set_timing(True)
