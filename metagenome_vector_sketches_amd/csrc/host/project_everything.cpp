@@ -3,10 +3,12 @@
 // the command line, stdout lines and the four DB files are the reference's.
 //
 //   project_everything sketch  <hash_file> <index_folder> [-t/--threads N] [-d/--dimension D] [--int16]
-//   project_everything convert <signature_folder> <hash_file> [-t/--threads N]      (not in this build)
+//   project_everything convert <signature_folder> <hash_file> [-t/--threads N]      (host only, zlib)
 #include <chrono>
+#include <mutex>
 
 #include "mvs_host.hpp"
+#include "mvs_ingest.hpp"
 
 namespace fs = std::filesystem;
 using namespace mvs_host;
@@ -25,6 +27,60 @@ static void usage(const char* argv0) {   // src/project_everything.cpp:394-407, 
     std::cerr << "      -t, --threads    : Number of threads (default: 1)\n";
     std::cerr << "      -d, --dimension  : Vector dimension (default: 2048)\n";
     std::cerr << "      --int16          : Use int16 instead of int32 for vector storage\n";
+}
+
+// src/project_everything.cpp:181-235.  Differences: archives are read in-process (no unzip/gunzip, no
+// /tmp/signature_extract*), hashes are written sorted, and the reference's side file ./all_hashes.txt
+// (appended in the current directory, :160-176) is not produced.
+static int convert(const std::string& folder_name, const std::string& output_file, int num_threads) {
+    auto start = std::chrono::high_resolution_clock::now();
+    std::vector<std::string> sig_files;
+    std::error_code ec;
+    for (const auto& entry : fs::directory_iterator(folder_name, ec)) sig_files.push_back(entry.path().string());
+    if (ec) {
+        std::cerr << "Error reading folder " << folder_name << std::endl;
+        return 0;
+    }
+    std::ofstream hash_out(output_file);
+    if (!hash_out) {
+        std::cerr << "Error opening " << output_file << " for writing." << std::endl;
+        return 0;
+    }
+    std::vector<std::pair<std::string, std::vector<uint64_t>>> results(sig_files.size());
+    std::mutex io;
+    const unsigned nt = (unsigned)std::max(1, std::min<int>(num_threads, (int)std::max<size_t>(1, sig_files.size())));
+    std::vector<std::thread> pool;
+    for (unsigned t = 0; t < nt; ++t)
+        pool.emplace_back([&, t]() {
+            for (size_t i = t; i < sig_files.size(); i += nt) {
+                std::vector<uint64_t> hashes;
+                if (!mvs_ingest::load_signatures(sig_files[i], hashes)) {
+                    std::lock_guard<std::mutex> g(io);
+                    std::cerr << "Failed to unzip: " << sig_files[i] << std::endl;
+                }
+                const std::string stem = fs::path(sig_files[i]).stem().string();
+                results[i] = {stem.substr(0, stem.find('.')), std::move(hashes)};
+                std::lock_guard<std::mutex> g(io);
+                std::cout << "Processed " << sig_files[i] << ", hashes size " << results[i].second.size()
+                          << ", file number " << i << std::endl;
+            }
+        });
+    for (auto& th : pool) th.join();
+    std::string line;
+    for (const auto& r : results) {
+        line = r.first + ":";
+        for (uint64_t h : r.second) {
+            line += ' ';
+            line += std::to_string(h);
+        }
+        line += '\n';
+        hash_out << line;
+    }
+    hash_out.close();
+    auto end = std::chrono::high_resolution_clock::now();
+    std::chrono::duration<double> elapsed = end - start;
+    std::cout << "Time to convert all signatures: " << elapsed.count() << " seconds" << std::endl;
+    return 0;
 }
 
 static bool parse_int(const char* s, int& out) {
@@ -150,12 +206,8 @@ int main(int argc, char* argv[]) {
         usage(argv[0]);
         return 1;
     }
+    if (is_convert) return convert(input_path, output_path, t);
     (void)t;   // the reference parses -t for sketch but never applies it (:384 vs :238)
-    if (is_convert) {
-        std::cerr << "convert: signature ingest is not part of this build (hot-path scope, DESIGN.md); "
-                     "use the reference's convert to produce the hash file" << std::endl;
-        return 3;
-    }
     if (d <= 0) {
         std::cerr << "dimension must be positive" << std::endl;
         return 1;
