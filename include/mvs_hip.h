@@ -172,6 +172,24 @@ int mvs_pairwise_rows(mvs_ctx* ctx, const mvs_sketch_set* set, const double* nor
                       int keep_mode, int64_t row_begin, int64_t row_end, mvs_cell* cells,
                       int64_t capacity, int mem_cells, int64_t* n_cells);
 
+/* One rectangular block of the comparison -- rows [row_begin,row_end) x columns [col_begin,col_end) -- for
+ * schedules that split a shard's work by column block (metagenome_vector_sketches_amd/parallel.py: with G
+ * shards every unordered pair of row blocks is compared ONCE and the mirrored cells are exchanged).
+ *   flags : MVS_BLOCK_SYMMETRIC  the column range contains the square of the row range: inside it tiles
+ *                                strictly below the diagonal are skipped and produced by mirroring (this is
+ *                                what mvs_pairwise_rows does on its own);
+ *           MVS_BLOCK_MIRROR_ALL every kept (row, col) is also appended as (col, row) -- the transposed block
+ *                                belongs to another shard, which then does not compute it.
+ *   norms_sq, cells : DEVICE buffers.  Cells are APPENDED, unsorted, at index *n_cells (in/out);
+ *   MVS_E_CAPACITY reports the needed total in *n_cells.  Order them with mvs_cells_sort.  Synchronous. */
+#define MVS_BLOCK_SYMMETRIC   1
+#define MVS_BLOCK_MIRROR_ALL  2
+int mvs_pairwise_block(mvs_ctx* ctx, const mvs_sketch_set* set, const double* norms_sq, int keep_mode,
+                       int64_t row_begin, int64_t row_end, int64_t col_begin, int64_t col_end, int flags,
+                       mvs_cell* cells, int64_t capacity, int64_t* n_cells);
+/* Sort n cells by (row, col) from one DEVICE buffer into another (asynchronous on the context's stream). */
+int mvs_cells_sort(mvs_ctx* ctx, const mvs_cell* cells_in, int64_t n, mvs_cell* cells_out);
+
 /* Dense int32 dot products of rows [r0,r1) x cols [c0,c1) (row-major, leading dimension c1-c0):
  * the bare `block_i.transpose() * block_j` of src/pairwise_comp_optimized.cpp:135.  For validation
  * and small problems.  `algo` 0 = matrix-core path, 1 = plain vector-ALU path (independent check). */

@@ -16,6 +16,7 @@ MVS_OK, MVS_E_INVALID, MVS_E_HIP, MVS_E_CAPACITY, MVS_E_NOMEM, MVS_E_RANGE = 0, 
 MEM_HOST, MEM_DEVICE = 0, 1
 KEEP_INT32, KEEP_INT16 = 0, 1
 LIMBS_K3 = 0x103
+BLOCK_SYMMETRIC, BLOCK_MIRROR_ALL = 1, 2
 
 CELL_DTYPE = np.dtype([("row", "<i4"), ("col", "<i4"), ("dot", "<i4"), ("q", "<i4")])
 
@@ -53,6 +54,9 @@ SYMBOLS = [
     ("mvs_sketch_set_destroy", _c.c_int, [_P]),
     ("mvs_pairwise_rows", _c.c_int, [_P, _P, _P, _c.c_int, _c.c_int, _c.c_int64, _c.c_int64, _P, _c.c_int64,
                                       _c.c_int, _c.POINTER(_c.c_int64)]),
+    ("mvs_pairwise_block", _c.c_int, [_P, _P, _P, _c.c_int, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int,
+                                       _P, _c.c_int64, _c.POINTER(_c.c_int64)]),
+    ("mvs_cells_sort", _c.c_int, [_P, _P, _c.c_int64, _P]),
     ("mvs_pairwise_dots", _c.c_int, [_P, _P, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _P, _c.c_int,
                                       _c.c_int]),
     ("mvs_chunk_size", _c.c_int64, [_c.c_double, _c.c_int]),
@@ -310,6 +314,26 @@ class Context:
                 continue
             _check(rc)
             return cells[:count.value], count.value
+
+    def pairwise_block(self, sset, norms_sq, row_begin, row_end, col_begin, col_end, flags, cells, n_cells,
+                       keep_mode=KEEP_INT32):
+        """Append the kept cells of one block to the device buffer `cells` ([capacity, 4] int32) at index
+        n_cells; returns the new count."""
+        np_, nm, nk = _buf(norms_sq)
+        cp, cm, ck = _buf(cells)
+        if nm != MEM_DEVICE or cm != MEM_DEVICE:
+            raise ValueError("norms_sq and cells must be device buffers")
+        count = _c.c_int64(int(n_cells))
+        _check(self.lib.mvs_pairwise_block(self._h, sset._h, np_, keep_mode, row_begin, row_end, col_begin, col_end,
+                                           flags, cp, cells.shape[0], ctypes.byref(count)))
+        return count.value
+
+    def cells_sort(self, cells_in, n, cells_out):
+        ip, im, ik = _buf(cells_in)
+        op, om, ok = _buf(cells_out)
+        if im != MEM_DEVICE or om != MEM_DEVICE:
+            raise ValueError("device buffers required")
+        _check(self.lib.mvs_cells_sort(self._h, ip, int(n), op))
 
     def pairwise_dots(self, sset, r0, r1, c0, c1, algo=0, out=None):
         if out is None:

@@ -631,6 +631,66 @@ int mvs_sketch_set_destroy(mvs_sketch_set* s) {
     return MVS_OK;
 }
 
+namespace {
+
+// thresholds + one comparison launch appending to `raw` (device) from the count already in c->d_counter
+int pairwise_launch(mvs_ctx* c, const mvs_sketch_set* s, const double* d_n2, int keep_mode, int64_t rb, int64_t re,
+                    int64_t cb, int64_t ce, bool symmetric, bool mirror_all, mvs_cell* raw, int64_t capacity) {
+    int rc = ensure_buf(c, &c->pw_thr, &c->pw_thr_bytes, (size_t)s->n_alloc * 4);
+    if (rc) return rc;
+    mvs::launch_cand_thr(c->stream, d_n2, s->n, s->n_alloc, s->d, (int32_t*)c->pw_thr);
+    rc = check_kernel("k_cand_thr");
+    if (rc) return rc;
+    mvs::PairwiseArgs a{};
+    a.planes = s->planes;
+    a.n = s->n;
+    a.n_alloc = s->n_alloc;
+    a.d = s->d;
+    a.d_pad = s->d_pad;
+    a.limbs = s->limbs;
+    a.row_begin = rb;
+    a.row_end = re;
+    a.col_begin = cb;
+    a.col_end = ce;
+    a.norms_sq = d_n2;
+    a.cand_thr = (const int32_t*)c->pw_thr;
+    a.keep_mode = keep_mode;
+    a.cells = raw;
+    a.capacity = (unsigned long long)capacity;
+    a.counter = c->d_counter;
+    a.dots = nullptr;
+    a.mirror_all = mirror_all ? 1 : 0;
+    {
+        const char* dbg = getenv("MVS_PAIRWISE_DEBUG");
+        a.debug_flags = dbg ? atoi(dbg) : 0;
+        const char* sym = getenv("MVS_PAIRWISE_SYMMETRIC");   // default on; 0 computes every tile
+        a.symmetric = (symmetric && !(sym && atoi(sym) == 0)) ? 1 : 0;   // the launcher checks the alignment
+    }
+    if (c->timing) HIP_TRY(hipEventRecord(c->ev[2], c->stream));
+    rc = mvs::launch_pairwise(c->stream, a, 0, 0);
+    if (rc) return fail(rc, "pairwise launch rejected");
+    rc = check_kernel("k_pairwise");
+    if (rc) return rc;
+    if (c->timing) {
+        HIP_TRY(hipEventRecord(c->ev[3], c->stream));
+        c->ev_valid[1] = true;
+    }
+    return MVS_OK;
+}
+
+int sort_on_device(mvs_ctx* c, mvs_cell* in, int64_t n, mvs_cell* out) {
+    size_t need = 0;
+    int rc = mvs::sort_cells(c->stream, in, out, n, nullptr, 0, &need);
+    if (rc) return fail(rc, "sort sizing failed");
+    rc = ensure_buf(c, &c->pw_sort, &c->pw_sort_bytes, need);
+    if (rc) return rc;
+    rc = mvs::sort_cells(c->stream, in, out, n, c->pw_sort, c->pw_sort_bytes, nullptr);
+    if (rc) return fail(rc, "sort failed");
+    return MVS_OK;
+}
+
+}  // namespace
+
 int mvs_pairwise_rows(mvs_ctx* c, const mvs_sketch_set* s, const double* norms_sq, int mem_norms, int keep_mode,
                       int64_t row_begin, int64_t row_end, mvs_cell* cells, int64_t capacity, int mem_cells,
                       int64_t* n_cells) {
@@ -659,49 +719,12 @@ int mvs_pairwise_rows(mvs_ctx* c, const mvs_sketch_set* s, const double* norms_s
         HIP_TRY(dcells.alloc((size_t)capacity * sizeof(mvs_cell)));
         d_cells = (mvs_cell*)dcells.p;
     }
-    int rc = ensure_buf(c, &c->pw_thr, &c->pw_thr_bytes, (size_t)s->n_alloc * 4);
-    if (rc) return rc;
     // kept cells are appended (unordered) to a staging buffer and merge-sorted into the caller's
-    rc = ensure_buf(c, &c->pw_tmp, &c->pw_tmp_bytes, (size_t)std::max<int64_t>(capacity, 1) * sizeof(mvs_cell));
-    if (rc) return rc;
-    mvs::launch_cand_thr(c->stream, d_n2, s->n, s->n_alloc, s->d, (int32_t*)c->pw_thr);
-    rc = check_kernel("k_cand_thr");
+    int rc = ensure_buf(c, &c->pw_tmp, &c->pw_tmp_bytes, (size_t)std::max<int64_t>(capacity, 1) * sizeof(mvs_cell));
     if (rc) return rc;
     HIP_TRY(hipMemsetAsync(c->d_counter, 0, 8, c->stream));
-
-    mvs::PairwiseArgs a{};
-    a.planes = s->planes;
-    a.n = s->n;
-    a.n_alloc = s->n_alloc;
-    a.d = s->d;
-    a.d_pad = s->d_pad;
-    a.limbs = s->limbs;
-    a.row_begin = row_begin;
-    a.row_end = row_end;
-    a.col_begin = 0;
-    a.col_end = s->n;
-    a.norms_sq = d_n2;
-    a.cand_thr = (const int32_t*)c->pw_thr;
-    a.keep_mode = keep_mode;
-    a.cells = (mvs_cell*)c->pw_tmp;
-    a.capacity = (unsigned long long)capacity;
-    a.counter = c->d_counter;
-    a.dots = nullptr;
-    {
-        const char* dbg = getenv("MVS_PAIRWISE_DEBUG");
-        a.debug_flags = dbg ? atoi(dbg) : 0;
-        const char* sym = getenv("MVS_PAIRWISE_SYMMETRIC");   // default on; 0 computes every tile
-        a.symmetric = !(sym && atoi(sym) == 0) ? 1 : 0;   // the launcher also requires row_begin % tile == 0
-    }
-    if (c->timing) HIP_TRY(hipEventRecord(c->ev[2], c->stream));
-    rc = mvs::launch_pairwise(c->stream, a, 0, 0);
-    if (rc) return fail(rc, "pairwise launch rejected");
-    rc = check_kernel("k_pairwise");
+    rc = pairwise_launch(c, s, d_n2, keep_mode, row_begin, row_end, 0, s->n, true, false, (mvs_cell*)c->pw_tmp, capacity);
     if (rc) return rc;
-    if (c->timing) {
-        HIP_TRY(hipEventRecord(c->ev[3], c->stream));
-        c->ev_valid[1] = true;
-    }
     unsigned long long count = 0;
     HIP_TRY(hipMemcpyAsync(&count, c->d_counter, 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -709,22 +732,54 @@ int mvs_pairwise_rows(mvs_ctx* c, const mvs_sketch_set* s, const double* norms_s
     if ((int64_t)count > capacity)
         return fail(MVS_E_CAPACITY, "%llu cells kept but capacity is %lld", count, (long long)capacity);
     if (count == 0) return MVS_OK;
-
     // order by (row, col): the per-row ascending-column order of the reference's result list
-    size_t need = 0;
-    rc = mvs::sort_cells(c->stream, (mvs_cell*)c->pw_tmp, d_cells, (int64_t)count, nullptr, 0, &need);
-    if (rc) return fail(rc, "sort sizing failed");
-    rc = ensure_buf(c, &c->pw_sort, &c->pw_sort_bytes, need);
+    rc = sort_on_device(c, (mvs_cell*)c->pw_tmp, (int64_t)count, d_cells);
     if (rc) return rc;
-    rc = mvs::sort_cells(c->stream, (mvs_cell*)c->pw_tmp, d_cells, (int64_t)count, c->pw_sort, c->pw_sort_bytes,
-                         nullptr);
-    if (rc) return fail(rc, "sort failed");
     if (mem_cells == MVS_MEM_HOST) {
         HIP_TRY(hipMemcpyAsync(cells, d_cells, (size_t)count * sizeof(mvs_cell), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
     }
     // device output: the sort is queued on the context's stream; *n_cells is already final
     return MVS_OK;
+}
+
+int mvs_pairwise_block(mvs_ctx* c, const mvs_sketch_set* s, const double* norms_sq, int keep_mode, int64_t row_begin,
+                       int64_t row_end, int64_t col_begin, int64_t col_end, int flags, mvs_cell* cells,
+                       int64_t capacity, int64_t* n_cells) {
+    if (!c || !s || !n_cells) return fail(MVS_E_INVALID, "NULL argument");
+    if (capacity < 0 || *n_cells < 0 || (keep_mode != MVS_KEEP_INT32 && keep_mode != MVS_KEEP_INT16) ||
+        (flags & ~(MVS_BLOCK_SYMMETRIC | MVS_BLOCK_MIRROR_ALL)) != 0 ||
+        ((flags & MVS_BLOCK_SYMMETRIC) && (flags & MVS_BLOCK_MIRROR_ALL)))
+        return fail(MVS_E_INVALID, "bad argument");
+    if (row_begin < 0 || row_end > s->n || row_begin > row_end || col_begin < 0 || col_end > s->n || col_begin > col_end)
+        return fail(MVS_E_INVALID, "block [%lld,%lld) x [%lld,%lld) outside [0,%lld)", (long long)row_begin,
+                    (long long)row_end, (long long)col_begin, (long long)col_end, (long long)s->n);
+    if ((flags & MVS_BLOCK_SYMMETRIC) && (col_begin > row_begin || col_end < row_end))
+        return fail(MVS_E_INVALID, "a symmetric block must contain the square of its row range");
+    if (row_begin == row_end || col_begin == col_end) return MVS_OK;
+    if (!norms_sq || (capacity > 0 && !cells)) return fail(MVS_E_INVALID, "NULL buffer");
+    HIP_TRY(hipSetDevice(c->device));
+    const unsigned long long start = (unsigned long long)*n_cells;
+    HIP_TRY(hipMemcpyAsync(c->d_counter, &start, 8, hipMemcpyHostToDevice, c->stream));
+    int rc = pairwise_launch(c, s, norms_sq, keep_mode, row_begin, row_end, col_begin, col_end,
+                             (flags & MVS_BLOCK_SYMMETRIC) != 0, (flags & MVS_BLOCK_MIRROR_ALL) != 0, cells, capacity);
+    if (rc) return rc;
+    unsigned long long count = 0;
+    HIP_TRY(hipMemcpyAsync(&count, c->d_counter, 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));   // also covers the lifetime of `start`
+    *n_cells = (int64_t)count;
+    if ((int64_t)count > capacity)
+        return fail(MVS_E_CAPACITY, "%llu cells appended but capacity is %lld", count, (long long)capacity);
+    return MVS_OK;
+}
+
+int mvs_cells_sort(mvs_ctx* c, const mvs_cell* cells_in, int64_t n, mvs_cell* cells_out) {
+    if (!c) return fail(MVS_E_INVALID, "ctx is NULL");
+    if (n < 0) return fail(MVS_E_INVALID, "bad argument");
+    if (n == 0) return MVS_OK;
+    if (!cells_in || !cells_out || cells_in == cells_out) return fail(MVS_E_INVALID, "need two distinct device buffers");
+    HIP_TRY(hipSetDevice(c->device));
+    return sort_on_device(c, const_cast<mvs_cell*>(cells_in), n, cells_out);
 }
 
 int mvs_pairwise_dots(mvs_ctx* c, const mvs_sketch_set* s, int64_t r0, int64_t r1, int64_t c0, int64_t c1,

@@ -48,6 +48,8 @@ struct PairwiseArgs {
     unsigned long long* counter;  // number of kept cells (may exceed capacity)
     // dense outputs (dots mode)
     int32_t* dots;                // (row_end-row_begin) x (col_end-col_begin)
+    int mirror_all;               // 1: every kept (row, col) is appended as (col, row) too (the transposed
+                                  //    block belongs to another shard and is not computed there)
     int symmetric;                // 1: tiles strictly below the diagonal of the row range are skipped and
                                   //    produced by mirroring the kept cells of their transposes
     int debug_flags;              // profiling ablations (MVS_PAIRWISE_DEBUG): 1 skip k-loop, 2 skip epilogue

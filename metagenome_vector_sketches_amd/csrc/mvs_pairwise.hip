@@ -356,7 +356,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void k_pairwise_mfma(const Pairwis
                         bool keep = false;
                         if (cand && row < a.row_end && col < a.col_end)
                             keep = keep_cell(P, a.d, a.norms_sq[row], a.norms_sq[col], a.keep_mode);
-                        emit_cell(a, keep, mirror_tile && col < a.row_end, (int32_t)row, (int32_t)col, P, lane);
+                        emit_cell(a, keep, a.mirror_all || (mirror_tile && col < a.row_end), (int32_t)row, (int32_t)col, P,
+                                  lane);
                     }
                 }
             }
@@ -403,7 +404,7 @@ __global__ __launch_bounds__(256) void k_pairwise_valu(const PairwiseArgs a) {
     } else {
         bool keep = false;
         if (in) keep = keep_cell(P, a.d, a.norms_sq[row], a.norms_sq[col], a.keep_mode);
-        emit_cell(a, keep, false, (int32_t)row, (int32_t)col, P, lane);
+        emit_cell(a, keep, a.mirror_all != 0, (int32_t)row, (int32_t)col, P, lane);
     }
 }
 
@@ -526,7 +527,8 @@ int launch_mfma_variant(hipStream_t stream, const PairwiseArgs& a) {
     if (blocks > 0x7fffffffLL) return MVS_E_INVALID;
     const size_t lds = (size_t)NST * L * (TM + TN) * kSK;
     PairwiseArgs b = a;
-    if (b.symmetric && (a.row_begin % TM != 0 || TM % TN != 0)) b.symmetric = 0;
+    // the symmetric schedule needs the row and column tile grids to share their origin modulo TM
+    if (b.symmetric && ((a.row_begin - a.col_begin) % TM != 0 || TM % TN != 0 || a.mirror_all)) b.symmetric = 0;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pairwise_mfma<L, KARA, MODE, NST, WM, WN, BT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return MVS_E_HIP;

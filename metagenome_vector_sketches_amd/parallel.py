@@ -10,7 +10,16 @@ every GPU all N columns.  Norms (N doubles) are all-gathered the same way.  Resu
 The collective calls are torch.distributed's; the numeric work goes through an `ops` object:
 `GpuOps` (libmvs_hip.so through the C ABI) in production.  tests/ substitutes a CPU stand-in built on
 the oracle to exercise this module with the gloo backend.
+
+With more than one rank the default schedule is SYMMETRIC across ranks as well: every unordered pair of row
+blocks is compared by exactly one rank (block (r, r+d) by rank r for 0 < d < G/2; the opposite block of an
+even G is split in halves between the two ranks), which appends each kept cell AND its mirror image; the
+mirrored cells that belong to other ranks' rows are then exchanged (one more all-gather, of kept cells --
+a few MB) and merged.  Per-rank comparison work drops from G - 1/2 blocks to G/2.  Set
+MVS_SHARDED_SYMMETRIC=0 for the plain rows x all-columns schedule.
 """
+import os
+
 import numpy as np
 
 from . import _capi
@@ -23,11 +32,58 @@ def shard_rows(n_total, world, rank):
     return b, min(b + rps, n_total)
 
 
+def block_plan(n_total, world, rank):
+    """Blocks (row_begin, row_end, col_begin, col_end, flags) rank `rank` compares in the symmetric schedule.
+    Over all ranks every unordered pair of samples is covered exactly once (diagonal blocks: both orders)."""
+    rb, re = shard_rows(n_total, world, rank)
+    plan = []
+    if re > rb:
+        plan.append((rb, re, rb, re, _capi.BLOCK_SYMMETRIC))
+    for d in range(1, (world - 1) // 2 + 1):
+        cb, ce = shard_rows(n_total, world, (rank + d) % world)
+        if re > rb and ce > cb:
+            plan.append((rb, re, cb, ce, _capi.BLOCK_MIRROR_ALL))
+    if world > 1 and world % 2 == 0:
+        p = (rank + world // 2) % world
+        pb, pe = shard_rows(n_total, world, p)
+        if rank < p:                      # the lower rank takes the first half of ITS rows against all of p's
+            mid = rb + (re - rb + 1) // 2
+            if mid > rb and pe > pb:
+                plan.append((rb, mid, pb, pe, _capi.BLOCK_MIRROR_ALL))
+        else:                             # the higher rank takes all of its rows against the second half of p's
+            mid = pb + (pe - pb + 1) // 2
+            if re > rb and pe > mid:
+                plan.append((rb, re, mid, pe, _capi.BLOCK_MIRROR_ALL))
+    return plan
+
+
 class GpuOps:
     """numeric back end on one MI355X: everything is a call into libmvs_hip.so"""
 
     def __init__(self, ctx, device):
         self.ctx, self.device = ctx, device
+        self.k2_ms = 0.0
+
+    def new_cells(self, capacity):
+        import torch
+        return torch.empty((capacity, 4), dtype=torch.int32, device=self.device)
+
+    def open_set(self, planes, n, n_alloc, d, d_pad, limbs):
+        return self.ctx.sketch_set_from_planes(planes, n, n_alloc, d, d_pad, limbs)
+
+    def close_set(self, sset):
+        sset.close()
+
+    def compare_block(self, sset, norms_sq, rb, re, cb, ce, flags, keep_mode, raw, n_raw):
+        n = self.ctx.pairwise_block(sset, norms_sq, rb, re, cb, ce, flags, raw, n_raw, keep_mode=keep_mode)
+        try:
+            self.k2_ms += self.ctx.kernel_ms(1)
+        except _capi.MvsError:
+            pass
+        return n
+
+    def sort_cells(self, cells_in, n, cells_out):
+        self.ctx.cells_sort(cells_in, n, cells_out)
 
     def max_abs(self, sketches):
         return self.ctx.max_abs(sketches)
@@ -65,6 +121,8 @@ class ShardedComparison:
         self.ops, self.rank, self.world, self.dist = ops, rank, world, dist
         self._planes = None
         self._key = None
+        self._raw = self._tmp = None
+        self.symmetric = os.environ.get("MVS_SHARDED_SYMMETRIC", "1") != "0"
         if world > 1 and dist is None:
             raise ValueError("world > 1 needs torch.distributed")
 
@@ -109,6 +167,51 @@ class ShardedComparison:
         else:
             n2_all = ops.to_device(n2_pad)
         # rows beyond n_total are zero sketches with zero norms: they can never be kept
-        cells, cnt = ops.compare(planes, n_total, n_alloc, d, d_pad, limbs, n2_all[:n_total].contiguous()
-                                 if hasattr(n2_all, "contiguous") else n2_all[:n_total], rb, re, keep_mode, cells_out)
-        return cells, cnt, {"limbs": limbs, "rows": (rb, re), "allgather_bytes_per_rank": blk if world > 1 else 0}
+        n2_dev = n2_all[:n_total].contiguous() if hasattr(n2_all, "contiguous") else n2_all[:n_total]
+        info = {"limbs": limbs, "rows": (rb, re), "allgather_bytes_per_rank": blk if world > 1 else 0}
+        if world > 1 and self.symmetric and cells_out is not None:
+            cells, cnt = self._run_symmetric(planes, n_total, n_alloc, d, d_pad, limbs, n2_dev, rb, re, keep_mode,
+                                             cells_out, info)
+        else:
+            cells, cnt = ops.compare(planes, n_total, n_alloc, d, d_pad, limbs, n2_dev, rb, re, keep_mode, cells_out)
+        return cells, cnt, info
+
+    def _run_symmetric(self, planes, n_total, n_alloc, d, d_pad, limbs, n2_dev, rb, re, keep_mode, cells_out, info):
+        """every unordered pair of row blocks once + exchange of the mirrored cells (module docstring)"""
+        import torch
+        ops, dist, rank, world = self.ops, self.dist, self.rank, self.world
+        cap = cells_out.shape[0]
+        if self._raw is None or self._raw.shape[0] != cap:
+            self._raw, self._tmp = ops.new_cells(cap), ops.new_cells(cap)
+        raw, tmp = self._raw, self._tmp
+        sset = ops.open_set(planes, n_total, n_alloc, d, d_pad, limbs)
+        n_raw = 0
+        try:
+            plan = block_plan(n_total, world, rank)
+            for (b0, b1, c0, c1, flags) in plan:
+                n_raw = ops.compare_block(sset, n2_dev, b0, b1, c0, c1, flags, keep_mode, raw, n_raw)
+        finally:
+            ops.close_set(sset)
+        ops.sort_cells(raw, n_raw, tmp)                     # (row, col) order: own rows form one contiguous run
+        rows = tmp[:n_raw, 0].contiguous()
+        bounds = torch.searchsorted(rows, torch.tensor([rb, re], dtype=rows.dtype, device=rows.device))
+        lo, hi = int(bounds[0]), int(bounds[1])
+        local = tmp[lo:hi]
+        foreign = torch.cat([tmp[:lo], tmp[hi:n_raw]])      # mirrored cells of rows other ranks own
+        # exchange: all-gather of the (padded) foreign lists, every rank keeps the cells of its own rows
+        cnt_t = torch.tensor([foreign.shape[0]], dtype=torch.int64, device=foreign.device)
+        dist.all_reduce(cnt_t, op=dist.ReduceOp.MAX)
+        max_f = max(int(cnt_t[0]), 1)
+        send = torch.full((max_f, 4), -1, dtype=foreign.dtype, device=foreign.device)
+        send[:foreign.shape[0]] = foreign
+        recv = torch.empty((world * max_f, 4), dtype=foreign.dtype, device=foreign.device)
+        dist.all_gather_into_tensor(recv, send)
+        mine = recv[(recv[:, 0] >= rb) & (recv[:, 0] < re)]
+        n_out = local.shape[0] + mine.shape[0]
+        if n_out > cap:
+            raise _capi.MvsError(_capi.MVS_E_CAPACITY, "%d cells for this shard but capacity is %d" % (n_out, cap))
+        raw[:local.shape[0]] = local
+        raw[local.shape[0]:n_out] = mine
+        ops.sort_cells(raw, n_out, cells_out)
+        info.update({"blocks": len(plan), "exchanged_cells": int(foreign.shape[0]), "schedule": "symmetric"})
+        return cells_out, n_out

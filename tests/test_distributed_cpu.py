@@ -51,12 +51,44 @@ class OracleOps:
     def to_device(self, a):
         return torch.from_numpy(np.ascontiguousarray(a))
 
-    def compare(self, planes, n, n_alloc, d, d_pad, limbs, norms_sq, rb, re, keep_mode, cells_out):
+    def _sketches(self, planes, n, d, d_pad, limbs):
         view = planes.numpy().reshape(-1, limbs, d_pad).astype(np.int64)
-        sk = sum(view[:n, l, :d] * (256 ** l) for l in range(limbs)).astype(np.int32)
+        return sum(view[:n, l, :d] * (256 ** l) for l in range(limbs)).astype(np.int32)
+
+    def compare(self, planes, n, n_alloc, d, d_pad, limbs, norms_sq, rb, re, keep_mode, cells_out):
+        sk = self._sketches(planes, n, d, d_pad, limbs)
         cells = self.orc.pairwise_rows(sk, norms_sq.numpy(), row_begin=rb, row_end=re, chunk=192, threads=2)
         order = np.lexsort((cells["col"], cells["row"]))
-        return cells[order], len(cells)
+        if cells_out is None:
+            return cells[order], len(cells)
+        arr = np.stack([cells[order][k] for k in ("row", "col", "dot", "q")], axis=1).astype(np.int32)
+        cells_out[:len(arr)] = torch.from_numpy(arr)
+        return cells_out, len(arr)
+
+    # ---- block interface of the symmetric schedule ----
+    def new_cells(self, capacity):
+        return torch.empty((capacity, 4), dtype=torch.int32)
+
+    def open_set(self, planes, n, n_alloc, d, d_pad, limbs):
+        return (self._sketches(planes, n, d, d_pad, limbs), n)
+
+    def close_set(self, sset):
+        pass
+
+    def compare_block(self, sset, norms_sq, rb, re, cb, ce, flags, keep_mode, raw, n_raw):
+        sk, n = sset
+        cells = self.orc.pairwise_rows(sk, norms_sq.numpy(), row_begin=rb, row_end=re, chunk=192, threads=2)
+        cells = cells[(cells["col"] >= cb) & (cells["col"] < ce)]
+        arr = np.stack([cells[k] for k in ("row", "col", "dot", "q")], axis=1).astype(np.int32)
+        if flags & 2:      # MVS_BLOCK_MIRROR_ALL
+            arr = np.concatenate([arr, arr[:, [1, 0, 2, 3]]])
+        arr = arr[np.random.default_rng(n_raw).permutation(len(arr))]      # the device appends in no particular order
+        raw[n_raw:n_raw + len(arr)] = torch.from_numpy(arr)
+        return n_raw + len(arr)
+
+    def sort_cells(self, cells_in, n, cells_out):
+        a = cells_in[:n].numpy()
+        cells_out[:n] = torch.from_numpy(a[np.lexsort((a[:, 1], a[:, 0]))])
 
 
 def _make(n, d, seed):
@@ -75,17 +107,41 @@ def _worker(rank, world, port, n, d, out_dir):
     sk, n2 = _make(n, d, seed=99)
     b, e = parallel.shard_rows(n, world, rank)
     sc = parallel.ShardedComparison(OracleOps(), rank, world, dist)
-    cells, cnt, info = sc.run(sk[b:e], n2[b:e], n)
+    cells, cnt, info = sc.run(sk[b:e], n2[b:e], n)          # no output buffer -> plain rows x all-columns schedule
     cells2, cnt2, _ = sc.run(sk[b:e], n2[b:e], n)          # second step reuses the plane buffer
     assert cnt == cnt2 and np.array_equal(cells, cells2)
     np.save(os.path.join(out_dir, "cells_%d.npy" % rank), cells)
+    # symmetric schedule: every unordered block pair once + exchange of the mirrored cells
+    out = torch.empty((n * n, 4), dtype=torch.int32)
+    _, cnt3, info3 = sc.run(sk[b:e], n2[b:e], n, cells_out=out)
+    assert info3.get("schedule") == "symmetric"
+    plain = np.stack([cells[k] for k in ("row", "col", "dot", "q")], axis=1).astype(np.int32)
+    assert cnt3 == cnt and np.array_equal(out[:cnt3].numpy(), plain), (rank, cnt3, cnt)
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n", [96, 101])     # 101: uneven last shard (51 + 50) -> padded block
-def test_two_rank_shards_equal_single_process(tmp_path, n):
-    d, world, port = 256, 2, 29500 + (os.getpid() + n) % 2000
+def test_block_plan_covers_every_pair_once():
+    from metagenome_vector_sketches_amd import parallel
+    for world in (1, 2, 3, 4, 5, 8):
+        for n in (1, 7, 64, 101):
+            seen = np.zeros((n, n), dtype=np.int32)
+            for rank in range(world):
+                for (rb, re, cb, ce, flags) in parallel.block_plan(n, world, rank):
+                    seen[rb:re, cb:ce] += 1
+                    if flags & 2:                      # mirrored into the transposed block
+                        seen[cb:ce, rb:re] += 1
+                    assert parallel.shard_rows(n, world, rank)[0] <= rb and re <= parallel.shard_rows(n, world, rank)[1]
+            assert np.all(seen == 1), (world, n)
+    # per-rank work is balanced: G/2 blocks each (even G)
+    work = [sum((re - rb) * (ce - cb) * (0.5 if f & 1 else 1.0) for rb, re, cb, ce, f in parallel.block_plan(8000, 8, r))
+            for r in range(8)]
+    assert max(work) == min(work) == 4 * 1000 * 1000
+
+
+@pytest.mark.parametrize("n,world", [(96, 2), (101, 2), (101, 3), (130, 4)])   # uneven last shards -> padded blocks
+def test_multi_rank_shards_equal_single_process(tmp_path, n, world):
+    d, port = 256, 29500 + (os.getpid() + n + world) % 2000
     mp.spawn(_worker, args=(world, port, n, d, str(tmp_path)), nprocs=world, join=True)
     from metagenome_vector_sketches_amd import parallel
     from oracle import pyoracle as orc
