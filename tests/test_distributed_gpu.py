@@ -1,0 +1,65 @@
+"""GPU, several ranks sharing the one card of the GPU box (gloo for the collectives; the driver's multi-GPU
+runs use RCCL): the real HIP back end under both multi-rank schedules -- rows x all-columns, and the
+symmetric one (every unordered block pair once, mirrored cells exchanged).  Each rank's shard must equal
+the oracle's rows for that shard, cell for cell."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def _make(n, d):
+    from metagenome_vector_sketches_amd import synth
+    from oracle import pyoracle as orc
+    sk = synth.make_sketches_numpy(n, d, 3000, seed=321, cluster=8)
+    n2 = np.array([orc.norm_sq_from_text(orc.format_norm(orc.norm(r))) for r in sk])
+    return sk, n2
+
+
+def _worker(rank, world, port, n, d, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import metagenome_vector_sketches_amd as pkg
+    from metagenome_vector_sketches_amd import parallel
+    torch.cuda.set_device(0)
+    ctx = pkg.Context(0)
+    ctx.set_stream(torch.cuda.current_stream())
+    sk, n2 = _make(n, d)
+    b, e = parallel.shard_rows(n, world, rank)
+    local = torch.from_numpy(sk[b:e]).to("cuda:0")
+    out = torch.empty((n * 40, 4), dtype=torch.int32, device="cuda:0")
+    for sym in (True, False):
+        sc = parallel.ShardedComparison(parallel.GpuOps(ctx, torch.device("cuda", 0)), rank, world, dist)
+        sc.symmetric = sym
+        _, cnt, info = sc.run(local, n2[b:e], n, cells_out=out)
+        torch.cuda.synchronize()
+        assert (info.get("schedule") == "symmetric") == sym
+        np.save(os.path.join(out_dir, "cells_%d_%d.npy" % (int(sym), rank)), out[:cnt].cpu().numpy())
+    dist.barrier()
+    ctx.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,world", [(700, 2), (650, 3)])
+def test_ranks_on_one_gpu_match_oracle(tmp_path, n, world):
+    d, port = 512, 29800 + (os.getpid() + n) % 1000
+    mp.spawn(_worker, args=(world, port, n, d, str(tmp_path)), nprocs=world, join=True)
+    from oracle import pyoracle as orc
+    sk, n2 = _make(n, d)
+    want = orc.pairwise_rows(sk, n2, chunk=192, threads=8)
+    want = want[np.lexsort((want["col"], want["row"]))]
+    want = np.stack([want[k] for k in ("row", "col", "dot", "q")], axis=1).astype(np.int32)
+    assert len(want) > 6 * n
+    for sym in (1, 0):
+        got = np.concatenate([np.load(os.path.join(str(tmp_path), "cells_%d_%d.npy" % (sym, r))) for r in range(world)])
+        assert np.array_equal(got, want), sym
