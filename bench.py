@@ -113,8 +113,8 @@ def main():
     state = {}
 
     def step():
-        ctx.project_csr(hashes, offsets, D, out=sketches)                 # K1
-        _, max_abs = ctx.stats(sketches, out=sumsq)                        # sum of squares + max |v|, one pass
+        # K1; the sums of squares and max |v| come out of the same kernel
+        max_abs = ctx.project_csr_stats(hashes, offsets, D, sketches, sumsq)
         n2_local = fast_norm_sq(sumsq.cpu().numpy(), D)                    # text round trip of the norms
         # limb split, [all-gather of plane row blocks + norms], K2 on this rank's rows x all columns
         _, cnt, info = sc.run(sketches, n2_local, N_total, cells_out=cells, max_abs_local=max_abs)

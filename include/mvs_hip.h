@@ -98,6 +98,13 @@ int mvs_ctx_kernel_ms(mvs_ctx* ctx, int which, float* ms);
 int mvs_project_csr(mvs_ctx* ctx, const uint64_t* hashes, int mem_hashes, const int64_t* offsets,
                     int64_t n_samples, int d, int32_t* out, int mem_out);
 
+/* mvs_project_csr plus the two statistics the next stages need, produced by the same kernel when every
+ * sample holds <= 65536 hashes (otherwise by one extra pass): sumsq[s] = exact sum of squares of sketch s
+ * (DEVICE int64[n_samples]) and *max_abs = largest |v| (host; decides the limb code).  `out` must be a
+ * device buffer.  Synchronous. */
+int mvs_project_csr_stats(mvs_ctx* ctx, const uint64_t* hashes, int mem_hashes, const int64_t* offsets,
+                          int64_t n_samples, int d, int32_t* out, int mem_out, int64_t* sumsq, int64_t* max_abs);
+
 /* Sum of squares of each sketch (exact int64): the integer the norm of
  * src/project_everything.cpp:328-329 is derived from (norm = sqrt(sumsq / d)). */
 int mvs_sketch_sumsq(mvs_ctx* ctx, const int32_t* sketches, int mem_in, int64_t n, int d,

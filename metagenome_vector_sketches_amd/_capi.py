@@ -35,6 +35,8 @@ SYMBOLS = [
     ("mvs_ctx_set_timing", _c.c_int, [_P, _c.c_int]),
     ("mvs_ctx_kernel_ms", _c.c_int, [_P, _c.c_int, _c.POINTER(_c.c_float)]),
     ("mvs_project_csr", _c.c_int, [_P, _P, _c.c_int, _P, _c.c_int64, _c.c_int, _P, _c.c_int]),
+    ("mvs_project_csr_stats", _c.c_int, [_P, _P, _c.c_int, _P, _c.c_int64, _c.c_int, _P, _c.c_int, _P,
+                                          _c.POINTER(_c.c_int64)]),
     ("mvs_sketch_sumsq", _c.c_int, [_P, _P, _c.c_int, _c.c_int64, _c.c_int, _P, _c.c_int]),
     ("mvs_sketch_stats", _c.c_int, [_P, _P, _c.c_int, _c.c_int64, _c.c_int, _P, _c.c_int, _c.POINTER(_c.c_int64)]),
     ("mvs_sketch_saturate_i16", _c.c_int, [_P, _P, _c.c_int, _c.c_int64, _P, _c.c_int]),
@@ -202,6 +204,22 @@ class Context:
         op, om, ok = _buf(out, np.int32, writable=True)
         _check(self.lib.mvs_project_csr(self._h, hp, hm, offsets.ctypes.data, n, int(d), op, om))
         return out
+
+    def project_csr_stats(self, hashes, offsets, d, out, sumsq):
+        """project_csr into the device tensor `out`, filling the device int64 tensor `sumsq` with the exact
+        sums of squares; returns the largest |v| (fused into the projection kernel when every sample is
+        a single unit)."""
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        n = len(offsets) - 1
+        hp, hm, hk = _buf(hashes) if _is_torch(hashes) else _buf(hashes, np.uint64)
+        op, om, ok = _buf(out)
+        sp, sm, sk = _buf(sumsq)
+        if om != MEM_DEVICE or sm != MEM_DEVICE:
+            raise ValueError("out and sumsq must be device buffers")
+        m = _c.c_int64()
+        _check(self.lib.mvs_project_csr_stats(self._h, hp, hm, offsets.ctypes.data, n, int(d), op, om, sp,
+                                              ctypes.byref(m)))
+        return m.value
 
     def sumsq(self, sketches, out=None):
         n, d = sketches.shape

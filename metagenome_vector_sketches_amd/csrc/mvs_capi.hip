@@ -239,7 +239,15 @@ int mvs_ctx_kernel_ms(mvs_ctx* c, int which, float* ms) {
 // -------------------------------------------------------------------------------------------------
 int mvs_project_csr(mvs_ctx* c, const uint64_t* hashes, int mem_hashes, const int64_t* offsets,
                     int64_t n_samples, int d, int32_t* out, int mem_out) {
+    return mvs_project_csr_stats(c, hashes, mem_hashes, offsets, n_samples, d, out, mem_out, nullptr, nullptr);
+}
+
+int mvs_project_csr_stats(mvs_ctx* c, const uint64_t* hashes, int mem_hashes, const int64_t* offsets,
+                          int64_t n_samples, int d, int32_t* out, int mem_out, int64_t* sumsq, int64_t* max_abs) {
     if (!c) return fail(MVS_E_INVALID, "ctx is NULL");
+    if ((sumsq == nullptr) != (max_abs == nullptr)) return fail(MVS_E_INVALID, "sumsq and max_abs go together");
+    if (sumsq && mem_out != MVS_MEM_DEVICE) return fail(MVS_E_INVALID, "statistics need device-resident sketches");
+    if (max_abs) *max_abs = 0;
     if (n_samples < 0 || d <= 0) return fail(MVS_E_INVALID, "n_samples=%lld d=%d", (long long)n_samples, d);
     if (!mem_ok(mem_hashes) || !mem_ok(mem_out)) return fail(MVS_E_INVALID, "bad mem flag");
     if (n_samples == 0) return MVS_OK;
@@ -249,11 +257,13 @@ int mvs_project_csr(mvs_ctx* c, const uint64_t* hashes, int mem_hashes, const in
     // units: runs of <= kProjUnitMax hashes, written straight into pinned memory
     if (n_samples >= (1LL << 31)) return fail(MVS_E_RANGE, "too many samples");
     size_t n_units = 0;
+    bool all_single = true;
     for (int64_t s = 0; s < n_samples; ++s) {
         const int64_t b = offsets[s], e = offsets[s + 1];
         if (e < b) return fail(MVS_E_INVALID, "offsets not monotone at sample %lld", (long long)s);
         if (e - b >= (1LL << 31)) return fail(MVS_E_RANGE, "sample %lld has >= 2^31 hashes", (long long)s);
         n_units += (size_t)((e - b + mvs::kProjUnitMax - 1) / mvs::kProjUnitMax);
+        all_single = all_single && (e - b) <= mvs::kProjUnitMax;
     }
     int rc = acquire_pinned(c, std::max<size_t>(n_units * sizeof(mvs::ProjUnit), 256));
     if (rc) return rc;
@@ -300,15 +310,32 @@ int mvs_project_csr(mvs_ctx* c, const uint64_t* hashes, int mem_hashes, const in
     }
 
     HIP_TRY(hipMemsetAsync(d_out, 0, out_bytes, c->stream));   // empty samples, atomically combined units
+    const bool fused = sumsq != nullptr && all_single;         // statistics inside the projection kernel
+    if (fused) {
+        HIP_TRY(hipMemsetAsync(sumsq, 0, (size_t)n_samples * 8, c->stream));
+        HIP_TRY(hipMemsetAsync(c->d_counter, 0, 8, c->stream));
+    }
     if (c->timing) HIP_TRY(hipEventRecord(c->ev[0], c->stream));
     const int nblk = (d + 63) / 64;
     const int bpw = nblk >= 2 ? 2 : 1;
-    mvs::launch_project(c->stream, d_hashes, (const mvs::ProjUnit*)c->scratch, (int64_t)n_units, d, d_out, bpw);
+    mvs::launch_project(c->stream, d_hashes, (const mvs::ProjUnit*)c->scratch, (int64_t)n_units, d, d_out, bpw,
+                        fused ? (unsigned long long*)sumsq : nullptr, fused ? c->d_counter : nullptr);
     rc = check_kernel("k_project");
     if (rc) return rc;
     if (c->timing) {
         HIP_TRY(hipEventRecord(c->ev[1], c->stream));
         c->ev_valid[0] = true;
+    }
+    if (sumsq) {
+        if (fused) {
+            unsigned long long m = 0;
+            HIP_TRY(hipMemcpyAsync(&m, c->d_counter, 8, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            *max_abs = (int64_t)m;
+        } else {   // some sample spans several units: its entries are final only now
+            rc = mvs_sketch_stats(c, d_out, MVS_MEM_DEVICE, n_samples, d, sumsq, MVS_MEM_DEVICE, max_abs);
+            if (rc) return rc;
+        }
     }
     if (mem_out == MVS_MEM_HOST) {
         HIP_TRY(hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, c->stream));

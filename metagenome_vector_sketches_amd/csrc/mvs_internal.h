@@ -55,8 +55,9 @@ struct PairwiseArgs {
     int debug_flags;              // profiling ablations (MVS_PAIRWISE_DEBUG): 1 skip k-loop, 2 skip epilogue
 };
 
+// d_sumsq / d_max_abs non-NULL: fused statistics (all samples must be single units; d_sumsq zeroed by the caller)
 int launch_project(hipStream_t stream, const uint64_t* d_hashes, const ProjUnit* d_units, int64_t n_units,
-                   int d, int32_t* d_out, int bpw);
+                   int d, int32_t* d_out, int bpw, unsigned long long* d_sumsq, unsigned long long* d_max_abs);
 int launch_sumsq(hipStream_t stream, const int32_t* d_sk, int64_t n, int d, int64_t* d_out);
 int launch_saturate_i16(hipStream_t stream, const int32_t* d_in, int64_t n, int16_t* d_out);
 int launch_stats(hipStream_t stream, const int32_t* d_sk, int64_t n, int d, int64_t* d_sumsq,

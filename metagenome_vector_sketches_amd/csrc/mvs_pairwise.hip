@@ -597,7 +597,9 @@ int launch_cand_thr(hipStream_t stream, const double* d_norms_sq, int64_t n, int
 }
 
 int launch_pairwise(hipStream_t stream, const PairwiseArgs& a, int mode, int algo) {
-    if (algo == 0 && (a.limbs <= 2 || is_k3(a.limbs))) {
+    // int32 accumulators hold up to two limb-pair products per k: exact while 2 * 128 * 128 * d_pad < 2^31;
+    // longer sketches take the vector-ALU path, which wraps mod 2^32 by construction
+    if (algo == 0 && (a.limbs <= 2 || is_k3(a.limbs)) && a.d_pad <= 32768) {
         if (is_k3(a.limbs)) return mode == 0 ? launch_mfma<3, true, 0>(stream, a) : launch_mfma<3, true, 1>(stream, a);
         if (a.limbs == 1) return mode == 0 ? launch_mfma<1, false, 0>(stream, a) : launch_mfma<1, false, 1>(stream, a);
         return mode == 0 ? launch_mfma<2, false, 0>(stream, a) : launch_mfma<2, false, 1>(stream, a);

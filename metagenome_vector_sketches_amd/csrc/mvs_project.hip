@@ -166,10 +166,15 @@ __device__ __forceinline__ int32_t reduce_counts(const uint32_t (&lo_in)[kLV], c
 // dealt round-robin over the 8 XCDs, so the ny workgroups of one unit are given linear ids 8 apart
 // (same XCD, dispatched together) and share the unit's hashes through that XCD's L2:
 //   id = (unit/8) * 8*ny + y*8 + unit%8.   Placement only affects HBM traffic, never results.
-template <int BPW>
+// STATS: also accumulate each sample's exact sum of squares (int64 atomics, one per wave) and the largest |v|
+// of the launch -- valid only when every sample is a single unit (the host checks), because a multi-unit
+// sample's entries are only final once all its units have been added.
+template <int BPW, bool STATS>
 __global__ __launch_bounds__(256) void k_project(const uint64_t* __restrict__ hashes,
                                                  const ProjUnit* __restrict__ units, long long n_units, int ny,
-                                                 int d, int nblk, int32_t* __restrict__ out) {
+                                                 int d, int nblk, int32_t* __restrict__ out,
+                                                 unsigned long long* __restrict__ sumsq,
+                                                 unsigned long long* __restrict__ max_abs) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long long grp = (long long)blockIdx.x / (8 * ny);
@@ -252,6 +257,8 @@ __global__ __launch_bounds__(256) void k_project(const uint64_t* __restrict__ ha
         }
     }
 
+    long long ss = 0;
+    unsigned int mx = 0;
 #pragma unroll
     for (int b = 0; b < BPW; ++b) {
         if (b0 + b >= nblk) break;
@@ -264,6 +271,23 @@ __global__ __launch_bounds__(256) void k_project(const uint64_t* __restrict__ ha
                 *dst = v;
             else
                 atomicAdd(dst, v);
+            if (STATS) {
+                ss += (long long)v * v;
+                const unsigned int av = (unsigned int)(v < 0 ? -v : v);
+                mx = av > mx ? av : mx;
+            }
+        }
+    }
+    if (STATS) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            ss += __shfl_xor(ss, o, 64);
+            const unsigned int other = (unsigned int)__shfl_xor((int)mx, o, 64);
+            mx = other > mx ? other : mx;
+        }
+        if (lane == 0) {
+            atomicAdd(sumsq + u.sample, (unsigned long long)ss);
+            if (mx) atomicMax(max_abs, (unsigned long long)mx);
         }
     }
 }
@@ -334,7 +358,7 @@ __global__ __launch_bounds__(256) void k_saturate_i16(const int32_t* __restrict_
 }  // namespace
 
 int launch_project(hipStream_t stream, const uint64_t* d_hashes, const ProjUnit* d_units, int64_t n_units,
-                   int d, int32_t* d_out, int bpw) {
+                   int d, int32_t* d_out, int bpw, unsigned long long* d_sumsq, unsigned long long* d_max_abs) {
     if (n_units == 0) return 0;
     const int nblk = (d + 63) / 64;
     // grid.x is limited to 2^31-1, plenty; launch in slabs anyway to keep blockIdx.x an int
@@ -344,12 +368,19 @@ int launch_project(hipStream_t stream, const uint64_t* d_hashes, const ProjUnit*
     for (int64_t u0 = 0; u0 < n_units; u0 += kMaxUnits) {
         const int64_t nu = n_units - u0 < kMaxUnits ? n_units - u0 : kMaxUnits;
         const unsigned grid = (unsigned)(((nu + 7) / 8) * 8 * ny);
-        if (bpw == 1)
-            hipLaunchKernelGGL(k_project<1>, dim3(grid), dim3(256), 0, stream, d_hashes, d_units + u0, (long long)nu,
-                               ny, d, nblk, d_out);
+        const bool stats = d_sumsq != nullptr;
+        if (bpw == 1 && !stats)
+            hipLaunchKernelGGL((k_project<1, false>), dim3(grid), dim3(256), 0, stream, d_hashes, d_units + u0,
+                               (long long)nu, ny, d, nblk, d_out, d_sumsq, d_max_abs);
+        else if (bpw == 1)
+            hipLaunchKernelGGL((k_project<1, true>), dim3(grid), dim3(256), 0, stream, d_hashes, d_units + u0,
+                               (long long)nu, ny, d, nblk, d_out, d_sumsq, d_max_abs);
+        else if (!stats)
+            hipLaunchKernelGGL((k_project<2, false>), dim3(grid), dim3(256), 0, stream, d_hashes, d_units + u0,
+                               (long long)nu, ny, d, nblk, d_out, d_sumsq, d_max_abs);
         else
-            hipLaunchKernelGGL(k_project<2>, dim3(grid), dim3(256), 0, stream, d_hashes, d_units + u0, (long long)nu,
-                               ny, d, nblk, d_out);
+            hipLaunchKernelGGL((k_project<2, true>), dim3(grid), dim3(256), 0, stream, d_hashes, d_units + u0,
+                               (long long)nu, ny, d, nblk, d_out, d_sumsq, d_max_abs);
     }
     return 0;
 }

@@ -130,3 +130,21 @@ def test_stats_one_pass(ctx, gold):
     v = np.array([[-2**31, 5, 0], [7, -9, 1]], dtype=np.int32)      # d % 4 != 0 path, INT32_MIN
     ss, m = ctx.stats(v)
     assert ss.tolist() == [2**62 + 25, 131] and m == 2**31
+
+
+def test_project_with_fused_stats(ctx):
+    """mvs_project_csr_stats: statistics fused into the projection kernel (single-unit samples) and the
+    fallback pass (a sample of > 65536 hashes spans several units)"""
+    import torch
+    rng = np.random.default_rng(5)
+    for sizes in ([0, 1, 300, 4096, 65536, 20000], [10, 70000, 3, 131073]):
+        lists = [rng.integers(0, synth.MAX_HASH, size=s, dtype=np.uint64) for s in sizes]
+        h, o = _csr(lists)
+        want = orc.project_csr(h, o, 2048, threads=8, fast=True)
+        out = torch.empty((len(sizes), 2048), dtype=torch.int32, device="cuda")
+        ss = torch.full((len(sizes),), -1, dtype=torch.int64, device="cuda")
+        m = ctx.project_csr_stats(torch.from_numpy(h.view(np.int64)).to("cuda"), o, 2048, out, ss)
+        ctx.synchronize()
+        assert np.array_equal(out.cpu().numpy(), want)
+        assert ss.cpu().tolist() == (want.astype(np.int64) ** 2).sum(1).tolist()
+        assert m == int(np.abs(want).max())
