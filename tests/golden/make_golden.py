@@ -168,6 +168,15 @@ def main():
     assert sp["kat_123_d8"]["stdout"] == "-1 1 -1 -1 3 1 -3 -3\n"
     kat["standalone_projection"] = sp
 
+    # 3b. BASELINE config 4 dimension (d = 4096) and a non-multiple-of-64 dimension on the toy set: digests only
+    for dim in (4096, 100):
+        run([os.path.join(REFBIN, "project_everything"), "sketch", hf, os.path.join(WORK, "toy_db_d%d" % dim), "-d",
+             str(dim)], cwd=WORK)
+        vd, nd = read_db(os.path.join(WORK, "toy_db_d%d" % dim), len(names), dim)
+        kat["toy_vectors_sha256_d%d" % dim] = hashlib.sha256(vd.tobytes()).hexdigest()
+        kat["toy_row_sha256_d%d" % dim] = {n: hashlib.sha256(vd[i].tobytes()).hexdigest() for i, n in enumerate(names)}
+        kat["toy_norms_d%d" % dim] = nd
+
     # a large-magnitude case for the float text formatting (|v| >= 1e6 prints in %g exponent form):
     # 1.2M hashes in ONE line is too slow/large for a fixture; covered by unit tests of the formatter.
 

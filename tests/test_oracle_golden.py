@@ -138,3 +138,10 @@ def test_dot_wraps_mod_2_32():
 def test_saturate_i16():
     v = np.array([0, 1, -1, 32767, 32768, -32768, -32769, 2**31 - 1, -2**31], dtype=np.int32)
     assert orc.saturate_i16(v).tolist() == [0, 1, -1, 32767, 32767, -32768, -32768, 32767, -32768]
+
+
+def test_toy_other_dimensions(gold):
+    """d = 4096 (BASELINE config 4) and d = 100 (tail block, d % 64 != 0): reference digests"""
+    for d in (4096, 100):
+        got = orc.project_csr(gold.hashes, gold.offsets, d, threads=4, fast=True)
+        assert hashlib.sha256(got.tobytes()).hexdigest() == gold.kat["toy_vectors_sha256_d%d" % d]

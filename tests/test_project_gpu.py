@@ -148,3 +148,15 @@ def test_project_with_fused_stats(ctx):
         assert np.array_equal(out.cpu().numpy(), want)
         assert ss.cpu().tolist() == (want.astype(np.int64) ** 2).sum(1).tolist()
         assert m == int(np.abs(want).max())
+
+
+def test_toy_set_other_dimensions_reference_digests(ctx, gold):
+    """the reference binary's own output at d = 4096 (BASELINE config 4) and d = 100 (d % 64 != 0)"""
+    for d in (4096, 100):
+        got = ctx.project_csr(gold.hashes, gold.offsets, d)
+        assert hashlib.sha256(got.tobytes()).hexdigest() == gold.kat["toy_vectors_sha256_d%d" % d]
+        for i, n in enumerate(gold.names):
+            assert hashlib.sha256(got[i].tobytes()).hexdigest() == gold.kat["toy_row_sha256_d%d" % d][n]
+        ref_norms = [float(l.split(" ")[1]) for l in gold.kat["toy_norms_d%d" % d].strip().split("\n")]
+        mine = np.sqrt(ctx.sumsq(got).astype(np.float64) / d)
+        assert np.allclose(mine, ref_norms, rtol=1e-5, atol=1e-12)
