@@ -194,6 +194,18 @@ int mvs_pairwise_rows(mvs_ctx* ctx, const mvs_sketch_set* set, const double* nor
 int mvs_pairwise_block(mvs_ctx* ctx, const mvs_sketch_set* set, const double* norms_sq, int keep_mode,
                        int64_t row_begin, int64_t row_end, int64_t col_begin, int64_t col_end, int flags,
                        mvs_cell* cells, int64_t capacity, int64_t* n_cells);
+/* Query-by-sketch search, the exact brute-force counterpart of the reference's FAISS IndexFlatIP path
+ * (src/jaccard.py:63-224: normalised inner products, then jaccard = ip*qn*nn / (nn^2 + qn^2 - ip*qn*nn) > j).
+ * Rows [row_begin,row_end) of the set are the queries (their sketches appended after the database rows),
+ * columns [col_begin,col_end) the database; a pair is reported iff its Jaccard estimate
+ * (dot/d) / (n2_row + n2_col - dot/d) exceeds jaccard_min (0 < jaccard_min < 1).  Same kernel as the
+ * comparison, with the keep coefficient 0.05 replaced by jaccard_min/(1+jaccard_min) and the floating keep
+ * test.  norms_sq and cells are DEVICE buffers; cells come back sorted by (row, col), `dot` exact, `q` the
+ * 8-bit quantised estimate.  Synchronous. */
+int mvs_search_block(mvs_ctx* ctx, const mvs_sketch_set* set, const double* norms_sq, double jaccard_min,
+                     int64_t row_begin, int64_t row_end, int64_t col_begin, int64_t col_end, mvs_cell* cells,
+                     int64_t capacity, int64_t* n_cells);
+
 /* Sort n cells by (row, col) from one DEVICE buffer into another (asynchronous on the context's stream). */
 int mvs_cells_sort(mvs_ctx* ctx, const mvs_cell* cells_in, int64_t n, mvs_cell* cells_out);
 

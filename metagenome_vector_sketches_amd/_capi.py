@@ -59,6 +59,8 @@ SYMBOLS = [
     ("mvs_pairwise_block", _c.c_int, [_P, _P, _P, _c.c_int, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int,
                                        _P, _c.c_int64, _c.POINTER(_c.c_int64)]),
     ("mvs_cells_sort", _c.c_int, [_P, _P, _c.c_int64, _P]),
+    ("mvs_search_block", _c.c_int, [_P, _P, _P, _c.c_double, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _P,
+                                     _c.c_int64, _c.POINTER(_c.c_int64)]),
     ("mvs_pairwise_dots", _c.c_int, [_P, _P, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _P, _c.c_int,
                                       _c.c_int]),
     ("mvs_chunk_size", _c.c_int64, [_c.c_double, _c.c_int]),
@@ -129,6 +131,13 @@ class SketchSet:
         n, d, limbs, n_alloc, d_pad = (_c.c_int64(), _c.c_int(), _c.c_int(), _c.c_int64(), _c.c_int())
         _check(ctx.lib.mvs_sketch_set_info(handle, n, d, limbs, n_alloc, d_pad))
         self.n, self.d, self.limbs, self.n_alloc, self.d_pad = n.value, d.value, limbs.value, n_alloc.value, d_pad.value
+
+    def fill(self, sketches, row_offset=0):
+        """re-code `sketches` into rows [row_offset, row_offset + len) of a set made by sketch_set_alloc"""
+        n, d = sketches.shape
+        p, m, k = _buf(sketches)
+        eb = self.ctx._elem_bytes(sketches)
+        _check(self.ctx.lib.mvs_sketch_set_fill(self._h, p, eb, m, int(row_offset), n))
 
     def close(self):
         if self._h:
@@ -298,6 +307,12 @@ class Context:
             self.synchronize()
         return SketchSet(self, h)
 
+    def sketch_set_alloc(self, n, d, limbs):
+        """zeroed planes for n samples with limb code `limbs`; fill row ranges with SketchSet.fill"""
+        h = _P()
+        _check(self.lib.mvs_sketch_set_alloc(self._h, int(n), int(d), int(limbs), ctypes.byref(h)))
+        return SketchSet(self, h)
+
     def sketch_set_from_planes(self, planes, n, n_alloc, d, d_pad, limbs):
         pp, pm, pk = _buf(planes)
         if pm != MEM_DEVICE:
@@ -344,6 +359,18 @@ class Context:
         count = _c.c_int64(int(n_cells))
         _check(self.lib.mvs_pairwise_block(self._h, sset._h, np_, keep_mode, row_begin, row_end, col_begin, col_end,
                                            flags, cp, cells.shape[0], ctypes.byref(count)))
+        return count.value
+
+    def search_block(self, sset, norms_sq, jaccard_min, row_begin, row_end, col_begin, col_end, cells):
+        """pairs (query row, database column) with Jaccard estimate > jaccard_min -> number of hits written to
+        the device buffer `cells`, sorted by (row, col)"""
+        np_, nm, nk = _buf(norms_sq)
+        cp, cm, ck = _buf(cells)
+        if nm != MEM_DEVICE or cm != MEM_DEVICE:
+            raise ValueError("norms_sq and cells must be device buffers")
+        count = _c.c_int64()
+        _check(self.lib.mvs_search_block(self._h, sset._h, np_, float(jaccard_min), row_begin, row_end, col_begin,
+                                         col_end, cp, cells.shape[0], ctypes.byref(count)))
         return count.value
 
     def cells_sort(self, cells_in, n, cells_out):

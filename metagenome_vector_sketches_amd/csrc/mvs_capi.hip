@@ -662,10 +662,11 @@ namespace {
 
 // thresholds + one comparison launch appending to `raw` (device) from the count already in c->d_counter
 int pairwise_launch(mvs_ctx* c, const mvs_sketch_set* s, const double* d_n2, int keep_mode, int64_t rb, int64_t re,
-                    int64_t cb, int64_t ce, bool symmetric, bool mirror_all, mvs_cell* raw, int64_t capacity) {
+                    int64_t cb, int64_t ce, bool symmetric, bool mirror_all, mvs_cell* raw, int64_t capacity,
+                    double keep_coeff = 0.05) {
     int rc = ensure_buf(c, &c->pw_thr, &c->pw_thr_bytes, (size_t)s->n_alloc * 4);
     if (rc) return rc;
-    mvs::launch_cand_thr(c->stream, d_n2, s->n, s->n_alloc, s->d, (int32_t*)c->pw_thr);
+    mvs::launch_cand_thr(c->stream, d_n2, s->n, s->n_alloc, s->d, keep_coeff, (int32_t*)c->pw_thr);
     rc = check_kernel("k_cand_thr");
     if (rc) return rc;
     mvs::PairwiseArgs a{};
@@ -682,6 +683,7 @@ int pairwise_launch(mvs_ctx* c, const mvs_sketch_set* s, const double* d_n2, int
     a.norms_sq = d_n2;
     a.cand_thr = (const int32_t*)c->pw_thr;
     a.keep_mode = keep_mode;
+    a.keep_coeff = keep_coeff;
     a.cells = raw;
     a.capacity = (unsigned long long)capacity;
     a.counter = c->d_counter;
@@ -797,6 +799,37 @@ int mvs_pairwise_block(mvs_ctx* c, const mvs_sketch_set* s, const double* norms_
     *n_cells = (int64_t)count;
     if ((int64_t)count > capacity)
         return fail(MVS_E_CAPACITY, "%llu cells appended but capacity is %lld", count, (long long)capacity);
+    return MVS_OK;
+}
+
+int mvs_search_block(mvs_ctx* c, const mvs_sketch_set* s, const double* norms_sq, double jaccard_min,
+                     int64_t row_begin, int64_t row_end, int64_t col_begin, int64_t col_end, mvs_cell* cells,
+                     int64_t capacity, int64_t* n_cells) {
+    if (!c || !s || !n_cells) return fail(MVS_E_INVALID, "NULL argument");
+    *n_cells = 0;
+    if (capacity < 0 || !(jaccard_min > 0.0) || !(jaccard_min < 1.0)) return fail(MVS_E_INVALID, "bad argument");
+    if (row_begin < 0 || row_end > s->n || row_begin > row_end || col_begin < 0 || col_end > s->n || col_begin > col_end)
+        return fail(MVS_E_INVALID, "block outside the sketch set");
+    if (row_begin == row_end || col_begin == col_end) return MVS_OK;
+    if (!norms_sq || (capacity > 0 && !cells)) return fail(MVS_E_INVALID, "NULL buffer");
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = ensure_buf(c, &c->pw_tmp, &c->pw_tmp_bytes, (size_t)std::max<int64_t>(capacity, 1) * sizeof(mvs_cell));
+    if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(c->d_counter, 0, 8, c->stream));
+    // J > j  <=>  (P/d) / (n2r + n2c - P/d) > j  <=>  double(P)/d > j/(1+j) * (n2r + n2c)   (for n2r + n2c > P/d >= 0)
+    rc = pairwise_launch(c, s, norms_sq, MVS_KEEP_INT16, row_begin, row_end, col_begin, col_end, false, false,
+                         (mvs_cell*)c->pw_tmp, capacity, jaccard_min / (1.0 + jaccard_min));
+    if (rc) return rc;
+    unsigned long long count = 0;
+    HIP_TRY(hipMemcpyAsync(&count, c->d_counter, 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    *n_cells = (int64_t)count;
+    if ((int64_t)count > capacity)
+        return fail(MVS_E_CAPACITY, "%llu hits but capacity is %lld", count, (long long)capacity);
+    if (count == 0) return MVS_OK;
+    rc = sort_on_device(c, (mvs_cell*)c->pw_tmp, (int64_t)count, cells);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));   // documented synchronous: `cells` is final on return
     return MVS_OK;
 }
 

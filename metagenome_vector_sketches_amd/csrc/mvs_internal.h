@@ -43,6 +43,7 @@ struct PairwiseArgs {
     const double* norms_sq;       // n
     const int32_t* cand_thr;      // n_alloc: conservative integer per-sample threshold part
     int keep_mode;
+    double keep_coeff;            // 0.05 in the reference's keep test; j/(1+j) for a Jaccard > j search
     mvs_cell* cells;
     unsigned long long capacity;
     unsigned long long* counter;  // number of kept cells (may exceed capacity)
@@ -68,7 +69,7 @@ int launch_max_abs(hipStream_t stream, const void* d_sk, int elem_bytes, int64_t
 int launch_limb_split(hipStream_t stream, const void* d_sk, int elem_bytes, int64_t n_rows, int d, int limbs,
                       int8_t* d_planes, int d_pad, int64_t row_offset);
 int launch_cand_thr(hipStream_t stream, const double* d_norms_sq, int64_t n, int64_t n_alloc, int d,
-                    int32_t* d_thr);
+                    double coeff, int32_t* d_thr);
 // mode 0: comparison (kept cells), mode 1: dense dots.  algo 0: MFMA, 1: vector ALU.
 int launch_pairwise(hipStream_t stream, const PairwiseArgs& a, int mode, int algo);
 // sort cells by (row, col); tmp buffers owned by the caller

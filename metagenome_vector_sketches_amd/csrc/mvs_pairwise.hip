@@ -59,8 +59,8 @@ __device__ __forceinline__ TileCoord map_tile(unsigned b, int n_tr, int n_tc, in
 }
 
 // exact per-cell decision + quantisation, identical operation order to the reference
-__device__ __forceinline__ bool keep_cell(int32_t P, int d, double n2r, double n2c, int keep_mode) {
-    const double threshold = 0.05 * (n2r + n2c);                       // :139
+__device__ __forceinline__ bool keep_cell(int32_t P, int d, double n2r, double n2c, int keep_mode, double coeff) {
+    const double threshold = coeff * (n2r + n2c);                      // :139 (coeff = 0.05)
     if (keep_mode == MVS_KEEP_INT32) {
         const long long q = (long long)P / (long long)d;               // :140-141 truncating
         return (double)q > threshold;
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void k_pairwise_mfma(const Pairwis
                     if (__any(cand)) {
                         bool keep = false;
                         if (cand && row < a.row_end && col < a.col_end)
-                            keep = keep_cell(P, a.d, a.norms_sq[row], a.norms_sq[col], a.keep_mode);
+                            keep = keep_cell(P, a.d, a.norms_sq[row], a.norms_sq[col], a.keep_mode, a.keep_coeff);
                         emit_cell(a, keep, a.mirror_all || (mirror_tile && col < a.row_end), (int32_t)row, (int32_t)col, P,
                                   lane);
                     }
@@ -403,7 +403,7 @@ __global__ __launch_bounds__(256) void k_pairwise_valu(const PairwiseArgs a) {
         if (in) a.dots[(row - a.row_begin) * (a.col_end - a.col_begin) + (col - a.col_begin)] = P;
     } else {
         bool keep = false;
-        if (in) keep = keep_cell(P, a.d, a.norms_sq[row], a.norms_sq[col], a.keep_mode);
+        if (in) keep = keep_cell(P, a.d, a.norms_sq[row], a.norms_sq[col], a.keep_mode, a.keep_coeff);
         emit_cell(a, keep, a.mirror_all != 0, (int32_t)row, (int32_t)col, P, lane);
     }
 }
@@ -478,7 +478,7 @@ __global__ __launch_bounds__(256) void k_limb_split(const T* __restrict__ sk, in
 
 // conservative integer part of the keep threshold: keep(i,j) implies P >= thr[i] + thr[j]
 __global__ __launch_bounds__(256) void k_cand_thr(const double* __restrict__ n2, int64_t n, int64_t n_alloc,
-                                                  int d, int32_t* __restrict__ thr) {
+                                                  int d, double coeff, int32_t* __restrict__ thr) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_alloc) return;
     int32_t t = (1 << 30) - 1;   // padding rows: never a candidate
@@ -486,7 +486,7 @@ __global__ __launch_bounds__(256) void k_cand_thr(const double* __restrict__ n2,
         const double x = n2[i];
         t = -1;
         if (x >= 0.0) {
-            const double f = floor(0.05 * (double)d * x * (1.0 - 1.0 / 1048576.0)) - 1.0;
+            const double f = floor(coeff * (double)d * x * (1.0 - 1.0 / 1048576.0)) - 1.0;
             t = f >= 1073741823.0 ? (1 << 30) - 1 : (f < -1.0 ? -1 : (int32_t)f);
         }
     }
@@ -590,9 +590,9 @@ int launch_limb_split(hipStream_t stream, const void* d_sk, int elem_bytes, int6
 }
 
 int launch_cand_thr(hipStream_t stream, const double* d_norms_sq, int64_t n, int64_t n_alloc, int d,
-                    int32_t* d_thr) {
+                    double coeff, int32_t* d_thr) {
     hipLaunchKernelGGL(k_cand_thr, dim3((unsigned)((n_alloc + 255) / 256)), dim3(256), 0, stream, d_norms_sq, n,
-                       n_alloc, d, d_thr);
+                       n_alloc, d, coeff, d_thr);
     return 0;
 }
 

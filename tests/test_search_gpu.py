@@ -1,0 +1,60 @@
+"""GPU: query-by-hashes search (metagenome_vector_sketches_amd/search.py, mvs_search_block) against a float64
+restatement of the reference's formula (src/jaccard.py:199) on exact dot products.  Tolerance 1e-5 relative
+on the Jaccard estimates (the reference path itself is float32)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _write_db(folder, gold):
+    os.makedirs(folder, exist_ok=True)
+    gold.vectors.astype("<i4").tofile(folder + "vectors.bin")
+    open(folder + "vector_norms.txt", "w").write(gold.norms_txt)
+    open(folder + "dimension.txt", "w").write("2048\n")
+    open(folder + "dtype.txt", "w").write("int32\n")
+
+
+def test_search_matches_float64_restatement(ctx, gold, tmp_path):
+    from metagenome_vector_sketches_amd import search
+    from oracle import pyoracle as orc
+    db = str(tmp_path / "db") + "/"
+    _write_db(db, gold)
+    # queries: two database samples verbatim, a half-subsample, a disjoint set, an empty set
+    rng = np.random.default_rng(1)
+    pick = [gold.names.index("DRR000821"), 6]
+    qlists = [gold.hashes[gold.offsets[i]:gold.offsets[i + 1]] for i in pick]
+    big = gold.hashes[gold.offsets[6]:gold.offsets[7]]
+    qlists.append(big[rng.random(len(big)) < 0.5])
+    qlists.append(rng.integers(0, 2**62, size=500, dtype=np.uint64))
+    qlists.append(np.zeros(0, dtype=np.uint64))
+    qf = tmp_path / "queries.txt"
+    with open(qf, "w") as f:
+        for k, h in enumerate(qlists):
+            f.write("q%d:" % k + "".join(" %d" % int(x) for x in h) + "\n")
+        f.write("\n")
+    j = 0.1
+    got = search.search_index(db, str(qf), j, ctx=ctx, verbose=False)
+    norms = np.array([float(l.split(" ")[1]) for l in gold.norm_lines()])
+    want = []
+    for qi, h in enumerate(qlists):
+        v = orc.project(np.unique(h), 2048).astype(np.int64)
+        qn2 = float((v * v).sum()) / 2048
+        if qn2 == 0:
+            continue
+        inter = (gold.vectors.astype(np.int64) @ v).astype(np.float64) / 2048
+        jac = inter / (norms ** 2 + qn2 - inter)
+        for k in np.argsort(-jac, kind="stable"):
+            if jac[k] > j:
+                want.append((qi, gold.names[k], float(jac[k])))
+    assert [(a, b) for a, b, _ in got] == [(a, b) for a, b, _ in want]
+    assert np.allclose([c for _, _, c in got], [c for _, _, c in want], rtol=1e-5, atol=0)
+    first = {}
+    for qi, nid, jac in got:
+        first.setdefault(qi, (nid, jac))
+    assert first[0][0] == "DRR000821" and abs(first[0][1] - 1.0) < 1e-4      # a database sample finds itself
+    assert first[1][0] == gold.names[6] and abs(first[1][1] - 1.0) < 1e-4
+    assert first[2][0] == gold.names[6] and 0.4 < first[2][1] < 0.6           # half subsample B of A: J = 0.5
+    assert 3 not in first and 4 not in first                                  # disjoint and empty queries: nothing
