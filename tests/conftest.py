@@ -13,6 +13,13 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the native pieces are git-ignored build products: build them once if this is a fresh checkout
+    pkg = os.path.join(ROOT, "metagenome_vector_sketches_amd")
+    need = [os.path.join(pkg, "libmvs_hip.so"), os.path.join(pkg, "bin", "query_pc_mat"),
+            os.path.join(pkg, "bin", "project_everything"), os.path.join(ROOT, "oracle", "libmvs_oracle.so")]
+    if not all(os.path.exists(p) for p in need):
+        import __graft_entry__
+        __graft_entry__.build()
 
 
 class Golden:
