@@ -1,0 +1,63 @@
+"""GPU: randomised parity sweeps (seeded) of both kernels against the oracle: ragged sample sizes with
+empty samples, odd dimensions, arbitrary row ranges, both keep modes, every limb code, thresholds that sit
+right at the keep boundary."""
+import numpy as np
+import pytest
+
+from metagenome_vector_sketches_amd import _capi, synth
+from oracle import pyoracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_projection_random_shapes(ctx, seed):
+    rng = np.random.default_rng(1000 + seed)
+    d = int(rng.choice([1, 63, 64, 65, 128, 777, 2048, 3000]))
+    n_samples = int(rng.integers(1, 40))
+    sizes = rng.choice([0, 1, 5, 64, 511, 512, 513, 2047, 4097, 30000, 66000], size=n_samples)
+    lists = [rng.integers(0, 2**64 - 1, size=int(s), dtype=np.uint64, endpoint=True) for s in sizes]
+    offs = np.zeros(n_samples + 1, dtype=np.int64)
+    offs[1:] = np.cumsum(sizes)
+    flat = np.concatenate(lists) if offs[-1] else np.zeros(0, dtype=np.uint64)
+    got = ctx.project_csr(flat, offs, d)
+    assert np.array_equal(got, orc.project_csr(flat, offs, d, threads=8, fast=True))
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_pairwise_random_cases(ctx, seed):
+    rng = np.random.default_rng(2000 + seed)
+    n = int(rng.integers(2, 420))
+    d = int(rng.choice([64, 100, 256, 1000, 2048]))
+    hi = int(rng.choice([100, 127, 128, 1500, 8127, 8128, 32639, 32640, 1_000_000]))
+    # clustered rows so that the keep test fires: base vectors plus noise
+    base = rng.integers(-hi, hi + 1, size=(max(1, n // 5), d))
+    sk = base[rng.integers(0, len(base), size=n)] + rng.integers(-max(1, hi // 8), max(1, hi // 8) + 1, size=(n, d))
+    sk = np.clip(sk, -hi, hi).astype(np.int32)
+    sk[rng.integers(0, n)] = 0                                  # an all-zero sketch (empty sample)
+    # norms: consistent with the sketches for most rows, deliberately off for a few (boundary behaviour)
+    n2 = np.array([orc.norm_sq_from_text(orc.format_norm(orc.norm(r))) for r in sk])
+    n2[rng.integers(0, n, size=max(1, n // 10))] *= rng.choice([0.5, 0.97, 1.03, 2.0])
+    code = None
+    if 128 <= np.abs(sk).max() <= 8127 and seed % 2:
+        code = _capi.LIMBS_K3
+    ss = ctx.sketch_set(sk, limbs=code)
+    r0 = int(rng.integers(0, n))
+    r1 = int(rng.integers(r0, n + 1))
+    for mode in (_capi.KEEP_INT32, _capi.KEEP_INT16):
+        for (b, e) in ((0, n), (r0, r1)):
+            cells, cnt = ctx.pairwise_rows(ss, n2, row_begin=b, row_end=e, keep_mode=mode)
+            skx = sk if mode == _capi.KEEP_INT32 else None
+            if mode == _capi.KEEP_INT32:
+                want = orc.pairwise_rows(sk, n2, row_begin=b, row_end=e, chunk=192, threads=8)
+                want = sorted(map(tuple, want.tolist()))
+            else:
+                # the oracle's int16 path takes int16 sketches; emulate its floating keep test on int32 dots
+                dots = orc.dots_dense(sk, b, e, 0, n, threads=8)
+                lib = orc.load()
+                want = sorted((b + i, j, int(dots[i, j]), lib.mvs_oracle_quantize(int(dots[i, j]), d, n2[b + i], n2[j]))
+                              for i in range(e - b) for j in range(n)
+                              if lib.mvs_oracle_keep_i16(int(dots[i, j]), d, n2[b + i], n2[j]))
+            got = [tuple(int(x) for x in c) for c in cells.tolist()]
+            assert got == want, (seed, mode, b, e, len(got), len(want))
+    ss.close()
