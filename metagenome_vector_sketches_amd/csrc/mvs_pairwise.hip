@@ -43,14 +43,16 @@ struct TileCoord {
     bool valid;
 };
 
-// blockIdx.x -> tile.  16x16 super-patches in row-major order; inside one, the XCD label (b % 8)
-// picks a 4-row x 8-col sub-patch and b / 8 walks it.  Placement only affects speed.
-__device__ __forceinline__ TileCoord map_tile(unsigned b, int n_tr, int n_tc, int n_spc) {
+// (blockIdx.x, blockIdx.y) -> tile.  The tile grid is cut into 16x16-tile super-patches: blockIdx.y is the
+// patch row, blockIdx.x / 256 the patch column; inside a patch the XCD label (blockIdx.x % 8 -- gridDim.x is
+// a multiple of 256, so this is also the linear workgroup id % 8) picks a 4-row x 8-col sub-patch and
+// (blockIdx.x / 8) % 32 walks it.  Placement only affects speed.  (A 2-D grid because a dispatch holds at
+// most 2^32 work-items per dimension: one dimension would cap the matrix at ~370k samples.)
+__device__ __forceinline__ TileCoord map_tile(unsigned b, unsigned patch_row, int n_tr, int n_tc) {
     const unsigned x = b & 7u;
     const unsigned q = b >> 3;
-    const unsigned sp = q >> 5;
     const unsigned ql = q & 31u;
-    const int spr = (int)(sp / (unsigned)n_spc), spc = (int)(sp % (unsigned)n_spc);
+    const int spr = (int)patch_row, spc = (int)(q >> 5);
     TileCoord t;
     t.tr = spr * 16 + (int)(x >> 1) * 4 + (int)(ql >> 3);
     t.tc = spc * 16 + (int)(x & 1u) * 8 + (int)(ql & 7u);
@@ -151,7 +153,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void k_pairwise_mfma(const Pairwis
     static_assert(kPieces % kWavesT == 0, "stage must split evenly over the waves");
     static_assert(TM % TN == 0 || TN % TM == 0, "tile edges must nest");
 
-    const TileCoord tc = map_tile(blockIdx.x, n_tr, n_tc, n_spc);
+    const TileCoord tc = map_tile(blockIdx.x, blockIdx.y, n_tr, n_tc);
+    (void)n_spc;
     if (!tc.valid) return;
 
     const int tid = threadIdx.x;
@@ -381,7 +384,8 @@ __global__ __launch_bounds__(512, 2) void k_pairwise_mfma16(const PairwiseArgs a
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int L = 2, TM = 128, TN = 128, kWavesT = 8, WN = 4;
     constexpr int kRegion = L * TM * kSK, kStage = 2 * kRegion, kPPW = kStage / 1024 / kWavesT;   // 4
-    const TileCoord tc = map_tile(blockIdx.x, n_tr, n_tc, n_spc);
+    const TileCoord tc = map_tile(blockIdx.x, blockIdx.y, n_tr, n_tc);
+    (void)n_spc;
     if (!tc.valid) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -666,8 +670,7 @@ int launch_mfma_variant(hipStream_t stream, const PairwiseArgs& a) {
     if (rows <= 0 || cols <= 0) return 0;
     const int n_tr = (int)((rows + TM - 1) / TM), n_tc = (int)((cols + TN - 1) / TN);
     const int n_spr = (n_tr + 15) / 16, n_spc = (n_tc + 15) / 16;
-    const int64_t blocks = (int64_t)n_spr * n_spc * 256;
-    if (blocks > 0x7fffffffLL) return MVS_E_INVALID;
+    if (n_spr > 65535 || (int64_t)n_spc * 256 * (WM * WN * 64) > 0xffffffffLL) return MVS_E_INVALID;
     const size_t lds = (size_t)NST * L * (TM + TN) * kSK;
     PairwiseArgs b = a;
     // the symmetric schedule needs the row and column tile grids to share their origin modulo TM
@@ -675,8 +678,8 @@ int launch_mfma_variant(hipStream_t stream, const PairwiseArgs& a) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pairwise_mfma<L, KARA, MODE, NST, WM, WN, BT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return MVS_E_HIP;
-    hipLaunchKernelGGL((k_pairwise_mfma<L, KARA, MODE, NST, WM, WN, BT>), dim3((unsigned)blocks), dim3(WM * WN * 64),
-                       lds, stream, b, n_tr, n_tc, n_spc);
+    hipLaunchKernelGGL((k_pairwise_mfma<L, KARA, MODE, NST, WM, WN, BT>), dim3((unsigned)n_spc * 256u, (unsigned)n_spr),
+                       dim3(WM * WN * 64), lds, stream, b, n_tr, n_tc, n_spc);
     return 0;
 }
 
@@ -687,16 +690,15 @@ int launch_mfma16(hipStream_t stream, const PairwiseArgs& a) {
     if (rows <= 0 || cols <= 0) return 0;
     const int n_tr = (int)((rows + TM - 1) / TM), n_tc = (int)((cols + TN - 1) / TN);
     const int n_spr = (n_tr + 15) / 16, n_spc = (n_tc + 15) / 16;
-    const int64_t blocks = (int64_t)n_spr * n_spc * 256;
-    if (blocks > 0x7fffffffLL) return MVS_E_INVALID;
+    if (n_spr > 65535 || (int64_t)n_spc * 256 * 512 > 0xffffffffLL) return MVS_E_INVALID;
     const size_t lds = (size_t)NST * 2 * (TM + TN) * kSK;
     PairwiseArgs b = a;
     if (b.symmetric && ((a.row_begin - a.col_begin) % TM != 0 || a.mirror_all)) b.symmetric = 0;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pairwise_mfma16<MODE, NST>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return MVS_E_HIP;
-    hipLaunchKernelGGL((k_pairwise_mfma16<MODE, NST>), dim3((unsigned)blocks), dim3(512), lds, stream, b, n_tr, n_tc,
-                       n_spc);
+    hipLaunchKernelGGL((k_pairwise_mfma16<MODE, NST>), dim3((unsigned)n_spc * 256u, (unsigned)n_spr), dim3(512), lds,
+                       stream, b, n_tr, n_tc, n_spc);
     return 0;
 }
 

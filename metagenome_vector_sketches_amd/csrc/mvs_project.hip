@@ -363,8 +363,8 @@ int launch_project(hipStream_t stream, const uint64_t* d_hashes, const ProjUnit*
     const int nblk = (d + 63) / 64;
     // grid.x is limited to 2^31-1, plenty; launch in slabs anyway to keep blockIdx.x an int
     const int ny = bpw == 1 ? (nblk + 3) / 4 : (nblk + 7) / 8;
-    // slabs keep the 1-D grid below 2^31 workgroups
-    const int64_t kMaxUnits = ((int64_t)0x7fffffff / (8 * ny) - 1) * 8;
+    // a dispatch holds at most 2^32 work-items per dimension: slabs of at most ~2^32/256 workgroups
+    const int64_t kMaxUnits = ((int64_t)(0xffffffffLL / 256) / (8 * ny) - 1) * 8;
     for (int64_t u0 = 0; u0 < n_units; u0 += kMaxUnits) {
         const int64_t nu = n_units - u0 < kMaxUnits ? n_units - u0 : kMaxUnits;
         const unsigned grid = (unsigned)(((nu + 7) / 8) * 8 * ny);
@@ -385,16 +385,24 @@ int launch_project(hipStream_t stream, const uint64_t* d_hashes, const ProjUnit*
     return 0;
 }
 
+// one wave per row, 4 rows per workgroup; slabs of 2^22 workgroups keep each dispatch below 2^32 work-items
+constexpr int64_t kRowSlab = (int64_t)4 << 22;
+
 int launch_sumsq(hipStream_t stream, const int32_t* d_sk, int64_t n, int d, int64_t* d_out) {
-    if (n == 0) return 0;
-    hipLaunchKernelGGL(k_sumsq, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, d_sk, n, d, d_out);
+    for (int64_t r0 = 0; r0 < n; r0 += kRowSlab) {
+        const int64_t m = n - r0 < kRowSlab ? n - r0 : kRowSlab;
+        hipLaunchKernelGGL(k_sumsq, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, stream, d_sk + r0 * d, m, d, d_out + r0);
+    }
     return 0;
 }
 
 int launch_stats(hipStream_t stream, const int32_t* d_sk, int64_t n, int d, int64_t* d_sumsq,
                  unsigned long long* d_max_abs) {
-    if (n == 0) return 0;
-    hipLaunchKernelGGL(k_stats, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, d_sk, n, d, d_sumsq, d_max_abs);
+    for (int64_t r0 = 0; r0 < n; r0 += kRowSlab) {
+        const int64_t m = n - r0 < kRowSlab ? n - r0 : kRowSlab;
+        hipLaunchKernelGGL(k_stats, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, stream, d_sk + r0 * d, m, d, d_sumsq + r0,
+                           d_max_abs);
+    }
     return 0;
 }
 

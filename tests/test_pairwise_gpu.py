@@ -238,3 +238,33 @@ def test_baseline_config2_full_size(ctx):
     want = _oracle_sorted(sk, n2, row_begin=5000, row_end=5048, chunk=192)
     got = [tuple(int(x) for x in c) for c in cells[(rows >= 5000) & (rows < 5048)]]
     assert got == want
+
+
+def test_half_million_samples_grid_limits(ctx):
+    """N = 500 000 (2.5e11 cells, 15.6 M workgroups): beyond what a one-dimensional dispatch can address
+    (2^32 work-items); exercises the 2-D tile grid.  Properties only: every row keeps its 16 cluster mates
+    (incl. itself, q = 255 on the diagonal), the kept set is symmetric, sorted, within bounds."""
+    import torch
+    n, d = 500_000, 2048
+    sk_t = synth.make_sketches_torch(n, d, 50_000, seed=31, device="cuda")
+    ss_t = torch.empty(n, dtype=torch.int64, device="cuda")
+    ctx.set_stream(torch.cuda.current_stream())
+    try:
+        _, max_abs = ctx.stats(sk_t, out=ss_t)
+        n2 = torch.sqrt(ss_t.double() / d) ** 2
+        sset = ctx.sketch_set(sk_t)
+        cells_t = torch.empty((n * 20, 4), dtype=torch.int32, device="cuda")
+        _, cnt = ctx.pairwise_rows(sset, n2, cells_out=cells_t)
+        torch.cuda.synchronize()
+        cells = cells_t[:cnt].cpu().numpy()
+        sset.close()
+    finally:
+        ctx.set_stream(None)
+    rows, cols = cells[:, 0].astype(np.int64), cells[:, 1].astype(np.int64)
+    assert rows.min() == 0 and rows.max() == n - 1 and cols.min() == 0 and cols.max() == n - 1
+    key = rows * n + cols
+    assert np.all(np.diff(key) > 0)
+    assert np.array_equal(np.sort(cols * n + rows), key)
+    assert int(((rows // 16) == (cols // 16)).sum()) == n * 16
+    per_row = np.bincount(rows, minlength=n)
+    assert per_row.min() >= 16 and np.all(cells[rows == cols][:, 3] == 255) and int((rows == cols).sum()) == n
