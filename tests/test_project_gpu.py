@@ -160,3 +160,33 @@ def test_toy_set_other_dimensions_reference_digests(ctx, gold):
         ref_norms = [float(l.split(" ")[1]) for l in gold.kat["toy_norms_d%d" % d].strip().split("\n")]
         mine = np.sqrt(ctx.sumsq(got).astype(np.float64) / d)
         assert np.allclose(mine, ref_norms, rtol=1e-5, atol=1e-12)
+
+
+def test_many_tiny_samples_cross_the_dispatch_limit(ctx):
+    """17.6 M samples of 2 hashes, d = 64: more workgroups than one dispatch can hold (2^32 work-items), so
+    the launcher must cut the unit list into slabs.  Expected sketches from a torch restatement of splitmix64
+    (int64 arithmetic wraps like uint64; logical shifts emulated)."""
+    import torch
+    n = 17_600_000
+    g = torch.Generator(device="cuda")
+    g.manual_seed(9)
+    h = torch.randint(0, synth.MAX_HASH, (n, 2), dtype=torch.int64, device="cuda", generator=g)
+    offsets = np.arange(n + 1, dtype=np.int64) * 2
+    out = torch.empty((n, 64), dtype=torch.int32, device="cuda")
+    ctx.project_csr(h.view(-1), offsets, 64, out=out)
+    ctx.synchronize()
+
+    def lsr(x, s):
+        return (x >> s) & ((1 << (64 - s)) - 1)
+
+    def c(v):   # uint64 constant as a wrapped int64
+        return v - (1 << 64) if v >= (1 << 63) else v
+
+    z = h + c(0x9e3779b97f4a7c15)
+    z = (z ^ lsr(z, 30)) * c(0xbf58476d1ce4e5b9)
+    z = (z ^ lsr(z, 27)) * c(0x94d049bb133111eb)
+    z = z ^ lsr(z, 31)
+    for k in (0, 1, 31, 32, 62, 63):
+        bits = (lsr(z, k) & 1) if k else (z & 1)
+        want = (2 - 2 * bits.sum(dim=1)).to(torch.int32)
+        assert torch.equal(out[:, k], want), k
