@@ -205,7 +205,12 @@ def main():
                      "note": "integer-VALU bound by construction (implicit hash-generated matrix): see valu"},
         "roofline_valu": {"kernel": "k_project", "achieved": k1_intops / (k1 * 1e-3) / 1e12,
                           "peak": VALU_INT_PEAK_TOPS, "unit": "T sign-accumulations/s vs T int32-op/s",
-                          "frac": k1_intops / (k1 * 1e-3) / 1e12 / VALU_INT_PEAK_TOPS},
+                          "frac": k1_intops / (k1 * 1e-3) / 1e12 / VALU_INT_PEAK_TOPS,
+                          # instruction-issue bound: 22.9 VALU per (hash, 64-dim block) at the issue costs measured by
+                          # tools/microbench/valu_rates (profiles/r01_valu_rates_microbench.txt): 35.5 ns per
+                          # (64 hashes x block) per SIMD, 1024 SIMDs
+                          "issue_bound_ms": S * float(NH) * ((D + 63) // 64) / 64.0 / 1024.0 * 35.5e-6,
+                          "issue_bound_frac": S * float(NH) * ((D + 63) // 64) / 64.0 / 1024.0 * 35.5e-6 / k1},
         "roofline_pairwise": {"kernel": "k_pairwise_mfma", "bound": "mfma",
                               "achieved": k2_flops / (k2 * 1e-3) / 1e12, "peak": INT8_MFMA_PEAK_TOPS,
                               "unit": "TFLOP/s", "frac": k2_flops / (k2 * 1e-3) / 1e12 / INT8_MFMA_PEAK_TOPS,
