@@ -222,3 +222,35 @@ def test_pairwise_streams_a_large_db(tmp_path):
         assert r.returncode == 0, r.stderr
         assert "Total vectors: 150000" in r.stdout and "Shard 1 processing rows 75000 to 150000" in r.stdout
         assert _dump(os.path.join(out, "shard_1")) == want
+
+
+def test_degenerate_inputs(tmp_path):
+    """empty hash file, CRLF + missing final newline, a single sample, an empty DB"""
+    exe = os.path.join(BIN, "project_everything")
+    hf = tmp_path / "empty.txt"
+    hf.write_text("")
+    r = run(exe, "sketch", str(hf), str(tmp_path / "db0"))
+    assert r.returncode == 0, r.stderr
+    assert "Loaded 0 hash sets" in r.stdout
+    assert os.path.getsize(str(tmp_path / "db0" / "vectors.bin")) == 0
+    assert open(str(tmp_path / "db0" / "vector_norms.txt")).read() == ""
+    # an empty DB: nothing to compare, an (empty) shard is still written
+    r = run(os.path.join(BIN, "pairwise_comp_optimized"), "--db", str(tmp_path / "db0") + "/", "--max_memory_gb", "1",
+            "--num_threads", "1", "--output_folder", str(tmp_path / "idx0"), "--num_shards", "1", "--shard_idx", "0")
+    assert r.returncode == 0, r.stderr
+    assert "Total vectors: 0" in r.stdout and _dump(str(tmp_path / "idx0" / "shard_0")) == []
+    # CRLF line ends, no newline at the end of the file, one sample with a single hash
+    hf1 = tmp_path / "one.txt"
+    hf1.write_bytes(b"solo: 42\r\nother: 1 2 3")
+    r = run(exe, "sketch", str(hf1), str(tmp_path / "db1"), "-d", "64")
+    assert r.returncode == 0, r.stderr
+    v = np.fromfile(str(tmp_path / "db1" / "vectors.bin"), dtype="<i4").reshape(2, 64)
+    from oracle import pyoracle as orc
+    assert np.array_equal(v[0], orc.project(np.array([42], dtype=np.uint64), 64))
+    assert np.array_equal(v[1], orc.project(np.array([1, 2, 3], dtype=np.uint64), 64))
+    assert open(str(tmp_path / "db1" / "vector_norms.txt")).read() == "solo 1\nother %s\n" % orc.format_norm(orc.norm(v[1]))
+    r = run(os.path.join(BIN, "pairwise_comp_optimized"), "--db", str(tmp_path / "db1") + "/", "--max_memory_gb", "1",
+            "--num_threads", "1", "--output_folder", str(tmp_path / "idx1"), "--num_shards", "1", "--shard_idx", "0")
+    assert r.returncode == 0, r.stderr
+    got = _dump(str(tmp_path / "idx1" / "shard_0"))
+    assert (0, 0, 255) in got and (1, 1, 255) in got
