@@ -254,3 +254,55 @@ def test_degenerate_inputs(tmp_path):
     assert r.returncode == 0, r.stderr
     got = _dump(str(tmp_path / "idx1" / "shard_0"))
     assert (0, 0, 255) in got and (1, 1, 255) in got
+
+
+REF = os.path.join(ROOT, "oracle", "_ref")
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REF, "project_everything")),
+                    reason="oracle/_ref is built only where /root/reference exists")
+def test_sketch_cli_vs_reference_binary_random(tmp_path):
+    """the reference's own executables (oracle/_ref, compiled from its sources) and ours on fresh random
+    input: ragged sizes, an empty sample, duplicates, hashes near 2^64; vectors.bin must be identical."""
+    import json
+    import time
+    rng = np.random.default_rng(20251226)
+    n = int(os.environ.get("MVS_CLI_COMPARE_N", "400"))            # scale up by hand for an end-to-end timing
+    sizes = rng.integers(1, int(os.environ.get("MVS_CLI_COMPARE_MAXH", "30000")), n)
+    sizes[7] = 0
+    sizes[11] = 1
+    hf = tmp_path / "h.txt"
+    with open(hf, "w") as f:
+        for i, s in enumerate(sizes):
+            h = rng.integers(0, 2 ** 64, int(s), dtype=np.uint64)
+            if i % 5 == 0 and s > 4:
+                h[:4] = np.array([0, 2 ** 64 - 1, 2 ** 63, h[4]], dtype=np.uint64)
+            f.write("s%d:" % i + "".join(" %d" % int(x) for x in h) + "\n")
+    t = {}
+    threads = os.cpu_count() or 16
+    for tag, exe in (("ref", os.path.join(REF, "project_everything")), ("ours", os.path.join(BIN, "project_everything"))):
+        t0 = time.time()
+        r = run(exe, "sketch", str(hf), str(tmp_path / tag), "-t", str(threads), "-d", "1024")
+        t[tag] = time.time() - t0
+        assert r.returncode == 0, r.stderr
+    a = np.fromfile(str(tmp_path / "ref" / "vectors.bin"), dtype="<i4")
+    b = np.fromfile(str(tmp_path / "ours" / "vectors.bin"), dtype="<i4")
+    assert a.size == n * 1024 and np.array_equal(a, b)
+    for name in ("dimension.txt", "dtype.txt"):
+        assert open(str(tmp_path / "ref" / name)).read() == open(str(tmp_path / "ours" / name)).read()
+    ra = open(str(tmp_path / "ref" / "vector_norms.txt")).read().strip().split("\n")
+    rb = open(str(tmp_path / "ours" / "vector_norms.txt")).read().strip().split("\n")
+    assert len(ra) == len(rb) == n
+    for x, y in zip(ra, rb):
+        (xn, xv), (yn, yv) = x.split(" "), y.split(" ")
+        assert xn == yn and abs(float(xv) - float(yv)) <= 1e-5 * abs(float(xv)) + 1e-12
+    # query-side protocol on the same file
+    q = tmp_path / "q.txt"
+    q.write_text("".join(open(hf).readlines()[:40]))
+    ra = run(os.path.join(REF, "standalone_projection"), str(q), "512")
+    rb = run(os.path.join(BIN, "standalone_projection"), str(q), "512")
+    assert ra.returncode == 0 and rb.returncode == 0 and ra.stdout == rb.stdout
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    json.dump({"samples": n, "hashes": int(sizes.sum()), "d": 1024, "threads": threads, "seconds": t},
+              open(os.path.join(out, "cli_vs_reference.json"), "w"))
