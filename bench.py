@@ -67,6 +67,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pairwise-extra", type=int, default=0,
                     help="also time a pairwise-only run on this many synthesised sketches (rank 0, N=1)")
+    ap.add_argument("--host-input", action="store_true",
+                    help="also time the step with the hash lists handed over as host buffers (PCIe inclusive; "
+                         "reported as pcie_inclusive, never as value)")
     args = ap.parse_args()
 
     import torch
@@ -243,6 +246,19 @@ def main():
                                  "kept_cells": cntx, "limbs": sset.limbs,
                                  "algorithmic_tflops": 2.0 * D * n * n / (kx * 1e-3) / 1e12}
         sset.close()
+
+    if args.host_input and world == 1:
+        h_host = hashes.cpu().numpy().view(np.uint64)                                      # pageable, as a caller's vector would be
+        o_host = np.asarray(offsets)
+        sk_host = np.empty((S, D), dtype=np.int32)
+        ts = []
+        for _ in range(3):
+            t1 = time.perf_counter()
+            ctx.project_csr(h_host, o_host, D, out=sk_host)               # H2D hashes, K1, D2H sketches
+            ts.append(time.perf_counter() - t1)
+        res["pcie_inclusive"] = {"workload": "projection with host in/out buffers (pageable)",
+                                 "seconds": min(ts), "samples_per_s": S / min(ts),
+                                 "h2d_gb": h_host.nbytes / 1e9, "d2h_gb": sk_host.nbytes / 1e9}
 
     if not args.no_cpu_baseline and world == 1:
         res["cpu_baseline"] = cpu_baseline(hashes, offsets, S, NH, D)
