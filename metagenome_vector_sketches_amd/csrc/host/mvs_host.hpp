@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <filesystem>
 #include <fstream>
@@ -17,6 +18,11 @@
 #include <string>
 #include <thread>
 #include <vector>
+
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include "../../../include/mvs_hip.h"
 #include "mvs_codec.hpp"
@@ -28,9 +34,30 @@ namespace fs = std::filesystem;
 // ---------------------------------------------------------------------------------------------------
 // hash text -> CSR
 // ---------------------------------------------------------------------------------------------------
+// Flat uint64 storage that is filled by the parser's workers (a std::vector would value-initialise
+// gigabytes on one thread first).
+struct HashBuffer {
+    uint64_t* p = nullptr;
+    size_t n = 0;
+    HashBuffer() = default;
+    HashBuffer(const HashBuffer&) = delete;
+    HashBuffer& operator=(const HashBuffer&) = delete;
+    ~HashBuffer() { free(p); }
+    bool reset(size_t count) {
+        free(p);
+        p = (uint64_t*)malloc(std::max<size_t>(8, count * sizeof(uint64_t)));
+        n = p ? count : 0;
+        return p != nullptr;
+    }
+    const uint64_t* data() const { return p; }
+    uint64_t* data() { return p; }
+    size_t size() const { return n; }
+    uint64_t operator[](size_t i) const { return p[i]; }
+};
+
 struct HashSets {
     std::vector<std::string> names;
-    std::vector<uint64_t> hashes;    // concatenated, unique within a sample (sorted)
+    HashBuffer hashes;               // concatenated, unique within a sample (sorted)
     std::vector<int64_t> offsets;    // names.size() + 1
 };
 
@@ -67,59 +94,92 @@ inline void parse_u64_tokens(const char* p, const char* end, std::vector<uint64_
 // src/project_everything.cpp:267-270); otherwise every line is a hash list
 // (src/standalone_projection.cpp:28-35).
 inline bool read_hash_file(const std::string& path, bool with_names, HashSets& out, unsigned threads = 0) {
-    std::ifstream in(path, std::ios::binary | std::ios::ate);
-    if (!in) return false;
-    const std::streamoff size = in.tellg();
-    std::string buf((size_t)size, '\0');
-    in.seekg(0);
-    if (size) in.read(&buf[0], size);
-    // line table
-    struct Line { size_t b, e; };
-    std::vector<Line> lines;
-    size_t pos = 0;
-    while (pos < buf.size()) {
-        const char* nl = (const char*)memchr(buf.data() + pos, '\n', buf.size() - pos);
-        const size_t e = nl ? (size_t)(nl - buf.data()) : buf.size();
-        lines.push_back({pos, e});
-        pos = e + 1;
+    // the file is mapped, not copied: hash lists run to gigabytes of text
+    const int fd = ::open(path.c_str(), O_RDONLY);
+    if (fd < 0) return false;
+    struct stat st;
+    if (::fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) {
+        ::close(fd);
+        return false;
     }
-    // std::getline yields a final empty line only if the file ends without '\n' after text; a trailing
-    // "\n" does not produce an extra record -- the loop above matches that.
-    std::vector<Line> recs;
-    std::vector<size_t> colon;
-    for (const Line& l : lines) {
-        if (with_names) {
-            const char* c = (const char*)memchr(buf.data() + l.b, ':', l.e - l.b);
-            if (!c) continue;
-            recs.push_back(l);
-            colon.push_back((size_t)(c - buf.data()));
-        } else {
-            recs.push_back(l);
-            colon.push_back(l.b - 1);
+    const size_t size = (size_t)st.st_size;
+    const char* buf = nullptr;
+    if (size) {
+        void* m = ::mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (m == MAP_FAILED) {
+            ::close(fd);
+            return false;
         }
+        ::madvise(m, size, MADV_SEQUENTIAL);
+        buf = (const char*)m;
     }
+    ::close(fd);
+    if (threads == 0) threads = std::max(1u, std::thread::hardware_concurrency());
+
+    // line table: each worker scans one slice of the file for '\n'.  std::getline yields a final record
+    // without '\n' if there is text after the last newline and no extra record for a trailing newline.
+    struct Rec { size_t b, e, colon; };
+    const unsigned tl = (unsigned)std::min<size_t>(threads, std::max<size_t>(1, size >> 22));
+    std::vector<std::vector<size_t>> nl(tl);
+    {
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < tl; ++t)
+            pool.emplace_back([&, t]() {
+                size_t pos = size * t / tl;
+                const size_t end = size * (t + 1) / tl;
+                while (pos < end) {
+                    const char* q = (const char*)memchr(buf + pos, '\n', end - pos);
+                    if (!q) break;
+                    nl[t].push_back((size_t)(q - buf));
+                    pos = (size_t)(q - buf) + 1;
+                }
+            });
+        for (auto& th : pool) th.join();
+    }
+    std::vector<Rec> recs;
+    size_t pos = 0;
+    auto add_line = [&](size_t b, size_t e) {
+        if (with_names) {
+            const char* c = (const char*)memchr(buf + b, ':', e - b);      // no ':' -> skipped (:267-270)
+            if (c) recs.push_back({b, e, (size_t)(c - buf)});
+        } else {
+            recs.push_back({b, e, b - 1});
+        }
+    };
+    for (unsigned t = 0; t < tl; ++t)
+        for (size_t e : nl[t]) {
+            add_line(pos, e);
+            pos = e + 1;
+        }
+    if (pos < size) add_line(pos, size);
+
     const size_t n = recs.size();
     std::vector<std::vector<uint64_t>> sets(n);
-    if (threads == 0) threads = std::max(1u, std::thread::hardware_concurrency());
     threads = (unsigned)std::min<size_t>(threads, std::max<size_t>(1, n));
-    std::vector<std::thread> pool;
-    for (unsigned t = 0; t < threads; ++t)
-        pool.emplace_back([&, t]() {
-            for (size_t i = t; i < n; i += threads)
-                parse_u64_tokens(buf.data() + colon[i] + 1, buf.data() + recs[i].e, sets[i]);
-        });
-    for (auto& th : pool) th.join();
-    out.names.clear();
-    out.offsets.assign(1, 0);
-    size_t total = 0;
-    for (auto& s : sets) total += s.size();
-    out.hashes.clear();
-    out.hashes.reserve(total);
-    for (size_t i = 0; i < n; ++i) {
-        out.names.push_back(with_names ? buf.substr(recs[i].b, colon[i] - recs[i].b) : std::string());
-        out.hashes.insert(out.hashes.end(), sets[i].begin(), sets[i].end());
-        out.offsets.push_back((int64_t)out.hashes.size());
+    auto run = [&](auto&& body) {
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < threads; ++t) pool.emplace_back([&, t]() { body(t); });
+        for (auto& th : pool) th.join();
+    };
+    run([&](unsigned t) {
+        for (size_t i = t; i < n; i += threads) parse_u64_tokens(buf + recs[i].colon + 1, buf + recs[i].e, sets[i]);
+    });
+    out.names.resize(n);
+    out.offsets.assign(n + 1, 0);
+    for (size_t i = 0; i < n; ++i) out.offsets[i + 1] = out.offsets[i] + (int64_t)sets[i].size();
+    if (!out.hashes.reset((size_t)out.offsets[n])) {
+        if (size) ::munmap((void*)buf, size);
+        return false;
     }
+    uint64_t* flat = out.hashes.data();
+    run([&](unsigned t) {
+        for (size_t i = t; i < n; i += threads) {
+            if (!sets[i].empty()) memcpy(flat + out.offsets[i], sets[i].data(), sets[i].size() * 8);
+            std::vector<uint64_t>().swap(sets[i]);
+            if (with_names) out.names[i].assign(buf + recs[i].b, recs[i].colon - recs[i].b);
+        }
+    });
+    if (size) ::munmap((void*)buf, size);
     return true;
 }
 
