@@ -11,6 +11,7 @@
 // build's own (the reference's `bits` library is not available); the int16 DB path writes the active
 // shard format instead of the legacy EF+zstd one.
 #include <chrono>
+#include <memory>
 
 #include "mvs_host.hpp"
 
@@ -89,58 +90,82 @@ static int gpu_fail(const char* what) {
     return 2;
 }
 
-// stream vectors.bin through the device in row chunks: pass 1 finds the limb count, pass 2 re-codes
+// vectors.bin goes through the device in row chunks straight from the page cache (the file is mapped, the
+// library copies from the mapping): pass 1 finds the limb count, pass 2 re-codes into the limb planes
 static int load_db(Gpu& g, const std::string& matrix_file, int elem_bytes, int64_t n, int d) {
     const int64_t row_bytes = (int64_t)d * elem_bytes;
     const int64_t chunk_rows = std::max<int64_t>(1, (1LL << 30) / row_bytes);
-    std::vector<char> buf((size_t)(std::min(chunk_rows, std::max<int64_t>(n, 1)) * row_bytes));
-    int64_t max_abs = 0;
-    for (int pass = 0; pass < 2; ++pass) {
-        std::ifstream file(matrix_file, std::ios::binary);
-        if (!file) {
-            std::cerr << "Error opening file: " << matrix_file << std::endl;   // :35-38
+    const int fd = ::open(matrix_file.c_str(), O_RDONLY);
+    if (fd < 0) {
+        std::cerr << "Error opening file: " << matrix_file << std::endl;       // :35-38
+        return 1;
+    }
+    const size_t bytes = (size_t)(n * row_bytes);
+    const char* base = nullptr;
+    if (bytes) {
+        void* m = ::mmap(nullptr, bytes, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (m == MAP_FAILED) {
+            ::close(fd);
+            std::cerr << "Error reading file: " << matrix_file << std::endl;
             return 1;
         }
+        ::madvise(m, bytes, MADV_SEQUENTIAL);
+        base = (const char*)m;
+    }
+    ::close(fd);
+    int rc = 0;
+    int64_t max_abs = 0;
+    for (int pass = 0; pass < 2 && !rc; ++pass) {
         if (pass == 1 && mvs_sketch_set_alloc(g.ctx, n, d, mvs_limbs_for_max_abs(max_abs), &g.set) != MVS_OK)
-            return gpu_fail("allocating sketch set");
-        for (int64_t r0 = 0; r0 < n; r0 += chunk_rows) {
+            rc = gpu_fail("allocating sketch set");
+        for (int64_t r0 = 0; r0 < n && !rc; r0 += chunk_rows) {
             const int64_t rows = std::min(chunk_rows, n - r0);
-            file.read(buf.data(), (std::streamsize)(rows * row_bytes));
-            if (!file) {
-                std::cerr << "Error reading file: " << matrix_file << std::endl;
-                return 1;
-            }
+            const char* src = base + r0 * row_bytes;
             if (pass == 0) {
                 int64_t m = 0;
-                if (mvs_sketch_max_abs(g.ctx, buf.data(), elem_bytes, MVS_MEM_HOST, rows * d, &m) != MVS_OK)
-                    return gpu_fail("scanning vectors.bin");
+                if (mvs_sketch_max_abs(g.ctx, src, elem_bytes, MVS_MEM_HOST, rows * d, &m) != MVS_OK)
+                    rc = gpu_fail("scanning vectors.bin");
                 max_abs = std::max(max_abs, m);
-            } else if (mvs_sketch_set_fill(g.set, buf.data(), elem_bytes, MVS_MEM_HOST, r0, rows) != MVS_OK) {
-                return gpu_fail("re-coding vectors.bin");
+            } else if (mvs_sketch_set_fill(g.set, src, elem_bytes, MVS_MEM_HOST, r0, rows) != MVS_OK) {
+                rc = gpu_fail("re-coding vectors.bin");
             }
         }
     }
-    return 0;
+    if (bytes) ::munmap((void*)base, bytes);
+    return rc;
 }
 
-// rows [b, e) against all columns; halves the range when the staging buffer is too small
-static int compare_rows(Gpu& g, const std::vector<double>& n2, int keep_mode, int64_t b, int64_t e,
-                        std::vector<mvs_cell>& staging, std::vector<mvs_cell>& all) {
+// Kept-cell staging: grows to what a call reports it needs, up to `limit` cells; never value-initialised
+// (the budget can be gigabytes).
+struct Staging {
+    std::unique_ptr<mvs_cell[]> p;
+    size_t cap = 0, limit = 0;
+    void reserve(size_t want) {
+        if (want <= cap) return;
+        p.reset();
+        p.reset(new mvs_cell[want]);
+        cap = want;
+    }
+};
+
+// rows [b, e) against all columns; grows the staging buffer, then halves the range, when it is too small
+static int compare_rows(Gpu& g, const std::vector<double>& n2, int keep_mode, int64_t b, int64_t e, Staging& st,
+                        std::vector<mvs_cell>& all) {
     if (b >= e) return 0;
     int64_t cnt = 0;
-    const int rc = mvs_pairwise_rows(g.ctx, g.set, n2.data(), MVS_MEM_HOST, keep_mode, b, e, staging.data(),
-                                     (int64_t)staging.size(), MVS_MEM_HOST, &cnt);
+    const int rc = mvs_pairwise_rows(g.ctx, g.set, n2.data(), MVS_MEM_HOST, keep_mode, b, e, st.p.get(),
+                                     (int64_t)st.cap, MVS_MEM_HOST, &cnt);
     if (rc == MVS_E_CAPACITY) {
-        if (e - b == 1) {
-            staging.resize((size_t)cnt);
-            return compare_rows(g, n2, keep_mode, b, e, staging, all);
+        if ((size_t)cnt <= st.limit || e - b == 1) {
+            st.reserve((size_t)cnt);                      // a single row is never split
+            return compare_rows(g, n2, keep_mode, b, e, st, all);
         }
         const int64_t mid = b + (e - b) / 2;
-        int r = compare_rows(g, n2, keep_mode, b, mid, staging, all);
-        return r ? r : compare_rows(g, n2, keep_mode, mid, e, staging, all);
+        int r = compare_rows(g, n2, keep_mode, b, mid, st, all);
+        return r ? r : compare_rows(g, n2, keep_mode, mid, e, st, all);
     }
     if (rc != MVS_OK) return gpu_fail("pairwise comparison");
-    all.insert(all.end(), staging.begin(), staging.begin() + cnt);
+    all.insert(all.end(), st.p.get(), st.p.get() + cnt);
     return 0;
 }
 
@@ -211,23 +236,38 @@ int main(int argc, char* argv[]) {
     mvs_shard_rows(total_vectors, o.num_shards, o.shard_idx, &begin_row, &end_row);                   // :938-940
     std::cout << "Shard " << o.shard_idx << " processing rows " << begin_row << " to " << end_row << std::endl;
 
+    // MVS_STAGE_TIMING=1: per-stage wall times on stderr (not part of the reference's output)
+    const bool stage_timing = getenv("MVS_STAGE_TIMING") != nullptr;
+    auto lap_t = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        const auto t = std::chrono::steady_clock::now();
+        if (stage_timing)
+            std::cerr << "[stage] " << what << " " << std::chrono::duration<double>(t - lap_t).count() << " s" << std::endl;
+        lap_t = t;
+    };
     Gpu g;
     int device = 0, ndev = 0;
     if (getenv("MVS_DEVICE")) device = pick_device();
     else if (mvs_device_count(&ndev) == MVS_OK && ndev > 0) device = o.shard_idx % ndev;
     if (mvs_ctx_create(device, &g.ctx) != MVS_OK) return gpu_fail("creating context");
+    lap("context");
     int rc = load_db(g, matrix_file, elem_bytes, total_vectors, dimension);
     if (rc) return rc;
+    lap("load vectors.bin");
 
-    // kept-cell staging: --max_memory_gb bounds it (16 bytes per cell), at least 1M cells
+    // kept-cell staging: --max_memory_gb bounds it (16 bytes per cell, a quarter of the budget, at least 1M
+    // cells); it starts at 64 cells per row of the shard and grows on demand
     double budget = o.max_memory_gb > 0 ? o.max_memory_gb : 1.0;
-    size_t cap = (size_t)std::min<double>(budget * 1024.0 * 1024.0 * 1024.0 / 16.0 / 4.0, 256e6);
-    cap = std::max<size_t>(cap, 1u << 20);
-    std::vector<mvs_cell> staging(cap), all_results;
+    Staging staging;
+    staging.limit = (size_t)std::min<double>(budget * 1024.0 * 1024.0 * 1024.0 / 16.0 / 4.0, 256e6);
+    staging.limit = std::max<size_t>(staging.limit, 1u << 20);
+    staging.reserve(std::min(staging.limit, std::max<size_t>(1u << 20, (size_t)(end_row - begin_row) * 64)));
+    std::vector<mvs_cell> all_results;
     db.norms_sq.resize((size_t)total_vectors);
     rc = compare_rows(g, db.norms_sq, int16 ? MVS_KEEP_INT16 : MVS_KEEP_INT32, begin_row, end_row, staging,
                       all_results);
     if (rc) return rc;
+    lap("compare");
     if (int16) {                                                                  // _16bits.cpp:419-423
         auto end_time = std::chrono::high_resolution_clock::now();
         auto duration = std::chrono::duration_cast<std::chrono::milliseconds>(end_time - start_time);
@@ -235,6 +275,7 @@ int main(int argc, char* argv[]) {
         std::cout << "Total results: " << all_results.size() << std::endl;
     }
     const ShardStats st = write_shard(shard_folder, all_results.data(), all_results.size());          // :990
+    lap("write shard");
     std::cout << "Jac space: " << st.jac_space << " ngh space: " << st.ngh_space << std::endl;        // :808
     if (!int16) {                                                                 // :993-996
         auto end_time = std::chrono::high_resolution_clock::now();
