@@ -80,6 +80,10 @@ int mvs_ctx_synchronize(mvs_ctx* ctx);
  * mvs_ctx_kernel_ms returns the duration of the most recent such launch in milliseconds. */
 int mvs_ctx_set_timing(mvs_ctx* ctx, int enabled);
 int mvs_ctx_kernel_ms(mvs_ctx* ctx, int which, float* ms);
+/* Diagnostics of the most recent comparison (mvs_pairwise_rows / _block / mvs_search_block): the number
+ * of candidate pairs its coarse filter passed on to the exact re-check, 0 if the exact kernel ran on
+ * every cell (see mvs_pairwise_rows). */
+int mvs_ctx_pairwise_candidates(mvs_ctx* ctx, int64_t* candidates);
 
 /* ---- projection ----------------------------------------------------------------------------------
  * Replaces transform_set_into_vector() (src/random_projection.cpp:9-26) called once per sample from
@@ -174,7 +178,13 @@ int mvs_sketch_set_destroy(mvs_sketch_set* set);
  *              (row, col) -- the per-row, ascending-column order the reference's writer relies on
  *              (:718-722).  If more than `capacity` cells are kept the call returns MVS_E_CAPACITY
  *              and *n_cells is the number needed (retry with a larger buffer or fewer rows).
- * Synchronous (returns after the count is known). */
+ * Synchronous (returns after the count is known).
+ * How the cells are found is the library's business and never changes the result: sets of two base-256
+ * limbs whose rows' sums of squares stay below 2^31 are compared in two stages -- a one-pass int8 filter on
+ * a coarse plane with a proven error bound drops the pairs that cannot pass the keep test, the exact int32
+ * dot and the reference's keep test run on the survivors -- everything else goes through the exact kernel
+ * cell by cell (environment MVS_PAIRWISE_FILTER=0 forces that, =2 forces the two stages on small blocks
+ * too; mvs_ctx_pairwise_candidates reports which one ran). */
 int mvs_pairwise_rows(mvs_ctx* ctx, const mvs_sketch_set* set, const double* norms_sq, int mem_norms,
                       int keep_mode, int64_t row_begin, int64_t row_end, mvs_cell* cells,
                       int64_t capacity, int mem_cells, int64_t* n_cells);

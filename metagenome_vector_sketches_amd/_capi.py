@@ -34,6 +34,7 @@ SYMBOLS = [
     ("mvs_ctx_synchronize", _c.c_int, [_P]),
     ("mvs_ctx_set_timing", _c.c_int, [_P, _c.c_int]),
     ("mvs_ctx_kernel_ms", _c.c_int, [_P, _c.c_int, _c.POINTER(_c.c_float)]),
+    ("mvs_ctx_pairwise_candidates", _c.c_int, [_P, _c.POINTER(_c.c_int64)]),
     ("mvs_project_csr", _c.c_int, [_P, _P, _c.c_int, _P, _c.c_int64, _c.c_int, _P, _c.c_int]),
     ("mvs_project_csr_stats", _c.c_int, [_P, _P, _c.c_int, _P, _c.c_int64, _c.c_int, _P, _c.c_int, _P,
                                           _c.POINTER(_c.c_int64)]),
@@ -197,6 +198,12 @@ class Context:
         ms = _c.c_float()
         _check(self.lib.mvs_ctx_kernel_ms(self._h, which, ctypes.byref(ms)))
         return ms.value
+
+    def pairwise_candidates(self):
+        """candidate pairs the last comparison's coarse filter passed to the exact re-check (0: exact kernel only)"""
+        v = _c.c_int64()
+        _check(self.lib.mvs_ctx_pairwise_candidates(self._h, ctypes.byref(v)))
+        return v.value
 
     # ---- projection ----
     def project_csr(self, hashes, offsets, d, out=None):

@@ -1,6 +1,7 @@
 // mvs_capi.hip -- the C ABI of libmvs_hip.so (include/mvs_hip.h): contexts, buffer staging and
 // kernel orchestration.  No compute happens on the host here and there is no CPU fallback.
 #include <algorithm>
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -26,6 +27,18 @@ struct mvs_ctx {
     void* pw_thr = nullptr;   size_t pw_thr_bytes = 0;
     void* pw_tmp = nullptr;   size_t pw_tmp_bytes = 0;
     void* pw_sort = nullptr;  size_t pw_sort_bytes = 0;
+    // two-stage comparison: coarse plane + row statistics of the set `coarse_id` (generation `coarse_gen`),
+    // per-call filter constants, candidate list
+    void* pw_coarse = nullptr;  size_t pw_coarse_bytes = 0;
+    void* pw_rows = nullptr;    size_t pw_rows_bytes = 0;
+    void* pw_fmeta = nullptr;   size_t pw_fmeta_bytes = 0;
+    void* pw_cand = nullptr;    size_t pw_cand_bytes = 0;
+    unsigned long long coarse_id = 0, coarse_gen = 0;
+    bool coarse_usable = false;          // no row's sum of squares reaches 2^31: exact dots cannot wrap
+    unsigned long long filter_off_id = 0;   // (set, coefficient) for which the filter passed too many pairs
+    double filter_off_coeff = 0.0;
+    unsigned long long last_candidates = 0; // candidate pairs of the last two-stage comparison (0: exact kernel)
+    unsigned long long h_start = 0;      // host copy of the starting cell count of an appending call
     // pinned host staging for small metadata uploads (projection unit lists)
     void* pinned = nullptr;
     size_t pinned_bytes = 0;
@@ -39,11 +52,13 @@ struct mvs_sketch_set {
     int8_t* owned = nullptr;
     int64_t n = 0, n_alloc = 0;
     int d = 0, d_pad = 0, limbs = 0;
+    unsigned long long id = 0, gen = 0;   // identity of the plane contents (cache key of derived data)
 };
 
 namespace {
 
 thread_local std::string g_err;
+std::atomic<unsigned long long> g_set_ids{0};
 
 int fail(int code, const char* fmt, ...) {
     char buf[512];
@@ -191,6 +206,10 @@ int mvs_ctx_destroy(mvs_ctx* c) {
     if (c->pw_thr) (void)hipFree(c->pw_thr);
     if (c->pw_tmp) (void)hipFree(c->pw_tmp);
     if (c->pw_sort) (void)hipFree(c->pw_sort);
+    if (c->pw_coarse) (void)hipFree(c->pw_coarse);
+    if (c->pw_rows) (void)hipFree(c->pw_rows);
+    if (c->pw_fmeta) (void)hipFree(c->pw_fmeta);
+    if (c->pw_cand) (void)hipFree(c->pw_cand);
     if (c->pinned) (void)hipHostFree(c->pinned);
     if (c->pinned_ev) (void)hipEventDestroy(c->pinned_ev);
     for (auto& ev : c->ev)
@@ -223,6 +242,12 @@ int mvs_ctx_set_timing(mvs_ctx* c, int enabled) {
     if (!c) return fail(MVS_E_INVALID, "ctx is NULL");
     c->timing = enabled != 0;
     c->ev_valid[0] = c->ev_valid[1] = false;
+    return MVS_OK;
+}
+
+int mvs_ctx_pairwise_candidates(mvs_ctx* c, int64_t* candidates) {
+    if (!c || !candidates) return fail(MVS_E_INVALID, "NULL argument");
+    *candidates = (int64_t)c->last_candidates;
     return MVS_OK;
 }
 
@@ -558,6 +583,7 @@ int mvs_sketch_set_create(mvs_ctx* c, const void* sketches, int elem_bytes, int 
     s->d = d;
     s->d_pad = d_pad;
     s->limbs = limbs;
+    s->id = ++g_set_ids;
     hipError_t e = hipMemsetAsync(s->owned, 0, bytes, c->stream);
     if (e == hipSuccess) {
         rc = mvs_limb_split(c, d_in, elem_bytes, MVS_MEM_DEVICE, n, d, limbs, s->owned, d_pad, 0);
@@ -593,6 +619,7 @@ int mvs_sketch_set_from_planes(mvs_ctx* c, const int8_t* planes, int64_t n, int6
     s->d = d;
     s->d_pad = d_pad;
     s->limbs = limbs;
+    s->id = ++g_set_ids;
     *out = s;
     return MVS_OK;
 }
@@ -620,6 +647,7 @@ int mvs_sketch_set_alloc(mvs_ctx* c, int64_t n, int d, int limbs, mvs_sketch_set
     s->d = d;
     s->d_pad = d_pad;
     s->limbs = limbs;
+    s->id = ++g_set_ids;
     if (hipMemsetAsync(s->owned, 0, bytes, c->stream) != hipSuccess) {
         mvs_sketch_set_destroy(s);
         return fail(MVS_E_HIP, "hipMemsetAsync failed");
@@ -634,6 +662,7 @@ int mvs_sketch_set_fill(mvs_sketch_set* s, const void* sketches, int elem_bytes,
     if (row_offset < 0 || n_rows < 0 || row_offset + n_rows > s->n)
         return fail(MVS_E_INVALID, "rows [%lld,%lld) outside the set", (long long)row_offset,
                     (long long)(row_offset + n_rows));
+    ++s->gen;   // derived data (coarse plane) of the old contents is stale
     return mvs_limb_split(s->ctx, sketches, elem_bytes, mem, n_rows, s->d, s->limbs, s->owned, s->d_pad, row_offset);
 }
 
@@ -660,15 +689,42 @@ int mvs_sketch_set_destroy(mvs_sketch_set* s) {
 
 namespace {
 
-// thresholds + one comparison launch appending to `raw` (device) from the count already in c->d_counter
+// MVS_PAIRWISE_FILTER: 0 = always the exact kernel, 1 (default) = two-stage comparison for blocks of at
+// least 2^22 cells, 2 = two-stage comparison whenever the set allows it
+int filter_mode() {
+    const char* e = getenv("MVS_PAIRWISE_FILTER");   // read per call: tests switch it inside one process
+    const int v = e ? atoi(e) : 1;
+    return (v < 0 || v > 2) ? 1 : v;
+}
+
+// coarse plane + row statistics of `s`, cached in the context until the set (or its contents) changes
+int prepare_coarse(mvs_ctx* c, const mvs_sketch_set* s) {
+    if (c->coarse_id == s->id && c->coarse_gen == s->gen) return MVS_OK;
+    c->coarse_id = 0;
+    int rc = ensure_buf(c, &c->pw_coarse, &c->pw_coarse_bytes, (size_t)s->n_alloc * (size_t)s->d_pad);
+    if (rc) return rc;
+    rc = ensure_buf(c, &c->pw_rows, &c->pw_rows_bytes, (size_t)s->n_alloc * sizeof(mvs::CoarseRow));
+    if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(c->d_counter + 3, 0, 8, c->stream));
+    mvs::launch_coarse_build(c->stream, s->planes, s->n, s->n_alloc, s->d_pad, (int8_t*)c->pw_coarse,
+                             (mvs::CoarseRow*)c->pw_rows, c->d_counter + 3);
+    rc = check_kernel("k_coarse_build");
+    if (rc) return rc;
+    unsigned long long max_ss = 0;
+    HIP_TRY(hipMemcpyAsync(&max_ss, c->d_counter + 3, 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->coarse_usable = max_ss < (1ULL << 31);   // |<v_i,v_j>| <= |v_i| |v_j| < 2^31: the int32 dot is the true dot
+    c->coarse_id = s->id;
+    c->coarse_gen = s->gen;
+    return MVS_OK;
+}
+
+// One comparison of rows [rb,re) x columns [cb,ce) appending to `raw` (device) after the first `start`
+// cells; the running count is left in c->d_counter[0].  Two-stage (filter + exact re-check of the
+// candidates) when the set allows it, otherwise the exact MFMA / vector-ALU kernel on every cell.
 int pairwise_launch(mvs_ctx* c, const mvs_sketch_set* s, const double* d_n2, int keep_mode, int64_t rb, int64_t re,
                     int64_t cb, int64_t ce, bool symmetric, bool mirror_all, mvs_cell* raw, int64_t capacity,
-                    double keep_coeff = 0.05) {
-    int rc = ensure_buf(c, &c->pw_thr, &c->pw_thr_bytes, (size_t)s->n_alloc * 4);
-    if (rc) return rc;
-    mvs::launch_cand_thr(c->stream, d_n2, s->n, s->n_alloc, s->d, keep_coeff, (int32_t*)c->pw_thr);
-    rc = check_kernel("k_cand_thr");
-    if (rc) return rc;
+                    unsigned long long start, double keep_coeff = 0.05) {
     mvs::PairwiseArgs a{};
     a.planes = s->planes;
     a.n = s->n;
@@ -681,7 +737,6 @@ int pairwise_launch(mvs_ctx* c, const mvs_sketch_set* s, const double* d_n2, int
     a.col_begin = cb;
     a.col_end = ce;
     a.norms_sq = d_n2;
-    a.cand_thr = (const int32_t*)c->pw_thr;
     a.keep_mode = keep_mode;
     a.keep_coeff = keep_coeff;
     a.cells = raw;
@@ -695,6 +750,79 @@ int pairwise_launch(mvs_ctx* c, const mvs_sketch_set* s, const double* d_n2, int
         const char* sym = getenv("MVS_PAIRWISE_SYMMETRIC");   // default on; 0 computes every tile
         a.symmetric = (symmetric && !(sym && atoi(sym) == 0)) ? 1 : 0;   // the launcher checks the alignment
     }
+    auto set_count = [&]() -> int {
+        c->h_start = start;   // outlives the asynchronous copy
+        if (start == 0) HIP_TRY(hipMemsetAsync(c->d_counter, 0, 8, c->stream));
+        else HIP_TRY(hipMemcpyAsync(c->d_counter, &c->h_start, 8, hipMemcpyHostToDevice, c->stream));
+        return MVS_OK;
+    };
+    int rc = MVS_OK;
+    const double block_cells = (double)(re - rb) * (double)(ce - cb);
+    bool two_stage = filter_mode() != 0 && s->limbs == 2 && s->d_pad <= 32768 && a.debug_flags == 0 &&
+                     (filter_mode() == 2 || block_cells >= 4194304.0) &&
+                     !(c->filter_off_id == s->id && c->filter_off_coeff == keep_coeff);
+    if (two_stage) {
+        rc = prepare_coarse(c, s);
+        if (rc) return rc;
+        two_stage = c->coarse_usable;
+    }
+    if (two_stage) {
+        rc = ensure_buf(c, &c->pw_fmeta, &c->pw_fmeta_bytes, (size_t)s->n_alloc * sizeof(float4));
+        if (rc) return rc;
+        mvs::launch_filter_meta(c->stream, (const mvs::CoarseRow*)c->pw_rows, d_n2, s->n, s->n_alloc, s->d, keep_coeff,
+                                (float4*)c->pw_fmeta);
+        rc = check_kernel("k_filter_meta");
+        if (rc) return rc;
+        rc = ensure_buf(c, &c->pw_cand, &c->pw_cand_bytes, (size_t)std::max<int64_t>(1 << 20, capacity) * sizeof(int2));
+        if (rc) return rc;
+        a.coarse = (const int8_t*)c->pw_coarse;
+        a.fmeta = (const float4*)c->pw_fmeta;
+        a.cand_counter = c->d_counter + 2;
+        // re-checking a candidate costs about as much as 500 cells of the exact kernel: beyond this many
+        // the filter is not paying (a search with a very low Jaccard bound, say) and the exact kernel runs
+        const double cand_limit = std::max(4194304.0, block_cells / 128.0);
+        for (int attempt = 0; attempt < 3; ++attempt) {
+            a.cand = (int2*)c->pw_cand;
+            a.cand_capacity = c->pw_cand_bytes / sizeof(int2);
+            rc = set_count();
+            if (rc) return rc;
+            HIP_TRY(hipMemsetAsync(c->d_counter + 2, 0, 8, c->stream));
+            if (c->timing) HIP_TRY(hipEventRecord(c->ev[2], c->stream));
+            rc = mvs::launch_filter(c->stream, a);
+            if (rc) return fail(rc, "filter launch rejected");
+            rc = check_kernel("k_pairwise_mfma(filter)");
+            if (rc) return rc;
+            rc = mvs::launch_exact_pairs(c->stream, a);
+            if (rc) return fail(rc, "exact re-check launch rejected");
+            rc = check_kernel("k_exact_pairs");
+            if (rc) return rc;
+            if (c->timing) {
+                HIP_TRY(hipEventRecord(c->ev[3], c->stream));
+                c->ev_valid[1] = true;
+            }
+            unsigned long long n_cand = 0;
+            HIP_TRY(hipMemcpyAsync(&n_cand, c->d_counter + 2, 8, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            c->last_candidates = n_cand;
+            if (n_cand <= a.cand_capacity) return MVS_OK;
+            if ((double)n_cand > cand_limit) {
+                c->filter_off_id = s->id;
+                c->filter_off_coeff = keep_coeff;
+                break;
+            }
+            rc = ensure_buf(c, &c->pw_cand, &c->pw_cand_bytes, (size_t)n_cand * sizeof(int2));
+            if (rc) return rc;
+        }
+    }
+    c->last_candidates = 0;
+    rc = ensure_buf(c, &c->pw_thr, &c->pw_thr_bytes, (size_t)s->n_alloc * 4);
+    if (rc) return rc;
+    mvs::launch_cand_thr(c->stream, d_n2, s->n, s->n_alloc, s->d, keep_coeff, (int32_t*)c->pw_thr);
+    rc = check_kernel("k_cand_thr");
+    if (rc) return rc;
+    a.cand_thr = (const int32_t*)c->pw_thr;
+    rc = set_count();
+    if (rc) return rc;
     if (c->timing) HIP_TRY(hipEventRecord(c->ev[2], c->stream));
     rc = mvs::launch_pairwise(c->stream, a, 0, 0);
     if (rc) return fail(rc, "pairwise launch rejected");
@@ -751,8 +879,7 @@ int mvs_pairwise_rows(mvs_ctx* c, const mvs_sketch_set* s, const double* norms_s
     // kept cells are appended (unordered) to a staging buffer and merge-sorted into the caller's
     int rc = ensure_buf(c, &c->pw_tmp, &c->pw_tmp_bytes, (size_t)std::max<int64_t>(capacity, 1) * sizeof(mvs_cell));
     if (rc) return rc;
-    HIP_TRY(hipMemsetAsync(c->d_counter, 0, 8, c->stream));
-    rc = pairwise_launch(c, s, d_n2, keep_mode, row_begin, row_end, 0, s->n, true, false, (mvs_cell*)c->pw_tmp, capacity);
+    rc = pairwise_launch(c, s, d_n2, keep_mode, row_begin, row_end, 0, s->n, true, false, (mvs_cell*)c->pw_tmp, capacity, 0);
     if (rc) return rc;
     unsigned long long count = 0;
     HIP_TRY(hipMemcpyAsync(&count, c->d_counter, 8, hipMemcpyDeviceToHost, c->stream));
@@ -788,14 +915,13 @@ int mvs_pairwise_block(mvs_ctx* c, const mvs_sketch_set* s, const double* norms_
     if (row_begin == row_end || col_begin == col_end) return MVS_OK;
     if (!norms_sq || (capacity > 0 && !cells)) return fail(MVS_E_INVALID, "NULL buffer");
     HIP_TRY(hipSetDevice(c->device));
-    const unsigned long long start = (unsigned long long)*n_cells;
-    HIP_TRY(hipMemcpyAsync(c->d_counter, &start, 8, hipMemcpyHostToDevice, c->stream));
     int rc = pairwise_launch(c, s, norms_sq, keep_mode, row_begin, row_end, col_begin, col_end,
-                             (flags & MVS_BLOCK_SYMMETRIC) != 0, (flags & MVS_BLOCK_MIRROR_ALL) != 0, cells, capacity);
+                             (flags & MVS_BLOCK_SYMMETRIC) != 0, (flags & MVS_BLOCK_MIRROR_ALL) != 0, cells, capacity,
+                             (unsigned long long)*n_cells);
     if (rc) return rc;
     unsigned long long count = 0;
     HIP_TRY(hipMemcpyAsync(&count, c->d_counter, 8, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));   // also covers the lifetime of `start`
+    HIP_TRY(hipStreamSynchronize(c->stream));
     *n_cells = (int64_t)count;
     if ((int64_t)count > capacity)
         return fail(MVS_E_CAPACITY, "%llu cells appended but capacity is %lld", count, (long long)capacity);
@@ -815,10 +941,9 @@ int mvs_search_block(mvs_ctx* c, const mvs_sketch_set* s, const double* norms_sq
     HIP_TRY(hipSetDevice(c->device));
     int rc = ensure_buf(c, &c->pw_tmp, &c->pw_tmp_bytes, (size_t)std::max<int64_t>(capacity, 1) * sizeof(mvs_cell));
     if (rc) return rc;
-    HIP_TRY(hipMemsetAsync(c->d_counter, 0, 8, c->stream));
     // J > j  <=>  (P/d) / (n2r + n2c - P/d) > j  <=>  double(P)/d > j/(1+j) * (n2r + n2c)   (for n2r + n2c > P/d >= 0)
     rc = pairwise_launch(c, s, norms_sq, MVS_KEEP_INT16, row_begin, row_end, col_begin, col_end, false, false,
-                         (mvs_cell*)c->pw_tmp, capacity, jaccard_min / (1.0 + jaccard_min));
+                         (mvs_cell*)c->pw_tmp, capacity, 0, jaccard_min / (1.0 + jaccard_min));
     if (rc) return rc;
     unsigned long long count = 0;
     HIP_TRY(hipMemcpyAsync(&count, c->d_counter, 8, hipMemcpyDeviceToHost, c->stream));

@@ -54,6 +54,20 @@ struct PairwiseArgs {
     int symmetric;                // 1: tiles strictly below the diagonal of the row range are skipped and
                                   //    produced by mirroring the kept cells of their transposes
     int debug_flags;              // profiling ablations (MVS_PAIRWISE_DEBUG): 1 skip k-loop, 2 skip epilogue
+    // two-stage comparison (coarse filter + exact re-check, see "filter" in mvs_pairwise.hip)
+    const int8_t* coarse;         // [row * d_pad + k], c = round(v / radix[row]), |c| <= 127
+    const float4* fmeta;          // n_alloc: per-row filter constants {s, w, a, p}
+    int2* cand;                   // candidate list: {row, col | mirror << 31}
+    unsigned long long cand_capacity;
+    unsigned long long* cand_counter;
+};
+
+// per-row statistics of the coarse plane: radix m, sum c^2, sum r^2 (r = v - m*c)
+struct CoarseRow {
+    int32_t radix;
+    int32_t c2;
+    int32_t r2;
+    int32_t pad;
 };
 
 // d_sumsq / d_max_abs non-NULL: fused statistics (all samples must be single units; d_sumsq zeroed by the caller)
@@ -72,6 +86,15 @@ int launch_cand_thr(hipStream_t stream, const double* d_norms_sq, int64_t n, int
                     double coeff, int32_t* d_thr);
 // mode 0: comparison (kept cells), mode 1: dense dots.  algo 0: MFMA, 1: vector ALU.
 int launch_pairwise(hipStream_t stream, const PairwiseArgs& a, int mode, int algo);
+// two-stage comparison for two base-256 limbs: coarse plane + row statistics from the limb planes
+// (d_max_ss receives the largest sum of squares of a row), per-call filter constants, the one-pass filter
+// that appends candidate pairs, and the exact re-check of the candidates that appends kept cells
+int launch_coarse_build(hipStream_t stream, const int8_t* d_planes, int64_t n, int64_t n_alloc, int d_pad,
+                        int8_t* d_coarse, CoarseRow* d_rows, unsigned long long* d_max_ss);
+int launch_filter_meta(hipStream_t stream, const CoarseRow* d_rows, const double* d_norms_sq, int64_t n,
+                       int64_t n_alloc, int d, double coeff, float4* d_meta);
+int launch_filter(hipStream_t stream, const PairwiseArgs& a);
+int launch_exact_pairs(hipStream_t stream, const PairwiseArgs& a);
 // sort cells by (row, col); tmp buffers owned by the caller
 int sort_cells(hipStream_t stream, mvs_cell* d_cells, mvs_cell* d_tmp, int64_t n, void* d_scratch,
                size_t scratch_bytes, size_t* scratch_needed);

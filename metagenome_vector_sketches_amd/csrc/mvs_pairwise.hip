@@ -107,8 +107,24 @@ __device__ __forceinline__ void emit_cell(const PairwiseArgs& a, bool keep, bool
     }
 }
 
+// Append the candidate pairs of one wave to the candidate list (one atomic per wave).
+__device__ __forceinline__ void emit_cand(const PairwiseArgs& a, bool cand, bool mirror, int32_t row, int32_t col,
+                                          int lane) {
+    const unsigned long long mask = __ballot(cand);
+    if (mask == 0ULL) return;
+    unsigned long long base = 0;
+    const int leader = __ffsll((long long)mask) - 1;
+    if (lane == leader) base = atomicAdd(a.cand_counter, (unsigned long long)__popcll(mask));
+    base = __shfl(base, leader, 64);
+    if (cand) {
+        const unsigned long long slot = base + (unsigned long long)__popcll(mask & ((1ULL << lane) - 1ULL));
+        if (slot < a.cand_capacity) a.cand[slot] = make_int2(row, mirror ? (int)((unsigned)col | 0x80000000u) : col);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
-// MFMA kernel.  L = limbs (1 or 2).  MODE 0: comparison, 1: dense dots.  NST = LDS ring depth.
+// MFMA kernel.  L = limbs (1 or 2).  MODE 0: comparison, 1: dense dots, 2: filter on the coarse plane.
+// NST = LDS ring depth.
 // LDS: NST stages x [A region | B region], region = [L][128 samples][64 B] (one 64-byte k-slice).
 // The ring keeps NST-1 slices in flight: the kernel is bound by the latency of the HBM/L2 -> LDS
 // copies (about 1-2 us under load), so what matters is the number of bytes in flight per CU.
@@ -170,7 +186,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void k_pairwise_mfma(const Pairwis
     // [row_begin,row_end)^2 a tile strictly below the diagonal is skipped; its cells come from the tile
     // strictly above the diagonal that holds their transposes (DESIGN.md K2 has the covering argument).
     bool mirror_tile = false;
-    if (MODE == 0 && a.symmetric) {
+    if (MODE != 1 && a.symmetric) {
         if (j0 >= a.row_begin && j0 + TN <= i0) return;
         mirror_tile = j0 >= i0 + TM && j0 < a.row_end;
     }
@@ -188,7 +204,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void k_pairwise_mfma(const Pairwis
         const int s = is_b ? rr % TN : rr % TM;
         const int c = (lane & 3) ^ ((s >> 2) & 3);
         const int64_t sample = (is_b ? j0 : i0) + s;
-        src[p] = a.planes + (sample * L + limb) * (int64_t)a.d_pad + c * 16;
+        src[p] = (MODE == 2 ? a.coarse : a.planes) + (sample * L + limb) * (int64_t)a.d_pad + c * 16;
     }
     auto stage_copy = [&](int slot, int k0) {
 #pragma unroll
@@ -321,6 +337,39 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void k_pairwise_mfma(const Pairwis
 #pragma unroll
                 for (int sset = 0; sset < NS; ++sset) x ^= acc[t][u][sset][0] ^ acc[t][u][sset][15];
         if (x == 0x7fffffff) a.counter[1] = 1;
+        return;
+    }
+    if constexpr (MODE == 2) {
+        // filter: a pair can only be kept if  <c_i,c_j>  >  s_i w_j + s_j w_i - a_i p_j - p_i (a_j + p_j)
+        // (derivation at k_filter_meta); everything else is dropped without ever forming the exact dot
+        static_assert(L == 1 && !KARA, "the filter runs on the single coarse plane");
+        float4* fm = reinterpret_cast<float4*>(smem);   // [0,TM): rows, [TM,TM+TN): cols
+        for (int x = tid; x < TM + TN; x += kWavesT * 64) fm[x] = a.fmeta[(x < TM ? i0 : j0 - TM) + x];
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < BT; ++u) {
+            const int col_l = (wn * BT + u) * 32 + fr;
+            const int64_t col = j0 + col_l;
+            const float4 mj = fm[TM + col_l];
+            const float bj = mj.z + mj.w;
+            const bool col_ok = col < a.col_end;
+            const bool mirror = a.mirror_all || (mirror_tile && col < a.row_end);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row_l = wm * 64 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                    const int64_t row = i0 + row_l;
+                    const float4 mi = fm[row_l];
+                    float rhs = mi.x * mj.y;
+                    rhs = fmaf(mj.x, mi.y, rhs);
+                    rhs = fmaf(-mi.z, mj.w, rhs);
+                    rhs = fmaf(-mi.w, bj, rhs);
+                    const bool cand = (float)acc[t][u][0][r] > rhs && col_ok && row < a.row_end;
+                    emit_cand(a, cand, mirror, (int32_t)row, (int32_t)col, lane);
+                }
+            }
+        }
         return;
     }
     int32_t* thr = reinterpret_cast<int32_t*>(smem);   // [0,TM): rows, [TM,TM+TN): cols
@@ -639,6 +688,152 @@ __global__ __launch_bounds__(256) void k_cand_thr(const double* __restrict__ n2,
     thr[i] = t;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Two-stage comparison ("filter"), for sets of two base-256 limbs whose dots cannot wrap.
+//
+// Every row also gets ONE int8 plane c = round(v / m) with its own radix m = ceil(max|v| / 127), and
+// r = v - m c is only known through its norm.  With A = m_i m_j <c_i,c_j>, Cauchy-Schwarz gives
+//     | <v_i,v_j> - A |  <=  m_i |c_i| |r_j| + |r_i| m_j |c_j| + |r_i| |r_j|  =: B .
+// Both keep tests imply  P > d * coeff * (n2_i + n2_j) =: tau_i + tau_j  (P = <v_i,v_j> exactly: the rows'
+// sums of squares are below 2^31, so nothing wraps), hence a kept pair satisfies  A + B > tau_i + tau_j,
+// i.e. after dividing by m_i m_j, with a = |c|, p = |r| / m, s = tau / m, w = 1 / m:
+//     <c_i,c_j>  >  s_i w_j + s_j w_i - a_i p_j - p_i (a_j + p_j) .
+// The one-pass MFMA filter evaluates exactly that per cell in fp32; s is deflated and a, p are inflated by
+// 2^-12, which dominates every rounding error of the evaluation (4 fused operations, 2^-22 relative to
+// the sum of magnitudes) and of the int -> float conversion of the dot, so no kept pair is ever dropped.
+// Pairs that pass go to a candidate list; k_exact_pairs recomputes their dots exactly from the limb
+// planes and applies the reference's keep test and quantisation.  On typical sketches (d = 2048) B is
+// about a fifth of the threshold and ~1e-4 of the unrelated pairs pass.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_coarse_build(const int8_t* __restrict__ planes, int64_t n, int64_t n_alloc,
+                                                      int d_pad, int8_t* __restrict__ coarse,
+                                                      CoarseRow* __restrict__ rows,
+                                                      unsigned long long* __restrict__ max_ss) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n_alloc) return;
+    const int words = d_pad / 4;
+    uint32_t* out = reinterpret_cast<uint32_t*>(coarse + row * (int64_t)d_pad);
+    if (row >= n) {   // padding rows
+        for (int k = lane; k < words; k += 64) out[k] = 0;
+        if (lane == 0) rows[row] = CoarseRow{1, 0, 0, 0};
+        return;
+    }
+    const uint32_t* lo = reinterpret_cast<const uint32_t*>(planes + row * 2 * (int64_t)d_pad);
+    const uint32_t* hi = lo + words;
+    int mx = 0;
+    unsigned long long ss = 0;
+    for (int k = lane; k < words; k += 64) {
+        const uint32_t l = lo[k], h = hi[k];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int v = (int)(int8_t)(l >> (8 * e)) + 256 * (int)(int8_t)(h >> (8 * e));
+            const int av = v < 0 ? -v : v;
+            mx = av > mx ? av : mx;
+            ss += (unsigned long long)((long long)v * v);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const int other = __shfl_xor(mx, o, 64);
+        mx = other > mx ? other : mx;
+        ss += __shfl_xor(ss, o, 64);
+    }
+    const int m = mx <= 127 ? 1 : (mx + 126) / 127;
+    const float inv = 1.0f / (float)m;
+    unsigned c2 = 0, r2 = 0;   // <= 129^2 * 32768 per row: fits
+    for (int k = lane; k < words; k += 64) {
+        const uint32_t l = lo[k], h = hi[k];
+        uint32_t packed = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int v = (int)(int8_t)(l >> (8 * e)) + 256 * (int)(int8_t)(h >> (8 * e));
+            int c = (int)rintf((float)v * inv);
+            c = c > 127 ? 127 : (c < -127 ? -127 : c);
+            const int r = v - m * c;   // exact, whatever the rounding above did
+            c2 += (unsigned)(c * c);
+            r2 += (unsigned)(r * r);
+            packed |= (uint32_t)(uint8_t)(int8_t)c << (8 * e);
+        }
+        out[k] = packed;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        c2 += __shfl_xor(c2, o, 64);
+        r2 += __shfl_xor(r2, o, 64);
+    }
+    if (lane == 0) {
+        rows[row] = CoarseRow{m, (int32_t)c2, (int32_t)r2, 0};
+        atomicMax(max_ss, ss);
+    }
+}
+
+// per-call filter constants {s, w, a, p} (see above); padding rows never pass (s = +inf)
+__global__ __launch_bounds__(256) void k_filter_meta(const CoarseRow* __restrict__ rows, const double* __restrict__ n2,
+                                                     int64_t n, int64_t n_alloc, int d, double coeff,
+                                                     float4* __restrict__ meta) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_alloc) return;
+    float4 o = make_float4(__builtin_inff(), 0.0f, 0.0f, 0.0f);
+    if (i < n) {
+        const CoarseRow st = rows[i];
+        const double m = (double)st.radix;
+        const double eps = 1.0 / 4096.0;
+        const double tau = coeff * (double)d * n2[i] / m;          // NaN stays NaN: such a row is never kept
+        o.x = (float)(tau - fabs(tau) * eps);
+        o.y = (float)(1.0 / m);
+        o.z = (float)(sqrt((double)st.c2) * (1.0 + eps));
+        o.w = (float)(sqrt((double)st.r2) / m * (1.0 + eps));
+    }
+    meta[i] = o;
+}
+
+// Exact re-check of the candidate pairs: one wave per pair and 64 pairs per round, so that the keep test,
+// the quantisation and the append run once per round on all lanes.
+__global__ __launch_bounds__(256) void k_exact_pairs(const PairwiseArgs a) {
+    const int lane = threadIdx.x & 63;
+    unsigned long long n_cand = *a.cand_counter;
+    if (n_cand > a.cand_capacity) n_cand = a.cand_capacity;
+    const unsigned long long waves = (unsigned long long)gridDim.x * 4;
+    const unsigned long long wid = (unsigned long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t stride = 2 * (int64_t)a.d_pad;
+    for (unsigned long long base = wid * 64; base < n_cand; base += waves * 64) {
+        const unsigned long long mine = base + lane;
+        int2 pr = make_int2(0, 0);
+        if (mine < n_cand) pr = a.cand[mine];
+        const int cnt = (int)(n_cand - base < 64 ? n_cand - base : 64);
+        int32_t P_mine = 0;
+        for (int q = 0; q < cnt; ++q) {
+            const int row = __shfl(pr.x, q, 64);
+            const int col = __shfl(pr.y, q, 64) & 0x7fffffff;
+            const int8_t* ri = a.planes + (int64_t)row * stride;
+            const int8_t* rj = a.planes + (int64_t)col * stride;
+            int acc0 = 0, acc1 = 0, acc2 = 0;
+            for (int k = lane * 16; k < a.d_pad; k += 1024) {
+                const v4i li = *reinterpret_cast<const v4i*>(ri + k);
+                const v4i hi = *reinterpret_cast<const v4i*>(ri + a.d_pad + k);
+                const v4i lj = *reinterpret_cast<const v4i*>(rj + k);
+                const v4i hj = *reinterpret_cast<const v4i*>(rj + a.d_pad + k);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc0 = __builtin_amdgcn_sdot4(li[e], lj[e], acc0, false);
+                    acc1 = __builtin_amdgcn_sdot4(li[e], hj[e], acc1, false);
+                    acc1 = __builtin_amdgcn_sdot4(hi[e], lj[e], acc1, false);
+                    acc2 = __builtin_amdgcn_sdot4(hi[e], hj[e], acc2, false);
+                }
+            }
+            uint32_t P = (uint32_t)acc0 + ((uint32_t)acc1 << 8) + ((uint32_t)acc2 << 16);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) P += __shfl_xor(P, o, 64);
+            if (lane == q) P_mine = (int32_t)P;
+        }
+        bool keep = false;
+        const int32_t row = pr.x, col = pr.y & 0x7fffffff;
+        if (mine < n_cand) keep = keep_cell(P_mine, a.d, a.norms_sq[row], a.norms_sq[col], a.keep_mode, a.keep_coeff);
+        emit_cell(a, keep, pr.y < 0, row, col, P_mine, lane);
+    }
+}
+
 struct CellLess {
     __host__ __device__ bool operator()(const mvs_cell& x, const mvs_cell& y) const {
         return x.row < y.row || (x.row == y.row && x.col < y.col);
@@ -761,6 +956,33 @@ int launch_cand_thr(hipStream_t stream, const double* d_norms_sq, int64_t n, int
                     double coeff, int32_t* d_thr) {
     hipLaunchKernelGGL(k_cand_thr, dim3((unsigned)((n_alloc + 255) / 256)), dim3(256), 0, stream, d_norms_sq, n,
                        n_alloc, d, coeff, d_thr);
+    return 0;
+}
+
+int launch_coarse_build(hipStream_t stream, const int8_t* d_planes, int64_t n, int64_t n_alloc, int d_pad,
+                        int8_t* d_coarse, CoarseRow* d_rows, unsigned long long* d_max_ss) {
+    if (n_alloc <= 0) return 0;
+    hipLaunchKernelGGL(k_coarse_build, dim3((unsigned)((n_alloc + 3) / 4)), dim3(256), 0, stream, d_planes, n, n_alloc,
+                       d_pad, d_coarse, d_rows, d_max_ss);
+    return 0;
+}
+
+int launch_filter_meta(hipStream_t stream, const CoarseRow* d_rows, const double* d_norms_sq, int64_t n,
+                       int64_t n_alloc, int d, double coeff, float4* d_meta) {
+    hipLaunchKernelGGL(k_filter_meta, dim3((unsigned)((n_alloc + 255) / 256)), dim3(256), 0, stream, d_rows,
+                       d_norms_sq, n, n_alloc, d, coeff, d_meta);
+    return 0;
+}
+
+int launch_filter(hipStream_t stream, const PairwiseArgs& a) {
+    if (a.limbs != 2 || a.d_pad > 32768) return MVS_E_INVALID;
+    return launch_mfma_variant<1, false, 2, 4, 2, 4, 1>(stream, a);
+}
+
+int launch_exact_pairs(hipStream_t stream, const PairwiseArgs& a) {
+    if (a.limbs != 2) return MVS_E_INVALID;
+    // the candidate count lives on the device: a fixed grid of waves strides over the list
+    hipLaunchKernelGGL(k_exact_pairs, dim3(256 * 16), dim3(256), 0, stream, a);
     return 0;
 }
 

@@ -26,6 +26,14 @@ def _oracle_sorted(sk, n2, **kw):
 K3 = 0x103   # MVS_LIMBS_K3: three planes of base-128 digits, 3 matrix-core passes per cell
 
 
+@pytest.fixture(params=["exact", "two_stage"])
+def pw_filter(request, monkeypatch):
+    """run a comparison test twice: exact kernel on every cell (MVS_PAIRWISE_FILTER=0) and the coarse filter
+    + exact re-check of the candidates forced on even for small blocks (=2)"""
+    monkeypatch.setenv("MVS_PAIRWISE_FILTER", "0" if request.param == "exact" else "2")
+    return request.param
+
+
 @pytest.mark.parametrize("n,d,hi,code", [(61, 2048, 1500, 2), (61, 2048, 1500, K3), (300, 2048, 8127, K3),
                                          (300, 2048, 8128, 2), (257, 100, 1500, K3), (257, 100, 32639, 2),
                                          (130, 4096, 1500, 2), (130, 4096, 1500, K3), (5, 64, 20000, 2),
@@ -76,7 +84,7 @@ def test_dots_wrap_and_many_limbs(ctx, hi, limbs):
     ss.close()
 
 
-def test_toy_cells_reference_db(ctx, gold):
+def test_toy_cells_reference_db(ctx, gold, pw_filter):
     """config 1: the reference-built toy DB (vectors.bin + vector_norms.txt) -> 1291 kept cells, the rows
     SURVEY.md recorded, every (row, col, dot, q) equal to the fixture"""
     n2 = np.array([orc.norm_sq_from_text(l.split(" ")[1]) for l in gold.norm_lines()])
@@ -103,7 +111,7 @@ def test_toy_cells_reference_db(ctx, gold):
     ss16.close()
 
 
-def test_clustered_synthetic_vs_oracle(ctx):
+def test_clustered_synthetic_vs_oracle(ctx, pw_filter):
     """sketches of real (synthetic) hash sets: clusters of 16 with Jaccard ~0.25 -> ~16 kept cells per row"""
     hashes, offsets = synth.make_csr_numpy(400, 3000, seed=5, cluster=16, shared=0.4, lognormal_sigma=0.8)
     sk = ctx.project_csr(hashes, offsets, 2048)
@@ -124,7 +132,7 @@ def test_clustered_synthetic_vs_oracle(ctx):
     ss.close()
 
 
-def test_keep_threshold_edges(ctx):
+def test_keep_threshold_edges(ctx, pw_filter):
     """cells sitting exactly on the keep threshold: truncating vs floating division"""
     d = 64
     sk = np.zeros((4, d), dtype=np.int32)
@@ -151,7 +159,7 @@ def test_capacity_error_reports_needed(ctx, gold):
     ss.close()
 
 
-def test_full_width_properties(ctx):
+def test_full_width_properties(ctx, pw_filter):
     """N = 4096, d = 2048 (sketch magnitudes of 50k-hash samples): no oracle for the whole matrix --
     symmetry of the kept set, diagonal = 255, checksum of dots vs the VALU path on a stripe, and an
     oracle check of 64 rows."""
@@ -179,7 +187,7 @@ def test_full_width_properties(ctx):
     ss.close()
 
 
-def test_sharded_comparison_single_rank(ctx):
+def test_sharded_comparison_single_rank(ctx, pw_filter):
     """metagenome_vector_sketches_amd.parallel with the real GPU back end, world = 1 (the multi-rank
     orchestration is covered on CPU with gloo in tests/test_distributed_cpu.py)"""
     import torch
@@ -268,3 +276,94 @@ def test_half_million_samples_grid_limits(ctx):
     assert int(((rows // 16) == (cols // 16)).sum()) == n * 16
     per_row = np.bincount(rows, minlength=n)
     assert per_row.min() >= 16 and np.all(cells[rows == cols][:, 3] == 255) and int((rows == cols).sum()) == n
+
+
+def _random_rows(rng, n, d, kind):
+    """sketch-like rows of very different shapes, all within two base-256 limbs"""
+    if kind == "mixed":       # set sizes over three decades, clusters of related rows
+        sizes = (10 ** rng.uniform(1.5, 5.0, n)).astype(np.int64)
+        base = rng.standard_normal((n // 8 + 1, d))
+        sk = np.empty((n, d), dtype=np.int64)
+        for i in range(n):
+            k = int(0.5 * sizes[i])
+            x = base[i // 8] * np.sqrt(k) + rng.standard_normal(d) * np.sqrt(sizes[i] - k)
+            sk[i] = np.round((x - (sizes[i] & 1)) / 2) * 2 + (sizes[i] & 1)
+        return np.clip(sk, -32639, 32639).astype(np.int32)
+    if kind == "peaky":       # a few huge coordinates on small noise: the coarse plane loses almost everything
+        sk = rng.integers(-3, 4, (n, d))
+        for i in range(n):
+            idx = rng.integers(0, d, 3)
+            sk[i, idx] = rng.integers(-18000, 18000, 3)   # sums of squares stay below 2^31
+        sk[::7] = sk[3]       # exact duplicates
+        sk[5] = -sk[3]        # and an anti-correlated row
+        return sk.astype(np.int32)
+    if kind == "flat":        # constant and near-constant rows, empty rows
+        sk = np.tile(rng.integers(-1500, 1500, (n, 1)), (1, d)) + rng.integers(-1, 2, (n, d))
+        sk[::5] = 0
+        return sk.astype(np.int32)
+    raise ValueError(kind)
+
+
+@pytest.mark.parametrize("kind,n,d", [("mixed", 700, 2048), ("mixed", 500, 4096), ("mixed", 900, 100),
+                                      ("peaky", 600, 2048), ("flat", 400, 512), ("mixed", 1500, 1024)])
+@pytest.mark.parametrize("mode", ["int32", "int16"])
+def test_two_stage_equals_exact_and_oracle(ctx, monkeypatch, kind, n, d, mode):
+    """the coarse filter may only drop pairs the keep test rejects: same cells as the exact kernel and the
+    oracle on adversarial row shapes, both keep tests"""
+    rng = np.random.default_rng(hash((kind, n, d)) % 2 ** 32)
+    sk = _random_rows(rng, n, d, kind)
+    n2 = _n2_from_sketches(sk)
+    n2[::11] *= 0.3          # norms that do not match the rows (the filter must not rely on them)
+    keep = _capi.KEEP_INT32 if mode == "int32" else _capi.KEEP_INT16
+    ss = ctx.sketch_set(sk)
+    assert ss.limbs == 2
+    monkeypatch.setenv("MVS_PAIRWISE_FILTER", "2")
+    two, cnt_two = ctx.pairwise_rows(ss, n2, keep_mode=keep)
+    n_cand = ctx.pairwise_candidates()
+    monkeypatch.setenv("MVS_PAIRWISE_FILTER", "0")
+    exact, cnt_exact = ctx.pairwise_rows(ss, n2, keep_mode=keep)
+    assert ctx.pairwise_candidates() == 0
+    assert cnt_two == cnt_exact and np.array_equal(two, exact)
+    assert n_cand >= (cnt_two + n) // 2 - 1                          # every kept pair was a candidate (upper triangle)
+    skx = sk if mode == "int32" else sk.astype(np.int16)
+    assert _cells_tuple(two) == _oracle_sorted(skx, n2, chunk=192)
+    ss.close()
+
+
+def test_two_stage_threshold_knife_edge(ctx, monkeypatch):
+    """pairs whose dot sits exactly on, one below and one above d * 0.05 * (n2_i + n2_j)"""
+    d = 2048
+    rng = np.random.default_rng(99)
+    base = rng.integers(-900, 900, d)
+    sk = np.stack([base + rng.integers(-40, 40, d) for _ in range(64)]).astype(np.int32)
+    P = sk.astype(np.int64) @ sk.astype(np.int64).T
+    n2 = np.empty(64)
+    # choose n2 so that 0.05 * (n2_0 + n2_j) lands on trunc(P_0j / d) + {-1, 0, +1} / 3
+    n2[0] = 1000.0
+    for j in range(1, 64):
+        q = P[0, j] // d
+        n2[j] = (q + ((j % 3) - 1) / 3.0) / 0.05 - n2[0]
+    ss = ctx.sketch_set(sk)
+    for keep in (_capi.KEEP_INT32, _capi.KEEP_INT16):
+        monkeypatch.setenv("MVS_PAIRWISE_FILTER", "2")
+        two, _ = ctx.pairwise_rows(ss, n2, keep_mode=keep)
+        assert ctx.pairwise_candidates() > 0
+        skx = sk if keep == _capi.KEEP_INT32 else sk.astype(np.int16)
+        assert _cells_tuple(two) == _oracle_sorted(skx, n2, chunk=192)
+    ss.close()
+
+
+def test_two_stage_wrap_guard(ctx, monkeypatch):
+    """rows whose sum of squares reaches 2^31: dots may wrap, the filter must stand down"""
+    d = 2048
+    rng = np.random.default_rng(5)
+    sk = rng.integers(-1200, 1200, (300, d)).astype(np.int32)
+    sk[17] = 1100                     # 2048 * 1100^2 = 2.48e9 >= 2^31
+    sk[18] = 1100
+    n2 = _n2_from_sketches(sk)
+    ss = ctx.sketch_set(sk)
+    monkeypatch.setenv("MVS_PAIRWISE_FILTER", "2")
+    cells, _ = ctx.pairwise_rows(ss, n2)
+    assert ctx.pairwise_candidates() == 0
+    assert _cells_tuple(cells) == _oracle_sorted(sk, n2, chunk=192)
+    ss.close()

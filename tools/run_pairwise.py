@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Run the pairwise comparison alone on synthesised sketches (profiling helper).
-   python tools/run_pairwise.py [N] [d] [reps]"""
+   python tools/run_pairwise.py [N] [d] [reps] [hashes per sample]"""
 import os
 import sys
 import time
@@ -15,10 +15,11 @@ from metagenome_vector_sketches_amd import synth
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
 d = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+nh = int(sys.argv[4]) if len(sys.argv) > 4 else 50_000
 ctx = pkg.Context(0)
 ctx.set_stream(torch.cuda.current_stream())
 ctx.set_timing(True)
-sk = synth.make_sketches_torch(n, d, 50_000, seed=2345, device="cuda")
+sk = synth.make_sketches_torch(n, d, nh, seed=2345, device="cuda")
 if os.environ.get("ZERO_DATA") == "1":       # power experiment: same instruction stream on all-zero operands
     sk.zero_()
     sk[:, 0] = 200                            # keeps limbs == 2 (max |v| > 127)
@@ -33,6 +34,7 @@ for r in range(reps):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     ms = ctx.kernel_ms(1)
+    print("candidates %d" % ctx.pairwise_candidates(), end="  ")
     print("N=%d d=%d limbs=%d kept=%d wall %.3f ms kernel %.3f ms -> %.3g cells/s, %.1f algorithmic TFLOP/s, MFMA issue %.1f%%"
           % (n, d, sset.limbs, cnt, dt * 1e3, ms, n * n / (ms * 1e-3), 2.0 * d * n * n / (ms * 1e-3) / 1e12,
              2.0 * d * n * n * {1: 1, 0x103: 3, 2: 4}.get(sset.limbs, 0) *
