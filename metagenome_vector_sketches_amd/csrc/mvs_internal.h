@@ -87,7 +87,7 @@ int launch_cand_thr(hipStream_t stream, const double* d_norms_sq, int64_t n, int
 // mode 0: comparison (kept cells), mode 1: dense dots.  algo 0: MFMA, 1: vector ALU.
 int launch_pairwise(hipStream_t stream, const PairwiseArgs& a, int mode, int algo);
 // two-stage comparison for two base-256 limbs: coarse plane + row statistics from the limb planes
-// (d_max_ss receives the largest sum of squares of a row), per-call filter constants, the one-pass filter
+// (d_max_ss receives the largest sum of squares of a row if one reaches 2^31, and is left alone otherwise), per-call filter constants, the one-pass filter
 // that appends candidate pairs, and the exact re-check of the candidates that appends kept cells
 int launch_coarse_build(hipStream_t stream, const int8_t* d_planes, int64_t n, int64_t n_alloc, int d_pad,
                         int8_t* d_coarse, CoarseRow* d_rows, unsigned long long* d_max_ss);

@@ -144,20 +144,19 @@ __device__ __forceinline__ void wait_vmcnt() {
 }
 
 // Geometry (template parameters):
-//   WM x WN waves; every wave owns 64 rows (two 32-row MFMA tiles) x BT*32 columns of the tile, so the
-//   workgroup tile is TM = WM*64 rows x TN = WN*BT*32 columns.  DBUF: fragments double buffered in
+//   WM x WN waves; every wave owns AT*32 rows (AT 32-row MFMA tiles, 2 unless stated) x BT*32 columns of the
+//   tile, so the workgroup tile is TM = WM*AT*32 rows x TN = WN*BT*32 columns.  DBUF: fragments double buffered in
 //   registers (BT = 1); with BT = 2 the wave's 16 MFMAs per k-step are long enough for the SIMD's other
 //   wave to hide the fragment reads, and the 192 accumulator registers leave no room for a second buffer.
 // KARA: the L = 3 planes are (l0, l1, l0+l1) of base-128 digits; only the three "diagonal" products
 //       X = <l0,l0'>, Z = <l1,l1'>, Y = <l0+l1, l0'+l1'> are formed and P = X + 128(Y-X-Z) + 16384 Z.
-template <int L, bool KARA, int MODE, int NST, int WM, int WN, int BT>
-__global__ __launch_bounds__(WM * WN * 64, 2) void k_pairwise_mfma(const PairwiseArgs a, int n_tr, int n_tc,
-                                                                   int n_spc) {
+template <int L, bool KARA, int MODE, int NST, int WM, int WN, int BT, int AT = 2, bool DBUF = (BT == 1)>
+__global__ __launch_bounds__(WM * WN * 64, (AT * BT > 2 ? 1 : 2)) void k_pairwise_mfma(const PairwiseArgs a, int n_tr,
+                                                                                      int n_tc, int n_spc) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int kWavesT = WM * WN;
-    constexpr int TM = WM * 64;                  // rows (A samples) per tile
+    constexpr int TM = WM * AT * 32;             // rows (A samples) per tile
     constexpr int TN = WN * BT * 32;             // columns (B samples) per tile
-    constexpr bool DBUF = BT == 1;
     constexpr int NB = DBUF ? 2 : 1;             // fragment register buffers
     constexpr int kRegion = L * TM * kSK;        // bytes of the A operand region
     constexpr int kRegionB = L * TN * kSK;       // bytes of the B operand region
@@ -176,7 +175,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void k_pairwise_mfma(const Pairwis
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WN;   // 64-row slice of the tile
+    const int wm = wave / WN;   // AT*32-row slice of the tile
     const int wn = wave % WN;   // BT*32-column slice of the tile
 
     const int64_t i0 = a.row_begin + (int64_t)tc.tr * TM;   // first A sample of the tile
@@ -219,12 +218,12 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void k_pairwise_mfma(const Pairwis
     const int fr = lane & 31;          // row (A) / col (B) inside a 32x32 MFMA tile
     const int fh = lane >> 5;          // k half
     const int key = (fr >> 2) & 3;     // swizzle key (tile bases are multiples of 16 samples)
-    const int a_row0 = (wm * 64 + fr) * kSK;                         // + t*32*kSK + limb*TM*kSK
+    const int a_row0 = (wm * AT * 32 + fr) * kSK;                    // + t*32*kSK + limb*TM*kSK
     const int b_row0 = kRegion + (wn * BT * 32 + fr) * kSK;          // + u*32*kSK + limb*TN*kSK
 
-    v16i acc[2][BT][NS];
+    v16i acc[AT][BT][NS];
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < AT; ++t)
 #pragma unroll
         for (int u = 0; u < BT; ++u)
 #pragma unroll
@@ -232,7 +231,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void k_pairwise_mfma(const Pairwis
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[t][u][s][r] = 0;
 
-    v4i fa[NB][2][L], fb[NB][BT][L];
+    v4i fa[NB][AT][L], fb[NB][BT][L];
     auto load_frags = [&](int buf, const char* sb, int kk) {
         const int coff = (((kk * 2 + fh) ^ key) << 4);
 #pragma unroll
@@ -241,7 +240,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void k_pairwise_mfma(const Pairwis
             for (int u = 0; u < BT; ++u)
                 fb[buf][u][l] = *reinterpret_cast<const v4i*>(sb + b_row0 + u * 32 * kSK + l * TN * kSK + coff);
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+            for (int t = 0; t < AT; ++t)
                 fa[buf][t][l] = *reinterpret_cast<const v4i*>(sb + a_row0 + t * 32 * kSK + l * TM * kSK + coff);
         }
     };
@@ -250,7 +249,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void k_pairwise_mfma(const Pairwis
     // after the loop back-edge, and that wait must not cover reads issued for the next step.
     auto mfma_group = [&](int buf, int part) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < AT; ++t)
 #pragma unroll
             for (int u = 0; u < BT; ++u)
 #pragma unroll
@@ -331,7 +330,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void k_pairwise_mfma(const Pairwis
     if (a.debug_flags & 2) {   // ablation: keep the accumulators alive, skip the epilogue
         int x = 0;
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < AT; ++t)
 #pragma unroll
             for (int u = 0; u < BT; ++u)
 #pragma unroll
@@ -355,10 +354,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void k_pairwise_mfma(const Pairwis
             const bool col_ok = col < a.col_end;
             const bool mirror = a.mirror_all || (mirror_tile && col < a.row_end);
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
+            for (int t = 0; t < AT; ++t) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int row_l = wm * 64 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                    const int row_l = wm * AT * 32 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
                     const int64_t row = i0 + row_l;
                     const float4 mi = fm[row_l];
                     float rhs = mi.x * mj.y;
@@ -385,10 +384,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void k_pairwise_mfma(const Pairwis
         const int col_l = (wn * BT + u) * 32 + fr;
         const int64_t col = j0 + col_l;
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
+        for (int t = 0; t < AT; ++t) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row_l = wm * 64 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                const int row_l = wm * AT * 32 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
                 const int64_t row = i0 + row_l;
                 uint32_t Pu = (uint32_t)acc[t][u][0][r];
                 if (KARA) {
@@ -712,25 +711,28 @@ __global__ __launch_bounds__(256) void k_coarse_build(const int8_t* __restrict__
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= n_alloc) return;
-    const int words = d_pad / 4;
-    uint32_t* out = reinterpret_cast<uint32_t*>(coarse + row * (int64_t)d_pad);
+    const int chunks = d_pad / 16;   // 16-byte chunks per plane row (d_pad is a multiple of 128)
+    v4i* out = reinterpret_cast<v4i*>(coarse + row * (int64_t)d_pad);
     if (row >= n) {   // padding rows
-        for (int k = lane; k < words; k += 64) out[k] = 0;
+        for (int k = lane; k < chunks; k += 64) out[k] = v4i{0, 0, 0, 0};
         if (lane == 0) rows[row] = CoarseRow{1, 0, 0, 0};
         return;
     }
-    const uint32_t* lo = reinterpret_cast<const uint32_t*>(planes + row * 2 * (int64_t)d_pad);
-    const uint32_t* hi = lo + words;
+    const v4i* lo = reinterpret_cast<const v4i*>(planes + row * 2 * (int64_t)d_pad);
+    const v4i* hi = lo + chunks;
     int mx = 0;
     unsigned long long ss = 0;
-    for (int k = lane; k < words; k += 64) {
-        const uint32_t l = lo[k], h = hi[k];
+    for (int k = lane; k < chunks; k += 64) {
+        const v4i l4 = lo[k], h4 = hi[k];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int v = (int)(int8_t)(l >> (8 * e)) + 256 * (int)(int8_t)(h >> (8 * e));
-            const int av = v < 0 ? -v : v;
-            mx = av > mx ? av : mx;
-            ss += (unsigned long long)((long long)v * v);
+        for (int w = 0; w < 4; ++w) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int v = (int)(int8_t)((uint32_t)l4[w] >> (8 * e)) + 256 * (int)(int8_t)((uint32_t)h4[w] >> (8 * e));
+                const int av = v < 0 ? -v : v;
+                mx = av > mx ? av : mx;
+                ss += (unsigned)(v * v);   // |v| <= 32895: the square fits 32 bits
+            }
         }
     }
 #pragma unroll
@@ -742,20 +744,25 @@ __global__ __launch_bounds__(256) void k_coarse_build(const int8_t* __restrict__
     const int m = mx <= 127 ? 1 : (mx + 126) / 127;
     const float inv = 1.0f / (float)m;
     unsigned c2 = 0, r2 = 0;   // <= 129^2 * 32768 per row: fits
-    for (int k = lane; k < words; k += 64) {
-        const uint32_t l = lo[k], h = hi[k];
-        uint32_t packed = 0;
+    for (int k = lane; k < chunks; k += 64) {
+        const v4i l4 = lo[k], h4 = hi[k];
+        v4i o4;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int v = (int)(int8_t)(l >> (8 * e)) + 256 * (int)(int8_t)(h >> (8 * e));
-            int c = (int)rintf((float)v * inv);
-            c = c > 127 ? 127 : (c < -127 ? -127 : c);
-            const int r = v - m * c;   // exact, whatever the rounding above did
-            c2 += (unsigned)(c * c);
-            r2 += (unsigned)(r * r);
-            packed |= (uint32_t)(uint8_t)(int8_t)c << (8 * e);
+        for (int w = 0; w < 4; ++w) {
+            uint32_t packed = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int v = (int)(int8_t)((uint32_t)l4[w] >> (8 * e)) + 256 * (int)(int8_t)((uint32_t)h4[w] >> (8 * e));
+                int c = (int)rintf((float)v * inv);
+                c = c > 127 ? 127 : (c < -127 ? -127 : c);
+                const int r = v - m * c;   // exact, whatever the rounding above did
+                c2 += (unsigned)(c * c);
+                r2 += (unsigned)(r * r);
+                packed |= (uint32_t)(uint8_t)(int8_t)c << (8 * e);
+            }
+            o4[w] = (int)packed;
         }
-        out[k] = packed;
+        out[k] = o4;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -764,7 +771,8 @@ __global__ __launch_bounds__(256) void k_coarse_build(const int8_t* __restrict__
     }
     if (lane == 0) {
         rows[row] = CoarseRow{m, (int32_t)c2, (int32_t)r2, 0};
-        atomicMax(max_ss, ss);
+        // only rows that rule the filter out report (one contended atomic per row would dominate the kernel)
+        if (ss >= (1ULL << 31)) atomicMax(max_ss, ss);
     }
 }
 
@@ -858,9 +866,9 @@ int pairwise_variant() {
     return v;
 }
 
-template <int L, bool KARA, int MODE, int NST, int WM, int WN, int BT>
+template <int L, bool KARA, int MODE, int NST, int WM, int WN, int BT, int AT = 2, bool DBUF = (BT == 1)>
 int launch_mfma_variant(hipStream_t stream, const PairwiseArgs& a) {
-    constexpr int TM = WM * 64, TN = WN * BT * 32;
+    constexpr int TM = WM * AT * 32, TN = WN * BT * 32;
     const int64_t rows = a.row_end - a.row_begin, cols = a.col_end - a.col_begin;
     if (rows <= 0 || cols <= 0) return 0;
     const int n_tr = (int)((rows + TM - 1) / TM), n_tc = (int)((cols + TN - 1) / TN);
@@ -870,10 +878,11 @@ int launch_mfma_variant(hipStream_t stream, const PairwiseArgs& a) {
     PairwiseArgs b = a;
     // the symmetric schedule needs the row and column tile grids to share their origin modulo TM
     if (b.symmetric && ((a.row_begin - a.col_begin) % TM != 0 || TM % TN != 0 || a.mirror_all)) b.symmetric = 0;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pairwise_mfma<L, KARA, MODE, NST, WM, WN, BT>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute(
+        reinterpret_cast<const void*>(&k_pairwise_mfma<L, KARA, MODE, NST, WM, WN, BT, AT, DBUF>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return MVS_E_HIP;
-    hipLaunchKernelGGL((k_pairwise_mfma<L, KARA, MODE, NST, WM, WN, BT>), dim3((unsigned)n_spc * 256u, (unsigned)n_spr),
+    hipLaunchKernelGGL((k_pairwise_mfma<L, KARA, MODE, NST, WM, WN, BT, AT, DBUF>), dim3((unsigned)n_spc * 256u, (unsigned)n_spr),
                        dim3(WM * WN * 64), lds, stream, b, n_tr, n_tc, n_spc);
     return 0;
 }
@@ -976,7 +985,18 @@ int launch_filter_meta(hipStream_t stream, const CoarseRow* d_rows, const double
 
 int launch_filter(hipStream_t stream, const PairwiseArgs& a) {
     if (a.limbs != 2 || a.d_pad > 32768) return MVS_E_INVALID;
-    return launch_mfma_variant<1, false, 2, 4, 2, 4, 1>(stream, a);
+    static int v = -1;   // MVS_FILTER_VARIANT: tile shape of the one-pass filter
+    if (v < 0) {
+        const char* e = getenv("MVS_FILTER_VARIANT");
+        v = e ? atoi(e) : 0;
+    }
+    switch (v) {
+        case 1: return launch_mfma_variant<1, false, 2, 4, 2, 4, 2, 4, true>(stream, a);   // 256 x 256, waves 128 x 64
+        case 2: return launch_mfma_variant<1, false, 2, 3, 2, 4, 2, 4, true>(stream, a);
+        case 3: return launch_mfma_variant<1, false, 2, 4, 4, 2, 2, 2, true>(stream, a);   // 256 x 128, waves 64 x 64
+        case 4: return launch_mfma_variant<1, false, 2, 4, 2, 4, 2, 2, true>(stream, a);   // 128 x 256, waves 64 x 64
+        default: return launch_mfma_variant<1, false, 2, 4, 2, 4, 1>(stream, a);           // 128 x 128, waves 64 x 32
+    }
 }
 
 int launch_exact_pairs(hipStream_t stream, const PairwiseArgs& a) {
