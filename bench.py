@@ -122,6 +122,7 @@ def main():
         # limb split, [all-gather of plane row blocks + norms], K2 on this rank's rows x all columns
         _, cnt, info = sc.run(sketches, n2_local, N_total, cells_out=cells, max_abs_local=max_abs)
         state["cnt"] = cnt
+        state["candidates"] = ctx.pairwise_candidates()
         state["limbs"] = info["limbs"]
         state["schedule"] = info.get("schedule", "rows x all columns")
 
@@ -219,7 +220,11 @@ def main():
                               "unit": "TFLOP/s", "frac": k2_flops / (k2 * 1e-3) / 1e12 / INT8_MFMA_PEAK_TOPS,
                               # matrix-core work actually issued: passes per cell (1 limb: 1, Karatsuba: 3,
                               # two base-256 limbs: 4) x share of the tiles the symmetric schedule computes
-                              "issued_frac": k2_flops * {1: 1, 0x103: 3, 2: 4}.get(limbs, 0) *
+                              # (the two-stage comparison issues one pass, on the coarse plane, and re-checks
+                              # `candidates` pairs on the vector ALU)
+                              "two_stage": state["candidates"] > 0, "candidates": state["candidates"],
+                              "issued_frac": k2_flops * (1 if state["candidates"] > 0 else
+                                                         {1: 1, 0x103: 3, 2: 4}.get(limbs, 0)) *
                               (0.5 + 0.5 * 128.0 / S if world == 1 or state["schedule"] == "symmetric"
                                else 1.0 - 0.5 / world + 0.5 * 128.0 / N_total)
                               / (k2 * 1e-3) / 1e12 / INT8_MFMA_PEAK_TOPS,

@@ -35,6 +35,7 @@ struct mvs_ctx {
     void* pw_cand = nullptr;    size_t pw_cand_bytes = 0;
     unsigned long long coarse_id = 0, coarse_gen = 0;
     bool coarse_usable = false;          // no row's sum of squares reaches 2^31: exact dots cannot wrap
+    bool coarse_checked = false;         // coarse_usable has been confirmed from the device flag
     unsigned long long filter_off_id = 0;   // (set, coefficient) for which the filter passed too many pairs
     double filter_off_coeff = 0.0;
     unsigned long long last_candidates = 0; // candidate pairs of the last two-stage comparison (0: exact kernel)
@@ -710,10 +711,10 @@ int prepare_coarse(mvs_ctx* c, const mvs_sketch_set* s) {
                              (mvs::CoarseRow*)c->pw_rows, c->d_counter + 3);
     rc = check_kernel("k_coarse_build");
     if (rc) return rc;
-    unsigned long long max_ss = 0;
-    HIP_TRY(hipMemcpyAsync(&max_ss, c->d_counter + 3, 8, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    c->coarse_usable = max_ss < (1ULL << 31);   // |<v_i,v_j>| <= |v_i| |v_j| < 2^31: the int32 dot is the true dot
+    // whether a row's sum of squares reaches 2^31 (then dots may wrap and the filter's bound does not hold)
+    // is read back together with the first candidate count: no extra synchronisation here
+    c->coarse_usable = true;
+    c->coarse_checked = false;
     c->coarse_id = s->id;
     c->coarse_gen = s->gen;
     return MVS_OK;
@@ -784,9 +785,13 @@ int pairwise_launch(mvs_ctx* c, const mvs_sketch_set* s, const double* d_n2, int
         for (int attempt = 0; attempt < 3; ++attempt) {
             a.cand = (int2*)c->pw_cand;
             a.cand_capacity = c->pw_cand_bytes / sizeof(int2);
-            rc = set_count();
-            if (rc) return rc;
-            HIP_TRY(hipMemsetAsync(c->d_counter + 2, 0, 8, c->stream));
+            if (start == 0) {
+                HIP_TRY(hipMemsetAsync(c->d_counter, 0, 24, c->stream));   // cell count, (debug slot), candidate count
+            } else {
+                rc = set_count();
+                if (rc) return rc;
+                HIP_TRY(hipMemsetAsync(c->d_counter + 2, 0, 8, c->stream));
+            }
             if (c->timing) HIP_TRY(hipEventRecord(c->ev[2], c->stream));
             rc = mvs::launch_filter(c->stream, a);
             if (rc) return fail(rc, "filter launch rejected");
@@ -800,9 +805,17 @@ int pairwise_launch(mvs_ctx* c, const mvs_sketch_set* s, const double* d_n2, int
                 HIP_TRY(hipEventRecord(c->ev[3], c->stream));
                 c->ev_valid[1] = true;
             }
-            unsigned long long n_cand = 0;
-            HIP_TRY(hipMemcpyAsync(&n_cand, c->d_counter + 2, 8, hipMemcpyDeviceToHost, c->stream));
+            unsigned long long back[2] = {0, 0};   // candidate count, largest sum of squares >= 2^31 (or 0)
+            HIP_TRY(hipMemcpyAsync(back, c->d_counter + 2, 16, hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(hipStreamSynchronize(c->stream));
+            if (!c->coarse_checked) {
+                c->coarse_checked = true;
+                if (back[1] != 0) {   // dots may wrap: the candidates prove nothing, the exact kernel decides
+                    c->coarse_usable = false;
+                    break;
+                }
+            }
+            const unsigned long long n_cand = back[0];
             c->last_candidates = n_cand;
             if (n_cand <= a.cand_capacity) return MVS_OK;
             if ((double)n_cand > cand_limit) {

@@ -150,7 +150,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 //   wave to hide the fragment reads, and the 192 accumulator registers leave no room for a second buffer.
 // KARA: the L = 3 planes are (l0, l1, l0+l1) of base-128 digits; only the three "diagonal" products
 //       X = <l0,l0'>, Z = <l1,l1'>, Y = <l0+l1, l0'+l1'> are formed and P = X + 128(Y-X-Z) + 16384 Z.
-template <int L, bool KARA, int MODE, int NST, int WM, int WN, int BT, int AT = 2, bool DBUF = (BT == 1)>
+template <int L, bool KARA, int MODE, int NST, int WM, int WN, int BT, int AT = 2, bool DBUF = (BT == 1), int ABL = 0>
 __global__ __launch_bounds__(WM * WN * 64, (AT * BT > 2 ? 1 : 2)) void k_pairwise_mfma(const PairwiseArgs a, int n_tr,
                                                                                       int n_tc, int n_spc) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -206,6 +206,7 @@ __global__ __launch_bounds__(WM * WN * 64, (AT * BT > 2 ? 1 : 2)) void k_pairwis
         src[p] = (MODE == 2 ? a.coarse : a.planes) + (sample * L + limb) * (int64_t)a.d_pad + c * 16;
     }
     auto stage_copy = [&](int slot, int k0) {
+        if (ABL == 2 && k0 != 0) return;   // ablation: no HBM/L2 -> LDS copies after the first slice
 #pragma unroll
         for (int p = 0; p < kPPW; ++p) {
             const int piece = wave * kPPW + p;
@@ -233,6 +234,7 @@ __global__ __launch_bounds__(WM * WN * 64, (AT * BT > 2 ? 1 : 2)) void k_pairwis
 
     v4i fa[NB][AT][L], fb[NB][BT][L];
     auto load_frags = [&](int buf, const char* sb, int kk) {
+        if (ABL == 3 && sb != smem) return;   // ablation: fragments are read from LDS only once
         const int coff = (((kk * 2 + fh) ^ key) << 4);
 #pragma unroll
         for (int l = 0; l < L; ++l) {
@@ -260,6 +262,7 @@ __global__ __launch_bounds__(WM * WN * 64, (AT * BT > 2 ? 1 : 2)) void k_pairwis
                         const bool first = t == 0 && u == 0 && la == 0 && lb == 0;
                         if ((part == 0 && !first) || (part == 1 && first)) continue;
                         const int s = KARA ? la : la + lb;
+                        if (ABL == 1) continue;   // ablation: no matrix-core work
                         acc[t][u][s] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[buf][t][la], fb[buf][u][lb],
                                                                             acc[t][u][s], 0, 0, 0);
                     }
@@ -352,7 +355,10 @@ __global__ __launch_bounds__(WM * WN * 64, (AT * BT > 2 ? 1 : 2)) void k_pairwis
             const float4 mj = fm[TM + col_l];
             const float bj = mj.z + mj.w;
             const bool col_ok = col < a.col_end;
-            const bool mirror = a.mirror_all || (mirror_tile && col < a.row_end);
+            // symmetric schedule: inside the square of the row range only the upper triangle is re-checked and
+            // its cells are mirrored (the exact kernel computes whole diagonal tiles instead, the filter would
+            // hand both (i,j) and (j,i) to the re-check)
+            const bool in_square = a.symmetric && col >= a.row_begin && col < a.row_end;
 #pragma unroll
             for (int t = 0; t < AT; ++t) {
 #pragma unroll
@@ -364,8 +370,10 @@ __global__ __launch_bounds__(WM * WN * 64, (AT * BT > 2 ? 1 : 2)) void k_pairwis
                     rhs = fmaf(mj.x, mi.y, rhs);
                     rhs = fmaf(-mi.z, mj.w, rhs);
                     rhs = fmaf(-mi.w, bj, rhs);
-                    const bool cand = (float)acc[t][u][0][r] > rhs && col_ok && row < a.row_end;
-                    emit_cand(a, cand, mirror, (int32_t)row, (int32_t)col, lane);
+                    bool cand = (float)acc[t][u][0][r] > rhs && col_ok && row < a.row_end;
+                    if (ABL >= 2) cand = cand && acc[t][u][0][r] == 0x7fffffff;   // ablations compute garbage
+                    if (in_square) cand = cand && col >= row;
+                    emit_cand(a, cand, a.mirror_all || (in_square && col > row), (int32_t)row, (int32_t)col, lane);
                 }
             }
         }
@@ -796,28 +804,36 @@ __global__ __launch_bounds__(256) void k_filter_meta(const CoarseRow* __restrict
     meta[i] = o;
 }
 
-// Exact re-check of the candidate pairs: one wave per pair and 64 pairs per round, so that the keep test,
-// the quantisation and the append run once per round on all lanes.
+// Exact re-check of the candidate pairs.  A wave takes B pairs per round (B = 64 unless stated).  QUAD = 0: all
+// 64 lanes stream the limb rows of one pair after the other (1 KiB per load instruction); QUAD = 1: each
+// quarter of the wave streams one pair, four pairs in flight.  Lanes 0..B-1 then run the keep test, the
+// quantisation and the append for the round's pairs.
+template <int B, int QUAD>
 __global__ __launch_bounds__(256) void k_exact_pairs(const PairwiseArgs a) {
+    static_assert(B == 16 || B == 32 || B == 64, "pairs per round");
     const int lane = threadIdx.x & 63;
     unsigned long long n_cand = *a.cand_counter;
     if (n_cand > a.cand_capacity) n_cand = a.cand_capacity;
     const unsigned long long waves = (unsigned long long)gridDim.x * 4;
     const unsigned long long wid = (unsigned long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t stride = 2 * (int64_t)a.d_pad;
-    for (unsigned long long base = wid * 64; base < n_cand; base += waves * 64) {
+    const int width = QUAD ? 16 : 64;                 // lanes per pair
+    const int sub = QUAD ? lane >> 4 : 0, sl = QUAD ? lane & 15 : lane;
+    for (unsigned long long base = wid * B; base < n_cand; base += waves * B) {
         const unsigned long long mine = base + lane;
+        const bool have = lane < B && mine < n_cand;
         int2 pr = make_int2(0, 0);
-        if (mine < n_cand) pr = a.cand[mine];
-        const int cnt = (int)(n_cand - base < 64 ? n_cand - base : 64);
+        if (have) pr = a.cand[mine];
+        const int cnt = (int)(n_cand - base < (unsigned long long)B ? n_cand - base : (unsigned long long)B);
         int32_t P_mine = 0;
-        for (int q = 0; q < cnt; ++q) {
-            const int row = __shfl(pr.x, q, 64);
+        for (int step = 0; step * (QUAD ? 4 : 1) < cnt; ++step) {
+            const int q = QUAD ? step * 4 + sub : step;   // pair handled by these lanes in this step
+            const int row = __shfl(pr.x, q, 64);          // beyond the round's count: (0, 0), harmless
             const int col = __shfl(pr.y, q, 64) & 0x7fffffff;
             const int8_t* ri = a.planes + (int64_t)row * stride;
             const int8_t* rj = a.planes + (int64_t)col * stride;
             int acc0 = 0, acc1 = 0, acc2 = 0;
-            for (int k = lane * 16; k < a.d_pad; k += 1024) {
+            for (int k = sl * 16; k < a.d_pad; k += width * 16) {
                 const v4i li = *reinterpret_cast<const v4i*>(ri + k);
                 const v4i hi = *reinterpret_cast<const v4i*>(ri + a.d_pad + k);
                 const v4i lj = *reinterpret_cast<const v4i*>(rj + k);
@@ -832,12 +848,17 @@ __global__ __launch_bounds__(256) void k_exact_pairs(const PairwiseArgs a) {
             }
             uint32_t P = (uint32_t)acc0 + ((uint32_t)acc1 << 8) + ((uint32_t)acc2 << 16);
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) P += __shfl_xor(P, o, 64);
-            if (lane == q) P_mine = (int32_t)P;
+            for (int o = width / 2; o > 0; o >>= 1) P += __shfl_xor(P, o, 64);
+            if (QUAD) {
+                const uint32_t got = __shfl(P, (lane & 3) * 16, 64);     // pair step*4 + (lane&3) -> lane
+                if ((lane >> 2) == step) P_mine = (int32_t)got;          // lanes 0..15: lane == its pair
+            } else if (lane == step) {
+                P_mine = (int32_t)P;
+            }
         }
         bool keep = false;
         const int32_t row = pr.x, col = pr.y & 0x7fffffff;
-        if (mine < n_cand) keep = keep_cell(P_mine, a.d, a.norms_sq[row], a.norms_sq[col], a.keep_mode, a.keep_coeff);
+        if (have) keep = keep_cell(P_mine, a.d, a.norms_sq[row], a.norms_sq[col], a.keep_mode, a.keep_coeff);
         emit_cell(a, keep, pr.y < 0, row, col, P_mine, lane);
     }
 }
@@ -866,7 +887,7 @@ int pairwise_variant() {
     return v;
 }
 
-template <int L, bool KARA, int MODE, int NST, int WM, int WN, int BT, int AT = 2, bool DBUF = (BT == 1)>
+template <int L, bool KARA, int MODE, int NST, int WM, int WN, int BT, int AT = 2, bool DBUF = (BT == 1), int ABL = 0>
 int launch_mfma_variant(hipStream_t stream, const PairwiseArgs& a) {
     constexpr int TM = WM * AT * 32, TN = WN * BT * 32;
     const int64_t rows = a.row_end - a.row_begin, cols = a.col_end - a.col_begin;
@@ -879,10 +900,10 @@ int launch_mfma_variant(hipStream_t stream, const PairwiseArgs& a) {
     // the symmetric schedule needs the row and column tile grids to share their origin modulo TM
     if (b.symmetric && ((a.row_begin - a.col_begin) % TM != 0 || TM % TN != 0 || a.mirror_all)) b.symmetric = 0;
     hipError_t e = hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&k_pairwise_mfma<L, KARA, MODE, NST, WM, WN, BT, AT, DBUF>),
+        reinterpret_cast<const void*>(&k_pairwise_mfma<L, KARA, MODE, NST, WM, WN, BT, AT, DBUF, ABL>),
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return MVS_E_HIP;
-    hipLaunchKernelGGL((k_pairwise_mfma<L, KARA, MODE, NST, WM, WN, BT, AT, DBUF>), dim3((unsigned)n_spc * 256u, (unsigned)n_spr),
+    hipLaunchKernelGGL((k_pairwise_mfma<L, KARA, MODE, NST, WM, WN, BT, AT, DBUF, ABL>), dim3((unsigned)n_spc * 256u, (unsigned)n_spr),
                        dim3(WM * WN * 64), lds, stream, b, n_tr, n_tc, n_spc);
     return 0;
 }
@@ -995,6 +1016,12 @@ int launch_filter(hipStream_t stream, const PairwiseArgs& a) {
         case 2: return launch_mfma_variant<1, false, 2, 3, 2, 4, 2, 4, true>(stream, a);
         case 3: return launch_mfma_variant<1, false, 2, 4, 4, 2, 2, 2, true>(stream, a);   // 256 x 128, waves 64 x 64
         case 4: return launch_mfma_variant<1, false, 2, 4, 2, 4, 2, 2, true>(stream, a);   // 128 x 256, waves 64 x 64
+        case 11: return launch_mfma_variant<1, false, 2, 4, 2, 4, 1, 2, true, 1>(stream, a);   // ablations of variant 0
+        case 12: return launch_mfma_variant<1, false, 2, 4, 2, 4, 1, 2, true, 2>(stream, a);
+        case 13: return launch_mfma_variant<1, false, 2, 4, 2, 4, 1, 2, true, 3>(stream, a);
+        case 5: return launch_mfma_variant<1, false, 2, 5, 2, 4, 1>(stream, a);            // 5-stage ring
+        case 6: return launch_mfma_variant<1, false, 2, 3, 2, 4, 1>(stream, a);            // 3-stage ring, 3 workgroups / CU
+        case 7: return launch_mfma_variant<1, false, 2, 2, 2, 4, 1>(stream, a);            // 2-stage ring, 5 workgroups / CU
         default: return launch_mfma_variant<1, false, 2, 4, 2, 4, 1>(stream, a);           // 128 x 128, waves 64 x 32
     }
 }
@@ -1002,7 +1029,17 @@ int launch_filter(hipStream_t stream, const PairwiseArgs& a) {
 int launch_exact_pairs(hipStream_t stream, const PairwiseArgs& a) {
     if (a.limbs != 2) return MVS_E_INVALID;
     // the candidate count lives on the device: a fixed grid of waves strides over the list
-    hipLaunchKernelGGL(k_exact_pairs, dim3(256 * 16), dim3(256), 0, stream, a);
+    static int v = -1;   // MVS_EXACT_VARIANT: 0 = 64 pairs per round, whole wave per pair (default; measured
+    if (v < 0) {         // 10-15 % faster on 1e5 candidates than 16 per round or a quarter wave per pair)
+        const char* e = getenv("MVS_EXACT_VARIANT");
+        v = e ? atoi(e) : 0;
+    }
+    const dim3 grid(256 * 16), block(256);
+    switch (v) {
+        case 1: hipLaunchKernelGGL((k_exact_pairs<16, 1>), grid, block, 0, stream, a); break;
+        case 2: hipLaunchKernelGGL((k_exact_pairs<16, 0>), grid, block, 0, stream, a); break;
+        default: hipLaunchKernelGGL((k_exact_pairs<64, 0>), grid, block, 0, stream, a); break;
+    }
     return 0;
 }
 

@@ -37,5 +37,5 @@ for r in range(reps):
     print("candidates %d" % ctx.pairwise_candidates(), end="  ")
     print("N=%d d=%d limbs=%d kept=%d wall %.3f ms kernel %.3f ms -> %.3g cells/s, %.1f algorithmic TFLOP/s, MFMA issue %.1f%%"
           % (n, d, sset.limbs, cnt, dt * 1e3, ms, n * n / (ms * 1e-3), 2.0 * d * n * n / (ms * 1e-3) / 1e12,
-             2.0 * d * n * n * {1: 1, 0x103: 3, 2: 4}.get(sset.limbs, 0) *
+             2.0 * d * n * n * (1 if ctx.pairwise_candidates() else {1: 1, 0x103: 3, 2: 4}.get(sset.limbs, 0)) *
              (0.5 + 64.0 / n if os.environ.get("MVS_PAIRWISE_SYMMETRIC", "1") != "0" else 1.0) / (ms * 1e-3) / 5e15 * 100))
