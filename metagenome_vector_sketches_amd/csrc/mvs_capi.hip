@@ -725,7 +725,9 @@ int prepare_coarse(mvs_ctx* c, const mvs_sketch_set* s) {
 // candidates) when the set allows it, otherwise the exact MFMA / vector-ALU kernel on every cell.
 int pairwise_launch(mvs_ctx* c, const mvs_sketch_set* s, const double* d_n2, int keep_mode, int64_t rb, int64_t re,
                     int64_t cb, int64_t ce, bool symmetric, bool mirror_all, mvs_cell* raw, int64_t capacity,
-                    unsigned long long start, double keep_coeff = 0.05) {
+                    unsigned long long start, unsigned long long* count, double keep_coeff = 0.05) {
+    // *count: the cell count if this call already had to synchronise for it, ~0 otherwise (read d_counter[0])
+    *count = ~0ULL;
     mvs::PairwiseArgs a{};
     a.planes = s->planes;
     a.n = s->n;
@@ -805,19 +807,23 @@ int pairwise_launch(mvs_ctx* c, const mvs_sketch_set* s, const double* d_n2, int
                 HIP_TRY(hipEventRecord(c->ev[3], c->stream));
                 c->ev_valid[1] = true;
             }
-            unsigned long long back[2] = {0, 0};   // candidate count, largest sum of squares >= 2^31 (or 0)
-            HIP_TRY(hipMemcpyAsync(back, c->d_counter + 2, 16, hipMemcpyDeviceToHost, c->stream));
+            // cell count, (debug slot), candidate count, largest sum of squares >= 2^31 (or 0)
+            unsigned long long back[4] = {0, 0, 0, 0};
+            HIP_TRY(hipMemcpyAsync(back, c->d_counter, 32, hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(hipStreamSynchronize(c->stream));
             if (!c->coarse_checked) {
                 c->coarse_checked = true;
-                if (back[1] != 0) {   // dots may wrap: the candidates prove nothing, the exact kernel decides
+                if (back[3] != 0) {   // dots may wrap: the candidates prove nothing, the exact kernel decides
                     c->coarse_usable = false;
                     break;
                 }
             }
-            const unsigned long long n_cand = back[0];
+            const unsigned long long n_cand = back[2];
             c->last_candidates = n_cand;
-            if (n_cand <= a.cand_capacity) return MVS_OK;
+            if (n_cand <= a.cand_capacity) {
+                *count = back[0];
+                return MVS_OK;
+            }
             if ((double)n_cand > cand_limit) {
                 c->filter_off_id = s->id;
                 c->filter_off_coeff = keep_coeff;
@@ -892,11 +898,14 @@ int mvs_pairwise_rows(mvs_ctx* c, const mvs_sketch_set* s, const double* norms_s
     // kept cells are appended (unordered) to a staging buffer and merge-sorted into the caller's
     int rc = ensure_buf(c, &c->pw_tmp, &c->pw_tmp_bytes, (size_t)std::max<int64_t>(capacity, 1) * sizeof(mvs_cell));
     if (rc) return rc;
-    rc = pairwise_launch(c, s, d_n2, keep_mode, row_begin, row_end, 0, s->n, true, false, (mvs_cell*)c->pw_tmp, capacity, 0);
-    if (rc) return rc;
     unsigned long long count = 0;
-    HIP_TRY(hipMemcpyAsync(&count, c->d_counter, 8, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    rc = pairwise_launch(c, s, d_n2, keep_mode, row_begin, row_end, 0, s->n, true, false, (mvs_cell*)c->pw_tmp, capacity, 0,
+                         &count);
+    if (rc) return rc;
+    if (count == ~0ULL) {
+        HIP_TRY(hipMemcpyAsync(&count, c->d_counter, 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
     *n_cells = (int64_t)count;
     if ((int64_t)count > capacity)
         return fail(MVS_E_CAPACITY, "%llu cells kept but capacity is %lld", count, (long long)capacity);
@@ -928,13 +937,15 @@ int mvs_pairwise_block(mvs_ctx* c, const mvs_sketch_set* s, const double* norms_
     if (row_begin == row_end || col_begin == col_end) return MVS_OK;
     if (!norms_sq || (capacity > 0 && !cells)) return fail(MVS_E_INVALID, "NULL buffer");
     HIP_TRY(hipSetDevice(c->device));
+    unsigned long long count = 0;
     int rc = pairwise_launch(c, s, norms_sq, keep_mode, row_begin, row_end, col_begin, col_end,
                              (flags & MVS_BLOCK_SYMMETRIC) != 0, (flags & MVS_BLOCK_MIRROR_ALL) != 0, cells, capacity,
-                             (unsigned long long)*n_cells);
+                             (unsigned long long)*n_cells, &count);
     if (rc) return rc;
-    unsigned long long count = 0;
-    HIP_TRY(hipMemcpyAsync(&count, c->d_counter, 8, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (count == ~0ULL) {
+        HIP_TRY(hipMemcpyAsync(&count, c->d_counter, 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
     *n_cells = (int64_t)count;
     if ((int64_t)count > capacity)
         return fail(MVS_E_CAPACITY, "%llu cells appended but capacity is %lld", count, (long long)capacity);
@@ -955,12 +966,14 @@ int mvs_search_block(mvs_ctx* c, const mvs_sketch_set* s, const double* norms_sq
     int rc = ensure_buf(c, &c->pw_tmp, &c->pw_tmp_bytes, (size_t)std::max<int64_t>(capacity, 1) * sizeof(mvs_cell));
     if (rc) return rc;
     // J > j  <=>  (P/d) / (n2r + n2c - P/d) > j  <=>  double(P)/d > j/(1+j) * (n2r + n2c)   (for n2r + n2c > P/d >= 0)
-    rc = pairwise_launch(c, s, norms_sq, MVS_KEEP_INT16, row_begin, row_end, col_begin, col_end, false, false,
-                         (mvs_cell*)c->pw_tmp, capacity, 0, jaccard_min / (1.0 + jaccard_min));
-    if (rc) return rc;
     unsigned long long count = 0;
-    HIP_TRY(hipMemcpyAsync(&count, c->d_counter, 8, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    rc = pairwise_launch(c, s, norms_sq, MVS_KEEP_INT16, row_begin, row_end, col_begin, col_end, false, false,
+                         (mvs_cell*)c->pw_tmp, capacity, 0, &count, jaccard_min / (1.0 + jaccard_min));
+    if (rc) return rc;
+    if (count == ~0ULL) {
+        HIP_TRY(hipMemcpyAsync(&count, c->d_counter, 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
     *n_cells = (int64_t)count;
     if ((int64_t)count > capacity)
         return fail(MVS_E_CAPACITY, "%llu hits but capacity is %lld", count, (long long)capacity);

@@ -150,6 +150,8 @@ __device__ __forceinline__ void wait_vmcnt() {
 //   wave to hide the fragment reads, and the 192 accumulator registers leave no room for a second buffer.
 // KARA: the L = 3 planes are (l0, l1, l0+l1) of base-128 digits; only the three "diagonal" products
 //       X = <l0,l0'>, Z = <l1,l1'>, Y = <l0+l1, l0'+l1'> are formed and P = X + 128(Y-X-Z) + 16384 Z.
+// ABL: profiling ablations of the k-loop (1 no MFMA, 2 no HBM/L2 -> LDS copies, 3 no fragment reads); the
+// second __launch_bounds__ argument is the number of waves per SIMD the register allocation leaves room for
 template <int L, bool KARA, int MODE, int NST, int WM, int WN, int BT, int AT = 2, bool DBUF = (BT == 1), int ABL = 0>
 __global__ __launch_bounds__(WM * WN * 64, (AT * BT > 2 ? 1 : 2)) void k_pairwise_mfma(const PairwiseArgs a, int n_tr,
                                                                                       int n_tc, int n_spc) {
@@ -1006,22 +1008,23 @@ int launch_filter_meta(hipStream_t stream, const CoarseRow* d_rows, const double
 
 int launch_filter(hipStream_t stream, const PairwiseArgs& a) {
     if (a.limbs != 2 || a.d_pad > 32768) return MVS_E_INVALID;
-    static int v = -1;   // MVS_FILTER_VARIANT: tile shape of the one-pass filter
+    // MVS_FILTER_VARIANT: tile shape / ring depth of the one-pass filter.  On 100k x 2048 every shape lands within
+    // 5 % of the default (k-loop 12.5 ms, of which 5 ms matrix-core time): ablations 11-13 show the copies, the
+    // fragment reads and the MFMAs of one workgroup hardly overlap (its waves move in lock step from barrier to
+    // barrier), only different workgroups of a CU overlap.
+    static int v = -1;
     if (v < 0) {
         const char* e = getenv("MVS_FILTER_VARIANT");
         v = e ? atoi(e) : 0;
     }
     switch (v) {
         case 1: return launch_mfma_variant<1, false, 2, 4, 2, 4, 2, 4, true>(stream, a);   // 256 x 256, waves 128 x 64
-        case 2: return launch_mfma_variant<1, false, 2, 3, 2, 4, 2, 4, true>(stream, a);
         case 3: return launch_mfma_variant<1, false, 2, 4, 4, 2, 2, 2, true>(stream, a);   // 256 x 128, waves 64 x 64
-        case 4: return launch_mfma_variant<1, false, 2, 4, 2, 4, 2, 2, true>(stream, a);   // 128 x 256, waves 64 x 64
         case 11: return launch_mfma_variant<1, false, 2, 4, 2, 4, 1, 2, true, 1>(stream, a);   // ablations of variant 0
         case 12: return launch_mfma_variant<1, false, 2, 4, 2, 4, 1, 2, true, 2>(stream, a);
         case 13: return launch_mfma_variant<1, false, 2, 4, 2, 4, 1, 2, true, 3>(stream, a);
         case 5: return launch_mfma_variant<1, false, 2, 5, 2, 4, 1>(stream, a);            // 5-stage ring
         case 6: return launch_mfma_variant<1, false, 2, 3, 2, 4, 1>(stream, a);            // 3-stage ring, 3 workgroups / CU
-        case 7: return launch_mfma_variant<1, false, 2, 2, 2, 4, 1>(stream, a);            // 2-stage ring, 5 workgroups / CU
         default: return launch_mfma_variant<1, false, 2, 4, 2, 4, 1>(stream, a);           // 128 x 128, waves 64 x 32
     }
 }

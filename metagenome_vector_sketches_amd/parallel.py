@@ -61,8 +61,12 @@ class GpuOps:
     """numeric back end on one MI355X: everything is a call into libmvs_hip.so"""
 
     def __init__(self, ctx, device):
+        import torch
         self.ctx, self.device = ctx, device
         self.k2_ms = 0.0
+        # buffers here are torch tensors (zero fills, copies and slices run on torch's stream): the library
+        # must issue its kernels on that same stream or nothing orders them against each other
+        ctx.set_stream(torch.cuda.current_stream(torch.device(device)))
 
     def new_cells(self, capacity):
         import torch

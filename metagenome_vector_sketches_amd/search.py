@@ -77,6 +77,8 @@ def search_index(index_folder, query_file, j, ctx=None, verbose=True):
         offs[1:] = np.cumsum([len(x) for x in lists])
         flat = np.concatenate(lists) if offs[-1] else np.zeros(0, dtype=np.uint64)
         dev = torch.device("cuda", ctx.device)
+        if own:
+            ctx.set_stream(torch.cuda.current_stream(dev))          # one stream for torch's copies and the kernels
         q_sk = torch.empty((nq, d), dtype=torch.int32, device=dev)
         q_ss = torch.empty(nq, dtype=torch.int64, device=dev)
         q_max = ctx.project_csr_stats(flat, offs, d, q_sk, q_ss)

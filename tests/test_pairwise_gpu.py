@@ -194,11 +194,14 @@ def test_sharded_comparison_single_rank(ctx, pw_filter):
     from metagenome_vector_sketches_amd import parallel
     sk = synth.make_sketches_numpy(300, 2048, 3000, seed=4, cluster=8)
     n2 = _n2_from_sketches(sk)
-    sc = parallel.ShardedComparison(parallel.GpuOps(ctx, "cuda:0"), 0, 1, None)
-    cells_dev = torch.empty((1 << 16, 4), dtype=torch.int32, device="cuda:0")
-    _, cnt, info = sc.run(torch.from_numpy(sk).to("cuda:0"), n2, 300, cells_out=cells_dev)
-    ctx.synchronize()
-    got = [tuple(int(x) for x in row) for row in cells_dev[:cnt].cpu().numpy()]
+    sc = parallel.ShardedComparison(parallel.GpuOps(ctx, "cuda:0"), 0, 1, None)   # binds ctx to torch's stream
+    try:
+        cells_dev = torch.empty((1 << 16, 4), dtype=torch.int32, device="cuda:0")
+        _, cnt, info = sc.run(torch.from_numpy(sk).to("cuda:0"), n2, 300, cells_out=cells_dev)
+        ctx.synchronize()
+        got = [tuple(int(x) for x in row) for row in cells_dev[:cnt].cpu().numpy()]
+    finally:
+        ctx.set_stream(None)
     assert got == _oracle_sorted(sk, n2, chunk=192) and info["limbs"] in (2, K3)
 
 
