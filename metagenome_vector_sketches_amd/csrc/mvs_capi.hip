@@ -776,7 +776,10 @@ int pairwise_launch(mvs_ctx* c, const mvs_sketch_set* s, const double* d_n2, int
                                 (float4*)c->pw_fmeta);
         rc = check_kernel("k_filter_meta");
         if (rc) return rc;
-        rc = ensure_buf(c, &c->pw_cand, &c->pw_cand_bytes, (size_t)std::max<int64_t>(1 << 20, capacity) * sizeof(int2));
+        // candidate list: room for every kept cell plus the ~2e-4 of the block the filter lets through on
+        // typical sketches (regrown below if that is not enough)
+        const int64_t cand_want = std::max<int64_t>(std::max<int64_t>(1 << 20, capacity), (int64_t)(block_cells / 4096.0));
+        rc = ensure_buf(c, &c->pw_cand, &c->pw_cand_bytes, (size_t)cand_want * sizeof(int2));
         if (rc) return rc;
         a.coarse = (const int8_t*)c->pw_coarse;
         a.fmeta = (const float4*)c->pw_fmeta;
