@@ -761,7 +761,7 @@ int pairwise_launch(mvs_ctx* c, const mvs_sketch_set* s, const double* d_n2, int
     };
     int rc = MVS_OK;
     const double block_cells = (double)(re - rb) * (double)(ce - cb);
-    bool two_stage = filter_mode() != 0 && s->limbs == 2 && s->d_pad <= 32768 && a.debug_flags == 0 &&
+    bool two_stage = filter_mode() != 0 && s->limbs == 2 && s->d_pad <= 32768 &&
                      (filter_mode() == 2 || block_cells >= 4194304.0) &&
                      !(c->filter_off_id == s->id && c->filter_off_coeff == keep_coeff);
     if (two_stage) {

@@ -23,6 +23,7 @@
 #include "mvs_internal.h"
 
 #include <cstring>
+#include <type_traits>
 
 #include <rocprim/device/device_merge_sort.hpp>
 
@@ -345,40 +346,83 @@ __global__ __launch_bounds__(WM * WN * 64, (AT * BT > 2 ? 1 : 2)) void k_pairwis
     }
     if constexpr (MODE == 2) {
         // filter: a pair can only be kept if  <c_i,c_j>  >  s_i w_j + s_j w_i - a_i p_j - p_i (a_j + p_j)
-        // (derivation at k_filter_meta); everything else is dropped without ever forming the exact dot
+        // (derivation at k_filter_meta); everything else is dropped without ever forming the exact dot.
+        // The test is evaluated for two rows at a time (packed fp32 FMAs); rows come in adjacent pairs in the
+        // accumulator layout, so the row constants sit in LDS as {s0 s1 w0 w1 | a0 a1 p0 p1} per row pair.
+        // Rows / columns outside the call's ranges get s = +inf there and never pass.
         static_assert(L == 1 && !KARA, "the filter runs on the single coarse plane");
-        float4* fm = reinterpret_cast<float4*>(smem);   // [0,TM): rows, [TM,TM+TN): cols
-        for (int x = tid; x < TM + TN; x += kWavesT * 64) fm[x] = a.fmeta[(x < TM ? i0 : j0 - TM) + x];
-        __syncthreads();
-#pragma unroll
-        for (int u = 0; u < BT; ++u) {
-            const int col_l = (wn * BT + u) * 32 + fr;
-            const int64_t col = j0 + col_l;
-            const float4 mj = fm[TM + col_l];
-            const float bj = mj.z + mj.w;
-            const bool col_ok = col < a.col_end;
-            // symmetric schedule: inside the square of the row range only the upper triangle is re-checked and
-            // its cells are mirrored (the exact kernel computes whole diagonal tiles instead, the filter would
-            // hand both (i,j) and (j,i) to the re-check)
-            const bool in_square = a.symmetric && col >= a.row_begin && col < a.row_end;
-#pragma unroll
-            for (int t = 0; t < AT; ++t) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row_l = wm * AT * 32 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-                    const int64_t row = i0 + row_l;
-                    const float4 mi = fm[row_l];
-                    float rhs = mi.x * mj.y;
-                    rhs = fmaf(mj.x, mi.y, rhs);
-                    rhs = fmaf(-mi.z, mj.w, rhs);
-                    rhs = fmaf(-mi.w, bj, rhs);
-                    bool cand = (float)acc[t][u][0][r] > rhs && col_ok && row < a.row_end;
-                    if (ABL >= 2) cand = cand && acc[t][u][0][r] == 0x7fffffff;   // ablations compute garbage
-                    if (in_square) cand = cand && col >= row;
-                    emit_cand(a, cand, a.mirror_all || (in_square && col > row), (int32_t)row, (int32_t)col, lane);
-                }
+        using v2f = __attribute__((ext_vector_type(2))) float;
+        using v4f = __attribute__((ext_vector_type(4))) float;
+        float* frow = reinterpret_cast<float*>(smem);                      // TM/2 pairs x 8 floats
+        float4* fcol = reinterpret_cast<float4*>(smem + TM * 16);          // TN entries
+        for (int x = tid; x < TM + TN; x += kWavesT * 64) {
+            const int64_t g = (x < TM ? i0 : j0 - TM) + x;
+            float4 m = a.fmeta[g];
+            if (g >= (x < TM ? a.row_end : a.col_end)) m = make_float4(__builtin_inff(), 0.0f, 0.0f, 0.0f);
+            if (x < TM) {
+                float* q = frow + (x >> 1) * 8 + (x & 1);
+                q[0] = m.x;
+                q[2] = m.y;
+                q[4] = m.z;
+                q[6] = m.w;
+            } else {
+                fcol[x - TM] = m;
             }
         }
+        __syncthreads();
+        // symmetric schedule: inside the square of the row range only the upper triangle is re-checked and its
+        // cells are mirrored (the exact kernel computes whole diagonal tiles instead; the filter would hand
+        // both (i,j) and (j,i) to the re-check).  Only tiles that touch the diagonal need the per-cell test.
+        const bool straddle = a.symmetric && j0 < i0 + TM && j0 + TN > i0;
+        const int delta = (int)(j0 - i0);                                  // col - row = col_l - row_l + delta
+        auto sweep = [&](auto tri) {   // tri: the tile touches the diagonal of the symmetric square
+            constexpr bool TRI = decltype(tri)::value;
+#pragma unroll
+            for (int u = 0; u < BT; ++u) {
+                const int col_l = (wn * BT + u) * 32 + fr;
+                const int64_t col = j0 + col_l;
+                const float4 mj = fcol[col_l];
+                const float bj = mj.z + mj.w;
+                const v2f wj = {mj.y, mj.y}, sj = {mj.x, mj.x}, npj = {-mj.w, -mj.w}, nbj = {-bj, -bj};
+                const bool in_square = a.symmetric && col >= a.row_begin && col < a.row_end;
+                const int cd = col_l + delta;
+                // rows above this one fail the triangle test: col >= row  <=>  row_l <= cd (columns outside the
+                // square are not restricted)
+                const int row_max = (TRI && in_square) ? cd : 0x7fffffff;
+#pragma unroll
+                for (int t = 0; t < AT; ++t) {
+                    const int row_b = wm * AT * 32 + t * 32 + 4 * fh;
+                    unsigned m16 = 0;
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        const int row_l = row_b + (r & 3) + 8 * (r >> 2);      // even: rows row_l, row_l + 1
+                        const v4f q0 = *reinterpret_cast<const v4f*>(frow + (row_l >> 1) * 8);
+                        const v4f q1 = *reinterpret_cast<const v4f*>(frow + (row_l >> 1) * 8 + 4);
+                        v2f rhs = v2f{q0[0], q0[1]} * wj;
+                        rhs = __builtin_elementwise_fma(v2f{q0[2], q0[3]}, sj, rhs);
+                        rhs = __builtin_elementwise_fma(v2f{q1[0], q1[1]}, npj, rhs);
+                        rhs = __builtin_elementwise_fma(v2f{q1[2], q1[3]}, nbj, rhs);
+                        bool c0 = (float)acc[t][u][0][r] > rhs[0];
+                        bool c1 = (float)acc[t][u][0][r + 1] > rhs[1];
+                        if (TRI) {
+                            c0 = c0 && row_l <= row_max;
+                            c1 = c1 && row_l < row_max;
+                        }
+                        m16 |= (c0 ? 1u << r : 0u) | (c1 ? 2u << r : 0u);
+                    }
+                    if (ABL >= 2 && acc[t][u][0][0] != 0x7fffffff) m16 = 0;   // ablations compute garbage
+                    if (__ballot(m16 != 0) == 0ULL) continue;                  // the common case: nothing passes
+#pragma unroll 1
+                    for (int r = 0; r < 16; ++r) {
+                        const int row_l = row_b + (r & 3) + 8 * (r >> 2);
+                        emit_cand(a, (m16 >> r) & 1u, a.mirror_all || (in_square && cd > row_l), (int32_t)(i0 + row_l),
+                                  (int32_t)col, lane);
+                    }
+                }
+            }
+        };
+        if (straddle) sweep(std::true_type{});
+        else sweep(std::false_type{});
         return;
     }
     int32_t* thr = reinterpret_cast<int32_t*>(smem);   // [0,TM): rows, [TM,TM+TN): cols
@@ -1012,10 +1056,18 @@ int launch_filter(hipStream_t stream, const PairwiseArgs& a) {
     // 5 % of the default (k-loop 12.5 ms, of which 5 ms matrix-core time): ablations 11-13 show the copies, the
     // fragment reads and the MFMAs of one workgroup hardly overlap (its waves move in lock step from barrier to
     // barrier), only different workgroups of a CU overlap.
-    static int v = -1;
-    if (v < 0) {
+    // Default: 256 x 256 tiles (half the L2 -> LDS bytes per cell; 11 % faster at 100k samples) once the block
+    // holds enough of them to keep 256 CUs busy through the tail, 128 x 128 tiles below that.
+    static int forced = -2;
+    if (forced == -2) {
         const char* e = getenv("MVS_FILTER_VARIANT");
-        v = e ? atoi(e) : 0;
+        forced = e ? atoi(e) : -1;
+    }
+    int v = forced;
+    if (v < 0) {
+        const double tiles = (double)(a.row_end - a.row_begin) * (double)(a.col_end - a.col_begin) / 65536.0 *
+                             (a.symmetric ? 0.5 : 1.0);
+        v = tiles >= 4096.0 ? 1 : 0;
     }
     switch (v) {
         case 1: return launch_mfma_variant<1, false, 2, 4, 2, 4, 2, 4, true>(stream, a);   // 256 x 256, waves 128 x 64
@@ -1023,6 +1075,9 @@ int launch_filter(hipStream_t stream, const PairwiseArgs& a) {
         case 11: return launch_mfma_variant<1, false, 2, 4, 2, 4, 1, 2, true, 1>(stream, a);   // ablations of variant 0
         case 12: return launch_mfma_variant<1, false, 2, 4, 2, 4, 1, 2, true, 2>(stream, a);
         case 13: return launch_mfma_variant<1, false, 2, 4, 2, 4, 1, 2, true, 3>(stream, a);
+        case 21: return launch_mfma_variant<1, false, 2, 4, 2, 4, 2, 4, true, 1>(stream, a);   // ablations of variant 1
+        case 22: return launch_mfma_variant<1, false, 2, 4, 2, 4, 2, 4, true, 2>(stream, a);
+        case 23: return launch_mfma_variant<1, false, 2, 4, 2, 4, 2, 4, true, 3>(stream, a);
         case 5: return launch_mfma_variant<1, false, 2, 5, 2, 4, 1>(stream, a);            // 5-stage ring
         case 6: return launch_mfma_variant<1, false, 2, 3, 2, 4, 1>(stream, a);            // 3-stage ring, 3 workgroups / CU
         default: return launch_mfma_variant<1, false, 2, 4, 2, 4, 1>(stream, a);           // 128 x 128, waves 64 x 32
