@@ -50,9 +50,12 @@ def _worker(rank, world, port, n, d, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n,world", [(700, 2), (650, 3)])
-def test_ranks_on_one_gpu_match_oracle(tmp_path, n, world):
-    d, port = 512, 29800 + (os.getpid() + n) % 1000
+@pytest.mark.parametrize("n,world,two_stage", [(700, 2, False), (650, 3, False), (700, 2, True), (650, 3, True)])
+def test_ranks_on_one_gpu_match_oracle(tmp_path, monkeypatch, n, world, two_stage):
+    # two_stage: force the coarse filter + exact re-check on these small blocks (symmetric, mirror-all and
+    # plain block calls all go through it); the spawned ranks inherit the environment
+    monkeypatch.setenv("MVS_PAIRWISE_FILTER", "2" if two_stage else "0")
+    d, port = 512, 29800 + (os.getpid() + n + 7 * two_stage) % 1000
     mp.spawn(_worker, args=(world, port, n, d, str(tmp_path)), nprocs=world, join=True)
     from oracle import pyoracle as orc
     sk, n2 = _make(n, d)
