@@ -370,3 +370,33 @@ def test_two_stage_wrap_guard(ctx, monkeypatch):
     assert ctx.pairwise_candidates() == 0
     assert _cells_tuple(cells) == _oracle_sorted(sk, n2, chunk=192)
     ss.close()
+
+
+def test_two_stage_gives_way_when_everything_is_a_candidate(ctx, monkeypatch):
+    """all rows equal: every pair is kept, the candidate list overflows its first size and holds more than
+    1/128 of the block -> the exact kernel takes over (and stays in charge for this set)"""
+    import torch
+    n, d = 3000, 256
+    row = np.random.default_rng(3).integers(-900, 900, d).astype(np.int32)
+    sk = np.tile(row, (n, 1))
+    n2 = _n2_from_sketches(sk[:1]).repeat(n)
+    monkeypatch.setenv("MVS_PAIRWISE_FILTER", "2")
+    ss = ctx.sketch_set(sk)
+    with pytest.raises(_capi.MvsError) as ei:
+        ctx.pairwise_rows(ss, n2, capacity=1 << 20)
+    assert ei.value.code == _capi.MVS_E_CAPACITY and str(n * n) in str(ei.value)
+    cells = torch.empty((n * n, 4), dtype=torch.int32, device="cuda")
+    _, cnt = ctx.pairwise_rows(ss, torch.from_numpy(n2).to("cuda"), cells_out=cells)
+    ctx.synchronize()
+    assert cnt == n * n and ctx.pairwise_candidates() == 0
+    got = cells.cpu().numpy()
+    assert np.array_equal(got[:, 0], np.repeat(np.arange(n), n)) and np.array_equal(got[:, 1], np.tile(np.arange(n), n))
+    assert (got[:, 2] == int((row.astype(np.int64) ** 2).sum())).all() and (got[:, 3] == 255).all()
+    ss.close()
+    # another set goes through the filter again
+    sk2 = synth.make_sketches_numpy(300, 2048, 3000, seed=8, cluster=8)
+    n22 = _n2_from_sketches(sk2)
+    ss2 = ctx.sketch_set(sk2)
+    c2, _ = ctx.pairwise_rows(ss2, n22)
+    assert ctx.pairwise_candidates() > 0 and _cells_tuple(c2) == _oracle_sorted(sk2, n22, chunk=192)
+    ss2.close()
