@@ -156,7 +156,8 @@ int mvs_limb_split(mvs_ctx* ctx, const void* sketches, int elem_bytes, int mem, 
  * mvs_sketch_set_create : allocates the planes, re-codes `sketches` (chooses the limb count itself).
  * mvs_sketch_set_from_planes : NON-owning view of a caller-owned device buffer filled by
  *   mvs_limb_split (and, across GPUs, by an all-gather of per-rank row blocks); the buffer must
- *   outlive the set. */
+ *   outlive the set and keep its contents while the set is compared (the library caches data derived
+ *   from the planes per set: make a new view after rewriting the buffer). */
 int mvs_sketch_set_create(mvs_ctx* ctx, const void* sketches, int elem_bytes, int mem, int64_t n, int d,
                           mvs_sketch_set** set);
 int mvs_sketch_set_from_planes(mvs_ctx* ctx, const int8_t* planes, int64_t n, int64_t n_alloc, int d,
