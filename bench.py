@@ -59,8 +59,9 @@ def fast_norm_sq(sumsq, d):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10,
+                    help="untimed steps; the clocks need ~10 steps (0.1 s) to settle after the set-up phase")
     ap.add_argument("--samples", type=int, default=10_000, help="samples per GPU")
     ap.add_argument("--hashes", type=int, default=50_000, help="hashes per sample")
     ap.add_argument("--dim", type=int, default=2048)
