@@ -288,7 +288,8 @@ int mvs_project_csr_stats(mvs_ctx* c, const uint64_t* hashes, int mem_hashes, co
         const int64_t b = offsets[s], e = offsets[s + 1];
         if (e < b) return fail(MVS_E_INVALID, "offsets not monotone at sample %lld", (long long)s);
         if (e - b >= (1LL << 31)) return fail(MVS_E_RANGE, "sample %lld has >= 2^31 hashes", (long long)s);
-        n_units += (size_t)((e - b + mvs::kProjUnitMax - 1) / mvs::kProjUnitMax);
+        // an empty sample gets one unit of zero hashes: the kernel then stores its row of zeros itself
+        n_units += e == b ? 1 : (size_t)((e - b + mvs::kProjUnitMax - 1) / mvs::kProjUnitMax);
         all_single = all_single && (e - b) <= mvs::kProjUnitMax;
     }
     int rc = acquire_pinned(c, std::max<size_t>(n_units * sizeof(mvs::ProjUnit), 256));
@@ -299,6 +300,7 @@ int mvs_project_csr_stats(mvs_ctx* c, const uint64_t* hashes, int mem_hashes, co
         for (int64_t s = 0; s < n_samples; ++s) {
             const int64_t b = offsets[s], e = offsets[s + 1];
             const bool single = (e - b) <= mvs::kProjUnitMax;
+            if (e == b) units[w++] = mvs::ProjUnit{b, 0, (int32_t)s, 1, 0};
             for (int64_t p = b; p < e; p += mvs::kProjUnitMax) {
                 mvs::ProjUnit u;
                 u.begin = p;
@@ -335,7 +337,8 @@ int mvs_project_csr_stats(mvs_ctx* c, const uint64_t* hashes, int mem_hashes, co
         c->pinned_busy = true;
     }
 
-    HIP_TRY(hipMemsetAsync(d_out, 0, out_bytes, c->stream));   // empty samples, atomically combined units
+    // samples cut into several units are combined with atomics and start from zero; single units store
+    if (!all_single) HIP_TRY(hipMemsetAsync(d_out, 0, out_bytes, c->stream));
     const bool fused = sumsq != nullptr && all_single;         // statistics inside the projection kernel
     if (fused) {
         HIP_TRY(hipMemsetAsync(sumsq, 0, (size_t)n_samples * 8, c->stream));
