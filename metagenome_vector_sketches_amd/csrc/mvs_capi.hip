@@ -27,6 +27,7 @@ struct mvs_ctx {
     void* pw_thr = nullptr;   size_t pw_thr_bytes = 0;
     void* pw_tmp = nullptr;   size_t pw_tmp_bytes = 0;
     void* pw_sort = nullptr;  size_t pw_sort_bytes = 0;
+    void* pw_out = nullptr;   size_t pw_out_bytes = 0;
     // two-stage comparison: coarse plane + row statistics of the set `coarse_id` (generation `coarse_gen`),
     // per-call filter constants, candidate list
     void* pw_coarse = nullptr;  size_t pw_coarse_bytes = 0;
@@ -207,6 +208,7 @@ int mvs_ctx_destroy(mvs_ctx* c) {
     if (c->pw_thr) (void)hipFree(c->pw_thr);
     if (c->pw_tmp) (void)hipFree(c->pw_tmp);
     if (c->pw_sort) (void)hipFree(c->pw_sort);
+    if (c->pw_out) (void)hipFree(c->pw_out);
     if (c->pw_coarse) (void)hipFree(c->pw_coarse);
     if (c->pw_rows) (void)hipFree(c->pw_rows);
     if (c->pw_fmeta) (void)hipFree(c->pw_fmeta);
@@ -889,7 +891,7 @@ int mvs_pairwise_rows(mvs_ctx* c, const mvs_sketch_set* s, const double* norms_s
     if (capacity > 0 && !cells) return fail(MVS_E_INVALID, "cells is NULL");
     HIP_TRY(hipSetDevice(c->device));
 
-    DevBuf dn, dcells;
+    DevBuf dn;
     const double* d_n2 = norms_sq;
     if (mem_norms == MVS_MEM_HOST) {
         HIP_TRY(dn.alloc((size_t)s->n * 8));
@@ -897,9 +899,10 @@ int mvs_pairwise_rows(mvs_ctx* c, const mvs_sketch_set* s, const double* norms_s
         d_n2 = (const double*)dn.p;
     }
     mvs_cell* d_cells = cells;
-    if (mem_cells == MVS_MEM_HOST) {
-        HIP_TRY(dcells.alloc((size_t)capacity * sizeof(mvs_cell)));
-        d_cells = (mvs_cell*)dcells.p;
+    if (mem_cells == MVS_MEM_HOST) {   // sorted cells are staged in a grow-only device buffer of the context
+        int rc0 = ensure_buf(c, &c->pw_out, &c->pw_out_bytes, (size_t)std::max<int64_t>(capacity, 1) * sizeof(mvs_cell));
+        if (rc0) return rc0;
+        d_cells = (mvs_cell*)c->pw_out;
     }
     // kept cells are appended (unordered) to a staging buffer and merge-sorted into the caller's
     int rc = ensure_buf(c, &c->pw_tmp, &c->pw_tmp_bytes, (size_t)std::max<int64_t>(capacity, 1) * sizeof(mvs_cell));
