@@ -108,21 +108,6 @@ __device__ __forceinline__ void emit_cell(const PairwiseArgs& a, bool keep, bool
     }
 }
 
-// Append the candidate pairs of one wave to the candidate list (one atomic per wave).
-__device__ __forceinline__ void emit_cand(const PairwiseArgs& a, bool cand, bool mirror, int32_t row, int32_t col,
-                                          int lane) {
-    const unsigned long long mask = __ballot(cand);
-    if (mask == 0ULL) return;
-    unsigned long long base = 0;
-    const int leader = __ffsll((long long)mask) - 1;
-    if (lane == leader) base = atomicAdd(a.cand_counter, (unsigned long long)__popcll(mask));
-    base = __shfl(base, leader, 64);
-    if (cand) {
-        const unsigned long long slot = base + (unsigned long long)__popcll(mask & ((1ULL << lane) - 1ULL));
-        if (slot < a.cand_capacity) a.cand[slot] = make_int2(row, mirror ? (int)((unsigned)col | 0x80000000u) : col);
-    }
-}
-
 // ---------------------------------------------------------------------------------------------------
 // MFMA kernel.  L = limbs (1 or 2).  MODE 0: comparison, 1: dense dots, 2: filter on the coarse plane.
 // NST = LDS ring depth.
@@ -375,6 +360,12 @@ __global__ __launch_bounds__(WM * WN * 64, (AT * BT > 2 ? 1 : 2)) void k_pairwis
         // both (i,j) and (j,i) to the re-check).  Only tiles that touch the diagonal need the per-cell test.
         const bool straddle = a.symmetric && j0 < i0 + TM && j0 + TN > i0;
         const int delta = (int)(j0 - i0);                                  // col - row = col_l - row_l + delta
+        // Pass 1 (sweep): one 16-bit mask of passing rows per lane and 32 x 32 block.  Pass 2: ONE atomic per wave
+        // reserves room for all of the wave's candidates (a counter bumped once per block of a dense region
+        // serialises at the L2: 5e6 bumps cost 35 ms), a wave-level prefix sum gives every lane its range.
+        // (the masks wait in LDS, which is idle by now, rather than in registers next to the accumulators)
+        unsigned* masks = reinterpret_cast<unsigned*>(smem + (TM + TN) * 16) + wave * (BT * AT * 64) + lane;
+        unsigned mine = 0;
         auto sweep = [&](auto tri) {   // tri: the tile touches the diagonal of the symmetric square
             constexpr bool TRI = decltype(tri)::value;
 #pragma unroll
@@ -385,10 +376,9 @@ __global__ __launch_bounds__(WM * WN * 64, (AT * BT > 2 ? 1 : 2)) void k_pairwis
                 const float bj = mj.z + mj.w;
                 const v2f wj = {mj.y, mj.y}, sj = {mj.x, mj.x}, npj = {-mj.w, -mj.w}, nbj = {-bj, -bj};
                 const bool in_square = a.symmetric && col >= a.row_begin && col < a.row_end;
-                const int cd = col_l + delta;
-                // rows above this one fail the triangle test: col >= row  <=>  row_l <= cd (columns outside the
-                // square are not restricted)
-                const int row_max = (TRI && in_square) ? cd : 0x7fffffff;
+                // rows above this one fail the triangle test: col >= row  <=>  row_l <= col_l + delta (columns
+                // outside the square are not restricted)
+                const int row_max = (TRI && in_square) ? col_l + delta : 0x7fffffff;
 #pragma unroll
                 for (int t = 0; t < AT; ++t) {
                     const int row_b = wm * AT * 32 + t * 32 + 4 * fh;
@@ -411,18 +401,45 @@ __global__ __launch_bounds__(WM * WN * 64, (AT * BT > 2 ? 1 : 2)) void k_pairwis
                         m16 |= (c0 ? 1u << r : 0u) | (c1 ? 2u << r : 0u);
                     }
                     if (ABL >= 2 && acc[t][u][0][0] != 0x7fffffff) m16 = 0;   // ablations compute garbage
-                    if (__ballot(m16 != 0) == 0ULL) continue;                  // the common case: nothing passes
-#pragma unroll 1
-                    for (int r = 0; r < 16; ++r) {
-                        const int row_l = row_b + (r & 3) + 8 * (r >> 2);
-                        emit_cand(a, (m16 >> r) & 1u, a.mirror_all || (in_square && cd > row_l), (int32_t)(i0 + row_l),
-                                  (int32_t)col, lane);
-                    }
+                    masks[(u * AT + t) * 64] = m16;
+                    mine += (unsigned)__popc(m16);
                 }
             }
         };
         if (straddle) sweep(std::true_type{});
         else sweep(std::false_type{});
+        if (__ballot(mine != 0) == 0ULL) return;               // the common case: nothing in this wave passes
+        unsigned incl = mine;                                   // inclusive prefix sum over the lanes
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned up = (unsigned)__shfl_up((int)incl, o, 64);
+            if (lane >= o) incl += up;
+        }
+        unsigned long long base = 0;
+        if (lane == 63) base = atomicAdd(a.cand_counter, (unsigned long long)incl);
+        base = __shfl(base, 63, 64);
+        unsigned long long slot = base + (incl - mine);
+#pragma unroll
+        for (int u = 0; u < BT; ++u) {
+            const int col_l = (wn * BT + u) * 32 + fr;
+            const int64_t col = j0 + col_l;
+            const bool in_square = a.symmetric && col >= a.row_begin && col < a.row_end;
+            const int cd = col_l + delta;
+#pragma unroll
+            for (int t = 0; t < AT; ++t) {
+                const int row_b = wm * AT * 32 + t * 32 + 4 * fh;
+                unsigned m = masks[(u * AT + t) * 64];            // this lane's own word: no barrier needed
+                while (m) {
+                    const int r = __ffs((int)m) - 1;
+                    m &= m - 1;
+                    const int row_l = row_b + (r & 3) + 8 * (r >> 2);
+                    const bool mirror = a.mirror_all || (in_square && cd > row_l);
+                    if (slot < a.cand_capacity)
+                        a.cand[slot] = make_int2((int32_t)(i0 + row_l), mirror ? (int)((unsigned)col | 0x80000000u) : (int)col);
+                    ++slot;
+                }
+            }
+        }
         return;
     }
     int32_t* thr = reinterpret_cast<int32_t*>(smem);   // [0,TM): rows, [TM,TM+TN): cols
