@@ -181,10 +181,10 @@ int mvs_sketch_set_destroy(mvs_sketch_set* set);
  *              and *n_cells is the number needed (retry with a larger buffer or fewer rows).
  * Synchronous (returns after the count is known).
  * How the cells are found is the library's business and never changes the result: sets of two base-256
- * limbs whose rows' sums of squares stay below 2^31 are compared in two stages -- a one-pass int8 filter on
- * a coarse plane with a proven error bound drops the pairs that cannot pass the keep test, the exact int32
- * dot and the reference's keep test run on the survivors -- everything else goes through the exact kernel
- * cell by cell (environment MVS_PAIRWISE_FILTER=0 forces that, =2 forces the two stages on small blocks
+ * limbs are compared in two stages -- a one-pass int8 filter on a coarse plane with a proven error bound
+ * drops the pairs that cannot pass the keep test, the exact int32 dot and the reference's keep test run on
+ * the survivors (rows whose sum of squares reaches 2^31, whose dots may wrap, are re-checked against every
+ * column) -- everything else goes through the exact kernel cell by cell (environment MVS_PAIRWISE_FILTER=0 forces that, =2 forces the two stages on small blocks
  * too; mvs_ctx_pairwise_candidates reports which one ran). */
 int mvs_pairwise_rows(mvs_ctx* ctx, const mvs_sketch_set* set, const double* norms_sq, int mem_norms,
                       int keep_mode, int64_t row_begin, int64_t row_end, mvs_cell* cells,

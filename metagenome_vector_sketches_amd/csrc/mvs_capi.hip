@@ -35,8 +35,6 @@ struct mvs_ctx {
     void* pw_fmeta = nullptr;   size_t pw_fmeta_bytes = 0;
     void* pw_cand = nullptr;    size_t pw_cand_bytes = 0;
     unsigned long long coarse_id = 0, coarse_gen = 0;
-    bool coarse_usable = false;          // no row's sum of squares reaches 2^31: exact dots cannot wrap
-    bool coarse_checked = false;         // coarse_usable has been confirmed from the device flag
     unsigned long long filter_off_id = 0;   // (set, coefficient) for which the filter passed too many pairs
     double filter_off_coeff = 0.0;
     unsigned long long last_candidates = 0; // candidate pairs of the last two-stage comparison (0: exact kernel)
@@ -711,15 +709,10 @@ int prepare_coarse(mvs_ctx* c, const mvs_sketch_set* s) {
     if (rc) return rc;
     rc = ensure_buf(c, &c->pw_rows, &c->pw_rows_bytes, (size_t)s->n_alloc * sizeof(mvs::CoarseRow));
     if (rc) return rc;
-    HIP_TRY(hipMemsetAsync(c->d_counter + 3, 0, 8, c->stream));
     mvs::launch_coarse_build(c->stream, s->planes, s->n, s->n_alloc, s->d_pad, (int8_t*)c->pw_coarse,
-                             (mvs::CoarseRow*)c->pw_rows, c->d_counter + 3);
+                             (mvs::CoarseRow*)c->pw_rows);
     rc = check_kernel("k_coarse_build");
     if (rc) return rc;
-    // whether a row's sum of squares reaches 2^31 (then dots may wrap and the filter's bound does not hold)
-    // is read back together with the first candidate count: no extra synchronisation here
-    c->coarse_usable = true;
-    c->coarse_checked = false;
     c->coarse_id = s->id;
     c->coarse_gen = s->gen;
     return MVS_OK;
@@ -772,9 +765,6 @@ int pairwise_launch(mvs_ctx* c, const mvs_sketch_set* s, const double* d_n2, int
     if (two_stage) {
         rc = prepare_coarse(c, s);
         if (rc) return rc;
-        two_stage = c->coarse_usable;
-    }
-    if (two_stage) {
         rc = ensure_buf(c, &c->pw_fmeta, &c->pw_fmeta_bytes, (size_t)s->n_alloc * sizeof(float4));
         if (rc) return rc;
         mvs::launch_filter_meta(c->stream, (const mvs::CoarseRow*)c->pw_rows, d_n2, s->n, s->n_alloc, s->d, keep_coeff,
@@ -815,17 +805,9 @@ int pairwise_launch(mvs_ctx* c, const mvs_sketch_set* s, const double* d_n2, int
                 HIP_TRY(hipEventRecord(c->ev[3], c->stream));
                 c->ev_valid[1] = true;
             }
-            // cell count, (debug slot), candidate count, largest sum of squares >= 2^31 (or 0)
-            unsigned long long back[4] = {0, 0, 0, 0};
-            HIP_TRY(hipMemcpyAsync(back, c->d_counter, 32, hipMemcpyDeviceToHost, c->stream));
+            unsigned long long back[3] = {0, 0, 0};   // cell count, (debug slot), candidate count
+            HIP_TRY(hipMemcpyAsync(back, c->d_counter, 24, hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(hipStreamSynchronize(c->stream));
-            if (!c->coarse_checked) {
-                c->coarse_checked = true;
-                if (back[3] != 0) {   // dots may wrap: the candidates prove nothing, the exact kernel decides
-                    c->coarse_usable = false;
-                    break;
-                }
-            }
             const unsigned long long n_cand = back[2];
             c->last_candidates = n_cand;
             if (n_cand <= a.cand_capacity) {

@@ -62,12 +62,13 @@ struct PairwiseArgs {
     unsigned long long* cand_counter;
 };
 
-// per-row statistics of the coarse plane: radix m, sum c^2, sum r^2 (r = v - m*c)
+// per-row statistics of the coarse plane: radix m, sum c^2, sum r^2 (r = v - m*c), and whether the row's sum
+// of squares reaches 2^31 (its dots may wrap: the filter then passes every pair of that row on to the re-check)
 struct CoarseRow {
     int32_t radix;
     int32_t c2;
     int32_t r2;
-    int32_t pad;
+    int32_t big;
 };
 
 // d_sumsq / d_max_abs non-NULL: fused statistics (all samples must be single units; d_sumsq zeroed by the caller)
@@ -86,11 +87,11 @@ int launch_cand_thr(hipStream_t stream, const double* d_norms_sq, int64_t n, int
                     double coeff, int32_t* d_thr);
 // mode 0: comparison (kept cells), mode 1: dense dots.  algo 0: MFMA, 1: vector ALU.
 int launch_pairwise(hipStream_t stream, const PairwiseArgs& a, int mode, int algo);
-// two-stage comparison for two base-256 limbs: coarse plane + row statistics from the limb planes
-// (d_max_ss receives the largest sum of squares of a row if one reaches 2^31, and is left alone otherwise), per-call filter constants, the one-pass filter
+// two-stage comparison for two base-256 limbs: coarse plane + row statistics from the limb planes,
+// per-call filter constants, the one-pass filter
 // that appends candidate pairs, and the exact re-check of the candidates that appends kept cells
 int launch_coarse_build(hipStream_t stream, const int8_t* d_planes, int64_t n, int64_t n_alloc, int d_pad,
-                        int8_t* d_coarse, CoarseRow* d_rows, unsigned long long* d_max_ss);
+                        int8_t* d_coarse, CoarseRow* d_rows);
 int launch_filter_meta(hipStream_t stream, const CoarseRow* d_rows, const double* d_norms_sq, int64_t n,
                        int64_t n_alloc, int d, double coeff, float4* d_meta);
 int launch_filter(hipStream_t stream, const PairwiseArgs& a);

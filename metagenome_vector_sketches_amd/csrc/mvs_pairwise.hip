@@ -759,13 +759,15 @@ __global__ __launch_bounds__(256) void k_cand_thr(const double* __restrict__ n2,
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Two-stage comparison ("filter"), for sets of two base-256 limbs whose dots cannot wrap.
+// Two-stage comparison ("filter"), for sets of two base-256 limbs.
 //
 // Every row also gets ONE int8 plane c = round(v / m) with its own radix m = ceil(max|v| / 127), and
 // r = v - m c is only known through its norm.  With A = m_i m_j <c_i,c_j>, Cauchy-Schwarz gives
 //     | <v_i,v_j> - A |  <=  m_i |c_i| |r_j| + |r_i| m_j |c_j| + |r_i| |r_j|  =: B .
-// Both keep tests imply  P > d * coeff * (n2_i + n2_j) =: tau_i + tau_j  (P = <v_i,v_j> exactly: the rows'
-// sums of squares are below 2^31, so nothing wraps), hence a kept pair satisfies  A + B > tau_i + tau_j,
+// Both keep tests imply  P > d * coeff * (n2_i + n2_j) =: tau_i + tau_j  where P is the int32 dot.  P is the
+// true dot unless it wraps, and it can only wrap if |v_i| |v_j| >= 2^31, i.e. if one of the two rows has a sum
+// of squares >= 2^31: such "big" rows get s = -inf and pair with everything as candidates (the re-check
+// reproduces the wrapped value exactly).  For all other pairs a kept pair satisfies  A + B > tau_i + tau_j,
 // i.e. after dividing by m_i m_j, with a = |c|, p = |r| / m, s = tau / m, w = 1 / m:
 //     <c_i,c_j>  >  s_i w_j + s_j w_i - a_i p_j - p_i (a_j + p_j) .
 // The one-pass MFMA filter evaluates exactly that per cell in fp32; s is deflated and a, p are inflated by
@@ -777,8 +779,7 @@ __global__ __launch_bounds__(256) void k_cand_thr(const double* __restrict__ n2,
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_coarse_build(const int8_t* __restrict__ planes, int64_t n, int64_t n_alloc,
                                                       int d_pad, int8_t* __restrict__ coarse,
-                                                      CoarseRow* __restrict__ rows,
-                                                      unsigned long long* __restrict__ max_ss) {
+                                                      CoarseRow* __restrict__ rows) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= n_alloc) return;
@@ -841,9 +842,7 @@ __global__ __launch_bounds__(256) void k_coarse_build(const int8_t* __restrict__
         r2 += __shfl_xor(r2, o, 64);
     }
     if (lane == 0) {
-        rows[row] = CoarseRow{m, (int32_t)c2, (int32_t)r2, 0};
-        // only rows that rule the filter out report (one contended atomic per row would dominate the kernel)
-        if (ss >= (1ULL << 31)) atomicMax(max_ss, ss);
+        rows[row] = CoarseRow{m, (int32_t)c2, (int32_t)r2, ss >= (1ULL << 31) ? 1 : 0};
     }
 }
 
@@ -859,7 +858,7 @@ __global__ __launch_bounds__(256) void k_filter_meta(const CoarseRow* __restrict
         const double m = (double)st.radix;
         const double eps = 1.0 / 4096.0;
         const double tau = coeff * (double)d * n2[i] / m;          // NaN stays NaN: such a row is never kept
-        o.x = (float)(tau - fabs(tau) * eps);
+        o.x = st.big ? -__builtin_inff() : (float)(tau - fabs(tau) * eps);   // big rows: dots may wrap, always re-check
         o.y = (float)(1.0 / m);
         o.z = (float)(sqrt((double)st.c2) * (1.0 + eps));
         o.w = (float)(sqrt((double)st.r2) / m * (1.0 + eps));
@@ -1053,10 +1052,10 @@ int launch_cand_thr(hipStream_t stream, const double* d_norms_sq, int64_t n, int
 }
 
 int launch_coarse_build(hipStream_t stream, const int8_t* d_planes, int64_t n, int64_t n_alloc, int d_pad,
-                        int8_t* d_coarse, CoarseRow* d_rows, unsigned long long* d_max_ss) {
+                        int8_t* d_coarse, CoarseRow* d_rows) {
     if (n_alloc <= 0) return 0;
     hipLaunchKernelGGL(k_coarse_build, dim3((unsigned)((n_alloc + 3) / 4)), dim3(256), 0, stream, d_planes, n, n_alloc,
-                       d_pad, d_coarse, d_rows, d_max_ss);
+                       d_pad, d_coarse, d_rows);
     return 0;
 }
 

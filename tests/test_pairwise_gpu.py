@@ -357,18 +357,26 @@ def test_two_stage_threshold_knife_edge(ctx, monkeypatch):
 
 
 def test_two_stage_wrap_guard(ctx, monkeypatch):
-    """rows whose sum of squares reaches 2^31: dots may wrap, the filter must stand down"""
+    """rows whose sum of squares reaches 2^31: their int32 dots may wrap, the bound says nothing about them --
+    every pair of such a row goes to the exact re-check, which reproduces the wrapped value"""
     d = 2048
     rng = np.random.default_rng(5)
-    sk = rng.integers(-1200, 1200, (300, d)).astype(np.int32)
-    sk[17] = 1100                     # 2048 * 1100^2 = 2.48e9 >= 2^31
-    sk[18] = 1100
+    sk = rng.integers(-700, 700, (300, d)).astype(np.int32)
+    for i in (17, 18, 40):
+        sk[i] = rng.integers(0, 2, d) * 2200 - 1100      # 2048 * 1100^2 = 2.48e9 >= 2^31
+    sk[18] = sk[17]                                       # dot = 2.48e9 -> wraps negative: not kept
+    sk[41] = -sk[40]                                      # dot = -2.48e9 -> wraps positive: kept by the reference
     n2 = _n2_from_sketches(sk)
+    P = (sk[17].astype(np.int64) * sk[18]).sum()
+    assert P >= 2 ** 31 and (sk[40].astype(np.int64) * sk[41]).sum() <= -2 ** 31
     ss = ctx.sketch_set(sk)
-    monkeypatch.setenv("MVS_PAIRWISE_FILTER", "2")
-    cells, _ = ctx.pairwise_rows(ss, n2)
-    assert ctx.pairwise_candidates() == 0
-    assert _cells_tuple(cells) == _oracle_sorted(sk, n2, chunk=192)
+    for f in ("2", "0"):
+        monkeypatch.setenv("MVS_PAIRWISE_FILTER", f)
+        cells, _ = ctx.pairwise_rows(ss, n2)
+        assert (ctx.pairwise_candidates() >= 4 * 300 - 16) == (f == "2")
+        got = _cells_tuple(cells)
+        assert got == _oracle_sorted(sk, n2, chunk=192)
+    assert (17, 18) not in {(r, c) for r, c, _, _ in got}
     ss.close()
 
 

@@ -27,7 +27,7 @@ ss = torch.empty(n, dtype=torch.int64, device="cuda")
 ctx.sumsq(sk, out=ss)
 n2 = torch.from_numpy(np.sqrt(ss.cpu().numpy() / d) ** 2).to("cuda")
 sset = ctx.sketch_set(sk)
-cells = torch.empty((max(1 << 22, 64 * n), 4), dtype=torch.int32, device="cuda")
+cells = torch.empty((int(os.environ.get("CELLS_CAP", max(1 << 22, 64 * n))), 4), dtype=torch.int32, device="cuda")
 for r in range(reps):
     t0 = time.perf_counter()
     _, cnt = ctx.pairwise_rows(sset, n2, cells_out=cells)
