@@ -889,13 +889,29 @@ int mvs_pairwise_rows(mvs_ctx* c, const mvs_sketch_set* s, const double* norms_s
     // kept cells are appended (unordered) to a staging buffer and merge-sorted into the caller's
     int rc = ensure_buf(c, &c->pw_tmp, &c->pw_tmp_bytes, (size_t)std::max<int64_t>(capacity, 1) * sizeof(mvs_cell));
     if (rc) return rc;
+    // Very large shards go through in row chunks of at most 2^40 cells (chunk borders on multiples of 256 rows so
+    // that every chunk can use the symmetric schedule): that bounds the candidate list of the two-stage
+    // comparison.  MVS_PAIRWISE_BLOCK_CELLS overrides the bound (tests).
+    double max_cells = 1099511627776.0;
+    if (const char* e = getenv("MVS_PAIRWISE_BLOCK_CELLS")) {
+        const double v = atof(e);
+        if (v >= 1.0) max_cells = v;
+    }
+    int64_t chunk_rows = (int64_t)(max_cells / (double)s->n);
+    chunk_rows = std::max<int64_t>(256, chunk_rows / 256 * 256);
     unsigned long long count = 0;
-    rc = pairwise_launch(c, s, d_n2, keep_mode, row_begin, row_end, 0, s->n, true, false, (mvs_cell*)c->pw_tmp, capacity, 0,
-                         &count);
-    if (rc) return rc;
-    if (count == ~0ULL) {
-        HIP_TRY(hipMemcpyAsync(&count, c->d_counter, 8, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
+    for (int64_t rb = row_begin; rb < row_end;) {
+        const int64_t re = std::min(row_end, (rb / 256) * 256 + chunk_rows);
+        unsigned long long got = 0;
+        rc = pairwise_launch(c, s, d_n2, keep_mode, rb, re, 0, s->n, true, false, (mvs_cell*)c->pw_tmp, capacity, count,
+                             &got);
+        if (rc) return rc;
+        if (got == ~0ULL) {
+            HIP_TRY(hipMemcpyAsync(&got, c->d_counter, 8, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+        }
+        count = got;
+        rb = re;
     }
     *n_cells = (int64_t)count;
     if ((int64_t)count > capacity)

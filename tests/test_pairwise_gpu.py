@@ -410,3 +410,20 @@ def test_two_stage_gives_way_when_everything_is_a_candidate(ctx, monkeypatch):
     c2, _ = ctx.pairwise_rows(ss2, n22)
     assert ctx.pairwise_candidates() > 0 and _cells_tuple(c2) == _oracle_sorted(sk2, n22, chunk=192)
     ss2.close()
+
+
+@pytest.mark.parametrize("filt", ["0", "2"])
+def test_row_chunked_shard(ctx, monkeypatch, filt):
+    """a shard cut into row chunks (the bound that applies beyond ~1M x 1M cells, lowered here): same cells"""
+    sk = synth.make_sketches_numpy(1100, 512, 3000, seed=12, cluster=8)
+    n2 = _n2_from_sketches(sk)
+    ss = ctx.sketch_set(sk)
+    monkeypatch.setenv("MVS_PAIRWISE_FILTER", filt)
+    monkeypatch.setenv("MVS_PAIRWISE_BLOCK_CELLS", str(300 * 1100))     # chunks of 256 rows
+    whole, _ = ctx.pairwise_rows(ss, n2)
+    part, _ = ctx.pairwise_rows(ss, n2, row_begin=130, row_end=901)
+    monkeypatch.delenv("MVS_PAIRWISE_BLOCK_CELLS")
+    want = _oracle_sorted(sk, n2, chunk=192)
+    assert _cells_tuple(whole) == want
+    assert _cells_tuple(part) == [t for t in want if 130 <= t[0] < 901]
+    ss.close()
