@@ -68,6 +68,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pairwise-extra", type=int, default=0,
                     help="also time a pairwise-only run on this many synthesised sketches (rank 0, N=1)")
+    ap.add_argument("--cluster", type=int, default=16, help="related samples per cluster (256: the dense variant)")
+    ap.add_argument("--lognormal-sigma", type=float, default=0.0,
+                    help="> 0: ragged samples, sizes ~ lognormal(ln hashes, sigma) clipped to [100, 2e6] (SURVEY 8d)")
     ap.add_argument("--host-input", action="store_true",
                     help="also time the step with the hash lists handed over as host buffers (PCIe inclusive; "
                          "reported as pcie_inclusive, never as value)")
@@ -104,11 +107,15 @@ def main():
     ctx.set_timing(True)
 
     # ---- synthetic input, resident in HBM ----
-    hashes, offsets = synth.make_csr_torch(S, NH, seed=1234 + rank, device=dev, cluster=16, shared=0.4)
+    if args.lognormal_sigma > 0:
+        hashes, offsets = synth.make_csr_torch_ragged(S, NH, args.lognormal_sigma, seed=1234 + rank, device=dev,
+                                                      cluster=args.cluster, shared=0.4)
+    else:
+        hashes, offsets = synth.make_csr_torch(S, NH, seed=1234 + rank, device=dev, cluster=args.cluster, shared=0.4)
     sketches = torch.empty((S, D), dtype=torch.int32, device=dev)
     sumsq = torch.empty(S, dtype=torch.int64, device=dev)
     N_total = S * world
-    cap = max(1 << 20, 64 * S)
+    cap = max(1 << 20, max(64, 4 * args.cluster) * S)
     cells = torch.empty((cap, 4), dtype=torch.int32, device=dev)
     torch.cuda.synchronize()
 
@@ -168,9 +175,10 @@ def main():
     limbs = state["limbs"]
 
     # roofline of the dominant kernel (K1, projection): algorithmic bytes = 8*n_i + 4*d per sample
-    k1_bytes = S * (8.0 * NH + 4.0 * D)
+    total_hashes = float(offsets[S])                       # == S * NH unless --lognormal-sigma
+    k1_bytes = 8.0 * total_hashes + 4.0 * D * S
     k1_gbs = k1_bytes / (k1 * 1e-3) / 1e9
-    k1_intops = S * float(NH) * D            # sign accumulations
+    k1_intops = total_hashes * D             # sign accumulations
     k2_flops = 2.0 * D * S * N_total         # this rank's rows x all columns
     # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 cannot run inside
     # this process); only valid for the default workload on one GPU
@@ -198,6 +206,8 @@ def main():
         "config": {"workload": "configs[1]: %d synthetic samples x %d hashes per GPU, d=%d, projection + "
                                "pairwise" % (S, NH, D),
                    "samples_per_gpu": S, "hashes_per_sample": NH, "d": D, "total_samples": N_total,
+                   "cluster": args.cluster, "lognormal_sigma": args.lognormal_sigma,
+                   "hashes_per_gpu": int(total_hashes),
                    "limbs": limbs, "kept_cells": kept_total, "parallelism": "row shards x%d" % world,
                    "schedule": state["schedule"]},
         "cells_per_s": cells_per_step / (elapsed / args.steps),
@@ -214,8 +224,8 @@ def main():
                           # instruction-issue bound: 22.9 VALU per (hash, 64-dim block) at the issue costs measured by
                           # tools/microbench/valu_rates (profiles/r01_valu_rates_microbench.txt): 35.5 ns per
                           # (64 hashes x block) per SIMD, 1024 SIMDs
-                          "issue_bound_ms": S * float(NH) * ((D + 63) // 64) / 64.0 / 1024.0 * 35.5e-6,
-                          "issue_bound_frac": S * float(NH) * ((D + 63) // 64) / 64.0 / 1024.0 * 35.5e-6 / k1},
+                          "issue_bound_ms": total_hashes * ((D + 63) // 64) / 64.0 / 1024.0 * 35.5e-6,
+                          "issue_bound_frac": total_hashes * ((D + 63) // 64) / 64.0 / 1024.0 * 35.5e-6 / k1},
         "roofline_pairwise": {"kernel": "k_pairwise_mfma", "bound": "mfma",
                               "achieved": k2_flops / (k2 * 1e-3) / 1e12, "peak": INT8_MFMA_PEAK_TOPS,
                               "unit": "TFLOP/s", "frac": k2_flops / (k2 * 1e-3) / 1e12 / INT8_MFMA_PEAK_TOPS,
@@ -280,16 +290,17 @@ def cpu_baseline(hashes, offsets, S, NH, D):
     from oracle import pyoracle as orc
     cores = orc.max_threads()
     ns = 96
-    h = hashes[:ns * NH].cpu().numpy().view(np.uint64)
-    o = offsets[:ns + 1]
+    o = np.asarray(offsets[:ns + 1])
+    h = hashes[:int(o[ns])].cpu().numpy().view(np.uint64)
+    per_sample = float(offsets[S]) / S / (float(o[ns]) / ns)       # ragged input: the sample's mean size vs the job's
     t0 = time.perf_counter()
-    sk_lit = orc.project_csr(h[:32 * NH], o[:33], D, threads=cores, native=True)     # literal loop nest
-    t_lit = (time.perf_counter() - t0) / 32
+    sk_lit = orc.project_csr(h[:int(o[32])], o[:33], D, threads=cores, native=True)     # literal loop nest
+    t_lit = (time.perf_counter() - t0) / 32 * (float(o[ns]) / ns) / (float(o[32]) / 32)
     t0 = time.perf_counter()
     sk = orc.project_csr(h, o, D, threads=cores, fast=True, native=True)
     t_fast = (time.perf_counter() - t0) / ns
     assert np.array_equal(sk[:32], sk_lit)
-    t_proj = min(t_lit, t_fast)
+    t_proj = min(t_lit, t_fast) * per_sample                     # seconds per sample of the job's mean size
     # pairwise: N = 2048 synthetic sketches of the same magnitude
     from metagenome_vector_sketches_amd import synth
     npw = 2048

@@ -56,6 +56,30 @@ def make_csr_torch(n_samples, n_hashes, seed, device, cluster=16, shared=0.4):
     return out.reshape(-1), offsets
 
 
+def make_csr_torch_ragged(n_samples, mean_hashes, sigma, seed, device, cluster=16, shared=0.4, lo=100, hi=2_000_000):
+    """Ragged samples generated on the device: sizes ~ lognormal(ln mean_hashes, sigma) clipped to [lo, hi]
+    (the spread of real FracMinHash sets); a sample shares the first 40 % of its hashes with its
+    cluster's pool.  -> (hashes int64 tensor [sum n_i], offsets numpy int64)."""
+    import torch
+    rng = np.random.default_rng(seed)
+    sizes = np.clip(rng.lognormal(np.log(mean_hashes), sigma, n_samples), lo, hi).astype(np.int64)
+    offsets = np.zeros(n_samples + 1, dtype=np.int64)
+    np.cumsum(sizes, out=offsets[1:])
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    out = torch.randint(0, MAX_HASH, (int(offsets[-1]),), dtype=torch.int64, device=device, generator=g)
+    ks = (shared * sizes).astype(np.int64)
+    for c0 in range(0, n_samples, cluster):
+        c1 = min(n_samples, c0 + cluster)
+        kmax = int(ks[c0:c1].max())
+        if kmax == 0:
+            continue
+        pool = torch.randint(0, MAX_HASH, (kmax,), dtype=torch.int64, device=device, generator=g)
+        for s in range(c0, c1):
+            out[int(offsets[s]):int(offsets[s]) + int(ks[s])] = pool[:int(ks[s])]
+    return out, offsets
+
+
 def make_sketches_numpy(n_samples, d, n_hashes, seed, cluster=16, shared=0.4):
     """Synthesise sketches directly (pairwise-only configs): v = shared component + private component,
     each n - 2*Binomial(n, 1/2) per entry.  int32 [n_samples, d]."""
