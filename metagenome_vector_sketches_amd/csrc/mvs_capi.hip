@@ -760,8 +760,8 @@ int pairwise_launch(mvs_ctx* c, const mvs_sketch_set* s, const double* d_n2, int
     int rc = MVS_OK;
     const double block_cells = (double)(re - rb) * (double)(ce - cb);
     bool two_stage = filter_mode() != 0 && s->limbs == 2 && s->d_pad <= 32768 &&
-                     (filter_mode() == 2 || block_cells >= 4194304.0) &&
-                     !(c->filter_off_id == s->id && c->filter_off_coeff == keep_coeff);
+                     (filter_mode() == 2 ||   // forced: also on small blocks and on sets it was found not to pay for
+                      (block_cells >= 4194304.0 && !(c->filter_off_id == s->id && c->filter_off_coeff == keep_coeff)));
     if (two_stage) {
         rc = prepare_coarse(c, s);
         if (rc) return rc;
@@ -812,6 +812,12 @@ int pairwise_launch(mvs_ctx* c, const mvs_sketch_set* s, const double* d_n2, int
             c->last_candidates = n_cand;
             if (n_cand <= a.cand_capacity) {
                 *count = back[0];
+                // this result stands; but with more than ~1/512 of the cells to re-check the exact kernel alone is
+                // the faster one (filter pass ~0.37 of it, a re-check ~330 cells' worth): use it from now on
+                if ((double)n_cand > block_cells / 512.0) {
+                    c->filter_off_id = s->id;
+                    c->filter_off_coeff = keep_coeff;
+                }
                 return MVS_OK;
             }
             if ((double)n_cand > cand_limit) {

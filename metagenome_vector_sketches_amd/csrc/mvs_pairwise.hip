@@ -109,6 +109,39 @@ __device__ __forceinline__ void emit_cell(const PairwiseArgs& a, bool keep, bool
     }
 }
 
+// Room for `mine` entries per lane behind *counter with ONE atomic per wave: returns the lane's first slot.
+// (A counter bumped once per 32 x 32 block serialises at the L2 as soon as many blocks hold something.)
+__device__ __forceinline__ unsigned long long wave_reserve(unsigned long long* counter, unsigned mine, int lane) {
+    unsigned incl = mine;   // inclusive prefix sum over the lanes
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned up = (unsigned)__shfl_up((int)incl, o, 64);
+        if (lane >= o) incl += up;
+    }
+    unsigned long long base = 0;
+    if (lane == 63) base = atomicAdd(counter, (unsigned long long)incl);
+    base = __shfl(base, 63, 64);
+    return base + (incl - mine);
+}
+
+// one kept cell (and its mirror image) at `slot`, which advances
+__device__ __forceinline__ void write_cell(const PairwiseArgs& a, unsigned long long& slot, bool mirror, int32_t row,
+                                           int32_t col, int32_t P) {
+    mvs_cell c;
+    c.row = row;
+    c.col = col;
+    c.dot = P;
+    c.q = quantize_cell(P, a.d, a.norms_sq[row], a.norms_sq[col]);
+    if (slot < a.capacity) a.cells[slot] = c;
+    ++slot;
+    if (mirror) {
+        c.row = col;
+        c.col = row;
+        if (slot < a.capacity) a.cells[slot] = c;
+        ++slot;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // MFMA kernel.  L = limbs (1 or 2).  MODE 0: comparison, 1: dense dots, 2: filter on the coarse plane.
 // NST = LDS ring depth.
@@ -451,39 +484,76 @@ __global__ __launch_bounds__(WM * WN * 64, (AT * BT > 2 ? 1 : 2)) void k_pairwis
         }
         __syncthreads();
     }
+    auto dot_of = [&](int t, int u, int r) -> int32_t {   // limb products -> int32 dot (mod 2^32)
+        uint32_t Pu = (uint32_t)acc[t][u][0][r];
+        if (KARA) {
+            const uint32_t X = Pu, Z = (uint32_t)acc[t][u][1][r], Y = (uint32_t)acc[t][u][NS - 1][r];
+            Pu = X + ((Y - X - Z) << 7) + (Z << 14);
+        } else {
+#pragma unroll
+            for (int s = 1; s < NS; ++s) Pu += (uint32_t)acc[t][u][s][r] << (8 * s);
+        }
+        return (int32_t)Pu;
+    };
+    if constexpr (MODE == 1) {
+#pragma unroll
+        for (int u = 0; u < BT; ++u) {
+            const int64_t col = j0 + (wn * BT + u) * 32 + fr;
+#pragma unroll
+            for (int t = 0; t < AT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int64_t row = i0 + wm * AT * 32 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                    if (row < a.row_end && col < a.col_end)
+                        a.dots[(row - a.row_begin) * (a.col_end - a.col_begin) + (col - a.col_begin)] = dot_of(t, u, r);
+                }
+        }
+        return;
+    }
+    // Pass 1: keep test per cell (integer pre-test, fp64 only for its survivors) -> one 16-bit mask per lane and
+    // 32 x 32 block, parked in LDS.  Pass 2: one atomic per wave reserves the wave's cells, then they are written.
+    unsigned* masks = reinterpret_cast<unsigned*>(smem + (((TM + TN) * 4 + 15) & ~15)) + wave * (BT * AT * 64) + lane;
+    unsigned mine = 0;
 #pragma unroll
     for (int u = 0; u < BT; ++u) {
         const int col_l = (wn * BT + u) * 32 + fr;
         const int64_t col = j0 + col_l;
+        const bool mirror = a.mirror_all || (mirror_tile && col < a.row_end);
 #pragma unroll
         for (int t = 0; t < AT; ++t) {
+            unsigned m16 = 0;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row_l = wm * AT * 32 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
                 const int64_t row = i0 + row_l;
-                uint32_t Pu = (uint32_t)acc[t][u][0][r];
-                if (KARA) {
-                    const uint32_t X = Pu, Z = (uint32_t)acc[t][u][1][r], Y = (uint32_t)acc[t][u][NS - 1][r];
-                    Pu = X + ((Y - X - Z) << 7) + (Z << 14);
-                } else {
-#pragma unroll
-                    for (int s = 1; s < NS; ++s) Pu += (uint32_t)acc[t][u][s][r] << (8 * s);
-                }
-                const int32_t P = (int32_t)Pu;
-                if (MODE == 1) {
-                    if (row < a.row_end && col < a.col_end)
-                        a.dots[(row - a.row_begin) * (a.col_end - a.col_begin) + (col - a.col_begin)] = P;
-                } else {
-                    const bool cand = P >= thr[row_l] + thr[TM + col_l];
-                    if (__any(cand)) {
-                        bool keep = false;
-                        if (cand && row < a.row_end && col < a.col_end)
-                            keep = keep_cell(P, a.d, a.norms_sq[row], a.norms_sq[col], a.keep_mode, a.keep_coeff);
-                        emit_cell(a, keep, a.mirror_all || (mirror_tile && col < a.row_end), (int32_t)row, (int32_t)col, P,
-                                  lane);
-                    }
+                const int32_t P = dot_of(t, u, r);
+                const bool cand = P >= thr[row_l] + thr[TM + col_l];
+                if (__any(cand)) {
+                    bool keep = false;
+                    if (cand && row < a.row_end && col < a.col_end)
+                        keep = keep_cell(P, a.d, a.norms_sq[row], a.norms_sq[col], a.keep_mode, a.keep_coeff);
+                    m16 |= keep ? 1u << r : 0u;
                 }
             }
+            masks[(u * AT + t) * 64] = m16;
+            mine += (unsigned)__popc(m16) << (mirror ? 1 : 0);
+        }
+    }
+    if (__ballot(mine != 0) == 0ULL) return;
+    unsigned long long out_slot = wave_reserve(a.counter, mine, lane);
+#pragma unroll
+    for (int u = 0; u < BT; ++u) {
+        const int64_t col = j0 + (wn * BT + u) * 32 + fr;
+        const bool mirror = a.mirror_all || (mirror_tile && col < a.row_end);
+#pragma unroll
+        for (int t = 0; t < AT; ++t) {
+            const unsigned m = masks[(u * AT + t) * 64];   // this lane's own word
+            if (__ballot(m != 0) == 0ULL) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (m & (1u << r))
+                    write_cell(a, out_slot, mirror, (int32_t)(i0 + wm * AT * 32 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh),
+                               (int32_t)col, dot_of(t, u, r));
         }
     }
 }
@@ -602,32 +672,66 @@ __global__ __launch_bounds__(512, 2) void k_pairwise_mfma16(const PairwiseArgs a
         for (int x = tid; x < TM + TN; x += kWavesT * 64) thr[x] = a.cand_thr[(x < TM ? i0 : j0 - TM) + x];
         __syncthreads();
     }
+    auto dot_of = [&](int t, int u, int r) -> int32_t {
+        return (int32_t)((uint32_t)acc[t][u][0][r] + ((uint32_t)acc[t][u][1][r] << 8) + ((uint32_t)acc[t][u][2][r] << 16));
+    };
+    if constexpr (MODE == 1) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int64_t col = j0 + wn * 32 + u * 16 + fr;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int64_t row = i0 + wm * 64 + t * 16 + fq * 4 + r;
+                    if (row < a.row_end && col < a.col_end)
+                        a.dots[(row - a.row_begin) * (a.col_end - a.col_begin) + (col - a.col_begin)] = dot_of(t, u, r);
+                }
+        }
+        return;
+    }
+    // pass 1: keep masks (16 cells per lane and column) parked in LDS; pass 2: one atomic per wave, then the writes
+    unsigned* masks = reinterpret_cast<unsigned*>(smem + (TM + TN) * 4) + wave * 128 + lane;
+    unsigned mine = 0;
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         const int col_l = wn * 32 + u * 16 + fr;
         const int64_t col = j0 + col_l;
+        const bool mirror = a.mirror_all || (mirror_tile && col < a.row_end);
+        unsigned m16 = 0;
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row_l = wm * 64 + t * 16 + fq * 4 + r;
                 const int64_t row = i0 + row_l;
-                const int32_t P = (int32_t)((uint32_t)acc[t][u][0][r] + ((uint32_t)acc[t][u][1][r] << 8) +
-                                            ((uint32_t)acc[t][u][2][r] << 16));
-                if (MODE == 1) {
-                    if (row < a.row_end && col < a.col_end)
-                        a.dots[(row - a.row_begin) * (a.col_end - a.col_begin) + (col - a.col_begin)] = P;
-                } else {
-                    const bool cand = P >= thr[row_l] + thr[TM + col_l];
-                    if (__any(cand)) {
-                        bool keep = false;
-                        if (cand && row < a.row_end && col < a.col_end)
-                            keep = keep_cell(P, a.d, a.norms_sq[row], a.norms_sq[col], a.keep_mode, a.keep_coeff);
-                        emit_cell(a, keep, a.mirror_all || (mirror_tile && col < a.row_end), (int32_t)row, (int32_t)col, P,
-                                  lane);
-                    }
+                const int32_t P = dot_of(t, u, r);
+                const bool cand = P >= thr[row_l] + thr[TM + col_l];
+                if (__any(cand)) {
+                    bool keep = false;
+                    if (cand && row < a.row_end && col < a.col_end)
+                        keep = keep_cell(P, a.d, a.norms_sq[row], a.norms_sq[col], a.keep_mode, a.keep_coeff);
+                    m16 |= keep ? 1u << (t * 4 + r) : 0u;
                 }
             }
+        masks[u * 64] = m16;
+        mine += (unsigned)__popc(m16) << (mirror ? 1 : 0);
+    }
+    if (__ballot(mine != 0) == 0ULL) return;
+    unsigned long long out_slot = wave_reserve(a.counter, mine, lane);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int64_t col = j0 + wn * 32 + u * 16 + fr;
+        const bool mirror = a.mirror_all || (mirror_tile && col < a.row_end);
+        const unsigned m = masks[u * 64];   // this lane's own word
+        if (__ballot(m != 0) == 0ULL) continue;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (m & (1u << (t * 4 + r)))
+                    write_cell(a, out_slot, mirror, (int32_t)(i0 + wm * 64 + t * 16 + fq * 4 + r), (int32_t)col,
+                               dot_of(t, u, r));
     }
 }
 
