@@ -23,7 +23,6 @@ namespace mvs {
 namespace {
 
 constexpr int kLV = 11;            // bit-sliced counter depth per lane: counts up to 2047
-constexpr int kRedLV = kLV + 6;    // after summing 64 lanes
 constexpr uint64_t kGolden = 0x9e3779b97f4a7c15ULL;
 
 __device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) {
@@ -128,20 +127,25 @@ __device__ __forceinline__ void load_batch(uint64_t (&h)[8], const uint64_t* bas
     }
 }
 
-// Sum the 64 lanes' bit-sliced counters and return, in lane k, the count for bit position k.
+// Sum the 64 lanes' bit-sliced counters and return, in lane k, the count for bit position k.  LV0 = number of
+// counter digits that can be non-zero (every lane absorbed fewer than 2^LV0 hashes): short units skip the dead
+// digits, which is most of this step's work (6*LV0 + 21 digit additions).
+template <int LV0>
 __device__ __forceinline__ int32_t reduce_counts(const uint32_t (&lo_in)[kLV], const uint32_t (&hi_in)[kLV],
                                                  int lane) {
-    uint32_t lo[kRedLV], hi[kRedLV];
+    static_assert(LV0 >= 1 && LV0 <= kLV, "live digits");
+    constexpr int kOut = LV0 + 6;
+    uint32_t lo[kOut], hi[kOut];
 #pragma unroll
-    for (int l = 0; l < kRedLV; ++l) {
-        lo[l] = l < kLV ? lo_in[l] : 0u;
-        hi[l] = l < kLV ? hi_in[l] : 0u;
+    for (int l = 0; l < kOut; ++l) {
+        lo[l] = l < LV0 ? lo_in[l] : 0u;
+        hi[l] = l < LV0 ? hi_in[l] : 0u;
     }
 #pragma unroll
     for (int s = 0; s < 6; ++s) {
         uint32_t cl = 0, ch = 0;
 #pragma unroll
-        for (int l = 0; l < kLV + s + 1; ++l) {
+        for (int l = 0; l < LV0 + s + 1; ++l) {
             const uint32_t pl = (uint32_t)__shfl_xor((int)lo[l], 1 << s, 64);
             const uint32_t ph = (uint32_t)__shfl_xor((int)hi[l], 1 << s, 64);
             const uint32_t sl = xor3(lo[l], pl, cl), sh = xor3(hi[l], ph, ch);
@@ -154,7 +158,7 @@ __device__ __forceinline__ int32_t reduce_counts(const uint32_t (&lo_in)[kLV], c
     int32_t cnt = 0;
     const int sh = lane & 31;
 #pragma unroll
-    for (int l = 0; l < kRedLV; ++l) {
+    for (int l = 0; l < kOut; ++l) {
         const uint32_t w = lane < 32 ? lo[l] : hi[l];
         cnt += (int32_t)((w >> sh) & 1u) << l;
     }
@@ -262,7 +266,11 @@ __global__ __launch_bounds__(256) void k_project(const uint64_t* __restrict__ ha
 #pragma unroll
     for (int b = 0; b < BPW; ++b) {
         if (b0 + b >= nblk) break;
-        const int32_t cnt = reduce_counts(s.lo[b], s.hi[b], lane);
+        int32_t cnt;   // a lane absorbed at most ceil(count / 64) hashes
+        if (count <= 64) cnt = reduce_counts<1>(s.lo[b], s.hi[b], lane);
+        else if (count <= 64 * 15) cnt = reduce_counts<4>(s.lo[b], s.hi[b], lane);
+        else if (count <= 64 * 127) cnt = reduce_counts<7>(s.lo[b], s.hi[b], lane);
+        else cnt = reduce_counts<kLV>(s.lo[b], s.hi[b], lane);
         const int k = (b0 + b) * 64 + lane;
         if (k < d) {
             const int32_t v = (int32_t)count - 2 * cnt;
@@ -287,7 +295,9 @@ __global__ __launch_bounds__(256) void k_project(const uint64_t* __restrict__ ha
         }
         if (lane == 0) {
             atomicAdd(sumsq + u.sample, (unsigned long long)ss);
-            if (mx) atomicMax(max_abs, (unsigned long long)mx);
+            // the running maximum only grows: look before bumping it (one atomic per wave on ONE address
+            // serialises at the L2 -- 1.6e7 of them cost 160 ms on a million small samples)
+            if (mx > *reinterpret_cast<volatile unsigned long long*>(max_abs)) atomicMax(max_abs, (unsigned long long)mx);
         }
     }
 }
@@ -342,7 +352,7 @@ __global__ __launch_bounds__(256) void k_stats(const int32_t* __restrict__ sk, i
     }
     if (lane == 0) {
         sumsq[row] = acc;
-        if (m) atomicMax(max_abs, (unsigned long long)m);
+        if (m > *reinterpret_cast<volatile unsigned long long*>(max_abs)) atomicMax(max_abs, (unsigned long long)m);
     }
 }
 
