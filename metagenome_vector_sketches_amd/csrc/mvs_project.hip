@@ -252,12 +252,25 @@ __global__ __launch_bounds__(256) void k_project(const uint64_t* __restrict__ ha
 #pragma unroll
             for (int j = 0; j < 8; ++j) hv[j] = hn[j];
         }
-        // partial last batch, masked
+        // partial last batch, masked; only as many of its 8 hash slots are evaluated as hold anything (a sample of
+        // 100 hashes needs 2 of them, not 8)
         if ((count & 511) != 0) {
+            const int rem = (int)(count & 511);
             BatchGen<BPW, true> g(hv, cb, count - (nfull << 9) - lane);
             uint32_t clo[BPW], chi[BPW];
-            absorb<3, BPW>(s, g, clo, chi);
-            ripple<3, BPW>(s, clo, chi);
+            if (rem <= 64) {
+                absorb<0, BPW>(s, g, clo, chi);
+                ripple<0, BPW>(s, clo, chi);
+            } else if (rem <= 128) {
+                absorb<1, BPW>(s, g, clo, chi);
+                ripple<1, BPW>(s, clo, chi);
+            } else if (rem <= 256) {
+                absorb<2, BPW>(s, g, clo, chi);
+                ripple<2, BPW>(s, clo, chi);
+            } else {
+                absorb<3, BPW>(s, g, clo, chi);
+                ripple<3, BPW>(s, clo, chi);
+            }
         }
     }
 
