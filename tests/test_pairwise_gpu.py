@@ -427,3 +427,48 @@ def test_row_chunked_shard(ctx, monkeypatch, filt):
     assert _cells_tuple(whole) == want
     assert _cells_tuple(part) == [t for t in want if 130 <= t[0] < 901]
     ss.close()
+
+
+@pytest.mark.parametrize("d", [2048, 4096])
+def test_baseline_config3_and_4_full_size(ctx, monkeypatch, d):
+    """BASELINE.json configs[2] and the size of configs[3] (100 000 sketches, d = 2048 / 4096, magnitudes of
+    50k-hash samples): the two-stage comparison and the exact kernel give the same 1.6 M cells bit for bit;
+    size-independent properties; 24 rows against the oracle."""
+    import torch
+    n = 100_000
+    sk_t = synth.make_sketches_torch(n, d, 50_000, seed=2345, device="cuda")
+    ss_t = torch.empty(n, dtype=torch.int64, device="cuda")
+    ctx.set_stream(torch.cuda.current_stream())
+    try:
+        ctx.sumsq(sk_t, out=ss_t)
+        ss_host = ss_t.cpu().numpy()
+        n2 = np.array([orc.norm_sq_from_text(orc.format_norm(float(np.sqrt(v / d)))) for v in ss_host])
+        n2_t = torch.from_numpy(n2).to("cuda")
+        sset = ctx.sketch_set(sk_t)
+        assert sset.limbs == 2
+        out = []
+        for f in ("1", "0"):
+            monkeypatch.setenv("MVS_PAIRWISE_FILTER", f)
+            cells_t = torch.empty((1 << 22, 4), dtype=torch.int32, device="cuda")
+            _, cnt = ctx.pairwise_rows(sset, n2_t, cells_out=cells_t)
+            assert (ctx.pairwise_candidates() > 0) == (f == "1")
+            ctx.synchronize()
+            out.append(cells_t[:cnt].cpu().numpy())
+        sset.close()
+        rows_chk = slice(77_000, 77_024)
+        sk_rows = sk_t[rows_chk].cpu().numpy()
+        sk_all = sk_t.cpu().numpy()
+    finally:
+        ctx.set_stream(None)
+    two, exact = out
+    assert np.array_equal(two, exact) and len(two) >= 16 * n
+    rows, cols = two[:, 0].astype(np.int64), two[:, 1].astype(np.int64)
+    key = rows * n + cols
+    assert np.all(np.diff(key) > 0)                                          # sorted, no duplicates
+    assert np.array_equal(np.sort(cols * n + rows), key)                     # symmetric
+    diag = two[rows == cols]
+    assert len(diag) == n and np.all(diag[:, 3] == 255)
+    assert ((rows // 16) == (cols // 16)).sum() == 16 * n                    # every cluster pair kept
+    want = _oracle_sorted(sk_all, n2, row_begin=rows_chk.start, row_end=rows_chk.stop, chunk=192)
+    got = [tuple(int(x) for x in c) for c in two[(rows >= rows_chk.start) & (rows < rows_chk.stop)]]
+    assert got == want and np.array_equal(sk_rows, sk_all[rows_chk])
