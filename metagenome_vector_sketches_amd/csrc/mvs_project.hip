@@ -283,6 +283,7 @@ __global__ __launch_bounds__(256) void k_project(const uint64_t* __restrict__ ha
         if (count <= 64) cnt = reduce_counts<1>(s.lo[b], s.hi[b], lane);
         else if (count <= 64 * 15) cnt = reduce_counts<4>(s.lo[b], s.hi[b], lane);
         else if (count <= 64 * 127) cnt = reduce_counts<7>(s.lo[b], s.hi[b], lane);
+        else if (count <= 64 * 511) cnt = reduce_counts<9>(s.lo[b], s.hi[b], lane);
         else cnt = reduce_counts<kLV>(s.lo[b], s.hi[b], lane);
         const int k = (b0 + b) * 64 + lane;
         if (k < d) {
