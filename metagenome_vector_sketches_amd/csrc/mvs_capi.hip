@@ -189,7 +189,7 @@ int mvs_ctx_create(int device, mvs_ctx** out) {
         mvs_ctx_destroy(c);
         return fail(MVS_E_HIP, "hipEventCreate failed");
     }
-    if (hipMalloc((void**)&c->d_counter, 64) != hipSuccess) {
+    if (hipMalloc((void**)&c->d_counter, 512) != hipSuccess) {   // 8 counter slots; +256 B: the filter's stop flag
         mvs_ctx_destroy(c);
         return fail(MVS_E_HIP, "hipMalloc failed");
     }
@@ -771,26 +771,34 @@ int pairwise_launch(mvs_ctx* c, const mvs_sketch_set* s, const double* d_n2, int
                                 (float4*)c->pw_fmeta);
         rc = check_kernel("k_filter_meta");
         if (rc) return rc;
-        // candidate list: room for every kept cell plus the ~2e-4 of the block the filter lets through on
-        // typical sketches (regrown below if that is not enough)
-        const int64_t cand_want = std::max<int64_t>(std::max<int64_t>(1 << 20, capacity), (int64_t)(block_cells / 4096.0));
+        // Re-checking a candidate costs about as much as 80-300 cells of the exact kernel (by how well the rows
+        // cache) and the filter pass a third of it: beyond ~1/128 of the block's cells in the list the exact
+        // kernel alone is faster (dense results; a search with a very low bound).  The filter tiles and the
+        // re-check give up as soon as the device-side counter passes that limit; the exact kernel then does the
+        // block (and later blocks of the same set).  The list starts at the caller's capacity or 1/4096 of the
+        // block and is regrown to what a run reports it needs.  Forced mode (MVS_PAIRWISE_FILTER=2, tests) has
+        // no limit.
+        const bool forced = filter_mode() == 2;
+        const unsigned long long limit =
+            forced ? ~0ULL : (unsigned long long)std::min(268435456.0, std::max(65536.0, block_cells / 128.0));
+        int64_t cand_want = std::max<int64_t>(std::max<int64_t>(1 << 20, capacity), (int64_t)(block_cells / 4096.0));
+        if (!forced) cand_want = std::min<int64_t>(cand_want, (int64_t)limit);
         rc = ensure_buf(c, &c->pw_cand, &c->pw_cand_bytes, (size_t)cand_want * sizeof(int2));
         if (rc) return rc;
         a.coarse = (const int8_t*)c->pw_coarse;
         a.fmeta = (const float4*)c->pw_fmeta;
         a.cand_counter = c->d_counter + 2;
-        // re-checking a candidate costs about as much as 500 cells of the exact kernel: beyond this many
-        // the filter is not paying (a search with a very low Jaccard bound, say) and the exact kernel runs
-        const double cand_limit = std::max(4194304.0, block_cells / 128.0);
+        a.cand_limit = limit;
+        a.cand_stop = reinterpret_cast<unsigned int*>(c->d_counter + 32);
         for (int attempt = 0; attempt < 3; ++attempt) {
             a.cand = (int2*)c->pw_cand;
             a.cand_capacity = c->pw_cand_bytes / sizeof(int2);
             if (start == 0) {
-                HIP_TRY(hipMemsetAsync(c->d_counter, 0, 24, c->stream));   // cell count, (debug slot), candidate count
+                HIP_TRY(hipMemsetAsync(c->d_counter, 0, 264, c->stream));   // cell count, (debug slot), candidate count ... stop flag
             } else {
+                HIP_TRY(hipMemsetAsync(c->d_counter + 2, 0, 248, c->stream));
                 rc = set_count();
                 if (rc) return rc;
-                HIP_TRY(hipMemsetAsync(c->d_counter + 2, 0, 8, c->stream));
             }
             if (c->timing) HIP_TRY(hipEventRecord(c->ev[2], c->stream));
             rc = mvs::launch_filter(c->stream, a);
@@ -810,20 +818,14 @@ int pairwise_launch(mvs_ctx* c, const mvs_sketch_set* s, const double* d_n2, int
             HIP_TRY(hipStreamSynchronize(c->stream));
             const unsigned long long n_cand = back[2];
             c->last_candidates = n_cand;
-            if (n_cand <= a.cand_capacity) {
-                *count = back[0];
-                // this result stands; but with more than ~1/512 of the cells to re-check the exact kernel alone is
-                // the faster one (filter pass ~0.37 of it, a re-check ~330 cells' worth): use it from now on
-                if ((double)n_cand > block_cells / 512.0) {
-                    c->filter_off_id = s->id;
-                    c->filter_off_coeff = keep_coeff;
-                }
-                return MVS_OK;
-            }
-            if ((double)n_cand > cand_limit) {
+            if (n_cand > limit) {   // not paying: exact kernel now and for this set's later blocks
                 c->filter_off_id = s->id;
                 c->filter_off_coeff = keep_coeff;
                 break;
+            }
+            if (n_cand <= a.cand_capacity) {
+                *count = back[0];
+                return MVS_OK;
             }
             rc = ensure_buf(c, &c->pw_cand, &c->pw_cand_bytes, (size_t)n_cand * sizeof(int2));
             if (rc) return rc;

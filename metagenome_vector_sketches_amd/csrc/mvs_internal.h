@@ -60,6 +60,10 @@ struct PairwiseArgs {
     int2* cand;                   // candidate list: {row, col | mirror << 31}
     unsigned long long cand_capacity;
     unsigned long long* cand_counter;
+    unsigned long long cand_limit;   // once the counter is beyond this the remaining filter tiles and the re-check
+                                     // give up at once: the caller falls back to the exact kernel
+    unsigned int* cand_stop;         // set by the wave that takes the counter past the limit; lives on its own cache
+                                     // line (polling the counter itself queues behind its atomics)
 };
 
 // per-row statistics of the coarse plane: radix m, sum c^2, sum r^2 (r = v - m*c), and whether the row's sum

@@ -211,6 +211,9 @@ __global__ __launch_bounds__(WM * WN * 64, (AT * BT > 2 ? 1 : 2)) void k_pairwis
         if (j0 >= a.row_begin && j0 + TN <= i0) return;
         mirror_tile = j0 >= i0 + TM && j0 < a.row_end;
     }
+    if constexpr (MODE == 2) {   // the filter is not paying on this block (see cand_limit): stop wasting time
+        if (*reinterpret_cast<volatile const unsigned int*>(a.cand_stop) != 0u) return;
+    }
 
     // ---- per-lane source pointers of this wave's pieces (k0 = 0).  One piece = 16 LDS rows of 64 B;
     //      lane -> row piece*16 + lane/4, 16-byte slot lane%4 holding logical chunk slot ^ ((s>>2)&3).
@@ -450,7 +453,10 @@ __global__ __launch_bounds__(WM * WN * 64, (AT * BT > 2 ? 1 : 2)) void k_pairwis
             if (lane >= o) incl += up;
         }
         unsigned long long base = 0;
-        if (lane == 63) base = atomicAdd(a.cand_counter, (unsigned long long)incl);
+        if (lane == 63) {
+            base = atomicAdd(a.cand_counter, (unsigned long long)incl);
+            if (base + incl > a.cand_limit) *a.cand_stop = 1u;   // tell the tiles that have not started yet
+        }
         base = __shfl(base, 63, 64);
         unsigned long long slot = base + (incl - mine);
 #pragma unroll
@@ -980,6 +986,7 @@ __global__ __launch_bounds__(256) void k_exact_pairs(const PairwiseArgs a) {
     static_assert(B == 16 || B == 32 || B == 64, "pairs per round");
     const int lane = threadIdx.x & 63;
     unsigned long long n_cand = *a.cand_counter;
+    if (n_cand > a.cand_limit) return;   // the caller will run the exact kernel instead
     if (n_cand > a.cand_capacity) n_cand = a.cand_capacity;
     const unsigned long long waves = (unsigned long long)gridDim.x * 4;
     const unsigned long long wid = (unsigned long long)blockIdx.x * 4 + (threadIdx.x >> 6);
