@@ -61,3 +61,62 @@ def test_pairwise_random_cases(ctx, seed):
             got = [tuple(int(x) for x in c) for c in cells.tolist()]
             assert got == want, (seed, mode, b, e, len(got), len(want))
     ss.close()
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_blocks_and_search_two_stage_vs_exact(ctx, monkeypatch, seed):
+    """random rectangular blocks (plain, symmetric, mirror-all; both keep tests) and searches with random
+    bounds: the coarse filter + exact re-check, forced on, must produce the cells of the exact kernel"""
+    import torch
+    rng = np.random.default_rng(3000 + seed)
+    n = int(rng.integers(300, 1500))
+    d = int(rng.choice([100, 512, 1000, 2048]))
+    sizes = (10 ** rng.uniform(2.0, 5.0, n)).astype(np.int64)
+    base = rng.standard_normal((n // 6 + 1, d))
+    grp = rng.integers(0, len(base), n)
+    sk = np.empty((n, d), dtype=np.int64)
+    for i in range(n):
+        k = int(0.5 * sizes[i])
+        x = base[grp[i]] * np.sqrt(k) + rng.standard_normal(d) * np.sqrt(sizes[i] - k)
+        sk[i] = np.round((x - (sizes[i] & 1)) / 2) * 2 + (sizes[i] & 1)
+    sk = np.clip(sk, -32639, 32639).astype(np.int32)
+    sk[rng.integers(0, n)] = 0
+    n2 = np.array([orc.norm_sq_from_text(orc.format_norm(orc.norm(r))) for r in sk])
+    n2[rng.integers(0, n, size=n // 10)] *= rng.choice([0.5, 0.97, 1.03, 2.0])
+    ss = ctx.sketch_set(sk)
+    if ss.limbs != 2:
+        ss.close()
+        pytest.skip("needs two limbs")
+    n2_t = torch.from_numpy(n2).to("cuda")
+    cells_t = torch.empty((n * n + 16, 4), dtype=torch.int32, device="cuda")
+
+    def both(fn):
+        out = []
+        for f in ("2", "0"):
+            monkeypatch.setenv("MVS_PAIRWISE_FILTER", f)
+            cnt = fn()
+            ctx.synchronize()
+            out.append(sorted(map(tuple, cells_t[:cnt].cpu().numpy().tolist())))
+        assert out[0] == out[1]
+        return out[0]
+
+    for _ in range(6):
+        rb = int(rng.integers(0, n - 1))
+        re = int(rng.integers(rb + 1, n + 1))
+        kind = int(rng.integers(0, 3))
+        if kind == 1:                                   # symmetric: columns contain the square of the rows
+            cb, ce = int(rng.integers(0, rb + 1)), int(rng.integers(re, n + 1))
+            flags = _capi.BLOCK_SYMMETRIC
+        else:
+            cb = int(rng.integers(0, n - 1))
+            ce = int(rng.integers(cb + 1, n + 1))
+            flags = _capi.BLOCK_MIRROR_ALL if kind == 2 else 0
+        mode = _capi.KEEP_INT32 if rng.integers(0, 2) else _capi.KEEP_INT16
+        got = both(lambda: ctx.pairwise_block(ss, n2_t, rb, re, cb, ce, flags, cells_t, 0, keep_mode=mode))
+        if flags == 0 and mode == _capi.KEEP_INT32:     # and the oracle on the plain int32 blocks
+            want = orc.pairwise_rows(sk, n2, row_begin=rb, row_end=re, chunk=192, threads=8)
+            assert got == sorted(t for t in map(tuple, want.tolist()) if cb <= t[1] < ce)
+    for j in (0.02, 0.1, 0.5):
+        q0 = int(rng.integers(0, n - 8))
+        both(lambda: ctx.search_block(ss, n2_t, j, q0, q0 + 8, 0, n, cells_t))
+    ss.close()
