@@ -9,15 +9,21 @@
 // MI355X design (DESIGN.md "K2"):
 //   * sketches live in HBM as signed base-256 int8 limb planes, planes[(row*L + limb)*d_pad + k];
 //     v == sum_a limb_a*256^a (mod 2^32), so P == sum_{a+b<=3} 256^(a+b) * <limb_a(i), limb_b(j)> (mod 2^32);
-//   * each limb-pair product runs on the int8 matrix cores (v_mfma_i32_32x32x32_i8, exact int32
+//   * each limb-pair product runs on the int8 matrix cores (v_mfma_i32_16x16x64_i8 / 32x32x32, exact int32
 //     accumulation: |sum| <= 2 * 128*128*d_pad < 2^31 for d_pad <= 32768);
-//   * workgroup = 512 threads = 8 waves (2 x 4), tile = 128 x 128 samples, k-slices of 128 bytes are
-//     copied HBM -> LDS with global_load_lds (16 B per lane, no VGPR round trip) into a two-stage ring;
-//     the LDS image is [limb][sample][128 B] with the 16-byte chunks XOR-swizzled by (sample>>1)&7 on the
-//     SOURCE address side so that the ds_read_b128 fragment reads are bank-conflict free;
-//   * the epilogue recombines the limb products, rejects almost every cell with one integer compare
-//     against a conservative per-sample threshold sum, and runs the reference's fp64 keep test / Jaccard
-//     only on the survivors, which are appended (wave-aggregated atomic) to the kept-cell list;
+//   * workgroup = 512 threads = 8 waves, tile = 128 x 128 (or 256 x 256) samples, k-slices of 64 bytes are
+//     copied HBM/L2 -> LDS with global_load_lds (16 B per lane, no VGPR round trip) into a 4-stage ring;
+//     the LDS image is [limb][sample][64 B] with the 16-byte chunks XOR-swizzled on the SOURCE address side
+//     so that the ds_read_b128 fragment reads are bank-conflict free;
+//   * TWO-STAGE comparison (default for two limbs): the same MFMA kernel first runs ONE pass on a coarse int8
+//     plane c = round(v / m_row) and drops every pair a proven bound rules out (MODE 2, "filter" below); the
+//     surviving candidate pairs get their exact int32 dot from the limb planes in k_exact_pairs, followed
+//     by the reference's fp64 keep test and Jaccard.  The exact kernel on every cell (MODE 0) remains for
+//     other limb counts, dense results and MVS_PAIRWISE_FILTER=0: its epilogue recombines the limb products,
+//     rejects almost every cell with one integer compare against a conservative per-sample threshold sum and
+//     runs the fp64 test only on the survivors;
+//   * kept cells / candidates are appended with one atomic per wave and tile (masks parked in LDS, wave
+//     prefix sum), then sorted by (row, col);
 //   * workgroup -> tile mapping walks 16 x 16-tile super-patches, each of the 8 XCDs (blockIdx % 8)
 //     taking a 4 x 8 sub-patch, so that one XCD's L2 serves 12 operand panels to 32 tiles.
 #include "mvs_internal.h"
