@@ -88,6 +88,30 @@ int main(int argc, char* argv[]) {
         for (size_t i = 0; i < cells.size(); ++i)
             CHECK(back[i].row == cells[i].row && back[i].col == cells[i].col && back[i].q == cells[i].q);
     }
+    {   // many rows: the multi-threaded writer produces the single-threaded writer's files byte for byte
+        std::vector<mvs_cell> cells;
+        for (int r = 0; r < 40000; ++r) {
+            const int cnt = r % 5 == 0 ? 1 : 1 + (int)(rng() % 20);
+            int col = (int)(rng() % 50);
+            for (int k = 0; k < cnt; ++k) {
+                cells.push_back(mvs_cell{r, col, 0, (int32_t)(13 + rng() % 243)});
+                col += 1 + (int)(rng() % 1000);
+            }
+        }
+        auto slurp = [](const std::string& f) {
+            std::ifstream in(f, std::ios::binary);
+            return std::string((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+        };
+        const mvs_host::ShardStats s1 = mvs_host::write_shard(dir + "one/", cells.data(), cells.size(), 1);
+        const mvs_host::ShardStats s4 = mvs_host::write_shard(dir + "many/", cells.data(), cells.size(), 7);
+        CHECK(s1.jac_space == s4.jac_space && s1.ngh_space == s4.ngh_space && s1.rows == s4.rows && s1.rows == 40000);
+        for (const char* f : {"matrix.bin", "row_index.bin", "neighbor_start.bin"})
+            CHECK(slurp(dir + "one/" + f) == slurp(dir + "many/" + f) && !slurp(dir + "one/" + f).empty());
+        std::vector<mvs_cell> back;
+        CHECK(mvs_host::read_shard(dir + "many/", back) && back.size() == cells.size());
+        for (size_t i = 0; i < cells.size(); i += 97)
+            CHECK(back[i].row == cells[i].row && back[i].col == cells[i].col && back[i].q == cells[i].q);
+    }
     std::filesystem::remove_all(dir);
     // hash text parsing: dedup, stop at the first bad token, lines without ':' skipped
     {

@@ -229,42 +229,84 @@ struct ShardStats {
 };
 
 // cells must be grouped by row with ascending columns inside a row (mvs_pairwise_rows order).
+// threads: 0 = all host threads (rows are encoded independently).
 // Rows are written in ascending order (the reference iterates a std::unordered_map, i.e. in an
 // unspecified order; its reader builds a map and accepts any order).
-inline ShardStats write_shard(const std::string& folder, const mvs_cell* cells, size_t n_cells) {
+inline ShardStats write_shard(const std::string& folder, const mvs_cell* cells, size_t n_cells,
+                              unsigned threads = 0) {
     if (!fs::exists(folder)) fs::create_directories(folder);
     std::ofstream bin_out(folder + "matrix.bin", std::ios::binary);
     std::ofstream index_out(folder + "row_index.bin", std::ios::binary);
-    std::vector<uint32_t> row_vec, start_neighbor;
-    std::vector<uint64_t> curr_pos_vec;
-    ShardStats st;
-    size_t i = 0;
-    while (i < n_cells) {
-        size_t j = i;
-        while (j < n_cells && cells[j].row == cells[i].row) ++j;
-        row_vec.push_back((uint32_t)cells[i].row);
-        curr_pos_vec.push_back((uint64_t)bin_out.tellp());
-        start_neighbor.push_back((uint32_t)cells[i].col);
-        std::vector<uint16_t> jac(j - i);
-        std::vector<uint64_t> delta(j - i - 1);
-        for (size_t k = i; k < j; ++k) {
-            jac[k - i] = (uint16_t)cells[k].q;
-            if (k > i) {
-                if (cells[k].col <= cells[k - 1].col) throw std::runtime_error("write_shard: columns not ascending");
-                delta[k - i - 1] = (uint64_t)(cells[k].col - cells[k - 1].col);
+    // row table (first cell of every row), then the rows are encoded by workers, each a contiguous run of
+    // rows into its own buffer; the buffers are written out in order, so the file is the one a single
+    // thread would write
+    std::vector<size_t> row_first;
+    for (size_t i = 0; i < n_cells; ++i)
+        if (i == 0 || cells[i].row != cells[i - 1].row) row_first.push_back(i);
+    const size_t n_rows = row_first.size();
+    row_first.push_back(n_cells);
+    std::vector<uint32_t> row_vec(n_rows), start_neighbor(n_rows);
+    std::vector<uint64_t> curr_pos_vec(n_rows);
+    if (threads == 0) threads = std::max(1u, std::thread::hardware_concurrency());
+    threads = (unsigned)std::min<size_t>(threads, std::max<size_t>(1, n_rows / 4096));
+    threads = std::max(1u, threads);
+    struct Part {
+        std::string bytes;
+        uint64_t jac_space = 0, ngh_space = 0;
+        std::string error;
+    };
+    std::vector<Part> parts(threads);
+    auto work = [&](unsigned t) {
+        Part& part = parts[t];
+        std::ostringstream os(std::ios::binary);
+        const size_t r0 = n_rows * t / threads, r1 = n_rows * (t + 1) / threads;
+        for (size_t r = r0; r < r1; ++r) {
+            const size_t i = row_first[r], j = row_first[r + 1];
+            row_vec[r] = (uint32_t)cells[i].row;
+            curr_pos_vec[r] = (uint64_t)os.tellp();             // relative to this part; rebased below
+            start_neighbor[r] = (uint32_t)cells[i].col;
+            std::vector<uint16_t> jac(j - i);
+            std::vector<uint64_t> delta(j - i - 1);
+            for (size_t k = i; k < j; ++k) {
+                jac[k - i] = (uint16_t)cells[k].q;
+                if (k > i) {
+                    if (cells[k].col <= cells[k - 1].col) {
+                        part.error = "write_shard: columns not ascending";
+                        return;
+                    }
+                    delta[k - i - 1] = (uint64_t)(cells[k].col - cells[k - 1].col);
+                }
+            }
+            mvs_codec::compact_vector cv_jc;
+            cv_jc.build(jac.begin(), jac.size());
+            cv_jc.save(os);
+            part.jac_space += cv_jc.num_bytes();
+            if (jac.size() > 1) {                     // :732 a single-entry row has no delta sequence
+                mvs_codec::rice_sequence rs_delta;
+                rs_delta.encode(delta.begin(), delta.size());
+                rs_delta.save(os);
+                part.ngh_space += rs_delta.num_bytes();
             }
         }
-        mvs_codec::compact_vector cv_jc;
-        cv_jc.build(jac.begin(), jac.size());
-        cv_jc.save(bin_out);
-        st.jac_space += cv_jc.num_bytes();
-        if (jac.size() > 1) {                     // :732 a single-entry row has no delta sequence
-            mvs_codec::rice_sequence rs_delta;
-            rs_delta.encode(delta.begin(), delta.size());
-            rs_delta.save(bin_out);
-            st.ngh_space += rs_delta.num_bytes();
-        }
-        i = j;
+        part.bytes = os.str();
+    };
+    if (threads == 1) {
+        work(0);
+    } else {
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < threads; ++t) pool.emplace_back(work, t);
+        for (auto& th : pool) th.join();
+    }
+    ShardStats st;
+    uint64_t base = 0;
+    for (unsigned t = 0; t < threads; ++t) {
+        if (!parts[t].error.empty()) throw std::runtime_error(parts[t].error);
+        const size_t r0 = n_rows * t / threads, r1 = n_rows * (t + 1) / threads;
+        for (size_t r = r0; r < r1; ++r) curr_pos_vec[r] += base;
+        bin_out.write(parts[t].bytes.data(), (std::streamsize)parts[t].bytes.size());
+        base += parts[t].bytes.size();
+        st.jac_space += parts[t].jac_space;
+        st.ngh_space += parts[t].ngh_space;
     }
     bin_out.close();
     st.rows = row_vec.size();
