@@ -167,6 +167,11 @@ int mvs_sketch_set_from_planes(mvs_ctx* ctx, const int8_t* planes, int64_t n, in
 int mvs_sketch_set_alloc(mvs_ctx* ctx, int64_t n, int d, int limbs, mvs_sketch_set** set);
 int mvs_sketch_set_fill(mvs_sketch_set* set, const void* sketches, int elem_bytes, int mem, int64_t row_offset,
                         int64_t n_rows);
+/* mvs_sketch_set_fill that also reports the largest |v| of the rows it was given (same upload).  A loader can
+ * then stream a database ONCE: allocate for two limbs, fill, and only if some chunk reports |v| beyond what the
+ * set's limb count holds (mvs_limbs_for_max_abs) start over with more limbs. */
+int mvs_sketch_set_fill_stats(mvs_sketch_set* set, const void* sketches, int elem_bytes, int mem,
+                              int64_t row_offset, int64_t n_rows, int64_t* max_abs);
 int mvs_sketch_set_info(const mvs_sketch_set* set, int64_t* n, int* d, int* limbs, int64_t* n_alloc,
                         int* d_pad);
 int mvs_sketch_set_destroy(mvs_sketch_set* set);

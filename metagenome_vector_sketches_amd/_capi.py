@@ -52,6 +52,7 @@ SYMBOLS = [
                                                _c.POINTER(_P)]),
     ("mvs_sketch_set_alloc", _c.c_int, [_P, _c.c_int64, _c.c_int, _c.c_int, _c.POINTER(_P)]),
     ("mvs_sketch_set_fill", _c.c_int, [_P, _P, _c.c_int, _c.c_int, _c.c_int64, _c.c_int64]),
+    ("mvs_sketch_set_fill_stats", _c.c_int, [_P, _P, _c.c_int, _c.c_int, _c.c_int64, _c.c_int64, _c.POINTER(_c.c_int64)]),
     ("mvs_sketch_set_info", _c.c_int, [_P, _c.POINTER(_c.c_int64), _c.POINTER(_c.c_int), _c.POINTER(_c.c_int),
                                         _c.POINTER(_c.c_int64), _c.POINTER(_c.c_int)]),
     ("mvs_sketch_set_destroy", _c.c_int, [_P]),

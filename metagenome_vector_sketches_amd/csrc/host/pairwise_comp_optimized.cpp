@@ -91,7 +91,7 @@ static int gpu_fail(const char* what) {
 }
 
 // vectors.bin goes through the device in row chunks straight from the page cache (the file is mapped, the
-// library copies from the mapping): pass 1 finds the limb count, pass 2 re-codes into the limb planes
+// library copies from the mapping) and is re-coded into the limb planes
 static int load_db(Gpu& g, const std::string& matrix_file, int elem_bytes, int64_t n, int d) {
     const int64_t row_bytes = (int64_t)d * elem_bytes;
     const int64_t chunk_rows = std::max<int64_t>(1, (1LL << 30) / row_bytes);
@@ -113,23 +113,35 @@ static int load_db(Gpu& g, const std::string& matrix_file, int elem_bytes, int64
         base = (const char*)m;
     }
     ::close(fd);
+    // One pass in the common case: the planes are allocated for two limbs (|v| <= 32639, i.e. samples of up to tens
+    // of millions of hashes) and every chunk reports its largest |v| with the same upload; only if a chunk needs
+    // more limbs than the set has does the load start over with the limb count the data seen so far asks for.
     int rc = 0;
-    int64_t max_abs = 0;
-    for (int pass = 0; pass < 2 && !rc; ++pass) {
-        if (pass == 1 && mvs_sketch_set_alloc(g.ctx, n, d, mvs_limbs_for_max_abs(max_abs), &g.set) != MVS_OK)
+    int limbs = 2;
+    for (int attempt = 0; attempt < 4 && !rc; ++attempt) {
+        if (g.set) {
+            mvs_sketch_set_destroy(g.set);
+            g.set = nullptr;
+        }
+        if (mvs_sketch_set_alloc(g.ctx, n, d, limbs, &g.set) != MVS_OK) {
             rc = gpu_fail("allocating sketch set");
+            break;
+        }
+        int64_t max_abs = 0;
+        bool restart = false;
         for (int64_t r0 = 0; r0 < n && !rc; r0 += chunk_rows) {
             const int64_t rows = std::min(chunk_rows, n - r0);
-            const char* src = base + r0 * row_bytes;
-            if (pass == 0) {
-                int64_t m = 0;
-                if (mvs_sketch_max_abs(g.ctx, src, elem_bytes, MVS_MEM_HOST, rows * d, &m) != MVS_OK)
-                    rc = gpu_fail("scanning vectors.bin");
-                max_abs = std::max(max_abs, m);
-            } else if (mvs_sketch_set_fill(g.set, src, elem_bytes, MVS_MEM_HOST, r0, rows) != MVS_OK) {
+            int64_t m = 0;
+            if (mvs_sketch_set_fill_stats(g.set, base + r0 * row_bytes, elem_bytes, MVS_MEM_HOST, r0, rows, &m) != MVS_OK)
                 rc = gpu_fail("re-coding vectors.bin");
+            max_abs = std::max(max_abs, m);
+            if (mvs_limbs_for_max_abs(max_abs) > limbs) {
+                restart = true;
+                break;
             }
         }
+        if (!restart) break;
+        limbs = mvs_limbs_for_max_abs(max_abs);
     }
     if (bytes) ::munmap((void*)base, bytes);
     return rc;

@@ -28,6 +28,7 @@ struct mvs_ctx {
     void* pw_tmp = nullptr;   size_t pw_tmp_bytes = 0;
     void* pw_sort = nullptr;  size_t pw_sort_bytes = 0;
     void* pw_out = nullptr;   size_t pw_out_bytes = 0;
+    void* stage = nullptr;    size_t stage_bytes = 0;   // host sketches on their way to the limb planes
     // two-stage comparison: coarse plane + row statistics of the set `coarse_id` (generation `coarse_gen`),
     // per-call filter constants, candidate list
     void* pw_coarse = nullptr;  size_t pw_coarse_bytes = 0;
@@ -207,6 +208,7 @@ int mvs_ctx_destroy(mvs_ctx* c) {
     if (c->pw_tmp) (void)hipFree(c->pw_tmp);
     if (c->pw_sort) (void)hipFree(c->pw_sort);
     if (c->pw_out) (void)hipFree(c->pw_out);
+    if (c->stage) (void)hipFree(c->stage);
     if (c->pw_coarse) (void)hipFree(c->pw_coarse);
     if (c->pw_rows) (void)hipFree(c->pw_rows);
     if (c->pw_fmeta) (void)hipFree(c->pw_fmeta);
@@ -478,12 +480,12 @@ int mvs_sketch_max_abs(mvs_ctx* c, const void* sketches, int elem_bytes, int mem
     if (n_elems == 0) return MVS_OK;
     if (!sketches) return fail(MVS_E_INVALID, "sketches is NULL");
     HIP_TRY(hipSetDevice(c->device));
-    DevBuf din;
     const void* d_in = sketches;
     if (mem == MVS_MEM_HOST) {
-        HIP_TRY(din.alloc((size_t)n_elems * elem_bytes));
-        HIP_TRY(hipMemcpyAsync(din.p, sketches, (size_t)n_elems * elem_bytes, hipMemcpyHostToDevice, c->stream));
-        d_in = din.p;
+        int rc0 = ensure_buf(c, &c->stage, &c->stage_bytes, (size_t)n_elems * elem_bytes);
+        if (rc0) return rc0;
+        HIP_TRY(hipMemcpyAsync(c->stage, sketches, (size_t)n_elems * elem_bytes, hipMemcpyHostToDevice, c->stream));
+        d_in = c->stage;
     }
     HIP_TRY(hipMemsetAsync(c->d_counter, 0, 8, c->stream));
     mvs::launch_max_abs(c->stream, d_in, elem_bytes, n_elems, c->d_counter);
@@ -535,12 +537,12 @@ int mvs_limb_split(mvs_ctx* c, const void* sketches, int elem_bytes, int mem, in
     if (n_rows == 0) return MVS_OK;
     if (!sketches || !planes) return fail(MVS_E_INVALID, "NULL buffer");
     HIP_TRY(hipSetDevice(c->device));
-    DevBuf din;
     const void* d_in = sketches;
-    if (mem == MVS_MEM_HOST) {
-        HIP_TRY(din.alloc((size_t)n_rows * d * elem_bytes));
-        HIP_TRY(hipMemcpyAsync(din.p, sketches, (size_t)n_rows * d * elem_bytes, hipMemcpyHostToDevice, c->stream));
-        d_in = din.p;
+    if (mem == MVS_MEM_HOST) {   // grow-only staging buffer of the context (no allocation per chunk)
+        int rc0 = ensure_buf(c, &c->stage, &c->stage_bytes, (size_t)n_rows * d * elem_bytes);
+        if (rc0) return rc0;
+        HIP_TRY(hipMemcpyAsync(c->stage, sketches, (size_t)n_rows * d * elem_bytes, hipMemcpyHostToDevice, c->stream));
+        d_in = c->stage;
     }
     mvs::launch_limb_split(c->stream, d_in, elem_bytes, n_rows, d, limbs, planes, d_pad, row_offset);
     int rc = check_kernel("k_limb_split");
@@ -668,6 +670,42 @@ int mvs_sketch_set_fill(mvs_sketch_set* s, const void* sketches, int elem_bytes,
                     (long long)(row_offset + n_rows));
     ++s->gen;   // derived data (coarse plane) of the old contents is stale
     return mvs_limb_split(s->ctx, sketches, elem_bytes, mem, n_rows, s->d, s->limbs, s->owned, s->d_pad, row_offset);
+}
+
+int mvs_sketch_set_fill_stats(mvs_sketch_set* s, const void* sketches, int elem_bytes, int mem, int64_t row_offset,
+                              int64_t n_rows, int64_t* max_abs) {
+    if (!s || !s->owned) return fail(MVS_E_INVALID, "set is NULL or not owned by the library");
+    if (!max_abs) return fail(MVS_E_INVALID, "max_abs is NULL");
+    *max_abs = 0;
+    if ((elem_bytes != 4 && elem_bytes != 2) || !mem_ok(mem)) return fail(MVS_E_INVALID, "bad argument");
+    if (row_offset < 0 || n_rows < 0 || row_offset + n_rows > s->n)
+        return fail(MVS_E_INVALID, "rows [%lld,%lld) outside the set", (long long)row_offset,
+                    (long long)(row_offset + n_rows));
+    if (n_rows == 0) return MVS_OK;
+    if (!sketches) return fail(MVS_E_INVALID, "sketches is NULL");
+    mvs_ctx* c = s->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t bytes = (size_t)n_rows * s->d * elem_bytes;
+    const void* d_in = sketches;
+    if (mem == MVS_MEM_HOST) {   // one upload serves both kernels
+        int rc0 = ensure_buf(c, &c->stage, &c->stage_bytes, bytes);
+        if (rc0) return rc0;
+        HIP_TRY(hipMemcpyAsync(c->stage, sketches, bytes, hipMemcpyHostToDevice, c->stream));
+        d_in = c->stage;
+    }
+    ++s->gen;
+    HIP_TRY(hipMemsetAsync(c->d_counter, 0, 8, c->stream));
+    mvs::launch_max_abs(c->stream, d_in, elem_bytes, n_rows * s->d, c->d_counter);
+    int rc = check_kernel("k_max_abs");
+    if (rc) return rc;
+    mvs::launch_limb_split(c->stream, d_in, elem_bytes, n_rows, s->d, s->limbs, s->owned, s->d_pad, row_offset);
+    rc = check_kernel("k_limb_split");
+    if (rc) return rc;
+    unsigned long long m = 0;
+    HIP_TRY(hipMemcpyAsync(&m, c->d_counter, 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    *max_abs = (int64_t)m;
+    return MVS_OK;
 }
 
 int mvs_sketch_set_info(const mvs_sketch_set* s, int64_t* n, int* d, int* limbs, int64_t* n_alloc, int* d_pad) {

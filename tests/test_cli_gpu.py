@@ -306,3 +306,26 @@ def test_sketch_cli_vs_reference_binary_random(tmp_path):
     os.makedirs(out, exist_ok=True)
     json.dump({"samples": n, "hashes": int(sizes.sum()), "d": 1024, "threads": threads, "seconds": t},
               open(os.path.join(out, "cli_vs_reference.json"), "w"))
+
+
+def test_pairwise_db_that_needs_more_limbs(tmp_path):
+    """the loader starts with two limbs and starts over when a later chunk holds |v| > 32639"""
+    from oracle import pyoracle as orc
+    rng = np.random.default_rng(77)
+    n, d = 90, 128
+    sk = rng.integers(-3000, 3000, (n, d)).astype(np.int32)
+    sk[60:] = sk[:30] * 1                      # related rows
+    sk[85, 5] = 40000                          # one entry beyond two limbs, late in the file
+    db = tmp_path / "db"
+    db.mkdir()
+    sk.astype("<i4").tofile(str(db / "vectors.bin"))
+    with open(str(db / "vector_norms.txt"), "w") as f:
+        for i, r in enumerate(sk):
+            f.write("s%d %s\n" % (i, orc.format_norm(orc.norm(r))))
+    (db / "dimension.txt").write_text("%d\n" % d)
+    n2 = np.array([orc.norm_sq_from_text(orc.format_norm(orc.norm(r))) for r in sk])
+    r = run(os.path.join(BIN, "pairwise_comp_optimized"), "--db", str(db) + "/", "--max_memory_gb", "1", "--num_threads",
+            "1", "--output_folder", str(tmp_path / "idx"), "--num_shards", "1", "--shard_idx", "0")
+    assert r.returncode == 0, r.stderr
+    want = orc.pairwise_rows(sk, n2, chunk=192, threads=4)
+    assert _dump(str(tmp_path / "idx" / "shard_0")) == sorted((int(c["row"]), int(c["col"]), int(c["q"])) for c in want)
