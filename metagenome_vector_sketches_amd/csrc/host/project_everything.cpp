@@ -5,6 +5,7 @@
 //   project_everything sketch  <hash_file> <index_folder> [-t/--threads N] [-d/--dimension D] [--int16]
 //   project_everything convert <signature_folder> <hash_file> [-t/--threads N]      (host only, zlib)
 #include <chrono>
+#include <thread>
 #include <mutex>
 
 #include "mvs_host.hpp"
@@ -101,17 +102,26 @@ static int sketch(const std::string& hash_file, std::string index_folder, int di
     }
     auto start = std::chrono::high_resolution_clock::now();                                            // :255
 
+    // the device context (0.1-0.2 s of runtime start-up) comes up while the text is parsed
+    mvs_ctx* ctx = nullptr;
+    int ctx_rc = MVS_OK;
+    std::string ctx_err;
+    std::thread ctx_thread([&]() {
+        ctx_rc = mvs_ctx_create(pick_device(), &ctx);
+        if (ctx_rc != MVS_OK) ctx_err = mvs_last_error();   // the message is per thread
+    });
     HashSets sets;
-    if (!read_hash_file(hash_file, true, sets)) {                                                      // :258-262
+    const bool parsed = read_hash_file(hash_file, true, sets);
+    ctx_thread.join();
+    if (!parsed) {                                                                                     // :258-262
         std::cerr << "Error opening " << hash_file << " for reading." << std::endl;
+        if (ctx) mvs_ctx_destroy(ctx);
         return 0;   // the reference returns from sketch() and exits 0
     }
     const int64_t n = (int64_t)sets.names.size();
     std::cout << "Loaded " << n << " hash sets from " << hash_file << std::endl;                       // :284
-
-    mvs_ctx* ctx = nullptr;
-    if (mvs_ctx_create(pick_device(), &ctx) != MVS_OK) {
-        std::cerr << "project_everything: " << mvs_last_error() << std::endl;
+    if (ctx_rc != MVS_OK) {
+        std::cerr << "project_everything: " << ctx_err << std::endl;
         return 2;
     }
     std::vector<int32_t> vectors((size_t)n * (size_t)dimension);
