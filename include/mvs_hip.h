@@ -178,7 +178,9 @@ int mvs_sketch_set_destroy(mvs_sketch_set* set);
 
 /* All-vs-all for the row range [row_begin, row_end) against ALL n columns -- one shard of
  * src/pairwise_comp_optimized.cpp:938-982.
- *   norms_sq : n doubles, (parsed norm)^2 as built at :893-901 (`mem_norms` says where).
+ *   norms_sq : n doubles, (parsed norm)^2 as built at :893-901 (`mem_norms` says where): squares, so >= 0,
+ *              or nan / inf if the text said so (such a sample keeps nothing, as in the reference);
+ *              negative values are outside the contract.
  *   keep_mode: MVS_KEEP_INT32 or MVS_KEEP_INT16.
  *   cells    : capacity entries (`mem_cells`); on success holds *n_cells kept cells sorted by
  *              (row, col) -- the per-row, ascending-column order the reference's writer relies on

@@ -975,7 +975,10 @@ __global__ __launch_bounds__(256) void k_filter_meta(const CoarseRow* __restrict
         const double m = (double)st.radix;
         const double eps = 1.0 / 4096.0;
         const double tau = coeff * (double)d * n2[i] / m;          // NaN stays NaN: such a row is never kept
-        o.x = st.big ? -__builtin_inff() : (float)(tau - fabs(tau) * eps);   // big rows: dots may wrap, always re-check
+        // big rows: dots may wrap, always re-check.  Negative squared norms (never produced by the reference's
+        // loader, but callers pass arbitrary doubles) too: with a negative threshold the truncating keep test no
+        // longer implies P > d * threshold.
+        o.x = (st.big || n2[i] < 0.0) ? -__builtin_inff() : (float)(tau - fabs(tau) * eps);
         o.y = (float)(1.0 / m);
         o.z = (float)(sqrt((double)st.c2) * (1.0 + eps));
         o.w = (float)(sqrt((double)st.r2) / m * (1.0 + eps));

@@ -472,3 +472,25 @@ def test_baseline_config3_and_4_full_size(ctx, monkeypatch, d):
     want = _oracle_sorted(sk_all, n2, row_begin=rows_chk.start, row_end=rows_chk.stop, chunk=192)
     got = [tuple(int(x) for x in c) for c in two[(rows >= rows_chk.start) & (rows < rows_chk.stop)]]
     assert got == want and np.array_equal(sk_rows, sk_all[rows_chk])
+
+
+def test_nan_and_infinite_norms(ctx, monkeypatch):
+    """a norm that parsed as nan or inf ("nan" in vector_norms.txt) makes every threshold of that row nan / inf:
+    the reference keeps nothing in its row and column; both comparison paths agree with the oracle"""
+    d = 256
+    rng = np.random.default_rng(41)
+    sk = rng.integers(-300, 300, (200, d)).astype(np.int32)
+    sk[100:] = sk[:100]
+    n2 = _n2_from_sketches(sk)
+    n2[[3, 50]] = np.nan
+    n2[[51, 120]] = np.inf
+    ss = ctx.sketch_set(sk)
+    for keep in (_capi.KEEP_INT32, _capi.KEEP_INT16):
+        skx = sk if keep == _capi.KEEP_INT32 else sk.astype(np.int16)
+        want = _oracle_sorted(skx, n2, chunk=192)
+        assert not any(r in (3, 50, 51, 120) or c in (3, 50, 51, 120) for r, c, _, _ in want) and len(want) > 300
+        for f in ("2", "0"):
+            monkeypatch.setenv("MVS_PAIRWISE_FILTER", f)
+            got, _ = ctx.pairwise_rows(ss, n2, keep_mode=keep)
+            assert _cells_tuple(got) == want
+    ss.close()
