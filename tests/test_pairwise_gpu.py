@@ -308,7 +308,8 @@ def _random_rows(rng, n, d, kind):
 
 
 @pytest.mark.parametrize("kind,n,d", [("mixed", 700, 2048), ("mixed", 500, 4096), ("mixed", 900, 100),
-                                      ("peaky", 600, 2048), ("flat", 400, 512), ("mixed", 1500, 1024)])
+                                      ("peaky", 600, 2048), ("flat", 400, 512), ("mixed", 1500, 1024),
+                                      ("mixed", 300, 8192), ("mixed", 260, 32768)])
 @pytest.mark.parametrize("mode", ["int32", "int16"])
 def test_two_stage_equals_exact_and_oracle(ctx, monkeypatch, kind, n, d, mode):
     """the coarse filter may only drop pairs the keep test rejects: same cells as the exact kernel and the
