@@ -184,7 +184,7 @@ def main():
     # this process); only valid for the default workload on one GPU
     traffic = {"k_project": None, "k_pairwise_mfma": None}
     try:
-        if (S, NH, D, world) == (10_000, 50_000, 2048, 1):
+        if (S, NH, D, world, args.cluster, args.lognormal_sigma) == (10_000, 50_000, 2048, 1, 16, 0.0):   # the profiled workload
             with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
                 pmc = json.load(f)
             traffic = {k: pmc[k]["hbm_bytes_per_launch_corrected"] for k in traffic}
