@@ -76,10 +76,31 @@ int mvs_ctx_set_stream(mvs_ctx* ctx, void* hip_stream);
 int mvs_ctx_use_own_stream(mvs_ctx* ctx);
 int mvs_ctx_synchronize(mvs_ctx* ctx);
 /* Optional kernel timing: when enabled, HIP events are recorded on the context's stream around the
- * dominant kernel of mvs_project_csr (which = 0) and of mvs_pairwise_rows (which = 1);
- * mvs_ctx_kernel_ms returns the duration of the most recent such launch in milliseconds. */
+ * dominant kernel of mvs_project_csr (which = 0) and around the comparison kernels of mvs_pairwise_rows /
+ * _block / mvs_search_block (which = 1: the whole comparison -- filter + re-check, or the exact kernel;
+ * which = 2: the filter kernel alone; which = 3: the re-check kernel alone; 2 and 3 are only recorded by a
+ * two-stage comparison).  mvs_ctx_kernel_ms returns the duration of the most recent such launch in ms. */
 int mvs_ctx_set_timing(mvs_ctx* ctx, int enabled);
 int mvs_ctx_kernel_ms(mvs_ctx* ctx, int which, float* ms);
+/* Tuning / diagnostic options of a context, by name.  The library reads the environment exactly once per
+ * context, in mvs_ctx_create: MVS_<NAME> (upper case) gives an option's initial value; afterwards only
+ * mvs_ctx_set_option changes it, so two contexts (or two threads with a context each) never interfere.
+ *   pairwise_filter       0 exact kernel on every cell; 1 (default) two-stage comparison for blocks of at least
+ *                         2^22 cells of a two-limb set; 2 two-stage whenever the set has two limbs (tests)
+ *   filter_variant        tile shape of the one-pass filter: -1 (default) by block size, 0 = 128 x 128,
+ *                         1 = 256 x 256, 3/5/6 other shapes / ring depths
+ *   exact_variant         re-check kernel: 0 (default) 64 pairs per wave round, 1 quarter wave per pair, 2 16 per round
+ *   pairwise_variant      exact kernel: 6 (default) 16x16x64 MFMA for two limbs, 0-5 32x32x32 tile / ring variants
+ *   pairwise_symmetric    1 (default) skip tiles below the diagonal and mirror; 0 compute every tile
+ *   pairwise_block_cells  row-chunk bound of mvs_pairwise_rows, in cells (default 2^40)
+ *   sort                  kept-cell sort: 0 (default) by list length, 1 merge sort, 2 radix sort
+ *   enable_k3             1: mvs_sketch_set_create codes sets with 127 < max|v| <= 8127 as MVS_LIMBS_K3
+ *   pairwise_debug        k-loop / epilogue ablations for profiling; rejected unless the library was built with
+ *                         -DMVS_ABLATIONS (make -C csrc ablations): such runs produce garbage by design
+ * Unknown names and out-of-range values return MVS_E_INVALID.  None of them changes a result. */
+int mvs_ctx_set_option(mvs_ctx* ctx, const char* name, int64_t value);
+int mvs_ctx_get_option(const mvs_ctx* ctx, const char* name, int64_t* value);
+
 /* Diagnostics of the most recent comparison (mvs_pairwise_rows / _block / mvs_search_block): the number
  * of candidate pairs its coarse filter passed on to the exact re-check, 0 if the exact kernel ran on
  * every cell (see mvs_pairwise_rows). */
@@ -139,8 +160,8 @@ int mvs_sketch_saturate_i16(mvs_ctx* ctx, const int32_t* sketches, int mem_in, i
 /* Largest |v| over n*d sketch entries (elem_bytes 4: int32, 2: int16); synchronous. */
 int mvs_sketch_max_abs(mvs_ctx* ctx, const void* sketches, int elem_bytes, int mem, int64_t n_elems,
                        int64_t* max_abs);
-/* Limb code for entries up to max_abs: 1 (<=127), 2 (<=32639), 3, or 4; with MVS_ENABLE_K3=1 in the
- * environment MVS_LIMBS_K3 is chosen for 128..8127 (it measures slower than 2 on MI355X, so it is opt-in). */
+/* Limb code for entries up to max_abs: 1 (<=127), 2 (<=32639), 3, or 4.  (MVS_LIMBS_K3 is never chosen here: it
+ * measures slower than 2 on MI355X; option enable_k3 makes mvs_sketch_set_create use it for 128..8127.) */
 int mvs_limbs_for_max_abs(int64_t max_abs);
 /* Geometry of the limb-plane buffer for n samples: rows are padded to n_alloc (multiple of 256,
  * plus one spare tile), the dimension to d_pad (multiple of 128); layout is
@@ -191,8 +212,8 @@ int mvs_sketch_set_destroy(mvs_sketch_set* set);
  * limbs are compared in two stages -- a one-pass int8 filter on a coarse plane with a proven error bound
  * drops the pairs that cannot pass the keep test, the exact int32 dot and the reference's keep test run on
  * the survivors (rows whose sum of squares reaches 2^31, whose dots may wrap, are re-checked against every
- * column) -- everything else goes through the exact kernel cell by cell (environment MVS_PAIRWISE_FILTER=0 forces that, =2 forces the two stages on small blocks
- * too; mvs_ctx_pairwise_candidates reports which one ran). */
+ * column) -- everything else goes through the exact kernel cell by cell (option pairwise_filter = 0 forces
+ * that, = 2 forces the two stages on small blocks too; mvs_ctx_pairwise_candidates reports which one ran). */
 int mvs_pairwise_rows(mvs_ctx* ctx, const mvs_sketch_set* set, const double* norms_sq, int mem_norms,
                       int keep_mode, int64_t row_begin, int64_t row_end, mvs_cell* cells,
                       int64_t capacity, int mem_cells, int64_t* n_cells);

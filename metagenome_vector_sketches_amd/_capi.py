@@ -29,6 +29,8 @@ SYMBOLS = [
     ("mvs_device_count", _c.c_int, [_c.POINTER(_c.c_int)]),
     ("mvs_ctx_create", _c.c_int, [_c.c_int, _c.POINTER(_P)]),
     ("mvs_ctx_destroy", _c.c_int, [_P]),
+    ("mvs_ctx_set_option", _c.c_int, [_P, _c.c_char_p, _c.c_int64]),
+    ("mvs_ctx_get_option", _c.c_int, [_P, _c.c_char_p, _c.POINTER(_c.c_int64)]),
     ("mvs_ctx_set_stream", _c.c_int, [_P, _P]),
     ("mvs_ctx_use_own_stream", _c.c_int, [_P]),
     ("mvs_ctx_synchronize", _c.c_int, [_P]),
@@ -191,6 +193,32 @@ class Context:
 
     def synchronize(self):
         _check(self.lib.mvs_ctx_synchronize(self._h))
+
+    def set_option(self, name, value):
+        """tuning / diagnostic switch of this context (include/mvs_hip.h lists them); never changes a result"""
+        _check(self.lib.mvs_ctx_set_option(self._h, name.encode(), int(value)))
+
+    def get_option(self, name):
+        v = _c.c_int64()
+        _check(self.lib.mvs_ctx_get_option(self._h, name.encode(), ctypes.byref(v)))
+        return v.value
+
+    def options(self, **kw):
+        """`with ctx.options(pairwise_filter=0): ...` -- set, run, restore"""
+        ctx = self
+
+        class _Scope:
+            def __enter__(self):
+                self.old = {k: ctx.get_option(k) for k in kw}
+                for k, v in kw.items():
+                    ctx.set_option(k, v)
+                return ctx
+
+            def __exit__(self, *exc):
+                for k, v in self.old.items():
+                    ctx.set_option(k, v)
+                return False
+        return _Scope()
 
     def set_timing(self, enabled=True):
         _check(self.lib.mvs_ctx_set_timing(self._h, 1 if enabled else 0))

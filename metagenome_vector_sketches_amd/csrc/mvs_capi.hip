@@ -13,12 +13,15 @@
 
 struct mvs_ctx {
     int device = 0;
+    mvs::Options opt;   // tuning switches: environment defaults read once at creation, then mvs_ctx_set_option
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     // timing of the dominant kernels (optional)
     bool timing = false;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // project start/stop, pairwise start/stop
-    bool ev_valid[2] = {false, false};
+    // event pairs: 0 projection kernel, 1 whole comparison (filter + re-check, or the exact kernel),
+    // 2 the filter kernel alone, 3 the re-check kernel alone
+    hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool ev_valid[4] = {false, false, false, false};
     // reusable device scratch
     void* scratch = nullptr;
     size_t scratch_bytes = 0;
@@ -133,6 +136,54 @@ int acquire_pinned(mvs_ctx* c, size_t bytes) {
     return MVS_OK;
 }
 
+// ---- options: one table drives the environment defaults, the setter and the getter ----
+struct OptionSpec {
+    const char* name;      // mvs_ctx_set_option name; the environment variable is MVS_<NAME in upper case>
+    int mvs::Options::*ifield;
+    double mvs::Options::*dfield;
+    long long lo, hi;
+};
+const OptionSpec kOptions[] = {
+    {"pairwise_filter", &mvs::Options::pairwise_filter, nullptr, 0, 2},
+    {"filter_variant", &mvs::Options::filter_variant, nullptr, -1, 99},
+    {"exact_variant", &mvs::Options::exact_variant, nullptr, 0, 2},
+    {"pairwise_variant", &mvs::Options::pairwise_variant, nullptr, 0, 6},
+    {"pairwise_symmetric", &mvs::Options::pairwise_symmetric, nullptr, 0, 1},
+    {"pairwise_debug", &mvs::Options::pairwise_debug, nullptr, 0, 3},
+    {"sort", &mvs::Options::sort, nullptr, 0, 2},
+    {"enable_k3", &mvs::Options::enable_k3, nullptr, 0, 1},
+    {"pairwise_block_cells", nullptr, &mvs::Options::pairwise_block_cells, 1, (1LL << 62)},
+};
+
+int apply_option(mvs::Options& o, const OptionSpec& sp, long long v) {
+#ifndef MVS_ABLATIONS
+    if (sp.ifield == &mvs::Options::pairwise_debug && v != 0)
+        return fail(MVS_E_INVALID, "pairwise_debug needs a library built with -DMVS_ABLATIONS");
+    if (sp.ifield == &mvs::Options::filter_variant && v >= 10)
+        return fail(MVS_E_INVALID, "filter_variant %lld is a k-loop ablation: needs -DMVS_ABLATIONS", v);
+#endif
+    if (v < sp.lo || v > sp.hi) return fail(MVS_E_INVALID, "option %s: %lld outside [%lld, %lld]", sp.name, v, sp.lo, sp.hi);
+    if (sp.ifield) o.*(sp.ifield) = (int)v;
+    else o.*(sp.dfield) = (double)v;
+    return MVS_OK;
+}
+
+// MVS_<NAME> environment variables give the initial values (MVS_SORT also takes "merge" / "radix");
+// values the setter would reject are ignored
+void options_from_env(mvs::Options& o) {
+    for (const OptionSpec& sp : kOptions) {
+        std::string env = "MVS_";
+        for (const char* p = sp.name; *p; ++p) env += (char)toupper((unsigned char)*p);
+        const char* e = getenv(env.c_str());
+        if (!e || !*e) continue;
+        long long v;
+        if (sp.ifield == &mvs::Options::sort && (e[0] == 'm' || e[0] == 'r')) v = e[0] == 'r' ? 2 : 1;
+        else v = sp.dfield ? (long long)atof(e) : atoll(e);
+        const std::string keep = g_err;
+        if (apply_option(o, sp, v) != MVS_OK) g_err = keep;
+    }
+}
+
 int check_kernel(const char* what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(MVS_E_HIP, "%s launch: %s", what, hipGetErrorString(e));
@@ -175,6 +226,7 @@ int mvs_ctx_create(int device, mvs_ctx** out) {
     mvs_ctx* c = new (std::nothrow) mvs_ctx();
     if (!c) return fail(MVS_E_NOMEM, "out of host memory");
     c->device = device;
+    options_from_env(c->opt);
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
         delete c;
         return fail(MVS_E_HIP, "hipStreamCreate failed");
@@ -222,6 +274,23 @@ int mvs_ctx_destroy(mvs_ctx* c) {
     return MVS_OK;
 }
 
+int mvs_ctx_set_option(mvs_ctx* c, const char* name, int64_t value) {
+    if (!c || !name) return fail(MVS_E_INVALID, "NULL argument");
+    for (const OptionSpec& sp : kOptions)
+        if (std::strcmp(sp.name, name) == 0) return apply_option(c->opt, sp, (long long)value);
+    return fail(MVS_E_INVALID, "unknown option '%s'", name);
+}
+
+int mvs_ctx_get_option(const mvs_ctx* c, const char* name, int64_t* value) {
+    if (!c || !name || !value) return fail(MVS_E_INVALID, "NULL argument");
+    for (const OptionSpec& sp : kOptions)
+        if (std::strcmp(sp.name, name) == 0) {
+            *value = sp.ifield ? (int64_t)(c->opt.*(sp.ifield)) : (int64_t)(c->opt.*(sp.dfield));
+            return MVS_OK;
+        }
+    return fail(MVS_E_INVALID, "unknown option '%s'", name);
+}
+
 int mvs_ctx_set_stream(mvs_ctx* c, void* hip_stream) {
     if (!c) return fail(MVS_E_INVALID, "ctx is NULL");
     c->stream = (hipStream_t)hip_stream;
@@ -244,7 +313,7 @@ int mvs_ctx_synchronize(mvs_ctx* c) {
 int mvs_ctx_set_timing(mvs_ctx* c, int enabled) {
     if (!c) return fail(MVS_E_INVALID, "ctx is NULL");
     c->timing = enabled != 0;
-    c->ev_valid[0] = c->ev_valid[1] = false;
+    for (bool& v : c->ev_valid) v = false;
     return MVS_OK;
 }
 
@@ -255,10 +324,13 @@ int mvs_ctx_pairwise_candidates(mvs_ctx* c, int64_t* candidates) {
 }
 
 int mvs_ctx_kernel_ms(mvs_ctx* c, int which, float* ms) {
-    if (!c || !ms || which < 0 || which > 1) return fail(MVS_E_INVALID, "bad argument");
+    if (!c || !ms || which < 0 || which > 3) return fail(MVS_E_INVALID, "bad argument");
     if (!c->ev_valid[which]) return fail(MVS_E_INVALID, "no timing recorded for kernel %d", which);
-    HIP_TRY(hipEventSynchronize(c->ev[2 * which + 1]));
-    HIP_TRY(hipEventElapsedTime(ms, c->ev[2 * which], c->ev[2 * which + 1]));
+    // pairs 2 and 3 share events with pair 1: filter = ev[2]..ev[5], re-check = ev[5]..ev[3]
+    hipEvent_t b = which == 2 ? c->ev[2] : which == 3 ? c->ev[5] : c->ev[2 * which];
+    hipEvent_t e = which == 2 ? c->ev[5] : which == 3 ? c->ev[3] : c->ev[2 * which + 1];
+    HIP_TRY(hipEventSynchronize(e));
+    HIP_TRY(hipEventElapsedTime(ms, b, e));
     return MVS_OK;
 }
 
@@ -501,17 +573,6 @@ int mvs_sketch_max_abs(mvs_ctx* c, const void* sketches, int elem_bytes, int mem
 int mvs_limbs_for_max_abs(int64_t max_abs) {
     if (max_abs < 0) max_abs = -max_abs;
     if (max_abs <= 127) return 1;
-    {
-        // The 3-pass Karatsuba scheme is exact and tested but measures 9-19 % SLOWER than two base-256
-        // limbs on MI355X (25 % fewer MFMAs, 1.5x the LDS traffic: the kernel is data-movement / power
-        // bound), so it is opt-in: MVS_ENABLE_K3=1.
-        static int k3 = -1;
-        if (k3 < 0) {
-            const char* e = getenv("MVS_ENABLE_K3");
-            k3 = (e && atoi(e) != 0) ? 1 : 0;
-        }
-        if (k3 && max_abs <= 8127) return MVS_LIMBS_K3;   // 63 * (1 + 128): digits in [-64,63], sum in int8
-    }
     if (max_abs <= 32639) return 2;      // 127 * (1 + 256)
     if (max_abs <= 8355711) return 3;    // 127 * (1 + 256 + 65536)
     return 4;                            // exact mod 2^32 for every int32
@@ -571,7 +632,11 @@ int mvs_sketch_set_create(mvs_ctx* c, const void* sketches, int elem_bytes, int 
     int64_t max_abs = 0;
     int rc = mvs_sketch_max_abs(c, d_in, elem_bytes, MVS_MEM_DEVICE, n * d, &max_abs);
     if (rc) return rc;
-    const int limbs = mvs_limbs_for_max_abs(max_abs);
+    int limbs = mvs_limbs_for_max_abs(max_abs);
+    // The 3-pass Karatsuba scheme (63 * (1 + 128): digits in [-64,63], their sum in int8) is exact and tested but
+    // measures 9-19 % SLOWER than two base-256 limbs on MI355X (25 % fewer MFMAs, 1.5x the LDS traffic), so it is
+    // opt-in: option enable_k3.
+    if (c->opt.enable_k3 && max_abs > 127 && max_abs <= 8127) limbs = MVS_LIMBS_K3;
     int64_t n_alloc = 0;
     int d_pad = 0;
     size_t bytes = 0;
@@ -731,14 +796,6 @@ int mvs_sketch_set_destroy(mvs_sketch_set* s) {
 
 namespace {
 
-// MVS_PAIRWISE_FILTER: 0 = always the exact kernel, 1 (default) = two-stage comparison for blocks of at
-// least 2^22 cells, 2 = two-stage comparison whenever the set allows it
-int filter_mode() {
-    const char* e = getenv("MVS_PAIRWISE_FILTER");   // read per call: tests switch it inside one process
-    const int v = e ? atoi(e) : 1;
-    return (v < 0 || v > 2) ? 1 : v;
-}
-
 // coarse plane + row statistics of `s`, cached in the context until the set (or its contents) changes
 int prepare_coarse(mvs_ctx* c, const mvs_sketch_set* s) {
     if (c->coarse_id == s->id && c->coarse_gen == s->gen) return MVS_OK;
@@ -783,12 +840,9 @@ int pairwise_launch(mvs_ctx* c, const mvs_sketch_set* s, const double* d_n2, int
     a.counter = c->d_counter;
     a.dots = nullptr;
     a.mirror_all = mirror_all ? 1 : 0;
-    {
-        const char* dbg = getenv("MVS_PAIRWISE_DEBUG");
-        a.debug_flags = dbg ? atoi(dbg) : 0;
-        const char* sym = getenv("MVS_PAIRWISE_SYMMETRIC");   // default on; 0 computes every tile
-        a.symmetric = (symmetric && !(sym && atoi(sym) == 0)) ? 1 : 0;   // the launcher checks the alignment
-    }
+    a.debug_flags = c->opt.pairwise_debug;
+    a.symmetric = (symmetric && c->opt.pairwise_symmetric) ? 1 : 0;   // the launcher checks the alignment
+    const int filter_mode = c->opt.pairwise_filter;
     auto set_count = [&]() -> int {
         c->h_start = start;   // outlives the asynchronous copy
         if (start == 0) HIP_TRY(hipMemsetAsync(c->d_counter, 0, 8, c->stream));
@@ -797,8 +851,8 @@ int pairwise_launch(mvs_ctx* c, const mvs_sketch_set* s, const double* d_n2, int
     };
     int rc = MVS_OK;
     const double block_cells = (double)(re - rb) * (double)(ce - cb);
-    bool two_stage = filter_mode() != 0 && s->limbs == 2 && s->d_pad <= 32768 &&
-                     (filter_mode() == 2 ||   // forced: also on small blocks and on sets it was found not to pay for
+    bool two_stage = filter_mode != 0 && s->limbs == 2 && s->d_pad <= 32768 &&
+                     (filter_mode == 2 ||   // forced: also on small blocks and on sets it was found not to pay for
                       (block_cells >= 4194304.0 && !(c->filter_off_id == s->id && c->filter_off_coeff == keep_coeff)));
     if (two_stage) {
         rc = prepare_coarse(c, s);
@@ -814,9 +868,9 @@ int pairwise_launch(mvs_ctx* c, const mvs_sketch_set* s, const double* d_n2, int
         // kernel alone is faster (dense results; a search with a very low bound).  The filter tiles and the
         // re-check give up as soon as the device-side counter passes that limit; the exact kernel then does the
         // block (and later blocks of the same set).  The list starts at the caller's capacity or 1/4096 of the
-        // block and is regrown to what a run reports it needs.  Forced mode (MVS_PAIRWISE_FILTER=2, tests) has
+        // block and is regrown to what a run reports it needs.  Forced mode (pairwise_filter = 2, tests) has
         // no limit.
-        const bool forced = filter_mode() == 2;
+        const bool forced = filter_mode == 2;
         const unsigned long long limit =
             forced ? ~0ULL : (unsigned long long)std::min(268435456.0, std::max(65536.0, block_cells / 128.0));
         int64_t cand_want = std::max<int64_t>(std::max<int64_t>(1 << 20, capacity), (int64_t)(block_cells / 4096.0));
@@ -839,17 +893,20 @@ int pairwise_launch(mvs_ctx* c, const mvs_sketch_set* s, const double* d_n2, int
                 if (rc) return rc;
             }
             if (c->timing) HIP_TRY(hipEventRecord(c->ev[2], c->stream));
-            rc = mvs::launch_filter(c->stream, a);
+            rc = mvs::launch_filter(c->stream, a, c->opt);
             if (rc) return fail(rc, "filter launch rejected");
             rc = check_kernel("k_pairwise_mfma(filter)");
             if (rc) return rc;
-            rc = mvs::launch_exact_pairs(c->stream, a);
+            if (c->timing) {   // ev[5] closes the filter's interval and opens the re-check's
+                HIP_TRY(hipEventRecord(c->ev[5], c->stream));
+            }
+            rc = mvs::launch_exact_pairs(c->stream, a, c->opt);
             if (rc) return fail(rc, "exact re-check launch rejected");
             rc = check_kernel("k_exact_pairs");
             if (rc) return rc;
             if (c->timing) {
                 HIP_TRY(hipEventRecord(c->ev[3], c->stream));
-                c->ev_valid[1] = true;
+                c->ev_valid[1] = c->ev_valid[2] = c->ev_valid[3] = true;
             }
             unsigned long long back[3] = {0, 0, 0};   // cell count, (debug slot), candidate count
             HIP_TRY(hipMemcpyAsync(back, c->d_counter, 24, hipMemcpyDeviceToHost, c->stream));
@@ -879,24 +936,25 @@ int pairwise_launch(mvs_ctx* c, const mvs_sketch_set* s, const double* d_n2, int
     rc = set_count();
     if (rc) return rc;
     if (c->timing) HIP_TRY(hipEventRecord(c->ev[2], c->stream));
-    rc = mvs::launch_pairwise(c->stream, a, 0, 0);
+    rc = mvs::launch_pairwise(c->stream, a, 0, 0, c->opt);
     if (rc) return fail(rc, "pairwise launch rejected");
     rc = check_kernel("k_pairwise");
     if (rc) return rc;
     if (c->timing) {
         HIP_TRY(hipEventRecord(c->ev[3], c->stream));
         c->ev_valid[1] = true;
+        c->ev_valid[2] = c->ev_valid[3] = false;   // no filter / re-check in this comparison
     }
     return MVS_OK;
 }
 
 int sort_on_device(mvs_ctx* c, mvs_cell* in, int64_t n, mvs_cell* out) {
     size_t need = 0;
-    int rc = mvs::sort_cells(c->stream, in, out, n, nullptr, 0, &need);
+    int rc = mvs::sort_cells(c->stream, in, out, n, nullptr, 0, &need, c->opt);
     if (rc) return fail(rc, "sort sizing failed");
     rc = ensure_buf(c, &c->pw_sort, &c->pw_sort_bytes, need);
     if (rc) return rc;
-    rc = mvs::sort_cells(c->stream, in, out, n, c->pw_sort, c->pw_sort_bytes, nullptr);
+    rc = mvs::sort_cells(c->stream, in, out, n, c->pw_sort, c->pw_sort_bytes, nullptr, c->opt);
     if (rc) return fail(rc, "sort failed");
     return MVS_OK;
 }
@@ -937,12 +995,8 @@ int mvs_pairwise_rows(mvs_ctx* c, const mvs_sketch_set* s, const double* norms_s
     if (rc) return rc;
     // Very large shards go through in row chunks of at most 2^40 cells (chunk borders on multiples of 256 rows so
     // that every chunk can use the symmetric schedule): that bounds the candidate list of the two-stage
-    // comparison.  MVS_PAIRWISE_BLOCK_CELLS overrides the bound (tests).
-    double max_cells = 1099511627776.0;
-    if (const char* e = getenv("MVS_PAIRWISE_BLOCK_CELLS")) {
-        const double v = atof(e);
-        if (v >= 1.0) max_cells = v;
-    }
+    // comparison.  Option pairwise_block_cells overrides the bound (tests).
+    const double max_cells = c->opt.pairwise_block_cells;
     int64_t chunk_rows = (int64_t)(max_cells / (double)s->n);
     chunk_rows = std::max<int64_t>(256, chunk_rows / 256 * 256);
     unsigned long long count = 0;
@@ -1074,7 +1128,7 @@ int mvs_pairwise_dots(mvs_ctx* c, const mvs_sketch_set* s, int64_t r0, int64_t r
     a.col_begin = c0;
     a.col_end = c1;
     a.dots = d_out;
-    int rc = mvs::launch_pairwise(c->stream, a, 1, algo);
+    int rc = mvs::launch_pairwise(c->stream, a, 1, algo, c->opt);
     if (rc) return fail(rc, "pairwise launch rejected");
     rc = check_kernel("k_pairwise(dots)");
     if (rc) return rc;

@@ -30,6 +30,20 @@ inline __host__ __device__ int planes_of(int code) { return code & 0xff; }
 inline __host__ __device__ bool is_k3(int code) { return code == kLimbsK3; }
 inline bool limb_code_ok(int code) { return (code >= 1 && code <= kMaxLimbs) || code == kLimbsK3; }
 
+// Tuning / diagnostic options of a context (mvs_ctx_set_option).  Initial values come from the MVS_*
+// environment variables, read once by mvs_ctx_create; nothing below the C ABI reads the environment.
+struct Options {
+    int pairwise_filter = 1;        // 0 exact kernel on every cell; 1 two-stage for blocks >= 2^22 cells; 2 always two-stage
+    int filter_variant = -1;        // -1 by block size; 0 128x128 tiles; 1 256x256; 3/5/6 other shapes / ring depths
+    int exact_variant = 0;          // re-check kernel: 0 = 64 pairs per wave round, 1 quarter wave per pair, 2 = 16 per round
+    int pairwise_variant = 6;       // exact kernel: 6 = 16x16x64 MFMA (two limbs), 0-5 = 32x32x32 tile / ring variants
+    int pairwise_symmetric = 1;     // 0: compute every tile (no mirroring)
+    int pairwise_debug = 0;         // profiling ablations; only honoured by a -DMVS_ABLATIONS build
+    int sort = 0;                   // kept-cell sort: 0 by list length, 1 merge, 2 radix
+    int enable_k3 = 0;              // 1: mvs_sketch_set_create picks the three-plane Karatsuba code for |v| <= 8127
+    double pairwise_block_cells = 1099511627776.0;   // row-chunk bound of mvs_pairwise_rows (2^40 cells)
+};
+
 struct PairwiseArgs {
     const int8_t* planes;   // [(row*limbs + limb) * d_pad + k]
     int64_t n;              // samples
@@ -53,7 +67,7 @@ struct PairwiseArgs {
                                   //    block belongs to another shard and is not computed there)
     int symmetric;                // 1: tiles strictly below the diagonal of the row range are skipped and
                                   //    produced by mirroring the kept cells of their transposes
-    int debug_flags;              // profiling ablations (MVS_PAIRWISE_DEBUG): 1 skip k-loop, 2 skip epilogue
+    int debug_flags;              // profiling ablations (-DMVS_ABLATIONS builds only): 1 skip k-loop, 2 skip epilogue
     // two-stage comparison (coarse filter + exact re-check, see "filter" in mvs_pairwise.hip)
     const int8_t* coarse;         // [row * d_pad + k], c = round(v / radix[row]), |c| <= 127
     const float4* fmeta;          // n_alloc: per-row filter constants {s, w, a, p}
@@ -90,7 +104,7 @@ int launch_limb_split(hipStream_t stream, const void* d_sk, int elem_bytes, int6
 int launch_cand_thr(hipStream_t stream, const double* d_norms_sq, int64_t n, int64_t n_alloc, int d,
                     double coeff, int32_t* d_thr);
 // mode 0: comparison (kept cells), mode 1: dense dots.  algo 0: MFMA, 1: vector ALU.
-int launch_pairwise(hipStream_t stream, const PairwiseArgs& a, int mode, int algo);
+int launch_pairwise(hipStream_t stream, const PairwiseArgs& a, int mode, int algo, const Options& opt);
 // two-stage comparison for two base-256 limbs: coarse plane + row statistics from the limb planes,
 // per-call filter constants, the one-pass filter
 // that appends candidate pairs, and the exact re-check of the candidates that appends kept cells
@@ -98,11 +112,11 @@ int launch_coarse_build(hipStream_t stream, const int8_t* d_planes, int64_t n, i
                         int8_t* d_coarse, CoarseRow* d_rows);
 int launch_filter_meta(hipStream_t stream, const CoarseRow* d_rows, const double* d_norms_sq, int64_t n,
                        int64_t n_alloc, int d, double coeff, float4* d_meta);
-int launch_filter(hipStream_t stream, const PairwiseArgs& a);
-int launch_exact_pairs(hipStream_t stream, const PairwiseArgs& a);
+int launch_filter(hipStream_t stream, const PairwiseArgs& a, const Options& opt);
+int launch_exact_pairs(hipStream_t stream, const PairwiseArgs& a, const Options& opt);
 // sort cells by (row, col); tmp buffers owned by the caller
 int sort_cells(hipStream_t stream, mvs_cell* d_cells, mvs_cell* d_tmp, int64_t n, void* d_scratch,
-               size_t scratch_bytes, size_t* scratch_needed);
+               size_t scratch_bytes, size_t* scratch_needed, const Options& opt);
 
 }  // namespace mvs
 

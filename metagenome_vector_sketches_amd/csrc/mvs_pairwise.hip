@@ -304,7 +304,12 @@ __global__ __launch_bounds__(WM * WN * 64, (AT * BT > 2 ? 1 : 2)) void k_pairwis
     // kPPW copies per slice in flight, oldest first) followed by a raw s_barrier; hipcc's own waitcnt
     // insertion is not relied on for global_load_lds (it was seen to drop the wait, and a plain
     // __syncthreads() would drain the whole ring).
+#ifdef MVS_ABLATIONS
     const int nk = (a.debug_flags & 1) ? 0 : a.d_pad / kSK;
+#else
+    static_assert(ABL == 0, "k-loop ablations need a -DMVS_ABLATIONS build");
+    const int nk = a.d_pad / kSK;
+#endif
 #pragma unroll
     for (int st = 0; st < NST - 1; ++st)
         if (st < nk) stage_copy(st, st * kSK);
@@ -361,6 +366,7 @@ __global__ __launch_bounds__(WM * WN * 64, (AT * BT > 2 ? 1 : 2)) void k_pairwis
     __syncthreads();
 
     // ---- epilogue ----
+#ifdef MVS_ABLATIONS
     if (a.debug_flags & 2) {   // ablation: keep the accumulators alive, skip the epilogue
         int x = 0;
 #pragma unroll
@@ -372,6 +378,7 @@ __global__ __launch_bounds__(WM * WN * 64, (AT * BT > 2 ? 1 : 2)) void k_pairwis
         if (x == 0x7fffffff) a.counter[1] = 1;
         return;
     }
+#endif
     if constexpr (MODE == 2) {
         // filter: a pair can only be kept if  <c_i,c_j>  >  s_i w_j + s_j w_i - a_i p_j - p_i (a_j + p_j)
         // (derivation at k_filter_meta); everything else is dropped without ever forming the exact dot.
@@ -1060,14 +1067,8 @@ struct CellLess {
 //   4 -> 8 waves 4x2, wave tile 64x64, tile 256x128, 3-stage ring          (fewer LDS/L2 bytes per MFMA)
 //   5 -> 8 waves 2x4, wave tile 64x64, tile 128x256, 3-stage ring
 //   6 -> variant 0 on the 16x16x64 MFMA shape (two base-256 limbs only; other limb codes use variant 0) [default]
-int pairwise_variant() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("MVS_PAIRWISE_VARIANT");
-        v = e ? atoi(e) : 6;   // default: the 16x16x64 shape, measured 5-7 % faster than variant 0
-        if (v < 0 || v > 6) v = 6;
-    }
-    return v;
+inline int pairwise_variant(const Options& opt) {
+    return (opt.pairwise_variant < 0 || opt.pairwise_variant > 6) ? 6 : opt.pairwise_variant;
 }
 
 template <int L, bool KARA, int MODE, int NST, int WM, int WN, int BT, int AT = 2, bool DBUF = (BT == 1), int ABL = 0>
@@ -1111,19 +1112,19 @@ int launch_mfma16(hipStream_t stream, const PairwiseArgs& a) {
 }
 
 template <int L, bool KARA, int MODE>
-int launch_mfma(hipStream_t stream, const PairwiseArgs& a) {
+int launch_mfma(hipStream_t stream, const PairwiseArgs& a, const Options& opt) {
     if constexpr (L == 2 && !KARA) {
-        if (pairwise_variant() == 6) return launch_mfma16<MODE>(stream, a);
+        if (pairwise_variant(opt) == 6) return launch_mfma16<MODE>(stream, a);
     }
     if constexpr (KARA) {   // 48 KB per 128x128 stage: at most three stages fit the 160 KB of LDS
-        switch (pairwise_variant()) {
+        switch (pairwise_variant(opt)) {
             case 1: return launch_mfma_variant<L, KARA, MODE, 3, 2, 2, 1>(stream, a);
             case 3: return launch_mfma_variant<L, KARA, MODE, 2, 2, 2, 1>(stream, a);
             case 2: return launch_mfma_variant<L, KARA, MODE, 2, 2, 4, 1>(stream, a);
             default: return launch_mfma_variant<L, KARA, MODE, 3, 2, 4, 1>(stream, a);
         }
     } else {
-        switch (pairwise_variant()) {
+        switch (pairwise_variant(opt)) {
             case 1: return launch_mfma_variant<L, KARA, MODE, 3, 2, 2, 1>(stream, a);
             case 2: return launch_mfma_variant<L, KARA, MODE, 5, 2, 4, 1>(stream, a);
             case 3: return launch_mfma_variant<L, KARA, MODE, 2, 2, 2, 1>(stream, a);
@@ -1187,20 +1188,12 @@ int launch_filter_meta(hipStream_t stream, const CoarseRow* d_rows, const double
     return 0;
 }
 
-int launch_filter(hipStream_t stream, const PairwiseArgs& a) {
+int launch_filter(hipStream_t stream, const PairwiseArgs& a, const Options& opt) {
     if (a.limbs != 2 || a.d_pad > 32768) return MVS_E_INVALID;
-    // MVS_FILTER_VARIANT: tile shape / ring depth of the one-pass filter.  On 100k x 2048 every shape lands within
-    // 5 % of the default (k-loop 12.5 ms, of which 5 ms matrix-core time): ablations 11-13 show the copies, the
-    // fragment reads and the MFMAs of one workgroup hardly overlap (its waves move in lock step from barrier to
-    // barrier), only different workgroups of a CU overlap.
-    // Default: 256 x 256 tiles (half the L2 -> LDS bytes per cell; 11 % faster at 100k samples) once the block
+    // opt.filter_variant: tile shape / ring depth of the one-pass filter.
+    // Default (-1): 256 x 256 tiles (half the L2 -> LDS bytes per cell; 11 % faster at 100k samples) once the block
     // holds enough of them to keep 256 CUs busy through the tail, 128 x 128 tiles below that.
-    static int forced = -2;
-    if (forced == -2) {
-        const char* e = getenv("MVS_FILTER_VARIANT");
-        forced = e ? atoi(e) : -1;
-    }
-    int v = forced;
+    int v = opt.filter_variant;
     if (v < 0) {
         const double tiles = (double)(a.row_end - a.row_begin) * (double)(a.col_end - a.col_begin) / 65536.0 *
                              (a.symmetric ? 0.5 : 1.0);
@@ -1209,28 +1202,27 @@ int launch_filter(hipStream_t stream, const PairwiseArgs& a) {
     switch (v) {
         case 1: return launch_mfma_variant<1, false, 2, 4, 2, 4, 2, 4, true>(stream, a);   // 256 x 256, waves 128 x 64
         case 3: return launch_mfma_variant<1, false, 2, 4, 4, 2, 2, 2, true>(stream, a);   // 256 x 128, waves 64 x 64
-        case 11: return launch_mfma_variant<1, false, 2, 4, 2, 4, 1, 2, true, 1>(stream, a);   // ablations of variant 0
+#ifdef MVS_ABLATIONS   // k-loop ablations (results are garbage): 1x no MFMA, x2 no copies, x3 no fragment reads
+        case 11: return launch_mfma_variant<1, false, 2, 4, 2, 4, 1, 2, true, 1>(stream, a);   // of variant 0
         case 12: return launch_mfma_variant<1, false, 2, 4, 2, 4, 1, 2, true, 2>(stream, a);
         case 13: return launch_mfma_variant<1, false, 2, 4, 2, 4, 1, 2, true, 3>(stream, a);
-        case 21: return launch_mfma_variant<1, false, 2, 4, 2, 4, 2, 4, true, 1>(stream, a);   // ablations of variant 1
+        case 21: return launch_mfma_variant<1, false, 2, 4, 2, 4, 2, 4, true, 1>(stream, a);   // of variant 1
         case 22: return launch_mfma_variant<1, false, 2, 4, 2, 4, 2, 4, true, 2>(stream, a);
         case 23: return launch_mfma_variant<1, false, 2, 4, 2, 4, 2, 4, true, 3>(stream, a);
+#endif
         case 5: return launch_mfma_variant<1, false, 2, 5, 2, 4, 1>(stream, a);            // 5-stage ring
         case 6: return launch_mfma_variant<1, false, 2, 3, 2, 4, 1>(stream, a);            // 3-stage ring, 3 workgroups / CU
         default: return launch_mfma_variant<1, false, 2, 4, 2, 4, 1>(stream, a);           // 128 x 128, waves 64 x 32
     }
 }
 
-int launch_exact_pairs(hipStream_t stream, const PairwiseArgs& a) {
+int launch_exact_pairs(hipStream_t stream, const PairwiseArgs& a, const Options& opt) {
     if (a.limbs != 2) return MVS_E_INVALID;
-    // the candidate count lives on the device: a fixed grid of waves strides over the list
-    static int v = -1;   // MVS_EXACT_VARIANT: 0 = 64 pairs per round, whole wave per pair (default; measured
-    if (v < 0) {         // 10-15 % faster on 1e5 candidates than 16 per round or a quarter wave per pair)
-        const char* e = getenv("MVS_EXACT_VARIANT");
-        v = e ? atoi(e) : 0;
-    }
+    // the candidate count lives on the device: a fixed grid of waves strides over the list.
+    // opt.exact_variant 0 = 64 pairs per round, whole wave per pair (default; measured 10-15 % faster on 1e5
+    // candidates than 16 per round or a quarter wave per pair)
     const dim3 grid(256 * 16), block(256);
-    switch (v) {
+    switch (opt.exact_variant) {
         case 1: hipLaunchKernelGGL((k_exact_pairs<16, 1>), grid, block, 0, stream, a); break;
         case 2: hipLaunchKernelGGL((k_exact_pairs<16, 0>), grid, block, 0, stream, a); break;
         default: hipLaunchKernelGGL((k_exact_pairs<64, 0>), grid, block, 0, stream, a); break;
@@ -1238,13 +1230,15 @@ int launch_exact_pairs(hipStream_t stream, const PairwiseArgs& a) {
     return 0;
 }
 
-int launch_pairwise(hipStream_t stream, const PairwiseArgs& a, int mode, int algo) {
+int launch_pairwise(hipStream_t stream, const PairwiseArgs& a, int mode, int algo, const Options& opt) {
     // int32 accumulators hold up to two limb-pair products per k: exact while 2 * 128 * 128 * d_pad < 2^31;
     // longer sketches take the vector-ALU path, which wraps mod 2^32 by construction
     if (algo == 0 && (a.limbs <= 2 || is_k3(a.limbs)) && a.d_pad <= 32768) {
-        if (is_k3(a.limbs)) return mode == 0 ? launch_mfma<3, true, 0>(stream, a) : launch_mfma<3, true, 1>(stream, a);
-        if (a.limbs == 1) return mode == 0 ? launch_mfma<1, false, 0>(stream, a) : launch_mfma<1, false, 1>(stream, a);
-        return mode == 0 ? launch_mfma<2, false, 0>(stream, a) : launch_mfma<2, false, 1>(stream, a);
+        if (is_k3(a.limbs))
+            return mode == 0 ? launch_mfma<3, true, 0>(stream, a, opt) : launch_mfma<3, true, 1>(stream, a, opt);
+        if (a.limbs == 1)
+            return mode == 0 ? launch_mfma<1, false, 0>(stream, a, opt) : launch_mfma<1, false, 1>(stream, a, opt);
+        return mode == 0 ? launch_mfma<2, false, 0>(stream, a, opt) : launch_mfma<2, false, 1>(stream, a, opt);
     }
     const int64_t rows = a.row_end - a.row_begin, cols = a.col_end - a.col_begin;
     if (rows <= 0 || cols <= 0) return 0;
@@ -1272,16 +1266,11 @@ struct CellKey {
 };
 
 int sort_cells(hipStream_t stream, mvs_cell* d_cells, mvs_cell* d_tmp, int64_t n, void* d_scratch,
-               size_t scratch_bytes, size_t* scratch_needed) {
+               size_t scratch_bytes, size_t* scratch_needed, const Options& opt) {
     size_t need = 0;
     // radix sort on the 64-bit (row, col) key for long lists (2.5e6 cells: 0.4 ms faster than the merge sort),
-    // merge sort for short ones (1.6e5 cells: 0.03 ms faster); MVS_SORT=merge|radix forces one
-    static int forced = -2;
-    if (forced == -2) {
-        const char* e = getenv("MVS_SORT");
-        forced = !e ? -1 : (e[0] == 'r' ? 1 : 0);
-    }
-    if (forced == 1 || (forced < 0 && n >= (1 << 19))) {
+    // merge sort for short ones (1.6e5 cells: 0.03 ms faster); opt.sort = 1 (merge) / 2 (radix) forces one
+    if (opt.sort == 2 || (opt.sort == 0 && n >= (1 << 19))) {
         hipError_t e = rocprim::radix_sort_keys(nullptr, need, d_cells, d_tmp, (size_t)n, CellKey(), 0u, 64u, stream);
         if (e != hipSuccess) return MVS_E_HIP;
         if (scratch_needed) *scratch_needed = need;

@@ -187,7 +187,8 @@ void mvs_oracle_shard_rows(int64_t n, int num_shards, int shard_idx, int64_t* be
 static void dots_tile(const void* sk, int elem_bytes, int d, int64_t i0, int64_t i1, int64_t j0,
                       int64_t j1, int32_t* out) {
     const int64_t cj = j1 - j0;
-#pragma omp parallel for schedule(static)
+    /* i x j collapsed: a tile has <= 192 rows, which alone would starve a host with more threads than that */
+#pragma omp parallel for collapse(2) schedule(static)
     for (int64_t i = i0; i < i1; ++i) {
         for (int64_t j = j0; j < j1; ++j) {
             int32_t v;

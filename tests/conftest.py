@@ -73,3 +73,14 @@ def ctx():
     c = Context(0)
     yield c
     c.close()
+
+
+@pytest.fixture
+def restore_options(ctx):
+    """the context is shared by the whole session: whatever a test switches is switched back"""
+    names = ("pairwise_filter", "pairwise_block_cells", "filter_variant", "exact_variant", "pairwise_variant",
+             "pairwise_symmetric", "sort")
+    old = {k: ctx.get_option(k) for k in names}
+    yield
+    for k, v in old.items():
+        ctx.set_option(k, v)

@@ -1,13 +1,15 @@
 """GPU: the pairwise kernels (through the C ABI) against the oracle and the reference fixtures.
 Bit-exact: dot products are int32 mod 2^32, the keep test and the 8-bit Jaccard are evaluated in the
 reference's own operation order in fp64."""
+import os
+
 import numpy as np
 import pytest
 
 from metagenome_vector_sketches_amd import _capi, synth
 from oracle import pyoracle as orc
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("restore_options")]
 
 
 def _n2_from_sketches(sk):
@@ -27,10 +29,10 @@ K3 = 0x103   # MVS_LIMBS_K3: three planes of base-128 digits, 3 matrix-core pass
 
 
 @pytest.fixture(params=["exact", "two_stage"])
-def pw_filter(request, monkeypatch):
-    """run a comparison test twice: exact kernel on every cell (MVS_PAIRWISE_FILTER=0) and the coarse filter
-    + exact re-check of the candidates forced on even for small blocks (=2)"""
-    monkeypatch.setenv("MVS_PAIRWISE_FILTER", "0" if request.param == "exact" else "2")
+def pw_filter(request, ctx):
+    """run a comparison test twice: exact kernel on every cell (option pairwise_filter = 0) and the coarse filter
+    + exact re-check of the candidates forced on even for small blocks (= 2)"""
+    ctx.set_option("pairwise_filter", 0 if request.param == "exact" else 2)
     return request.param
 
 
@@ -321,10 +323,10 @@ def test_two_stage_equals_exact_and_oracle(ctx, monkeypatch, kind, n, d, mode):
     keep = _capi.KEEP_INT32 if mode == "int32" else _capi.KEEP_INT16
     ss = ctx.sketch_set(sk)
     assert ss.limbs == 2
-    monkeypatch.setenv("MVS_PAIRWISE_FILTER", "2")
+    ctx.set_option("pairwise_filter", 2)
     two, cnt_two = ctx.pairwise_rows(ss, n2, keep_mode=keep)
     n_cand = ctx.pairwise_candidates()
-    monkeypatch.setenv("MVS_PAIRWISE_FILTER", "0")
+    ctx.set_option("pairwise_filter", 0)
     exact, cnt_exact = ctx.pairwise_rows(ss, n2, keep_mode=keep)
     assert ctx.pairwise_candidates() == 0
     assert cnt_two == cnt_exact and np.array_equal(two, exact)
@@ -349,7 +351,7 @@ def test_two_stage_threshold_knife_edge(ctx, monkeypatch):
         n2[j] = (q + ((j % 3) - 1) / 3.0) / 0.05 - n2[0]
     ss = ctx.sketch_set(sk)
     for keep in (_capi.KEEP_INT32, _capi.KEEP_INT16):
-        monkeypatch.setenv("MVS_PAIRWISE_FILTER", "2")
+        ctx.set_option("pairwise_filter", 2)
         two, _ = ctx.pairwise_rows(ss, n2, keep_mode=keep)
         assert ctx.pairwise_candidates() > 0
         skx = sk if keep == _capi.KEEP_INT32 else sk.astype(np.int16)
@@ -372,7 +374,7 @@ def test_two_stage_wrap_guard(ctx, monkeypatch):
     assert P >= 2 ** 31 and (sk[40].astype(np.int64) * sk[41]).sum() <= -2 ** 31
     ss = ctx.sketch_set(sk)
     for f in ("2", "0"):
-        monkeypatch.setenv("MVS_PAIRWISE_FILTER", f)
+        ctx.set_option("pairwise_filter", int(f))
         cells, _ = ctx.pairwise_rows(ss, n2)
         assert (ctx.pairwise_candidates() >= 4 * 300 - 16) == (f == "2")
         got = _cells_tuple(cells)
@@ -389,7 +391,7 @@ def test_two_stage_gives_way_when_everything_is_a_candidate(ctx, monkeypatch):
     row = np.random.default_rng(3).integers(-900, 900, d).astype(np.int32)
     sk = np.tile(row, (n, 1))
     n2 = _n2_from_sketches(sk[:1]).repeat(n)
-    monkeypatch.setenv("MVS_PAIRWISE_FILTER", "2")
+    ctx.set_option("pairwise_filter", 2)
     ss = ctx.sketch_set(sk)
     with pytest.raises(_capi.MvsError) as ei:
         ctx.pairwise_rows(ss, n2, capacity=1 << 20)
@@ -419,11 +421,11 @@ def test_row_chunked_shard(ctx, monkeypatch, filt):
     sk = synth.make_sketches_numpy(1100, 512, 3000, seed=12, cluster=8)
     n2 = _n2_from_sketches(sk)
     ss = ctx.sketch_set(sk)
-    monkeypatch.setenv("MVS_PAIRWISE_FILTER", filt)
-    monkeypatch.setenv("MVS_PAIRWISE_BLOCK_CELLS", str(300 * 1100))     # chunks of 256 rows
+    ctx.set_option("pairwise_filter", int(filt))
+    ctx.set_option("pairwise_block_cells", 300 * 1100)     # chunks of 256 rows
     whole, _ = ctx.pairwise_rows(ss, n2)
     part, _ = ctx.pairwise_rows(ss, n2, row_begin=130, row_end=901)
-    monkeypatch.delenv("MVS_PAIRWISE_BLOCK_CELLS")
+    ctx.set_option("pairwise_block_cells", 1 << 40)
     want = _oracle_sorted(sk, n2, chunk=192)
     assert _cells_tuple(whole) == want
     assert _cells_tuple(part) == [t for t in want if 130 <= t[0] < 901]
@@ -449,7 +451,7 @@ def test_baseline_config3_and_4_full_size(ctx, monkeypatch, d):
         assert sset.limbs == 2
         out = []
         for f in ("1", "0"):
-            monkeypatch.setenv("MVS_PAIRWISE_FILTER", f)
+            ctx.set_option("pairwise_filter", int(f))
             cells_t = torch.empty((1 << 22, 4), dtype=torch.int32, device="cuda")
             _, cnt = ctx.pairwise_rows(sset, n2_t, cells_out=cells_t)
             assert (ctx.pairwise_candidates() > 0) == (f == "1")
@@ -491,7 +493,100 @@ def test_nan_and_infinite_norms(ctx, monkeypatch):
         want = _oracle_sorted(skx, n2, chunk=192)
         assert not any(r in (3, 50, 51, 120) or c in (3, 50, 51, 120) for r, c, _, _ in want) and len(want) > 300
         for f in ("2", "0"):
-            monkeypatch.setenv("MVS_PAIRWISE_FILTER", f)
+            ctx.set_option("pairwise_filter", int(f))
             got, _ = ctx.pairwise_rows(ss, n2, keep_mode=keep)
             assert _cells_tuple(got) == want
     ss.close()
+
+
+def test_baseline_config5_full_size(ctx, tmp_path):
+    """BASELINE.json configs[4] on one card: 1 000 000 sketches, d = 2048 (1e12 cells; 8.2 GB of int32 sketches,
+    4.1 GB of limb planes + 2 GB coarse plane, all resident).  The oracle cannot do the whole, so:
+      * size-independent properties of the two-stage result (sorted, symmetric, every row keeps its 16 cluster
+        mates incl. itself with q = 255, indices in range);
+      * the exact kernel on a 65 536-row stripe gives the stripe's cells of the two-stage run bit for bit;
+      * 24 rows against the oracle, column slab by column slab (the sketches go through the host 100k rows at a time);
+      * the executable on the same DB (written slab-wise, 8.2 GB vectors.bin) with --num_shards 8 and a staging
+        budget small enough that compare_rows() splits the shard's rows: same cells as the library call."""
+    import subprocess
+    import torch
+    n, d = 1_000_000, 2048
+    sk_t = synth.make_sketches_torch(n, d, 50_000, seed=4567, device="cuda")
+    ss_t = torch.empty(n, dtype=torch.int64, device="cuda")
+    ctx.set_stream(torch.cuda.current_stream())
+    try:
+        ctx.sumsq(sk_t, out=ss_t)
+        norms = np.sqrt(ss_t.cpu().numpy().astype(np.float64) / d)
+        norm_txt = [orc.format_norm(float(x)) for x in norms]
+        n2 = np.array([float(t) ** 2 for t in norm_txt])
+        n2_t = torch.from_numpy(n2).to("cuda")
+        sset = ctx.sketch_set(sk_t)
+        assert sset.limbs == 2
+        cells_t = torch.empty((n * 24, 4), dtype=torch.int32, device="cuda")
+        ctx.set_option("pairwise_filter", 1)
+        _, cnt = ctx.pairwise_rows(sset, n2_t, cells_out=cells_t)
+        assert ctx.pairwise_candidates() > 0
+        torch.cuda.synchronize()
+        two = cells_t[:cnt].cpu().numpy()
+        rb, re = 458_752, 458_752 + 65_536
+        ctx.set_option("pairwise_filter", 0)
+        _, cnt_x = ctx.pairwise_rows(sset, n2_t, row_begin=rb, row_end=re, cells_out=cells_t)
+        assert ctx.pairwise_candidates() == 0
+        torch.cuda.synchronize()
+        exact = cells_t[:cnt_x].cpu().numpy()
+        sset.close()
+        del cells_t
+    finally:
+        ctx.set_stream(None)
+    rows, cols = two[:, 0].astype(np.int64), two[:, 1].astype(np.int64)
+    assert rows.min() == 0 and rows.max() == n - 1 and cols.min() == 0 and cols.max() == n - 1
+    key = rows * n + cols
+    assert np.all(np.diff(key) > 0)                                          # sorted by (row, col), no duplicates
+    assert np.array_equal(np.sort(cols * n + rows), key)                     # symmetric kept set
+    assert int(((rows // 16) == (cols // 16)).sum()) == 16 * n               # every cluster pair kept
+    diag = two[rows == cols]
+    assert len(diag) == n and np.all(diag[:, 3] == 255)
+    lo, hi = np.searchsorted(rows, [rb, re])
+    assert np.array_equal(two[lo:hi], exact)                                 # exact kernel == two-stage on the stripe
+
+    # 24 rows against the oracle, slab by slab
+    q0 = 777_000
+    qrows = sk_t[q0:q0 + 24].cpu().numpy()
+    want = []
+    for s0 in range(0, n, 100_000):
+        slab = sk_t[s0:s0 + 100_000].cpu().numpy()
+        stack = np.concatenate([qrows, slab])
+        n2s = np.concatenate([n2[q0:q0 + 24], n2[s0:s0 + 100_000]])
+        for c in orc.pairwise_rows(stack, n2s, row_begin=0, row_end=24, chunk=192, threads=8):
+            if c["col"] >= 24:
+                want.append((q0 + int(c["row"]), s0 + int(c["col"]) - 24, int(c["dot"]), int(c["q"])))
+    lo, hi = np.searchsorted(rows, [q0, q0 + 24])
+    assert sorted(want) == [tuple(int(x) for x in c) for c in two[lo:hi]]
+
+    # the executable, one of 8 shards, staging budget of 1M cells (< the shard's ~2.4M): rows are split
+    db = str(tmp_path / "db1m") + "/"
+    os.makedirs(db)
+    with open(db + "vectors.bin", "wb") as f:
+        for s0 in range(0, n, 100_000):
+            sk_t[s0:s0 + 100_000].cpu().numpy().tofile(f)
+    del sk_t
+    torch.cuda.empty_cache()
+    with open(db + "vector_norms.txt", "w") as f:
+        f.write("".join("s%d %s\n" % (i, t) for i, t in enumerate(norm_txt)))
+    open(db + "dimension.txt", "w").write("%d\n" % d)
+    open(db + "dtype.txt", "w").write("int32\n")
+    out = str(tmp_path / "idx1m")
+    bin_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "metagenome_vector_sketches_amd", "bin")
+    r = subprocess.run([os.path.join(bin_dir, "pairwise_comp_optimized"), "--db", db, "--max_memory_gb", "0.02",
+                        "--num_threads", "8", "--output_folder", out, "--num_shards", "8", "--shard_idx", "3"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "Total vectors: 1000000" in r.stdout and "Shard 3 processing rows 375000 to 500000" in r.stdout
+    os.remove(db + "vectors.bin")
+    r = subprocess.run([os.path.join(bin_dir, "mvs_dump_matrix"), os.path.join(out, "shard_3")], capture_output=True,
+                       text=True)
+    assert r.returncode == 0, r.stderr
+    got = np.array([[int(t) for t in l.split()] for l in r.stdout.strip().split("\n") if l], dtype=np.int64)
+    lo, hi = np.searchsorted(rows, [375_000, 500_000])
+    assert hi - lo > 1_000_000 and len(got) == hi - lo                       # more cells than the staging budget
+    assert np.array_equal(got, two[lo:hi][:, [0, 1, 3]].astype(np.int64))

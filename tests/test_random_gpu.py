@@ -7,7 +7,7 @@ import pytest
 from metagenome_vector_sketches_amd import _capi, synth
 from oracle import pyoracle as orc
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("restore_options")]
 
 
 @pytest.mark.parametrize("seed", range(6))
@@ -93,7 +93,7 @@ def test_blocks_and_search_two_stage_vs_exact(ctx, monkeypatch, seed):
     def both(fn):
         out = []
         for f in ("2", "0"):
-            monkeypatch.setenv("MVS_PAIRWISE_FILTER", f)
+            ctx.set_option("pairwise_filter", int(f))
             cnt = fn()
             ctx.synchronize()
             out.append(sorted(map(tuple, cells_t[:cnt].cpu().numpy().tolist())))

@@ -1,0 +1,50 @@
+#!/bin/bash
+# Collect the rocprofv3 evidence of a round on the GPU box (run through gpurun from the repository root):
+#   bash tools/collect_profiles.sh r02
+# -> gpurun_out/<tag>/{c1,c2,c2x}_{stats,pmc_*}/ + text/JSON summaries; copy what should be judged into profiles/.
+# Workloads:  c1  = configs[1] step (bench.py without the configs[2] leg)
+#             c2  = configs[2] pairwise, two-stage comparison (tools/run_pairwise.py 100000 2048)
+#             c2x = configs[2] pairwise, exact kernel on every cell (MVS_PAIRWISE_FILTER=0)
+# The profiled program itself follows `--` (no env / sh wrapper); counters are collected in their own passes.
+set -u
+TAG=${1:-r02}
+REPO=$(pwd)
+OUT=$REPO/gpurun_out/$TAG
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+
+PMC_SETS=("FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VALU_MFMA_I8 SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"
+          "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAVE_CYCLES"
+          "TCC_HIT_sum TCC_MISS_sum")
+
+run_set() {   # name, command...
+    local name=$1; shift
+    echo "[$name] kernel trace" ; date
+    rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${name}_stats" -- "$@" > "$OUT/${name}_stats.out" 2> "$OUT/${name}_stats.err" || return 1
+    echo "$*" > "$OUT/${name}_stats/command.txt"
+    local i=0
+    for set in "${PMC_SETS[@]}"; do
+        i=$((i + 1))
+        echo "[$name] pmc pass $i: $set"
+        rocprofv3 --pmc $set --kernel-trace --output-format csv -d "$OUT/${name}_pmc/p$i" -- "$@" > "$OUT/${name}_pmc_p$i.out" 2> "$OUT/${name}_pmc_p$i.err" || return 1
+    done
+    echo "$*" > "$OUT/${name}_pmc/command.txt"
+}
+
+run_set c1 python3 "$REPO/bench.py" --steps 3 --warmup 2 --no-cpu-baseline --pairwise-samples 0 || exit 1
+export MVS_PAIRWISE_FILTER=1
+run_set c2 python3 "$REPO/tools/run_pairwise.py" 100000 2048 4 || exit 1
+export MVS_PAIRWISE_FILTER=0
+run_set c2x python3 "$REPO/tools/run_pairwise.py" 100000 2048 3 || exit 1
+unset MVS_PAIRWISE_FILTER
+
+cd "$REPO"
+for w in c1 c2 c2x; do
+    python3 tools/pmc_summary.py --stats "$OUT/${w}_stats" > "$OUT/${w}_kernel_stats.txt"
+    python3 tools/pmc_summary.py "$OUT/${w}_pmc" > "$OUT/${w}_pmc_summary.txt"
+done
+python3 tools/pmc_summary.py --traffic "$OUT/pmc_traffic.json" "configs[1]=$OUT/c1_pmc" "configs[2]=$OUT/c2_pmc" "configs[2]-exact=$OUT/c2x_pmc"
+# keep the merged-back payload small: the raw per-dispatch CSVs of the PMC passes are summarised above
+find "$OUT" -name "*_counter_collection.csv" -size +4M -delete
+find "$OUT" -name "*_kernel_trace.csv" -size +4M -delete
+echo done

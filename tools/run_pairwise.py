@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Run the pairwise comparison alone on synthesised sketches (profiling helper).
-   python tools/run_pairwise.py [N] [d] [reps] [hashes per sample]"""
+   python tools/run_pairwise.py [N] [d] [reps] [hashes per sample]
+The MVS_* environment (read once by the context) selects variants, e.g. MVS_PAIRWISE_FILTER=0 for the exact kernel."""
 import os
 import sys
 import time
@@ -34,8 +35,10 @@ for r in range(reps):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     ms = ctx.kernel_ms(1)
+    if ctx.pairwise_candidates():
+        print("filter %.3f ms  re-check %.3f ms" % (ctx.kernel_ms(2), ctx.kernel_ms(3)), end="  ")
     print("candidates %d" % ctx.pairwise_candidates(), end="  ")
     print("N=%d d=%d limbs=%d kept=%d wall %.3f ms kernel %.3f ms -> %.3g cells/s, %.1f algorithmic TFLOP/s, MFMA issue %.1f%%"
           % (n, d, sset.limbs, cnt, dt * 1e3, ms, n * n / (ms * 1e-3), 2.0 * d * n * n / (ms * 1e-3) / 1e12,
              2.0 * d * n * n * (1 if ctx.pairwise_candidates() else {1: 1, 0x103: 3, 2: 4}.get(sset.limbs, 0)) *
-             (0.5 + 64.0 / n if os.environ.get("MVS_PAIRWISE_SYMMETRIC", "1") != "0" else 1.0) / (ms * 1e-3) / 5e15 * 100))
+             (0.5 + 64.0 / n if ctx.get_option("pairwise_symmetric") else 1.0) / (ms * 1e-3) / 5e15 * 100))
