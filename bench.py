@@ -368,6 +368,22 @@ def pairwise_leg(ctx, dev, n, d, nh, reps):
     return {"workload": "configs[2]: %d synthetic samples, d=%d, pairwise" % (n, d), "leg": leg, "roofline": roof}
 
 
+def usable_cores(visible):
+    """threads worth starting: the cgroup CPU quota when there is one (a GPU box hands a 1-GPU job a share of the
+    host's cores; 128 OpenMP threads on a 16-core quota run slower than 16), else every visible core"""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            return max(1, min(visible, int(round(float(quota) / float(period)))))
+    except Exception:
+        pass
+    try:
+        return max(1, min(visible, len(os.sched_getaffinity(0))))
+    except Exception:
+        return visible
+
+
 def cpu_baseline(hashes, offsets, S, NH, D, dev):
     """The oracle (CPU port of the reference path, kind "port") timed on this host's cores on bounded samples of the
     same workloads, as BASELINE.md section 3 lays out: projection and pairwise each with 8 threads (the reference's
@@ -378,7 +394,7 @@ def cpu_baseline(hashes, offsets, S, NH, D, dev):
     point there is (survey-session build)."""
     from oracle import pyoracle as orc
     from metagenome_vector_sketches_amd import synth
-    cores = orc.max_threads()
+    cores = usable_cores(orc.max_threads())
     thr_list = [8, cores] if cores > 8 else [cores]
     o_all = np.asarray(offsets)
     mean_size = float(o_all[S]) / S
@@ -448,6 +464,7 @@ def cpu_baseline(hashes, offsets, S, NH, D, dev):
     detail["calibration"] = ("projection port calibrated against the reference binary in the dev container (BASELINE.md "
                              "section 3 table: 1.0-2.2x the reference's speed, the faster port is used); pairwise port NOT "
                              "calibrated against the reference (unbuildable: `bits` submodule absent)")
+    detail["host_threads_visible"] = orc.max_threads()
     return {"value": S / t_job, "unit": "samples/s (projected and compared all-vs-all)", "cores": cores,
             "kind": "port",
             "sample": "projection: %s samples x %d hashes per thread count %s, faster of the literal and the restructured "

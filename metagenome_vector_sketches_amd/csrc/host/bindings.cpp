@@ -1,81 +1,92 @@
-// read_pc_mat_module -- pybind11 surface of the query library, same module name, functions, argument names
-// and return shapes as the reference's src/bindings.cpp:110-126 (used by src/read_pc_mat.py:7-44):
-//   query(matrix_folder, db_folder, query_file) -> list[dict{id, neighbor_ids: list[str],
-//                                                            jaccard_similarities: np.float32[]}]
+// read_pc_mat_module -- Python surface of the shard reader.  The module name, the two function names, their
+// keyword arguments and the shapes they return are the reference's (src/bindings.cpp:110-126; consumer
+// src/read_pc_mat.py:7-44):
+//   query(matrix_folder, db_folder, query_file)
+//       -> [ {'id': str, 'neighbor_ids': [str, ...], 'jaccard_similarities': float32 ndarray}, ... ]
 //   query_sliced(matrix_folder, db_folder, row_file, col_file)
-//                                             -> dict{'row-list', 'col-list', 'jac-dict': {row_id: list[float]}}
+//       -> {'row-list': [str], 'col-list': [str], 'jac-dict': {row id: [float, ...]}}
+// Everything behind that is this build's: one SampleTable scan of vector_norms.txt per call, the MatrixView row
+// iterator, results written straight into Python objects (numpy allocates the arrays; nothing is handed over
+// through capsules).
+#include <cstring>
+
 #include <pybind11/numpy.h>
 #include <pybind11/pybind11.h>
-#include <pybind11/stl.h>
 
 #include "read_pc_mat.hpp"
 
 namespace py = pybind11;
 
-// the array owns its buffer through a capsule (src/bindings.cpp:11-34)
-template <typename T>
-static py::array_t<T> vector_to_numpy(std::vector<T>&& vec) {
-    auto* heap_vec = new std::vector<T>(std::move(vec));
-    py::capsule free_when_done(heap_vec, [](void* p) { delete static_cast<std::vector<T>*>(p); });
-    return py::array_t<T>({(py::ssize_t)heap_vec->size()}, {(py::ssize_t)sizeof(T)}, heap_vec->data(), free_when_done);
+namespace {
+
+// the rows named in `file`, with the text they were named by
+struct Request {
+    std::vector<int> rows;
+    std::vector<std::string> labels;
+    Request(const std::string& file, const pc_mat::SampleTable& db) {
+        rows = pc_mat::read_queries_from_file(file, db.index_of, labels);
+    }
+};
+
+pc_mat::SampleTable open_db(const std::string& db_folder) {
+    pc_mat::SampleTable db(db_folder);
+    if (!db.opened) throw std::runtime_error("cannot read " + pc_mat::SampleTable::path_in(db_folder));
+    return db;
 }
 
-static py::list query_py(std::string matrix_folder, std::string db_folder, std::string query_file) {
-    std::vector<std::string> identifiers;
-    auto id_to_index = pc_mat::load_vector_identifiers(db_folder, identifiers);
-    std::vector<std::string> query_ids_str;
-    std::vector<int32_t> queries = pc_mat::read_queries_from_file(query_file, id_to_index, query_ids_str);
-    std::vector<float> vector_norms;
-    pc_mat::load_vector_norms(db_folder, vector_norms);
-    std::vector<pc_mat::Result> results = pc_mat::query(matrix_folder, queries, vector_norms, identifiers);
-    py::list all_results;
-    for (auto& res : results) {
-        py::dict res_dict;
-        res_dict["id"] = res.self_id;
-        py::list ids;
-        for (const auto& s : res.neighbor_ids) ids.append(s);
-        res_dict["neighbor_ids"] = ids;
-        res_dict["jaccard_similarities"] = vector_to_numpy(std::move(res.jaccard_similarities));
-        all_results.append(res_dict);
-    }
-    return all_results;
+py::list strings(const std::vector<std::string>& v) {
+    py::list out(v.size());
+    for (size_t i = 0; i < v.size(); ++i) out[i] = py::str(v[i]);
+    return out;
 }
 
-static py::dict query_sliced_py(std::string matrix_folder, std::string db_folder, std::string row_file,
-                                std::string col_file) {
-    std::vector<std::string> identifiers;
-    auto id_to_index = pc_mat::load_vector_identifiers(db_folder, identifiers);
-    std::vector<std::string> row_vec, col_vec;
-    std::vector<int32_t> row_query_vec = pc_mat::read_queries_from_file(row_file, id_to_index, row_vec);
-    std::vector<int32_t> col_query_vec = pc_mat::read_queries_from_file(col_file, id_to_index, col_vec);
-    const int total_vectors = (int)identifiers.size();
-    std::vector<float> vector_norms;
-    pc_mat::load_vector_norms(db_folder, vector_norms);
-    std::vector<std::vector<float>> results =
-        pc_mat::query_sliced(matrix_folder, row_query_vec, col_query_vec, total_vectors, vector_norms);
-    py::list row_list, col_list;
-    for (const auto& row : row_vec) row_list.append(row);
-    for (const auto& col : col_vec) col_list.append(col);
-    py::dict jaccard_dict;
-    for (size_t i = 0; i < results.size(); i++) {
-        py::list jaccard_list;
-        for (float v : results[i]) jaccard_list.append(v);
-        jaccard_dict[row_vec[i].c_str()] = jaccard_list;
+py::list neighbours(const std::string& matrix_folder, const std::string& db_folder, const std::string& query_file) {
+    pc_mat::SampleTable db = open_db(db_folder);
+    Request req(query_file, db);
+    std::vector<pc_mat::Result> found = pc_mat::query(matrix_folder, req.rows, db.norms, db.names);
+    py::list out(found.size());
+    for (size_t i = 0; i < found.size(); ++i) {
+        const pc_mat::Result& r = found[i];
+        py::array_t<float> jac((py::ssize_t)r.jaccard_similarities.size());
+        if (!r.jaccard_similarities.empty())
+            std::memcpy(jac.mutable_data(), r.jaccard_similarities.data(), r.jaccard_similarities.size() * sizeof(float));
+        py::dict d;
+        d["id"] = py::str(r.self_id);
+        d["neighbor_ids"] = strings(r.neighbor_ids);
+        d["jaccard_similarities"] = std::move(jac);
+        out[i] = std::move(d);
     }
-    py::dict final_result;
-    final_result["row-list"] = row_list;
-    final_result["col-list"] = col_list;
-    final_result["jac-dict"] = jaccard_dict;
-    return final_result;
+    return out;
 }
+
+py::dict slice(const std::string& matrix_folder, const std::string& db_folder, const std::string& row_file,
+               const std::string& col_file) {
+    pc_mat::SampleTable db = open_db(db_folder);
+    Request rows(row_file, db), cols(col_file, db);
+    const std::vector<std::vector<float>> values =
+        pc_mat::query_sliced(matrix_folder, rows.rows, cols.rows, (int32_t)db.names.size(), db.norms);
+    py::dict per_row;
+    for (size_t i = 0; i < values.size(); ++i) {
+        py::list line(values[i].size());
+        for (size_t j = 0; j < values[i].size(); ++j) line[j] = py::float_(values[i][j]);
+        per_row[py::str(rows.labels[i])] = std::move(line);
+    }
+    py::dict out;
+    out["row-list"] = strings(rows.labels);
+    out["col-list"] = strings(cols.labels);
+    out["jac-dict"] = std::move(per_row);
+    return out;
+}
+
+}  // namespace
 
 PYBIND11_MODULE(read_pc_mat_module, m) {
-    m.doc() = "Module for querying pairwise comparison matrix";
-    m.def("query", &query_py, py::arg("matrix_folder"), py::arg("db_folder"), py::arg("query_file"),
-          "Compute neighbors for queries in the given matrix folder, database folder and query file / ids;"
-          " returns a list of dictionaries with neighbor IDs and jaccard similarities.");
-    m.def("query_sliced", &query_sliced_py, py::arg("matrix_folder"), py::arg("db_folder"), py::arg("row_file"),
+    m.doc() = "Reader for the pairwise-comparison matrix shards written by pairwise_comp_optimized";
+    m.def("query", &neighbours, py::arg("matrix_folder"), py::arg("db_folder"), py::arg("query_file"),
+          "Neighbours of the samples listed in query_file (names or row indices, one per line): a list with one dict "
+          "per query -- 'id', 'neighbor_ids' (strongest first) and 'jaccard_similarities' (float32 array).");
+    m.def("query_sliced", &slice, py::arg("matrix_folder"), py::arg("db_folder"), py::arg("row_file"),
           py::arg("col_file"),
-          "Compute neighbors for queries in the given matrix folder, database folder and from the corresponding row-col "
-          "files; returns a dictionary containing row, col IDS and their corresponding jaccard similarities.");
+          "Rows x columns slice of the matrix for the samples listed in row_file / col_file: a dict with 'row-list', "
+          "'col-list' and 'jac-dict' (row id -> list of Jaccard estimates in column order; 0 where nothing is stored).");
 }

@@ -1,308 +1,374 @@
-// query_pc_mat -- drop-in for the reference's query tool (src/query_pc_mat.cpp): nearest neighbours of
-// query rows, or a row x column slice, out of the shard folders written by pairwise_comp_optimized.
-// CPU only (IO bound); same options, stdout text and output files as the reference.
+// query_pc_mat -- command-line reader of the matrix shards pairwise_comp_optimized writes: nearest neighbours of
+// query samples, or a rows x columns slice.  Drop-in for the reference's tool of the same name (src/query_pc_mat.cpp):
+// the options, the text on stdout / stderr, the exit codes and the files written are the reference's; the program
+// behind them is this build's own:
+//   * one table describes the options (parsing and the help text both come from it);
+//   * output goes through small sink classes (screen, per-query neighbour file, delimited slice, .npy slice) so the
+//     two query modes share one batch driver;
+//   * the .npy sink writes its 128-byte header once and patches the row count at the end.
+// CPU only (IO bound).
 //
 //   query_pc_mat --matrix M --db D  (--query_file F | --query_ids id... | --row_file R --col_file C)
 //                [--top N] [--batch_size B] [--write_to_file OUT] [--show_all] [--print] [--help]
 #include <chrono>
-#include <cmath>
+#include <cstdio>
+#include <functional>
 #include <iomanip>
 
 #include "read_pc_mat.hpp"
 
-namespace fs = std::filesystem;
-using std::string;
+namespace {
 
-static void show_error_and_exit(const std::string& msg) {   // :9-13
-    std::cerr << msg << std::endl;
-    std::cerr << "Aborting...\n";
-    exit(1);
+[[noreturn]] void abort_with(const std::string& message) {
+    std::cerr << message << std::endl << "Aborting...\n";
+    std::exit(1);
 }
 
-static std::pair<double, std::string> get_time_unit(double total_time) {   // :19-35
-    if (total_time < 60) return {total_time, "seconds"};
-    if (total_time < 60 * 60) return {total_time / 60.0, "minutes"};
-    return {total_time / (60.0 * 60), "hours"};
+// ---------------------------------------------------------------------------------------------------
+// options
+// ---------------------------------------------------------------------------------------------------
+struct Settings {
+    std::string matrix, db, query_file, row_file, col_file, out_name = "out.txt";
+    std::vector<std::string> query_ids;
+    uint32_t top = 10, batch = 1000;
+    bool to_file = false, show_all = false, to_screen = false, help = false;
+    bool saw_query_file = false, saw_query_ids = false, saw_row_file = false;
+};
+
+enum class Takes { Word, Count, Words, Nothing };
+
+struct Option {
+    const char* flag;
+    Takes takes;
+    std::function<void(Settings&, const std::string&)> store;   // called once per value (Nothing: once, with "")
+    const char* about;
+};
+
+const std::vector<Option>& option_table() {
+    static const std::vector<Option> table = {
+        {"--matrix", Takes::Word, [](Settings& s, const std::string& v) { s.matrix = v; },
+         "Folder containing the pairwise matrix files"},
+        {"--db", Takes::Word, [](Settings& s, const std::string& v) { s.db = v; },
+         "Folder containing the matrix meta data"},
+        {"--query_file", Takes::Word, [](Settings& s, const std::string& v) { s.query_file = v; s.saw_query_file = true; },
+         "File containing query IDs (one per line)"},
+        {"--query_ids", Takes::Words, [](Settings& s, const std::string& v) { s.query_ids.push_back(v); s.saw_query_ids = true; },
+         "Query IDs as command line arguments (numeric indices or identifiers)"},
+        {"--row_file", Takes::Word, [](Settings& s, const std::string& v) { s.row_file = v; s.saw_row_file = true; },
+         "File containing query row IDs (one per line)"},
+        {"--col_file", Takes::Word, [](Settings& s, const std::string& v) { s.col_file = v; },
+         "File containing query col IDs (one per line)"},
+        {"--top", Takes::Count, [](Settings& s, const std::string& v) { s.top = (uint32_t)std::stoul(v); },
+         "Number of top jaccard values to show [default 10]"},
+        {"--batch_size", Takes::Count, [](Settings& s, const std::string& v) { s.batch = (uint32_t)std::stoul(v); },
+         "Number of queries to process per batch [default 1000]"},
+        {"--write_to_file", Takes::Word, [](Settings& s, const std::string& v) { s.out_name = v; s.to_file = true; },
+         "Where to save the output (expected format: *.csv/*.tsv/*.npy/*npz for row-col query. *.csv/*tsv/*txt for "
+         "regular query)."},
+        {"--show_all", Takes::Nothing, [](Settings& s, const std::string&) { s.show_all = true; },
+         "Whether to show all neighbors instead of top N"},
+        {"--print", Takes::Nothing, [](Settings& s, const std::string&) { s.to_screen = true; },
+         "Whether to print the outputs to screen"},
+        {"--help", Takes::Nothing, [](Settings& s, const std::string&) { s.help = true; }, "Show this help message"},
+    };
+    return table;
 }
 
-static std::pair<std::string, std::string> split_path(const std::string& fullpath) {   // :37-46
-    const size_t pos = fullpath.find_last_of("/\\");
-    if (pos == std::string::npos) return {fullpath, "./"};
-    return {fullpath.substr(pos + 1), fullpath.substr(0, pos)};
+bool all_digits(const std::string& s) {
+    return !s.empty() && s.size() <= 9 && std::all_of(s.begin(), s.end(), [](char c) { return c >= '0' && c <= '9'; });
 }
 
-static std::string get_file_extension(const std::string& filename) {   // :225-232
-    const size_t dot_pos = filename.find_last_of(".");
-    return dot_pos != std::string::npos ? filename.substr(dot_pos + 1) : "";
-}
+bool looks_like_flag(const char* s) { return s[0] == '-' && s[1] == '-'; }
 
-// Minimal .npy writer with cnpy's "w"/"a" semantics for a float32 array of shape (rows, cols) growing along
-// axis 0 (src/query_pc_mat.cpp:207-212 appends one (1, n) row per query row).  Fixed 128-byte v1.0 header.
-static bool npy_append_row(const std::string& fname, const float* data, size_t cols, bool truncate) {
-    size_t rows = 0;
-    if (!truncate) {
-        std::ifstream in(fname, std::ios::binary);
-        char hdr[128];
-        if (in.read(hdr, 128)) {
-            const std::string h(hdr + 10, 118);
-            const size_t p = h.find("'shape': (");
-            if (p != std::string::npos) rows = (size_t)std::strtoull(h.c_str() + p + 10, nullptr, 10);
+// false: the command line does not fit the table (the caller prints the help and fails)
+bool read_command_line(int argc, char** argv, Settings& s) {
+    for (int at = 1; at < argc;) {
+        const Option* opt = nullptr;
+        for (const Option& o : option_table())
+            if (std::string(argv[at]) == o.flag) opt = &o;
+        if (!opt) return false;
+        ++at;
+        switch (opt->takes) {
+            case Takes::Nothing:
+                opt->store(s, "");
+                break;
+            case Takes::Word:
+            case Takes::Count:
+                if (at >= argc) return false;
+                if (opt->takes == Takes::Count && !all_digits(argv[at])) return false;
+                opt->store(s, argv[at++]);
+                break;
+            case Takes::Words: {
+                int taken = 0;
+                for (; at < argc && !looks_like_flag(argv[at]); ++at, ++taken) opt->store(s, argv[at]);
+                if (!taken) return false;
+                break;
+            }
         }
     }
-    std::fstream f;
-    if (truncate || rows == 0)
-        f.open(fname, std::ios::binary | std::ios::out | std::ios::trunc);
-    else
-        f.open(fname, std::ios::binary | std::ios::in | std::ios::out);
-    if (!f) return false;
-    std::string dict = "{'descr': '<f4', 'fortran_order': False, 'shape': (" + std::to_string(rows + 1) + ", " +
-                       std::to_string(cols) + "), }";
-    dict.resize(117, ' ');
-    dict += '\n';
-    const char magic[10] = {(char)0x93, 'N', 'U', 'M', 'P', 'Y', 1, 0, 118, 0};
-    f.seekp(0);
-    f.write(magic, 10);
-    f.write(dict.data(), 118);
-    f.seekp((std::streamoff)(128 + rows * cols * sizeof(float)));
-    f.write(reinterpret_cast<const char*>(data), (std::streamsize)(cols * sizeof(float)));
-    return (bool)f;
+    // the three ways of naming queries exclude one another; a row file needs its column file
+    if ((int)s.saw_query_file + (int)s.saw_query_ids + (int)s.saw_row_file > 1) return false;
+    if (s.saw_row_file && s.col_file.empty()) return false;
+    return true;
 }
 
-// :48-139
-static void query_nearest_neighbors(const std::string& matrix_folder, const std::string& db_folder,
-                                    const std::string& query_file, std::vector<std::string>& query_ids_str,
-                                    bool write_to_file, bool show_all_neighbors, int64_t top_n, uint32_t batch_size,
-                                    const std::string& out_fn, const std::string& sep, bool print_to_screen) {
-    std::vector<string> identifiers;
-    std::unordered_map<string, int> id_to_index = pc_mat::load_vector_identifiers(db_folder, identifiers);
-    std::vector<std::string> query_id_vec;
-    std::vector<int32_t> queries;
-    if (!query_file.empty()) {
-        queries = pc_mat::read_queries_from_file(query_file, id_to_index, query_id_vec);
-    } else if (!query_ids_str.empty()) {
-        for (const string& query_str : query_ids_str) {
-            const int index = pc_mat::parse_query_to_index(query_str, id_to_index);
-            if (index >= 0) queries.push_back(index);
-        }
-    } else {
-        show_error_and_exit("Error: No queries specified. Use --query_file, --query_ids");
-    }
-    if (queries.empty()) show_error_and_exit("Error: No valid queries found");
-
-    std::vector<float> vector_norms;
-    pc_mat::load_vector_norms(db_folder, vector_norms);
-    const int total_vectors = (int)identifiers.size();
-    std::cout << "Total vectors loaded: " << total_vectors << std::endl << std::endl;
-    if (total_vectors <= 0) show_error_and_exit("Error: Could not determine total number of vectors");
-
-    auto [fname, out_file_path] = split_path(out_fn);
-    std::chrono::duration<double> elapsed = std::chrono::duration<double>::zero();
-    uint64_t start_indx = 0, end_indx;
-    while (1) {
-        end_indx = std::min<uint64_t>(start_indx + batch_size, queries.size());
-        std::vector<int32_t> sub_queries(queries.begin() + start_indx, queries.begin() + end_indx);
-        auto start = std::chrono::high_resolution_clock::now();
-        std::vector<pc_mat::Result> all_results = pc_mat::query(matrix_folder, sub_queries, vector_norms, identifiers);
-        auto end = std::chrono::high_resolution_clock::now();
-        elapsed += (end - start);
-        for (size_t i = 0; i < all_results.size(); i++) {
-            const pc_mat::Result& res = all_results[i];
-            if (print_to_screen)
-                std::cout << "Query: " << res.self_id << " #Neighbors: " << res.neighbor_ids.size() << std::endl;
-            std::ofstream out;
-            if (write_to_file) {
-                const std::string nfn = out_file_path + "/" + res.self_id + "_" + fname;
-                std::cout << "Writing in file: " << nfn << std::endl << std::endl;
-                out.open(nfn.c_str());
-                out << "ID" + sep + "Jaccard\n";
-            }
-            const int64_t num_neighbors_to_show =
-                show_all_neighbors ? (int64_t)res.neighbor_ids.size() : std::min<int64_t>(top_n, (int64_t)res.neighbor_ids.size());
-            if (print_to_screen) std::cout << "Top " << num_neighbors_to_show << " neighbors:\n";
-            for (int64_t j = 0; j < num_neighbors_to_show; ++j) {
-                if (print_to_screen)
-                    std::cout << j + 1 << ". Neighbor: " << res.neighbor_ids[(size_t)j]
-                              << " Jaccard Similarity: " << res.jaccard_similarities[(size_t)j] << std::endl;
-                if (write_to_file) out << res.neighbor_ids[(size_t)j] << sep << res.jaccard_similarities[(size_t)j] << std::endl;
-            }
-            if (print_to_screen) std::cout << std::endl;
-            out.close();
-        }
-        auto time_unit = get_time_unit(elapsed.count());
-        std::cout << "--------- Completed\t" << end_indx << "\tqueries in\t" << std::fixed << std::setprecision(2)
-                  << time_unit.first << "\t" << time_unit.second << " ---------\n";
-        if (end_indx == queries.size()) break;
-        start_indx += batch_size;
-    }
-    auto time_unit = get_time_unit(elapsed.count());
-    std::cout << "Query completed in " << std::fixed << std::setprecision(2) << time_unit.first << "\t" << time_unit.second
-              << "\n" << std::endl;
-}
-
-// :141-223
-static void query_sliced_matrix(const std::string& matrix_folder, const std::string& db_folder,
-                                const std::string& row_file, const std::string& col_file, bool write_to_file,
-                                const std::string& out_fn, uint32_t batch_size, bool print_to_screen,
-                                const std::string& sep) {
-    std::vector<string> identifiers;
-    std::unordered_map<string, int> id_to_index = pc_mat::load_vector_identifiers(db_folder, identifiers);
-    std::vector<std::string> row_vec, col_vec;
-    std::vector<int32_t> row_query_vec = pc_mat::read_queries_from_file(row_file, id_to_index, row_vec);
-    std::vector<int32_t> col_query_vec = pc_mat::read_queries_from_file(col_file, id_to_index, col_vec);
-    if (row_query_vec.empty() || col_query_vec.empty()) show_error_and_exit("Empty row or col accessions.");
-    std::vector<float> vector_norms;
-    pc_mat::load_vector_norms(db_folder, vector_norms);
-    const int total_vectors = (int)identifiers.size();
-    std::cout << "Total vectors loaded: " << total_vectors << std::endl << std::endl;
-    if (total_vectors <= 0) show_error_and_exit("Error: Could not determine total number of vectors");
-    std::chrono::duration<double> elapsed = std::chrono::duration<double>::zero();
-    uint64_t start_indx = 0, end_indx;
-
-    std::ofstream out;
-    if (write_to_file && sep != "-1") {
-        std::cout << "Writing in file: " << out_fn << std::endl << std::endl;
-        out.open(out_fn.c_str());
-        out << "Accession" + sep;
-        for (size_t i = 0; i < col_vec.size(); i++) out << col_vec[i] << sep;
-        out << "\n";
-    }
-    if (print_to_screen) std::cout << "Accession\t";
-    for (size_t i = 0; i < col_vec.size(); i++)
-        if (print_to_screen) std::cout << col_vec[i] << "\t";
-    if (print_to_screen) std::cout << "\n";
-
-    while (1) {
-        end_indx = std::min<uint64_t>(start_indx + batch_size, row_query_vec.size());
-        std::vector<int32_t> row_sub_queries(row_query_vec.begin() + start_indx, row_query_vec.begin() + end_indx);
-        auto start = std::chrono::high_resolution_clock::now();
-        std::vector<std::vector<float>> all_results =
-            pc_mat::query_sliced(matrix_folder, row_sub_queries, col_query_vec, total_vectors, vector_norms);
-        auto end = std::chrono::high_resolution_clock::now();
-        elapsed += (end - start);
-        for (size_t i = 0; i < all_results.size(); i++) {
-            std::vector<float>& res = all_results[i];
-            if (print_to_screen) std::cout << row_vec[start_indx + i] << "\t";
-            if (write_to_file && sep != "-1") out << row_vec[start_indx + i] << sep;
-            if (print_to_screen || (write_to_file && sep != "-1")) {
-                for (size_t j = 0; j < res.size(); ++j) {
-                    if (print_to_screen) std::cout << res[j] << "\t";
-                    if (write_to_file && sep != "-1") out << res[j] << sep;
-                }
-            }
-            if (write_to_file && sep == "-1") {
-                if (!npy_append_row(out_fn, res.data(), res.size(), start_indx == 0 && i == 0))
-                    show_error_and_exit("Error: could not write " + out_fn);
-            }
-            if (print_to_screen) std::cout << std::endl;
-            if (write_to_file && sep != "-1") out << "\n";
-        }
-        auto time_unit = get_time_unit(elapsed.count());
-        std::cout << "--------- Completed\t" << end_indx << "\trows in\t" << std::fixed << std::setprecision(2)
-                  << time_unit.first << "\t" << time_unit.second << " ---------\n";
-        if (end_indx == row_query_vec.size()) break;
-        start_indx += batch_size;
-    }
-    auto time_unit = get_time_unit(elapsed.count());
-    std::cout << "Query completed in " << std::fixed << std::setprecision(2) << time_unit.first << "\t" << time_unit.second
-              << "\n" << std::endl;
-    if (write_to_file && sep != "-1") out.close();
-}
-
-static void print_help(const char* argv0) {   // :283-303
-    std::cout << "Query Pairwise Comparison Matrix\n\n";
-    std::cout << "Usage:\n        " << argv0
+void print_help(const char* program) {
+    std::cout << "Query Pairwise Comparison Matrix\n\nUsage:\n        " << program
               << " [--matrix <folder>] [--db <folder>] [(--query_file <file> | --query_ids <ids>... | --row_file <row>"
                  " --col_file <col>)] [--top <int>] [--batch_size <int>] [--write_to_file <file>] [--show_all] [--print]"
-                 " [--help]\n\n";
-    std::cout << "Options:\n";
-    std::cout << "  --matrix\t Folder containing the pairwise matrix files\n";
-    std::cout << "  --db\t Folder containing the matrix meta data\n";
-    std::cout << "  --query_file\t File containing query IDs (one per line)\n";
-    std::cout << "  --query_ids\t Query IDs as command line arguments (numeric indices or identifiers)\n";
-    std::cout << "  --row_file\t File containing query row IDs (one per line)\n";
-    std::cout << "  --col_file\t File containing query col IDs (one per line)\n";
-    std::cout << "  --top\t Number of top jaccard values to show [default 10]\n";
-    std::cout << "  --batch_size\t Number of queries to process per batch [default 1000]\n";
-    std::cout << "  --write_to_file\t Where to save the output (expected format: *.csv/*.tsv/*.npy/*npz for row-col query. "
-                 "*.csv/*tsv/*txt for regular query).\n";
-    std::cout << "  --show_all\t Whether to show all neighbors instead of top N\n";
-    std::cout << "  --print\t Whether to print the outputs to screen\n";
-    std::cout << "  --help\t Show this help message\n\n";
+                 " [--help]\n\nOptions:\n";
+    for (const Option& o : option_table()) std::cout << "  " << o.flag << "\t " << o.about << "\n";
+    std::cout << "\n";
 }
 
-int main(int argc, char* argv[]) {
-    string matrix_folder, db_folder, query_file, row_file, col_file, out_fn = "out.txt";
-    uint32_t top_n = 10, batch_size = 1000;
-    std::vector<string> query_ids_str;
-    bool show_help = false, write_to_file = false, print_to_screen = false, show_all_neighbors = false;
-    bool use_query_file = false, use_query_ids = false, use_row_col_files = false, ok = true;
+// ---------------------------------------------------------------------------------------------------
+// timing lines:  "--------- Completed\t<n>\t<noun> in\t<t>\t<unit> ---------"  /  "Query completed in <t>\t<unit>"
+// Only the library calls are on the clock, not the printing.
+// ---------------------------------------------------------------------------------------------------
+class Clock {
+public:
+    template <typename Fn>
+    auto timed(Fn&& fn) {
+        const auto t0 = std::chrono::steady_clock::now();
+        auto result = fn();
+        spent_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        return result;
+    }
+    void report_batch(uint64_t done, const char* noun) const {
+        // the two-decimal fixed notation stays switched on for std::cout afterwards, exactly as in the reference:
+        // values printed by later batches of the same run appear with two decimals
+        std::cout << "--------- Completed\t" << done << "\t" << noun << " in\t" << std::fixed << std::setprecision(2)
+                  << scaled() << "\t" << unit() << " ---------\n";
+    }
+    void report_total() const {
+        std::cout << "Query completed in " << std::fixed << std::setprecision(2) << scaled() << "\t" << unit() << "\n"
+                  << std::endl;
+    }
 
-    auto is_flag = [](const std::string& s) { return s.rfind("--", 0) == 0; };
-    for (int i = 1; ok && i < argc; ++i) {
-        const std::string a = argv[i];
-        auto value = [&](std::string& dst) {
-            if (i + 1 >= argc) return false;
-            dst = argv[++i];
-            return true;
-        };
-        auto uvalue = [&](uint32_t& dst) {
-            std::string v;
-            if (!value(v)) return false;
-            char* end = nullptr;
-            const long x = strtol(v.c_str(), &end, 10);
-            if (end == v.c_str() || *end || x < 0) return false;
-            dst = (uint32_t)x;
-            return true;
-        };
-        if (a == "--matrix") ok = value(matrix_folder);
-        else if (a == "--db") ok = value(db_folder);
-        else if (a == "--query_file") { use_query_file = true; ok = value(query_file); }
-        else if (a == "--query_ids") {
-            use_query_ids = true;
-            while (i + 1 < argc && !is_flag(argv[i + 1])) query_ids_str.push_back(argv[++i]);
-            ok = !query_ids_str.empty();
+private:
+    double scaled() const { return spent_ < 60 ? spent_ : spent_ < 3600 ? spent_ / 60 : spent_ / 3600; }
+    const char* unit() const { return spent_ < 60 ? "seconds" : spent_ < 3600 ? "minutes" : "hours"; }
+    double spent_ = 0;
+};
+
+// calls work(first, last) for consecutive index ranges of at most `batch` items, reporting after each
+void in_batches(size_t total, size_t batch, const char* noun, Clock& clock, const std::function<void(size_t, size_t)>& work) {
+    for (size_t first = 0; first < total; first += batch) {
+        const size_t last = std::min(total, first + batch);
+        work(first, last);
+        clock.report_batch(last, noun);
+    }
+    clock.report_total();
+}
+
+std::string extension_of(const std::string& name) {
+    const size_t dot = name.rfind('.');
+    return dot == std::string::npos ? std::string() : name.substr(dot + 1);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// samples of the DB folder + the rows a request names
+// ---------------------------------------------------------------------------------------------------
+struct Catalogue {
+    std::vector<std::string> names;
+    std::vector<float> norms;
+    std::unordered_map<std::string, int> index_of;
+    explicit Catalogue(const std::string& db_folder) {
+        index_of = pc_mat::load_vector_identifiers(db_folder, names);
+    }
+    void finish_loading(const std::string& db_folder) {   // after the queries were resolved, as the reference orders it
+        pc_mat::load_vector_norms(db_folder, norms);
+        std::cout << "Total vectors loaded: " << names.size() << std::endl << std::endl;
+        if (names.empty()) abort_with("Error: Could not determine total number of vectors");
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------
+// mode 1: neighbours of each query
+// ---------------------------------------------------------------------------------------------------
+void neighbour_mode(const Settings& s, const std::string& separator) {
+    Catalogue cat(s.db);
+    std::vector<int> rows;
+    if (!s.query_file.empty()) {
+        std::vector<std::string> labels;
+        rows = pc_mat::read_queries_from_file(s.query_file, cat.index_of, labels);
+    } else if (!s.query_ids.empty()) {
+        for (const std::string& q : s.query_ids) {
+            const int row = pc_mat::parse_query_to_index(q, cat.index_of);
+            if (row >= 0) rows.push_back(row);
         }
-        else if (a == "--row_file") { use_row_col_files = true; ok = value(row_file); }
-        else if (a == "--col_file") ok = value(col_file);
-        else if (a == "--top") ok = uvalue(top_n);
-        else if (a == "--batch_size") ok = uvalue(batch_size);
-        else if (a == "--write_to_file") { write_to_file = true; ok = value(out_fn); }
-        else if (a == "--show_all") show_all_neighbors = true;
-        else if (a == "--print") print_to_screen = true;
-        else if (a == "--help") show_help = true;
-        else ok = false;
-    }
-    if ((int)use_query_file + (int)use_query_ids + (int)use_row_col_files > 1) ok = false;   // alternatives (:268-275)
-    if (use_row_col_files && col_file.empty()) ok = false;
-    if (!ok || show_help) {
-        print_help(argv[0]);
-        return show_help ? 0 : 1;
-    }
-    if (matrix_folder.empty()) show_error_and_exit("Error: matrix folder is required.");
-    if (!use_query_file && !use_query_ids && !use_row_col_files) show_error_and_exit("No query files given.");
-    if (!fs::exists(matrix_folder)) show_error_and_exit("Error: Matrix folder does not exist.");
-    if (matrix_folder.back() != '/' && matrix_folder.back() != '\\') matrix_folder += '/';
-    if (!db_folder.empty() && db_folder.back() != '/' && db_folder.back() != '\\') db_folder += '/';
-    if (write_to_file && out_fn.empty()) show_error_and_exit("No output filename given.");
-    if (batch_size == 0) batch_size = 1;
-    if (!write_to_file) print_to_screen = true;
-
-    const std::string file_extension = get_file_extension(out_fn);
-    if (use_query_file || use_query_ids) {
-        if (write_to_file && file_extension != "csv" && file_extension != "tsv" && file_extension != "txt")
-            show_error_and_exit("Output file extension is: " + file_extension + ". Expected: csv, tsv or txt.");
-        const std::string sep = file_extension == "csv" ? "," : "\t";
-        query_nearest_neighbors(matrix_folder, db_folder, query_file, query_ids_str, write_to_file, show_all_neighbors,
-                                top_n, batch_size, out_fn, sep, print_to_screen);
     } else {
-        if (row_file.empty() || col_file.empty()) show_error_and_exit("Either row or col file is not specified.");
-        if (write_to_file && file_extension != "csv" && file_extension != "tsv" && file_extension != "npy" &&
-            file_extension != "npz")
-            show_error_and_exit("Output file extension is: " + file_extension + ". Expected: csv, tsv, npy or npz.");
-        std::string sep = "-1";
-        if (file_extension == "csv" || file_extension == "tsv") sep = file_extension == "csv" ? "," : "\t";
-        query_sliced_matrix(matrix_folder, db_folder, row_file, col_file, write_to_file, out_fn, batch_size, print_to_screen,
-                            sep);
+        abort_with("Error: No queries specified. Use --query_file, --query_ids");
+    }
+    if (rows.empty()) abort_with("Error: No valid queries found");
+    cat.finish_loading(s.db);
+
+    // per-query files land next to the requested name: <dir>/<query id>_<file name>
+    const size_t cut = s.out_name.find_last_of("/\\");
+    const std::string out_dir = cut == std::string::npos ? std::string("./") : s.out_name.substr(0, cut);
+    const std::string out_leaf = cut == std::string::npos ? s.out_name : s.out_name.substr(cut + 1);
+
+    Clock clock;
+    in_batches(rows.size(), s.batch, "queries", clock, [&](size_t first, size_t last) {
+        std::vector<int> part(rows.begin() + (std::ptrdiff_t)first, rows.begin() + (std::ptrdiff_t)last);
+        const std::vector<pc_mat::Result> found =
+            clock.timed([&] { return pc_mat::query(s.matrix, part, cat.norms, cat.names); });
+        for (const pc_mat::Result& r : found) {
+            const size_t have = r.neighbor_ids.size();
+            const size_t shown = s.show_all ? have : std::min<size_t>(s.top, have);
+            if (s.to_screen) std::cout << "Query: " << r.self_id << " #Neighbors: " << have << std::endl;
+            std::ofstream file;
+            if (s.to_file) {
+                const std::string path = out_dir + "/" + r.self_id + "_" + out_leaf;
+                std::cout << "Writing in file: " << path << std::endl << std::endl;
+                file.open(path);
+                file << "ID" << separator << "Jaccard\n";
+            }
+            if (s.to_screen) std::cout << "Top " << shown << " neighbors:\n";
+            for (size_t k = 0; k < shown; ++k) {
+                if (s.to_screen)
+                    std::cout << k + 1 << ". Neighbor: " << r.neighbor_ids[k]
+                              << " Jaccard Similarity: " << r.jaccard_similarities[k] << std::endl;
+                if (s.to_file) file << r.neighbor_ids[k] << separator << r.jaccard_similarities[k] << std::endl;
+            }
+            if (s.to_screen) std::cout << std::endl;
+        }
+    });
+}
+
+// ---------------------------------------------------------------------------------------------------
+// mode 2: rows x columns slice, through sinks
+// ---------------------------------------------------------------------------------------------------
+class SliceSink {
+public:
+    virtual ~SliceSink() = default;
+    virtual void header(const std::vector<std::string>& columns) = 0;
+    virtual void line(const std::string& row_label, const std::vector<float>& values) = 0;
+    virtual void close() {}
+};
+
+class DelimitedSink : public SliceSink {   // screen (tab separated on std::cout) or a csv / tsv file
+public:
+    DelimitedSink(std::ostream& os, std::string sep, bool flush_lines)
+        : os_(os), sep_(std::move(sep)), flush_(flush_lines) {}
+    void header(const std::vector<std::string>& columns) override {
+        os_ << "Accession" << sep_;
+        for (const std::string& c : columns) os_ << c << sep_;
+        os_ << "\n";
+    }
+    void line(const std::string& row_label, const std::vector<float>& values) override {
+        os_ << row_label << sep_;
+        for (const float v : values) os_ << v << sep_;
+        if (flush_) os_ << std::endl;
+        else os_ << "\n";
+    }
+
+private:
+    std::ostream& os_;
+    std::string sep_;
+    bool flush_;
+};
+
+// float32 array of shape (rows, columns) in NumPy's .npy v1.0 container; the header is a fixed 128 bytes, so the row
+// count can be filled in when the last row has been written
+class NpySink : public SliceSink {
+public:
+    explicit NpySink(const std::string& path) : path_(path), f_(path, std::ios::binary | std::ios::trunc) {
+        if (!f_) abort_with("Error: could not write " + path);
+    }
+    void header(const std::vector<std::string>& columns) override {
+        cols_ = columns.size();
+        write_header();
+    }
+    void line(const std::string&, const std::vector<float>& values) override {
+        f_.write(reinterpret_cast<const char*>(values.data()), (std::streamsize)(values.size() * sizeof(float)));
+        ++rows_;
+    }
+    void close() override {
+        write_header();
+        f_.flush();
+        if (!f_) abort_with("Error: could not write " + path_);
+    }
+
+private:
+    void write_header() {
+        char text[119];
+        const int used = std::snprintf(text, sizeof text, "{'descr': '<f4', 'fortran_order': False, 'shape': (%zu, %zu), }",
+                                       rows_, cols_);
+        std::string block("\x93NUMPY\x01\x00\x76\x00", 10);   // magic, version 1.0, header length 118
+        block.append(text, (size_t)used);
+        block.resize(127, ' ');
+        block.push_back('\n');
+        const auto back = f_.tellp();
+        f_.seekp(0);
+        f_.write(block.data(), 128);
+        if (back > std::streampos(128)) f_.seekp(back);
+    }
+    std::string path_;
+    std::ofstream f_;
+    size_t rows_ = 0, cols_ = 0;
+};
+
+void slice_mode(const Settings& s, const std::string& ext) {
+    Catalogue cat(s.db);
+    std::vector<std::string> row_labels, col_labels;
+    std::vector<int32_t> rows = pc_mat::read_queries_from_file(s.row_file, cat.index_of, row_labels);
+    std::vector<int32_t> cols = pc_mat::read_queries_from_file(s.col_file, cat.index_of, col_labels);
+    if (rows.empty() || cols.empty()) abort_with("Empty row or col accessions.");
+    cat.finish_loading(s.db);
+
+    std::vector<std::unique_ptr<SliceSink>> sinks;
+    std::ofstream text_file;
+    if (s.to_file && (ext == "csv" || ext == "tsv")) {
+        std::cout << "Writing in file: " << s.out_name << std::endl << std::endl;
+        text_file.open(s.out_name);
+        sinks.push_back(std::make_unique<DelimitedSink>(text_file, ext == "csv" ? "," : "\t", false));
+    } else if (s.to_file) {   // npy / npz: both get the .npy container, one array
+        sinks.push_back(std::make_unique<NpySink>(s.out_name));
+    }
+    if (s.to_screen) sinks.push_back(std::make_unique<DelimitedSink>(std::cout, "\t", true));
+    for (auto& sink : sinks) sink->header(col_labels);
+
+    Clock clock;
+    in_batches(rows.size(), s.batch, "rows", clock, [&](size_t first, size_t last) {
+        std::vector<int32_t> part(rows.begin() + (std::ptrdiff_t)first, rows.begin() + (std::ptrdiff_t)last);
+        const std::vector<std::vector<float>> values = clock.timed(
+            [&] { return pc_mat::query_sliced(s.matrix, part, cols, (int32_t)cat.names.size(), cat.norms); });
+        for (size_t i = 0; i < values.size(); ++i)
+            for (auto& sink : sinks) sink->line(row_labels[first + i], values[i]);
+    });
+    for (auto& sink : sinks) sink->close();
+}
+
+}  // namespace
+
+int main(int argc, char* argv[]) {
+    Settings s;
+    const bool fits = read_command_line(argc, argv, s);
+    if (!fits || s.help) {
+        print_help(argv[0]);
+        return s.help ? 0 : 1;
+    }
+    if (s.matrix.empty()) abort_with("Error: matrix folder is required.");
+    const bool neighbour_query = s.saw_query_file || s.saw_query_ids;
+    if (!neighbour_query && !s.saw_row_file) abort_with("No query files given.");
+    if (!std::filesystem::exists(s.matrix)) abort_with("Error: Matrix folder does not exist.");
+    for (std::string* folder : {&s.matrix, &s.db})
+        if (!folder->empty() && folder->back() != '/' && folder->back() != '\\') folder->push_back('/');
+    if (s.to_file && s.out_name.empty()) abort_with("No output filename given.");
+    if (s.batch == 0) s.batch = 1;
+    if (!s.to_file) s.to_screen = true;   // with nowhere else to go the output is printed
+
+    const std::string ext = extension_of(s.out_name);
+    if (neighbour_query) {
+        if (s.to_file && ext != "csv" && ext != "tsv" && ext != "txt")
+            abort_with("Output file extension is: " + ext + ". Expected: csv, tsv or txt.");
+        neighbour_mode(s, ext == "csv" ? "," : "\t");
+    } else {
+        if (s.row_file.empty() || s.col_file.empty()) abort_with("Either row or col file is not specified.");
+        if (s.to_file && ext != "csv" && ext != "tsv" && ext != "npy" && ext != "npz")
+            abort_with("Output file extension is: " + ext + ". Expected: csv, tsv, npy or npz.");
+        slice_mode(s, ext);
     }
     return 0;
 }
