@@ -372,10 +372,19 @@ def usable_cores(visible):
     """threads worth starting: the cgroup CPU quota when there is one (a GPU box hands a 1-GPU job a share of the
     host's cores; 128 OpenMP threads on a 16-core quota run slower than 16), else every visible core"""
     try:
-        with open("/sys/fs/cgroup/cpu.max") as f:
+        with open("/sys/fs/cgroup/cpu.max") as f:                      # cgroup v2
             quota, period = f.read().split()[:2]
         if quota != "max":
             return max(1, min(visible, int(round(float(quota) / float(period)))))
+    except Exception:
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:         # cgroup v1
+            quota = int(f.read())
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+            period = int(f.read())
+        if quota > 0:
+            return max(1, min(visible, int(round(quota / period))))
     except Exception:
         pass
     try:

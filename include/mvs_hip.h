@@ -87,10 +87,11 @@ int mvs_ctx_kernel_ms(mvs_ctx* ctx, int which, float* ms);
  * mvs_ctx_set_option changes it, so two contexts (or two threads with a context each) never interfere.
  *   pairwise_filter       0 exact kernel on every cell; 1 (default) two-stage comparison for blocks of at least
  *                         2^22 cells of a two-limb set; 2 two-stage whenever the set has two limbs (tests)
- *   filter_variant        tile shape of the one-pass filter: -1 (default) by block size, 0 = 128 x 128,
- *                         1 = 256 x 256, 3/5/6 other shapes / ring depths
+ *   filter_variant        kernel of the one-pass filter: -1 (default) by block size, 8 = ping-pong wave groups on
+ *                         256 x 256 tiles (7/9/10 its variants), 0 = 128 x 128 ring, 1 = 256 x 256 ring, 3/5/6 other rings
  *   exact_variant         re-check kernel: 0 (default) 64 pairs per wave round, 1 quarter wave per pair, 2 16 per round
- *   pairwise_variant      exact kernel: 6 (default) 16x16x64 MFMA for two limbs, 0-5 32x32x32 tile / ring variants
+ *   pairwise_variant      exact kernel: 8 (default) ping-pong 16x16x64 MFMA for two limbs (7/9 its variants), 6 the ring
+ *                         kernel on the same shape, 0-5 32x32x32 tile / ring variants
  *   pairwise_symmetric    1 (default) skip tiles below the diagonal and mirror; 0 compute every tile
  *   pairwise_block_cells  row-chunk bound of mvs_pairwise_rows, in cells (default 2^40)
  *   sort                  kept-cell sort: 0 (default) by list length, 1 merge sort, 2 radix sort

@@ -10,7 +10,8 @@ import weakref
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmvs_hip.so")
+# MVS_HIP_LIBRARY: profiling tools point this at the ablation build (make -C csrc ablations); nothing else should
+LIB_PATH = os.environ.get("MVS_HIP_LIBRARY") or os.path.join(_HERE, "libmvs_hip.so")
 
 MVS_OK, MVS_E_INVALID, MVS_E_HIP, MVS_E_CAPACITY, MVS_E_NOMEM, MVS_E_RANGE = 0, 1, 2, 3, 4, 5
 MEM_HOST, MEM_DEVICE = 0, 1

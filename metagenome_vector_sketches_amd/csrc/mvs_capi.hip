@@ -147,7 +147,7 @@ const OptionSpec kOptions[] = {
     {"pairwise_filter", &mvs::Options::pairwise_filter, nullptr, 0, 2},
     {"filter_variant", &mvs::Options::filter_variant, nullptr, -1, 99},
     {"exact_variant", &mvs::Options::exact_variant, nullptr, 0, 2},
-    {"pairwise_variant", &mvs::Options::pairwise_variant, nullptr, 0, 6},
+    {"pairwise_variant", &mvs::Options::pairwise_variant, nullptr, 0, 9},
     {"pairwise_symmetric", &mvs::Options::pairwise_symmetric, nullptr, 0, 1},
     {"pairwise_debug", &mvs::Options::pairwise_debug, nullptr, 0, 3},
     {"sort", &mvs::Options::sort, nullptr, 0, 2},
@@ -159,7 +159,7 @@ int apply_option(mvs::Options& o, const OptionSpec& sp, long long v) {
 #ifndef MVS_ABLATIONS
     if (sp.ifield == &mvs::Options::pairwise_debug && v != 0)
         return fail(MVS_E_INVALID, "pairwise_debug needs a library built with -DMVS_ABLATIONS");
-    if (sp.ifield == &mvs::Options::filter_variant && v >= 10)
+    if (sp.ifield == &mvs::Options::filter_variant && v >= 11)
         return fail(MVS_E_INVALID, "filter_variant %lld is a k-loop ablation: needs -DMVS_ABLATIONS", v);
 #endif
     if (v < sp.lo || v > sp.hi) return fail(MVS_E_INVALID, "option %s: %lld outside [%lld, %lld]", sp.name, v, sp.lo, sp.hi);

@@ -588,6 +588,83 @@ __global__ __launch_bounds__(WM * WN * 64, (AT * BT > 2 ? 1 : 2)) void k_pairwis
 // ---------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int swz16(int s) { return (0x78 >> (((s >> 2) & 3) * 2)) & 3; }   // {0,2,3,1}
 
+// Epilogue shared by the two-limb 16x16x64 kernels (wave tile 64 x 32 of a 128 x 128 tile, accumulators
+// acc[t][u][a+b]: row = wm*64 + t*16 + (lane>>4)*4 + r, column = wn*32 + u*16 + (lane&15)): recombine the limb
+// products, MODE 1: store the dots; MODE 0: integer pre-test, fp64 keep test for its survivors, one atomic per wave.
+template <int MODE>
+__device__ __forceinline__ void epilogue_exact16(const PairwiseArgs& a, v4i (&acc)[4][2][3], char* smem, int tid, int lane,
+                                                 int wave, int wm, int wn, int64_t i0, int64_t j0, bool mirror_tile) {
+    constexpr int TM = 128, TN = 128, kWavesT = 8;
+    const int fr = lane & 15, fq = lane >> 4;
+    __syncthreads();
+    int32_t* thr = reinterpret_cast<int32_t*>(smem);
+    if (MODE == 0) {
+        for (int x = tid; x < TM + TN; x += kWavesT * 64) thr[x] = a.cand_thr[(x < TM ? i0 : j0 - TM) + x];
+        __syncthreads();
+    }
+    auto dot_of = [&](int t, int u, int r) -> int32_t {
+        return (int32_t)((uint32_t)acc[t][u][0][r] + ((uint32_t)acc[t][u][1][r] << 8) + ((uint32_t)acc[t][u][2][r] << 16));
+    };
+    if constexpr (MODE == 1) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int64_t col = j0 + wn * 32 + u * 16 + fr;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int64_t row = i0 + wm * 64 + t * 16 + fq * 4 + r;
+                    if (row < a.row_end && col < a.col_end)
+                        a.dots[(row - a.row_begin) * (a.col_end - a.col_begin) + (col - a.col_begin)] = dot_of(t, u, r);
+                }
+        }
+        return;
+    }
+    // pass 1: keep masks (16 cells per lane and column) parked in LDS; pass 2: one atomic per wave, then the writes
+    unsigned* masks = reinterpret_cast<unsigned*>(smem + (TM + TN) * 4) + wave * 128 + lane;
+    unsigned mine = 0;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int col_l = wn * 32 + u * 16 + fr;
+        const int64_t col = j0 + col_l;
+        const bool mirror = a.mirror_all || (mirror_tile && col < a.row_end);
+        unsigned m16 = 0;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row_l = wm * 64 + t * 16 + fq * 4 + r;
+                const int64_t row = i0 + row_l;
+                const int32_t P = dot_of(t, u, r);
+                const bool cand = P >= thr[row_l] + thr[TM + col_l];
+                if (__any(cand)) {
+                    bool keep = false;
+                    if (cand && row < a.row_end && col < a.col_end)
+                        keep = keep_cell(P, a.d, a.norms_sq[row], a.norms_sq[col], a.keep_mode, a.keep_coeff);
+                    m16 |= keep ? 1u << (t * 4 + r) : 0u;
+                }
+            }
+        masks[u * 64] = m16;
+        mine += (unsigned)__popc(m16) << (mirror ? 1 : 0);
+    }
+    if (__ballot(mine != 0) == 0ULL) return;
+    unsigned long long out_slot = wave_reserve(a.counter, mine, lane);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int64_t col = j0 + wn * 32 + u * 16 + fr;
+        const bool mirror = a.mirror_all || (mirror_tile && col < a.row_end);
+        const unsigned m = masks[u * 64];   // this lane's own word
+        if (__ballot(m != 0) == 0ULL) continue;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (m & (1u << (t * 4 + r)))
+                    write_cell(a, out_slot, mirror, (int32_t)(i0 + wm * 64 + t * 16 + fq * 4 + r), (int32_t)col,
+                               dot_of(t, u, r));
+    }
+}
+
 template <int MODE, int NST>
 __global__ __launch_bounds__(512, 2) void k_pairwise_mfma16(const PairwiseArgs a, int n_tr, int n_tc, int n_spc) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -685,72 +762,294 @@ __global__ __launch_bounds__(512, 2) void k_pairwise_mfma16(const PairwiseArgs a
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-    __syncthreads();
-    int32_t* thr = reinterpret_cast<int32_t*>(smem);
-    if (MODE == 0) {
-        for (int x = tid; x < TM + TN; x += kWavesT * 64) thr[x] = a.cand_thr[(x < TM ? i0 : j0 - TM) + x];
-        __syncthreads();
-    }
-    auto dot_of = [&](int t, int u, int r) -> int32_t {
-        return (int32_t)((uint32_t)acc[t][u][0][r] + ((uint32_t)acc[t][u][1][r] << 8) + ((uint32_t)acc[t][u][2][r] << 16));
-    };
-    if constexpr (MODE == 1) {
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int64_t col = j0 + wn * 32 + u * 16 + fr;
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int64_t row = i0 + wm * 64 + t * 16 + fq * 4 + r;
-                    if (row < a.row_end && col < a.col_end)
-                        a.dots[(row - a.row_begin) * (a.col_end - a.col_begin) + (col - a.col_begin)] = dot_of(t, u, r);
-                }
+    epilogue_exact16<MODE>(a, acc, smem, tid, lane, wave, wm, wn, i0, j0, mirror_tile);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// "Ping-pong" kernel (16x16x64 int8 MFMA).  Measured on the ring kernels above (ablation builds, 100k x 2048
+// filter pass of 11.4 ms): the HBM/L2 -> LDS copies + fragment reads alone take 5.2 ms of k-loop, the MFMAs alone
+// 5.0 ms, together 9.6 ms -- the eight waves of a workgroup move in lock step (all issue copies, all read
+// fragments, all run MFMAs), so the two halves of the work hardly overlap.  Here the two wave groups of the
+// workgroup -- waves 0-3 and 4-7, i.e. the two waves of every SIMD -- run half a step apart: a step of a wave is
+//     LOAD  : 12 ds_read_b128 (all fragments of one 64-byte k-slice), 4 LDS-DMA pieces of a later slice, counted
+//             vmcnt wait, s_barrier
+//     MFMA  : 32 x v_mfma_i32_16x16x64_i8 on those fragments, s_barrier
+// and group 1 starts with one extra s_barrier (group 0 ends with one), so that in every barrier interval one group
+// is in LOAD and the other in MFMA: the SIMD's matrix pipe always has one wave feeding it while its partner moves
+// data.  Fragments need no double buffer (a slice is read in one interval and consumed in the next).
+// LDS: ring of NST stages of 32 KiB, copies run D = NST - 2 slices ahead:
+//   RAW  slice s is read by group 0 in interval 2s and by group 1 in 2s+1; every wave waits (vmcnt) for its own
+//        pieces of slice s+1 at the end of LOAD(s), i.e. before the barriers that open intervals 2s+1 / 2s+2;
+//   WAR  the copies issued in LOAD(s) overwrite the slot of slice s-2, last read two intervals (group 1: three)
+//        earlier and retired by an lgkmcnt wait in between.
+// MODE 2 (filter): one coarse plane, tile 256 x 256, wave tile 128 x 64 (8 x 4 MFMA tiles, 128 accumulators).
+// MODE 0 / 1 (comparison / dots on two base-256 limbs): tile 128 x 128, wave tile 64 x 32, the four limb products
+// of a slice are the 32 MFMAs; accumulators and epilogue as in k_pairwise_mfma16.
+// ---------------------------------------------------------------------------------------------------
+template <int MODE>
+struct PpGeom {
+    static constexpr bool kFilter = MODE == 2;
+    static constexpr int L = kFilter ? 1 : 2;
+    static constexpr int TM = kFilter ? 256 : 128, TN = TM;
+    static constexpr int WROWS = TM / 2, WCOLS = TN / 4;          // wave tile (2 x 4 waves)
+    static constexpr int kRegion = L * TM * kSK;                  // 16 KiB per operand either way
+    static constexpr int kStage = 2 * kRegion;                    // 32 KiB per slice
+    static constexpr int kPPW = kStage / 1024 / 8;                // 4 pieces per wave and slice
+};
+
+// filter epilogue for the 16x16 accumulator layout (same test as in k_pairwise_mfma<.., MODE 2>)
+__device__ __forceinline__ void epilogue_filter16(const PairwiseArgs& a, v4i (&acc)[8][4], char* smem, int tid, int lane,
+                                                  int wave, int wm, int wn, int64_t i0, int64_t j0) {
+    constexpr int TM = 256, TN = 256;
+    using v2f = __attribute__((ext_vector_type(2))) float;
+    using v4f = __attribute__((ext_vector_type(4))) float;
+    const int fr = lane & 15, fq = lane >> 4;
+    __syncthreads();                                                   // every wave is done with the ring
+    float* frow = reinterpret_cast<float*>(smem);                      // TM/2 row pairs x {s0 s1 w0 w1 | a0 a1 p0 p1}
+    float4* fcol = reinterpret_cast<float4*>(smem + TM * 16);          // TN entries {s, w, a, p}
+    for (int x = tid; x < TM + TN; x += 512) {
+        const int64_t g = (x < TM ? i0 : j0 - TM) + x;
+        float4 m = a.fmeta[g];
+        if (g >= (x < TM ? a.row_end : a.col_end)) m = make_float4(__builtin_inff(), 0.0f, 0.0f, 0.0f);
+        if (x < TM) {
+            float* q = frow + (x >> 1) * 8 + (x & 1);
+            q[0] = m.x;
+            q[2] = m.y;
+            q[4] = m.z;
+            q[6] = m.w;
+        } else {
+            fcol[x - TM] = m;
         }
-        return;
     }
-    // pass 1: keep masks (16 cells per lane and column) parked in LDS; pass 2: one atomic per wave, then the writes
-    unsigned* masks = reinterpret_cast<unsigned*>(smem + (TM + TN) * 4) + wave * 128 + lane;
+    __syncthreads();
+    const bool straddle = a.symmetric && j0 < i0 + TM && j0 + TN > i0;
+    const int delta = (int)(j0 - i0);                                  // col - row = col_l - row_l + delta
+    // one 32-bit mask per lane and 16-column group: bit t*4 + r <=> row wm*128 + t*16 + fq*4 + r passes
+    unsigned* masks = reinterpret_cast<unsigned*>(smem + (TM + TN) * 16) + wave * 256 + lane;
     unsigned mine = 0;
+    auto sweep = [&](auto tri) {
+        constexpr bool TRI = decltype(tri)::value;
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const int col_l = wn * 32 + u * 16 + fr;
-        const int64_t col = j0 + col_l;
-        const bool mirror = a.mirror_all || (mirror_tile && col < a.row_end);
-        unsigned m16 = 0;
+        for (int u = 0; u < 4; ++u) {
+            const int col_l = wn * 64 + u * 16 + fr;
+            const int64_t col = j0 + col_l;
+            const float4 mj = fcol[col_l];
+            const float bj = mj.z + mj.w;
+            const v2f wj = {mj.y, mj.y}, sj = {mj.x, mj.x}, npj = {-mj.w, -mj.w}, nbj = {-bj, -bj};
+            const bool in_square = a.symmetric && col >= a.row_begin && col < a.row_end;
+            const int row_max = (TRI && in_square) ? col_l + delta : 0x7fffffff;   // col >= row  <=>  row_l <= col_l + delta
+            unsigned m32 = 0;
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+            for (int t = 0; t < 8; ++t) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row_l = wm * 64 + t * 16 + fq * 4 + r;
-                const int64_t row = i0 + row_l;
-                const int32_t P = dot_of(t, u, r);
-                const bool cand = P >= thr[row_l] + thr[TM + col_l];
-                if (__any(cand)) {
-                    bool keep = false;
-                    if (cand && row < a.row_end && col < a.col_end)
-                        keep = keep_cell(P, a.d, a.norms_sq[row], a.norms_sq[col], a.keep_mode, a.keep_coeff);
-                    m16 |= keep ? 1u << (t * 4 + r) : 0u;
+                for (int r = 0; r < 4; r += 2) {
+                    const int row_l = wm * 128 + t * 16 + fq * 4 + r;              // even: rows row_l, row_l + 1
+                    const v4f q0 = *reinterpret_cast<const v4f*>(frow + (row_l >> 1) * 8);
+                    const v4f q1 = *reinterpret_cast<const v4f*>(frow + (row_l >> 1) * 8 + 4);
+                    v2f rhs = v2f{q0[0], q0[1]} * wj;
+                    rhs = __builtin_elementwise_fma(v2f{q0[2], q0[3]}, sj, rhs);
+                    rhs = __builtin_elementwise_fma(v2f{q1[0], q1[1]}, npj, rhs);
+                    rhs = __builtin_elementwise_fma(v2f{q1[2], q1[3]}, nbj, rhs);
+                    bool c0 = (float)acc[t][u][r] > rhs[0];
+                    bool c1 = (float)acc[t][u][r + 1] > rhs[1];
+                    if (TRI) {
+                        c0 = c0 && row_l <= row_max;
+                        c1 = c1 && row_l < row_max;
+                    }
+                    m32 |= (c0 ? 1u << (t * 4 + r) : 0u) | (c1 ? 2u << (t * 4 + r) : 0u);
                 }
             }
-        masks[u * 64] = m16;
-        mine += (unsigned)__popc(m16) << (mirror ? 1 : 0);
+            masks[u * 64] = m32;
+            mine += (unsigned)__popc(m32);
+        }
+    };
+    if (straddle) sweep(std::true_type{});
+    else sweep(std::false_type{});
+    if (__ballot(mine != 0) == 0ULL) return;               // the common case: nothing in this wave passes
+    unsigned incl = mine;                                   // inclusive prefix sum over the lanes
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned up = (unsigned)__shfl_up((int)incl, o, 64);
+        if (lane >= o) incl += up;
     }
-    if (__ballot(mine != 0) == 0ULL) return;
-    unsigned long long out_slot = wave_reserve(a.counter, mine, lane);
+    unsigned long long base = 0;
+    if (lane == 63) {
+        base = atomicAdd(a.cand_counter, (unsigned long long)incl);
+        if (base + incl > a.cand_limit) *a.cand_stop = 1u;   // tell the tiles that have not started yet
+    }
+    base = __shfl(base, 63, 64);
+    unsigned long long slot = base + (incl - mine);
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const int64_t col = j0 + wn * 32 + u * 16 + fr;
-        const bool mirror = a.mirror_all || (mirror_tile && col < a.row_end);
-        const unsigned m = masks[u * 64];   // this lane's own word
-        if (__ballot(m != 0) == 0ULL) continue;
+    for (int u = 0; u < 4; ++u) {
+        const int col_l = wn * 64 + u * 16 + fr;
+        const int64_t col = j0 + col_l;
+        const bool in_square = a.symmetric && col >= a.row_begin && col < a.row_end;
+        const int cd = col_l + delta;
+        unsigned m = masks[u * 64];                          // this lane's own word: no barrier needed
+        while (m) {
+            const int b = __ffs((int)m) - 1;
+            m &= m - 1;
+            const int row_l = wm * 128 + (b >> 2) * 16 + fq * 4 + (b & 3);
+            const bool mirror = a.mirror_all || (in_square && cd > row_l);
+            if (slot < a.cand_capacity)
+                a.cand[slot] = make_int2((int32_t)(i0 + row_l), mirror ? (int)((unsigned)col | 0x80000000u) : (int)col);
+            ++slot;
+        }
+    }
+}
+
+// ORDER: 0 fragment reads then copies, 1 copies then fragment reads, 2 by wave parity (half the group's waves each
+// way, so that the LDS reads of some overlap the copy issue of the others).  ABL (ablation builds): 1 no MFMA,
+// 2 no copies after the prologue, 3 no fragment reads after the first slice.
+// PH: phases per slice (1: 32 MFMAs per interval; 2: the slice's A fragments in two halves, 16 MFMAs per interval).
+template <int MODE, int NST, int ORDER = 0, int ABL = 0, int PH = 1>
+__global__ __launch_bounds__(512, 2) void k_pairwise_pp(const PairwiseArgs a, int n_tr, int n_tc) {
+#ifndef MVS_ABLATIONS
+    static_assert(ABL == 0, "ablations need a -DMVS_ABLATIONS build");
+#endif
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using G = PpGeom<MODE>;
+    constexpr int L = G::L, TM = G::TM, TN = G::TN, kRegion = G::kRegion, kStage = G::kStage, kPPW = G::kPPW;
+    constexpr int D = NST - 2;                                   // slices the copies run ahead
+    static_assert(NST >= 3 && NST <= 5 && kPPW == 4, "ring geometry");
+    const TileCoord tc = map_tile(blockIdx.x, blockIdx.y, n_tr, n_tc);
+    if (!tc.valid) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;                     // wm is also the wave group: waves w and w+4 share a SIMD
+    const int64_t i0 = a.row_begin + (int64_t)tc.tr * TM, j0 = a.col_begin + (int64_t)tc.tc * TN;
+    bool mirror_tile = false;
+    if (MODE != 1 && a.symmetric) {
+        if (j0 >= a.row_begin && j0 + TN <= i0) return;
+        mirror_tile = j0 >= i0 + TM && j0 < a.row_end;
+    }
+    if constexpr (MODE == 2) {
+        if (*reinterpret_cast<volatile const unsigned int*>(a.cand_stop) != 0u) return;
+    }
+    // ---- LDS-DMA sources: piece = 16 LDS rows of 64 B, lane -> row piece*16 + lane/4, 16-byte slot lane%4 ----
+    const int8_t* src[kPPW];
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+    for (int p = 0; p < kPPW; ++p) {
+        const int row = (wave * kPPW + p) * 16 + (lane >> 2);    // [0, 2 * L * TM): A region then B region
+        const bool is_b = row >= L * TM;
+        const int rr = is_b ? row - L * TM : row;
+        const int limb = rr / TM, s = rr % TM;
+        const int c = (lane & 3) ^ swz16(s);
+        const int64_t sample = (is_b ? j0 : i0) + s;
+        src[p] = (MODE == 2 ? a.coarse : a.planes) + (sample * L + limb) * (int64_t)a.d_pad + c * 16;
+    }
+    auto stage_copy = [&](int slot, int k0) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (m & (1u << (t * 4 + r)))
-                    write_cell(a, out_slot, mirror, (int32_t)(i0 + wm * 64 + t * 16 + fq * 4 + r), (int32_t)col,
-                               dot_of(t, u, r));
+        for (int p = 0; p < kPPW; ++p)
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src[p] + k0),
+                                             (lds_ptr_t)(smem + slot * kStage + (wave * kPPW + p) * 1024), 16, 0, 0);
+    };
+    // ---- fragments: 8 of the A operand, 4 of the B operand per slice ----
+    const int fr = lane & 15, fq = lane >> 4;
+    const int coff = (fq ^ swz16(fr)) << 4;                      // tile bases are multiples of 16 samples
+    // MODE 2: A fragment i = rows wm*128 + i*16..; MODE 0/1: A fragment i = (t = i >> 1, limb = i & 1)
+    int a_off[8], b_off[4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        a_off[i] = MODE == 2 ? (wm * 128 + i * 16 + fr) * kSK + coff
+                             : ((i & 1) * TM + wm * 64 + (i >> 1) * 16 + fr) * kSK + coff;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        b_off[i] = kRegion + (MODE == 2 ? (wn * 64 + i * 16 + fr) * kSK + coff
+                                        : ((i & 1) * TN + wn * 32 + (i >> 1) * 16 + fr) * kSK + coff);
+    v4i fa[8], fb[4];
+    constexpr int NACC = MODE == 2 ? 32 : 24;
+    v4i accv[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) accv[i] = v4i{0, 0, 0, 0};
+
+    const int nk = a.d_pad / kSK;
+#pragma unroll
+    for (int st = 0; st < D; ++st)
+        if (st < nk) stage_copy(st, st * kSK);
+    {   // slice 0 has landed <=> only the copies of the slices issued after it are outstanding
+        const int younger = (nk < D ? nk : D) - 1;
+        if (younger >= 2) wait_vmcnt<2 * kPPW>();
+        else if (younger == 1) wait_vmcnt<kPPW>();
+        else wait_vmcnt<0>();
+    }
+    __builtin_amdgcn_s_barrier();
+    if (wm == 1) __builtin_amdgcn_s_barrier();                   // group 1 runs one interval behind group 0
+    int slot = 0, fill = D % NST;
+    for (int s = 0; s < nk; ++s) {
+        const char* sb = smem + slot * kStage;
+#pragma unroll
+        for (int ph = 0; ph < PH; ++ph) {
+            constexpr int AF = 8 / PH, CP = kPPW / PH;               // A fragments / copy pieces per phase
+            // ---- LOAD: this phase's fragments (all B fragments belong to phase 0), its share of the copies ----
+            const bool copies_first = ORDER == 1 || (ORDER == 2 && (wn & 1));
+            auto copies = [&]() {
+                if (s + D < nk && ABL != 2) {
+#pragma unroll
+                    for (int p = ph * CP; p < (ph + 1) * CP; ++p)
+                        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src[p] + (s + D) * kSK),
+                                                         (lds_ptr_t)(smem + fill * kStage + (wave * kPPW + p) * 1024), 16, 0, 0);
+                }
+            };
+            if (copies_first) copies();
+            if (ABL != 3 || s == 0) {
+                if (ph == 0) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) fb[i] = *reinterpret_cast<const v4i*>(sb + b_off[i]);
+                }
+#pragma unroll
+                for (int i = ph * AF; i < (ph + 1) * AF; ++i) fa[i] = *reinterpret_cast<const v4i*>(sb + a_off[i]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (!copies_first) copies();
+            if (ph == PH - 1) {
+                // slice s+1 must have landed before the barriers that open its readers' intervals: only slices
+                // s+2 .. min(s+D, nk-1) may still be in flight
+                const int last = s + D < nk - 1 ? s + D : nk - 1;
+                const int younger = last - (s + 1);
+                if (younger >= 2) wait_vmcnt<2 * kPPW>();
+                else if (younger == 1) wait_vmcnt<kPPW>();
+                else wait_vmcnt<0>();
+            }
+            // fragments in registers before the barrier: the MFMA interval then starts on the matrix pipe at once
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            // ---- MFMA ----
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+            if constexpr (ABL == 1) {
+                // no matrix-core work
+            } else if constexpr (MODE == 2) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int t = ph * AF; t < (ph + 1) * AF; ++t)
+                        accv[t * 4 + u] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[t], fb[u], accv[t * 4 + u], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int t = ph * AF / 2; t < (ph + 1) * AF / 2; ++t)
+#pragma unroll
+                        for (int la = 0; la < 2; ++la)
+#pragma unroll
+                            for (int lb = 0; lb < 2; ++lb)
+                                accv[(t * 2 + u) * 3 + la + lb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(
+                                    fa[t * 2 + la], fb[u * 2 + lb], accv[(t * 2 + u) * 3 + la + lb], 0, 0, 0);
+            }
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+        }
+        slot = slot == NST - 1 ? 0 : slot + 1;
+        fill = fill == NST - 1 ? 0 : fill + 1;
+    }
+    if (wm == 0) __builtin_amdgcn_s_barrier();                   // group 0 waits for group 1's last interval
+    if constexpr (MODE == 2) {
+        epilogue_filter16(a, *reinterpret_cast<v4i(*)[8][4]>(&accv[0]), smem, tid, lane, wave, wm, wn, i0, j0);
+    } else {
+        epilogue_exact16<MODE>(a, *reinterpret_cast<v4i(*)[4][2][3]>(&accv[0]), smem, tid, lane, wave, wm, wn, i0, j0,
+                               mirror_tile);
     }
 }
 
@@ -1068,7 +1367,7 @@ struct CellLess {
 //   5 -> 8 waves 2x4, wave tile 64x64, tile 128x256, 3-stage ring
 //   6 -> variant 0 on the 16x16x64 MFMA shape (two base-256 limbs only; other limb codes use variant 0) [default]
 inline int pairwise_variant(const Options& opt) {
-    return (opt.pairwise_variant < 0 || opt.pairwise_variant > 6) ? 6 : opt.pairwise_variant;
+    return (opt.pairwise_variant < 0 || opt.pairwise_variant > 9) ? 8 : opt.pairwise_variant;
 }
 
 template <int L, bool KARA, int MODE, int NST, int WM, int WN, int BT, int AT = 2, bool DBUF = (BT == 1), int ABL = 0>
@@ -1111,9 +1410,31 @@ int launch_mfma16(hipStream_t stream, const PairwiseArgs& a) {
     return 0;
 }
 
+template <int MODE, int NST, int ORDER = 0, int ABL = 0, int PH = 1>
+int launch_pp(hipStream_t stream, const PairwiseArgs& a) {
+    using G = PpGeom<MODE>;
+    const int64_t rows = a.row_end - a.row_begin, cols = a.col_end - a.col_begin;
+    if (rows <= 0 || cols <= 0) return 0;
+    const int n_tr = (int)((rows + G::TM - 1) / G::TM), n_tc = (int)((cols + G::TN - 1) / G::TN);
+    const int n_spr = (n_tr + 15) / 16, n_spc = (n_tc + 15) / 16;
+    if (n_spr > 65535 || (int64_t)n_spc * 256 * 512 > 0xffffffffLL) return MVS_E_INVALID;
+    const size_t lds = (size_t)NST * G::kStage;
+    PairwiseArgs b = a;
+    if (b.symmetric && ((a.row_begin - a.col_begin) % G::TM != 0 || a.mirror_all)) b.symmetric = 0;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pairwise_pp<MODE, NST, ORDER, ABL, PH>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return MVS_E_HIP;
+    hipLaunchKernelGGL((k_pairwise_pp<MODE, NST, ORDER, ABL, PH>), dim3((unsigned)n_spc * 256u, (unsigned)n_spr), dim3(512), lds, stream,
+                       b, n_tr, n_tc);
+    return 0;
+}
+
 template <int L, bool KARA, int MODE>
 int launch_mfma(hipStream_t stream, const PairwiseArgs& a, const Options& opt) {
     if constexpr (L == 2 && !KARA) {
+        if (pairwise_variant(opt) == 7) return launch_pp<MODE, 5>(stream, a);
+        if (pairwise_variant(opt) == 8) return launch_pp<MODE, 4>(stream, a);
+        if (pairwise_variant(opt) == 9) return launch_pp<MODE, 4, 0, 0, 2>(stream, a);
         if (pairwise_variant(opt) == 6) return launch_mfma16<MODE>(stream, a);
     }
     if constexpr (KARA) {   // 48 KB per 128x128 stage: at most three stages fit the 160 KB of LDS
@@ -1191,15 +1512,25 @@ int launch_filter_meta(hipStream_t stream, const CoarseRow* d_rows, const double
 int launch_filter(hipStream_t stream, const PairwiseArgs& a, const Options& opt) {
     if (a.limbs != 2 || a.d_pad > 32768) return MVS_E_INVALID;
     // opt.filter_variant: tile shape / ring depth of the one-pass filter.
-    // Default (-1): 256 x 256 tiles (half the L2 -> LDS bytes per cell; 11 % faster at 100k samples) once the block
-    // holds enough of them to keep 256 CUs busy through the tail, 128 x 128 tiles below that.
+    // Default (-1): the ping-pong kernel on 256 x 256 tiles (half the L2 -> LDS bytes per cell of 128 x 128 tiles; its
+    // two wave groups overlap copies and MFMAs: 11.4 -> 10.0 ms at 100k samples against the ring kernel on the same
+    // tiles) once the block holds enough tiles to keep 256 CUs busy through the tail, 128 x 128 ring tiles below that.
     int v = opt.filter_variant;
     if (v < 0) {
         const double tiles = (double)(a.row_end - a.row_begin) * (double)(a.col_end - a.col_begin) / 65536.0 *
                              (a.symmetric ? 0.5 : 1.0);
-        v = tiles >= 4096.0 ? 1 : 0;
+        v = tiles >= 4096.0 ? 8 : 0;
     }
     switch (v) {
+        case 7: return launch_pp<2, 5>(stream, a);   // ping-pong wave groups, 256 x 256, 5-stage ring (all 160 KiB of LDS)
+        case 8: return launch_pp<2, 4>(stream, a);   // the same on a 4-stage ring
+        case 9: return launch_pp<2, 4, 0, 0, 2>(stream, a);    // two phases per slice
+        case 10: return launch_pp<2, 4, 2, 0, 2>(stream, a);   // two phases, copy / read order by wave parity
+#ifdef MVS_ABLATIONS
+        case 31: return launch_pp<2, 4, 0, 1>(stream, a);
+        case 32: return launch_pp<2, 4, 0, 2>(stream, a);
+        case 33: return launch_pp<2, 4, 0, 3>(stream, a);
+#endif
         case 1: return launch_mfma_variant<1, false, 2, 4, 2, 4, 2, 4, true>(stream, a);   // 256 x 256, waves 128 x 64
         case 3: return launch_mfma_variant<1, false, 2, 4, 4, 2, 2, 2, true>(stream, a);   // 256 x 128, waves 64 x 64
 #ifdef MVS_ABLATIONS   // k-loop ablations (results are garbage): 1x no MFMA, x2 no copies, x3 no fragment reads
