@@ -255,6 +255,45 @@ int mvs_cells_sort(mvs_ctx* ctx, const mvs_cell* cells_in, int64_t n, mvs_cell* 
 int mvs_pairwise_dots(mvs_ctx* ctx, const mvs_sketch_set* set, int64_t r0, int64_t r1, int64_t c0,
                       int64_t c1, int32_t* out, int mem_out, int algo);
 
+/* ---- multi-GPU exchange ---------------------------------------------------------------------------
+ * One process per GPU; shard k of src/pairwise_comp_optimized.cpp:938-940 is rank k.  Where the reference's shard
+ * processes each re-read the whole vectors.bin (:953, :962), a rank here loads (or sketches) only its own rows,
+ * re-codes them into ITS row block of the global plane buffer (mvs_limb_split with row_offset = rank *
+ * rows_per_rank) and ONE all-gather over RCCL / xGMI gives every GPU all N columns.  Norms travel the same way.
+ *
+ * mvs_comm_unique_id  : rank 0 draws the 128-byte RCCL id; the caller hands it to the other ranks out of band
+ *                       (a file, an environment variable, MPI, a torch.distributed store ...).
+ * mvs_comm_create     : collective over all ranks (ncclCommInitRank on the context's device).  RCCL is bound at
+ *                       run time (dlopen): if it is missing this call fails with MVS_E_HIP, nothing else does.
+ * mvs_comm_create_callbacks : the same interface over caller-supplied collectives -- for ranks that share one
+ *                       device (RCCL refuses that), for tests, or for an application's own transport.  The
+ *                       callbacks receive DEVICE pointers and the context's stream and return 0 on success.
+ * The collectives below are in place and asynchronous on the context's stream (the callback kind: as the
+ * callback chooses); every rank must call them in the same order with the same sizes. */
+#define MVS_COMM_ID_BYTES 128
+typedef struct mvs_comm mvs_comm;
+typedef struct {
+    void* user;
+    /* buf holds world * bytes_per_rank bytes on the device; block `rank` is filled in, the others are wanted */
+    int (*allgather)(void* user, void* buf, size_t bytes_per_rank, int rank, int world, void* hip_stream);
+    /* *value (host) becomes the maximum over the ranks */
+    int (*allreduce_max_i64)(void* user, int64_t* value, int rank, int world);
+} mvs_comm_callbacks;
+int mvs_comm_unique_id(void* id /* MVS_COMM_ID_BYTES */);
+int mvs_comm_create(mvs_ctx* ctx, const void* id, int rank, int world, mvs_comm** comm);
+int mvs_comm_create_callbacks(mvs_ctx* ctx, const mvs_comm_callbacks* callbacks, int rank, int world, mvs_comm** comm);
+int mvs_comm_destroy(mvs_comm* comm);
+int mvs_comm_info(const mvs_comm* comm, int* rank, int* world, int* is_rccl);
+/* planes: the global plane buffer (mvs_limb_geometry of rows_per_rank * world rows); rank r has filled rows
+ * [r * rows_per_rank, (r+1) * rows_per_rank).  After the call (on the stream) every block is present. */
+int mvs_allgather_planes(mvs_ctx* ctx, mvs_comm* comm, int8_t* planes, int64_t rows_per_rank, int limbs, int d_pad);
+/* values: DEVICE array of world * count_per_rank doubles (e.g. squared norms), block `rank` filled in */
+int mvs_allgather_f64(mvs_ctx* ctx, mvs_comm* comm, double* values, int64_t count_per_rank);
+/* any DEVICE buffer of world * bytes_per_rank bytes (e.g. kept cells that belong to other ranks' rows) */
+int mvs_allgather_bytes(mvs_ctx* ctx, mvs_comm* comm, void* buf, int64_t bytes_per_rank);
+/* *value (HOST) becomes the maximum over all ranks (largest |v| -> one limb code for everybody).  Synchronous. */
+int mvs_allreduce_max_i64(mvs_ctx* ctx, mvs_comm* comm, int64_t* value);
+
 /* src/pairwise_comp_optimized.cpp:903-906 and :938-940, for drivers that keep the reference CLI */
 int64_t mvs_chunk_size(double max_memory_gb, int d);
 void mvs_shard_rows(int64_t n, int num_shards, int shard_idx, int64_t* begin, int64_t* end);

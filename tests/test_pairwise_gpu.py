@@ -28,11 +28,17 @@ def _oracle_sorted(sk, n2, **kw):
 K3 = 0x103   # MVS_LIMBS_K3: three planes of base-128 digits, 3 matrix-core passes per cell
 
 
-@pytest.fixture(params=["exact", "two_stage"])
+@pytest.fixture(params=["exact", "exact_ring", "two_stage", "two_stage_pp"])
 def pw_filter(request, ctx):
-    """run a comparison test twice: exact kernel on every cell (option pairwise_filter = 0) and the coarse filter
-    + exact re-check of the candidates forced on even for small blocks (= 2)"""
-    ctx.set_option("pairwise_filter", 0 if request.param == "exact" else 2)
+    """run a comparison test on every comparison path: the exact kernel on every cell (option pairwise_filter = 0;
+    ping-pong kernel = default, and the ring kernel it replaced), and the coarse filter + exact re-check of the
+    candidates forced on even for small blocks (= 2; 128 x 128 ring tiles = default for small blocks, and the
+    256 x 256 ping-pong kernel that large blocks get)"""
+    ctx.set_option("pairwise_filter", 0 if request.param.startswith("exact") else 2)
+    if request.param == "exact_ring":
+        ctx.set_option("pairwise_variant", 6)
+    if request.param == "two_stage_pp":
+        ctx.set_option("filter_variant", 8)
     return request.param
 
 
@@ -313,7 +319,8 @@ def _random_rows(rng, n, d, kind):
                                       ("peaky", 600, 2048), ("flat", 400, 512), ("mixed", 1500, 1024),
                                       ("mixed", 300, 8192), ("mixed", 260, 32768)])
 @pytest.mark.parametrize("mode", ["int32", "int16"])
-def test_two_stage_equals_exact_and_oracle(ctx, monkeypatch, kind, n, d, mode):
+@pytest.mark.parametrize("fv", [-1, 8])
+def test_two_stage_equals_exact_and_oracle(ctx, monkeypatch, kind, n, d, mode, fv):
     """the coarse filter may only drop pairs the keep test rejects: same cells as the exact kernel and the
     oracle on adversarial row shapes, both keep tests"""
     rng = np.random.default_rng(hash((kind, n, d)) % 2 ** 32)
@@ -324,6 +331,7 @@ def test_two_stage_equals_exact_and_oracle(ctx, monkeypatch, kind, n, d, mode):
     ss = ctx.sketch_set(sk)
     assert ss.limbs == 2
     ctx.set_option("pairwise_filter", 2)
+    ctx.set_option("filter_variant", fv)                             # -1: 128 x 128 ring tiles here; 8: ping-pong kernel
     two, cnt_two = ctx.pairwise_rows(ss, n2, keep_mode=keep)
     n_cand = ctx.pairwise_candidates()
     ctx.set_option("pairwise_filter", 0)

@@ -26,8 +26,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def short(name):
     name = re.sub(r"^void\s+", "", name)
-    name = re.sub(r"\(.*$", "", name)
-    name = name.replace("mvs::(anonymous namespace)::", "").replace("mvs::", "")
+    name = name.replace("(anonymous namespace)::", "").replace("mvs::", "")
+    name = re.sub(r"\(.*$", "", name).strip()
+    m = re.match(r"k_pairwise_pp<\s*(\d+)", name)
+    if m:
+        return {"2": "k_pairwise_pp_filter", "1": "k_pairwise_pp_dots", "0": "k_pairwise_pp_exact"}[m.group(1)]
     m = re.match(r"k_pairwise_mfma<\s*(\d+),\s*(?:false|true|0|1),\s*(\d+)", name)
     if m:
         return {"2": "k_pairwise_mfma_filter", "1": "k_pairwise_mfma_dots"}.get(m.group(2), "k_pairwise_mfma_exact_L" + m.group(1))
