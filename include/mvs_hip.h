@@ -196,6 +196,11 @@ int mvs_sketch_set_fill_stats(mvs_sketch_set* set, const void* sketches, int ele
                               int64_t row_offset, int64_t n_rows, int64_t* max_abs);
 int mvs_sketch_set_info(const mvs_sketch_set* set, int64_t* n, int* d, int* limbs, int64_t* n_alloc,
                         int* d_pad);
+/* The DEVICE plane buffer of a set the library allocated (mvs_sketch_set_alloc / _create), for collectives that fill
+ * other ranks' row blocks in place (mvs_allgather_planes).  mvs_sketch_set_touch tells the library that the caller
+ * has rewritten the planes (data derived from them is rebuilt on the next comparison). */
+int mvs_sketch_set_planes(mvs_sketch_set* set, int8_t** planes);
+int mvs_sketch_set_touch(mvs_sketch_set* set);
 int mvs_sketch_set_destroy(mvs_sketch_set* set);
 
 /* All-vs-all for the row range [row_begin, row_end) against ALL n columns -- one shard of
@@ -282,6 +287,10 @@ typedef struct {
 int mvs_comm_unique_id(void* id /* MVS_COMM_ID_BYTES */);
 int mvs_comm_create(mvs_ctx* ctx, const void* id, int rank, int world, mvs_comm** comm);
 int mvs_comm_create_callbacks(mvs_ctx* ctx, const mvs_comm_callbacks* callbacks, int rank, int world, mvs_comm** comm);
+/* File transport: ranks exchange their blocks through files named <path_prefix>_<sequence>_<rank> in a directory
+ * all of them can reach.  For ranks that share one device (RCCL refuses that) and for one-GPU test boxes; every
+ * rank must pass the same prefix, unique to the job. */
+int mvs_comm_create_files(mvs_ctx* ctx, const char* path_prefix, int rank, int world, mvs_comm** comm);
 int mvs_comm_destroy(mvs_comm* comm);
 int mvs_comm_info(const mvs_comm* comm, int* rank, int* world, int* is_rccl);
 /* planes: the global plane buffer (mvs_limb_geometry of rows_per_rank * world rows); rank r has filled rows

@@ -68,6 +68,18 @@ SYMBOLS = [
                                      _c.c_int64, _c.POINTER(_c.c_int64)]),
     ("mvs_pairwise_dots", _c.c_int, [_P, _P, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _P, _c.c_int,
                                       _c.c_int]),
+    ("mvs_sketch_set_planes", _c.c_int, [_P, _c.POINTER(_P)]),
+    ("mvs_sketch_set_touch", _c.c_int, [_P]),
+    ("mvs_comm_unique_id", _c.c_int, [_P]),
+    ("mvs_comm_create", _c.c_int, [_P, _P, _c.c_int, _c.c_int, _c.POINTER(_P)]),
+    ("mvs_comm_create_callbacks", _c.c_int, [_P, _P, _c.c_int, _c.c_int, _c.POINTER(_P)]),
+    ("mvs_comm_create_files", _c.c_int, [_P, _c.c_char_p, _c.c_int, _c.c_int, _c.POINTER(_P)]),
+    ("mvs_comm_destroy", _c.c_int, [_P]),
+    ("mvs_comm_info", _c.c_int, [_P, _c.POINTER(_c.c_int), _c.POINTER(_c.c_int), _c.POINTER(_c.c_int)]),
+    ("mvs_allgather_planes", _c.c_int, [_P, _P, _P, _c.c_int64, _c.c_int, _c.c_int]),
+    ("mvs_allgather_f64", _c.c_int, [_P, _P, _P, _c.c_int64]),
+    ("mvs_allgather_bytes", _c.c_int, [_P, _P, _P, _c.c_int64]),
+    ("mvs_allreduce_max_i64", _c.c_int, [_P, _P, _c.POINTER(_c.c_int64)]),
     ("mvs_chunk_size", _c.c_int64, [_c.c_double, _c.c_int]),
     ("mvs_shard_rows", None, [_c.c_int64, _c.c_int, _c.c_int, _c.POINTER(_c.c_int64), _c.POINTER(_c.c_int64)]),
 ]
@@ -156,6 +168,61 @@ class SketchSet:
             pass
 
 
+COMM_ID_BYTES = 128
+
+
+class Comm:
+    """Communicator of the multi-GPU exchange step (mvs_comm): RCCL (one process per GPU), the file transport
+    (ranks sharing a device), or caller-supplied collectives."""
+
+    def __init__(self, ctx, handle, keep=None):
+        self.ctx, self._h, self._keep = ctx, handle, keep
+        r, w, k = _c.c_int(), _c.c_int(), _c.c_int()
+        _check(ctx.lib.mvs_comm_info(handle, r, w, k))
+        self.rank, self.world, self.is_rccl = r.value, w.value, bool(k.value)
+
+    def allgather_planes(self, planes, rows_per_rank, limbs, d_pad):
+        pp, pm, pk = _buf(planes)
+        if pm != MEM_DEVICE:
+            raise ValueError("planes must be a device buffer")
+        _check(self.ctx.lib.mvs_allgather_planes(self.ctx._h, self._h, pp, int(rows_per_rank), int(limbs), int(d_pad)))
+
+    def allgather_f64(self, values, count_per_rank):
+        vp, vm, vk = _buf(values)
+        if vm != MEM_DEVICE:
+            raise ValueError("values must be a device buffer")
+        _check(self.ctx.lib.mvs_allgather_f64(self.ctx._h, self._h, vp, int(count_per_rank)))
+
+    def allgather_bytes(self, buf, bytes_per_rank):
+        bp, bm, bk = _buf(buf)
+        if bm != MEM_DEVICE:
+            raise ValueError("buf must be a device buffer")
+        _check(self.ctx.lib.mvs_allgather_bytes(self.ctx._h, self._h, bp, int(bytes_per_rank)))
+
+    def allreduce_max(self, value):
+        v = _c.c_int64(int(value))
+        _check(self.ctx.lib.mvs_allreduce_max_i64(self.ctx._h, self._h, ctypes.byref(v)))
+        return v.value
+
+    def close(self):
+        if self._h:
+            self.ctx.lib.mvs_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def comm_unique_id():
+    """rank 0: the 128-byte RCCL id to hand to the other ranks"""
+    buf = ctypes.create_string_buffer(COMM_ID_BYTES)
+    _check(load_library().mvs_comm_unique_id(buf))
+    return buf.raw
+
+
 class Context:
     """One device + one stream (mvs_ctx)."""
 
@@ -194,6 +261,16 @@ class Context:
 
     def synchronize(self):
         _check(self.lib.mvs_ctx_synchronize(self._h))
+
+    def comm_rccl(self, unique_id, rank, world):
+        h = _P()
+        _check(self.lib.mvs_comm_create(self._h, unique_id, int(rank), int(world), ctypes.byref(h)))
+        return Comm(self, h)
+
+    def comm_files(self, path_prefix, rank, world):
+        h = _P()
+        _check(self.lib.mvs_comm_create_files(self._h, path_prefix.encode(), int(rank), int(world), ctypes.byref(h)))
+        return Comm(self, h)
 
     def set_option(self, name, value):
         """tuning / diagnostic switch of this context (include/mvs_hip.h lists them); never changes a result"""

@@ -5,6 +5,13 @@
 //   pairwise_comp_optimized --db D/ --max_memory_gb G --num_threads T --output_folder O
 //                           --num_shards S --shard_idx k [--start_shard a] [--end_shard b] [--help]
 //
+// Multi-GPU: the reference runs one process per shard and every process re-reads the whole vectors.bin
+// (src/pairwise_comp_optimized.cpp:953,962).  Started the same way -- one process per shard, --shard_idx k on GPU
+// k % device_count -- with MVS_COLLECTIVE=rccl in the environment, every process loads only the rows of ITS shard,
+// re-codes them into its row block of the plane buffer and one RCCL all-gather (mvs_allgather_planes) gives every
+// GPU all columns; the processes find each other through <output_folder>/.mvs_comm_<MVS_COLLECTIVE_TOKEN>.
+// MVS_COLLECTIVE=files does the exchange through files in the output folder instead (ranks sharing one GPU).
+//
 // Differences a user can observe (all listed in DESIGN.md): tiles are sized by the kernel, not by
 // --max_memory_gb (the "Using chunks of size" line still prints the reference's formula; the flag bounds
 // the kept-cell staging buffer instead); rows are written in ascending order; the codec bytes are this
@@ -79,7 +86,9 @@ static bool parse(int argc, char* argv[], Options& o) {
 struct Gpu {
     mvs_ctx* ctx = nullptr;
     mvs_sketch_set* set = nullptr;
+    mvs_comm* comm = nullptr;
     ~Gpu() {
+        if (comm) mvs_comm_destroy(comm);
         if (set) mvs_sketch_set_destroy(set);
         if (ctx) mvs_ctx_destroy(ctx);
     }
@@ -144,6 +153,124 @@ static int load_db(Gpu& g, const std::string& matrix_file, int elem_bytes, int64
         limbs = mvs_limbs_for_max_abs(max_abs);
     }
     if (bytes) ::munmap((void*)base, bytes);
+    return rc;
+}
+
+// Rendezvous of the shard processes of one job: rank 0 draws the RCCL id and leaves it in a file next to the shards;
+// the others wait for a file that is not older than their own start (a stale file of an earlier job is ignored).
+static int open_communicator(Gpu& g, const std::string& kind, const std::string& output_folder, int rank, int world) {
+    const char* tok = getenv("MVS_COLLECTIVE_TOKEN");
+    const std::string base = output_folder + ".mvs_comm_" + (tok ? tok : "job");
+    if (kind == "files") {
+        if (mvs_comm_create_files(g.ctx, base.c_str(), rank, world, &g.comm) != MVS_OK) return gpu_fail("file communicator");
+        return 0;
+    }
+    char id[MVS_COMM_ID_BYTES];
+    const std::string id_file = base + ".id";
+    const auto started = std::chrono::system_clock::now();
+    if (rank == 0) {
+        if (mvs_comm_unique_id(id) != MVS_OK) return gpu_fail("RCCL id");
+        const std::string tmp = id_file + ".part";
+        std::ofstream f(tmp, std::ios::binary | std::ios::trunc);
+        f.write(id, sizeof id);
+        f.close();
+        if (!f || std::rename(tmp.c_str(), id_file.c_str()) != 0) {
+            std::cerr << "pairwise_comp_optimized: cannot write " << id_file << std::endl;
+            return 1;
+        }
+    } else {
+        const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(300);
+        for (;;) {
+            std::error_code ec;
+            if (fs::exists(id_file, ec) && fs::file_size(id_file, ec) == sizeof id) {
+                const auto age = std::chrono::duration_cast<std::chrono::seconds>(
+                    fs::file_time_type::clock::now() - fs::last_write_time(id_file, ec)).count();
+                const auto mine = std::chrono::duration_cast<std::chrono::seconds>(std::chrono::system_clock::now() - started).count();
+                if (!ec && age <= mine + 120) {
+                    std::ifstream f(id_file, std::ios::binary);
+                    if (f.read(id, sizeof id)) break;
+                }
+            }
+            if (std::chrono::steady_clock::now() > deadline) {
+                std::cerr << "pairwise_comp_optimized: no RCCL id from shard 0 in " << id_file << std::endl;
+                return 1;
+            }
+            std::this_thread::sleep_for(std::chrono::milliseconds(20));
+        }
+    }
+    if (mvs_comm_create(g.ctx, id, rank, world, &g.comm) != MVS_OK) return gpu_fail("RCCL communicator");
+    return 0;
+}
+
+// Collective load: this process brings rows [b, e) of vectors.bin; the all-gather brings the rest.
+static int load_db_collective(Gpu& g, const std::string& matrix_file, int elem_bytes, int64_t n, int d, int64_t b, int64_t e,
+                              int world) {
+    const int64_t row_bytes = (int64_t)d * elem_bytes;
+    const int64_t rps = (n + world - 1) / world;
+    const int fd = ::open(matrix_file.c_str(), O_RDONLY);
+    if (fd < 0) {
+        std::cerr << "Error opening file: " << matrix_file << std::endl;
+        return 1;
+    }
+    const size_t bytes = (size_t)((e - b) * row_bytes);
+    const char* base = nullptr;
+    const size_t map_off = (size_t)(b * row_bytes) & ~(size_t)4095, map_len = (size_t)(b * row_bytes) - map_off + bytes;
+    void* m = nullptr;
+    if (bytes) {
+        m = ::mmap(nullptr, map_len, PROT_READ, MAP_PRIVATE, fd, (off_t)map_off);
+        if (m == MAP_FAILED) {
+            ::close(fd);
+            std::cerr << "Error reading file: " << matrix_file << std::endl;
+            return 1;
+        }
+        ::madvise(m, map_len, MADV_SEQUENTIAL);
+        base = (const char*)m + ((size_t)(b * row_bytes) - map_off);
+    }
+    ::close(fd);
+    const int64_t chunk_rows = std::max<int64_t>(1, (1LL << 30) / row_bytes);
+    int rc = 0, limbs = 2;
+    for (int attempt = 0; attempt < 4 && !rc; ++attempt) {
+        if (g.set) {
+            mvs_sketch_set_destroy(g.set);
+            g.set = nullptr;
+        }
+        if (mvs_sketch_set_alloc(g.ctx, n, d, limbs, &g.set) != MVS_OK) {
+            rc = gpu_fail("allocating sketch set");
+            break;
+        }
+        int64_t n_alloc = 0;
+        int d_pad = 0;
+        mvs_sketch_set_info(g.set, nullptr, nullptr, nullptr, &n_alloc, &d_pad);
+        if (rps * world > n_alloc) {
+            std::cerr << "pairwise_comp_optimized: too many shards for the plane padding" << std::endl;
+            rc = 1;
+            break;
+        }
+        int64_t max_abs = 0;
+        for (int64_t r0 = b; r0 < e && !rc; r0 += chunk_rows) {
+            const int64_t rows = std::min(chunk_rows, e - r0);
+            int64_t mx = 0;
+            if (mvs_sketch_set_fill_stats(g.set, base + (r0 - b) * row_bytes, elem_bytes, MVS_MEM_HOST, r0, rows, &mx) != MVS_OK)
+                rc = gpu_fail("re-coding vectors.bin");
+            max_abs = std::max(max_abs, mx);
+        }
+        if (rc) break;
+        // one limb code for everybody: the largest |v| over all shards decides (every rank takes the same branch)
+        if (mvs_allreduce_max_i64(g.ctx, g.comm, &max_abs) != MVS_OK) {
+            rc = gpu_fail("all-reduce of max|v|");
+            break;
+        }
+        if (mvs_limbs_for_max_abs(max_abs) > limbs) {
+            limbs = mvs_limbs_for_max_abs(max_abs);
+            continue;
+        }
+        int8_t* planes = nullptr;
+        if (mvs_sketch_set_planes(g.set, &planes) != MVS_OK || mvs_allgather_planes(g.ctx, g.comm, planes, rps, limbs, d_pad) != MVS_OK ||
+            mvs_sketch_set_touch(g.set) != MVS_OK || mvs_ctx_synchronize(g.ctx) != MVS_OK)
+            rc = gpu_fail("all-gather of the limb planes");
+        break;
+    }
+    if (m) ::munmap(m, map_len);
     return rc;
 }
 
@@ -263,9 +390,30 @@ int main(int argc, char* argv[]) {
     else if (mvs_device_count(&ndev) == MVS_OK && ndev > 0) device = o.shard_idx % ndev;
     if (mvs_ctx_create(device, &g.ctx) != MVS_OK) return gpu_fail("creating context");
     lap("context");
-    int rc = load_db(g, matrix_file, elem_bytes, total_vectors, dimension);
-    if (rc) return rc;
-    lap("load vectors.bin");
+    // MVS_COLLECTIVE=rccl|files: the shard processes of the job exchange their row blocks instead of each reading
+    // the whole file
+    const char* coll = getenv("MVS_COLLECTIVE");
+    int rc = 0;
+    if (coll && *coll && o.num_shards > 1) {
+        if (std::string(coll) != "rccl" && std::string(coll) != "files") {
+            std::cerr << "pairwise_comp_optimized: MVS_COLLECTIVE must be rccl or files" << std::endl;
+            return 1;
+        }
+        if (o.shard_idx < 0 || o.shard_idx >= o.num_shards) {
+            std::cerr << "pairwise_comp_optimized: collective mode needs 0 <= shard_idx < num_shards" << std::endl;
+            return 1;
+        }
+        rc = open_communicator(g, coll, output_folder, o.shard_idx, o.num_shards);
+        if (rc) return rc;
+        lap("communicator");
+        rc = load_db_collective(g, matrix_file, elem_bytes, total_vectors, dimension, begin_row, end_row, o.num_shards);
+        if (rc) return rc;
+        lap("load own rows + all-gather");
+    } else {
+        rc = load_db(g, matrix_file, elem_bytes, total_vectors, dimension);
+        if (rc) return rc;
+        lap("load vectors.bin");
+    }
 
     // kept-cell staging: --max_memory_gb bounds it (16 bytes per cell, a quarter of the budget, at least 1M
     // cells); it starts at 64 cells per row of the shard and grows on demand

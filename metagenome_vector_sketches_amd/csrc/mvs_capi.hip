@@ -38,7 +38,6 @@ struct mvs_ctx {
     void* pw_rows = nullptr;    size_t pw_rows_bytes = 0;
     void* pw_fmeta = nullptr;   size_t pw_fmeta_bytes = 0;
     void* pw_cand = nullptr;    size_t pw_cand_bytes = 0;
-    void* pw_patch = nullptr;   size_t pw_patch_bytes = 0;   // super-patch list of the persistent filter
     unsigned long long coarse_id = 0, coarse_gen = 0;
     unsigned long long filter_off_id = 0;   // (set, coefficient) for which the filter passed too many pairs
     double filter_off_coeff = 0.0;
@@ -286,7 +285,6 @@ int mvs_ctx_destroy(mvs_ctx* c) {
     if (c->pw_rows) (void)hipFree(c->pw_rows);
     if (c->pw_fmeta) (void)hipFree(c->pw_fmeta);
     if (c->pw_cand) (void)hipFree(c->pw_cand);
-    if (c->pw_patch) (void)hipFree(c->pw_patch);
     if (c->pinned) (void)hipHostFree(c->pinned);
     if (c->pinned_ev) (void)hipEventDestroy(c->pinned_ev);
     for (auto& ev : c->ev)
@@ -805,6 +803,19 @@ int mvs_sketch_set_info(const mvs_sketch_set* s, int64_t* n, int* d, int* limbs,
     return MVS_OK;
 }
 
+int mvs_sketch_set_planes(mvs_sketch_set* s, int8_t** planes) {
+    if (!s || !planes) return fail(MVS_E_INVALID, "NULL argument");
+    if (!s->owned) return fail(MVS_E_INVALID, "the set is a view of a caller-owned buffer");
+    *planes = s->owned;
+    return MVS_OK;
+}
+
+int mvs_sketch_set_touch(mvs_sketch_set* s) {
+    if (!s) return fail(MVS_E_INVALID, "set is NULL");
+    ++s->gen;
+    return MVS_OK;
+}
+
 int mvs_sketch_set_destroy(mvs_sketch_set* s) {
     if (!s) return MVS_OK;
     if (s->owned) {
@@ -899,13 +910,6 @@ int pairwise_launch(mvs_ctx* c, const mvs_sketch_set* s, const double* d_n2, int
         if (!forced) cand_want = std::min<int64_t>(cand_want, (int64_t)limit);
         rc = ensure_buf(c, &c->pw_cand, &c->pw_cand_bytes, (size_t)cand_want * sizeof(int2));
         if (rc) return rc;
-        {
-            const int64_t pr = ((re - rb + 255) / 256 + 15) / 16, pc = ((ce - cb + 255) / 256 + 15) / 16;
-            rc = ensure_buf(c, &c->pw_patch, &c->pw_patch_bytes, (size_t)(1 + pr * pc) * sizeof(int));
-            if (rc) return rc;
-        }
-        a.patch_list = (int*)c->pw_patch;
-        a.tile_queue = reinterpret_cast<unsigned int*>(c->d_counter + 8);   // slots 8..15, inside the zeroed 264 bytes
         a.coarse = (const int8_t*)c->pw_coarse;
         a.fmeta = (const float4*)c->pw_fmeta;
         a.cand_counter = c->d_counter + 2;

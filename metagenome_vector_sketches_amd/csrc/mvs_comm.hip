@@ -7,13 +7,18 @@
 // A second kind of communicator forwards the same three collectives to caller-supplied functions: ranks that
 // share one device (RCCL refuses that), tests, or an application with its own transport.
 #include <dlfcn.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
+#include <vector>
 
 #include "mvs_internal.h"
 
@@ -79,7 +84,98 @@ struct mvs_comm {
     int rank = 0, world = 1;
     void* nccl = nullptr;            // ncclComm_t, or NULL for a callback communicator
     mvs_comm_callbacks cb{};         // used when nccl == NULL
+    // file transport (mvs_comm_create_files): exchange through <prefix>_<seq>_<rank> files
+    std::string prefix;
+    unsigned long long seq = 0;
+    double timeout_s = 600.0;
 };
+
+// ---- file transport: ranks that share one device (or a test box with one GPU) exchange blocks through a directory
+// every rank can reach.  A block is written under a temporary name and renamed; readers poll for it; the writer
+// removes it once every reader has left an acknowledgement. ----
+namespace {
+
+bool exists(const std::string& p) {
+    struct stat st;
+    return ::stat(p.c_str(), &st) == 0;
+}
+
+bool wait_for(const std::string& p, double timeout_s) {
+    const auto t0 = std::chrono::steady_clock::now();
+    while (!exists(p)) {
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) return false;
+        std::this_thread::sleep_for(std::chrono::milliseconds(1));
+    }
+    return true;
+}
+
+bool write_file(const std::string& p, const void* data, size_t bytes) {
+    const std::string tmp = p + ".part";
+    FILE* f = std::fopen(tmp.c_str(), "wb");
+    if (!f) return false;
+    const bool ok = bytes == 0 || std::fwrite(data, 1, bytes, f) == bytes;
+    if (std::fclose(f) != 0 || !ok) return false;
+    return std::rename(tmp.c_str(), p.c_str()) == 0;
+}
+
+bool read_file(const std::string& p, void* data, size_t bytes) {
+    FILE* f = std::fopen(p.c_str(), "rb");
+    if (!f) return false;
+    const bool ok = bytes == 0 || std::fread(data, 1, bytes, f) == bytes;
+    std::fclose(f);
+    return ok;
+}
+
+// exchange `bytes` of HOST data per rank: mine in, all ranks' blocks out (world * bytes)
+int files_exchange(mvs_comm* m, const void* mine, size_t bytes, char* all) {
+    const std::string base = m->prefix + "_" + std::to_string(m->seq++) + "_";
+    if (!write_file(base + std::to_string(m->rank), mine, bytes)) return 1;
+    for (int r = 0; r < m->world; ++r) {
+        char* dst = all + (size_t)r * bytes;
+        if (r == m->rank) {
+            if (bytes) std::memcpy(dst, mine, bytes);
+            continue;
+        }
+        const std::string f = base + std::to_string(r);
+        if (!wait_for(f, m->timeout_s) || !read_file(f, dst, bytes)) return 2;
+        if (!write_file(f + ".ack" + std::to_string(m->rank), nullptr, 0)) return 3;
+    }
+    for (int r = 0; r < m->world; ++r) {   // my block has been read by everybody: remove it and the acknowledgements
+        if (r == m->rank) continue;
+        const std::string ack = base + std::to_string(m->rank) + ".ack" + std::to_string(r);
+        if (!wait_for(ack, m->timeout_s)) return 4;
+        ::unlink(ack.c_str());
+    }
+    ::unlink((base + std::to_string(m->rank)).c_str());
+    return 0;
+}
+
+int files_allgather(void* user, void* buf, size_t bytes, int rank, int world, void* stream) {
+    mvs_comm* m = static_cast<mvs_comm*>(user);
+    std::vector<char> mine(bytes ? bytes : 1), all((size_t)world * bytes + 1);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (hipMemcpyAsync(mine.data(), static_cast<char*>(buf) + (size_t)rank * bytes, bytes, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess)
+        return 10;
+    const int rc = files_exchange(m, mine.data(), bytes, all.data());
+    if (rc) return rc;
+    if (hipMemcpyAsync(buf, all.data(), (size_t)world * bytes, hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess)
+        return 11;
+    return 0;
+}
+
+int files_allreduce_max(void* user, int64_t* value, int rank, int world) {
+    (void)rank;
+    mvs_comm* m = static_cast<mvs_comm*>(user);
+    std::vector<int64_t> all((size_t)world);
+    const int rc = files_exchange(m, value, sizeof(int64_t), reinterpret_cast<char*>(all.data()));
+    if (rc) return rc;
+    for (int64_t v : all) *value = v > *value ? v : *value;
+    return 0;
+}
+
+}  // namespace
 
 namespace {
 
@@ -156,6 +252,23 @@ int mvs_comm_create_callbacks(mvs_ctx* c, const mvs_comm_callbacks* cb, int rank
     m->rank = rank;
     m->world = world;
     m->cb = *cb;
+    *out = m;
+    return MVS_OK;
+}
+
+int mvs_comm_create_files(mvs_ctx* c, const char* path_prefix, int rank, int world, mvs_comm** out) {
+    if (!c || !path_prefix || !out) return mvs::capi_fail(MVS_E_INVALID, "NULL argument");
+    *out = nullptr;
+    if (world < 1 || rank < 0 || rank >= world) return mvs::capi_fail(MVS_E_INVALID, "rank %d of %d", rank, world);
+    mvs_comm* m = new (std::nothrow) mvs_comm();
+    if (!m) return mvs::capi_fail(MVS_E_NOMEM, "out of host memory");
+    m->ctx = c;
+    m->rank = rank;
+    m->world = world;
+    m->prefix = path_prefix;
+    m->cb.user = m;
+    m->cb.allgather = files_allgather;
+    m->cb.allreduce_max_i64 = files_allreduce_max;
     *out = m;
     return MVS_OK;
 }

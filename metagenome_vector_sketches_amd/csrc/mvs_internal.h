@@ -78,9 +78,6 @@ struct PairwiseArgs {
     unsigned long long* cand_counter;
     unsigned long long cand_limit;   // once the counter is beyond this the remaining filter tiles and the re-check
                                      // give up at once: the caller falls back to the exact kernel
-    int* patch_list;                 // persistent filter: [0] = number of super-patches with work, then their ids
-                                     // (room for 1 + ceil(rows/4096) * ceil(cols/4096) ints; written by the launch)
-    unsigned int* tile_queue;        // persistent filter: 8 work-item counters (8 bytes apart), zeroed by the caller
     unsigned int* cand_stop;         // set by the wave that takes the counter past the limit; lives on its own cache
                                      // line (polling the counter itself queues behind its atomics)
 };

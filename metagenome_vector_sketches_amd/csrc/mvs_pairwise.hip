@@ -798,8 +798,10 @@ struct PpGeom {
 };
 
 // filter epilogue for the 16x16 accumulator layout (same test as in k_pairwise_mfma<.., MODE 2>)
+// fm: this thread's entry of the tile's row / column constants (thread x < 256: row i0 + x, else column j0 + x - 256),
+// loaded by the caller before the k-loop so that its latency is not paid here
 __device__ __forceinline__ void epilogue_filter16(const PairwiseArgs& a, v4i (&acc)[8][4], char* smem, int tid, int lane,
-                                                  int wave, int wm, int wn, int64_t i0, int64_t j0) {
+                                                  int wave, int wm, int wn, int64_t i0, int64_t j0, float4 fm) {
     constexpr int TM = 256, TN = 256;
     using v2f = __attribute__((ext_vector_type(2))) float;
     using v4f = __attribute__((ext_vector_type(4))) float;
@@ -807,19 +809,14 @@ __device__ __forceinline__ void epilogue_filter16(const PairwiseArgs& a, v4i (&a
     __syncthreads();                                                   // every wave is done with the ring
     float* frow = reinterpret_cast<float*>(smem);                      // TM/2 row pairs x {s0 s1 w0 w1 | a0 a1 p0 p1}
     float4* fcol = reinterpret_cast<float4*>(smem + TM * 16);          // TN entries {s, w, a, p}
-    for (int x = tid; x < TM + TN; x += 512) {
-        const int64_t g = (x < TM ? i0 : j0 - TM) + x;
-        float4 m = a.fmeta[g];
-        if (g >= (x < TM ? a.row_end : a.col_end)) m = make_float4(__builtin_inff(), 0.0f, 0.0f, 0.0f);
-        if (x < TM) {
-            float* q = frow + (x >> 1) * 8 + (x & 1);
-            q[0] = m.x;
-            q[2] = m.y;
-            q[4] = m.z;
-            q[6] = m.w;
-        } else {
-            fcol[x - TM] = m;
-        }
+    if (tid < TM) {
+        float* q = frow + (tid >> 1) * 8 + (tid & 1);
+        q[0] = fm.x;
+        q[2] = fm.y;
+        q[4] = fm.z;
+        q[6] = fm.w;
+    } else {
+        fcol[tid - TM] = fm;
     }
     __syncthreads();
     const bool straddle = a.symmetric && j0 < i0 + TM && j0 + TN > i0;
@@ -957,6 +954,12 @@ __global__ __launch_bounds__(512, 2) void k_pairwise_pp(const PairwiseArgs a, in
     for (int i = 0; i < 4; ++i)
         b_off[i] = kRegion + (MODE == 2 ? (wn * 64 + i * 16 + fr) * kSK + coff
                                         : ((i & 1) * TN + wn * 32 + (i >> 1) * 16 + fr) * kSK + coff);
+    float4 fm = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if constexpr (MODE == 2) {   // the epilogue's row / column constants: one per thread, on their way during the k-loop
+        const int64_t g = tid < TM ? i0 + tid : j0 + (tid - TM);
+        fm = a.fmeta[g];
+        if (g >= (tid < TM ? a.row_end : a.col_end)) fm = make_float4(__builtin_inff(), 0.0f, 0.0f, 0.0f);
+    }
     v4i fa[8], fb[4];
     constexpr int NACC = MODE == 2 ? 32 : 24;
     v4i accv[NACC];
@@ -1059,399 +1062,10 @@ __global__ __launch_bounds__(512, 2) void k_pairwise_pp(const PairwiseArgs a, in
     }
 #endif
     if constexpr (MODE == 2) {
-        epilogue_filter16(a, *reinterpret_cast<v4i(*)[8][4]>(&accv[0]), smem, tid, lane, wave, wm, wn, i0, j0);
+        epilogue_filter16(a, *reinterpret_cast<v4i(*)[8][4]>(&accv[0]), smem, tid, lane, wave, wm, wn, i0, j0, fm);
     } else {
         epilogue_exact16<MODE>(a, *reinterpret_cast<v4i(*)[4][2][3]>(&accv[0]), smem, tid, lane, wave, wm, wn, i0, j0,
                                mirror_tile);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------
-// Persistent filter kernel: the ping-pong k-loop of k_pairwise_pp<2> inside a workgroup that walks over tiles.
-// Measured on the one-tile-per-workgroup form at 100k x 2048 (9.9 ms): 0.6 ms is workgroup dispatch (153k
-// workgroups, half of which exit at once), 1.3 ms the epilogue, and every tile starts by waiting for its first
-// copies.  Here
-//   * 256 workgroups stay resident; workgroup b takes position (b + p) of super-patch p (the XCD label rotates with
-//     the patch, so the tiles the symmetric schedule skips are spread evenly over XCDs and workgroups);
-//   * the first copies of the NEXT tile are issued before the epilogue of the current one;
-//   * the filter test is folded into the accumulators: with tile-wide extrema of the column (row) constants the
-//     bilinear threshold  s_i w_j + s_j w_i - a_i p_j - p_i b_j  is bounded below by R_i + C_j; the accumulators
-//     start at -(floor R_i + floor C_j) instead of 0, so after the k-loop "accumulator > 0" is a necessary condition
-//     for the exact test: the sweep is one v_max3 per two cells, and only 16-column groups in which some lane
-//     holds a positive accumulator run the exact test of epilogue_filter16 on the reconstructed dot.
-//     Soundness: R_i = s_i wmin_c (1-e) - (a_i pmax_c + p_i bmax_c)(1+e), C_j = s_j wmin_r (1-e), e = 2^-10, extrema
-//     over the tile's entries that can pass at all (s < +inf).  For s >= 0 every term is a lower bound of the exact
-//     term; e covers the fp32 evaluation error of the exact test (2^-22 of the term magnitudes, which exceed the
-//     bound's terms by at most w_max / w_min <= 259 < e 2^22) and the slack of 8 the two floors and the int -> float
-//     rounding of the dot (|dot| < 2^25).  s = -inf (rows that must always be re-checked) gives -2^29: always positive.
-// ---------------------------------------------------------------------------------------------------
-struct FilterTile {
-    int tr, tc;      // tile coordinates
-    bool valid;
-};
-
-// super-patches (16 x 16 tiles) that hold at least one tile with work, in row-major order: list[0] = count, then ids
-__global__ __launch_bounds__(256) void k_patch_list(int n_tr, int n_tc, int n_spr, int n_spc, int symmetric, int off_tiles,
-                                                    int* __restrict__ list) {
-    __shared__ int counts[256];
-    const int n = n_spr * n_spc, per = (n + 255) / 256, lo = threadIdx.x * per, hi = min(n, lo + per);
-    auto useful = [&](int p) {
-        const int spr = p / n_spc, spc = p - spr * n_spc;
-        if (!symmetric) return true;
-        // tile (tr, tc) is skipped iff off <= tc < tr + off: the patch has work iff some column lies left of the
-        // square or reaches the diagonal of the patch's first row
-        const int r0 = spr * 16, c0 = spc * 16, c1 = min(c0 + 16, n_tc);
-        return r0 < n_tr && (c0 < off_tiles || c1 - 1 >= r0 + off_tiles);
-    };
-    int mine = 0;
-    for (int p = lo; p < hi; ++p) mine += useful(p) ? 1 : 0;
-    counts[threadIdx.x] = mine;
-    __syncthreads();
-    int before = 0;
-    for (int t = 0; t < (int)threadIdx.x; ++t) before += counts[t];
-    if (threadIdx.x == 255) list[0] = before + mine;
-    for (int p = lo; p < hi; ++p)
-        if (useful(p)) list[1 + before++] = p;
-}
-
-template <int NST>
-__global__ __launch_bounds__(512, 2) void k_filter_pp(const PairwiseArgs a, int n_tr, int n_tc, int n_spr, int n_spc) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    using G = PpGeom<2>;
-    constexpr int TM = G::TM, TN = G::TN, kRegion = G::kRegion, kStage = G::kStage, kPPW = G::kPPW;
-    constexpr int D = NST - 2;
-    using v2f = __attribute__((ext_vector_type(2))) float;
-    using v4f = __attribute__((ext_vector_type(4))) float;
-    // LDS above the ring: row constants in pairs, column constants, integer bounds, reduction scratch
-    char* const scratch = smem + NST * kStage;
-    float* const frow = reinterpret_cast<float*>(scratch);                    // 128 pairs x {s0 s1 w0 w1 | a0 a1 p0 p1}
-    float4* const fcol = reinterpret_cast<float4*>(scratch + 4096);           // 256 x {s, w, a, p}
-    int* const r_int = reinterpret_cast<int*>(scratch + 8192);                // 256 row bounds
-    int* const c_int = reinterpret_cast<int*>(scratch + 9216);                // 256 column bounds
-    float* const red = reinterpret_cast<float*>(scratch + 10240);             // 8 waves x 4 partial extrema
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
-    const int fr = lane & 15, fq = lane >> 4;
-    (void)n_spr;
-    int* const sched = reinterpret_cast<int*>(scratch + 10240 + 128);       // next work item, published by thread 0
-    const int label = (int)blockIdx.x & 7;                                   // workgroups that share an L2
-    const int n_list = a.patch_list[0];
-    const int n_items = n_list * 32;                                         // per label: (useful patch, position) pairs
-
-    // Work items come from eight queues (one per label; a.tile_queue, zeroed by the host): item v of label x is
-    // position v % 32 of the sub-patch (x + v / 32) % 8 of useful super-patch v / 32, so the 32 workgroups of a label
-    // always work inside the same one or two sub-patches (their operand panels stay in that XCD's L2, as under
-    // in-order hardware dispatch) and the sub-patches the symmetric schedule thins out rotate over the labels.  A label
-    // that has run dry takes items of the next one.  Thread 0 draws, everybody reads the draw from LDS.
-    auto draw = [&]() -> int {   // thread 0 only, synchronous: encoded item (label << 28 | v) or -1
-        if (*reinterpret_cast<volatile const unsigned int*>(a.cand_stop) != 0u) return -1;   // the filter is not paying
-        for (int k = 0; k < 8; ++k) {
-            const int x = (label + k) & 7;
-            if (*reinterpret_cast<volatile const unsigned int*>(a.tile_queue + 2 * x) >= (unsigned)n_items) continue;
-            const unsigned v = atomicAdd(a.tile_queue + 2 * x, 1u);
-            if (v < (unsigned)n_items) return (x << 28) | (int)v;
-        }
-        return -1;
-    };
-    auto decode = [&](int item) -> FilterTile {
-        FilterTile t{0, 0, false};
-        if (item < 0) return t;
-        const int x = item >> 28, v = item & 0x0fffffff;
-        const int li = v >> 5, q = v & 31;
-        const int p = a.patch_list[1 + li];
-        const int spr = p / n_spc, spc = p - spr * n_spc;
-        const int sub = (x + li) & 7;
-        t.tr = spr * 16 + (sub >> 1) * 4 + (q >> 3);
-        t.tc = spc * 16 + (sub & 1) * 8 + (q & 7);
-        if (t.tr >= n_tr || t.tc >= n_tc) return t;
-        const int64_t ti0 = a.row_begin + (int64_t)t.tr * TM, tj0 = a.col_begin + (int64_t)t.tc * TN;
-        if (a.symmetric && tj0 >= a.row_begin && tj0 + TN <= ti0) return t;                  // mirrored from its transpose
-        t.valid = true;
-        return t;
-    };
-    // all threads: next tile with work, starting from the draw `first` thread 0 already holds (-2: none yet);
-    // `done` comes back true when the queues are empty
-    auto next_tile = [&](int first, bool& done) -> FilterTile {
-        int item = first;
-        while (true) {
-            if (tid == 0) {
-                if (item == -2) item = draw();
-                sched[0] = item;
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            const int got = __builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile int*>(sched));
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();                                    // everybody has read the slot
-            if (got < 0) {
-                done = true;
-                return FilterTile{0, 0, false};
-            }
-            const FilterTile t = decode(got);
-            if (t.valid) return t;
-            item = -2;
-        }
-    };
-
-    const int coff = (fq ^ swz16(fr)) << 4;
-    int a_off[8], b_off[4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) a_off[i] = (wm * 128 + i * 16 + fr) * kSK + coff;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) b_off[i] = kRegion + (wn * 64 + i * 16 + fr) * kSK + coff;
-
-    const int8_t* src[kPPW];
-    float4 fm;                                                               // this thread's entry of the tile's constants
-    // row / column constants of a tile (one entry per thread; outside the call's ranges: never passes) and the
-    // copy sources; then the first D slices
-    auto begin_tile = [&](const FilterTile& t) {
-        const int64_t i0 = a.row_begin + (int64_t)t.tr * TM, j0 = a.col_begin + (int64_t)t.tc * TN;
-        {
-            const int64_t g = tid < TM ? i0 + tid : j0 + (tid - TM);
-            fm = a.fmeta[g];
-            if (g >= (tid < TM ? a.row_end : a.col_end)) fm = make_float4(__builtin_inff(), 0.0f, 0.0f, 0.0f);
-        }
-#pragma unroll
-        for (int p = 0; p < kPPW; ++p) {
-            const int row = (wave * kPPW + p) * 16 + (lane >> 2);
-            const bool is_b = row >= TM;
-            const int sl = is_b ? row - TM : row;
-            const int c = (lane & 3) ^ swz16(sl);
-            src[p] = a.coarse + ((is_b ? j0 : i0) + sl) * (int64_t)a.d_pad + c * 16;
-        }
-    };
-    auto stage_copy = [&](int slot, int k0) {
-#pragma unroll
-        for (int p = 0; p < kPPW; ++p)
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src[p] + k0),
-                                             (lds_ptr_t)(smem + slot * kStage + (wave * kPPW + p) * 1024), 16, 0, 0);
-    };
-#ifdef MVS_ABLATIONS
-    const int nk = (a.debug_flags & 1) ? 0 : a.d_pad / kSK;
-#else
-    const int nk = a.d_pad / kSK;
-#endif
-
-    bool done = false;
-    FilterTile cur = next_tile(-2, done);
-    if (done) return;
-    begin_tile(cur);
-#pragma unroll
-    for (int st = 0; st < D; ++st)
-        if (st < nk) stage_copy(st, st * kSK);
-
-    v4i fa[8], fb[4];
-    v4i accv[32];
-    while (true) {
-        const int64_t i0 = a.row_begin + (int64_t)cur.tr * TM, j0 = a.col_begin + (int64_t)cur.tc * TN;
-        // ---- tile set-up (the first copies are in flight): constants -> LDS, extrema, integer bounds, accumulators ----
-        {
-            const bool ok = fm.x < __builtin_inff();                      // entries that can pass at all (not +inf, not NaN)
-            float wmin = ok ? fm.y : __builtin_inff(), pmax = ok ? fm.w : 0.0f, bmax = ok ? fm.z + fm.w : 0.0f;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                wmin = fminf(wmin, __shfl_xor(wmin, o, 64));
-                pmax = fmaxf(pmax, __shfl_xor(pmax, o, 64));
-                bmax = fmaxf(bmax, __shfl_xor(bmax, o, 64));
-            }
-            if (tid < TM) {
-                float* q = frow + (tid >> 1) * 8 + (tid & 1);
-                q[0] = fm.x;
-                q[2] = fm.y;
-                q[4] = fm.z;
-                q[6] = fm.w;
-            } else {
-                fcol[tid - TM] = fm;
-            }
-            if (lane == 0) {
-                red[wave * 4 + 0] = wmin;
-                red[wave * 4 + 1] = pmax;
-                red[wave * 4 + 2] = bmax;
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            // waves 0-3 hold the rows, 4-7 the columns
-            const float wmin_r = fminf(fminf(red[0], red[4]), fminf(red[8], red[12]));
-            const float wmin_c = fminf(fminf(red[16], red[20]), fminf(red[24], red[28]));
-            const float pmax_c = fmaxf(fmaxf(red[17], red[21]), fmaxf(red[25], red[29]));
-            const float bmax_c = fmaxf(fmaxf(red[18], red[22]), fmaxf(red[26], red[30]));
-            const float lo = 1.0f - 1.0f / 1024.0f, hi = 1.0f + 1.0f / 1024.0f;
-            float bound;
-            if (tid < TM) bound = fm.x * (wmin_c * lo) - (fm.z * pmax_c + fm.w * bmax_c) * hi;
-            else bound = fm.x * (wmin_r * lo);
-            // an empty side (no entry that can pass) leaves wmin = +inf: then nothing of this tile passes, any bound is sound
-            int ib = 1 << 29;                                              // NaN, +inf: never
-            if (bound < 536870912.0f) ib = bound > -536870912.0f ? (int)floorf(bound) - 4 : -(1 << 29);
-            if (tid < TM) r_int[tid] = ib;
-            else c_int[tid - TM] = ib;
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-#pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                const v4i ri = *reinterpret_cast<const v4i*>(r_int + wm * 128 + t * 16 + fq * 4);
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int cj = c_int[wn * 64 + u * 16 + fr];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) accv[t * 4 + u][r] = -(ri[r] + cj);
-                }
-            }
-        }
-        // ---- k-loop: as k_pairwise_pp (one phase per slice) ----
-        // the next work item of this label, drawn now and looked at after the k-loop (nothing here waits for memory)
-        unsigned ahead_v = 0, ahead_stop = 0;
-        if (tid == 0) {
-            ahead_v = atomicAdd(a.tile_queue + 2 * label, 1u);
-            ahead_stop = *reinterpret_cast<volatile const unsigned int*>(a.cand_stop);
-        }
-        {
-            const int younger = (nk < D ? nk : D) - 1;
-            if (younger >= 2) wait_vmcnt<2 * kPPW>();
-            else if (younger == 1) wait_vmcnt<kPPW>();
-            else wait_vmcnt<0>();
-        }
-        __builtin_amdgcn_s_barrier();
-        if (wm == 1) __builtin_amdgcn_s_barrier();
-        int slot = 0, fill = D % NST;
-        for (int s = 0; s < nk; ++s) {
-            const char* sb = smem + slot * kStage;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) fb[i] = *reinterpret_cast<const v4i*>(sb + b_off[i]);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) fa[i] = *reinterpret_cast<const v4i*>(sb + a_off[i]);
-            __builtin_amdgcn_sched_barrier(0);
-            if (s + D < nk) stage_copy(fill, (s + D) * kSK);
-            {
-                const int last = s + D < nk - 1 ? s + D : nk - 1;
-                const int younger = last - (s + 1);
-                if (younger >= 2) wait_vmcnt<2 * kPPW>();
-                else if (younger == 1) wait_vmcnt<kPPW>();
-                else wait_vmcnt<0>();
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-                for (int t = 0; t < 8; ++t)
-                    accv[t * 4 + u] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[t], fb[u], accv[t * 4 + u], 0, 0, 0);
-            __builtin_amdgcn_s_setprio(0);
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
-            slot = slot == NST - 1 ? 0 : slot + 1;
-            fill = fill == NST - 1 ? 0 : fill + 1;
-        }
-        if (wm == 0) __builtin_amdgcn_s_barrier();
-        // ---- the next tile's constants and first copies go out before this tile's epilogue ----
-        int ahead = -2;                                                   // own queue dry: draw again (from the other labels)
-        if (tid == 0) {
-            if (ahead_stop != 0u) ahead = -1;
-            else if (ahead_v < (unsigned)n_items) ahead = (label << 28) | (int)ahead_v;
-        }
-        const FilterTile nxt = next_tile(ahead, done);
-        if (nxt.valid) {
-            begin_tile(nxt);
-#pragma unroll
-            for (int st = 0; st < D; ++st)
-                if (st < nk) stage_copy(st, st * kSK);
-        }
-        // ---- epilogue: accumulator > 0 is necessary for the exact test ----
-#ifdef MVS_ABLATIONS
-        if (a.debug_flags & 2) {
-            int x = 0;
-#pragma unroll
-            for (int i = 0; i < 32; ++i) x ^= accv[i][0] ^ accv[i][3];
-            if (x == 0x7fffffff) a.counter[1] = 1;
-        } else
-#endif
-        {
-            const bool straddle = a.symmetric && j0 < i0 + TM && j0 + TN > i0;
-            const int delta = (int)(j0 - i0);
-            unsigned m32[4] = {0u, 0u, 0u, 0u};
-            unsigned mine = 0;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                int top = accv[u][0];
-#pragma unroll
-                for (int t = 0; t < 8; ++t) {
-                    top = max(top, max(accv[t * 4 + u][0], accv[t * 4 + u][1]));
-                    top = max(top, max(accv[t * 4 + u][2], accv[t * 4 + u][3]));
-                }
-                if (__ballot(top > 0) == 0ULL) continue;
-                // exact test on the reconstructed dots of this 16-column group (the test of epilogue_filter16)
-                const int col_l = wn * 64 + u * 16 + fr;
-                const int64_t col = j0 + col_l;
-                const float4 mj = fcol[col_l];
-                const float bj = mj.z + mj.w;
-                const int cj = c_int[col_l];
-                const v2f wj = {mj.y, mj.y}, sj = {mj.x, mj.x}, npj = {-mj.w, -mj.w}, nbj = {-bj, -bj};
-                const bool in_square = a.symmetric && col >= a.row_begin && col < a.row_end;
-                const int row_max = (straddle && in_square) ? col_l + delta : 0x7fffffff;
-                unsigned m = 0;
-#pragma unroll
-                for (int t = 0; t < 8; ++t) {
-                    const v4i ri = *reinterpret_cast<const v4i*>(r_int + wm * 128 + t * 16 + fq * 4);
-#pragma unroll
-                    for (int r = 0; r < 4; r += 2) {
-                        const int row_l = wm * 128 + t * 16 + fq * 4 + r;
-                        const v4f q0 = *reinterpret_cast<const v4f*>(frow + (row_l >> 1) * 8);
-                        const v4f q1 = *reinterpret_cast<const v4f*>(frow + (row_l >> 1) * 8 + 4);
-                        v2f rhs = v2f{q0[0], q0[1]} * wj;
-                        rhs = __builtin_elementwise_fma(v2f{q0[2], q0[3]}, sj, rhs);
-                        rhs = __builtin_elementwise_fma(v2f{q1[0], q1[1]}, npj, rhs);
-                        rhs = __builtin_elementwise_fma(v2f{q1[2], q1[3]}, nbj, rhs);
-                        const int d0 = accv[t * 4 + u][r] + ri[r] + cj, d1 = accv[t * 4 + u][r + 1] + ri[r + 1] + cj;
-                        const bool c0 = (float)d0 > rhs[0] && row_l <= row_max;
-                        const bool c1 = (float)d1 > rhs[1] && row_l < row_max;
-                        m |= (c0 ? 1u << (t * 4 + r) : 0u) | (c1 ? 2u << (t * 4 + r) : 0u);
-                    }
-                }
-                m32[u] = m;
-                mine += (unsigned)__popc(m);
-                asm volatile("" ::: "memory");   // the row constants are re-read per group: hoisting them costs 128 registers
-            }
-            if (__ballot(mine != 0) != 0ULL) {
-                unsigned incl = mine;
-#pragma unroll
-                for (int o = 1; o < 64; o <<= 1) {
-                    const unsigned up = (unsigned)__shfl_up((int)incl, o, 64);
-                    if (lane >= o) incl += up;
-                }
-                unsigned long long base = 0;
-                if (lane == 63) {
-                    base = atomicAdd(a.cand_counter, (unsigned long long)incl);
-                    if (base + incl > a.cand_limit) *a.cand_stop = 1u;
-                }
-                base = __shfl(base, 63, 64);
-                unsigned long long out = base + (incl - mine);
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int col_l = wn * 64 + u * 16 + fr;
-                    const int64_t col = j0 + col_l;
-                    const bool in_square = a.symmetric && col >= a.row_begin && col < a.row_end;
-                    const int cd = col_l + delta;
-                    unsigned m = m32[u];
-                    while (m) {
-                        const int bit = __ffs((int)m) - 1;
-                        m &= m - 1;
-                        const int row_l = wm * 128 + (bit >> 2) * 16 + fq * 4 + (bit & 3);
-                        const bool mirror = a.mirror_all || (in_square && cd > row_l);
-                        if (out < a.cand_capacity)
-                            a.cand[out] = make_int2((int32_t)(i0 + row_l), mirror ? (int)((unsigned)col | 0x80000000u) : (int)col);
-                        ++out;
-                    }
-                }
-            }
-        }
-        if (!nxt.valid) break;
-        cur = nxt;
-        // every wave is done with this tile's constants before the next set-up overwrites them
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
     }
 }
 
@@ -1933,25 +1547,6 @@ int launch_filter(hipStream_t stream, const PairwiseArgs& a, const Options& opt)
     switch (v) {
         case 7: return launch_pp<2, 5>(stream, a);   // ping-pong wave groups, 256 x 256, 5-stage ring (all 160 KiB of LDS)
         case 8: return launch_pp<2, 4>(stream, a);   // the same on a 4-stage ring
-        case 4: {   // persistent ping-pong filter: 256 resident workgroups draw tiles from per-XCD queues
-            constexpr int NST = 4;
-            const int64_t rows = a.row_end - a.row_begin, cols = a.col_end - a.col_begin;
-            if (rows <= 0 || cols <= 0) return 0;
-            const int n_tr = (int)((rows + 255) / 256), n_tc = (int)((cols + 255) / 256);
-            const int n_spr = (n_tr + 15) / 16, n_spc = (n_tc + 15) / 16;
-            if ((int64_t)n_spr * n_spc > 0x7fffff00LL) return MVS_E_INVALID;
-            const size_t lds = (size_t)NST * PpGeom<2>::kStage + 10240 + 128 + 64;
-            PairwiseArgs b = a;
-            if (b.symmetric && ((a.row_begin - a.col_begin) % 256 != 0 || a.mirror_all)) b.symmetric = 0;
-            if (!a.patch_list || !a.tile_queue) return MVS_E_INVALID;
-            hipLaunchKernelGGL(k_patch_list, dim3(1), dim3(256), 0, stream, n_tr, n_tc, n_spr, n_spc, b.symmetric,
-                               (int)((a.row_begin - a.col_begin) / 256), a.patch_list);
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_filter_pp<NST>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return MVS_E_HIP;
-            hipLaunchKernelGGL((k_filter_pp<NST>), dim3(256), dim3(512), lds, stream, b, n_tr, n_tc, n_spr, n_spc);
-            return 0;
-        }
         case 9: return launch_pp<2, 4, 0, 0, 2>(stream, a);    // two phases per slice
         case 10: return launch_pp<2, 4, 2, 0, 2>(stream, a);   // two phases, copy / read order by wave parity
 #ifdef MVS_ABLATIONS

@@ -17,12 +17,55 @@ even G is split in halves between the two ranks), which appends each kept cell A
 mirrored cells that belong to other ranks' rows are then exchanged (one more all-gather, of kept cells --
 a few MB) and merged.  Per-rank comparison work drops from G - 1/2 blocks to G/2.  Set
 MVS_SHARDED_SYMMETRIC=0 for the plain rows x all-columns schedule.
+
+The exchange itself goes through a small `collectives` object: `NativeCollectives` wraps the communicator of the
+C ABI (mvs_comm: RCCL bound at run time, or the file transport for ranks sharing a device) -- the same entry
+points the C++ `pairwise_comp_optimized` uses with MVS_COLLECTIVE=rccl; `TorchCollectives` wraps a
+torch.distributed process group (gloo in the CPU tests, nccl = RCCL otherwise).
 """
 import os
 
 import numpy as np
 
 from . import _capi
+
+
+class TorchCollectives:
+    """the three collectives of the exchange over torch.distributed"""
+    kind = "torch.distributed"
+
+    def __init__(self, dist, rank, world):
+        self.dist, self.rank, self.world = dist, rank, world
+
+    def allreduce_max(self, value, like):
+        import torch
+        t = torch.tensor([int(value)], dtype=torch.int64, device=getattr(like, "device", "cpu"))
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return int(t.cpu()[0])
+
+    def allgather_blocks(self, buf, block_elems):
+        """buf: 1-D tensor of world * block_elems elements whose block `rank` is filled in"""
+        send = buf[self.rank * block_elems:(self.rank + 1) * block_elems]
+        if self._send is None or self._send.shape != send.shape or self._send.dtype != send.dtype:
+            self._send = send.new_empty(send.shape)
+        self._send.copy_(send)     # a separate send block: NCCL / gloo need not support aliased in-place gathers
+        self.dist.all_gather_into_tensor(buf[:self.world * block_elems], self._send)
+
+    _send = None
+
+
+class NativeCollectives:
+    """the same over the communicator of the C ABI (in place on the device, on the context's stream)"""
+
+    def __init__(self, comm):
+        self.comm, self.rank, self.world = comm, comm.rank, comm.world
+        self.kind = "libmvs_hip mvs_comm (%s)" % ("RCCL" if comm.is_rccl else "file transport")
+
+    def allreduce_max(self, value, like):
+        return self.comm.allreduce_max(value)
+
+    def allgather_blocks(self, buf, block_elems):
+        self.comm.allgather_bytes(buf, block_elems * buf.element_size())
 
 
 def shard_rows(n_total, world, rank):
@@ -121,21 +164,32 @@ class GpuOps:
 class ShardedComparison:
     """State that survives between steps (the gathered plane buffer is reused while its geometry holds)."""
 
-    def __init__(self, ops, rank=0, world=1, dist=None):
-        self.ops, self.rank, self.world, self.dist = ops, rank, world, dist
+    def __init__(self, ops, rank=0, world=1, dist=None, collectives=None):
+        """dist: a torch.distributed module with an initialised default group, or collectives: a
+        TorchCollectives / NativeCollectives object (takes precedence)."""
+        self.ops, self.rank, self.world = ops, rank, world
+        self.coll = collectives if collectives is not None else (TorchCollectives(dist, rank, world) if dist is not None else None)
         self._planes = None
         self._key = None
         self._raw = self._tmp = None
+        self._n2 = None
         self.symmetric = os.environ.get("MVS_SHARDED_SYMMETRIC", "1") != "0"
-        if world > 1 and dist is None:
-            raise ValueError("world > 1 needs torch.distributed")
+        if world > 1 and self.coll is None:
+            raise ValueError("world > 1 needs torch.distributed or a communicator")
+
+    def _agree(self, status):
+        """every rank learns whether any rank failed (a rank that raises alone would leave the others inside the
+        next collective until the launcher's timeout): returns the largest status"""
+        if self.world == 1:
+            return status
+        return self.coll.allreduce_max(status, self._planes)
 
     def run(self, sketches_local, norms_sq_local, n_total, keep_mode=_capi.KEEP_INT32, cells_out=None,
             max_abs_local=None):
         """sketches_local: this rank's rows (int32/int16 [n_local, d]); norms_sq_local: host float64
         [n_local]; max_abs_local: largest |v| of sketches_local if the caller already has it
         (Context.stats).  Returns (cells, n_cells, info) for this rank's shard."""
-        ops, dist, rank, world = self.ops, self.dist, self.rank, self.world
+        ops, rank, world = self.ops, self.rank, self.world
         n_local, d = sketches_local.shape
         rb, re = shard_rows(n_total, world, rank)
         if re - rb != n_local:
@@ -146,76 +200,85 @@ class ShardedComparison:
         else:
             max_abs = ops.max_abs(sketches_local) if n_local else 0
         if world > 1:
-            import torch
-            t = ops.to_device(np.array([max_abs], dtype=np.int64))
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            max_abs = int(t.cpu()[0])
+            max_abs = self.coll.allreduce_max(max_abs, sketches_local)
         limbs = ops.limbs_for(max_abs)
         n_rows_global = rps * world                      # >= n_total; the tail rows stay zero
         n_alloc, d_pad, nbytes = ops.limb_geometry(n_rows_global, d, limbs)
         key = (limbs, n_alloc, d_pad)
         if self._key != key:
             self._planes = ops.new_planes(nbytes)
+            self._n2 = ops.to_device(np.zeros(rps * world, dtype=np.float64))
             self._key = key
-        planes = self._planes
+        planes, n2_all = self._planes, self._n2
         blk = rps * limbs * d_pad
         if n_local:
             ops.limb_split(sketches_local, limbs, planes, d_pad, rank * rps)
         n2_pad = np.zeros(rps, dtype=np.float64)
         n2_pad[:n_local] = norms_sq_local
+        n2_all[rank * rps:(rank + 1) * rps] = ops.to_device(n2_pad)
         if world > 1:
-            mine = planes[rank * blk:(rank + 1) * blk].clone()
-            dist.all_gather_into_tensor(planes[:world * blk], mine)
-            n2_all = ops.to_device(np.zeros(rps * world, dtype=np.float64))
-            dist.all_gather_into_tensor(n2_all, ops.to_device(n2_pad))
-        else:
-            n2_all = ops.to_device(n2_pad)
+            self.coll.allgather_blocks(planes, blk)     # int8 row blocks: 2 B per entry at two limbs instead of 4
+            self.coll.allgather_blocks(n2_all, rps)
         # rows beyond n_total are zero sketches with zero norms: they can never be kept
-        n2_dev = n2_all[:n_total].contiguous() if hasattr(n2_all, "contiguous") else n2_all[:n_total]
-        info = {"limbs": limbs, "rows": (rb, re), "allgather_bytes_per_rank": blk if world > 1 else 0}
+        n2_dev = n2_all[:n_total]
+        info = {"limbs": limbs, "rows": (rb, re), "allgather_bytes_per_rank": blk if world > 1 else 0,
+                "collectives": self.coll.kind if world > 1 else "none"}
         if world > 1 and self.symmetric and cells_out is not None:
             cells, cnt = self._run_symmetric(planes, n_total, n_alloc, d, d_pad, limbs, n2_dev, rb, re, keep_mode,
                                              cells_out, info)
         else:
-            cells, cnt = ops.compare(planes, n_total, n_alloc, d, d_pad, limbs, n2_dev, rb, re, keep_mode, cells_out)
+            status, err = 0, None
+            try:
+                cells, cnt = ops.compare(planes, n_total, n_alloc, d, d_pad, limbs, n2_dev, rb, re, keep_mode, cells_out)
+            except _capi.MvsError as e:
+                status, err = e.code, e
+            if self._agree(status):
+                raise err if err is not None else _capi.MvsError(_capi.MVS_E_HIP, "another rank failed in the comparison")
         return cells, cnt, info
 
     def _run_symmetric(self, planes, n_total, n_alloc, d, d_pad, limbs, n2_dev, rb, re, keep_mode, cells_out, info):
         """every unordered pair of row blocks once + exchange of the mirrored cells (module docstring)"""
         import torch
-        ops, dist, rank, world = self.ops, self.dist, self.rank, self.world
+        ops, rank, world = self.ops, self.rank, self.world
         cap = cells_out.shape[0]
         if self._raw is None or self._raw.shape[0] != cap:
             self._raw, self._tmp = ops.new_cells(cap), ops.new_cells(cap)
         raw, tmp = self._raw, self._tmp
-        sset = ops.open_set(planes, n_total, n_alloc, d, d_pad, limbs)
+        status, err = 0, None
         n_raw = 0
+        plan = block_plan(n_total, world, rank)
+        sset = ops.open_set(planes, n_total, n_alloc, d, d_pad, limbs)
         try:
-            plan = block_plan(n_total, world, rank)
             for (b0, b1, c0, c1, flags) in plan:
                 n_raw = ops.compare_block(sset, n2_dev, b0, b1, c0, c1, flags, keep_mode, raw, n_raw)
+        except _capi.MvsError as e:          # e.g. capacity: tell the others before anybody enters the exchange
+            status, err = e.code, e
         finally:
             ops.close_set(sset)
+        if self._agree(status):
+            raise err if err is not None else _capi.MvsError(_capi.MVS_E_HIP, "another rank failed in its block comparisons")
         ops.sort_cells(raw, n_raw, tmp)                     # (row, col) order: own rows form one contiguous run
         rows = tmp[:n_raw, 0].contiguous()
-        bounds = torch.searchsorted(rows, torch.tensor([rb, re], dtype=rows.dtype, device=rows.device))
-        lo, hi = int(bounds[0]), int(bounds[1])
-        local = tmp[lo:hi]
-        foreign = torch.cat([tmp[:lo], tmp[hi:n_raw]])      # mirrored cells of rows other ranks own
-        # exchange: all-gather of the (padded) foreign lists, every rank keeps the cells of its own rows
-        cnt_t = torch.tensor([foreign.shape[0]], dtype=torch.int64, device=foreign.device)
-        dist.all_reduce(cnt_t, op=dist.ReduceOp.MAX)
-        max_f = max(int(cnt_t[0]), 1)
-        send = torch.full((max_f, 4), -1, dtype=foreign.dtype, device=foreign.device)
-        send[:foreign.shape[0]] = foreign
-        recv = torch.empty((world * max_f, 4), dtype=foreign.dtype, device=foreign.device)
-        dist.all_gather_into_tensor(recv, send)
-        mine = recv[(recv[:, 0] >= rb) & (recv[:, 0] < re)]
-        n_out = local.shape[0] + mine.shape[0]
-        if n_out > cap:
-            raise _capi.MvsError(_capi.MVS_E_CAPACITY, "%d cells for this shard but capacity is %d" % (n_out, cap))
-        raw[:local.shape[0]] = local
-        raw[local.shape[0]:n_out] = mine
-        ops.sort_cells(raw, n_out, cells_out)
-        info.update({"blocks": len(plan), "exchanged_cells": int(foreign.shape[0]), "schedule": "symmetric"})
+        lo, hi = torch.searchsorted(rows, torch.tensor([rb, re], dtype=rows.dtype, device=rows.device)).tolist()   # sync 1
+        n_local, n_foreign = hi - lo, n_raw - (hi - lo)     # mirrored cells of rows other ranks own: before lo / after hi
+        max_f = max(self.coll.allreduce_max(n_foreign, rows), 1)
+        # exchange: all-gather of the padded foreign lists; every rank keeps the cells of its own rows.  Unwanted
+        # entries get row = INT32_MAX so that the final (row, col) sort pushes them behind the shard's cells.
+        recv = torch.full((world * max_f, 4), 2147483647, dtype=tmp.dtype, device=tmp.device)
+        mine = recv[rank * max_f:(rank + 1) * max_f]
+        mine[:lo] = tmp[:lo]
+        mine[lo:n_foreign] = tmp[hi:n_raw]
+        self.coll.allgather_blocks(recv.view(-1), max_f * 4)
+        wanted = (recv[:, 0] >= rb) & (recv[:, 0] < re)
+        recv[:, 0] = torch.where(wanted, recv[:, 0], torch.full_like(recv[:, 0], 2147483647))
+        n_mine = int(wanted.sum())                          # sync 2
+        n_out = n_local + n_mine
+        status = _capi.MVS_E_CAPACITY if (n_out > cap or n_local + world * max_f > cap) else 0
+        if self._agree(status):
+            raise _capi.MvsError(_capi.MVS_E_CAPACITY, "%d cells for this shard (%d in flight) but capacity is %d"
+                                 % (n_out, n_local + world * max_f, cap))
+        raw[:n_local] = tmp[lo:hi]
+        raw[n_local:n_local + world * max_f] = recv
+        ops.sort_cells(raw, n_local + world * max_f, cells_out)
+        info.update({"blocks": len(plan), "exchanged_cells": int(n_foreign), "schedule": "symmetric"})
         return cells_out, n_out

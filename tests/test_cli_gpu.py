@@ -196,6 +196,7 @@ def test_pairwise_streams_a_large_db(tmp_path):
     from oracle import pyoracle as orc
     n, d = 150_000, 2048
     sk_t = synth.make_sketches_torch(n, d, 50_000, seed=77, device="cuda")
+    torch.cuda.synchronize()           # the context below runs on its own stream, not on torch's
     ctx = pkg.Context(0)
     ss, _ = ctx.stats(sk_t)
     norms = np.sqrt(ss.astype(np.float64) / d)
@@ -329,3 +330,41 @@ def test_pairwise_db_that_needs_more_limbs(tmp_path):
     assert r.returncode == 0, r.stderr
     want = orc.pairwise_rows(sk, n2, chunk=192, threads=4)
     assert _dump(str(tmp_path / "idx" / "shard_0")) == sorted((int(c["row"]), int(c["col"]), int(c["q"])) for c in want)
+
+
+def test_pairwise_collective_mode_two_processes_one_gpu(tmp_path):
+    """MVS_COLLECTIVE=files: two shard processes, each loads only its own rows of vectors.bin and the all-gather of
+    the limb planes (mvs_allgather_planes, file transport because both share the one card) supplies the rest: the
+    shards equal those of the plain one-process-per-shard runs.  A db whose second shard needs three limbs makes the
+    ranks agree on the limb code through the all-reduce and start over together."""
+    from oracle import pyoracle as orc
+    from metagenome_vector_sketches_amd import synth
+    n, d = 3001, 512
+    sk = synth.make_sketches_numpy(n, d, 3000, seed=5, cluster=8)
+    for variant, bump in (("two_limbs", 0), ("three_limbs", 40000)):
+        skv = sk.copy()
+        if bump:
+            skv[2500, 7] = bump                       # |v| > 32639 in shard 1 only
+        db = str(tmp_path / ("db_" + variant)) + "/"
+        os.makedirs(db)
+        skv.astype("<i4").tofile(db + "vectors.bin")
+        with open(db + "vector_norms.txt", "w") as f:
+            f.write("".join("s%d %s\n" % (i, orc.format_norm(orc.norm(r))) for i, r in enumerate(skv)))
+        open(db + "dimension.txt", "w").write("%d\n" % d)
+        open(db + "dtype.txt", "w").write("int32\n")
+        plain, coll = str(tmp_path / (variant + "_plain")), str(tmp_path / (variant + "_coll"))
+        exe = os.path.join(BIN, "pairwise_comp_optimized")
+        for k in range(2):
+            r = run(exe, "--db", db, "--max_memory_gb", "1", "--num_threads", "4", "--output_folder", plain,
+                    "--num_shards", "2", "--shard_idx", str(k))
+            assert r.returncode == 0, r.stderr
+        env = dict(os.environ, MVS_COLLECTIVE="files", MVS_COLLECTIVE_TOKEN=variant, MVS_DEVICE="0")
+        procs = [subprocess.Popen([exe, "--db", db, "--max_memory_gb", "1", "--num_threads", "4", "--output_folder", coll,
+                                   "--num_shards", "2", "--shard_idx", str(k)], env=env, stdout=subprocess.PIPE,
+                                  stderr=subprocess.PIPE, text=True) for k in range(2)]
+        outs = [p.communicate(timeout=300) for p in procs]
+        assert all(p.returncode == 0 for p in procs), outs
+        for k in range(2):
+            assert "Shard %d processing rows" % k in outs[k][0]
+            got = _dump(os.path.join(coll, "shard_%d" % k))
+            assert got == _dump(os.path.join(plain, "shard_%d" % k)) and len(got) > 1500 * 7

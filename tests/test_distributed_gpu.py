@@ -66,3 +66,63 @@ def test_ranks_on_one_gpu_match_oracle(tmp_path, monkeypatch, n, world, two_stag
     for sym in (1, 0):
         got = np.concatenate([np.load(os.path.join(str(tmp_path), "cells_%d_%d.npy" % (sym, r))) for r in range(world)])
         assert np.array_equal(got, want), sym
+
+
+def _native_worker(rank, world, n, d, out_dir):
+    """no torch.distributed at all: the exchange goes through the C ABI's communicator (file transport: the ranks
+    share the one card, which RCCL refuses)"""
+    import metagenome_vector_sketches_amd as pkg
+    from metagenome_vector_sketches_amd import parallel
+    torch.cuda.set_device(0)
+    ctx = pkg.Context(0)
+    ctx.set_stream(torch.cuda.current_stream())
+    comm = ctx.comm_files(os.path.join(out_dir, "xchg"), rank, world)
+    assert (comm.rank, comm.world, comm.is_rccl) == (rank, world, False)
+    sk, n2 = _make(n, d)
+    b, e = parallel.shard_rows(n, world, rank)
+    local = torch.from_numpy(sk[b:e]).to("cuda:0")
+    out = torch.empty((n * 40, 4), dtype=torch.int32, device="cuda:0")
+    for sym in (True, False):
+        sc = parallel.ShardedComparison(parallel.GpuOps(ctx, torch.device("cuda", 0)), rank, world,
+                                        collectives=parallel.NativeCollectives(comm))
+        sc.symmetric = sym
+        _, cnt, info = sc.run(local, n2[b:e], n, cells_out=out)
+        torch.cuda.synchronize()
+        assert "file transport" in info["collectives"]
+        np.save(os.path.join(out_dir, "ncells_%d_%d.npy" % (int(sym), rank)), out[:cnt].cpu().numpy())
+    comm.close()
+    ctx.close()
+
+
+@pytest.mark.parametrize("n,world", [(700, 2), (650, 3)])
+def test_native_communicator_ranks_on_one_gpu(tmp_path, n, world):
+    d = 512
+    mp.spawn(_native_worker, args=(world, n, d, str(tmp_path)), nprocs=world, join=True)
+    from oracle import pyoracle as orc
+    sk, n2 = _make(n, d)
+    want = orc.pairwise_rows(sk, n2, chunk=192, threads=8)
+    want = want[np.lexsort((want["col"], want["row"]))]
+    want = np.stack([want[k] for k in ("row", "col", "dot", "q")], axis=1).astype(np.int32)
+    for sym in (1, 0):
+        got = np.concatenate([np.load(os.path.join(str(tmp_path), "ncells_%d_%d.npy" % (sym, r))) for r in range(world)])
+        assert np.array_equal(got, want), sym
+    assert not [f for f in os.listdir(str(tmp_path)) if f.startswith("xchg")]      # the transport cleans up after itself
+
+
+def test_rccl_communicator_first_contact():
+    """RCCL through the C ABI with a world of one (all a one-GPU box can do): the library is found and bound at run
+    time, ncclGetUniqueId / ncclCommInitRank succeed, the collectives return at once and leave the data alone"""
+    import metagenome_vector_sketches_amd as pkg
+    from metagenome_vector_sketches_amd import _capi
+    ctx = pkg.Context(0)
+    uid = _capi.comm_unique_id()
+    assert len(uid) == _capi.COMM_ID_BYTES and any(uid)
+    comm = ctx.comm_rccl(uid, 0, 1)
+    assert (comm.rank, comm.world, comm.is_rccl) == (0, 1, True)
+    buf = torch.arange(1024, dtype=torch.int8, device="cuda:0")
+    comm.allgather_bytes(buf, 1024)
+    ctx.synchronize()
+    assert torch.equal(buf.cpu(), torch.arange(1024, dtype=torch.int8))
+    assert comm.allreduce_max(41) == 41
+    comm.close()
+    ctx.close()
