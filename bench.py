@@ -101,6 +101,10 @@ def main():
     ap.add_argument("--hashes", type=int, default=50_000, help="hashes per sample")
     ap.add_argument("--dim", type=int, default=2048)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5],
+                    help="2 (default): configs[1], 10k samples x 50k hashes per GPU, projection + pairwise, weak scaling; "
+                         "3 / 4 / 5: pairwise only on 100k x 2048 / 100k x 4096 / 1M x 2048 synthesised sketches split "
+                         "over the ranks (strong scaling: BASELINE.json configs[2] / [3] / [4])")
     ap.add_argument("--pairwise-samples", type=int, default=100_000,
                     help="N=1: size of the configs[2] leg (pairwise only on synthesised sketches); 0 skips it")
     ap.add_argument("--pairwise-reps", type=int, default=10, help="timed repetitions of the configs[2] leg")
@@ -142,6 +146,38 @@ def main():
     stream = torch.cuda.current_stream()
     ctx.set_stream(stream)
     ctx.set_timing(True)
+    from metagenome_vector_sketches_amd import parallel, _capi
+    coll, coll_note = None, None
+    if world > 1:
+        # the data path's collectives go through the C ABI's RCCL communicator (the id travels over torch.distributed);
+        # should that fail on a node we could never try, torch.distributed's own collectives carry the exchange
+        try:
+            if rehearsal:
+                comm = ctx.comm_files(os.path.join(os.environ.get("TMPDIR", "/tmp"), "mvs_bench_%s" %
+                                                   os.environ.get("MASTER_PORT", "0")), rank, world)
+            else:
+                uid = torch.zeros(_capi.COMM_ID_BYTES, dtype=torch.uint8, device=dev)
+                if rank == 0:
+                    uid.copy_(torch.frombuffer(bytearray(_capi.comm_unique_id()), dtype=torch.uint8))
+                dist.broadcast(uid, src=0)
+                comm = ctx.comm_rccl(bytes(uid.cpu().numpy().tobytes()), rank, world)
+            coll = parallel.NativeCollectives(comm)
+        except Exception as e:      # noqa: BLE001 -- any failure here must not take the benchmark down
+            coll_note = "native communicator failed (%s: %s); torch.distributed carries the exchange" % (type(e).__name__, e)
+            coll = parallel.TorchCollectives(dist, rank, world)
+        ok = torch.tensor([1 if isinstance(coll, parallel.NativeCollectives) else 0], device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0 and isinstance(coll, parallel.NativeCollectives):   # all ranks use the same transport
+            coll_note = "another rank could not create the native communicator; torch.distributed carries the exchange"
+            coll = parallel.TorchCollectives(dist, rank, world)
+
+    if args.config != 2:
+        res = strong_scaling(args, ctx, dev, rank, world, dist if world > 1 else None, coll, coll_note)
+        if rank == 0:
+            print(json.dumps(res))
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     # ---- synthetic input, resident in HBM ----
     if args.lognormal_sigma > 0:
@@ -156,8 +192,7 @@ def main():
     cells = torch.empty((cap, 4), dtype=torch.int32, device=dev)
     torch.cuda.synchronize()
 
-    from metagenome_vector_sketches_amd import parallel
-    sc = parallel.ShardedComparison(parallel.GpuOps(ctx, dev), rank, world, dist if world > 1 else None)
+    sc = parallel.ShardedComparison(parallel.GpuOps(ctx, dev), rank, world, collectives=coll)
     state = {}
 
     def step():
@@ -239,7 +274,8 @@ def main():
                    "cluster": args.cluster, "lognormal_sigma": args.lognormal_sigma,
                    "hashes_per_gpu": int(total_hashes),
                    "limbs": limbs, "kept_cells": kept_total, "parallelism": "row shards x%d" % world,
-                   "schedule": state["schedule"]},
+                   "schedule": state["schedule"],
+                   "collectives": (coll.kind if coll is not None else "none"), "collectives_note": coll_note},
         "cells_per_s": cells_per_step / (elapsed / args.steps),
         "stages": {"projection_kernel_ms": k1, "projection_samples_per_s_per_gpu": S / (k1 * 1e-3),
                    "pairwise_kernel_ms": k2, "pairwise_cells_per_s_per_gpu": S * float(N_total) / (k2 * 1e-3),
@@ -298,6 +334,83 @@ def main():
     print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()
+
+
+def strong_scaling(args, ctx, dev, rank, world, dist, coll, coll_note):
+    """--config 3 / 4 / 5: BASELINE.json configs[2] / [3] / [4] -- pairwise only, a FIXED number of synthesised sketches
+    split over the ranks by the reference's shard formula.  One step = re-code this rank's rows into its block of the
+    plane buffer -> all-gather of the int8 plane blocks and the norms -> this rank's share of the symmetric block plan
+    (two-stage comparison) -> exchange of the mirrored cells -> this rank's shard, sorted.  Sketches and norms are
+    resident in HBM when the clock starts."""
+    import torch
+    from metagenome_vector_sketches_amd import parallel, synth
+    n_total, d = {3: (100_000, 2048), 4: (100_000, 4096), 5: (1_000_000, 2048)}[args.config]
+    rb, re = parallel.shard_rows(n_total, world, rank)
+    sk = synth.make_sketches_torch_rows(n_total, d, args.hashes, seed={3: 2345, 4: 3456, 5: 4567}[args.config], device=dev,
+                                        row_begin=rb, row_end=re)
+    ss = torch.empty(re - rb, dtype=torch.int64, device=dev)
+    _, max_abs = ctx.stats(sk, out=ss)
+    n2_local = fast_norm_sq(ss.cpu().numpy(), d)
+    sc = parallel.ShardedComparison(parallel.GpuOps(ctx, dev), rank, world, collectives=coll)
+    sc.time_gather = True
+    cap = max(1 << 22, 40 * (re - rb) + (1 << 20))
+    cells = torch.empty((cap, 4), dtype=torch.int32, device=dev)
+    state = {}
+
+    def step():
+        sc.ops.k2_ms = 0.0
+        _, cnt, info = sc.run(sk, n2_local, n_total, cells_out=cells, max_abs_local=max_abs)
+        state.update(cnt=cnt, info=info, k2=sc.ops.k2_ms if sc.ops.k2_ms > 0 else ctx.kernel_ms(1))
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    k2, gather = [], []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        k2.append(state["k2"])
+        gather.append(sc.last_gather_ms())
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    kept = state["cnt"]
+    if world > 1:
+        t = torch.tensor([elapsed, float(np.mean(k2)), float(np.mean(gather))], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, k2_max, gather_max = (float(x) for x in t.tolist())
+        c = torch.tensor([kept], dtype=torch.int64, device=dev)
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        kept = int(c.item())
+    else:
+        k2_max, gather_max = float(np.mean(k2)), float(np.mean(gather))
+    info = state["info"]
+    cells_total = float(n_total) * n_total
+    per_step = elapsed / args.steps
+    return {"metric": "samples projected/sec + pairwise Jaccard cells/sec, d=2048, 1/2/4/8 GPUs",
+            "value": cells_total / per_step, "unit": "pairwise cells/s (ordered pairs of the full N x N matrix, whole job)",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": per_step * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "int8 limbs x int32 MFMA accumulate; fp64 keep test", "data": "synthetic",
+            "config": {"workload": "configs[%d]: %d synthetic samples, d=%d, pairwise, row shards over %d GPU(s)" %
+                                   (args.config - 1, n_total, d, world),
+                       "total_samples": n_total, "d": d, "limbs": info["limbs"], "kept_cells": kept,
+                       "schedule": info.get("schedule", "rows x all columns"),
+                       "collectives": info.get("collectives"), "collectives_note": coll_note},
+            "stages": {"comparison_kernels_ms_max_over_ranks": k2_max, "allgather_ms_max_over_ranks": gather_max,
+                       "allgather_bytes_per_rank": info["allgather_bytes_per_rank"],
+                       "allgather_bytes_received_per_rank": info["allgather_bytes_per_rank"] * (world - 1),
+                       "exchanged_cells": info.get("exchanged_cells", 0),
+                       "other_ms": per_step * 1e3 - k2_max - gather_max},
+            "roofline": {"kernel": "k_pairwise_pp<filter> + k_exact_pairs (per rank)", "bound": "mfma",
+                         "achieved": 2.0 * d * cells_total / world / (k2_max * 1e-3) / 1e12, "peak": INT8_MFMA_PEAK_TOPS,
+                         "unit": "TFLOP/s per GPU (algorithmic: 2 d flop per cell of the rank's share)",
+                         "frac": 2.0 * d * cells_total / world / (k2_max * 1e-3) / 1e12 / INT8_MFMA_PEAK_TOPS,
+                         "traffic": None}}
 
 
 def pairwise_leg(ctx, dev, n, d, nh, reps):

@@ -173,9 +173,18 @@ class ShardedComparison:
         self._key = None
         self._raw = self._tmp = None
         self._n2 = None
+        self.time_gather = False         # bench: torch events around the all-gathers (read with last_gather_ms())
+        self._ev = None
         self.symmetric = os.environ.get("MVS_SHARDED_SYMMETRIC", "1") != "0"
         if world > 1 and self.coll is None:
             raise ValueError("world > 1 needs torch.distributed or a communicator")
+
+    def last_gather_ms(self):
+        """duration of the last step's all-gathers on the stream (0 with one rank); synchronises on the end event"""
+        if self._ev is None:
+            return 0.0
+        self._ev[1].synchronize()
+        return self._ev[0].elapsed_time(self._ev[1])
 
     def _agree(self, status):
         """every rank learns whether any rank failed (a rank that raises alone would leave the others inside the
@@ -217,8 +226,14 @@ class ShardedComparison:
         n2_pad[:n_local] = norms_sq_local
         n2_all[rank * rps:(rank + 1) * rps] = ops.to_device(n2_pad)
         if world > 1:
+            if self.time_gather:
+                import torch
+                self._ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                self._ev[0].record()
             self.coll.allgather_blocks(planes, blk)     # int8 row blocks: 2 B per entry at two limbs instead of 4
             self.coll.allgather_blocks(n2_all, rps)
+            if self.time_gather:
+                self._ev[1].record()
         # rows beyond n_total are zero sketches with zero norms: they can never be kept
         n2_dev = n2_all[:n_total]
         info = {"limbs": limbs, "rows": (rb, re), "allgather_bytes_per_rank": blk if world > 1 else 0,

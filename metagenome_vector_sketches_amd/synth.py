@@ -112,3 +112,30 @@ def make_sketches_torch(n_samples, d, n_hashes, seed, device, cluster=16, shared
     base = pm_binomial((n_clusters, d), k).repeat_interleave(cluster, dim=0)[:n_samples]
     out = base + pm_binomial((n_samples, d), n_hashes - k)
     return out.contiguous()
+
+
+def make_sketches_torch_rows(n_total, d, n_hashes, seed, device, row_begin, row_end, cluster=16, shared=0.4, slab=65536):
+    """Rows [row_begin, row_end) of an n_total-row synthetic sketch matrix that is the same whichever rank (and
+    whatever row range) asks: the matrix is defined slab by slab (slab = a multiple of the cluster size), every slab
+    from its own generator seeded with (seed, slab index), so a rank generates only the slabs its rows touch.
+    Same distribution as make_sketches_torch.  int32 [row_end - row_begin, d]."""
+    import torch
+    assert slab % cluster == 0
+    k = int(round(shared * n_hashes))
+    out = torch.empty((max(0, row_end - row_begin), d), dtype=torch.int32, device=device)
+
+    def pm_binomial(shape, n, g):
+        x = torch.randn(shape, device=device, generator=g) * (n ** 0.5)
+        return (torch.round((x - (n & 1)) / 2) * 2 + (n & 1)).to(torch.int32)
+
+    for s0 in range(row_begin // slab * slab, row_end, slab):
+        s1 = min(n_total, s0 + slab)
+        g = torch.Generator(device=device)
+        g.manual_seed(seed * 1_000_003 + s0 // slab)
+        n_cl = (s1 - s0 + cluster - 1) // cluster
+        base = pm_binomial((n_cl, d), k, g).repeat_interleave(cluster, dim=0)[:s1 - s0]
+        rows = base + pm_binomial((s1 - s0, d), n_hashes - k, g)
+        lo, hi = max(s0, row_begin), min(s1, row_end)
+        if hi > lo:
+            out[lo - row_begin:hi - row_begin] = rows[lo - s0:hi - s0]
+    return out
