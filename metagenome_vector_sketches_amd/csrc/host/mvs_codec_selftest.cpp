@@ -131,6 +131,36 @@ int main(int argc, char* argv[]) {
         mvs_host::HashSets hl;
         CHECK(mvs_host::read_hash_file(p, false, hl, 1));
         CHECK(hl.offsets.size() == 7);   // six lines, every one a record
+        // negative tokens: num_get<unsigned long> negates modulo 2^64 and carries on (-1 = 2^64 - 1, -0 = 0); a bare
+        // or doubled sign ends the line
+        {
+            std::ofstream f(p);
+            f << "n: 5 -1 7 -0\nm: 4 - 5\nk: +3 -+2 9\n";
+        }
+        mvs_host::HashSets hn;
+        CHECK(mvs_host::read_hash_file(p, true, hn, 1));
+        CHECK(hn.offsets[1] == 4 && hn.hashes[0] == 0 && hn.hashes[1] == 5 && hn.hashes[2] == 7 &&
+              hn.hashes[3] == 18446744073709551615ULL);
+        CHECK(hn.offsets[2] - hn.offsets[1] == 1 && hn.offsets[3] - hn.offsets[2] == 1 && hn.hashes[5] == 3);
+        // binary CSR cache: round trip, then stale once the text changes
+        CHECK(!mvs_host::load_csr_cache(p, hl));
+        CHECK(mvs_host::write_csr_cache(p, hn));
+        mvs_host::HashSets hc;
+        CHECK(mvs_host::load_csr_cache(p, hc));
+        CHECK(hc.names == hn.names && hc.offsets == hn.offsets && hc.hashes.size() == hn.hashes.size());
+        for (size_t i = 0; i < hn.hashes.size(); ++i) CHECK(hc.hashes[i] == hn.hashes[i]);
+        {
+            std::ofstream f(p, std::ios::app);
+            f << "extra: 1\n";
+        }
+        mvs_host::HashSets hs2;
+        CHECK(!mvs_host::load_csr_cache(p, hs2));                       // size / mtime no longer match
+        {
+            std::ofstream f(mvs_host::csr_cache_path(p), std::ios::binary | std::ios::trunc);
+            f << "garbage";
+        }
+        CHECK(!mvs_host::load_csr_cache(p, hs2));
+        std::remove(mvs_host::csr_cache_path(p).c_str());
         std::remove(p.c_str());
     }
     CHECK(mvs_host::format_g(56.46254) == "56.4625" && mvs_host::format_g(1234567.0) == "1.23457e+06");

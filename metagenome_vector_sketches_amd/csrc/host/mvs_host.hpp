@@ -16,6 +16,8 @@
 #include <iostream>
 #include <sstream>
 #include <string>
+#include <exception>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -39,15 +41,31 @@ namespace fs = std::filesystem;
 struct HashBuffer {
     uint64_t* p = nullptr;
     size_t n = 0;
+    void* map_base = nullptr;        // non-NULL: p points into a read-only file mapping of map_len bytes (the CSR cache)
+    size_t map_len = 0;
     HashBuffer() = default;
     HashBuffer(const HashBuffer&) = delete;
     HashBuffer& operator=(const HashBuffer&) = delete;
-    ~HashBuffer() { free(p); }
+    ~HashBuffer() { release(); }
+    void release() {
+        if (map_base) ::munmap(map_base, map_len);
+        else free(p);
+        p = nullptr;
+        map_base = nullptr;
+        n = map_len = 0;
+    }
     bool reset(size_t count) {
-        free(p);
+        release();
         p = (uint64_t*)malloc(std::max<size_t>(8, count * sizeof(uint64_t)));
         n = p ? count : 0;
         return p != nullptr;
+    }
+    void adopt_mapping(void* base, size_t len, const uint64_t* first, size_t count) {
+        release();
+        map_base = base;
+        map_len = len;
+        p = const_cast<uint64_t*>(first);
+        n = count;
     }
     const uint64_t* data() const { return p; }
     uint64_t* data() { return p; }
@@ -69,7 +87,9 @@ inline void parse_u64_tokens(const char* p, const char* end, std::vector<uint64_
     while (true) {
         while (p < end && (*p == ' ' || *p == '\t' || *p == '\r' || *p == '\v' || *p == '\f')) ++p;
         if (p >= end) break;
-        if (*p == '+') ++p;
+        // one optional sign; num_get<unsigned long> accepts '-' and negates modulo 2^64 ("-1" reads 2^64 - 1)
+        const bool negate = *p == '-';
+        if (*p == '+' || *p == '-') ++p;
         if (p >= end || *p < '0' || *p > '9') break;
         uint64_t v = 0;
         bool overflow = false;
@@ -80,6 +100,7 @@ inline void parse_u64_tokens(const char* p, const char* end, std::vector<uint64_
             ++p;
         }
         if (overflow) break;                                   // failbit in the reference
+        if (negate) v = 0 - v;
         if (p < end && !(*p == ' ' || *p == '\t' || *p == '\r' || *p == '\v' || *p == '\f')) {
             out.push_back(v);                                  // "12abc": 12 is extracted, then the stream fails
             break;
@@ -156,14 +177,29 @@ inline bool read_hash_file(const std::string& path, bool with_names, HashSets& o
     const size_t n = recs.size();
     std::vector<std::vector<uint64_t>> sets(n);
     threads = (unsigned)std::min<size_t>(threads, std::max<size_t>(1, n));
+    // an exception in a worker (bad_alloc on a huge line) must not end in std::terminate: it is carried to the caller
+    std::exception_ptr worker_error;
+    std::mutex worker_mutex;
     auto run = [&](auto&& body) {
         std::vector<std::thread> pool;
-        for (unsigned t = 0; t < threads; ++t) pool.emplace_back([&, t]() { body(t); });
+        for (unsigned t = 0; t < threads; ++t)
+            pool.emplace_back([&, t]() {
+                try {
+                    body(t);
+                } catch (...) {
+                    std::lock_guard<std::mutex> lock(worker_mutex);
+                    if (!worker_error) worker_error = std::current_exception();
+                }
+            });
         for (auto& th : pool) th.join();
     };
     run([&](unsigned t) {
         for (size_t i = t; i < n; i += threads) parse_u64_tokens(buf + recs[i].colon + 1, buf + recs[i].e, sets[i]);
     });
+    if (worker_error) {
+        if (size) ::munmap((void*)buf, size);
+        std::rethrow_exception(worker_error);
+    }
     out.names.resize(n);
     out.offsets.assign(n + 1, 0);
     for (size_t i = 0; i < n; ++i) out.offsets[i + 1] = out.offsets[i] + (int64_t)sets[i].size();
@@ -180,6 +216,115 @@ inline bool read_hash_file(const std::string& path, bool with_names, HashSets& o
         }
     });
     if (size) ::munmap((void*)buf, size);
+    if (worker_error) std::rethrow_exception(worker_error);
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Binary CSR cache of a hash text file: "<hash_file>.csr" next to it.  Parsing the text is what bounds
+// `project_everything sketch` end to end (src/project_everything.cpp:264-281 parses serially; here all host threads
+// parse, and it still is 10-100x the device time), so the parsed form -- names, offsets, unique sorted u64 values,
+// exactly what read_hash_file() returns -- is kept and mapped on the next run.  The cache is valid only for the
+// text file it was made from (size and modification time are recorded); anything else falls back to the text.
+//   header (64 B): magic "MVSCSR01", u64 text size, i64 text mtime (ns), u64 samples, u64 values, u64 name bytes
+//   i64 offsets[samples + 1], u64 name_ends[samples], names, padding to 8, u64 values[]
+// ---------------------------------------------------------------------------------------------------
+struct CsrHeader {
+    char magic[8];
+    uint64_t text_size;
+    int64_t text_mtime_ns;
+    uint64_t samples, values, name_bytes;
+    uint64_t reserved[2];
+};
+static_assert(sizeof(CsrHeader) == 64, "header layout");
+
+inline std::string csr_cache_path(const std::string& hash_file) { return hash_file + ".csr"; }
+
+inline bool text_identity(const std::string& path, uint64_t& size, int64_t& mtime_ns) {
+    struct stat st;
+    if (::stat(path.c_str(), &st) != 0 || !S_ISREG(st.st_mode)) return false;
+    size = (uint64_t)st.st_size;
+    mtime_ns = (int64_t)st.st_mtim.tv_sec * 1000000000LL + st.st_mtim.tv_nsec;
+    return true;
+}
+
+// best effort: a cache that cannot be written is simply not there next time
+inline bool write_csr_cache(const std::string& hash_file, const HashSets& sets) {
+    CsrHeader h{};
+    memcpy(h.magic, "MVSCSR01", 8);
+    if (!text_identity(hash_file, h.text_size, h.text_mtime_ns)) return false;
+    h.samples = sets.names.size();
+    h.values = sets.hashes.size();
+    std::vector<uint64_t> ends(sets.names.size());
+    uint64_t at = 0;
+    for (size_t i = 0; i < sets.names.size(); ++i) ends[i] = at += sets.names[i].size();
+    h.name_bytes = at;
+    const std::string path = csr_cache_path(hash_file), tmp = path + ".part";
+    FILE* f = fopen(tmp.c_str(), "wb");
+    if (!f) return false;
+    bool ok = fwrite(&h, sizeof h, 1, f) == 1;
+    ok = ok && fwrite(sets.offsets.data(), 8, sets.offsets.size(), f) == sets.offsets.size();
+    ok = ok && (ends.empty() || fwrite(ends.data(), 8, ends.size(), f) == ends.size());
+    for (size_t i = 0; ok && i < sets.names.size(); ++i)
+        ok = sets.names[i].empty() || fwrite(sets.names[i].data(), 1, sets.names[i].size(), f) == sets.names[i].size();
+    const char zeros[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (ok && at % 8) ok = fwrite(zeros, 1, 8 - at % 8, f) == 8 - at % 8;
+    ok = ok && (h.values == 0 || fwrite(sets.hashes.data(), 8, h.values, f) == h.values);
+    ok = (fclose(f) == 0) && ok;
+    if (!ok || rename(tmp.c_str(), path.c_str()) != 0) {
+        ::unlink(tmp.c_str());
+        return false;
+    }
+    return true;
+}
+
+// true: `out` holds the cached sets (values mapped, not copied).  false: no cache, stale cache, or damaged file.
+inline bool load_csr_cache(const std::string& hash_file, HashSets& out) {
+    uint64_t text_size = 0;
+    int64_t text_mtime = 0;
+    if (!text_identity(hash_file, text_size, text_mtime)) return false;
+    const std::string path = csr_cache_path(hash_file);
+    const int fd = ::open(path.c_str(), O_RDONLY);
+    if (fd < 0) return false;
+    struct stat st;
+    if (::fstat(fd, &st) != 0 || (size_t)st.st_size < sizeof(CsrHeader)) {
+        ::close(fd);
+        return false;
+    }
+    const size_t len = (size_t)st.st_size;
+    void* m = ::mmap(nullptr, len, PROT_READ, MAP_PRIVATE, fd, 0);
+    ::close(fd);
+    if (m == MAP_FAILED) return false;
+    const char* base = (const char*)m;
+    CsrHeader h;
+    memcpy(&h, base, sizeof h);
+    const size_t names_pad = (size_t)((h.name_bytes + 7) / 8 * 8);
+    const bool sane = memcmp(h.magic, "MVSCSR01", 8) == 0 && h.text_size == text_size && h.text_mtime_ns == text_mtime &&
+                      h.samples < (1ULL << 40) && h.values < (1ULL << 48) && h.name_bytes < (1ULL << 40) &&
+                      len == sizeof h + (h.samples + 1) * 8 + h.samples * 8 + names_pad + h.values * 8;
+    if (!sane) {
+        ::munmap(m, len);
+        return false;
+    }
+    const int64_t* offs = (const int64_t*)(base + sizeof h);
+    const uint64_t* ends = (const uint64_t*)(offs + h.samples + 1);
+    const char* names = (const char*)(ends + h.samples);
+    const uint64_t* values = (const uint64_t*)(names + names_pad);
+    bool ok = offs[0] == 0 && (uint64_t)offs[h.samples] == h.values && (h.samples == 0 || ends[h.samples - 1] == h.name_bytes);
+    for (uint64_t i = 0; ok && i < h.samples; ++i)
+        ok = offs[i + 1] >= offs[i] && (i == 0 || ends[i] >= ends[i - 1]);
+    if (!ok) {
+        ::munmap(m, len);
+        return false;
+    }
+    out.offsets.assign(offs, offs + h.samples + 1);
+    out.names.resize((size_t)h.samples);
+    for (uint64_t i = 0; i < h.samples; ++i) {
+        const uint64_t b = i ? ends[i - 1] : 0;
+        out.names[(size_t)i].assign(names + b, (size_t)(ends[i] - b));
+    }
+    ::madvise(m, len, MADV_SEQUENTIAL);
+    out.hashes.adopt_mapping(m, len, values, (size_t)h.values);
     return true;
 }
 

@@ -4,6 +4,7 @@
 //
 //   project_everything sketch  <hash_file> <index_folder> [-t/--threads N] [-d/--dimension D] [--int16]
 //   project_everything convert <signature_folder> <hash_file> [-t/--threads N]      (host only, zlib)
+#include <atomic>
 #include <chrono>
 #include <thread>
 #include <mutex>
@@ -78,6 +79,27 @@ static int convert(const std::string& folder_name, const std::string& output_fil
         hash_out << line;
     }
     hash_out.close();
+    // the binary form `sketch` would otherwise have to parse back out of the text (hash_file.csr, see mvs_host.hpp)
+    if (hash_out && !getenv("MVS_NO_CSR_CACHE")) {
+        HashSets sets;
+        bool plain_names = true;
+        size_t total = 0;
+        for (auto& r : results) {
+            std::sort(r.second.begin(), r.second.end());
+            r.second.erase(std::unique(r.second.begin(), r.second.end()), r.second.end());
+            total += r.second.size();
+            plain_names = plain_names && r.first.find_first_of(":\n") == std::string::npos;
+        }
+        if (plain_names && sets.hashes.reset(total)) {
+            sets.offsets.assign(1, 0);
+            for (const auto& r : results) {
+                sets.names.push_back(r.first);
+                if (!r.second.empty()) memcpy(sets.hashes.data() + sets.offsets.back(), r.second.data(), r.second.size() * 8);
+                sets.offsets.push_back(sets.offsets.back() + (int64_t)r.second.size());
+            }
+            (void)write_csr_cache(output_file, sets);
+        }
+    }
     auto end = std::chrono::high_resolution_clock::now();
     std::chrono::duration<double> elapsed = end - start;
     std::cout << "Time to convert all signatures: " << elapsed.count() << " seconds" << std::endl;
@@ -101,6 +123,15 @@ static int sketch(const std::string& hash_file, std::string index_folder, int di
         fs::create_directories(index_folder);
     }
     auto start = std::chrono::high_resolution_clock::now();                                            // :255
+    // MVS_STAGE_TIMING=1: per-stage wall times on stderr (not part of the reference's output)
+    const bool stage_timing = getenv("MVS_STAGE_TIMING") != nullptr;
+    auto lap_t = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        const auto t = std::chrono::steady_clock::now();
+        if (stage_timing)
+            std::cerr << "[stage] " << what << " " << std::chrono::duration<double>(t - lap_t).count() << " s" << std::endl;
+        lap_t = t;
+    };
 
     // the device context (0.1-0.2 s of runtime start-up) comes up while the text is parsed
     mvs_ctx* ctx = nullptr;
@@ -110,14 +141,43 @@ static int sketch(const std::string& hash_file, std::string index_folder, int di
         ctx_rc = mvs_ctx_create(pick_device(), &ctx);
         if (ctx_rc != MVS_OK) ctx_err = mvs_last_error();   // the message is per thread
     });
+    // the parsed form of an unchanged hash file is kept next to it (<hash_file>.csr): mapped instead of parsed again
     HashSets sets;
-    const bool parsed = read_hash_file(hash_file, true, sets);
+    bool parsed = load_csr_cache(hash_file, sets);
+    if (parsed && sets.hashes.size() > (1u << 24)) {
+        // page the mapping in on all host threads now (the context needs ~0.1 s anyway) instead of one fault at a
+        // time inside the upload
+        const size_t bytes = sets.hashes.size() * 8;
+        const unsigned nt = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+        std::vector<std::thread> pool;
+        std::atomic<uint64_t> sink{0};
+        for (unsigned t = 0; t < nt; ++t)
+            pool.emplace_back([&, t]() {
+                const volatile char* b = reinterpret_cast<const volatile char*>(sets.hashes.data());
+                uint64_t acc = 0;
+                for (size_t o = bytes / nt * t, e = t + 1 == nt ? bytes : bytes / nt * (t + 1); o < e; o += 4096) acc += (uint64_t)b[o];
+                sink += acc;
+            });
+        for (auto& th : pool) th.join();
+    }
+    if (!parsed) {
+        try {
+            parsed = read_hash_file(hash_file, true, sets);
+        } catch (const std::exception& e) {
+            ctx_thread.join();
+            std::cerr << "project_everything: reading " << hash_file << ": " << e.what() << std::endl;
+            if (ctx) mvs_ctx_destroy(ctx);
+            return 2;
+        }
+        if (parsed && !getenv("MVS_NO_CSR_CACHE")) (void)write_csr_cache(hash_file, sets);
+    }
     ctx_thread.join();
     if (!parsed) {                                                                                     // :258-262
         std::cerr << "Error opening " << hash_file << " for reading." << std::endl;
         if (ctx) mvs_ctx_destroy(ctx);
         return 0;   // the reference returns from sketch() and exits 0
     }
+    lap("hash sets (text or cache) + device context");
     const int64_t n = (int64_t)sets.names.size();
     std::cout << "Loaded " << n << " hash sets from " << hash_file << std::endl;                       // :284
     if (ctx_rc != MVS_OK) {
@@ -133,11 +193,10 @@ static int sketch(const std::string& hash_file, std::string index_folder, int di
         while (s1 < n && sets.offsets[s1 + 1] - sets.offsets[s0] <= kMaxBatchHashes) ++s1;
         std::vector<int64_t> offs((size_t)(s1 - s0 + 1));
         for (int64_t s = s0; s <= s1; ++s) offs[(size_t)(s - s0)] = sets.offsets[s] - sets.offsets[s0];
-        int rc = mvs_project_csr(ctx, sets.hashes.data() + sets.offsets[s0], MVS_MEM_HOST, offs.data(), s1 - s0,
-                                 dimension, vectors.data() + (size_t)s0 * dimension, MVS_MEM_HOST);
-        if (rc == MVS_OK)
-            rc = mvs_sketch_sumsq(ctx, vectors.data() + (size_t)s0 * dimension, MVS_MEM_HOST, s1 - s0, dimension,
-                                  sumsq.data() + s0, MVS_MEM_HOST);
+        int64_t max_abs = 0;   // not needed here; the statistics come out of the projection kernel for free
+        const int rc = mvs_project_csr_stats(ctx, sets.hashes.data() + sets.offsets[s0], MVS_MEM_HOST, offs.data(), s1 - s0,
+                                             dimension, vectors.data() + (size_t)s0 * dimension, MVS_MEM_HOST,
+                                             sumsq.data() + s0, &max_abs);
         if (rc != MVS_OK) {
             std::cerr << "project_everything: " << mvs_last_error() << std::endl;
             mvs_ctx_destroy(ctx);
@@ -145,6 +204,7 @@ static int sketch(const std::string& hash_file, std::string index_folder, int di
         }
         s0 = s1;
     }
+    lap("projection (upload, kernels, download)");
     for (int64_t i = 0; i < n; ++i)                                                                    // :294-297
         std::cout << "Projected " << sets.names[(size_t)i] << ", vector dimension " << dimension << ", index " << i
                   << "\n";
@@ -179,7 +239,9 @@ static int sketch(const std::string& hash_file, std::string index_folder, int di
             bin_out.write(reinterpret_cast<const char*>(vectors.data()), (std::streamsize)(vectors.size() * 4));
         }
     }
+    lap("progress lines + DB files");
     mvs_ctx_destroy(ctx);
+    lap("context teardown");
     return status;
 }
 

@@ -7,6 +7,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "mvs_internal.h"
@@ -43,6 +44,12 @@ struct mvs_ctx {
     double filter_off_coeff = 0.0;
     unsigned long long last_candidates = 0; // candidate pairs of the last two-stage comparison (0: exact kernel)
     unsigned long long h_start = 0;      // host copy of the starting cell count of an appending call
+    // host hash lists on their way to the device: two pinned staging buffers + a copy stream, so that the host-side
+    // copy into pinned memory, the DMA and the projection kernel of consecutive pieces overlap
+    void* up_pinned[2] = {nullptr, nullptr};
+    size_t up_bytes = 0;
+    hipStream_t up_stream = nullptr;
+    hipEvent_t up_done[2] = {nullptr, nullptr};   // DMA out of staging buffer i has completed
     // pinned host staging for small metadata uploads (projection unit lists)
     void* pinned = nullptr;
     size_t pinned_bytes = 0;
@@ -204,6 +211,41 @@ void options_from_env(mvs::Options& o) {
     }
 }
 
+// Copy `bytes` from pageable host memory into pinned memory on several threads: one thread moves ~10 GB/s, the PCIe
+// link 50+ GB/s, so a single memcpy would be what bounds the upload.
+void parallel_copy(void* dst, const void* src, size_t bytes) {
+    const size_t kMin = 8u << 20;
+    unsigned nt = std::thread::hardware_concurrency();
+    nt = nt == 0 ? 4 : (nt > 16 ? 16 : nt);
+    if (bytes < 2 * kMin) nt = 1;
+    if (nt <= 1) {
+        std::memcpy(dst, src, bytes);
+        return;
+    }
+    std::vector<std::thread> pool;
+    const size_t per = (bytes / nt + 4095) & ~(size_t)4095;
+    for (unsigned t = 0; t < nt; ++t) {
+        const size_t b = (size_t)t * per;
+        if (b >= bytes) break;
+        const size_t n = std::min(per, bytes - b);
+        pool.emplace_back([=]() { std::memcpy((char*)dst + b, (const char*)src + b, n); });
+    }
+    for (auto& th : pool) th.join();
+}
+
+constexpr size_t kUploadPiece = 32u << 20;    // bytes per staging buffer (pinning memory costs ~0.3 ms per MiB: keep them small)
+
+int ensure_upload_pipeline(mvs_ctx* c) {
+    if (c->up_bytes) return MVS_OK;
+    HIP_TRY(hipStreamCreateWithFlags(&c->up_stream, hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i) {
+        HIP_TRY(hipHostMalloc(&c->up_pinned[i], kUploadPiece, hipHostMallocDefault));
+        HIP_TRY(hipEventCreateWithFlags(&c->up_done[i], hipEventDisableTiming));
+    }
+    c->up_bytes = kUploadPiece;
+    return MVS_OK;
+}
+
 int check_kernel(const char* what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(MVS_E_HIP, "%s launch: %s", what, hipGetErrorString(e));
@@ -285,6 +327,11 @@ int mvs_ctx_destroy(mvs_ctx* c) {
     if (c->pw_rows) (void)hipFree(c->pw_rows);
     if (c->pw_fmeta) (void)hipFree(c->pw_fmeta);
     if (c->pw_cand) (void)hipFree(c->pw_cand);
+    for (int i = 0; i < 2; ++i) {
+        if (c->up_pinned[i]) (void)hipHostFree(c->up_pinned[i]);
+        if (c->up_done[i]) (void)hipEventDestroy(c->up_done[i]);
+    }
+    if (c->up_stream) (void)hipStreamDestroy(c->up_stream);
     if (c->pinned) (void)hipHostFree(c->pinned);
     if (c->pinned_ev) (void)hipEventDestroy(c->pinned_ev);
     for (auto& ev : c->ev)
@@ -366,7 +413,9 @@ int mvs_project_csr_stats(mvs_ctx* c, const uint64_t* hashes, int mem_hashes, co
                           int64_t n_samples, int d, int32_t* out, int mem_out, int64_t* sumsq, int64_t* max_abs) {
     if (!c) return fail(MVS_E_INVALID, "ctx is NULL");
     if ((sumsq == nullptr) != (max_abs == nullptr)) return fail(MVS_E_INVALID, "sumsq and max_abs go together");
-    if (sumsq && mem_out != MVS_MEM_DEVICE) return fail(MVS_E_INVALID, "statistics need device-resident sketches");
+    // sumsq lives where the sketches live: device array for device sketches, host array for host sketches
+    int64_t* const sumsq_user = sumsq;
+    DevBuf dsum;
     if (max_abs) *max_abs = 0;
     if (n_samples < 0 || d <= 0) return fail(MVS_E_INVALID, "n_samples=%lld d=%d", (long long)n_samples, d);
     if (!mem_ok(mem_hashes) || !mem_ok(mem_out)) return fail(MVS_E_INVALID, "bad mem flag");
@@ -411,9 +460,12 @@ int mvs_project_csr_stats(mvs_ctx* c, const uint64_t* hashes, int mem_hashes, co
 
     DevBuf dh, dout;
     const uint64_t* d_hashes = hashes;
+    // Host hash lists larger than one staging piece go up through the two-buffer pipeline: while piece k is on the
+    // link, piece k+1 is being copied into pinned memory and the samples that piece k-1 completed are being projected.
+    const bool pipelined = mem_hashes == MVS_MEM_HOST && (size_t)total * 8 > kUploadPiece;
     if (mem_hashes == MVS_MEM_HOST) {
         HIP_TRY(dh.alloc((size_t)total * 8));
-        HIP_TRY(hipMemcpyAsync(dh.p, hashes, (size_t)total * 8, hipMemcpyHostToDevice, c->stream));
+        if (!pipelined) HIP_TRY(hipMemcpyAsync(dh.p, hashes, (size_t)total * 8, hipMemcpyHostToDevice, c->stream));
         d_hashes = (const uint64_t*)dh.p;
     }
     int32_t* d_out = out;
@@ -421,6 +473,10 @@ int mvs_project_csr_stats(mvs_ctx* c, const uint64_t* hashes, int mem_hashes, co
     if (mem_out == MVS_MEM_HOST) {
         HIP_TRY(dout.alloc(out_bytes));
         d_out = (int32_t*)dout.p;
+        if (sumsq) {
+            HIP_TRY(dsum.alloc((size_t)n_samples * 8));
+            sumsq = (int64_t*)dsum.p;
+        }
     }
     const size_t ubytes = n_units * sizeof(mvs::ProjUnit);
     rc = ensure_scratch(c, std::max<size_t>(ubytes, 256));
@@ -441,10 +497,39 @@ int mvs_project_csr_stats(mvs_ctx* c, const uint64_t* hashes, int mem_hashes, co
     if (c->timing) HIP_TRY(hipEventRecord(c->ev[0], c->stream));
     const int nblk = (d + 63) / 64;
     const int bpw = nblk >= 2 ? 2 : 1;
-    mvs::launch_project(c->stream, d_hashes, (const mvs::ProjUnit*)c->scratch, (int64_t)n_units, d, d_out, bpw,
-                        fused ? (unsigned long long*)sumsq : nullptr, fused ? c->d_counter : nullptr);
-    rc = check_kernel("k_project");
-    if (rc) return rc;
+    if (!pipelined) {
+        mvs::launch_project(c->stream, d_hashes, (const mvs::ProjUnit*)c->scratch, (int64_t)n_units, d, d_out, bpw,
+                            fused ? (unsigned long long*)sumsq : nullptr, fused ? c->d_counter : nullptr);
+        rc = check_kernel("k_project");
+        if (rc) return rc;
+    } else {
+        rc = ensure_upload_pipeline(c);
+        if (rc) return rc;
+        // the unit list is in hash order: units [u_done, u_next) are those whose hashes the pieces sent so far cover
+        size_t u_done = 0;
+        const size_t total_bytes = (size_t)total * 8;
+        int piece = 0;
+        for (size_t off = 0; off < total_bytes; off += kUploadPiece, ++piece) {
+            const int b = piece & 1;
+            const size_t len = std::min(kUploadPiece, total_bytes - off);
+            if (piece >= 2) HIP_TRY(hipEventSynchronize(c->up_done[b]));      // staging buffer b is free again
+            parallel_copy(c->up_pinned[b], (const char*)hashes + off, len);
+            HIP_TRY(hipMemcpyAsync((char*)dh.p + off, c->up_pinned[b], len, hipMemcpyHostToDevice, c->up_stream));
+            HIP_TRY(hipEventRecord(c->up_done[b], c->up_stream));
+            const int64_t covered = (int64_t)((off + len) / 8);
+            size_t u_next = u_done;
+            while (u_next < n_units && units[u_next].begin + units[u_next].count <= covered) ++u_next;
+            if (u_next > u_done) {
+                HIP_TRY(hipStreamWaitEvent(c->stream, c->up_done[b], 0));
+                mvs::launch_project(c->stream, d_hashes, (const mvs::ProjUnit*)c->scratch + u_done, (int64_t)(u_next - u_done), d,
+                                    d_out, bpw, fused ? (unsigned long long*)sumsq : nullptr, fused ? c->d_counter : nullptr);
+                rc = check_kernel("k_project");
+                if (rc) return rc;
+                u_done = u_next;
+            }
+        }
+        if (u_done != n_units) return fail(MVS_E_INVALID, "internal: %zu of %zu projection units launched", u_done, n_units);
+    }
     if (c->timing) {
         HIP_TRY(hipEventRecord(c->ev[1], c->stream));
         c->ev_valid[0] = true;
@@ -462,6 +547,7 @@ int mvs_project_csr_stats(mvs_ctx* c, const uint64_t* hashes, int mem_hashes, co
     }
     if (mem_out == MVS_MEM_HOST) {
         HIP_TRY(hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, c->stream));
+        if (sumsq_user) HIP_TRY(hipMemcpyAsync(sumsq_user, sumsq, (size_t)n_samples * 8, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
     } else if (mem_hashes == MVS_MEM_HOST) {
         HIP_TRY(hipStreamSynchronize(c->stream));   // staging buffer is freed on return

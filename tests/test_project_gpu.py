@@ -190,3 +190,24 @@ def test_many_tiny_samples_cross_the_dispatch_limit(ctx):
         bits = (lsr(z, k) & 1) if k else (z & 1)
         want = (2 - 2 * bits.sum(dim=1)).to(torch.int32)
         assert torch.equal(out[:, k], want), k
+
+
+def test_host_input_goes_through_the_upload_pipeline(ctx):
+    """host hash lists beyond one 32 MiB staging piece are uploaded piecewise through two pinned buffers while the
+    samples already complete are projected (several launches): same sketches as from device-resident input, also with
+    a sample that spans pieces and is cut into several units"""
+    import torch
+    sizes = np.full(600, 60_000, dtype=np.int64)
+    sizes[7] = 0
+    sizes[300] = 2_500_000                       # spans the first piece border region and several 65 536-hash units
+    offsets = np.zeros(len(sizes) + 1, dtype=np.int64)
+    offsets[1:] = np.cumsum(sizes)
+    rng = np.random.default_rng(77)
+    hashes = rng.integers(0, synth.MAX_HASH, size=int(offsets[-1]), dtype=np.uint64)
+    assert hashes.nbytes > 2 * (128 << 20)
+    got = ctx.project_csr(hashes, offsets, 1024)                      # host in, host out
+    dev = torch.from_numpy(hashes.view(np.int64)).to("cuda")
+    want = ctx.project_csr(dev, offsets, 1024)                        # device in, host out (single launch)
+    assert np.array_equal(got, want)
+    for s in (0, 7, 300, 599):
+        assert np.array_equal(got[s], orc.project(hashes[offsets[s]:offsets[s + 1]], 1024))
