@@ -96,6 +96,8 @@ int mvs_ctx_kernel_ms(mvs_ctx* ctx, int which, float* ms);
  *   pairwise_block_cells  row-chunk bound of mvs_pairwise_rows, in cells (default 2^40)
  *   sort                  kept-cell sort: 0 (default) by list length, 1 merge sort, 2 radix sort
  *   enable_k3             1: mvs_sketch_set_create codes sets with 127 < max|v| <= 8127 as MVS_LIMBS_K3
+ *   markers               1: roctx ranges named after the entry points around mvs_project_csr / mvs_pairwise_rows /
+ *                         mvs_pairwise_block (rocprofv3 --marker-trace); libroctx64 is bound at run time
  *   pairwise_debug        k-loop / epilogue ablations for profiling; rejected unless the library was built with
  *                         -DMVS_ABLATIONS (make -C csrc ablations): such runs produce garbage by design
  * Unknown names and out-of-range values return MVS_E_INVALID.  None of them changes a result. */

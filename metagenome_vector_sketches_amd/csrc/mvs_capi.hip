@@ -2,6 +2,8 @@
 // kernel orchestration.  No compute happens on the host here and there is no CPU fallback.
 #include <algorithm>
 #include <atomic>
+#include <dlfcn.h>
+
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -109,6 +111,30 @@ namespace {
 
 bool mem_ok(int m) { return m == MVS_MEM_HOST || m == MVS_MEM_DEVICE; }
 
+// rocprofv3 --marker-trace ranges around the ABI's main entry points (option `markers`, off by default).  The roctx
+// library (librocprofiler-sdk-roctx / libroctx64) is bound at run time: without it the ranges are no-ops.
+struct Roctx {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx() {
+        for (const char* name : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4",
+                                 "libroctx64.so", "/opt/rocm/lib/librocprofiler-sdk-roctx.so"}) {
+            if (void* h = dlopen(name, RTLD_NOW | RTLD_LOCAL)) {
+                push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+                pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+                if (push && pop) return;
+                push = nullptr;
+                pop = nullptr;
+            }
+        }
+    }
+};
+struct Range {
+    bool on = false;
+    Range(const mvs_ctx* c, const char* name);
+    ~Range();
+};
+
 // RAII device buffer used for staging host inputs / outputs
 struct DevBuf {
     void* p = nullptr;
@@ -179,6 +205,7 @@ const OptionSpec kOptions[] = {
     {"pairwise_debug", &mvs::Options::pairwise_debug, nullptr, 0, 3},
     {"sort", &mvs::Options::sort, nullptr, 0, 2},
     {"enable_k3", &mvs::Options::enable_k3, nullptr, 0, 1},
+    {"markers", &mvs::Options::markers, nullptr, 0, 1},
     {"pairwise_block_cells", nullptr, &mvs::Options::pairwise_block_cells, 1, (1LL << 62)},
 };
 
@@ -244,6 +271,20 @@ int ensure_upload_pipeline(mvs_ctx* c) {
     }
     c->up_bytes = kUploadPiece;
     return MVS_OK;
+}
+
+const Roctx& roctx() {
+    static const Roctx r;
+    return r;
+}
+Range::Range(const mvs_ctx* c, const char* name) {
+    if (c && c->opt.markers && roctx().push) {
+        roctx().push(name);
+        on = true;
+    }
+}
+Range::~Range() {
+    if (on) roctx().pop();
 }
 
 int check_kernel(const char* what) {
@@ -412,6 +453,7 @@ int mvs_project_csr(mvs_ctx* c, const uint64_t* hashes, int mem_hashes, const in
 int mvs_project_csr_stats(mvs_ctx* c, const uint64_t* hashes, int mem_hashes, const int64_t* offsets,
                           int64_t n_samples, int d, int32_t* out, int mem_out, int64_t* sumsq, int64_t* max_abs) {
     if (!c) return fail(MVS_E_INVALID, "ctx is NULL");
+    const Range range(c, "mvs_project_csr");
     if ((sumsq == nullptr) != (max_abs == nullptr)) return fail(MVS_E_INVALID, "sumsq and max_abs go together");
     // sumsq lives where the sketches live: device array for device sketches, host array for host sketches
     int64_t* const sumsq_user = sumsq;
@@ -1084,6 +1126,7 @@ int mvs_pairwise_rows(mvs_ctx* c, const mvs_sketch_set* s, const double* norms_s
                       int64_t row_begin, int64_t row_end, mvs_cell* cells, int64_t capacity, int mem_cells,
                       int64_t* n_cells) {
     if (!c || !s || !n_cells) return fail(MVS_E_INVALID, "NULL argument");
+    const Range range(c, "mvs_pairwise_rows");
     *n_cells = 0;
     if (!mem_ok(mem_norms) || !mem_ok(mem_cells) || capacity < 0 ||
         (keep_mode != MVS_KEEP_INT32 && keep_mode != MVS_KEEP_INT16))
@@ -1151,6 +1194,7 @@ int mvs_pairwise_block(mvs_ctx* c, const mvs_sketch_set* s, const double* norms_
                        int64_t row_end, int64_t col_begin, int64_t col_end, int flags, mvs_cell* cells,
                        int64_t capacity, int64_t* n_cells) {
     if (!c || !s || !n_cells) return fail(MVS_E_INVALID, "NULL argument");
+    const Range range(c, "mvs_pairwise_block");
     if (capacity < 0 || *n_cells < 0 || (keep_mode != MVS_KEEP_INT32 && keep_mode != MVS_KEEP_INT16) ||
         (flags & ~(MVS_BLOCK_SYMMETRIC | MVS_BLOCK_MIRROR_ALL)) != 0 ||
         ((flags & MVS_BLOCK_SYMMETRIC) && (flags & MVS_BLOCK_MIRROR_ALL)))

@@ -42,6 +42,7 @@ struct Options {
     int pairwise_symmetric = 1;     // 0: compute every tile (no mirroring)
     int pairwise_debug = 0;         // profiling ablations; only honoured by a -DMVS_ABLATIONS build
     int sort = 0;                   // kept-cell sort: 0 by list length, 1 merge, 2 radix
+    int markers = 0;                // 1: roctx ranges around the main entry points (rocprofv3 --marker-trace)
     int enable_k3 = 0;              // 1: mvs_sketch_set_create picks the three-plane Karatsuba code for |v| <= 8127
     double pairwise_block_cells = 1099511627776.0;   // row-chunk bound of mvs_pairwise_rows (2^40 cells)
 };

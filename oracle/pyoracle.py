@@ -167,3 +167,28 @@ def shard_rows(n, num_shards, shard_idx):
 
 def max_threads():
     return load().mvs_oracle_max_threads()
+
+
+def search_scores(db_vectors, db_norms_text, query_sketch, d, j):
+    """Query-by-hashes search as src/jaccard.py scores it (numpy restatement, float64 throughout; the reference
+    holds queries, index and inner products in float32, hence the 1e-5 tolerance of the test that uses this).
+    db_vectors: int sketches [N, d] as stored in vectors.bin; db_norms_text: the norms parsed from vector_norms.txt
+    (:192 `float(line.split()[1])`); query_sketch: int sketch [d] of the query (standalone_projection's output, :98-118).
+      :117      query vector = sketch / sqrt(dimension)
+      :123-124  query_norm = ||query||, then the query is L2-normalised
+      :18-61    the index holds the L2-normalised database vectors (vector / sqrt(d), normalize_L2, IndexFlatIP)
+      :199      jaccard = ip*qn*nn / (nn^2 + qn^2 - ip*qn*nn), reported when > j (:200), best first
+      :184      a query with norm 0 reports nothing
+    Returns [(database index, jaccard)] sorted by descending jaccard (ties: ascending index)."""
+    v = np.asarray(query_sketch, dtype=np.float64) / np.sqrt(float(d))                    # :117
+    qn = float(np.linalg.norm(v))                                                         # :123
+    if qn == 0.0:                                                                         # :184
+        return []
+    x = np.asarray(db_vectors, dtype=np.float64) / np.sqrt(float(d))
+    xn = np.linalg.norm(x, axis=1)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        ip = (x @ v) / (xn * qn)                                                          # normalised inner products
+        nn = np.asarray(db_norms_text, dtype=np.float64)
+        jac = ip * qn * nn / (nn ** 2 + qn ** 2 - ip * qn * nn)                           # :199
+    order = np.argsort(-np.where(np.isnan(jac), -np.inf, jac), kind="stable")
+    return [(int(k), float(jac[k])) for k in order if jac[k] > j]                         # :200

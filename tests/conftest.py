@@ -57,6 +57,22 @@ class Golden:
                 out.append((idx[r], idx[c], int(dot), int(q)))
         return out
 
+    @staticmethod
+    def eigen_blocks(case):
+        """the blocks oracle/eigen_gemm_check.cpp generated for a kat.json eigen_gemm_cases entry (same splitmix64-based
+        formula): -> (block_i int32 [c_i, d], block_j int32 [c_j, d])"""
+        def mix(x):
+            x = (x + 0x9e3779b97f4a7c15) & (2**64 - 1)
+            x = ((x ^ (x >> 30)) * 0xbf58476d1ce4e5b9) & (2**64 - 1)
+            x = ((x ^ (x >> 27)) * 0x94d049bb133111eb) & (2**64 - 1)
+            return x ^ (x >> 31)
+        d, mag, seed = case["d"], case["magnitude"], case["seed"]
+
+        def block(first, count):
+            return np.array([[mix(seed * 1000003 + (first + s) * 65537 + k) % (2 * mag + 1) - mag for k in range(d)]
+                             for s in range(count)], dtype=np.int64).astype(np.int32)
+        return block(0, case["c_i"]), block(1000, case["c_j"])
+
     def norm_lines(self):
         return [l for l in self.norms_txt.split("\n") if l]
 
