@@ -299,12 +299,12 @@ def main():
                                 # NOT a roofline fraction: bit-slicing does 64 sign-accumulations in ~4.4 instructions
                                 "sign_accumulations_per_s_T": k1_intops / (k1 * 1e-3) / 1e12,
                                 "int32_lane_op_peak_T": VALU_INT_PEAK_TOPS},
-        "roofline_pairwise_step": {"kernel": "k_pairwise_mfma (filter) + k_exact_pairs", "bound": "mfma",
+        "roofline_pairwise_step": {"kernel": "k_pairwise_mfma<filter> (128 x 128 ring tiles) + k_exact_pairs", "bound": "mfma",
                                    "workload": "the %d x %d comparison inside the step" % (S, N_total),
                                    "achieved": k2_flops / (k2 * 1e-3) / 1e12, "peak": INT8_MFMA_PEAK_TOPS,
                                    "unit": "TFLOP/s", "frac": k2_flops / (k2 * 1e-3) / 1e12 / INT8_MFMA_PEAK_TOPS,
                                    "two_stage": state["candidates"] > 0, "candidates": state["candidates"],
-                                   "traffic": traffic.get("k_pairwise_mfma")},
+                                   "traffic": traffic.get("k_pairwise_mfma_filter")},
     }
 
     if args.pairwise_samples and world == 1:
@@ -470,21 +470,21 @@ def pairwise_leg(ctx, dev, n, d, nh, reps):
     tiles_share = 0.5 + 0.5 * 256.0 / n            # symmetric schedule: upper triangle + the diagonal tiles
     traffic, src = pmc_traffic("configs[2]") if (n, d) == (100_000, 2048) else ({}, {"file": None, "dropped": "non-default size"})
     t_f = two.get("filter_kernel_ms", two["kernels_ms"])
-    roof = {"kernel": "k_pairwise_mfma<filter> + k_exact_pairs (two-stage comparison)", "bound": "mfma",
+    roof = {"kernel": "k_pairwise_pp<filter> + k_exact_pairs (two-stage comparison)", "bound": "mfma",
             "workload": "configs[2]", "achieved": flops / (two["kernels_ms"] * 1e-3) / 1e12,
             "peak": INT8_MFMA_PEAK_TOPS, "unit": "TFLOP/s",
             "frac": flops / (two["kernels_ms"] * 1e-3) / 1e12 / INT8_MFMA_PEAK_TOPS,
             "algorithmic_flops": flops, "kernel_ms": two["kernels_ms"],
             # matrix-core work actually issued by the filter: ONE int8 pass over the tiles the symmetric schedule
             # computes; the re-check of the candidates runs on the vector ALU
-            "issued": {"kernel": "k_pairwise_mfma<filter>", "kernel_ms": t_f,
+            "issued": {"kernel": "k_pairwise_pp<filter> (ping-pong wave groups, 256 x 256 tiles)", "kernel_ms": t_f,
                        "tflops": flops * tiles_share / (t_f * 1e-3) / 1e12,
                        "frac": flops * tiles_share / (t_f * 1e-3) / 1e12 / INT8_MFMA_PEAK_TOPS},
-            "exact_kernel": {"kernel": "k_pairwise_mfma16 (4 limb-pair passes per cell)", "kernel_ms": ex["kernels_ms"],
+            "exact_kernel": {"kernel": "k_pairwise_pp<exact> (4 limb-pair passes per cell)", "kernel_ms": ex["kernels_ms"],
                              "algorithmic_frac": flops / (ex["kernels_ms"] * 1e-3) / 1e12 / INT8_MFMA_PEAK_TOPS,
                              "issued_frac": 4.0 * flops * (0.5 + 0.5 * 128.0 / n) / (ex["kernels_ms"] * 1e-3) / 1e12 /
                              INT8_MFMA_PEAK_TOPS},
-            "traffic": traffic.get("k_pairwise_mfma_filter"), "traffic_recheck": traffic.get("k_exact_pairs"),
+            "traffic": traffic.get("k_pairwise_pp_filter"), "traffic_recheck": traffic.get("k_exact_pairs"),
             "traffic_source": src,
             "algorithmic_bytes": float(n) * d * limbs + 16.0 * two["kept_cells"]}
     leg = {"cells_per_s": cells_total / (two["wall_ms"] * 1e-3), "cells_per_s_kernels": cells_total / (two["kernels_ms"] * 1e-3),

@@ -89,7 +89,7 @@ def main():
             agg = counters([d])
             kernels = {}
             for (k, c), v in agg.items():
-                if c in ("FETCH_SIZE", "WRITE_SIZE"):
+                if c in ("FETCH_SIZE", "WRITE_SIZE") and k.startswith("k_"):
                     kernels.setdefault(k, {})[c + "_KiB_raw"] = sum(v) / len(v)
                     kernels[k]["launches_" + c] = len(v)
             for k, e in kernels.items():
@@ -98,8 +98,34 @@ def main():
         with open(args[1], "w") as f:
             json.dump(out, f, indent=1, sort_keys=True)
         return
+    if args and args[0] == "--derived":
+        # --derived <pmc dir> <stats dir>: per library kernel the quantities the roofline discussion uses
+        agg = {kc: sum(v) / len(v) for kc, v in counters([args[1]]).items()}
+        dur = {k: sum(v) / len(v) for k, v in kernel_stats(args[2]).items()}
+        for k in sorted({k for k, _ in agg if k.startswith("k_")}):
+            g = agg.get((k, "GRBM_GUI_ACTIVE"))
+            if not g or k not in dur:
+                continue
+            cyc = g / 8.0                                     # the counter sums the 8 XCDs
+            line = "%-26s avg %.4f ms (kernel-trace pass)  clock %.2f GHz" % (k, dur[k], cyc / (dur[k] * 1e-3) / 1e9)
+            busy = agg.get((k, "SQ_VALU_MFMA_BUSY_CYCLES"), 0.0)
+            if busy:
+                line += "  MFMA busy %.3f of SIMD cycles (%.4g / (%.4g x 1024))" % (busy / (cyc * 1024.0), busy, cyc)
+            hit, miss = agg.get((k, "TCC_HIT_sum")), agg.get((k, "TCC_MISS_sum"))
+            if hit is not None and miss is not None and hit + miss > 0:
+                line += "  L2 hit %.3f" % (hit / (hit + miss))
+            f, w = agg.get((k, "FETCH_SIZE")), agg.get((k, "WRITE_SIZE"))
+            if f is not None and w is not None:
+                b = 2048.0 * f + 1024.0 * w
+                line += "  HBM-side bytes %.4g (%.2f TB/s)" % (b, b / (dur[k] * 1e-3) / 1e12)
+            wc, wa = agg.get((k, "SQ_WAVE_CYCLES")), agg.get((k, "SQ_WAIT_ANY"))
+            if wc and wa is not None:
+                line += "  waiting %.2f of wave cycles" % (wa / wc)
+            print(line)
+        return
     for (k, c), v in sorted(counters(args).items()):
-        print("%s %s n=%d mean=%.6g" % (k, c, len(v), sum(v) / len(v)))
+        if k.startswith("k_"):
+            print("%s %s n=%d mean=%.6g" % (k, c, len(v), sum(v) / len(v)))
 
 
 if __name__ == "__main__":
