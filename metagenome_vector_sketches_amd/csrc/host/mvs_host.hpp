@@ -401,7 +401,7 @@ inline ShardStats write_shard(const std::string& folder, const mvs_cell* cells, 
         std::string error;
     };
     std::vector<Part> parts(threads);
-    auto work = [&](unsigned t) {
+    auto encode_part = [&](unsigned t) {
         Part& part = parts[t];
         std::ostringstream os(std::ios::binary);
         const size_t r0 = n_rows * t / threads, r1 = n_rows * (t + 1) / threads;
@@ -434,6 +434,17 @@ inline ShardStats write_shard(const std::string& folder, const mvs_cell* cells, 
             }
         }
         part.bytes = os.str();
+    };
+    // an exception inside a worker (the codec's runtime_error, bad_alloc) travels through Part::error to the caller
+    // instead of ending the process in std::terminate
+    auto work = [&](unsigned t) {
+        try {
+            encode_part(t);
+        } catch (const std::exception& e) {
+            parts[t].error = std::string("write_shard: ") + e.what();
+        } catch (...) {
+            parts[t].error = "write_shard: unknown error in an encoder thread";
+        }
     };
     if (threads == 1) {
         work(0);

@@ -167,3 +167,25 @@ def test_empty_and_missing_shards(tmp_path, gold):
     res = rpc.query(str(m), str(db), str(q))
     assert res[0]["id"] == "a" and list(res[0]["neighbor_ids"]) == ["a", "b"]
     assert len(res) == 2 and list(res[1].get("neighbor_ids", [])) == []
+
+
+def test_reader_and_codec_under_address_sanitizer(toy_index, gold, tmp_path):
+    """`make asan`: the device-free host tools built with -fsanitize=address,undefined; the codec self-test (codec round
+    trips, shard writer on 1 and 7 threads, hash text parser, CSR cache) and a query of each kind must run clean"""
+    d, db, idx, by_row = toy_index
+    r = run("make", "-s", "-C", os.path.join(PKG, "csrc"), "asan")
+    assert r.returncode == 0, r.stderr
+    asan = os.path.join(BIN, "asan")
+    r = run(os.path.join(asan, "mvs_codec_selftest"))
+    assert r.returncode == 0 and "mvs_codec_selftest ok" in r.stdout, r.stderr
+    qf = tmp_path / "q.txt"
+    qf.write_text("DRR000821\n10\nNOT_THERE\n")
+    r = run(os.path.join(asan, "query_pc_mat"), "--matrix", idx[3], "--db", db, "--query_file", str(qf), "--top", "5")
+    assert r.returncode == 0 and "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr
+    rf, cf = tmp_path / "r.txt", tmp_path / "c.txt"
+    rf.write_text("\n".join(gold.names[i] for i in (6, 20, 60)) + "\n")
+    cf.write_text("\n".join(gold.names[i] for i in (6, 10, 22)) + "\n")
+    r = run(os.path.join(asan, "query_pc_mat"), "--matrix", idx[1], "--db", db, "--row_file", str(rf), "--col_file", str(cf),
+            "--write_to_file", str(tmp_path / "s.npy"), "--batch_size", "2")
+    assert r.returncode == 0 and "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr
+    assert np.load(str(tmp_path / "s.npy")).shape == (3, 3)
