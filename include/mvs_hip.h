@@ -96,6 +96,9 @@ int mvs_ctx_kernel_ms(mvs_ctx* ctx, int which, float* ms);
  *   pairwise_block_cells  row-chunk bound of mvs_pairwise_rows, in cells (default 2^40)
  *   sort                  kept-cell sort: 0 (default) by list length, 1 merge sort, 2 radix sort
  *   enable_k3             1: mvs_sketch_set_create codes sets with 127 < max|v| <= 8127 as MVS_LIMBS_K3
+ *   project_variant       projection kernel: 0 (default) by dimension -- 14 = four 64-dim blocks per wave sharing the
+ *                         first splitmix64 round when d is a multiple of 256 (>= 512), else 2 or 1 blocks per wave;
+ *                         1 / 2 / 12 / 14 force a variant
  *   markers               1: roctx ranges named after the entry points around mvs_project_csr / mvs_pairwise_rows /
  *                         mvs_pairwise_block (rocprofv3 --marker-trace); libroctx64 is bound at run time
  *   pairwise_debug        k-loop / epilogue ablations for profiling; rejected unless the library was built with

@@ -42,6 +42,8 @@ struct Options {
     int pairwise_symmetric = 1;     // 0: compute every tile (no mirroring)
     int pairwise_debug = 0;         // profiling ablations; only honoured by a -DMVS_ABLATIONS build
     int sort = 0;                   // kept-cell sort: 0 by list length, 1 merge, 2 radix
+    int project_variant = 0;        // projection kernel: 0 by dimension; 1 / 2 blocks per wave; 12 / 14 = 2 / 4 blocks per
+                                    // wave sharing the first splitmix64 round
     int markers = 0;                // 1: roctx ranges around the main entry points (rocprofv3 --marker-trace)
     int enable_k3 = 0;              // 1: mvs_sketch_set_create picks the three-plane Karatsuba code for |v| <= 8127
     double pairwise_block_cells = 1099511627776.0;   // row-chunk bound of mvs_pairwise_rows (2^40 cells)
@@ -94,7 +96,7 @@ struct CoarseRow {
 
 // d_sumsq / d_max_abs non-NULL: fused statistics (all samples must be single units; d_sumsq zeroed by the caller)
 int launch_project(hipStream_t stream, const uint64_t* d_hashes, const ProjUnit* d_units, int64_t n_units,
-                   int d, int32_t* d_out, int bpw, unsigned long long* d_sumsq, unsigned long long* d_max_abs);
+                   int d, int32_t* d_out, int variant, unsigned long long* d_sumsq, unsigned long long* d_max_abs);
 int launch_sumsq(hipStream_t stream, const int32_t* d_sk, int64_t n, int d, int64_t* d_out);
 int launch_saturate_i16(hipStream_t stream, const int32_t* d_in, int64_t n, int16_t* d_out);
 int launch_stats(hipStream_t stream, const int32_t* d_sk, int64_t n, int d, int64_t* d_sumsq,

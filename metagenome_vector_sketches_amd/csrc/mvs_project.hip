@@ -108,6 +108,55 @@ struct BatchGen {
     }
 };
 
+// The same values for a wave that owns BPW CONSECUTIVE blocks, with the part of the first splitmix64 round that the
+// blocks share computed once per hash.  x_b = x_0 + 64 b differs from x_0 only below bit 30 unless the addition carries
+// out of bit 29; without that carry  x_b >> 30 == x_0 >> 30 =: t  and the high word of x_b equals that of x_0, so
+//     z_b = x_b ^ (x_b >> 30)  has  z_b.hi = x_0.hi ^ t.hi  (shared)  and  z_b.lo = (x_0.lo + 64 b) ^ t.lo ,
+//     z_b * C1 mod 2^64 = z_b.lo * C1.lo  +  ((z_b.lo * C1.hi + z_b.hi * C1.lo) << 32)     with z_b.hi * C1.lo shared.
+// Per block that saves the 64-bit add, the 64-bit shift, one xor and one of the four 32-bit multiplies of the round
+// (9 quarter-rate instructions per hash at BPW = 4).  The carry case -- bits 8..29 of x_0 all ones, one hash in 4 million
+// -- is detected per batch by hazard() and such a batch goes through BatchGen (the wave-uniform branch costs nothing
+// when it is not taken), so every value is exact.
+constexpr uint32_t kC1Lo = 0x1ce4e5b9u, kC1Hi = 0xbf58476du;
+
+template <int BPW>
+struct BatchGenShared {
+    const uint64_t (&h)[8];
+    const uint64_t cb0;          // 64 * first block + golden
+    int j = 0;
+    __device__ __forceinline__ BatchGenShared(const uint64_t (&h_)[8], uint64_t cb0_) : h(h_), cb0(cb0_) {}
+    __device__ __forceinline__ void next(uint32_t (&lo)[BPW], uint32_t (&hi)[BPW]) {
+        const uint64_t x0 = h[j++] + cb0;
+        const uint64_t t = x0 >> 30;
+        const uint32_t x0l = (uint32_t)x0, tl = (uint32_t)t;
+        const uint32_t zh = (uint32_t)(x0 >> 32) ^ (uint32_t)(t >> 32);
+        const uint32_t p = zh * kC1Lo;
+#pragma unroll
+        for (int b = 0; b < BPW; ++b) {
+            const uint32_t zl = (x0l + 64u * (uint32_t)b) ^ tl;
+            const uint64_t m = (uint64_t)zl * (uint64_t)kC1Lo;
+            const uint32_t whi = (uint32_t)(m >> 32) + zl * kC1Hi + p;
+            uint64_t w = ((uint64_t)whi << 32) | (uint64_t)(uint32_t)m;
+            w = (w ^ (w >> 27)) * 0x94d049bb133111ebULL;
+            w ^= w >> 31;
+            lo[b] = (uint32_t)w;
+            hi[b] = (uint32_t)(w >> 32);
+        }
+    }
+};
+
+// true if some hash of the batch could carry out of bit 29 when 64 * b (b < 4) is added to h + cb0
+__device__ __forceinline__ bool hazard(const uint64_t (&h)[8], uint64_t cb0) {
+    uint32_t least = 0xffffffffu;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const uint32_t xl = (uint32_t)h[j] + (uint32_t)cb0;
+        const uint32_t miss = ~xl & 0x3fffff00u;                 // zero <=> bits 8..29 are all ones
+        least = miss < least ? miss : least;
+    }
+    return __any(least == 0u) != 0;
+}
+
 // load the batch that starts at hash index `pos` of the unit; indices are clamped into the unit so the
 // prefetch of a batch that does not exist (or the tail of a partial one) stays in bounds
 template <bool CLAMP>
@@ -173,7 +222,7 @@ __device__ __forceinline__ int32_t reduce_counts(const uint32_t (&lo_in)[kLV], c
 // STATS: also accumulate each sample's exact sum of squares (int64 atomics, one per wave) and the largest |v|
 // of the launch -- valid only when every sample is a single unit (the host checks), because a multi-unit
 // sample's entries are only final once all its units have been added.
-template <int BPW, bool STATS>
+template <int BPW, bool STATS, bool SHARED = false>
 __global__ __launch_bounds__(256) void k_project(const uint64_t* __restrict__ hashes,
                                                  const ProjUnit* __restrict__ units, long long n_units, int ny,
                                                  int d, int nblk, int32_t* __restrict__ out,
@@ -216,8 +265,13 @@ __global__ __launch_bounds__(256) void k_project(const uint64_t* __restrict__ ha
 #pragma unroll
             for (int sb = 0; sb < 4; ++sb) {
                 load_batch<false>(hn, base, (b + sb + 1) << 9, lane, last);
-                BatchGen<BPW, false> g(hv, cb, 0);
-                absorb<3, BPW>(s, g, c8lo[sb], c8hi[sb]);
+                if (SHARED && !hazard(hv, cb[0])) {
+                    BatchGenShared<BPW> g(hv, cb[0]);
+                    absorb<3, BPW>(s, g, c8lo[sb], c8hi[sb]);
+                } else {
+                    BatchGen<BPW, false> g(hv, cb, 0);
+                    absorb<3, BPW>(s, g, c8lo[sb], c8hi[sb]);
+                }
 #pragma unroll
                 for (int j = 0; j < 8; ++j) hv[j] = hn[j];
             }
@@ -381,30 +435,38 @@ __global__ __launch_bounds__(256) void k_saturate_i16(const int32_t* __restrict_
 
 }  // namespace
 
+// variant: 1 / 2 = that many 64-dim blocks per wave, every block hashed on its own; 12 / 14 = two / four blocks per wave
+// with the shared first splitmix64 round (BatchGenShared)
+template <int BPW, bool SHARED>
+static void launch_project_as(hipStream_t stream, unsigned grid, bool stats, const uint64_t* d_hashes, const ProjUnit* d_units,
+                              long long nu, int ny, int d, int nblk, int32_t* d_out, unsigned long long* d_sumsq,
+                              unsigned long long* d_max_abs) {
+    if (stats)
+        hipLaunchKernelGGL((k_project<BPW, true, SHARED>), dim3(grid), dim3(256), 0, stream, d_hashes, d_units, nu, ny, d, nblk,
+                           d_out, d_sumsq, d_max_abs);
+    else
+        hipLaunchKernelGGL((k_project<BPW, false, SHARED>), dim3(grid), dim3(256), 0, stream, d_hashes, d_units, nu, ny, d, nblk,
+                           d_out, d_sumsq, d_max_abs);
+}
+
 int launch_project(hipStream_t stream, const uint64_t* d_hashes, const ProjUnit* d_units, int64_t n_units,
-                   int d, int32_t* d_out, int bpw, unsigned long long* d_sumsq, unsigned long long* d_max_abs) {
+                   int d, int32_t* d_out, int variant, unsigned long long* d_sumsq, unsigned long long* d_max_abs) {
     if (n_units == 0) return 0;
     const int nblk = (d + 63) / 64;
-    // grid.x is limited to 2^31-1, plenty; launch in slabs anyway to keep blockIdx.x an int
-    const int ny = bpw == 1 ? (nblk + 3) / 4 : (nblk + 7) / 8;
+    const int bpw = variant % 10;
+    const int ny = (nblk + 4 * bpw - 1) / (4 * bpw);
     // a dispatch holds at most 2^32 work-items per dimension: slabs of at most ~2^32/256 workgroups
     const int64_t kMaxUnits = ((int64_t)(0xffffffffLL / 256) / (8 * ny) - 1) * 8;
     for (int64_t u0 = 0; u0 < n_units; u0 += kMaxUnits) {
         const int64_t nu = n_units - u0 < kMaxUnits ? n_units - u0 : kMaxUnits;
         const unsigned grid = (unsigned)(((nu + 7) / 8) * 8 * ny);
         const bool stats = d_sumsq != nullptr;
-        if (bpw == 1 && !stats)
-            hipLaunchKernelGGL((k_project<1, false>), dim3(grid), dim3(256), 0, stream, d_hashes, d_units + u0,
-                               (long long)nu, ny, d, nblk, d_out, d_sumsq, d_max_abs);
-        else if (bpw == 1)
-            hipLaunchKernelGGL((k_project<1, true>), dim3(grid), dim3(256), 0, stream, d_hashes, d_units + u0,
-                               (long long)nu, ny, d, nblk, d_out, d_sumsq, d_max_abs);
-        else if (!stats)
-            hipLaunchKernelGGL((k_project<2, false>), dim3(grid), dim3(256), 0, stream, d_hashes, d_units + u0,
-                               (long long)nu, ny, d, nblk, d_out, d_sumsq, d_max_abs);
-        else
-            hipLaunchKernelGGL((k_project<2, true>), dim3(grid), dim3(256), 0, stream, d_hashes, d_units + u0,
-                               (long long)nu, ny, d, nblk, d_out, d_sumsq, d_max_abs);
+        switch (variant) {
+            case 1: launch_project_as<1, false>(stream, grid, stats, d_hashes, d_units + u0, (long long)nu, ny, d, nblk, d_out, d_sumsq, d_max_abs); break;
+            case 12: launch_project_as<2, true>(stream, grid, stats, d_hashes, d_units + u0, (long long)nu, ny, d, nblk, d_out, d_sumsq, d_max_abs); break;
+            case 14: launch_project_as<4, true>(stream, grid, stats, d_hashes, d_units + u0, (long long)nu, ny, d, nblk, d_out, d_sumsq, d_max_abs); break;
+            default: launch_project_as<2, false>(stream, grid, stats, d_hashes, d_units + u0, (long long)nu, ny, d, nblk, d_out, d_sumsq, d_max_abs); break;
+        }
     }
     return 0;
 }

@@ -211,3 +211,34 @@ def test_host_input_goes_through_the_upload_pipeline(ctx):
     assert np.array_equal(got, want)
     for s in (0, 7, 300, 599):
         assert np.array_equal(got[s], orc.project(hashes[offsets[s]:offsets[s + 1]], 1024))
+
+
+@pytest.mark.parametrize("d", [2048, 512, 300])
+def test_shared_round_variants_and_their_carry_hazard(ctx, d):
+    """project_variant 14 / 12 compute the part of the first splitmix64 round that consecutive blocks share once per
+    hash; that is only valid while adding 64*b does not carry out of bit 29 of h + golden + 64*b0, so batches holding
+    such a hash (bits 8..29 all ones: one in 4 million) take the general path.  Hashes built to sit on that edge for
+    every block group, mixed into ordinary ones: every variant must give the oracle's sketch."""
+    rng = np.random.default_rng(5)
+    golden, nblk = 0x9e3779b97f4a7c15, (d + 63) // 64
+    edge = []
+    for b0 in range(0, nblk):
+        for low8 in (0, 63, 64, 65, 128, 200, 255):
+            target = 0x3fffff00 | low8 | (int(rng.integers(0, 4)) << 30)
+            lo = (target - ((golden + 64 * b0) & 0xffffffff)) & 0xffffffff
+            edge.append((int(rng.integers(0, 2**31)) << 32) | lo)
+    sizes = [len(edge) + 3000, 700, 0, 66000, 5]
+    offsets = np.zeros(len(sizes) + 1, dtype=np.int64)
+    offsets[1:] = np.cumsum(sizes)
+    hashes = rng.integers(0, 2**63, size=int(offsets[-1]), dtype=np.uint64)
+    pos = rng.permutation(sizes[0])[:len(edge)]
+    hashes[pos] = np.array(edge, dtype=np.uint64)
+    hashes[offsets[3] + 1000:offsets[3] + 1000 + len(edge)] = np.array(edge, dtype=np.uint64)
+    want = orc.project_csr(hashes, offsets, d, threads=8, fast=True)
+    old = ctx.get_option("project_variant")
+    try:
+        for v in (14, 12, 2, 1, 0):
+            ctx.set_option("project_variant", v)
+            assert np.array_equal(ctx.project_csr(hashes, offsets, d), want), v
+    finally:
+        ctx.set_option("project_variant", old)
