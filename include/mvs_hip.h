@@ -89,7 +89,8 @@ int mvs_ctx_kernel_ms(mvs_ctx* ctx, int which, float* ms);
  *                         2^22 cells of a two-limb set; 2 two-stage whenever the set has two limbs (tests)
  *   filter_variant        kernel of the one-pass filter: -1 (default) by block size, 8 = ping-pong wave groups on
  *                         256 x 256 tiles (7/9/10 its variants), 0 = 128 x 128 ring, 1 = 256 x 256 ring, 3/5/6 other rings
- *   exact_variant         re-check kernel: 0 (default) 64 pairs per wave round, 1 quarter wave per pair, 2 16 per round
+ *   exact_variant         re-check kernel: 3 (default) tree reduction over rounds of 64 pairs, 0 one shuffle butterfly per
+ *                         pair, 1 quarter wave per pair, 2 16 pairs per round
  *   pairwise_variant      exact kernel: 8 (default) ping-pong 16x16x64 MFMA for two limbs (7/9 its variants), 6 the ring
  *                         kernel on the same shape, 0-5 32x32x32 tile / ring variants
  *   pairwise_symmetric    1 (default) skip tiles below the diagonal and mirror; 0 compute every tile

@@ -199,7 +199,7 @@ struct OptionSpec {
 const OptionSpec kOptions[] = {
     {"pairwise_filter", &mvs::Options::pairwise_filter, nullptr, 0, 2},
     {"filter_variant", &mvs::Options::filter_variant, nullptr, -1, 99},
-    {"exact_variant", &mvs::Options::exact_variant, nullptr, 0, 2},
+    {"exact_variant", &mvs::Options::exact_variant, nullptr, 0, 3},
     {"pairwise_variant", &mvs::Options::pairwise_variant, nullptr, 0, 9},
     {"pairwise_symmetric", &mvs::Options::pairwise_symmetric, nullptr, 0, 1},
     {"pairwise_debug", &mvs::Options::pairwise_debug, nullptr, 0, 3},

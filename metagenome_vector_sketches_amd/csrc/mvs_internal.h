@@ -36,7 +36,8 @@ struct Options {
     int pairwise_filter = 1;        // 0 exact kernel on every cell; 1 two-stage for blocks >= 2^22 cells; 2 always two-stage
     int filter_variant = -1;        // -1 by block size; 0 128x128 ring; 1 256x256 ring; 8 256x256 ping-pong (7/9/10: its
                                     // variants); 3/5/6 other ring shapes / depths
-    int exact_variant = 0;          // re-check kernel: 0 = 64 pairs per wave round, 1 quarter wave per pair, 2 = 16 per round
+    int exact_variant = 3;          // re-check kernel: 3 = tree reduction over a round of 64 pairs (default); 0 = 64 pairs per
+                                    // round with a shuffle butterfly per pair, 1 quarter wave per pair, 2 = 16 per round
     int pairwise_variant = 8;       // exact kernel, two limbs: 8 = ping-pong 16x16x64 (7/9: its variants), 6 = 16x16x64 ring;
                                     // 0-5 = 32x32x32 tile / ring variants (the only ones for other limb codes)
     int pairwise_symmetric = 1;     // 0: compute every tile (no mirroring)

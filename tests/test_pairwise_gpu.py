@@ -614,3 +614,18 @@ def test_dots_match_the_references_eigen_product(ctx, gold):
             got = ctx.pairwise_dots(ss, 0, ci, ci, ci + cj, algo=algo)
             assert np.array_equal(got, want), (case["d"], case["magnitude"], algo, ss.limbs)
         ss.close()
+
+
+@pytest.mark.parametrize("ev", [0, 1, 2, 3])
+def test_recheck_kernel_variants(ctx, ev):
+    """every re-check kernel (tree reduction = default, one butterfly per pair, quarter wave per pair, 16 per round) on a
+    round structure with a partial last round: the oracle's cells"""
+    sk = synth.make_sketches_numpy(777, 1000, 3000, seed=21, cluster=8)
+    n2 = _n2_from_sketches(sk)
+    ss = ctx.sketch_set(sk)
+    ctx.set_option("pairwise_filter", 2)
+    ctx.set_option("exact_variant", ev)
+    got, _ = ctx.pairwise_rows(ss, n2)
+    assert ctx.pairwise_candidates() > 777 * 4
+    assert _cells_tuple(got) == _oracle_sorted(sk, n2, chunk=192)
+    ss.close()
