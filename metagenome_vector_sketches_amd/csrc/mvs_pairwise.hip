@@ -822,46 +822,53 @@ __device__ __forceinline__ void epilogue_filter16(const PairwiseArgs& a, v4i (&a
     const bool straddle = a.symmetric && j0 < i0 + TM && j0 + TN > i0;
     const int delta = (int)(j0 - i0);                                  // col - row = col_l - row_l + delta
     // one 32-bit mask per lane and 16-column group: bit t*4 + r <=> row wm*128 + t*16 + fq*4 + r passes
-    unsigned* masks = reinterpret_cast<unsigned*>(smem + (TM + TN) * 16) + wave * 256 + lane;
-    unsigned mine = 0;
+    // the four column groups' constants stay in registers, the row constants are read once per row pair (rows outer,
+    // column groups inner: a quarter of the LDS reads of the column-major order)
+    unsigned m32[4] = {0u, 0u, 0u, 0u};
+    v2f wj[4], sj[4], npj[4], nbj[4];
+    int row_max[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int col_l = wn * 64 + u * 16 + fr;
+        const int64_t col = j0 + col_l;
+        const float4 mj = fcol[col_l];
+        const float bj = mj.z + mj.w;
+        wj[u] = v2f{mj.y, mj.y};
+        sj[u] = v2f{mj.x, mj.x};
+        npj[u] = v2f{-mj.w, -mj.w};
+        nbj[u] = v2f{-bj, -bj};
+        const bool in_square = a.symmetric && col >= a.row_begin && col < a.row_end;
+        row_max[u] = (straddle && in_square) ? col_l + delta : 0x7fffffff;   // col >= row  <=>  row_l <= col_l + delta
+    }
     auto sweep = [&](auto tri) {
         constexpr bool TRI = decltype(tri)::value;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int col_l = wn * 64 + u * 16 + fr;
-            const int64_t col = j0 + col_l;
-            const float4 mj = fcol[col_l];
-            const float bj = mj.z + mj.w;
-            const v2f wj = {mj.y, mj.y}, sj = {mj.x, mj.x}, npj = {-mj.w, -mj.w}, nbj = {-bj, -bj};
-            const bool in_square = a.symmetric && col >= a.row_begin && col < a.row_end;
-            const int row_max = (TRI && in_square) ? col_l + delta : 0x7fffffff;   // col >= row  <=>  row_l <= col_l + delta
-            unsigned m32 = 0;
+        for (int t = 0; t < 8; ++t) {
 #pragma unroll
-            for (int t = 0; t < 8; ++t) {
+            for (int r = 0; r < 4; r += 2) {
+                const int row_l = wm * 128 + t * 16 + fq * 4 + r;              // even: rows row_l, row_l + 1
+                const v4f q0 = *reinterpret_cast<const v4f*>(frow + (row_l >> 1) * 8);
+                const v4f q1 = *reinterpret_cast<const v4f*>(frow + (row_l >> 1) * 8 + 4);
 #pragma unroll
-                for (int r = 0; r < 4; r += 2) {
-                    const int row_l = wm * 128 + t * 16 + fq * 4 + r;              // even: rows row_l, row_l + 1
-                    const v4f q0 = *reinterpret_cast<const v4f*>(frow + (row_l >> 1) * 8);
-                    const v4f q1 = *reinterpret_cast<const v4f*>(frow + (row_l >> 1) * 8 + 4);
-                    v2f rhs = v2f{q0[0], q0[1]} * wj;
-                    rhs = __builtin_elementwise_fma(v2f{q0[2], q0[3]}, sj, rhs);
-                    rhs = __builtin_elementwise_fma(v2f{q1[0], q1[1]}, npj, rhs);
-                    rhs = __builtin_elementwise_fma(v2f{q1[2], q1[3]}, nbj, rhs);
+                for (int u = 0; u < 4; ++u) {
+                    v2f rhs = v2f{q0[0], q0[1]} * wj[u];
+                    rhs = __builtin_elementwise_fma(v2f{q0[2], q0[3]}, sj[u], rhs);
+                    rhs = __builtin_elementwise_fma(v2f{q1[0], q1[1]}, npj[u], rhs);
+                    rhs = __builtin_elementwise_fma(v2f{q1[2], q1[3]}, nbj[u], rhs);
                     bool c0 = (float)acc[t][u][r] > rhs[0];
                     bool c1 = (float)acc[t][u][r + 1] > rhs[1];
                     if (TRI) {
-                        c0 = c0 && row_l <= row_max;
-                        c1 = c1 && row_l < row_max;
+                        c0 = c0 && row_l <= row_max[u];
+                        c1 = c1 && row_l < row_max[u];
                     }
-                    m32 |= (c0 ? 1u << (t * 4 + r) : 0u) | (c1 ? 2u << (t * 4 + r) : 0u);
+                    m32[u] |= (c0 ? 1u << (t * 4 + r) : 0u) | (c1 ? 2u << (t * 4 + r) : 0u);
                 }
             }
-            masks[u * 64] = m32;
-            mine += (unsigned)__popc(m32);
         }
     };
     if (straddle) sweep(std::true_type{});
     else sweep(std::false_type{});
+    const unsigned mine = (unsigned)(__popc(m32[0]) + __popc(m32[1]) + __popc(m32[2]) + __popc(m32[3]));
     if (__ballot(mine != 0) == 0ULL) return;               // the common case: nothing in this wave passes
     unsigned incl = mine;                                   // inclusive prefix sum over the lanes
 #pragma unroll
@@ -882,7 +889,7 @@ __device__ __forceinline__ void epilogue_filter16(const PairwiseArgs& a, v4i (&a
         const int64_t col = j0 + col_l;
         const bool in_square = a.symmetric && col >= a.row_begin && col < a.row_end;
         const int cd = col_l + delta;
-        unsigned m = masks[u * 64];                          // this lane's own word: no barrier needed
+        unsigned m = m32[u];
         while (m) {
             const int b = __ffs((int)m) - 1;
             m &= m - 1;
