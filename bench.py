@@ -30,9 +30,9 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 INT8_MFMA_PEAK_TOPS = 5000.0   # dense int8 MFMA = 2x bf16 = ~5 POP/s
 VALU_INT_PEAK_TOPS = 78.6      # 256 CU x 4 SIMD-32 x 32 lanes x 2.4 GHz int32 lane-ops/s (MI355X_MICROARCH.md)
 VALU_ISSUE_PEAK_GIPS = 1228.8  # wave64 VALU instructions/s: 1024 SIMDs x 2.4 GHz / 2 cycles per instruction
-K1_VALU_PER_HASH_BLOCK = 22.9  # VALU instructions per (hash, 64-dim block) and lane in k_project: 16 splitmix64 +
-                               # 4.4 bit-sliced counting + loop/prefetch share; matches SQ_INSTS_VALU of the PMC pass
-                               # (profiles/r01_pmc_summary_final.txt: 5.957e9 per launch = 22.9 x 1.6e10 / 64)
+K1_VALU_PER_HASH_BLOCK = 22.4  # VALU instructions per (hash, 64-dim block) and lane in k_project (four blocks per wave
+                               # sharing the first splitmix64 round): SQ_INSTS_VALU of the PMC pass,
+                               # profiles/r02_c1_pmc_summary.txt: 5.596e9 per launch = 22.4 x 1.6e10 / 64 (22.9 in round 1)
 
 
 def source_sha():

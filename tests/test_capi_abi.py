@@ -57,3 +57,25 @@ def test_product_package_never_imports_oracle():
                 with open(os.path.join(dirpath, fn)) as f:
                     src = f.read()
                 assert "pyoracle" not in src and "mvs_oracle" not in src and "libmvs_oracle" not in src, fn
+
+
+def test_library_reads_the_environment_only_when_a_context_is_created():
+    """tuning switches live in the context (mvs_ctx_set_option); below the C ABI exactly one getenv exists, in the
+    function that seeds a new context's options, and the k-loop ablations are not part of the product library"""
+    csrc = os.path.join(ROOT, "metagenome_vector_sketches_amd", "csrc")
+    hits = []
+    for fn in sorted(os.listdir(csrc)):
+        if fn.endswith((".hip", ".h")):
+            with open(os.path.join(csrc, fn)) as f:
+                for i, line in enumerate(f, 1):
+                    if "getenv(" in line:
+                        hits.append((fn, i, line.strip()))
+    assert len(hits) == 1 and hits[0][0] == "mvs_capi.hip", hits
+    with open(os.path.join(csrc, "mvs_capi.hip")) as f:
+        text = f.read()
+    assert text.index("void options_from_env") < text.index("getenv(") < text.index("int check_kernel")
+    lib = _capi.load_library()
+    assert not hasattr(lib, "mvs_ctx_debug")                       # no debug entry points
+    import subprocess
+    syms = subprocess.run(["nm", "-D", "--defined-only", _capi.LIB_PATH], capture_output=True, text=True).stdout
+    assert "mvs_ctx_set_option" in syms and "mvs_comm_create" in syms and "mvs_allgather_planes" in syms
