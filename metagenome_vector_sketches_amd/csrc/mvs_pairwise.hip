@@ -840,28 +840,50 @@ __device__ __forceinline__ void epilogue_filter16(const PairwiseArgs& a, v4i (&a
         const bool in_square = a.symmetric && col >= a.row_begin && col < a.row_end;
         row_max[u] = (straddle && in_square) ? col_l + delta : 0x7fffffff;   // col >= row  <=>  row_l <= col_l + delta
     }
+    // Candidates are rare (1.5e-5 of the cells), so the sweep first only asks "does any lane pass in this row pair"
+    // -- compares into scalar registers, OR-ed on the scalar unit, four independent chains -- and builds the
+    // per-lane masks just for the row pairs that say yes.
     auto sweep = [&](auto tri) {
         constexpr bool TRI = decltype(tri)::value;
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
 #pragma unroll
             for (int r = 0; r < 4; r += 2) {
-                const int row_l = wm * 128 + t * 16 + fq * 4 + r;              // even: rows row_l, row_l + 1
+                const int row_l = wm * 128 + t * 16 + fq * 4 + r;
                 const v4f q0 = *reinterpret_cast<const v4f*>(frow + (row_l >> 1) * 8);
                 const v4f q1 = *reinterpret_cast<const v4f*>(frow + (row_l >> 1) * 8 + 4);
+                const v2f qs = v2f{q0[0], q0[1]}, qw = v2f{q0[2], q0[3]}, qa = v2f{q1[0], q1[1]}, qp = v2f{q1[2], q1[3]};
+                v2f rhs[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) rhs[u] = qs * wj[u];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) rhs[u] = __builtin_elementwise_fma(qw, sj[u], rhs[u]);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) rhs[u] = __builtin_elementwise_fma(qa, npj[u], rhs[u]);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) rhs[u] = __builtin_elementwise_fma(qp, nbj[u], rhs[u]);
+                unsigned long long any = 0ULL;
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    v2f rhs = v2f{q0[0], q0[1]} * wj[u];
-                    rhs = __builtin_elementwise_fma(v2f{q0[2], q0[3]}, sj[u], rhs);
-                    rhs = __builtin_elementwise_fma(v2f{q1[0], q1[1]}, npj[u], rhs);
-                    rhs = __builtin_elementwise_fma(v2f{q1[2], q1[3]}, nbj[u], rhs);
-                    bool c0 = (float)acc[t][u][r] > rhs[0];
-                    bool c1 = (float)acc[t][u][r + 1] > rhs[1];
+                    bool c0 = (float)acc[t][u][r] > rhs[u][0];
+                    bool c1 = (float)acc[t][u][r + 1] > rhs[u][1];
                     if (TRI) {
                         c0 = c0 && row_l <= row_max[u];
                         c1 = c1 && row_l < row_max[u];
                     }
-                    m32[u] |= (c0 ? 1u << (t * 4 + r) : 0u) | (c1 ? 2u << (t * 4 + r) : 0u);
+                    any |= __ballot(c0) | __ballot(c1);
+                }
+                if (any != 0ULL) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        bool c0 = (float)acc[t][u][r] > rhs[u][0];
+                        bool c1 = (float)acc[t][u][r + 1] > rhs[u][1];
+                        if (TRI) {
+                            c0 = c0 && row_l <= row_max[u];
+                            c1 = c1 && row_l < row_max[u];
+                        }
+                        m32[u] |= (c0 ? 1u << (t * 4 + r) : 0u) | (c1 ? 2u << (t * 4 + r) : 0u);
+                    }
                 }
             }
         }
