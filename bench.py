@@ -529,7 +529,8 @@ def cpu_baseline(hashes, offsets, S, NH, D, dev):
     point there is (survey-session build)."""
     from oracle import pyoracle as orc
     from metagenome_vector_sketches_amd import synth
-    cores = usable_cores(orc.max_threads())
+    visible = orc.max_threads()               # before any call changes the OpenMP thread count
+    cores = usable_cores(visible)
     thr_list = [8, cores] if cores > 8 else [cores]
     o_all = np.asarray(offsets)
     mean_size = float(o_all[S]) / S
@@ -599,7 +600,7 @@ def cpu_baseline(hashes, offsets, S, NH, D, dev):
     detail["calibration"] = ("projection port calibrated against the reference binary in the dev container (BASELINE.md "
                              "section 3 table: 1.0-2.2x the reference's speed, the faster port is used); pairwise port NOT "
                              "calibrated against the reference (unbuildable: `bits` submodule absent)")
-    detail["host_threads_visible"] = orc.max_threads()
+    detail["host_threads_visible"] = visible
     return {"value": S / t_job, "unit": "samples/s (projected and compared all-vs-all)", "cores": cores,
             "kind": "port",
             "sample": "projection: %s samples x %d hashes per thread count %s, faster of the literal and the restructured "
