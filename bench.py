@@ -187,6 +187,7 @@ def main():
         hashes, offsets = synth.make_csr_torch(S, NH, seed=1234 + rank, device=dev, cluster=args.cluster, shared=0.4)
     sketches = torch.empty((S, D), dtype=torch.int32, device=dev)
     sumsq = torch.empty(S, dtype=torch.int64, device=dev)
+    n2_local = torch.empty(S, dtype=torch.float64, device=dev)
     N_total = S * world
     cap = max(1 << 20, max(64, 4 * args.cluster) * S)
     cells = torch.empty((cap, 4), dtype=torch.int32, device=dev)
@@ -198,7 +199,7 @@ def main():
     def step():
         # K1; the sums of squares and max |v| come out of the same kernel
         max_abs = ctx.project_csr_stats(hashes, offsets, D, sketches, sumsq)
-        n2_local = fast_norm_sq(sumsq.cpu().numpy(), D)                    # text round trip of the norms
+        ctx.norms_sq_text(sumsq, D, out=n2_local)       # text round trip of the norms (vector_norms.txt), on the device
         # limb split, [all-gather of plane row blocks + norms], K2 on this rank's rows x all columns
         _, cnt, info = sc.run(sketches, n2_local, N_total, cells_out=cells, max_abs_local=max_abs)
         state["cnt"] = cnt
@@ -224,6 +225,9 @@ def main():
         k2_ms.append(sc.ops.k2_ms if sc.ops.k2_ms > 0 else ctx.kernel_ms(1))
     sync_all()
     elapsed = time.perf_counter() - t0
+    # outside the timed region: the device's text round trip against the host's (printf / strtod semantics)
+    if not np.array_equal(n2_local.cpu().numpy(), fast_norm_sq(sumsq.cpu().numpy(), D)):
+        raise SystemExit("device norm text round trip differs from the host's")
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -144,6 +144,14 @@ int mvs_project_csr_stats(mvs_ctx* ctx, const uint64_t* hashes, int mem_hashes, 
 int mvs_sketch_sumsq(mvs_ctx* ctx, const int32_t* sketches, int mem_in, int64_t n, int d,
                      int64_t* sumsq, int mem_out);
 
+/* The vector_norms.txt round trip without the file, on the device: out[i] = strtod(text_i)^2 where text_i is the
+ * "%g" (6 significant digits) rendering of sqrt(double(sumsq[i]) / d) -- i.e. exactly the squared norm that
+ * src/pairwise_comp_optimized.cpp:893-901 parses from the line src/project_everything.cpp:328-330 writes (with this
+ * build's norm definition).  Decimal rounding is done in exact arithmetic (ties included), so
+ * the values are bit-identical to the ones read back from the file.  sumsq and out are device arrays of n entries;
+ * asynchronous on the context's stream.  For a pipeline that sketches and compares in one process. */
+int mvs_norms_sq_text(mvs_ctx* ctx, const int64_t* sumsq, int64_t n, int d, double* out);
+
 /* Both statistics the stages after the projection need, in one pass over the sketches: the per-sketch sum
  * of squares (as mvs_sketch_sumsq) and the largest |v| of the whole array (as mvs_sketch_max_abs, which
  * decides the limb code).  Synchronous: *max_abs is valid on return. */

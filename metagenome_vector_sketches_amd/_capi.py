@@ -43,6 +43,7 @@ SYMBOLS = [
                                           _c.POINTER(_c.c_int64)]),
     ("mvs_sketch_sumsq", _c.c_int, [_P, _P, _c.c_int, _c.c_int64, _c.c_int, _P, _c.c_int]),
     ("mvs_sketch_stats", _c.c_int, [_P, _P, _c.c_int, _c.c_int64, _c.c_int, _P, _c.c_int, _c.POINTER(_c.c_int64)]),
+    ("mvs_norms_sq_text", _c.c_int, [_P, _P, _c.c_int64, _c.c_int, _P]),
     ("mvs_sketch_saturate_i16", _c.c_int, [_P, _P, _c.c_int, _c.c_int64, _P, _c.c_int]),
     ("mvs_sketch_max_abs", _c.c_int, [_P, _P, _c.c_int, _c.c_int, _c.c_int64, _c.POINTER(_c.c_int64)]),
     ("mvs_limbs_for_max_abs", _c.c_int, [_c.c_int64]),
@@ -351,6 +352,16 @@ class Context:
             out = np.empty(n, dtype=np.int64)
         op, om, ok = _buf(out, np.int64, writable=True)
         _check(self.lib.mvs_sketch_sumsq(self._h, ip, im, n, d, op, om))
+        return out
+
+    def norms_sq_text(self, sumsq, d, out):
+        """device int64 sums of squares -> device float64 squared norms as they come back from vector_norms.txt
+        (6-significant-digit text round trip, exact); asynchronous on the context's stream."""
+        ip, im, ik = _buf(sumsq, np.int64)
+        op, om, ok = _buf(out, np.float64, writable=True)
+        if im != MEM_DEVICE or om != MEM_DEVICE:
+            raise ValueError("norms_sq_text works on device arrays")
+        _check(self.lib.mvs_norms_sq_text(self._h, ip, int(sumsq.shape[0]), int(d), op))
         return out
 
     def stats(self, sketches, out=None):

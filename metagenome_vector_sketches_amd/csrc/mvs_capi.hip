@@ -635,6 +635,67 @@ int mvs_sketch_sumsq(mvs_ctx* c, const int32_t* sketches, int mem_in, int64_t n,
     return MVS_OK;
 }
 
+namespace {
+
+// "%g" keeps 6 significant digits: x -> the decimal r * 10^-j (r an integer of 6 digits, round-half-even on the exact
+// binary value of x as printf does) -> the double nearest to that decimal (what strtod returns) -> squared.
+// The product x * 10^j is rounded once; only when it lands exactly on k + 0.5 can the true product lie on either side,
+// and the fma residual says which (rounding is monotonic, so a product off the tie is on the true side of it).  An
+// exponent estimate that is off by one next to a power of ten yields the same decimal (r = 10^6 is renormalised).
+__device__ double norm_sq_from_text(long long sumsq, int d) {
+    if (sumsq <= 0) return 0.0;
+    const double x = sqrt((double)sumsq / (double)d);
+    constexpr double p10[23] = {1e0,  1e1,  1e2,  1e3,  1e4,  1e5,  1e6,  1e7,  1e8,  1e9,  1e10, 1e11,
+                                1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
+    int e = 0;                                   // 10^e <= x < 10^(e+1), up to the off-by-one noted above
+    if (x >= 1.0) {
+        while (e < 21 && x >= p10[e + 1]) ++e;
+    } else {
+        double y = x;
+        while (e > -16 && y < 1.0) {
+            y *= 10.0;
+            --e;
+        }
+    }
+    int j = 5 - e;                               // x * 10^j has 6 digits before the point
+    double m, err;
+    if (j >= 0) {
+        m = x * p10[j];
+        err = fma(x, p10[j], -m);                // exact: true product = m + err
+    } else {
+        m = x / p10[-j];
+        err = -fma(m, p10[-j], -x);              // sign of (true quotient - m)
+    }
+    double r = rint(m);                          // half-even
+    const double fl = floor(m);
+    if (m - fl == 0.5 && err != 0.0) r = err > 0.0 ? fl + 1.0 : fl;
+    if (r >= 1e6) {
+        r = 1e5;
+        --j;
+    }
+    const double v = j >= 0 ? r / p10[j] : r * p10[-j];
+    return v * v;
+}
+
+__global__ __launch_bounds__(256) void k_norms_sq_text(const int64_t* __restrict__ sumsq, int64_t n, int d,
+                                                       double* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = norm_sq_from_text(sumsq[i], d);
+}
+
+}  // namespace
+
+int mvs_norms_sq_text(mvs_ctx* c, const int64_t* sumsq, int64_t n, int d, double* out) {
+    if (!c) return fail(MVS_E_INVALID, "ctx is NULL");
+    if (n < 0 || d <= 0) return fail(MVS_E_INVALID, "bad argument");
+    if (n == 0) return MVS_OK;
+    if (!sumsq || !out) return fail(MVS_E_INVALID, "NULL buffer");
+    if ((n + 255) / 256 > 0x7fffffffLL) return fail(MVS_E_INVALID, "too many entries");
+    HIP_TRY(hipSetDevice(c->device));
+    hipLaunchKernelGGL(k_norms_sq_text, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, sumsq, n, d, out);
+    return check_kernel("k_norms_sq_text");
+}
+
 int mvs_sketch_stats(mvs_ctx* c, const int32_t* sketches, int mem_in, int64_t n, int d, int64_t* sumsq, int mem_out,
                      int64_t* max_abs) {
     if (!c || !max_abs) return fail(MVS_E_INVALID, "NULL argument");

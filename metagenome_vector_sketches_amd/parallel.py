@@ -195,8 +195,8 @@ class ShardedComparison:
 
     def run(self, sketches_local, norms_sq_local, n_total, keep_mode=_capi.KEEP_INT32, cells_out=None,
             max_abs_local=None):
-        """sketches_local: this rank's rows (int32/int16 [n_local, d]); norms_sq_local: host float64
-        [n_local]; max_abs_local: largest |v| of sketches_local if the caller already has it
+        """sketches_local: this rank's rows (int32/int16 [n_local, d]); norms_sq_local: float64 [n_local], a host
+        array or a device tensor; max_abs_local: largest |v| of sketches_local if the caller already has it
         (Context.stats).  Returns (cells, n_cells, info) for this rank's shard."""
         ops, rank, world = self.ops, self.rank, self.world
         n_local, d = sketches_local.shape
@@ -222,9 +222,15 @@ class ShardedComparison:
         blk = rps * limbs * d_pad
         if n_local:
             ops.limb_split(sketches_local, limbs, planes, d_pad, rank * rps)
-        n2_pad = np.zeros(rps, dtype=np.float64)
-        n2_pad[:n_local] = norms_sq_local
-        n2_all[rank * rps:(rank + 1) * rps] = ops.to_device(n2_pad)
+        if _capi._is_torch(norms_sq_local):
+            # already on the device (Context.norms_sq_text): no host round trip; the block's tail rows stay zero
+            n2_all[rank * rps:rank * rps + n_local].copy_(norms_sq_local)
+            if n_local < rps:
+                n2_all[rank * rps + n_local:(rank + 1) * rps].zero_()
+        else:
+            n2_pad = np.zeros(rps, dtype=np.float64)
+            n2_pad[:n_local] = norms_sq_local
+            n2_all[rank * rps:(rank + 1) * rps] = ops.to_device(n2_pad)
         if world > 1:
             if self.time_gather:
                 import torch

@@ -242,3 +242,45 @@ def test_shared_round_variants_and_their_carry_hazard(ctx, d):
             assert np.array_equal(ctx.project_csr(hashes, offsets, d), want), v
     finally:
         ctx.set_option("project_variant", old)
+
+
+def test_norm_text_round_trip_on_the_device(ctx):
+    """mvs_norms_sq_text == (strtod of the "%g" line of vector_norms.txt)^2, bit for bit: the oracle's
+    format_norm / norm_sq_from_text (project_everything.cpp:328-330, pairwise_comp_optimized.cpp:893-901) on
+    random sums of squares, on exact decimal ties, next to powers of ten and at the extremes."""
+    import torch
+    rng = np.random.default_rng(99)
+    cases = []
+    for d in (2048, 4096, 64, 1, 3, 1000):
+        vals = [0, 1, 2, 3, d - 1, d, d + 1, 2**62, 2**63 - 1]
+        vals += [int(v) for v in rng.integers(1, 2**40, size=3000)]
+        vals += [int(v) for v in rng.integers(1, 2**62, size=2000)]
+        vals += [int(v) for v in (rng.integers(1, 3000, size=1000).astype(np.int64) ** 2 * 50_000)]   # sketch-like sizes
+        # sqrt(s / d) a short dyadic decimal: exact ties at the 7th digit (k / 16, k / 32, ... with 7 digits)
+        for k in range(1, 400000, 997):
+            for den in (2, 4, 8, 16, 32, 64):
+                num = k * k * d
+                if num % (den * den) == 0:
+                    vals.append(num // (den * den))
+        # next to powers of ten: sqrt(s / d) ~ 10^e
+        for e in range(-1, 9):
+            c = int(round(d * 10.0 ** (2 * e)))
+            vals += [max(0, c + o) for o in (-2, -1, 0, 1, 2)]
+        # 6-digit boundaries: x ~ 999999.5 * 10^q
+        for q in range(-5, 4):
+            x = 999999.5 * 10.0 ** q
+            c = int(x * x * d)
+            vals += [max(0, c + o) for o in (-1, 0, 1)]
+        cases.append((d, np.array([v for v in vals if 0 <= v < 2**63], dtype=np.int64)))
+    for d, s in cases:
+        dev = torch.from_numpy(s).cuda()
+        out = torch.empty(len(s), dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()              # the upload ran on torch's stream, the kernel runs on the context's
+        ctx.norms_sq_text(dev, d, out)
+        ctx.synchronize()                     # asynchronous entry point
+        got = out.cpu().numpy()
+        want = np.array([orc.norm_sq_from_text(orc.format_norm(np.sqrt(float(v) / float(d)))) for v in s.tolist()])
+        bad = np.nonzero(got != want)[0]
+        assert len(bad) == 0, (d, s[bad[:5]], got[bad[:5]], want[bad[:5]])
+    with pytest.raises(ValueError):
+        ctx.norms_sq_text(np.zeros(4, dtype=np.int64), 2048, np.zeros(4))
