@@ -102,8 +102,9 @@ int mvs_ctx_kernel_ms(mvs_ctx* ctx, int which, float* ms);
  *                         1 / 2 / 12 / 14 force a variant
  *   markers               1: roctx ranges named after the entry points around mvs_project_csr / mvs_pairwise_rows /
  *                         mvs_pairwise_block (rocprofv3 --marker-trace); libroctx64 is bound at run time
- *   pairwise_debug        k-loop / epilogue ablations for profiling; rejected unless the library was built with
- *                         -DMVS_ABLATIONS (make -C csrc ablations): such runs produce garbage by design
+ *   pairwise_debug        profiling aids, bit mask: 1 / 2 skip the k-loop / the epilogue (such runs produce garbage by
+ *                         design), 8 per-workgroup time stamps of the comparison kernel dumped to /tmp/mvs_stamps.bin;
+ *                         rejected unless the library was built with -DMVS_ABLATIONS (make -C csrc ablations)
  * Unknown names and out-of-range values return MVS_E_INVALID.  None of them changes a result. */
 int mvs_ctx_set_option(mvs_ctx* ctx, const char* name, int64_t value);
 int mvs_ctx_get_option(const mvs_ctx* ctx, const char* name, int64_t* value);

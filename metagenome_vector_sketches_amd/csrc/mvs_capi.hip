@@ -202,7 +202,7 @@ const OptionSpec kOptions[] = {
     {"exact_variant", &mvs::Options::exact_variant, nullptr, 0, 3},
     {"pairwise_variant", &mvs::Options::pairwise_variant, nullptr, 0, 9},
     {"pairwise_symmetric", &mvs::Options::pairwise_symmetric, nullptr, 0, 1},
-    {"pairwise_debug", &mvs::Options::pairwise_debug, nullptr, 0, 3},
+    {"pairwise_debug", &mvs::Options::pairwise_debug, nullptr, 0, 15},
     {"sort", &mvs::Options::sort, nullptr, 0, 2},
     {"enable_k3", &mvs::Options::enable_k3, nullptr, 0, 1},
     {"markers", &mvs::Options::markers, nullptr, 0, 1},
@@ -1071,6 +1071,28 @@ int pairwise_launch(mvs_ctx* c, const mvs_sketch_set* s, const double* d_n2, int
     a.dots = nullptr;
     a.mirror_all = mirror_all ? 1 : 0;
     a.debug_flags = c->opt.pairwise_debug;
+    a.stamps = nullptr;
+#ifdef MVS_ABLATIONS
+    // per-workgroup time stamps of k_pairwise_pp (profiling only): one buffer for the process, dumped after the call
+    static unsigned long long* g_stamps = nullptr;
+    const size_t stamp_bytes = (size_t)mvs::kStampSlots * 64;
+    if (c->opt.pairwise_debug & 8) {
+        if (!g_stamps) HIP_TRY(hipMalloc((void**)&g_stamps, stamp_bytes));
+        HIP_TRY(hipMemsetAsync(g_stamps, 0, stamp_bytes, c->stream));
+        a.stamps = g_stamps;
+    }
+    struct StampDump {
+        unsigned long long* p; size_t bytes; hipStream_t st;
+        ~StampDump() {
+            if (!p) return;
+            (void)hipStreamSynchronize(st);
+            std::vector<char> h(bytes);
+            (void)hipMemcpy(h.data(), p, bytes, hipMemcpyDeviceToHost);
+            FILE* f = fopen("/tmp/mvs_stamps.bin", "wb");
+            if (f) { fwrite(h.data(), 1, bytes, f); fclose(f); }
+        }
+    } stamp_dump{a.stamps, stamp_bytes, c->stream};
+#endif
     a.symmetric = (symmetric && c->opt.pairwise_symmetric) ? 1 : 0;   // the launcher checks the alignment
     const int filter_mode = c->opt.pairwise_filter;
     auto set_count = [&]() -> int {

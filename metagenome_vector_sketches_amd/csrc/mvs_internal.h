@@ -50,6 +50,8 @@ struct Options {
     double pairwise_block_cells = 1099511627776.0;   // row-chunk bound of mvs_pairwise_rows (2^40 cells)
 };
 
+constexpr unsigned long long kStampSlots = 400000ULL;   // workgroups the time-stamp buffer of an ablation build holds
+
 struct PairwiseArgs {
     const int8_t* planes;   // [(row*limbs + limb) * d_pad + k]
     int64_t n;              // samples
@@ -82,6 +84,10 @@ struct PairwiseArgs {
     unsigned long long* cand_counter;
     unsigned long long cand_limit;   // once the counter is beyond this the remaining filter tiles and the re-check
                                      // give up at once: the caller falls back to the exact kernel
+    unsigned long long* stamps;      // ablation builds (pairwise_debug bit 8): kStampSlots x 8 words, per workgroup of
+                                     //    k_pairwise_pp {XCC / HW id, start, end, k-loop end, epilogue phases} on the
+                                     //    100 MHz realtime clock; the library dumps them to /tmp/mvs_stamps.bin
+                                     //    (tools/exp/stamps.py reads that)
     unsigned int* cand_stop;         // set by the wave that takes the counter past the limit; lives on its own cache
                                      // line (polling the counter itself queues behind its atomics)
 };

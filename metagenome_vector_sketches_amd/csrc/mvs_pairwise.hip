@@ -53,11 +53,15 @@ struct TileCoord {
 
 // (blockIdx.x, blockIdx.y) -> tile.  The tile grid is cut into 16x16-tile super-patches: blockIdx.y is the
 // patch row, blockIdx.x / 256 the patch column; inside a patch the XCD label (blockIdx.x % 8 -- gridDim.x is
-// a multiple of 256, so this is also the linear workgroup id % 8) picks a 4-row x 8-col sub-patch and
+// a multiple of 256, so this is also the linear workgroup id % 8), rotated by the patch row, picks a 4-row x 8-col sub-patch and
 // (blockIdx.x / 8) % 32 walks it.  Placement only affects speed.  (A 2-D grid because a dispatch holds at
 // most 2^32 work-items per dimension: one dimension would cap the matrix at ~370k samples.)
 __device__ __forceinline__ TileCoord map_tile(unsigned b, unsigned patch_row, int n_tr, int n_tc) {
-    const unsigned x = b & 7u;
+    // The sub-patch an XCD takes rotates with the patch row.  With a fixed assignment the symmetric schedule is
+    // lopsided: in a patch on the diagonal the sub-patches hold 32, 26, 10 or 0 tiles above the diagonal, in the
+    // last patch column only the left sub-patches exist -- measured at 100k samples (per-workgroup time stamps):
+    // 9072 .. 10150 tiles per XCD, the fullest XCD finishing 4 % after the average one.
+    const unsigned x = (b + patch_row) & 7u;
     const unsigned q = b >> 3;
     const unsigned ql = q & 31u;
     const int spr = (int)patch_row, spc = (int)(q >> 5);
@@ -801,95 +805,96 @@ struct PpGeom {
 // fm: this thread's entry of the tile's row / column constants (thread x < 256: row i0 + x, else column j0 + x - 256),
 // loaded by the caller before the k-loop so that its latency is not paid here
 __device__ __forceinline__ void epilogue_filter16(const PairwiseArgs& a, v4i (&acc)[8][4], char* smem, int tid, int lane,
-                                                  int wave, int wm, int wn, int64_t i0, int64_t j0, float4 fm) {
+                                                  int wave, int wm, int wn, int64_t i0, int64_t j0, float4 fm,
+                                                  unsigned long long* stamp = nullptr) {
     constexpr int TM = 256, TN = 256;
-    using v2f = __attribute__((ext_vector_type(2))) float;
     using v4f = __attribute__((ext_vector_type(4))) float;
     const int fr = lane & 15, fq = lane >> 4;
     __syncthreads();                                                   // every wave is done with the ring
-    float* frow = reinterpret_cast<float*>(smem);                      // TM/2 row pairs x {s0 s1 w0 w1 | a0 a1 p0 p1}
-    float4* fcol = reinterpret_cast<float4*>(smem + TM * 16);          // TN entries {s, w, a, p}
+#ifdef MVS_ABLATIONS
+    if (stamp && tid == 0) stamp[4] = wall_clock64();
+#endif
+    // The threshold of a 16 x 16 block of cells is a rank-4 product,
+    //     T_ij = [s_i w_i a_i p_i] . [w_j s_j -p_j -(a_j + p_j)] ,
+    // i.e. ONE v_mfma_f32_16x16x4_f32 (an fp32 fma chain per cell, like the vector code it replaces) whose result
+    // lands in the accumulator layout of the int8 products: the matrix pipe -- idle in the epilogue -- forms the
+    // thresholds and subtracts them.  Operands: lane (fr, fq)
+    // holds constant #fq of row / column fr of the block, so the constants are staged in planes of 256 floats.
+    float* rowc = reinterpret_cast<float*>(smem);                      // [4][TM]: s, w, a, p of the tile's rows
+    float* colc = rowc + 4 * TM;                                       // [4][TN]: w, s, -p, -(a + p) of its columns
     if (tid < TM) {
-        float* q = frow + (tid >> 1) * 8 + (tid & 1);
-        q[0] = fm.x;
-        q[2] = fm.y;
-        q[4] = fm.z;
-        q[6] = fm.w;
+        rowc[tid] = fm.x;
+        rowc[TM + tid] = fm.y;
+        rowc[2 * TM + tid] = fm.z;
+        rowc[3 * TM + tid] = fm.w;
     } else {
-        fcol[tid - TM] = fm;
+        const int cidx = tid - TM;
+        colc[cidx] = fm.y;
+        colc[TN + cidx] = fm.x;
+        colc[2 * TN + cidx] = -fm.w;
+        colc[3 * TN + cidx] = -(fm.z + fm.w);
     }
     __syncthreads();
+#ifdef MVS_ABLATIONS
+    if (stamp && tid == 0) stamp[5] = wall_clock64();
+#endif
     const bool straddle = a.symmetric && j0 < i0 + TM && j0 + TN > i0;
     const int delta = (int)(j0 - i0);                                  // col - row = col_l - row_l + delta
     // one 32-bit mask per lane and 16-column group: bit t*4 + r <=> row wm*128 + t*16 + fq*4 + r passes
-    // the four column groups' constants stay in registers, the row constants are read once per row pair (rows outer,
-    // column groups inner: a quarter of the LDS reads of the column-major order)
     unsigned m32[4] = {0u, 0u, 0u, 0u};
-    v2f wj[4], sj[4], npj[4], nbj[4];
+    float bop[4];
     int row_max[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const int col_l = wn * 64 + u * 16 + fr;
         const int64_t col = j0 + col_l;
-        const float4 mj = fcol[col_l];
-        const float bj = mj.z + mj.w;
-        wj[u] = v2f{mj.y, mj.y};
-        sj[u] = v2f{mj.x, mj.x};
-        npj[u] = v2f{-mj.w, -mj.w};
-        nbj[u] = v2f{-bj, -bj};
+        bop[u] = colc[fq * TN + col_l];
         const bool in_square = a.symmetric && col >= a.row_begin && col < a.row_end;
         row_max[u] = (straddle && in_square) ? col_l + delta : 0x7fffffff;   // col >= row  <=>  row_l <= col_l + delta
     }
-    // Candidates are rare (1.5e-5 of the cells), so the sweep first only asks "does any lane pass in this row pair"
-    // -- compares into scalar registers, OR-ed on the scalar unit, four independent chains -- and builds the
-    // per-lane masks just for the row pairs that say yes.
+    // Candidates are rare (1.5e-5 of the cells), so the sweep first only asks "does any lane pass in this row block"
+    // -- compares into scalar registers, OR-ed on the scalar unit -- and builds the per-lane masks just for the row
+    // blocks that say yes.
+    // D = (float)acc - T comes out of the matrix pipe (the converted int8 products go in as the C operand, the row
+    // constants negated); a positive float is a positive int32 bit pattern, so "does any cell of this row block
+    // pass" is an integer maximum over the 16 values of a lane -- 1.5 vector instructions per cell (convert, half
+    // a v_max3) and no traffic through scalar registers.  (A NaN -- padding rows / columns: inf x 0 -- may look
+    // positive to the maximum; the exact compare below then drops it.)
     auto sweep = [&](auto tri) {
         constexpr bool TRI = decltype(tri)::value;
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
+            const float aop = -rowc[fq * TM + wm * 128 + t * 16 + fr];
+            const int row_l = wm * 128 + t * 16 + fq * 4;
+            v4f dif[4];
 #pragma unroll
-            for (int r = 0; r < 4; r += 2) {
-                const int row_l = wm * 128 + t * 16 + fq * 4 + r;
-                const v4f q0 = *reinterpret_cast<const v4f*>(frow + (row_l >> 1) * 8);
-                const v4f q1 = *reinterpret_cast<const v4f*>(frow + (row_l >> 1) * 8 + 4);
-                const v2f qs = v2f{q0[0], q0[1]}, qw = v2f{q0[2], q0[3]}, qa = v2f{q1[0], q1[1]}, qp = v2f{q1[2], q1[3]};
-                v2f rhs[4];
+            for (int u = 0; u < 4; ++u) {
+                const v4f accf = {(float)acc[t][u][0], (float)acc[t][u][1], (float)acc[t][u][2], (float)acc[t][u][3]};
+                dif[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(aop, bop[u], accf, 0, 0, 0);
+            }
+            int top = 0;
 #pragma unroll
-                for (int u = 0; u < 4; ++u) rhs[u] = qs * wj[u];
+            for (int u = 0; u < 4; ++u) {
+                const v4i bits = __builtin_bit_cast(v4i, dif[u]);
+                top = max(max(top, bits[0]), max(max(bits[1], bits[2]), bits[3]));
+            }
+            if (__ballot(top > 0) != 0ULL) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) rhs[u] = __builtin_elementwise_fma(qw, sj[u], rhs[u]);
+                for (int u = 0; u < 4; ++u)
 #pragma unroll
-                for (int u = 0; u < 4; ++u) rhs[u] = __builtin_elementwise_fma(qa, npj[u], rhs[u]);
-#pragma unroll
-                for (int u = 0; u < 4; ++u) rhs[u] = __builtin_elementwise_fma(qp, nbj[u], rhs[u]);
-                unsigned long long any = 0ULL;
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    bool c0 = (float)acc[t][u][r] > rhs[u][0];
-                    bool c1 = (float)acc[t][u][r + 1] > rhs[u][1];
-                    if (TRI) {
-                        c0 = c0 && row_l <= row_max[u];
-                        c1 = c1 && row_l < row_max[u];
+                    for (int r = 0; r < 4; ++r) {
+                        bool c = dif[u][r] > 0.0f;
+                        if (TRI) c = c && row_l + r <= row_max[u];
+                        m32[u] |= c ? 1u << (t * 4 + r) : 0u;
                     }
-                    any |= __ballot(c0) | __ballot(c1);
-                }
-                if (any != 0ULL) {
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        bool c0 = (float)acc[t][u][r] > rhs[u][0];
-                        bool c1 = (float)acc[t][u][r + 1] > rhs[u][1];
-                        if (TRI) {
-                            c0 = c0 && row_l <= row_max[u];
-                            c1 = c1 && row_l < row_max[u];
-                        }
-                        m32[u] |= (c0 ? 1u << (t * 4 + r) : 0u) | (c1 ? 2u << (t * 4 + r) : 0u);
-                    }
-                }
             }
         }
     };
     if (straddle) sweep(std::true_type{});
     else sweep(std::false_type{});
+#ifdef MVS_ABLATIONS
+    if (stamp && tid == 0) stamp[6] = wall_clock64();
+#endif
     const unsigned mine = (unsigned)(__popc(m32[0]) + __popc(m32[1]) + __popc(m32[2]) + __popc(m32[3]));
     if (__ballot(mine != 0) == 0ULL) return;               // the common case: nothing in this wave passes
     unsigned incl = mine;                                   // inclusive prefix sum over the lanes
@@ -938,6 +943,22 @@ __global__ __launch_bounds__(512, 2) void k_pairwise_pp(const PairwiseArgs a, in
     constexpr int L = G::L, TM = G::TM, TN = G::TN, kRegion = G::kRegion, kStage = G::kStage, kPPW = G::kPPW;
     constexpr int D = NST - 2;                                   // slices the copies run ahead
     static_assert(NST >= 3 && NST <= 5 && kPPW == 4, "ring geometry");
+#ifdef MVS_ABLATIONS
+    unsigned long long* stamp = nullptr;
+    if (a.stamps && (unsigned long long)blockIdx.y * gridDim.x + blockIdx.x < kStampSlots) {
+        stamp = a.stamps + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8;
+        if (threadIdx.x == 0) {
+            unsigned xcc, hw;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            const unsigned long long t = __builtin_readcyclecounter();
+            stamp[0] = ((unsigned long long)xcc << 32) | hw;
+            stamp[1] = wall_clock64();
+            stamp[2] = stamp[1];
+            stamp[3] = t;
+        }
+    }
+#endif
     const TileCoord tc = map_tile(blockIdx.x, blockIdx.y, n_tr, n_tc);
     if (!tc.valid) return;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1090,8 +1111,18 @@ __global__ __launch_bounds__(512, 2) void k_pairwise_pp(const PairwiseArgs a, in
         return;
     }
 #endif
+#ifdef MVS_ABLATIONS
+    if (stamp && threadIdx.x == 0) stamp[3] = wall_clock64();   // end of the k-loop
+#endif
     if constexpr (MODE == 2) {
+#ifdef MVS_ABLATIONS
+        epilogue_filter16(a, *reinterpret_cast<v4i(*)[8][4]>(&accv[0]), smem, tid, lane, wave, wm, wn, i0, j0, fm, stamp);
+#else
         epilogue_filter16(a, *reinterpret_cast<v4i(*)[8][4]>(&accv[0]), smem, tid, lane, wave, wm, wn, i0, j0, fm);
+#endif
+#ifdef MVS_ABLATIONS
+        if (stamp && threadIdx.x == 0) stamp[2] = wall_clock64();
+#endif
     } else {
         epilogue_exact16<MODE>(a, *reinterpret_cast<v4i(*)[4][2][3]>(&accv[0]), smem, tid, lane, wave, wm, wn, i0, j0,
                                mirror_tile);
