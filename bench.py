@@ -523,6 +523,45 @@ def usable_cores(visible):
         return visible
 
 
+def reference_sketch_leg(hashes, o_all, S, D, cores, orc, ns=128):
+    """-> dict for cpu_baseline.detail.projection.reference_binary (None-valued when the binary is not there)"""
+    import shutil
+    import subprocess
+    import tempfile
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "oracle", "_ref", "project_everything")
+    if not os.path.exists(exe):
+        return {"available": False, "why": "oracle/_ref/project_everything not built (needs /root/reference at build time)"}
+    ns = min(ns, S)
+    o = o_all[:ns + 1]
+    h = hashes[:int(o[ns])].cpu().numpy().view(np.uint64)
+    tmp = tempfile.mkdtemp(prefix="mvs_refleg_")
+    try:
+        hf = os.path.join(tmp, "hashes.txt")
+        with open(hf, "w") as f:
+            for i in range(ns):
+                f.write("s%d: " % i + " ".join(map(str, h[int(o[i]):int(o[i + 1])].tolist())) + "\n")
+        env = dict(os.environ, OMP_NUM_THREADS=str(cores))
+        t0 = time.perf_counter()
+        r = subprocess.run([exe, "sketch", hf, os.path.join(tmp, "db"), "-d", str(D)], env=env, capture_output=True,
+                           text=True, timeout=300)
+        wall = time.perf_counter() - t0
+        if r.returncode != 0:
+            return {"available": False, "why": "reference binary failed: " + r.stderr[-200:]}
+        span = None
+        for line in r.stdout.splitlines():
+            if line.startswith("Time to compute all projected vectors:"):
+                span = float(line.split(":")[1].split()[0])
+        got = np.fromfile(os.path.join(tmp, "db", "vectors.bin"), dtype="<i4").reshape(ns, D)
+        same = bool(np.array_equal(got, orc.project_csr(h, o, D, threads=cores, fast=True, native=True)))
+        return {"available": True, "samples": ns, "hashes": int(o[ns]), "threads": cores,
+                "reference_span_s": span, "wall_s": wall,
+                "samples_per_s": (ns / span) if span else None,
+                "vectors_equal_to_port": same,
+                "note": "parse + projection as the reference times them; the ports above time the projection alone"}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def cpu_baseline(hashes, offsets, S, NH, D, dev):
     """The oracle (CPU port of the reference path, kind "port") timed on this host's cores on bounded samples of the
     same workloads, as BASELINE.md section 3 lays out: projection and pairwise each with 8 threads (the reference's
@@ -562,6 +601,12 @@ def cpu_baseline(hashes, offsets, S, NH, D, dev):
             "samples_timed": [min(n_lit, S), min(n_fast, S)]}
     best_proj = max(max(v["literal_port_samples_per_s"], v["restructured_port_samples_per_s"])
                     for v in detail["projection"].values())
+
+    # ---- projection by the reference's OWN executable (oracle/_ref/project_everything, compiled from its sources in
+    # the dev container and shipped as a binary): `sketch` on a text file of the first samples.  Its span "Time to
+    # compute all projected vectors" covers the serial text parse and the OpenMP projection (project_everything.cpp:
+    # 255-303); -t is ignored by the reference's sketch (:373-408), so OMP_NUM_THREADS carries the core quota. ----
+    detail["projection"]["reference_binary"] = reference_sketch_leg(hashes, o_all, S, D, cores, orc)
 
     # ---- pairwise: N = 4096 (full square) and N = 16384 (row stripe sized from the first rate) ----
     skp = synth.make_sketches_torch(16384, D, NH, seed=2345, device=dev).cpu().numpy()
@@ -608,7 +653,8 @@ def cpu_baseline(hashes, offsets, S, NH, D, dev):
     return {"value": S / t_job, "unit": "samples/s (projected and compared all-vs-all)", "cores": cores,
             "kind": "port",
             "sample": "projection: %s samples x %d hashes per thread count %s, faster of the literal and the restructured "
-                      "port; pairwise: N=4096 full square and a row stripe of N=16384, d=%d, chunk 192; toy set with 8 "
+                      "port, and the reference's own sketch executable on 128 samples where oracle/_ref is present "
+                      "(detail.projection.reference_binary); pairwise: N=4096 full square and a row stripe of N=16384, d=%d, chunk 192; toy set with 8 "
                       "threads; best all-core rates extrapolated to %d samples (linear + quadratic)" %
                       ("/".join(str(x) for x in detail["projection"]["%d_threads" % thr_list[-1]]["samples_timed"]), NH,
                        thr_list, D, S),
