@@ -222,6 +222,8 @@ class ShardedComparison:
         blk = rps * limbs * d_pad
         if n_local:
             ops.limb_split(sketches_local, limbs, planes, d_pad, rank * rps)
+        if _capi._is_torch(norms_sq_local) and not _capi._is_torch(n2_all):
+            norms_sq_local = norms_sq_local.cpu().numpy()    # host back end (tests): plain arrays
         if _capi._is_torch(norms_sq_local):
             # already on the device (Context.norms_sq_text): no host round trip; the block's tail rows stay zero
             n2_all[rank * rps:rank * rps + n_local].copy_(norms_sq_local)
