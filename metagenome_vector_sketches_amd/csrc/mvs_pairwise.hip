@@ -1272,6 +1272,10 @@ __global__ __launch_bounds__(256) void k_cand_thr(const double* __restrict__ n2,
 // The one-pass MFMA filter evaluates exactly that per cell in fp32; s is deflated and a, p are inflated by
 // 2^-12, which dominates every rounding error of the evaluation (4 fused operations, 2^-22 relative to
 // the sum of magnitudes) and of the int -> float conversion of the dot, so no kept pair is ever dropped.
+// (The ping-pong kernel's epilogue forms  (float)dot - rhs  as ONE fma chain on the matrix pipe, the converted dot
+// being the addend: five roundings of 2^-24 relative to |dot| + the sum of magnitudes.  The sign of the result can
+// only be in doubt where |dot| is about rhs, i.e. at most that sum, so the error is below 2^-20 of it against a
+// margin of 2^-12.)
 // Pairs that pass go to a candidate list; k_exact_pairs recomputes their dots exactly from the limb
 // planes and applies the reference's keep test and quantisation.  On typical sketches (d = 2048) B is
 // about a fifth of the threshold and ~1e-4 of the unrelated pairs pass.

@@ -121,12 +121,11 @@ constexpr uint32_t kC1Lo = 0x1ce4e5b9u, kC1Hi = 0xbf58476du;
 
 template <int BPW>
 struct BatchGenShared {
-    const uint64_t (&h)[8];
-    const uint64_t cb0;          // 64 * first block + golden
+    const uint64_t (&x)[8];      // hash + 64 * first block + golden (the sums hazard() has looked at)
     int j = 0;
-    __device__ __forceinline__ BatchGenShared(const uint64_t (&h_)[8], uint64_t cb0_) : h(h_), cb0(cb0_) {}
+    __device__ __forceinline__ explicit BatchGenShared(const uint64_t (&x_)[8]) : x(x_) {}
     __device__ __forceinline__ void next(uint32_t (&lo)[BPW], uint32_t (&hi)[BPW]) {
-        const uint64_t x0 = h[j++] + cb0;
+        const uint64_t x0 = x[j++];
         const uint64_t t = x0 >> 30;
         const uint32_t x0l = (uint32_t)x0, tl = (uint32_t)t;
         const uint32_t zh = (uint32_t)(x0 >> 32) ^ (uint32_t)(t >> 32);
@@ -145,12 +144,13 @@ struct BatchGenShared {
     }
 };
 
-// true if some hash of the batch could carry out of bit 29 when 64 * b (b < 4) is added to h + cb0
-__device__ __forceinline__ bool hazard(const uint64_t (&h)[8], uint64_t cb0) {
+// x[j] = h[j] + cb0 for the batch; true if some hash of it could carry out of bit 29 when 64 * b (b < 4) is added
+__device__ __forceinline__ bool hazard(const uint64_t (&h)[8], uint64_t cb0, uint64_t (&x)[8]) {
     uint32_t least = 0xffffffffu;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const uint32_t xl = (uint32_t)h[j] + (uint32_t)cb0;
+        x[j] = h[j] + cb0;
+        const uint32_t xl = (uint32_t)x[j];
         const uint32_t miss = ~xl & 0x3fffff00u;                 // zero <=> bits 8..29 are all ones
         least = miss < least ? miss : least;
     }
@@ -265,8 +265,9 @@ __global__ __launch_bounds__(256) void k_project(const uint64_t* __restrict__ ha
 #pragma unroll
             for (int sb = 0; sb < 4; ++sb) {
                 load_batch<false>(hn, base, (b + sb + 1) << 9, lane, last);
-                if (SHARED && !hazard(hv, cb[0])) {
-                    BatchGenShared<BPW> g(hv, cb[0]);
+                uint64_t xv[8];
+                if (SHARED && !hazard(hv, cb[0], xv)) {
+                    BatchGenShared<BPW> g(xv);
                     absorb<3, BPW>(s, g, c8lo[sb], c8hi[sb]);
                 } else {
                     BatchGen<BPW, false> g(hv, cb, 0);
