@@ -11,6 +11,7 @@
 //
 // Layout (all little-endian u64 words)
 //   compact_vector : [size][width][n_words][words...]            value i at bit i*width
+//   elias_fano     : see the class (legacy int16 shard format only)
 //   rice_sequence  : [size][k][low: compact_vector of width k (absent when k == 0)]
 //                    [n_high_bits][n_words][high words...]       unary quotients: q zeros then a one
 //                    [n_samples][sample...]                      bit position after every 64th terminator
@@ -196,6 +197,104 @@ private:
         return q;
     }
     uint64_t m_size = 0, m_k = 0, m_high_bits = 0;
+    compact_vector m_low;
+    std::vector<uint64_t> m_high, m_samples;
+};
+
+// Elias-Fano coded non-decreasing sequence below a universe bound, with random access.  The legacy int16 shard
+// format stores a row's column list this way (src/pairwise_comp_optimized_16bits.cpp:294-297:
+// `ef.encode(cols.begin(), cols.size(), cols.back() + 1)`).
+// Layout: [size][universe][l][low: compact_vector of width l (absent when l == 0)]
+//         [n_high_bits][n_words][high words...]   per element: (high part - previous high part) zeros, then a one
+//         [n_samples][sample...]                  bit position after every 64th terminator
+class elias_fano {
+public:
+    template <typename It>
+    void encode(It begin, uint64_t n, uint64_t universe) {
+        m_size = n;
+        m_universe = universe;
+        m_l = (n && universe / n > 1) ? bit_width(universe / n) - 1 : 0;
+        std::vector<uint64_t> lows;
+        lows.reserve(n);
+        m_high.clear();
+        m_samples.clear();
+        uint64_t bitpos = 0, prev_high = 0, prev = 0;
+        It it = begin;
+        for (uint64_t i = 0; i < n; ++i, ++it) {
+            const uint64_t v = (uint64_t)*it;
+            if (v < prev || v >= universe) throw std::invalid_argument("elias_fano: sequence must ascend below the universe");
+            prev = v;
+            if ((i & 63) == 0) m_samples.push_back(bitpos);
+            const uint64_t h = m_l ? (v >> m_l) : v;
+            lows.push_back(m_l ? (v & ((1ULL << m_l) - 1)) : 0);
+            bitpos += h - prev_high;
+            prev_high = h;
+            const uint64_t w = bitpos >> 6;
+            if (m_high.size() <= w) m_high.resize(w + 1, 0);
+            m_high[w] |= 1ULL << (bitpos & 63);
+            ++bitpos;
+        }
+        m_high_bits = bitpos;
+        if (m_l) m_low.build(lows.begin(), n, m_l);
+    }
+    uint64_t size() const { return m_size; }
+    uint64_t universe() const { return m_universe; }
+    void decode(std::vector<uint64_t>& out) const {
+        out.resize(m_size);
+        uint64_t pos = 0, high = 0;
+        for (uint64_t i = 0; i < m_size; ++i) {
+            high += next_unary(pos);
+            out[i] = (high << m_l) | (m_l ? m_low.access(i) : 0);
+        }
+    }
+    uint64_t access(uint64_t i) const {
+        // the high part of element i = (position of its terminator) - i
+        uint64_t pos = m_samples[i >> 6];
+        for (uint64_t j = (i >> 6) << 6; j <= i; ++j) next_unary(pos);
+        const uint64_t high = pos - 1 - i;
+        return (high << m_l) | (m_l ? m_low.access(i) : 0);
+    }
+    uint64_t num_bytes() const {
+        return 8 * (3 + 2 + m_high.size() + 1 + m_samples.size()) + (m_l ? m_low.num_bytes() : 0);
+    }
+    void save(std::ostream& os) const {
+        put_u64(os, m_size);
+        put_u64(os, m_universe);
+        put_u64(os, m_l);
+        if (m_l) m_low.save(os);
+        put_u64(os, m_high_bits);
+        put_words(os, m_high);
+        put_words(os, m_samples);
+    }
+    void load(std::istream& is) {
+        m_size = get_u64(is);
+        m_universe = get_u64(is);
+        m_l = get_u64(is);
+        if (m_l > 63) throw std::runtime_error("elias_fano: corrupt header");
+        if (m_l) m_low.load(is);
+        m_high_bits = get_u64(is);
+        get_words(is, m_high);
+        get_words(is, m_samples);
+        if (m_samples.size() != (m_size + 63) / 64) throw std::runtime_error("elias_fano: corrupt samples");
+    }
+
+private:
+    uint64_t next_unary(uint64_t& pos) const {
+        uint64_t q = 0;
+        uint64_t w = pos >> 6;
+        uint64_t cur = m_high[w] >> (pos & 63);
+        uint64_t avail = 64 - (pos & 63);
+        while (cur == 0) {
+            q += avail;
+            ++w;
+            cur = m_high[w];
+            avail = 64;
+        }
+        q += (uint64_t)__builtin_ctzll(cur);
+        pos += q + 1;
+        return q;
+    }
+    uint64_t m_size = 0, m_universe = 0, m_l = 0, m_high_bits = 0;
     compact_vector m_low;
     std::vector<uint64_t> m_high, m_samples;
 };

@@ -62,6 +62,42 @@ int main(int argc, char* argv[]) {
             if (n) CHECK(back.access(n - 1) == v[n - 1]);
         }
     }
+    // elias_fano: ascending sequences (dense, sparse, repeats, a single element, universe = last + 1 as the legacy
+    // writer passes it); descending input is refused
+    for (int mode = 0; mode < 4; ++mode) {
+        for (size_t n : {size_t(1), size_t(2), size_t(64), size_t(65), size_t(129), size_t(5000)}) {
+            std::vector<uint64_t> v(n);
+            uint64_t cur = mode == 3 ? (1ULL << 33) : rng() % 50;
+            for (auto& x : v) {
+                x = cur;
+                cur += mode == 0 ? 1 : (mode == 1 ? rng() % 100000 : (mode == 2 ? rng() % 2 : 1 + rng() % 7));
+            }
+            mvs_codec::elias_fano ef;
+            ef.encode(v.begin(), v.size(), v.back() + 1);
+            std::stringstream ss;
+            ef.save(ss);
+            CHECK((uint64_t)ss.str().size() == ef.num_bytes());
+            mvs_codec::elias_fano back;
+            back.load(ss);
+            CHECK(back.size() == n && back.universe() == v.back() + 1);
+            std::vector<uint64_t> dec;
+            back.decode(dec);
+            CHECK(dec == v);
+            for (size_t i = 0; i < n; i += (n > 100 ? 37 : 1)) CHECK(back.access(i) == v[i]);
+            CHECK(back.access(n - 1) == v[n - 1]);
+        }
+    }
+    {
+        std::vector<uint64_t> bad = {5, 3};
+        mvs_codec::elias_fano ef;
+        bool threw = false;
+        try {
+            ef.encode(bad.begin(), bad.size(), 6);
+        } catch (const std::invalid_argument&) {
+            threw = true;
+        }
+        CHECK(threw);
+    }
     // shard writer/reader: rows with 1 entry, many entries, gaps; empty shard
     const std::string dir = argc > 1 ? std::string(argv[1]) : std::string("/tmp/mvs_codec_selftest/");
     std::filesystem::remove_all(dir);
@@ -87,6 +123,35 @@ int main(int argc, char* argv[]) {
         CHECK(back.size() == cells.size());
         for (size_t i = 0; i < cells.size(); ++i)
             CHECK(back[i].row == cells[i].row && back[i].col == cells[i].col && back[i].q == cells[i].q);
+    }
+    {   // legacy int16 shard (elias_fano columns + round(dot / d) values, zstd where libzstd is present): round trip
+        std::vector<mvs_cell> cells;
+        const int d = 2048;
+        for (int r = 0; r < 300; ++r) {
+            if (r % 11 == 4) continue;
+            const int cnt = r % 5 == 0 ? 1 : 1 + (int)(rng() % 30);
+            int col = (int)(rng() % 50);
+            for (int k = 0; k < cnt; ++k) {
+                cells.push_back(mvs_cell{r * 2 + 1, col, (int32_t)(d * (10 + rng() % 4000) + rng() % d), 0});
+                col += 1 + (int)(rng() % (k % 4 == 0 ? 50000 : 3));
+            }
+        }
+        const std::string sub = dir + "legacy16/";
+        CHECK(mvs_host::write_shard_legacy16(sub, cells.data(), cells.size(), d) > 0);
+        if (mvs_host::Zstd::get().ok) {
+            CHECK(std::filesystem::exists(sub + "matrix.bin.zst") && !std::filesystem::exists(sub + "matrix.bin"));
+            CHECK(std::filesystem::exists(sub + "row_index.bin.zst") && !std::filesystem::exists(sub + "row_index.bin"));
+        }
+        std::vector<mvs_cell> back;
+        CHECK(mvs_host::read_shard_legacy16(sub, back));
+        CHECK(back.size() == cells.size());
+        for (size_t i = 0; i < cells.size(); ++i)
+            CHECK(back[i].row == cells[i].row && back[i].col == cells[i].col &&
+                  back[i].dot == (int32_t)std::llround((double)cells[i].dot / d));
+        std::vector<mvs_cell> none;
+        CHECK(mvs_host::write_shard_legacy16(dir + "legacy16_empty/", none.data(), 0, d) == 0);
+        back.clear();
+        CHECK(mvs_host::read_shard_legacy16(dir + "legacy16_empty/", back) && back.empty());
     }
     {   // many rows: the multi-threaded writer produces the single-threaded writer's files byte for byte
         std::vector<mvs_cell> cells;

@@ -5,14 +5,15 @@
 
 int main(int argc, char* argv[]) {
     if (argc < 2) {
-        std::cerr << "Usage: " << argv[0] << " <shard_folder/>" << std::endl;
+        std::cerr << "Usage: " << argv[0] << " <shard_folder/> [--legacy16]" << std::endl;
         return 1;
     }
     std::string folder = argv[1];
     if (folder.empty() || folder.back() != '/') folder += '/';
+    const bool legacy16 = argc > 2 && std::string(argv[2]) == "--legacy16";   // lines are then "row col round(dot/d)"
     std::vector<mvs_cell> cells;
     try {
-        if (!mvs_host::read_shard(folder, cells)) {
+        if (!(legacy16 ? mvs_host::read_shard_legacy16(folder, cells) : mvs_host::read_shard(folder, cells))) {
             std::cerr << "Error opening shard files in " << folder << std::endl;
             return 1;
         }
@@ -22,7 +23,7 @@ int main(int argc, char* argv[]) {
     }
     std::string out;
     for (const mvs_cell& c : cells)
-        out += std::to_string(c.row) + " " + std::to_string(c.col) + " " + std::to_string(c.q) + "\n";
+        out += std::to_string(c.row) + " " + std::to_string(c.col) + " " + std::to_string(legacy16 ? c.dot : c.q) + "\n";
     std::cout << out;
     return 0;
 }

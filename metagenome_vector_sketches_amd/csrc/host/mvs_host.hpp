@@ -14,6 +14,7 @@
 #include <filesystem>
 #include <fstream>
 #include <iostream>
+#include <iterator>
 #include <sstream>
 #include <string>
 #include <exception>
@@ -21,6 +22,7 @@
 #include <thread>
 #include <vector>
 
+#include <dlfcn.h>
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -516,6 +518,145 @@ inline bool read_shard(const std::string& folder, std::vector<mvs_cell>& out) {
             c.col = (int32_t)col;
             c.dot = 0;
             c.q = (int32_t)jac.access(k);
+            out.push_back(c);
+        }
+    }
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// legacy int16 shard format (writer src/pairwise_comp_optimized_16bits.cpp:251-323; the reference has no reader
+// for it).  matrix.bin: per row elias_fano(cols, universe = last col + 1) then compact_vector(round(dot / d));
+// row_index.bin: compact_vector(rows) + compact_vector(byte offset of each row in matrix.bin); both files are
+// then compressed with zstd and the originals removed (:317-322, `system("zstd -f ...")`).  zstd is bound at run
+// time (libzstd.so.1); where it is missing the uncompressed files stay, which is also what the reference's
+// `zstd -f x && rm -f x` leaves behind when the command fails.
+// ---------------------------------------------------------------------------------------------------
+struct Zstd {
+    size_t (*bound)(size_t) = nullptr;
+    size_t (*compress)(void*, size_t, const void*, size_t, int) = nullptr;
+    size_t (*decompress)(void*, size_t, const void*, size_t) = nullptr;
+    unsigned long long (*content_size)(const void*, size_t) = nullptr;
+    unsigned (*is_error)(size_t) = nullptr;
+    bool ok = false;
+    Zstd() {
+        void* h = dlopen("libzstd.so.1", RTLD_NOW | RTLD_LOCAL);
+        if (!h) h = dlopen("libzstd.so", RTLD_NOW | RTLD_LOCAL);
+        if (!h) return;
+        bound = reinterpret_cast<decltype(bound)>(dlsym(h, "ZSTD_compressBound"));
+        compress = reinterpret_cast<decltype(compress)>(dlsym(h, "ZSTD_compress"));
+        decompress = reinterpret_cast<decltype(decompress)>(dlsym(h, "ZSTD_decompress"));
+        content_size = reinterpret_cast<decltype(content_size)>(dlsym(h, "ZSTD_getFrameContentSize"));
+        is_error = reinterpret_cast<decltype(is_error)>(dlsym(h, "ZSTD_isError"));
+        ok = bound && compress && decompress && content_size && is_error;
+    }
+    static const Zstd& get() {
+        static Zstd z;
+        return z;
+    }
+};
+
+inline bool read_whole_file(const std::string& path, std::string& bytes) {
+    std::ifstream in(path, std::ios::binary);
+    if (!in) return false;
+    bytes.assign(std::istreambuf_iterator<char>(in), std::istreambuf_iterator<char>());
+    return true;
+}
+
+// `zstd -f path && rm -f path` (level 3, the tool's default)
+inline bool zstd_file_and_remove(const std::string& path) {
+    const Zstd& z = Zstd::get();
+    std::string raw;
+    if (!z.ok || !read_whole_file(path, raw)) return false;
+    std::string out(z.bound(raw.size()), '\0');
+    const size_t n = z.compress(&out[0], out.size(), raw.data(), raw.size(), 3);
+    if (z.is_error(n)) return false;
+    std::ofstream os(path + ".zst", std::ios::binary);
+    os.write(out.data(), (std::streamsize)n);
+    os.close();
+    if (!os) return false;
+    fs::remove(path);
+    return true;
+}
+
+// contents of path, or of path.zst when only that exists
+inline bool read_maybe_zstd(const std::string& path, std::string& bytes) {
+    if (read_whole_file(path, bytes)) return true;
+    std::string packed;
+    const Zstd& z = Zstd::get();
+    if (!z.ok || !read_whole_file(path + ".zst", packed)) return false;
+    const unsigned long long n = z.content_size(packed.data(), packed.size());
+    if (n > (1ULL << 40)) return false;                       // unknown / error sentinel values are huge
+    bytes.assign((size_t)n, '\0');
+    const size_t got = z.decompress(&bytes[0], bytes.size(), packed.data(), packed.size());
+    return !z.is_error(got) && got == n;
+}
+
+// cells grouped by row with ascending columns (mvs_pairwise_rows order); returns the number of rows written
+inline uint64_t write_shard_legacy16(const std::string& folder, const mvs_cell* cells, size_t n_cells, int dimension) {
+    if (!fs::exists(folder)) fs::create_directories(folder);
+    const std::string bin_filename = folder + "matrix.bin", index_filename = folder + "row_index.bin";
+    std::ofstream bin_out(bin_filename, std::ios::binary);
+    std::ofstream index_out(index_filename, std::ios::binary);
+    std::vector<int32_t> row_vec;
+    std::vector<int64_t> curr_pos_vec;
+    int64_t current_pos = 0;
+    for (size_t i = 0; i < n_cells;) {
+        size_t j = i;
+        while (j < n_cells && cells[j].row == cells[i].row) ++j;
+        std::vector<int32_t> cols(j - i);
+        std::vector<int64_t> vals(j - i);
+        for (size_t k = i; k < j; ++k) {
+            cols[k - i] = cells[k].col;
+            vals[k - i] = (int64_t)std::round((double)cells[k].dot / (double)dimension);        // :274-279
+        }
+        row_vec.push_back(cells[i].row);
+        curr_pos_vec.push_back(current_pos);
+        mvs_codec::elias_fano ef;
+        ef.encode(cols.begin(), cols.size(), (uint64_t)cols.back() + 1);                      // :294-296
+        ef.save(bin_out);
+        current_pos += (int64_t)ef.num_bytes();
+        mvs_codec::compact_vector cv;
+        cv.build(vals.begin(), vals.size());                                                   // :299-302
+        cv.save(bin_out);
+        current_pos += (int64_t)cv.num_bytes();
+        i = j;
+    }
+    bin_out.close();
+    mvs_codec::compact_vector cv_rows, cv_pos;
+    cv_rows.build(row_vec.begin(), row_vec.size());
+    cv_rows.save(index_out);
+    cv_pos.build(curr_pos_vec.begin(), curr_pos_vec.size());
+    cv_pos.save(index_out);
+    index_out.close();
+    if (!zstd_file_and_remove(bin_filename) || !zstd_file_and_remove(index_filename))
+        std::cerr << "zstd not available: " << bin_filename << " / " << index_filename << " left uncompressed" << std::endl;
+    return row_vec.size();
+}
+
+// decode the legacy int16 shard back into (row, col, value = round(dot / d)) triples (value in mvs_cell::dot, q = 0)
+inline bool read_shard_legacy16(const std::string& folder, std::vector<mvs_cell>& out) {
+    std::string bin, index;
+    if (!read_maybe_zstd(folder + "matrix.bin", bin) || !read_maybe_zstd(folder + "row_index.bin", index)) return false;
+    std::istringstream index_in(index, std::ios::binary), bin_in(bin, std::ios::binary);
+    mvs_codec::compact_vector cv_rows, cv_pos;
+    cv_rows.load(index_in);
+    cv_pos.load(index_in);
+    for (uint64_t r = 0; r < cv_rows.size(); ++r) {
+        bin_in.seekg((std::streamoff)cv_pos.access(r));
+        mvs_codec::elias_fano ef;
+        ef.load(bin_in);
+        mvs_codec::compact_vector cv;
+        cv.load(bin_in);
+        if (ef.size() != cv.size()) throw std::runtime_error("legacy shard: row lengths disagree");
+        std::vector<uint64_t> cols;
+        ef.decode(cols);
+        for (uint64_t k = 0; k < cols.size(); ++k) {
+            mvs_cell c;
+            c.row = (int32_t)cv_rows.access(r);
+            c.col = (int32_t)cols[k];
+            c.dot = (int32_t)cv.access(k);
+            c.q = 0;
             out.push_back(c);
         }
     }

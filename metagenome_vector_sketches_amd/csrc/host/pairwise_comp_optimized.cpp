@@ -94,6 +94,13 @@ struct Gpu {
     }
 };
 
+// MVS_INT16_LEGACY_OUTPUT=1: an int16 DB's shard in the reference's legacy format (elias_fano columns +
+// round(dot / d) values + zstd, _16bits.cpp:251-323) instead of the active, queryable one
+static bool legacy16_output() {
+    const char* e = getenv("MVS_INT16_LEGACY_OUTPUT");
+    return e && e[0] == '1';
+}
+
 static int gpu_fail(const char* what) {
     std::cerr << "pairwise_comp_optimized: " << what << ": " << mvs_last_error() << std::endl;
     return 2;
@@ -433,6 +440,11 @@ int main(int argc, char* argv[]) {
         auto duration = std::chrono::duration_cast<std::chrono::milliseconds>(end_time - start_time);
         std::cout << "Total computation time: " << duration.count() << " ms" << std::endl;
         std::cout << "Total results: " << all_results.size() << std::endl;
+    }
+    if (int16 && legacy16_output()) {   // the reference's own output for an int16 DB (_16bits.cpp:251-323, :426)
+        write_shard_legacy16(shard_folder, all_results.data(), all_results.size(), dimension);
+        lap("write shard (legacy int16 format)");
+        return 0;
     }
     const ShardStats st = write_shard(shard_folder, all_results.data(), all_results.size());          // :990
     lap("write shard");

@@ -140,6 +140,43 @@ def test_pairwise_int16_db(gold, tmp_path):
     assert _dump(os.path.join(out, "shard_0")) == sorted((r_, c, q) for r_, c, _, q in gold.cells(int16=True))
 
 
+def test_pairwise_int16_db_legacy_output(gold, tmp_path):
+    """MVS_INT16_LEGACY_OUTPUT=1: the reference's own output for an int16 DB (_16bits.cpp:251-323): per row the
+    Elias-Fano coded columns and round(dot / d), both files zstd frames, originals removed (:317-322)."""
+    import ctypes
+    db = str(tmp_path / "refdb16") + "/"
+    _write_ref_db(db, gold, "int16")
+    out = str(tmp_path / "idx16")
+    env = dict(os.environ, MVS_INT16_LEGACY_OUTPUT="1")
+    r = subprocess.run([os.path.join(BIN, "pairwise_comp_optimized"), "--db", db, "--max_memory_gb", "1",
+                        "--num_threads", "8", "--output_folder", out, "--num_shards", "1", "--shard_idx", "0"],
+                       capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    assert "dtyeom" in r.stdout and "Total results: 1293" in r.stdout
+    shard = os.path.join(out, "shard_0")
+    try:
+        zstd = ctypes.CDLL("libzstd.so.1")
+    except OSError:
+        zstd = None
+    if zstd is not None:
+        assert sorted(os.listdir(shard)) == ["matrix.bin.zst", "row_index.bin.zst"]
+        for f in os.listdir(shard):
+            data = open(os.path.join(shard, f), "rb").read()
+            assert data[:4] == bytes.fromhex("28b52ffd")                       # a zstd frame, as the zstd tool writes
+            zstd.ZSTD_getFrameContentSize.restype = ctypes.c_ulonglong
+            n = zstd.ZSTD_getFrameContentSize(data, len(data))
+            buf = ctypes.create_string_buffer(int(n))
+            zstd.ZSTD_decompress.restype = ctypes.c_size_t
+            assert zstd.ZSTD_decompress(buf, int(n), data, len(data)) == n      # decodes with the stock library
+    else:
+        assert sorted(os.listdir(shard)) == ["matrix.bin", "row_index.bin"]
+    rr = run(os.path.join(BIN, "mvs_dump_matrix"), shard, "--legacy16")
+    assert rr.returncode == 0, rr.stderr
+    got = [tuple(int(t) for t in l.split()) for l in rr.stdout.strip().split("\n") if l]
+    want = sorted((r_, c, int(np.floor(dot / 2048.0 + 0.5))) for r_, c, dot, _ in gold.cells(int16=True))   # std::round, dots > 0
+    assert got == want
+
+
 def test_pairwise_after_own_sketch(toy_db, gold, tmp_path):
     """whole config-1 pipeline with OUR vector_norms.txt (3 of 61 lines may differ in the 6th digit):
     kept set must still equal what the oracle gives on the same files"""
