@@ -28,6 +28,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 INT8_MFMA_PEAK_TOPS = 5000.0   # dense int8 MFMA = 2x bf16 = ~5 POP/s
+FP64_MATRIX_PEAK_TFLOPS = 78.6  # nominal fp64 matrix peak of the part (datasheet figure, not measured here)
 VALU_INT_PEAK_TOPS = 78.6      # 256 CU x 4 SIMD-32 x 32 lanes x 2.4 GHz int32 lane-ops/s (MI355X_MICROARCH.md)
 VALU_ISSUE_PEAK_GIPS = 1228.8  # wave64 VALU instructions/s: 1024 SIMDs x 2.4 GHz / 2 cycles per instruction
 K1_VALU_PER_HASH_BLOCK = 22.4  # VALU instructions per (hash, 64-dim block) and lane in k_project (four blocks per wave
@@ -488,7 +489,10 @@ def pairwise_leg(ctx, dev, n, d, nh, reps):
                              "algorithmic_frac": flops / (ex["kernels_ms"] * 1e-3) / 1e12 / INT8_MFMA_PEAK_TOPS,
                              "issued_frac": 4.0 * flops * (0.5 + 0.5 * 128.0 / n) / (ex["kernels_ms"] * 1e-3) / 1e12 /
                              INT8_MFMA_PEAK_TOPS},
-            "traffic": traffic.get("k_pairwise_pp_filter"), "traffic_recheck": traffic.get("k_exact_pairs"),
+            # the only single-pass exact matrix type would be fp64 (78.6 TFLOP/s dense on MI355X)
+            "vs_fp64_matrix_peak": flops / (two["kernels_ms"] * 1e-3) / 1e12 / FP64_MATRIX_PEAK_TFLOPS,
+            "traffic": traffic.get("k_pairwise_pp_filter"),
+            "traffic_recheck": traffic.get("k_exact_pairs_tree", traffic.get("k_exact_pairs")),
             "traffic_source": src,
             "algorithmic_bytes": float(n) * d * limbs + 16.0 * two["kept_cells"]}
     leg = {"cells_per_s": cells_total / (two["wall_ms"] * 1e-3), "cells_per_s_kernels": cells_total / (two["kernels_ms"] * 1e-3),
