@@ -654,6 +654,12 @@ def cpu_baseline(hashes, offsets, S, NH, D, dev):
                              "section 3 table: 1.0-2.2x the reference's speed, the faster port is used); pairwise port NOT "
                              "calibrated against the reference (unbuildable: `bits` submodule absent)")
     detail["host_threads_visible"] = visible
+    try:                                                  # state the host CPU the baseline ran on
+        with open("/proc/cpuinfo") as f:
+            models = [l.split(":", 1)[1].strip() for l in f if l.startswith("model name")]
+        detail["host_cpu_model"] = models[0] if models else None
+    except Exception:   # noqa: BLE001
+        detail["host_cpu_model"] = None
     return {"value": S / t_job, "unit": "samples/s (projected and compared all-vs-all)", "cores": cores,
             "kind": "port",
             "sample": "projection: %s samples x %d hashes per thread count %s, faster of the literal and the restructured "
