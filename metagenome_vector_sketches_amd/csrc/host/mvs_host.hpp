@@ -345,6 +345,16 @@ inline std::string format_g_float(float v) { return format_g((double)v); }
 // norm of one sketch: the reference takes the float32 path (cast / sqrt(float d), Eigen norm) whose
 // last digit is not reproducible; this build defines it as sqrt(double(sumsq) / d).
 inline double norm_from_sumsq(int64_t sumsq, int d) { return std::sqrt((double)sumsq / (double)d); }
+// the float32 evaluation of src/project_everything.cpp:328-329, summed in index order
+inline float norm_float32_path(const int32_t* v, int d) {
+    const float root = std::sqrt((float)d);
+    float acc = 0.0f;
+    for (int k = 0; k < d; ++k) {
+        const float f = (float)v[k] / root;
+        acc += f * f;
+    }
+    return std::sqrt(acc);
+}
 
 struct DbInfo {
     std::string dtype = "int32";

@@ -224,8 +224,17 @@ static int sketch(const std::string& hash_file, std::string index_folder, int di
     if (norm_out && bin_out && dim_out && dtype_out) {
         dim_out << dimension << "\n";                                                                  // :319
         dtype_out << (use_int16 ? "int16" : "int32") << "\n";                                          // :320
-        for (int64_t i = 0; i < n; ++i)                                                                // :328-330
-            norm_out << sets.names[(size_t)i] << " " << format_g(norm_from_sumsq(sumsq[(size_t)i], dimension)) << "\n";
+        // MVS_NORM_FLOAT32=1: the reference's float32 evaluation (`vec.cast<float>() / sqrt(dimension)`, then Eigen's
+        // float norm, :328-329) in sequential order instead of this build's sqrt(double(sum v^2) / d).  The
+        // reference's own last digit depends on its vectorised summation order and -ffast-math, so this
+        // is the closest defined stand-in, not a bit-exact reproduction.
+        const char* nf = getenv("MVS_NORM_FLOAT32");
+        const bool norm_f32 = nf && nf[0] == '1';
+        for (int64_t i = 0; i < n; ++i) {                                                              // :328-330
+            double norm = norm_from_sumsq(sumsq[(size_t)i], dimension);
+            if (norm_f32) norm = (double)norm_float32_path(vectors.data() + (size_t)i * (size_t)dimension, dimension);
+            norm_out << sets.names[(size_t)i] << " " << format_g(norm) << "\n";
+        }
         if (use_int16) {                                                                               // :332-347
             std::vector<int16_t> v16(vectors.size());
             if (mvs_sketch_saturate_i16(ctx, vectors.data(), MVS_MEM_HOST, (int64_t)vectors.size(), v16.data(),

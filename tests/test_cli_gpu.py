@@ -88,6 +88,27 @@ def test_standalone_projection_text_protocol(gold, tmp_path):
         assert r.stdout == case["stdout"], key       # the reference binary's stdout, byte for byte
 
 
+def test_sketch_float32_norm_switch(toy_db, gold, tmp_path):
+    """MVS_NORM_FLOAT32=1: vector_norms.txt from the float32 evaluation of project_everything.cpp:328-329 (in index
+    order; the oracle's norm_f32path).  Same vectors; every line within 1e-5 of the reference's file, and equal to the
+    oracle's float32 path printed with %g."""
+    from oracle import pyoracle as orc
+    d, db, _ = toy_db
+    out = str(tmp_path / "db32")
+    r = subprocess.run([os.path.join(BIN, "project_everything"), "sketch", str(d / "toy_hashes.txt"), out, "-d", "2048"],
+                       capture_output=True, text=True, env=dict(os.environ, MVS_NORM_FLOAT32="1", MVS_NO_CSR_CACHE="1"))
+    assert r.returncode == 0, r.stderr
+    assert open(out + "/vectors.bin", "rb").read() == open(db + "vectors.bin", "rb").read()
+    got = open(out + "/vector_norms.txt").read().strip().split("\n")
+    ref = gold.norm_lines()
+    assert len(got) == len(ref) == 61
+    for i, (g, rline) in enumerate(zip(got, ref)):
+        gn, gv = g.split(" ")
+        rn, rv = rline.split(" ")
+        assert gn == rn and abs(float(gv) - float(rv)) <= 1e-5 * float(rv) + 1e-12
+        assert gv == orc.format_norm(orc.norm_f32path(gold.vectors[i]))
+
+
 def _dump(shard):
     r = run(os.path.join(BIN, "mvs_dump_matrix"), shard)
     assert r.returncode == 0, r.stderr
