@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the sketch + pairwise hot path on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W
+
+N > 1 either way: under a launcher (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`: RANK /
+WORLD_SIZE come from the environment) or plain (`python bench.py --gpus N ...`: this process starts N fresh workers
+itself before it touches torch or HIP, relays rank 0's line and returns the worst exit code -- launch_workers()).
 
 Workload (BASELINE.json configs[1]): per GPU 10 000 synthetic FracMinHash-like samples x 50 000 hashes,
 d = 2048.  One "step" = one pass of the whole hot path over that batch with the hash lists already
@@ -92,6 +96,66 @@ def fast_norm_sq(sumsq, d):
     return out * out
 
 
+def launch_workers(n, argv, script=None, python=None, env=None, poll_s=0.05, grace_s=20.0):
+    """`bench.py --gpus N` started WITHOUT a launcher (no RANK / WORLD_SIZE in the environment): this process becomes
+    the parent of N fresh workers -- the same script with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT
+    set, one per GPU, which is the reference's own way of distributing (one process per shard,
+    src/pairwise_comp_optimized.cpp:937-940).  The parent never imports torch and never touches HIP (a process that has
+    initialised the GPU must not be replaced or forked); it relays rank 0's stdout (the ONE JSON line) and returns the
+    worst child exit code.  When a worker dies, the others -- which would wait in the next collective for ever, RCCL has
+    no timeout -- get `grace_s` seconds and are then terminated (by the exact PIDs started here)."""
+    import socket
+    import subprocess
+    script = script or os.path.abspath(__file__)
+    python = python or sys.executable
+    base = dict(os.environ if env is None else env)
+    base.setdefault("MASTER_ADDR", "127.0.0.1")
+    if "MASTER_PORT" not in base:
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+            sk.bind(("127.0.0.1", 0))
+            base["MASTER_PORT"] = str(sk.getsockname()[1])
+    base["WORLD_SIZE"] = base["LOCAL_WORLD_SIZE"] = str(n)
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL between processes needs it on this driver
+    procs = []
+    for r in range(n):
+        e = dict(base, RANK=str(r), LOCAL_RANK=str(r), GROUP_RANK="0")
+        # rank 0's stdout is the bench line; whatever the other ranks print must not land next to it
+        procs.append(subprocess.Popen([python, script] + list(argv), env=e,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    out0 = []
+    import threading
+    reader = threading.Thread(target=lambda: out0.extend(procs[0].stdout.read().decode("utf-8", "replace").splitlines()))
+    reader.start()
+    first_fail = None
+    while any(p.poll() is None for p in procs):
+        codes = [p.poll() for p in procs]
+        if first_fail is None and any(c not in (None, 0) for c in codes):
+            first_fail = time.monotonic()
+        if first_fail is not None and time.monotonic() - first_fail > grace_s:
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            first_fail = time.monotonic() + 3600.0          # terminate once; kill below if that is ignored too
+            deadline = time.monotonic() + 10.0
+            while any(p.poll() is None for p in procs) and time.monotonic() < deadline:
+                time.sleep(poll_s)
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+        time.sleep(poll_s)
+    reader.join()
+    for line in out0:
+        print(line, flush=True)
+    codes = [p.returncode for p in procs]
+    worst = 0
+    for c in codes:
+        if c != 0:
+            worst = max(worst, c if c > 0 else 128 - c)      # killed by signal s: 128 + s, as a shell reports it
+    if worst:
+        print("bench.py: worker exit codes %s" % codes, file=sys.stderr)
+    return worst
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -113,10 +177,17 @@ def main():
     ap.add_argument("--cluster", type=int, default=16, help="related samples per cluster (256: the dense variant)")
     ap.add_argument("--lognormal-sigma", type=float, default=0.0,
                     help="> 0: ragged samples, sizes ~ lognormal(ln hashes, sigma) clipped to [100, 2e6] (SURVEY 8d)")
+    ap.add_argument("--overlap-parts", type=int, default=2,
+                    help="N > 1: pieces the rank's samples are projected in; the all-gather of a finished piece's limb "
+                         "planes runs beside the projection of the next (1: no overlap)")
     ap.add_argument("--host-input", action="store_true",
                     help="also time the step with the hash lists handed over as host buffers (PCIe inclusive; "
                          "reported as pcie_inclusive, never as value)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher (before torch / HIP are touched in this process)
+        sys.exit(launch_workers(args.gpus, sys.argv[1:]))
 
     import torch
     import torch.distributed as dist
@@ -150,27 +221,33 @@ def main():
     from metagenome_vector_sketches_amd import parallel, _capi
     coll, coll_note = None, None
     if world > 1:
-        # the data path's collectives go through the C ABI's RCCL communicator (the id travels over torch.distributed);
-        # should that fail on a node we could never try, torch.distributed's own collectives carry the exchange
+        # The data path's collectives go through the C ABI's communicator.  It gets a context of its own on a SIDE stream
+        # so that the exchange of the rows a rank has finished can run beside the projection of the rest (parallel.py:
+        # begin / feed / finish); ShardedComparison orders the two streams around every exchange.  RCCL: the 128-byte id
+        # travels over torch.distributed; should creating the communicator fail on a node this build could never try,
+        # torch.distributed's own collectives carry the exchange (on the same side stream) and the line says so.
+        side = torch.cuda.Stream(device=dev)
+        ctx_comm = pkg.Context(dev_index)
+        ctx_comm.set_stream(side)
         try:
             if rehearsal:
-                comm = ctx.comm_files(os.path.join(os.environ.get("TMPDIR", "/tmp"), "mvs_bench_%s" %
-                                                   os.environ.get("MASTER_PORT", "0")), rank, world)
+                comm = ctx_comm.comm_files(os.path.join(os.environ.get("TMPDIR", "/tmp"), "mvs_bench_%s" %
+                                                        os.environ.get("MASTER_PORT", "0")), rank, world)
             else:
                 uid = torch.zeros(_capi.COMM_ID_BYTES, dtype=torch.uint8, device=dev)
                 if rank == 0:
                     uid.copy_(torch.frombuffer(bytearray(_capi.comm_unique_id()), dtype=torch.uint8))
                 dist.broadcast(uid, src=0)
-                comm = ctx.comm_rccl(bytes(uid.cpu().numpy().tobytes()), rank, world)
-            coll = parallel.NativeCollectives(comm)
+                comm = ctx_comm.comm_rccl(bytes(uid.cpu().numpy().tobytes()), rank, world)
+            coll = parallel.NativeCollectives(comm, stream=side)
         except Exception as e:      # noqa: BLE001 -- any failure here must not take the benchmark down
             coll_note = "native communicator failed (%s: %s); torch.distributed carries the exchange" % (type(e).__name__, e)
-            coll = parallel.TorchCollectives(dist, rank, world)
+            coll = parallel.TorchCollectives(dist, rank, world, stream=side)
         ok = torch.tensor([1 if isinstance(coll, parallel.NativeCollectives) else 0], device=dev)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if int(ok.item()) == 0 and isinstance(coll, parallel.NativeCollectives):   # all ranks use the same transport
             coll_note = "another rank could not create the native communicator; torch.distributed carries the exchange"
-            coll = parallel.TorchCollectives(dist, rank, world)
+            coll = parallel.TorchCollectives(dist, rank, world, stream=side)
 
     if args.config != 2:
         res = strong_scaling(args, ctx, dev, rank, world, dist if world > 1 else None, coll, coll_note)
@@ -195,18 +272,38 @@ def main():
     torch.cuda.synchronize()
 
     sc = parallel.ShardedComparison(parallel.GpuOps(ctx, dev), rank, world, collectives=coll)
+    sc.time_gather = world > 1
     state = {}
 
+    o_host = np.ascontiguousarray(np.asarray(offsets), dtype=np.int64)
+    # N > 1: the rank's samples are projected in `overlap_parts` pieces and the limb planes of a finished piece go into
+    # the all-gather while the next piece is being projected; N = 1: one piece (nothing to overlap) -- the same step()
+    n_parts = 1 if world == 1 else max(1, args.overlap_parts)
+    bounds = sc.part_bounds(N_total, n_parts)
+
     def step():
-        # K1; the sums of squares and max |v| come out of the same kernel
-        max_abs = ctx.project_csr_stats(hashes, offsets, D, sketches, sumsq)
-        ctx.norms_sq_text(sumsq, D, out=n2_local)       # text round trip of the norms (vector_norms.txt), on the device
-        # limb split, [all-gather of plane row blocks + norms], K2 on this rank's rows x all columns
-        _, cnt, info = sc.run(sketches, n2_local, N_total, cells_out=cells, max_abs_local=max_abs)
+        sc.begin(sketches, n2_local, N_total)
+        k1 = 0.0
+        for (p0, p1) in bounds:
+            q0, q1 = min(p0, S), min(p1, S)
+            m = 0
+            if q1 > q0:
+                # K1; the sums of squares and max |v| come out of the same kernel
+                m = ctx.project_csr_stats(hashes, o_host[q0:q1 + 1], D, sketches[q0:q1], sumsq[q0:q1])
+                k1 += ctx.kernel_ms(0)
+                # text round trip of the norms (vector_norms.txt), on the device
+                ctx.norms_sq_text(sumsq[q0:q1], D, out=n2_local[q0:q1])
+            # limb split of these rows, [all-gather of exactly these rows of every rank's block, on the side stream]
+            sc.feed(p0, p1, m)
+        # [all-gather of the norms, streams joined], K2 on this rank's share of the block plan, kept cells sorted
+        _, cnt, info = sc.finish(cells_out=cells)
+        state["k1_ms"] = k1
         state["cnt"] = cnt
         state["candidates"] = ctx.pairwise_candidates()
         state["limbs"] = info["limbs"]
         state["schedule"] = info.get("schedule", "rows x all columns")
+        state["allgather_bytes_per_rank"] = info["allgather_bytes_per_rank"]
+        state["overlap"] = info["overlap"]
 
     def sync_all():
         if world > 1:
@@ -216,12 +313,13 @@ def main():
     for _ in range(args.warmup):
         step()
     sync_all()
-    k1_ms, k2_ms = [], []
+    k1_ms, k2_ms, gather_ms = [], [], []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         sc.ops.k2_ms = 0.0
         step()
-        k1_ms.append(ctx.kernel_ms(0))
+        k1_ms.append(state["k1_ms"])
+        gather_ms.append(sc.last_gather_ms())    # events recorded before the comparison: already complete
         # symmetric multi-rank schedule: several comparison launches per step (summed by GpuOps)
         k2_ms.append(sc.ops.k2_ms if sc.ops.k2_ms > 0 else ctx.kernel_ms(1))
     sync_all()
@@ -279,11 +377,15 @@ def main():
                    "cluster": args.cluster, "lognormal_sigma": args.lognormal_sigma,
                    "hashes_per_gpu": int(total_hashes),
                    "limbs": limbs, "kept_cells": kept_total, "parallelism": "row shards x%d" % world,
-                   "schedule": state["schedule"],
-                   "collectives": (coll.kind if coll is not None else "none"), "collectives_note": coll_note},
+                   "schedule": state["schedule"], "projection_parts": len(bounds), "overlap": state["overlap"],
+                   "collectives": (coll.kind if coll is not None else "none"), "collectives_note": coll_note,
+                   **comm_facts(coll, world)},
         "cells_per_s": cells_per_step / (elapsed / args.steps),
         "stages": {"projection_kernel_ms": k1, "projection_samples_per_s_per_gpu": S / (k1 * 1e-3),
                    "pairwise_kernel_ms": k2, "pairwise_cells_per_s_per_gpu": S * float(N_total) / (k2 * 1e-3),
+                   "allgather_ms": float(np.mean(gather_ms)) if world > 1 else 0.0,
+                   "allgather_bytes_per_rank": state.get("allgather_bytes_per_rank", 0),
+                   "allgather_bytes_received_per_rank": state.get("allgather_bytes_per_rank", 0) * (world - 1),
                    "other_ms": ms_per_step - k1 - k2},
         # the dominant kernel of the step.  The contract prices it against HBM (algorithmic bytes = 8 n_i + 4 d per
         # sample); the +-1 matrix is generated from the hashes, so the kernel's binding bound is integer-VALU issue:
@@ -354,6 +456,16 @@ def main():
         dist.destroy_process_group()
 
 
+def comm_facts(coll, world):
+    """what mvs_comm_info says about the communicator that carried the exchange: `rccl_ranks` answers "did RCCL see N
+    ranks" (0: the exchange did not go through the library's RCCL communicator -- one rank, the file transport of a
+    rehearsal, or torch.distributed's collectives after a fallback)"""
+    comm = getattr(coll, "comm", None)
+    if comm is None:
+        return {"rccl_ranks": 0, "comm_world": world if coll is not None else 1}
+    return {"rccl_ranks": comm.world if comm.is_rccl else 0, "comm_world": comm.world, "comm_rank0": comm.rank}
+
+
 def strong_scaling(args, ctx, dev, rank, world, dist, coll, coll_note):
     """--config 3 / 4 / 5: BASELINE.json configs[2] / [3] / [4] -- pairwise only, a FIXED number of synthesised sketches
     split over the ranks by the reference's shard formula.  One step = re-code this rank's rows into its block of the
@@ -418,7 +530,7 @@ def strong_scaling(args, ctx, dev, rank, world, dist, coll, coll_note):
                                    (args.config - 1, n_total, d, world),
                        "total_samples": n_total, "d": d, "limbs": info["limbs"], "kept_cells": kept,
                        "schedule": info.get("schedule", "rows x all columns"),
-                       "collectives": info.get("collectives"), "collectives_note": coll_note},
+                       "collectives": info.get("collectives"), "collectives_note": coll_note, **comm_facts(coll, world)},
             "stages": {"comparison_kernels_ms_max_over_ranks": k2_max, "allgather_ms_max_over_ranks": gather_max,
                        "allgather_bytes_per_rank": info["allgather_bytes_per_rank"],
                        "allgather_bytes_received_per_rank": info["allgather_bytes_per_rank"] * (world - 1),

@@ -100,6 +100,7 @@ int mvs_ctx_kernel_ms(mvs_ctx* ctx, int which, float* ms);
  *   project_variant       projection kernel: 0 (default) by dimension -- 14 = four 64-dim blocks per wave sharing the
  *                         first splitmix64 round when d is a multiple of 256 (>= 512), else 2 or 1 blocks per wave;
  *                         1 / 2 / 12 / 14 force a variant
+ *   comm_timeout_s        file transport (mvs_comm_create_files / _rendezvous): seconds a rank waits for its peers
  *   markers               1: roctx ranges named after the entry points around mvs_project_csr / mvs_pairwise_rows /
  *                         mvs_pairwise_block (rocprofv3 --marker-trace); libroctx64 is bound at run time
  *   pairwise_debug        profiling aids, bit mask: 1 / 2 skip the k-loop / the epilogue (such runs produce garbage by
@@ -306,13 +307,28 @@ int mvs_comm_create(mvs_ctx* ctx, const void* id, int rank, int world, mvs_comm*
 int mvs_comm_create_callbacks(mvs_ctx* ctx, const mvs_comm_callbacks* callbacks, int rank, int world, mvs_comm** comm);
 /* File transport: ranks exchange their blocks through files named <path_prefix>_<sequence>_<rank> in a directory
  * all of them can reach.  For ranks that share one device (RCCL refuses that) and for one-GPU test boxes; every
- * rank must pass the same prefix, unique to the job. */
+ * rank passes the same prefix.  Collective: the call returns when all `world` ranks have met under the prefix and
+ * agreed on a job nonce (option comm_timeout_s, default 600, bounds the wait); every block carries that nonce and its
+ * sequence number, so files an earlier job left under the same prefix are never read as this job's data, and a rank
+ * removes its own files when it fails and when the communicator is destroyed. */
 int mvs_comm_create_files(mvs_ctx* ctx, const char* path_prefix, int rank, int world, mvs_comm** comm);
+/* RCCL communicator for shard processes that share nothing but a directory (how the reference's shard processes
+ * relate: one process per --shard_idx, src/pairwise_comp_optimized.cpp:937-940): the ranks meet through the file
+ * transport's handshake above, rank 0's id (mvs_comm_unique_id) travels as one verified block, the meeting point is
+ * removed again, then mvs_comm_create.  Replaces "rank 0 leaves the id in a file": a file a previous job left behind
+ * can no longer be taken for this job's id. */
+int mvs_comm_create_rendezvous(mvs_ctx* ctx, const char* path_prefix, int rank, int world, mvs_comm** comm);
 int mvs_comm_destroy(mvs_comm* comm);
 int mvs_comm_info(const mvs_comm* comm, int* rank, int* world, int* is_rccl);
 /* planes: the global plane buffer (mvs_limb_geometry of rows_per_rank * world rows); rank r has filled rows
  * [r * rows_per_rank, (r+1) * rows_per_rank).  After the call (on the stream) every block is present. */
 int mvs_allgather_planes(mvs_ctx* ctx, mvs_comm* comm, int8_t* planes, int64_t rows_per_rank, int limbs, int d_pad);
+/* The same for a sub-range of every rank's block: rows [row_first, row_first + row_count) of each block of
+ * rows_per_rank rows (each rank has filled that sub-range of ITS block).  A rank can thus hand over the rows it has
+ * finished while it is still producing the rest -- e.g. sketch the first half of its samples, start this exchange on
+ * the communicator's stream, sketch the second half meanwhile (metagenome_vector_sketches_amd/parallel.py does). */
+int mvs_allgather_rows(mvs_ctx* ctx, mvs_comm* comm, int8_t* planes, int64_t rows_per_rank, int64_t row_first,
+                       int64_t row_count, int limbs, int d_pad);
 /* values: DEVICE array of world * count_per_rank doubles (e.g. squared norms), block `rank` filled in */
 int mvs_allgather_f64(mvs_ctx* ctx, mvs_comm* comm, double* values, int64_t count_per_rank);
 /* any DEVICE buffer of world * bytes_per_rank bytes (e.g. kept cells that belong to other ranks' rows) */

@@ -75,9 +75,11 @@ SYMBOLS = [
     ("mvs_comm_create", _c.c_int, [_P, _P, _c.c_int, _c.c_int, _c.POINTER(_P)]),
     ("mvs_comm_create_callbacks", _c.c_int, [_P, _P, _c.c_int, _c.c_int, _c.POINTER(_P)]),
     ("mvs_comm_create_files", _c.c_int, [_P, _c.c_char_p, _c.c_int, _c.c_int, _c.POINTER(_P)]),
+    ("mvs_comm_create_rendezvous", _c.c_int, [_P, _c.c_char_p, _c.c_int, _c.c_int, _c.POINTER(_P)]),
     ("mvs_comm_destroy", _c.c_int, [_P]),
     ("mvs_comm_info", _c.c_int, [_P, _c.POINTER(_c.c_int), _c.POINTER(_c.c_int), _c.POINTER(_c.c_int)]),
     ("mvs_allgather_planes", _c.c_int, [_P, _P, _P, _c.c_int64, _c.c_int, _c.c_int]),
+    ("mvs_allgather_rows", _c.c_int, [_P, _P, _P, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int, _c.c_int]),
     ("mvs_allgather_f64", _c.c_int, [_P, _P, _P, _c.c_int64]),
     ("mvs_allgather_bytes", _c.c_int, [_P, _P, _P, _c.c_int64]),
     ("mvs_allreduce_max_i64", _c.c_int, [_P, _P, _c.POINTER(_c.c_int64)]),
@@ -89,9 +91,10 @@ _lib = None
 
 
 class MvsError(RuntimeError):
-    def __init__(self, code, message):
+    def __init__(self, code, message, needed=None):
         super().__init__("libmvs_hip error %d: %s" % (code, message))
         self.code = code
+        self.needed = needed     # MVS_E_CAPACITY: the size the call reported it needs
 
 
 def load_library():
@@ -188,6 +191,13 @@ class Comm:
             raise ValueError("planes must be a device buffer")
         _check(self.ctx.lib.mvs_allgather_planes(self.ctx._h, self._h, pp, int(rows_per_rank), int(limbs), int(d_pad)))
 
+    def allgather_rows(self, planes, rows_per_rank, row_first, row_count, limbs, d_pad):
+        pp, pm, pk = _buf(planes)
+        if pm != MEM_DEVICE:
+            raise ValueError("planes must be a device buffer")
+        _check(self.ctx.lib.mvs_allgather_rows(self.ctx._h, self._h, pp, int(rows_per_rank), int(row_first), int(row_count),
+                                               int(limbs), int(d_pad)))
+
     def allgather_f64(self, values, count_per_rank):
         vp, vm, vk = _buf(values)
         if vm != MEM_DEVICE:
@@ -271,6 +281,12 @@ class Context:
     def comm_files(self, path_prefix, rank, world):
         h = _P()
         _check(self.lib.mvs_comm_create_files(self._h, path_prefix.encode(), int(rank), int(world), ctypes.byref(h)))
+        return Comm(self, h)
+
+    def comm_rendezvous(self, path_prefix, rank, world):
+        """RCCL communicator whose ranks find each other under a path prefix (mvs_comm_create_rendezvous)"""
+        h = _P()
+        _check(self.lib.mvs_comm_create_rendezvous(self._h, path_prefix.encode(), int(rank), int(world), ctypes.byref(h)))
         return Comm(self, h)
 
     def set_option(self, name, value):
@@ -482,8 +498,11 @@ class Context:
         if nm != MEM_DEVICE or cm != MEM_DEVICE:
             raise ValueError("norms_sq and cells must be device buffers")
         count = _c.c_int64(int(n_cells))
-        _check(self.lib.mvs_pairwise_block(self._h, sset._h, np_, keep_mode, row_begin, row_end, col_begin, col_end,
-                                           flags, cp, cells.shape[0], ctypes.byref(count)))
+        rc = self.lib.mvs_pairwise_block(self._h, sset._h, np_, keep_mode, row_begin, row_end, col_begin, col_end,
+                                         flags, cp, cells.shape[0], ctypes.byref(count))
+        if rc == MVS_E_CAPACITY:
+            raise MvsError(rc, self.lib.mvs_last_error().decode("utf-8", "replace"), needed=count.value)
+        _check(rc)
         return count.value
 
     def search_block(self, sset, norms_sq, jaccard_min, row_begin, row_end, col_begin, col_end, cells):

@@ -163,8 +163,9 @@ static int load_db(Gpu& g, const std::string& matrix_file, int elem_bytes, int64
     return rc;
 }
 
-// Rendezvous of the shard processes of one job: rank 0 draws the RCCL id and leaves it in a file next to the shards;
-// the others wait for a file that is not older than their own start (a stale file of an earlier job is ignored).
+// Rendezvous of the shard processes of one job: they meet under <output_folder>/.mvs_comm_<token> through the
+// library's file handshake (a job nonce all ranks agree on; files an earlier job left there are never taken for this
+// job's), and with MVS_COLLECTIVE=rccl rank 0's RCCL id travels as one verified block of that transport.
 static int open_communicator(Gpu& g, const std::string& kind, const std::string& output_folder, int rank, int world) {
     const char* tok = getenv("MVS_COLLECTIVE_TOKEN");
     const std::string base = output_folder + ".mvs_comm_" + (tok ? tok : "job");
@@ -172,40 +173,21 @@ static int open_communicator(Gpu& g, const std::string& kind, const std::string&
         if (mvs_comm_create_files(g.ctx, base.c_str(), rank, world, &g.comm) != MVS_OK) return gpu_fail("file communicator");
         return 0;
     }
-    char id[MVS_COMM_ID_BYTES];
-    const std::string id_file = base + ".id";
-    const auto started = std::chrono::system_clock::now();
-    if (rank == 0) {
-        if (mvs_comm_unique_id(id) != MVS_OK) return gpu_fail("RCCL id");
-        const std::string tmp = id_file + ".part";
-        std::ofstream f(tmp, std::ios::binary | std::ios::trunc);
-        f.write(id, sizeof id);
-        f.close();
-        if (!f || std::rename(tmp.c_str(), id_file.c_str()) != 0) {
-            std::cerr << "pairwise_comp_optimized: cannot write " << id_file << std::endl;
-            return 1;
-        }
-    } else {
-        const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(300);
-        for (;;) {
-            std::error_code ec;
-            if (fs::exists(id_file, ec) && fs::file_size(id_file, ec) == sizeof id) {
-                const auto age = std::chrono::duration_cast<std::chrono::seconds>(
-                    fs::file_time_type::clock::now() - fs::last_write_time(id_file, ec)).count();
-                const auto mine = std::chrono::duration_cast<std::chrono::seconds>(std::chrono::system_clock::now() - started).count();
-                if (!ec && age <= mine + 120) {
-                    std::ifstream f(id_file, std::ios::binary);
-                    if (f.read(id, sizeof id)) break;
-                }
-            }
-            if (std::chrono::steady_clock::now() > deadline) {
-                std::cerr << "pairwise_comp_optimized: no RCCL id from shard 0 in " << id_file << std::endl;
-                return 1;
-            }
-            std::this_thread::sleep_for(std::chrono::milliseconds(20));
-        }
+    if (mvs_comm_create_rendezvous(g.ctx, base.c_str(), rank, world, &g.comm) != MVS_OK) return gpu_fail("RCCL communicator");
+    return 0;
+}
+
+// Ranks leave together: before a collective every rank contributes its status, and all of them learn the worst one
+// (a rank that returned early on its own would leave the others inside RCCL for ever -- it has no timeout).  The
+// status rides in the high bits of the value the ranks reduce anyway (max|v| < 2^40).
+static int agree(Gpu& g, int my_rc, int64_t* value) {
+    int64_t v = ((int64_t)(my_rc != 0) << 40) | (value ? (*value & ((1LL << 40) - 1)) : 0);
+    if (mvs_allreduce_max_i64(g.ctx, g.comm, &v) != MVS_OK) return gpu_fail("all-reduce of status / max|v|");
+    if (value) *value = v & ((1LL << 40) - 1);
+    if ((v >> 40) != 0) {
+        if (!my_rc) std::cerr << "pairwise_comp_optimized: another shard process failed; leaving with it" << std::endl;
+        return my_rc ? my_rc : 3;
     }
-    if (mvs_comm_create(g.ctx, id, rank, world, &g.comm) != MVS_OK) return gpu_fail("RCCL communicator");
     return 0;
 }
 
@@ -214,46 +196,47 @@ static int load_db_collective(Gpu& g, const std::string& matrix_file, int elem_b
                               int world) {
     const int64_t row_bytes = (int64_t)d * elem_bytes;
     const int64_t rps = (n + world - 1) / world;
+    int rc = 0, limbs = 2;              // a failure before the first collective is carried into it (agree), not returned
     const int fd = ::open(matrix_file.c_str(), O_RDONLY);
     if (fd < 0) {
         std::cerr << "Error opening file: " << matrix_file << std::endl;
-        return 1;
+        rc = 1;
     }
     const size_t bytes = (size_t)((e - b) * row_bytes);
     const char* base = nullptr;
     const size_t map_off = (size_t)(b * row_bytes) & ~(size_t)4095, map_len = (size_t)(b * row_bytes) - map_off + bytes;
     void* m = nullptr;
-    if (bytes) {
+    if (bytes && !rc) {
         m = ::mmap(nullptr, map_len, PROT_READ, MAP_PRIVATE, fd, (off_t)map_off);
         if (m == MAP_FAILED) {
-            ::close(fd);
+            m = nullptr;
             std::cerr << "Error reading file: " << matrix_file << std::endl;
-            return 1;
+            rc = 1;
+        } else {
+            ::madvise(m, map_len, MADV_SEQUENTIAL);
+            base = (const char*)m + ((size_t)(b * row_bytes) - map_off);
         }
-        ::madvise(m, map_len, MADV_SEQUENTIAL);
-        base = (const char*)m + ((size_t)(b * row_bytes) - map_off);
     }
-    ::close(fd);
+    if (fd >= 0) ::close(fd);
     const int64_t chunk_rows = std::max<int64_t>(1, (1LL << 30) / row_bytes);
-    int rc = 0, limbs = 2;
-    for (int attempt = 0; attempt < 4 && !rc; ++attempt) {
+    for (int attempt = 0; attempt < 4; ++attempt) {
         if (g.set) {
             mvs_sketch_set_destroy(g.set);
             g.set = nullptr;
         }
-        if (mvs_sketch_set_alloc(g.ctx, n, d, limbs, &g.set) != MVS_OK) {
-            rc = gpu_fail("allocating sketch set");
-            break;
-        }
-        int64_t n_alloc = 0;
+        int64_t n_alloc = 0, max_abs = 0;
         int d_pad = 0;
-        mvs_sketch_set_info(g.set, nullptr, nullptr, nullptr, &n_alloc, &d_pad);
-        if (rps * world > n_alloc) {
-            std::cerr << "pairwise_comp_optimized: too many shards for the plane padding" << std::endl;
-            rc = 1;
-            break;
+        if (rc) {
+            // failed before the loop: only the agreement below is left to do
+        } else if (mvs_sketch_set_alloc(g.ctx, n, d, limbs, &g.set) != MVS_OK) {
+            rc = gpu_fail("allocating sketch set");
+        } else {
+            mvs_sketch_set_info(g.set, nullptr, nullptr, nullptr, &n_alloc, &d_pad);
+            if (rps * world > n_alloc) {
+                std::cerr << "pairwise_comp_optimized: too many shards for the plane padding" << std::endl;
+                rc = 1;
+            }
         }
-        int64_t max_abs = 0;
         for (int64_t r0 = b; r0 < e && !rc; r0 += chunk_rows) {
             const int64_t rows = std::min(chunk_rows, e - r0);
             int64_t mx = 0;
@@ -261,12 +244,10 @@ static int load_db_collective(Gpu& g, const std::string& matrix_file, int elem_b
                 rc = gpu_fail("re-coding vectors.bin");
             max_abs = std::max(max_abs, mx);
         }
+        // one limb code for everybody: the largest |v| over all shards decides (every rank takes the same branch),
+        // and a rank that failed above takes everybody out with it
+        rc = agree(g, rc, &max_abs);
         if (rc) break;
-        // one limb code for everybody: the largest |v| over all shards decides (every rank takes the same branch)
-        if (mvs_allreduce_max_i64(g.ctx, g.comm, &max_abs) != MVS_OK) {
-            rc = gpu_fail("all-reduce of max|v|");
-            break;
-        }
         if (mvs_limbs_for_max_abs(max_abs) > limbs) {
             limbs = mvs_limbs_for_max_abs(max_abs);
             continue;

@@ -72,6 +72,7 @@ namespace mvs {
 int capi_fail(int code, const char* fmt, ...);
 hipStream_t capi_stream(mvs_ctx* c) { return c->stream; }
 int capi_device(mvs_ctx* c) { return c->device; }
+const Options& capi_options(mvs_ctx* c) { return c->opt; }
 }  // namespace mvs
 
 namespace {
@@ -207,6 +208,7 @@ const OptionSpec kOptions[] = {
     {"enable_k3", &mvs::Options::enable_k3, nullptr, 0, 1},
     {"markers", &mvs::Options::markers, nullptr, 0, 1},
     {"project_variant", &mvs::Options::project_variant, nullptr, 0, 14},
+    {"comm_timeout_s", &mvs::Options::comm_timeout_s, nullptr, 1, 86400},
     {"pairwise_block_cells", nullptr, &mvs::Options::pairwise_block_cells, 1, (1LL << 62)},
 };
 

@@ -6,6 +6,7 @@
 // without it, and in a process that already carries a copy (PyTorch ships one) the loader hands back that copy.
 // A second kind of communicator forwards the same three collectives to caller-supplied functions: ranks that
 // share one device (RCCL refuses that), tests, or an application with its own transport.
+#include <dirent.h>
 #include <dlfcn.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -26,6 +27,7 @@ namespace mvs {
 int capi_fail(int code, const char* fmt, ...);          // mvs_capi.hip: sets mvs_last_error() of this thread
 hipStream_t capi_stream(mvs_ctx* c);
 int capi_device(mvs_ctx* c);
+const Options& capi_options(mvs_ctx* c);
 }  // namespace mvs
 
 namespace {
@@ -87,67 +89,185 @@ struct mvs_comm {
     // file transport (mvs_comm_create_files): exchange through <prefix>_<seq>_<rank> files
     std::string prefix;
     unsigned long long seq = 0;
+    unsigned long long job = 0;      // nonce all ranks of THIS job agreed on at creation; every block carries it
     double timeout_s = 600.0;
+    // mvs_allgather_rows: contiguous staging of a row sub-range of every rank's block (grow-only, device)
+    void* pack = nullptr;
+    size_t pack_bytes = 0;
 };
 
 // ---- file transport: ranks that share one device (or a test box with one GPU) exchange blocks through a directory
 // every rank can reach.  A block is written under a temporary name and renamed; readers poll for it; the writer
-// removes it once every reader has left an acknowledgement. ----
+// removes it once every reader has left an acknowledgement.
+// Leftovers of an earlier job that used the same prefix (killed, timed out, failed on one rank) must never be taken
+// for this job's data: at creation a rank removes its own old files, the ranks then agree on a job nonce (below), and
+// every block starts with a header {magic, job nonce, sequence number, payload bytes} the reader verifies -- a file
+// that does not carry this job's header is ignored (polled past) like a file that is not there. ----
 namespace {
+
+struct BlockHeader {
+    unsigned long long magic, job, seq, bytes;
+};
+constexpr unsigned long long kBlockMagic = 0x4b4c424d4f435653ULL;   // "SVCOMBLK"
 
 bool exists(const std::string& p) {
     struct stat st;
     return ::stat(p.c_str(), &st) == 0;
 }
 
+double seconds_since(std::chrono::steady_clock::time_point t0) {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+
 bool wait_for(const std::string& p, double timeout_s) {
     const auto t0 = std::chrono::steady_clock::now();
     while (!exists(p)) {
-        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) return false;
+        if (seconds_since(t0) > timeout_s) return false;
         std::this_thread::sleep_for(std::chrono::milliseconds(1));
     }
     return true;
 }
 
-bool write_file(const std::string& p, const void* data, size_t bytes) {
+bool write_file(const std::string& p, const BlockHeader* h, const void* data, size_t bytes) {
     const std::string tmp = p + ".part";
     FILE* f = std::fopen(tmp.c_str(), "wb");
     if (!f) return false;
-    const bool ok = bytes == 0 || std::fwrite(data, 1, bytes, f) == bytes;
-    if (std::fclose(f) != 0 || !ok) return false;
+    bool ok = !h || std::fwrite(h, sizeof *h, 1, f) == 1;
+    ok = ok && (bytes == 0 || std::fwrite(data, 1, bytes, f) == bytes);
+    if (std::fclose(f) != 0 || !ok) {
+        ::unlink(tmp.c_str());
+        return false;
+    }
     return std::rename(tmp.c_str(), p.c_str()) == 0;
 }
 
-bool read_file(const std::string& p, void* data, size_t bytes) {
+// 1: read, 0: no such file / not this job's block (keep polling), -1: this job's block but damaged
+int read_block(const std::string& p, const BlockHeader& want, void* data) {
+    FILE* f = std::fopen(p.c_str(), "rb");
+    if (!f) return 0;
+    BlockHeader h{};
+    int rc = 0;
+    if (std::fread(&h, sizeof h, 1, f) == 1 && h.magic == want.magic && h.job == want.job && h.seq == want.seq) {
+        rc = (h.bytes == want.bytes && (want.bytes == 0 || std::fread(data, 1, want.bytes, f) == want.bytes)) ? 1 : -1;
+    }
+    std::fclose(f);
+    return rc;
+}
+
+bool read_u64(const std::string& p, unsigned long long* v) {
     FILE* f = std::fopen(p.c_str(), "rb");
     if (!f) return false;
-    const bool ok = bytes == 0 || std::fread(data, 1, bytes, f) == bytes;
+    const bool ok = std::fread(v, 8, 1, f) == 1;
     std::fclose(f);
     return ok;
 }
 
+// this rank's files of any job under the prefix: "<prefix>_<anything>_<rank>" and "..._<rank>.<suffix>"
+void remove_own_files(const std::string& prefix, int rank) {
+    const size_t slash = prefix.find_last_of('/');
+    const std::string dir = slash == std::string::npos ? "." : prefix.substr(0, slash + 1);
+    const std::string stem = (slash == std::string::npos ? prefix : prefix.substr(slash + 1)) + "_";
+    const std::string mine = "_" + std::to_string(rank);
+    DIR* d = ::opendir(dir.c_str());
+    if (!d) return;
+    std::vector<std::string> victims;
+    while (dirent* e = ::readdir(d)) {
+        const std::string name = e->d_name;
+        if (name.compare(0, stem.size(), stem) != 0) continue;
+        const size_t dot = name.find('.', stem.size());
+        const std::string core = name.substr(0, dot);                       // without ".part" / ".ackN"
+        if (core.size() >= stem.size() - 1 + mine.size() && core.compare(core.size() - mine.size(), mine.size(), mine) == 0)
+            victims.push_back((slash == std::string::npos ? std::string() : dir) + name);
+    }
+    ::closedir(d);
+    for (const std::string& v : victims) ::unlink(v.c_str());
+}
+
+unsigned long long fresh_nonce(int rank) {
+    unsigned long long x = (unsigned long long)std::chrono::system_clock::now().time_since_epoch().count();
+    x ^= (unsigned long long)::getpid() << 32;
+    x ^= (unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count() * 0x9e3779b97f4a7c15ULL;
+    x += (unsigned long long)(rank + 1) * 0xbf58476d1ce4e5b9ULL;
+    x ^= x >> 31;
+    return x ? x : 1;
+}
+
+// Agreement on the job nonce.  Every rank publishes a fresh random number in <prefix>_hello_<rank>; the job nonce is a
+// hash of all of them; every rank then publishes the nonce it computed in <prefix>_ready_<rank> and waits until all
+// ranks show the same one.  A rank that picked up the hello file of an EARLIER job (its owner had not replaced it yet)
+// computes a nonce nobody else has, sees the disagreement, reads the hello files again and publishes anew -- so the
+// loop ends exactly when all ranks of this job have seen each other's fresh numbers.
+int files_handshake(mvs_comm* m) {
+    remove_own_files(m->prefix, m->rank);
+    const unsigned long long mine = fresh_nonce(m->rank);
+    if (!write_file(m->prefix + "_hello_" + std::to_string(m->rank), nullptr, &mine, 8)) return 1;
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned long long published = 0;
+    for (;;) {
+        unsigned long long job = 0x243f6a8885a308d3ULL;
+        bool all = true;
+        for (int r = 0; r < m->world && all; ++r) {
+            unsigned long long v = mine;
+            if (r != m->rank) all = read_u64(m->prefix + "_hello_" + std::to_string(r), &v);
+            job = (job ^ v) * 0x100000001b3ULL;
+            job ^= job >> 29;
+        }
+        if (all) {
+            if (job == 0) job = 1;
+            if (job != published) {
+                if (!write_file(m->prefix + "_ready_" + std::to_string(m->rank), nullptr, &job, 8)) return 2;
+                published = job;
+            }
+            bool agreed = true;
+            for (int r = 0; r < m->world && agreed; ++r) {
+                unsigned long long v = 0;
+                agreed = r == m->rank || (read_u64(m->prefix + "_ready_" + std::to_string(r), &v) && v == job);
+            }
+            if (agreed) {
+                m->job = job;
+                return 0;
+            }
+        }
+        if (seconds_since(t0) > m->timeout_s) return 3;
+        std::this_thread::sleep_for(std::chrono::milliseconds(2));
+    }
+}
+
 // exchange `bytes` of HOST data per rank: mine in, all ranks' blocks out (world * bytes)
-int files_exchange(mvs_comm* m, const void* mine, size_t bytes, char* all) {
+int files_exchange(mvs_comm* m, const void* mine, size_t bytes, char* all, double timeout_s = -1.0) {
+    if (timeout_s < 0) timeout_s = m->timeout_s;
+    const BlockHeader h{kBlockMagic, m->job, m->seq, (unsigned long long)bytes};
     const std::string base = m->prefix + "_" + std::to_string(m->seq++) + "_";
-    if (!write_file(base + std::to_string(m->rank), mine, bytes)) return 1;
-    for (int r = 0; r < m->world; ++r) {
+    const std::string own = base + std::to_string(m->rank);
+    if (!write_file(own, &h, mine, bytes)) return 1;
+    int rc = 0;
+    for (int r = 0; r < m->world && !rc; ++r) {
         char* dst = all + (size_t)r * bytes;
         if (r == m->rank) {
             if (bytes) std::memcpy(dst, mine, bytes);
             continue;
         }
         const std::string f = base + std::to_string(r);
-        if (!wait_for(f, m->timeout_s) || !read_file(f, dst, bytes)) return 2;
-        if (!write_file(f + ".ack" + std::to_string(m->rank), nullptr, 0)) return 3;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (;;) {
+            const int got = read_block(f, h, dst);
+            if (got == 1) break;
+            if (got < 0 || seconds_since(t0) > timeout_s) {
+                rc = 2;
+                break;
+            }
+            std::this_thread::sleep_for(std::chrono::milliseconds(1));
+        }
+        if (!rc && !write_file(f + ".ack" + std::to_string(m->rank), nullptr, nullptr, 0)) rc = 3;
     }
     for (int r = 0; r < m->world; ++r) {   // my block has been read by everybody: remove it and the acknowledgements
         if (r == m->rank) continue;
-        const std::string ack = base + std::to_string(m->rank) + ".ack" + std::to_string(r);
-        if (!wait_for(ack, m->timeout_s)) return 4;
+        const std::string ack = own + ".ack" + std::to_string(r);
+        if (!rc && !wait_for(ack, timeout_s)) rc = 4;
         ::unlink(ack.c_str());
     }
-    ::unlink((base + std::to_string(m->rank)).c_str());
-    return 0;
+    ::unlink(own.c_str());                 // on the error paths too: nothing of this rank stays behind
+    return rc;
 }
 
 int files_allgather(void* user, void* buf, size_t bytes, int rank, int world, void* stream) {
@@ -269,8 +389,37 @@ int mvs_comm_create_files(mvs_ctx* c, const char* path_prefix, int rank, int wor
     m->cb.user = m;
     m->cb.allgather = files_allgather;
     m->cb.allreduce_max_i64 = files_allreduce_max;
+    m->timeout_s = (double)mvs::capi_options(c).comm_timeout_s;
+    const int rc = files_handshake(m);      // collective: all ranks of the job meet here
+    if (rc) {
+        remove_own_files(m->prefix, rank);
+        delete m;
+        return mvs::capi_fail(MVS_E_HIP, "file transport: the %d ranks did not meet under %s (%d)", world, path_prefix, rc);
+    }
     *out = m;
     return MVS_OK;
+}
+
+int mvs_comm_create_rendezvous(mvs_ctx* c, const char* path_prefix, int rank, int world, mvs_comm** out) {
+    if (!c || !path_prefix || !out) return mvs::capi_fail(MVS_E_INVALID, "NULL argument");
+    *out = nullptr;
+    // the ranks meet through the file transport's handshake (stale files of an earlier job cannot be mistaken for this
+    // one's), rank 0's RCCL id travels as one verified block, the meeting point is cleaned up, then ncclCommInitRank
+    mvs_comm* meet = nullptr;
+    int rc = mvs_comm_create_files(c, path_prefix, rank, world, &meet);
+    if (rc) return rc;
+    std::vector<char> ids((size_t)world * MVS_COMM_ID_BYTES);
+    char id[MVS_COMM_ID_BYTES] = {0};
+    long long status = 0;
+    if (rank == 0 && mvs_comm_unique_id(id) != MVS_OK) status = 1;      // the others must not wait for an id that never comes
+    const int xrc = files_exchange(meet, id, sizeof id, ids.data());
+    mvs_comm_destroy(meet);
+    if (status) return MVS_E_HIP;                                        // mvs_last_error() is mvs_comm_unique_id's
+    if (xrc) return mvs::capi_fail(MVS_E_HIP, "file transport: exchange of the RCCL id failed (%d)", xrc);
+    bool any = false;
+    for (int i = 0; i < MVS_COMM_ID_BYTES; ++i) any = any || ids[i] != 0;
+    if (!any) return mvs::capi_fail(MVS_E_HIP, "rank 0 could not draw an RCCL id");
+    return mvs_comm_create(c, ids.data(), rank, world, out);
 }
 
 int mvs_comm_destroy(mvs_comm* m) {
@@ -279,6 +428,21 @@ int mvs_comm_destroy(mvs_comm* m) {
         (void)hipSetDevice(mvs::capi_device(m->ctx));
         (void)hipStreamSynchronize(mvs::capi_stream(m->ctx));
         (void)rccl().CommDestroy(m->nccl);
+    }
+    if (m->pack) {
+        (void)hipSetDevice(mvs::capi_device(m->ctx));
+        (void)hipStreamSynchronize(mvs::capi_stream(m->ctx));
+        (void)hipFree(m->pack);
+    }
+    if (!m->prefix.empty()) {
+        // a last (empty) exchange: once it is through every rank has finished the handshake and read every block, so
+        // the hello / ready files can go; a peer that died does not hold this rank for more than a few seconds
+        if (m->world > 1) {
+            char none = 0;
+            std::vector<char> all((size_t)m->world);
+            (void)files_exchange(m, &none, 0, all.data(), m->timeout_s < 10.0 ? m->timeout_s : 10.0);
+        }
+        remove_own_files(m->prefix, m->rank);
     }
     delete m;
     return MVS_OK;
@@ -298,6 +462,44 @@ int mvs_allgather_planes(mvs_ctx* c, mvs_comm* comm, int8_t* planes, int64_t row
     if (!planes || rows_per_rank < 0 || !mvs::limb_code_ok(limbs) || d_pad <= 0 || d_pad % mvs::kBK != 0)
         return mvs::capi_fail(MVS_E_INVALID, "bad argument");
     return gather_bytes(c, comm, planes, (size_t)rows_per_rank * (size_t)mvs::planes_of(limbs) * (size_t)d_pad);
+}
+
+int mvs_allgather_rows(mvs_ctx* c, mvs_comm* comm, int8_t* planes, int64_t rows_per_rank, int64_t row_first,
+                       int64_t row_count, int limbs, int d_pad) {
+    int rc = check_comm(c, comm);
+    if (rc) return rc;
+    if (!planes || rows_per_rank < 0 || row_first < 0 || row_count < 0 || row_first + row_count > rows_per_rank ||
+        !mvs::limb_code_ok(limbs) || d_pad <= 0 || d_pad % mvs::kBK != 0)
+        return mvs::capi_fail(MVS_E_INVALID, "bad argument");
+    const size_t row_bytes = (size_t)mvs::planes_of(limbs) * (size_t)d_pad;
+    const size_t block = (size_t)rows_per_rank * row_bytes, part = (size_t)row_count * row_bytes;
+    if (row_count == rows_per_rank) return gather_bytes(c, comm, planes, block);
+    if (comm->world == 1 || part == 0) return MVS_OK;
+    if (hipSetDevice(mvs::capi_device(c)) != hipSuccess) return mvs::capi_fail(MVS_E_HIP, "hipSetDevice failed");
+    hipStream_t st = mvs::capi_stream(c);
+    const size_t need = part * (size_t)comm->world;
+    if (comm->pack_bytes < need) {
+        if (comm->pack) {
+            if (hipStreamSynchronize(st) != hipSuccess) return mvs::capi_fail(MVS_E_HIP, "sync failed");
+            (void)hipFree(comm->pack);
+            comm->pack = nullptr;
+            comm->pack_bytes = 0;
+        }
+        if (hipMalloc(&comm->pack, need) != hipSuccess) return mvs::capi_fail(MVS_E_NOMEM, "hipMalloc of %zu bytes failed", need);
+        comm->pack_bytes = need;
+    }
+    // the sub-range of every rank's block is `part` contiguous bytes at stride `block`: this rank's goes into its slot
+    // of the contiguous staging buffer, the ordinary in-place all-gather runs there, and one strided copy puts the
+    // other ranks' rows where they belong (2 x part x world bytes of device copies: microseconds)
+    char* own_src = reinterpret_cast<char*>(planes) + (size_t)comm->rank * block + (size_t)row_first * row_bytes;
+    if (hipMemcpyAsync(static_cast<char*>(comm->pack) + (size_t)comm->rank * part, own_src, part, hipMemcpyDeviceToDevice, st) != hipSuccess)
+        return mvs::capi_fail(MVS_E_HIP, "staging copy failed");
+    rc = gather_bytes(c, comm, comm->pack, part);
+    if (rc) return rc;
+    if (hipMemcpy2DAsync(reinterpret_cast<char*>(planes) + (size_t)row_first * row_bytes, block, comm->pack, part, part,
+                         (size_t)comm->world, hipMemcpyDeviceToDevice, st) != hipSuccess)
+        return mvs::capi_fail(MVS_E_HIP, "strided copy failed");
+    return MVS_OK;
 }
 
 int mvs_allgather_f64(mvs_ctx* c, mvs_comm* comm, double* values, int64_t count_per_rank) {

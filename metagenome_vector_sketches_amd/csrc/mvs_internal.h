@@ -47,6 +47,7 @@ struct Options {
                                     // wave sharing the first splitmix64 round
     int markers = 0;                // 1: roctx ranges around the main entry points (rocprofv3 --marker-trace)
     int enable_k3 = 0;              // 1: mvs_sketch_set_create picks the three-plane Karatsuba code for |v| <= 8127
+    int comm_timeout_s = 600;       // file transport: how long a rank waits for a peer's block before it gives up
     double pairwise_block_cells = 1099511627776.0;   // row-chunk bound of mvs_pairwise_rows (2^40 cells)
 };
 

@@ -25,3 +25,51 @@ def test_fast_norm_sq_equals_text_round_trip():
         got = fast_norm_sq(ss, d)
         want = np.array([orc.norm_sq_from_text(orc.format_norm(float(np.sqrt(v / d)))) for v in ss])
         assert np.array_equal(got, want), d
+
+
+# ---- `python bench.py --gpus N` without a launcher: the parent starts N fresh workers itself (launch_workers) ----
+_STUB = r'''
+import json, os, sys, time
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+assert os.environ["LOCAL_RANK"] == os.environ["RANK"] and os.environ["MASTER_ADDR"] == "127.0.0.1"
+assert int(os.environ["MASTER_PORT"]) > 0
+mode = sys.argv[1]
+if mode == "fail" and rank == 1:
+    sys.exit(7)
+if mode == "fail" and rank == 0:
+    time.sleep(60)          # a rank left inside a collective by the one that died
+print("noise from rank %d" % rank if rank else json.dumps({"world": world, "argv": sys.argv[1:]}))
+'''
+
+
+def test_launcher_relays_rank0_line_and_worst_exit_code(tmp_path, capfd):
+    import json
+    import time
+    from bench import launch_workers
+    stub = tmp_path / "stub.py"
+    stub.write_text(_STUB)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    rc = launch_workers(3, ["ok", "--steps", "2"], script=str(stub), env=env)
+    out, err = capfd.readouterr()
+    assert rc == 0
+    lines = [l for l in out.splitlines() if l.strip()]
+    assert len(lines) == 1 and json.loads(lines[0]) == {"world": 3, "argv": ["ok", "--steps", "2"]}
+    assert "noise from rank 1" in err and "noise from rank 2" in err      # other ranks never write to the bench line's stream
+    t0 = time.monotonic()
+    rc = launch_workers(2, ["fail"], script=str(stub), env=env, grace_s=0.5)
+    out, err = capfd.readouterr()
+    assert rc != 0 and time.monotonic() - t0 < 30                         # rank 0 was not waited for for a minute
+    assert "worker exit codes" in err and not out.strip()
+
+
+def test_bench_parent_does_not_import_torch_before_launching(tmp_path):
+    """the process that becomes the launcher must not initialise HIP: bench.py decides before `import torch`"""
+    import ast
+    with open(os.path.join(ROOT, "bench.py")) as f:
+        tree = ast.parse(f.read())
+    main = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "main")
+    launch_line = next(n.lineno for n in ast.walk(main) if isinstance(n, ast.Call) and getattr(n.func, "id", "") == "launch_workers")
+    torch_line = min(n.lineno for n in ast.walk(main) if isinstance(n, ast.Import) and any(a.name.startswith("torch") for a in n.names))
+    assert launch_line < torch_line
+    top = [a.name for n in tree.body if isinstance(n, (ast.Import, ast.ImportFrom)) for a in n.names]
+    assert not any(x.startswith("torch") or x.startswith("metagenome") for x in top)

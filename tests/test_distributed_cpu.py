@@ -117,6 +117,31 @@ def _worker(rank, world, port, n, d, out_dir):
     assert info3.get("schedule") == "symmetric"
     plain = np.stack([cells[k] for k in ("row", "col", "dot", "q")], axis=1).astype(np.int32)
     assert cnt3 == cnt and np.array_equal(out[:cnt3].numpy(), plain), (rank, cnt3, cnt)
+    # local rows arriving in parts (begin / feed / finish): the exchange of a part starts when it is fed; same cells
+    local, n2l = torch.from_numpy(sk[b:e].copy()), n2[b:e]
+    sc.begin(local, n2l, n)
+    bounds = sc.part_bounds(n, 3)
+    assert bounds[0][0] == 0 and bounds[-1][1] == (n + world - 1) // world and len(bounds) in (2, 3)
+    for (p0, p1) in bounds:                                  # block coordinates: the same on every rank
+        q0, q1 = min(p0, e - b), min(p1, e - b)
+        sc.feed(p0, p1, int(np.abs(sk[b + q0:b + q1]).max()) if q1 > q0 else 0)
+    _, cnt4, info4 = sc.finish(cells_out=out)
+    assert cnt4 == cnt and np.array_equal(out[:cnt4].numpy(), plain) and info4["overlap"].startswith("exchange of a part")
+    # a limb guess that does not hold on ONE rank only: every rank falls back to the plain exchange, same cells
+    sc.begin(local, n2l, n, limbs_guess=1)
+    sc.feed(0, (n + world - 1) // world, int(np.abs(sk[b:e]).max()) if rank == world - 1 else 1)
+    _, cnt5, info5 = sc.finish(cells_out=out)
+    assert cnt5 == cnt and np.array_equal(out[:cnt5].numpy(), plain) and "did not hold" in info5["overlap"]
+    # an output buffer that holds exactly this shard (the mirrored cells in flight live in internal buffers)
+    tight = torch.empty((cnt, 4), dtype=torch.int32)
+    _, cnt6, _ = sc.run(sk[b:e], n2[b:e], n, cells_out=tight)
+    assert cnt6 == cnt and np.array_equal(tight.numpy(), plain)
+    # a second, larger problem that pads to the same plane geometry: the gathered-norm buffer follows the row count
+    n_big = n + 3
+    sk2, n22 = _make(n_big, d, seed=99)
+    b2, e2 = parallel.shard_rows(n_big, world, rank)
+    cells7, cnt7, _ = sc.run(sk2[b2:e2], n22[b2:e2], n_big)
+    np.save(os.path.join(out_dir, "cells_big_%d.npy" % rank), cells7)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -155,6 +180,11 @@ def test_multi_rank_shards_equal_single_process(tmp_path, n, world):
         b, e = parallel.shard_rows(n, world, r)
         part = np.load(os.path.join(str(tmp_path), "cells_%d.npy" % r))
         assert np.all((part["row"] >= b) & (part["row"] < e))
+    sk2, n22 = _make(n + 3, d, seed=99)
+    want2 = orc.pairwise_rows(sk2, n22, chunk=192)
+    want2 = want2[np.lexsort((want2["col"], want2["row"]))]
+    got2 = np.concatenate([np.load(os.path.join(str(tmp_path), "cells_big_%d.npy" % r)) for r in range(world)])
+    assert np.array_equal(got2, want2)
 
 
 def test_shard_rows_matches_reference_formula():

@@ -91,12 +91,41 @@ def _native_worker(rank, world, n, d, out_dir):
         assert "file transport" in info["collectives"]
         np.save(os.path.join(out_dir, "ncells_%d_%d.npy" % (int(sym), rank)), out[:cnt].cpu().numpy())
     comm.close()
+    # local rows arriving in parts, the communicator on a context and stream of its own (what bench.py --gpus N does):
+    # mvs_allgather_rows moves a part of every rank's block while the compute stream goes on
+    side = torch.cuda.Stream()
+    ctx2 = pkg.Context(0)
+    ctx2.set_stream(side)
+    comm2 = ctx2.comm_files(os.path.join(out_dir, "xchg"), rank, world)
+    sc = parallel.ShardedComparison(parallel.GpuOps(ctx, torch.device("cuda", 0)), rank, world,
+                                    collectives=parallel.NativeCollectives(comm2, stream=side))
+    n2_dev = torch.from_numpy(n2[b:e].copy()).to("cuda:0")
+    for parts in (2, 3):
+        sc.begin(local, n2_dev, n)
+        for (p0, p1) in sc.part_bounds(n, parts):
+            q0, q1 = min(p0, e - b), min(p1, e - b)
+            sc.feed(p0, p1, int(local[q0:q1].abs().max()) if q1 > q0 else 0)
+        _, cnt, info = sc.finish(cells_out=out)
+        torch.cuda.synchronize()
+        assert info["overlap"].startswith("exchange of a part")
+        np.save(os.path.join(out_dir, "ncells_p%d_%d.npy" % (parts, rank)), out[:cnt].cpu().numpy())
+    comm2.close()
+    ctx2.close()
     ctx.close()
 
 
-@pytest.mark.parametrize("n,world", [(700, 2), (650, 3)])
-def test_native_communicator_ranks_on_one_gpu(tmp_path, n, world):
+@pytest.mark.parametrize("n,world,stale", [(700, 2, False), (650, 3, False), (700, 2, True)])
+def test_native_communicator_ranks_on_one_gpu(tmp_path, n, world, stale):
     d = 512
+    if stale:
+        # what a killed earlier job with the same prefix leaves behind: blocks of the first sequence numbers (one of
+        # them exactly the 8 bytes of the max|v| all-reduce), hello / ready files with that job's numbers, an
+        # acknowledgement.  None of it may be read as this job's data, and all of it is gone afterwards.
+        for name, data in (("xchg_0_0", b"\x7f" * 8), ("xchg_0_1", b"\x7f" * 8), ("xchg_1_1", b"\x01" * 4096),
+                           ("xchg_hello_0", b"\x11" * 8), ("xchg_hello_1", b"\x22" * 8), ("xchg_ready_0", b"\x33" * 8),
+                           ("xchg_ready_1", b"\x33" * 8), ("xchg_0_1.ack0", b"")):
+            with open(os.path.join(str(tmp_path), name), "wb") as f:
+                f.write(data)
     mp.spawn(_native_worker, args=(world, n, d, str(tmp_path)), nprocs=world, join=True)
     from oracle import pyoracle as orc
     sk, n2 = _make(n, d)
@@ -106,6 +135,9 @@ def test_native_communicator_ranks_on_one_gpu(tmp_path, n, world):
     for sym in (1, 0):
         got = np.concatenate([np.load(os.path.join(str(tmp_path), "ncells_%d_%d.npy" % (sym, r))) for r in range(world)])
         assert np.array_equal(got, want), sym
+    for parts in (2, 3):
+        got = np.concatenate([np.load(os.path.join(str(tmp_path), "ncells_p%d_%d.npy" % (parts, r))) for r in range(world)])
+        assert np.array_equal(got, want), parts
     assert not [f for f in os.listdir(str(tmp_path)) if f.startswith("xchg")]      # the transport cleans up after itself
 
 
@@ -126,3 +158,36 @@ def test_rccl_communicator_first_contact():
     assert comm.allreduce_max(41) == 41
     comm.close()
     ctx.close()
+
+
+def _bare_bench(extra, timeout=600):
+    """`python3 bench.py --gpus 2 ...` exactly as the round driver types it for a SCALE run -- no launcher, no RANK /
+    WORLD_SIZE in the environment -- with MVS_BENCH_REHEARSAL=1 putting both ranks on the one card (gloo + the file
+    transport instead of RCCL, which refuses two ranks on one device)"""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "MVS_PAIRWISE_FILTER")}
+    env["MVS_BENCH_REHEARSAL"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline"] + extra, env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]                     # ONE JSON line, nothing else on stdout
+    return json.loads(lines[0])
+
+
+def test_bare_bench_gpus2_launches_itself():
+    d = _bare_bench(["--samples", "2000", "--hashes", "4000"])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["total_samples"] == 4000 and d["config"]["schedule"] == "symmetric"
+    assert d["config"]["comm_world"] == 2 and d["config"]["rccl_ranks"] == 0      # rehearsal: file transport, not RCCL
+    assert d["config"]["kept_cells"] >= 4000 * 10
+    assert d["stages"]["allgather_bytes_per_rank"] == 2000 * 2 * 2048 and d["stages"]["allgather_ms"] > 0
+
+
+def test_bare_bench_gpus2_config4_launches_itself():
+    d = _bare_bench(["--config", "4"])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["total_samples"] == 100_000
+    assert d["config"]["d"] == 4096 and d["config"]["comm_world"] == 2
+    assert d["config"]["kept_cells"] >= 100_000 * 10
