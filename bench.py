@@ -144,8 +144,8 @@ def launch_workers(n, argv, script=None, python=None, env=None, poll_s=0.05, gra
                     p.kill()
         time.sleep(poll_s)
     reader.join()
-    for line in out0:
-        print(line, flush=True)
+    for line in out0:       # stdout carries the bench line and nothing else (gloo, for one, announces itself on stdout)
+        print(line, flush=True, file=sys.stdout if line.lstrip().startswith("{") else sys.stderr)
     codes = [p.returncode for p in procs]
     worst = 0
     for c in codes:

@@ -41,7 +41,10 @@ struct mvs_ctx {
     void* pw_rows = nullptr;    size_t pw_rows_bytes = 0;
     void* pw_fmeta = nullptr;   size_t pw_fmeta_bytes = 0;
     void* pw_cand = nullptr;    size_t pw_cand_bytes = 0;
+    void* pw_chdr = nullptr;    size_t pw_chdr_bytes = 0;   // candidate regions of the ping-pong filter: counts, entries
+    void* pw_cent = nullptr;    size_t pw_cent_bytes = 0;
     unsigned long long coarse_id = 0, coarse_gen = 0;
+    int coarse_mode = -1;                   // radix rule (option coarse_radix) the cached plane was built with
     unsigned long long filter_off_id = 0;   // (set, coefficient) for which the filter passed too many pairs
     double filter_off_coeff = 0.0;
     unsigned long long last_candidates = 0; // candidate pairs of the last two-stage comparison (0: exact kernel)
@@ -209,6 +212,9 @@ const OptionSpec kOptions[] = {
     {"markers", &mvs::Options::markers, nullptr, 0, 1},
     {"project_variant", &mvs::Options::project_variant, nullptr, 0, 14},
     {"comm_timeout_s", &mvs::Options::comm_timeout_s, nullptr, 1, 86400},
+    {"pairwise_map", &mvs::Options::pairwise_map, nullptr, 0, 2},
+    {"coarse_radix", &mvs::Options::coarse_radix, nullptr, 0, 1},
+    {"cand_regions", &mvs::Options::cand_regions, nullptr, 0, 1},
     {"pairwise_block_cells", nullptr, &mvs::Options::pairwise_block_cells, 1, (1LL << 62)},
 };
 
@@ -371,6 +377,8 @@ int mvs_ctx_destroy(mvs_ctx* c) {
     if (c->pw_rows) (void)hipFree(c->pw_rows);
     if (c->pw_fmeta) (void)hipFree(c->pw_fmeta);
     if (c->pw_cand) (void)hipFree(c->pw_cand);
+    if (c->pw_chdr) (void)hipFree(c->pw_chdr);
+    if (c->pw_cent) (void)hipFree(c->pw_cent);
     for (int i = 0; i < 2; ++i) {
         if (c->up_pinned[i]) (void)hipHostFree(c->up_pinned[i]);
         if (c->up_done[i]) (void)hipEventDestroy(c->up_done[i]);
@@ -1030,18 +1038,19 @@ namespace {
 
 // coarse plane + row statistics of `s`, cached in the context until the set (or its contents) changes
 int prepare_coarse(mvs_ctx* c, const mvs_sketch_set* s) {
-    if (c->coarse_id == s->id && c->coarse_gen == s->gen) return MVS_OK;
+    if (c->coarse_id == s->id && c->coarse_gen == s->gen && c->coarse_mode == c->opt.coarse_radix) return MVS_OK;
     c->coarse_id = 0;
     int rc = ensure_buf(c, &c->pw_coarse, &c->pw_coarse_bytes, (size_t)s->n_alloc * (size_t)s->d_pad);
     if (rc) return rc;
     rc = ensure_buf(c, &c->pw_rows, &c->pw_rows_bytes, (size_t)s->n_alloc * sizeof(mvs::CoarseRow));
     if (rc) return rc;
     mvs::launch_coarse_build(c->stream, s->planes, s->n, s->n_alloc, s->d_pad, (int8_t*)c->pw_coarse,
-                             (mvs::CoarseRow*)c->pw_rows);
+                             (mvs::CoarseRow*)c->pw_rows, c->opt.coarse_radix);
     rc = check_kernel("k_coarse_build");
     if (rc) return rc;
     c->coarse_id = s->id;
     c->coarse_gen = s->gen;
+    c->coarse_mode = c->opt.coarse_radix;
     return MVS_OK;
 }
 
@@ -1073,6 +1082,7 @@ int pairwise_launch(mvs_ctx* c, const mvs_sketch_set* s, const double* d_n2, int
     a.dots = nullptr;
     a.mirror_all = mirror_all ? 1 : 0;
     a.debug_flags = c->opt.pairwise_debug;
+    a.map_mode = c->opt.pairwise_map;
     a.stamps = nullptr;
 #ifdef MVS_ABLATIONS
     // per-workgroup time stamps of k_pairwise_pp (profiling only): one buffer for the process, dumped after the call
@@ -1136,6 +1146,15 @@ int pairwise_launch(mvs_ctx* c, const mvs_sketch_set* s, const double* d_n2, int
         a.cand_counter = c->d_counter + 2;
         a.cand_limit = limit;
         a.cand_stop = reinterpret_cast<unsigned int*>(c->d_counter + 32);
+        const int64_t n_regions = mvs::filter_region_count(a, c->opt);
+        if (n_regions > 0) {
+            rc = ensure_buf(c, &c->pw_chdr, &c->pw_chdr_bytes, (size_t)n_regions * 4);
+            if (rc) return rc;
+            rc = ensure_buf(c, &c->pw_cent, &c->pw_cent_bytes, (size_t)n_regions * mvs::kCandRegion * sizeof(int2));
+            if (rc) return rc;
+            a.cand_hdr = (unsigned int*)c->pw_chdr;
+            a.cand_ent = (int2*)c->pw_cent;
+        }
         for (int attempt = 0; attempt < 3; ++attempt) {
             a.cand = (int2*)c->pw_cand;
             a.cand_capacity = c->pw_cand_bytes / sizeof(int2);
@@ -1146,6 +1165,7 @@ int pairwise_launch(mvs_ctx* c, const mvs_sketch_set* s, const double* d_n2, int
                 rc = set_count();
                 if (rc) return rc;
             }
+            if (n_regions > 0) HIP_TRY(hipMemsetAsync(a.cand_hdr, 0, (size_t)n_regions * 4, c->stream));
             if (c->timing) HIP_TRY(hipEventRecord(c->ev[2], c->stream));
             rc = mvs::launch_filter(c->stream, a, c->opt);
             if (rc) return fail(rc, "filter launch rejected");
@@ -1153,6 +1173,11 @@ int pairwise_launch(mvs_ctx* c, const mvs_sketch_set* s, const double* d_n2, int
             if (rc) return rc;
             if (c->timing) {   // ev[5] closes the filter's interval and opens the re-check's
                 HIP_TRY(hipEventRecord(c->ev[5], c->stream));
+            }
+            if (n_regions > 0) {   // the waves' own candidate regions -> the list (counted with the re-check)
+                mvs::launch_cand_gather(c->stream, a, n_regions);
+                rc = check_kernel("k_cand_gather");
+                if (rc) return rc;
             }
             rc = mvs::launch_exact_pairs(c->stream, a, c->opt);
             if (rc) return fail(rc, "exact re-check launch rejected");

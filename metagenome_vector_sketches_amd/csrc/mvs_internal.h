@@ -47,9 +47,14 @@ struct Options {
                                     // wave sharing the first splitmix64 round
     int markers = 0;                // 1: roctx ranges around the main entry points (rocprofv3 --marker-trace)
     int enable_k3 = 0;              // 1: mvs_sketch_set_create picks the three-plane Karatsuba code for |v| <= 8127
+    int pairwise_map = 0;           // sub-patch an XCD takes in k_pairwise_pp: 0 = 4 rows x 8 cols, 1 = 8 x 4, 2 = 2 x 16
+    int coarse_radix = 1;           // radix of the filter's coarse plane: 1 = smallest residual (default), 0 = ceil(max|v| / 127)
+    int cand_regions = 1;           // 1: filter waves leave up to 8 candidates in a region of their own (no atomic to wait for)
     int comm_timeout_s = 600;       // file transport: how long a rank waits for a peer's block before it gives up
     double pairwise_block_cells = 1099511627776.0;   // row-chunk bound of mvs_pairwise_rows (2^40 cells)
 };
+
+constexpr int kCandRegion = 8;   // candidate entries a filter wave can leave in its own region (one 64-byte line)
 
 constexpr unsigned long long kStampSlots = 400000ULL;   // workgroups the time-stamp buffer of an ablation build holds
 
@@ -76,7 +81,9 @@ struct PairwiseArgs {
                                   //    block belongs to another shard and is not computed there)
     int symmetric;                // 1: tiles strictly below the diagonal of the row range are skipped and
                                   //    produced by mirroring the kept cells of their transposes
-    int debug_flags;              // profiling ablations (-DMVS_ABLATIONS builds only): 1 skip k-loop, 2 skip epilogue
+    int debug_flags;              // profiling ablations (-DMVS_ABLATIONS builds only): 1 skip k-loop, 2 skip epilogue,
+                                  // 4 filter epilogue: injected candidates instead of the accumulators' verdict
+    int map_mode;                 // workgroup -> tile map of k_pairwise_pp: 0 = 4 x 8 sub-patch per XCD, 1 = 8 x 4, 2 = 2 x 16
     // two-stage comparison (coarse filter + exact re-check, see "filter" in mvs_pairwise.hip)
     const int8_t* coarse;         // [row * d_pad + k], c = round(v / radix[row]), |c| <= 127
     const float4* fmeta;          // n_alloc: per-row filter constants {s, w, a, p}
@@ -89,6 +96,8 @@ struct PairwiseArgs {
                                      //    k_pairwise_pp {XCC / HW id, start, end, k-loop end, epilogue phases} on the
                                      //    100 MHz realtime clock; the library dumps them to /tmp/mvs_stamps.bin
                                      //    (tools/exp/stamps.py reads that)
+    unsigned int* cand_hdr;          // per (workgroup, wave) region of the ping-pong filter: number of candidates the wave
+    int2* cand_ent;                  //    left in its kCandRegion entries (0: none, or it went to the list itself)
     unsigned int* cand_stop;         // set by the wave that takes the counter past the limit; lives on its own cache
                                      // line (polling the counter itself queues behind its atomics)
 };
@@ -122,11 +131,15 @@ int launch_pairwise(hipStream_t stream, const PairwiseArgs& a, int mode, int alg
 // per-call filter constants, the one-pass filter
 // that appends candidate pairs, and the exact re-check of the candidates that appends kept cells
 int launch_coarse_build(hipStream_t stream, const int8_t* d_planes, int64_t n, int64_t n_alloc, int d_pad,
-                        int8_t* d_coarse, CoarseRow* d_rows);
+                        int8_t* d_coarse, CoarseRow* d_rows, int radix_mode);
 int launch_filter_meta(hipStream_t stream, const CoarseRow* d_rows, const double* d_norms_sq, int64_t n,
                        int64_t n_alloc, int d, double coeff, float4* d_meta);
 int launch_filter(hipStream_t stream, const PairwiseArgs& a, const Options& opt);
 int launch_exact_pairs(hipStream_t stream, const PairwiseArgs& a, const Options& opt);
+// candidate regions of the ping-pong filter: how many (workgroups x 8 waves) launch_filter's grid has for this block, 0 if
+// the variant it would pick appends with atomics only; k_cand_gather moves the regions' contents into the candidate list
+int64_t filter_region_count(const PairwiseArgs& a, const Options& opt);
+int launch_cand_gather(hipStream_t stream, const PairwiseArgs& a, int64_t n_regions);
 // sort cells by (row, col); tmp buffers owned by the caller
 int sort_cells(hipStream_t stream, mvs_cell* d_cells, mvs_cell* d_tmp, int64_t n, void* d_scratch,
                size_t scratch_bytes, size_t* scratch_needed, const Options& opt);

@@ -56,7 +56,7 @@ struct TileCoord {
 // a multiple of 256, so this is also the linear workgroup id % 8), rotated by the patch row, picks a 4-row x 8-col sub-patch and
 // (blockIdx.x / 8) % 32 walks it.  Placement only affects speed.  (A 2-D grid because a dispatch holds at
 // most 2^32 work-items per dimension: one dimension would cap the matrix at ~370k samples.)
-__device__ __forceinline__ TileCoord map_tile(unsigned b, unsigned patch_row, int n_tr, int n_tc) {
+__device__ __forceinline__ TileCoord map_tile(unsigned b, unsigned patch_row, int n_tr, int n_tc, int map_mode = 0) {
     // The sub-patch an XCD takes rotates with the patch row.  With a fixed assignment the symmetric schedule is
     // lopsided: in a patch on the diagonal the sub-patches hold 32, 26, 10 or 0 tiles above the diagonal, in the
     // last patch column only the left sub-patches exist -- measured at 100k samples (per-workgroup time stamps):
@@ -66,8 +66,16 @@ __device__ __forceinline__ TileCoord map_tile(unsigned b, unsigned patch_row, in
     const unsigned ql = q & 31u;
     const int spr = (int)patch_row, spc = (int)(q >> 5);
     TileCoord t;
-    t.tr = spr * 16 + (int)(x >> 1) * 4 + (int)(ql >> 3);
-    t.tc = spc * 16 + (int)(x & 1u) * 8 + (int)(ql & 7u);
+    if (map_mode == 1) {          // 8-row x 4-col sub-patches
+        t.tr = spr * 16 + (int)(x >> 2) * 8 + (int)(ql >> 2);
+        t.tc = spc * 16 + (int)(x & 3u) * 4 + (int)(ql & 3u);
+    } else if (map_mode == 2) {   // 2-row x 16-col sub-patches
+        t.tr = spr * 16 + (int)x * 2 + (int)(ql >> 4);
+        t.tc = spc * 16 + (int)(ql & 15u);
+    } else {
+        t.tr = spr * 16 + (int)(x >> 1) * 4 + (int)(ql >> 3);
+        t.tc = spc * 16 + (int)(x & 1u) * 8 + (int)(ql & 7u);
+    }
     t.valid = t.tr < n_tr && t.tc < n_tc;
     return t;
 }
@@ -820,19 +828,23 @@ __device__ __forceinline__ void epilogue_filter16(const PairwiseArgs& a, v4i (&a
     // lands in the accumulator layout of the int8 products: the matrix pipe -- idle in the epilogue -- forms the
     // thresholds and subtracts them.  Operands: lane (fr, fq)
     // holds constant #fq of row / column fr of the block, so the constants are staged in planes of 256 floats.
-    float* rowc = reinterpret_cast<float*>(smem);                      // [4][TM]: s, w, a, p of the tile's rows
-    float* colc = rowc + 4 * TM;                                       // [4][TN]: w, s, -p, -(a + p) of its columns
+    // Plane stride PS = 256 + 16 floats: lane (fr, fq) reads word fq * PS + base + fr, i.e. bank 16 fq + fr (+ base) --
+    // 64 distinct banks.  With a stride of 256 the four fq groups of a wave met on the same 16 banks: a 4-way conflict on
+    // every one of the 12 constant reads per wave (SQ_LDS_BANK_CONFLICT 1.5e7 cycles per 100k filter pass, round 2).
+    constexpr int PS = TM + 16;
+    float* rowc = reinterpret_cast<float*>(smem);                      // [4][PS]: s, w, a, p of the tile's rows
+    float* colc = rowc + 4 * PS;                                       // [4][PS]: w, s, -p, -(a + p) of its columns
     if (tid < TM) {
         rowc[tid] = fm.x;
-        rowc[TM + tid] = fm.y;
-        rowc[2 * TM + tid] = fm.z;
-        rowc[3 * TM + tid] = fm.w;
+        rowc[PS + tid] = fm.y;
+        rowc[2 * PS + tid] = fm.z;
+        rowc[3 * PS + tid] = fm.w;
     } else {
         const int cidx = tid - TM;
         colc[cidx] = fm.y;
-        colc[TN + cidx] = fm.x;
-        colc[2 * TN + cidx] = -fm.w;
-        colc[3 * TN + cidx] = -(fm.z + fm.w);
+        colc[PS + cidx] = fm.x;
+        colc[2 * PS + cidx] = -fm.w;
+        colc[3 * PS + cidx] = -(fm.z + fm.w);
     }
     __syncthreads();
 #ifdef MVS_ABLATIONS
@@ -848,7 +860,7 @@ __device__ __forceinline__ void epilogue_filter16(const PairwiseArgs& a, v4i (&a
     for (int u = 0; u < 4; ++u) {
         const int col_l = wn * 64 + u * 16 + fr;
         const int64_t col = j0 + col_l;
-        bop[u] = colc[fq * TN + col_l];
+        bop[u] = colc[fq * PS + col_l];
         const bool in_square = a.symmetric && col >= a.row_begin && col < a.row_end;
         row_max[u] = (straddle && in_square) ? col_l + delta : 0x7fffffff;   // col >= row  <=>  row_l <= col_l + delta
     }
@@ -860,11 +872,24 @@ __device__ __forceinline__ void epilogue_filter16(const PairwiseArgs& a, v4i (&a
     // pass" is an integer maximum over the 16 values of a lane -- 1.5 vector instructions per cell (convert, half
     // a v_max3) and no traffic through scalar registers.  (A NaN -- padding rows / columns: inf x 0 -- may look
     // positive to the maximum; the exact compare below then drops it.)
+#ifdef MVS_ABLATIONS
+    // pairwise_debug bit 4: the accumulators are ignored and ONE pseudo-random cell of the wave tile is declared a
+    // candidate with probability 225/256 -- the rate of chance candidates on 50k-hash sketches (0.54 M in 76 636 tiles of
+    // 8 waves) -- so that a run on constant operands goes through the epilogue's rare path (row-block masks, prefix sum,
+    // atomic, append, re-check) as often as a run on sketches does: what that path costs, apart from what the data costs
+    const bool inject = (a.debug_flags & 4) != 0;
+    unsigned inj = 0xffffffffu;                                        // t | u << 3 | r << 5 | lane << 7, or none
+    if (inject) {
+        unsigned h = (unsigned)(i0 * 2654435761u) ^ (unsigned)(j0 * 40503u) ^ (unsigned)(wave * 0x9e3779b9u);
+        h ^= h >> 15; h *= 0x2c1b3c6du; h ^= h >> 12; h *= 0x297a2d39u; h ^= h >> 15;
+        if ((h & 0xffu) < 225u) inj = (h >> 8) & 0x1fffu;
+    }
+#endif
     auto sweep = [&](auto tri) {
         constexpr bool TRI = decltype(tri)::value;
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
-            const float aop = -rowc[fq * TM + wm * 128 + t * 16 + fr];
+            const float aop = -rowc[fq * PS + wm * 128 + t * 16 + fr];
             const int row_l = wm * 128 + t * 16 + fq * 4;
             v4f dif[4];
 #pragma unroll
@@ -878,12 +903,18 @@ __device__ __forceinline__ void epilogue_filter16(const PairwiseArgs& a, v4i (&a
                 const v4i bits = __builtin_bit_cast(v4i, dif[u]);
                 top = max(max(top, bits[0]), max(max(bits[1], bits[2]), bits[3]));
             }
+#ifdef MVS_ABLATIONS
+            if (inject) top = ((inj & 7u) == (unsigned)t && (inj >> 7) == (unsigned)lane) ? 1 : 0;
+#endif
             if (__ballot(top > 0) != 0ULL) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         bool c = dif[u][r] > 0.0f;
+#ifdef MVS_ABLATIONS
+                        if (inject) c = top > 0 && ((inj >> 3) & 3u) == (unsigned)u && ((inj >> 5) & 3u) == (unsigned)r;
+#endif
                         if (TRI) c = c && row_l + r <= row_max[u];
                         m32[u] |= c ? 1u << (t * 4 + r) : 0u;
                     }
@@ -896,20 +927,41 @@ __device__ __forceinline__ void epilogue_filter16(const PairwiseArgs& a, v4i (&a
     if (stamp && tid == 0) stamp[6] = wall_clock64();
 #endif
     const unsigned mine = (unsigned)(__popc(m32[0]) + __popc(m32[1]) + __popc(m32[2]) + __popc(m32[3]));
-    if (__ballot(mine != 0) == 0ULL) return;               // the common case: nothing in this wave passes
+    if (__ballot(mine != 0) == 0ULL) return;               // nothing in this wave passes (its region header stays 0)
     unsigned incl = mine;                                   // inclusive prefix sum over the lanes
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
         const unsigned up = (unsigned)__shfl_up((int)incl, o, 64);
         if (lane >= o) incl += up;
     }
-    unsigned long long base = 0;
-    if (lane == 63) {
-        base = atomicAdd(a.cand_counter, (unsigned long long)incl);
-        if (base + incl > a.cand_limit) *a.cand_stop = 1u;   // tell the tiles that have not started yet
+    // Where do the candidates go?  Reserving list space with an atomic means waiting for its RETURN at the very end of
+    // the tile, with nothing left to overlap it -- and on 50k-hash sketches nine waves in ten hold a chance candidate:
+    // measured on constant operands with candidates injected at that rate, the wait costs 1.5 ms of a 100k filter pass
+    // (7.0 -> 8.5 ms).  So a wave with up to kCandRegion candidates writes them, and their count, into a region of its own
+    // (indexed by workgroup and wave: plain stores, nothing to wait for) and k_cand_gather moves the regions' contents
+    // into the list afterwards; only a wave with more than that (tiles on the diagonal, dense data) takes the atomic.
+    const unsigned total = (unsigned)__shfl((int)incl, 63, 64);
+    const bool to_region = a.cand_hdr != nullptr && total <= (unsigned)kCandRegion;
+    unsigned long long slot;
+    int2* list;
+    unsigned long long list_cap;
+    if (to_region) {
+        const unsigned long long reg = ((unsigned long long)blockIdx.y * gridDim.x + blockIdx.x) * 8ull + (unsigned)wave;
+        if (lane == 63) a.cand_hdr[reg] = total;
+        slot = reg * kCandRegion + (incl - mine);
+        list = a.cand_ent;
+        list_cap = ~0ULL;
+    } else {
+        unsigned long long base = 0;
+        if (lane == 63) {
+            base = atomicAdd(a.cand_counter, (unsigned long long)incl);
+            if (base + incl > a.cand_limit) *a.cand_stop = 1u;   // tell the tiles that have not started yet
+        }
+        base = __shfl(base, 63, 64);
+        slot = base + (incl - mine);
+        list = a.cand;
+        list_cap = a.cand_capacity;
     }
-    base = __shfl(base, 63, 64);
-    unsigned long long slot = base + (incl - mine);
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const int col_l = wn * 64 + u * 16 + fr;
@@ -922,18 +974,51 @@ __device__ __forceinline__ void epilogue_filter16(const PairwiseArgs& a, v4i (&a
             m &= m - 1;
             const int row_l = wm * 128 + (b >> 2) * 16 + fq * 4 + (b & 3);
             const bool mirror = a.mirror_all || (in_square && cd > row_l);
-            if (slot < a.cand_capacity)
-                a.cand[slot] = make_int2((int32_t)(i0 + row_l), mirror ? (int)((unsigned)col | 0x80000000u) : (int)col);
+            if (slot < list_cap)
+                list[slot] = make_int2((int32_t)(i0 + row_l), mirror ? (int)((unsigned)col | 0x80000000u) : (int)col);
             ++slot;
         }
     }
+}
+
+// The candidates the filter's waves left in their regions (see epilogue_filter16) are appended to the candidate list:
+// one thread per region, a block-wide prefix sum of the region counts, ONE atomic per block.
+__global__ __launch_bounds__(256) void k_cand_gather(const PairwiseArgs a, unsigned long long n_regions) {
+    __shared__ unsigned wave_sum[4];
+    __shared__ unsigned long long block_base;
+    const unsigned long long reg = (unsigned long long)blockIdx.x * 256ull + threadIdx.x;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const unsigned cnt = reg < n_regions ? a.cand_hdr[reg] : 0u;
+    unsigned incl = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned up = (unsigned)__shfl_up((int)incl, o, 64);
+        if (lane >= o) incl += up;
+    }
+    if (lane == 63) wave_sum[w] = incl;
+    __syncthreads();
+    unsigned before = 0, total = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        before += i < w ? wave_sum[i] : 0u;
+        total += wave_sum[i];
+    }
+    if (total == 0) return;                                  // block-uniform
+    if (threadIdx.x == 0) block_base = atomicAdd(a.cand_counter, (unsigned long long)total);
+    __syncthreads();
+    unsigned long long slot = block_base + before + (incl - cnt);
+    for (unsigned e = 0; e < cnt; ++e, ++slot)
+        if (slot < a.cand_capacity) a.cand[slot] = a.cand_ent[reg * kCandRegion + e];
 }
 
 // ORDER: 0 fragment reads then copies, 1 copies then fragment reads, 2 by wave parity (half the group's waves each
 // way, so that the LDS reads of some overlap the copy issue of the others).  ABL (ablation builds): 1 no MFMA,
 // 2 no copies after the prologue, 3 no fragment reads after the first slice.
 // PH: phases per slice (1: 32 MFMAs per interval; 2: the slice's A fragments in two halves, 16 MFMAs per interval).
-template <int MODE, int NST, int ORDER = 0, int ABL = 0, int PH = 1>
+// NT: cache policy of the HBM/L2 -> LDS copies: 0 default, 1 column panels (B region) non-temporal, 2 row panels (A region),
+// 3 both.  An XCD walks its sub-patch along a patch ROW, so consecutive groups of 32 tiles share their 4 row panels and
+// stream 8 new column panels through the L2; `nt` marks the stream as evict-first.
+template <int MODE, int NST, int ORDER = 0, int ABL = 0, int PH = 1, int NT = 0>
 __global__ __launch_bounds__(512, 2) void k_pairwise_pp(const PairwiseArgs a, int n_tr, int n_tc) {
 #ifndef MVS_ABLATIONS
     static_assert(ABL == 0, "ablations need a -DMVS_ABLATIONS build");
@@ -959,7 +1044,7 @@ __global__ __launch_bounds__(512, 2) void k_pairwise_pp(const PairwiseArgs a, in
         }
     }
 #endif
-    const TileCoord tc = map_tile(blockIdx.x, blockIdx.y, n_tr, n_tc);
+    const TileCoord tc = map_tile(blockIdx.x, blockIdx.y, n_tr, n_tc, a.map_mode);
     if (!tc.valid) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -985,11 +1070,15 @@ __global__ __launch_bounds__(512, 2) void k_pairwise_pp(const PairwiseArgs a, in
         const int64_t sample = (is_b ? j0 : i0) + s;
         src[p] = (MODE == 2 ? a.coarse : a.planes) + (sample * L + limb) * (int64_t)a.d_pad + c * 16;
     }
+    // waves 0-3 copy the A region (pieces 0..15), waves 4-7 the B region: the policy is wave-uniform
+    const bool nt_wave = NT == 3 || (NT == 1 && wave >= 4) || (NT == 2 && wave < 4);
+    auto copy_piece = [&](const int8_t* g, char* l) {
+        if (NT != 0 && nt_wave) __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)l, 16, 0, 2);
+        else __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)l, 16, 0, 0);
+    };
     auto stage_copy = [&](int slot, int k0) {
 #pragma unroll
-        for (int p = 0; p < kPPW; ++p)
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src[p] + k0),
-                                             (lds_ptr_t)(smem + slot * kStage + (wave * kPPW + p) * 1024), 16, 0, 0);
+        for (int p = 0; p < kPPW; ++p) copy_piece(src[p] + k0, smem + slot * kStage + (wave * kPPW + p) * 1024);
     };
     // ---- fragments: 8 of the A operand, 4 of the B operand per slice ----
     const int fr = lane & 15, fq = lane >> 4;
@@ -1044,8 +1133,7 @@ __global__ __launch_bounds__(512, 2) void k_pairwise_pp(const PairwiseArgs a, in
                 if (s + D < nk && ABL != 2) {
 #pragma unroll
                     for (int p = ph * CP; p < (ph + 1) * CP; ++p)
-                        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src[p] + (s + D) * kSK),
-                                                         (lds_ptr_t)(smem + fill * kStage + (wave * kPPW + p) * 1024), 16, 0, 0);
+                        copy_piece(src[p] + (s + D) * kSK, smem + fill * kStage + (wave * kPPW + p) * 1024);
                 }
             };
             if (copies_first) copies();
@@ -1282,7 +1370,7 @@ __global__ __launch_bounds__(256) void k_cand_thr(const double* __restrict__ n2,
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_coarse_build(const int8_t* __restrict__ planes, int64_t n, int64_t n_alloc,
                                                       int d_pad, int8_t* __restrict__ coarse,
-                                                      CoarseRow* __restrict__ rows) {
+                                                      CoarseRow* __restrict__ rows, int radix_mode) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= n_alloc) return;
@@ -1316,7 +1404,42 @@ __global__ __launch_bounds__(256) void k_coarse_build(const int8_t* __restrict__
         mx = other > mx ? other : mx;
         ss += __shfl_xor(ss, o, 64);
     }
-    const int m = mx <= 127 ? 1 : (mx + 126) / 127;
+    int m = mx <= 127 ? 1 : (mx + 126) / 127;
+    if (radix_mode == 1 && m > 1) {
+        // The filter's bound grows with |r| (r = v - m c, c clamped to +-127): the radix that just avoids clamping is
+        // not the one with the smallest residual -- sketch entries are bell shaped, a slightly smaller radix halves
+        // the rounding error of ALL entries and clamps a handful of them.  Try 16 radices from ceil(max|v| / 127)
+        // downwards and keep the one with the smallest sum of squared residuals (exact integers).
+        const int step = m >= 64 ? m / 32 : 1;
+        unsigned long long best = ~0ULL;
+        int best_m = m;
+        for (int t = 0; t < 16; ++t) {
+            const int mc = m - t * step;
+            if (mc < 1) break;
+            const float ic = 1.0f / (float)mc;
+            unsigned long long r2c = 0;
+            for (int k = lane; k < chunks; k += 64) {
+                const v4i l4 = lo[k], h4 = hi[k];
+#pragma unroll
+                for (int w = 0; w < 4; ++w)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int v = (int)(int8_t)((uint32_t)l4[w] >> (8 * e)) + 256 * (int)(int8_t)((uint32_t)h4[w] >> (8 * e));
+                        int c = (int)rintf((float)v * ic);
+                        c = c > 127 ? 127 : (c < -127 ? -127 : c);
+                        const int r = v - mc * c;
+                        r2c += (unsigned long long)((long long)r * r);
+                    }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) r2c += __shfl_xor(r2c, o, 64);
+            if (r2c < best) {
+                best = r2c;
+                best_m = mc;
+            }
+        }
+        m = best_m;
+    }
     const float inv = 1.0f / (float)m;
     unsigned c2 = 0, r2 = 0;   // <= 129^2 * 32768 per row: fits
     for (int k = lane; k < chunks; k += 64) {
@@ -1496,12 +1619,20 @@ __global__ __launch_bounds__(256) void k_exact_pairs_tree(const PairwiseArgs a) 
     unsigned long long n_cand = *a.cand_counter;
     if (n_cand > a.cand_limit) return;
     if (n_cand > a.cand_capacity) n_cand = a.cand_capacity;
-    const unsigned long long per = ((n_cand + 7) / 8 + 63) / 64 * 64;
-    const unsigned long long first = (unsigned long long)(blockIdx.x & 7) * per;
-    const unsigned long long last = first + per < n_cand ? first + per : n_cand;
+    // Work split: the list is cut into chunks of 64 rounds (4096 pairs) and chunk c belongs to XCD label c % 8
+    // (blockIdx.x % 8: the workgroups that share an L2), whose waves stride over the rounds of its chunks.  A chunk keeps
+    // neighbours of the list -- pairs of the same tile, which share rows -- in one L2; dealing the chunks out round robin
+    // keeps the XCDs level whatever the order of the list (one contiguous eighth each did not: the pairs of the
+    // diagonal tiles' clusters are cheap L2 hits and sit together, chance pairs cost two rows from HBM each).
+    const unsigned long long rounds = (n_cand + 63) / 64;
+    const unsigned long long xcd = blockIdx.x & 7;
     const unsigned long long waves = (unsigned long long)(gridDim.x >> 3) * 4;
     const unsigned long long wid = (unsigned long long)(blockIdx.x >> 3) * 4 + (threadIdx.x >> 6);
-    for (unsigned long long base = first + wid * 64; base < last; base += waves * 64) {
+    const unsigned long long last = n_cand;
+    for (unsigned long long i = wid;; i += waves) {            // i: index among this XCD's rounds
+        const unsigned long long round = ((i >> 6) * 8 + xcd) * 64 + (i & 63);
+        if (round >= rounds) break;                            // round grows with i (the stride is a multiple of 64)
+        const unsigned long long base = round * 64;
         const unsigned long long mine = base + lane;
         const bool have = mine < last;
         int2 pr = make_int2(0, 0);
@@ -1574,7 +1705,7 @@ int launch_mfma16(hipStream_t stream, const PairwiseArgs& a) {
     return 0;
 }
 
-template <int MODE, int NST, int ORDER = 0, int ABL = 0, int PH = 1>
+template <int MODE, int NST, int ORDER = 0, int ABL = 0, int PH = 1, int NT = 0>
 int launch_pp(hipStream_t stream, const PairwiseArgs& a) {
     using G = PpGeom<MODE>;
     const int64_t rows = a.row_end - a.row_begin, cols = a.col_end - a.col_begin;
@@ -1585,10 +1716,10 @@ int launch_pp(hipStream_t stream, const PairwiseArgs& a) {
     const size_t lds = (size_t)NST * G::kStage;
     PairwiseArgs b = a;
     if (b.symmetric && ((a.row_begin - a.col_begin) % G::TM != 0 || a.mirror_all)) b.symmetric = 0;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pairwise_pp<MODE, NST, ORDER, ABL, PH>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pairwise_pp<MODE, NST, ORDER, ABL, PH, NT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return MVS_E_HIP;
-    hipLaunchKernelGGL((k_pairwise_pp<MODE, NST, ORDER, ABL, PH>), dim3((unsigned)n_spc * 256u, (unsigned)n_spr), dim3(512), lds, stream,
+    hipLaunchKernelGGL((k_pairwise_pp<MODE, NST, ORDER, ABL, PH, NT>), dim3((unsigned)n_spc * 256u, (unsigned)n_spr), dim3(512), lds, stream,
                        b, n_tr, n_tc);
     return 0;
 }
@@ -1659,10 +1790,10 @@ int launch_cand_thr(hipStream_t stream, const double* d_norms_sq, int64_t n, int
 }
 
 int launch_coarse_build(hipStream_t stream, const int8_t* d_planes, int64_t n, int64_t n_alloc, int d_pad,
-                        int8_t* d_coarse, CoarseRow* d_rows) {
+                        int8_t* d_coarse, CoarseRow* d_rows, int radix_mode) {
     if (n_alloc <= 0) return 0;
     hipLaunchKernelGGL(k_coarse_build, dim3((unsigned)((n_alloc + 3) / 4)), dim3(256), 0, stream, d_planes, n, n_alloc,
-                       d_pad, d_coarse, d_rows);
+                       d_pad, d_coarse, d_rows, radix_mode);
     return 0;
 }
 
@@ -1673,23 +1804,23 @@ int launch_filter_meta(hipStream_t stream, const CoarseRow* d_rows, const double
     return 0;
 }
 
+static int filter_variant_for(const PairwiseArgs& a, const Options& opt);
+
 int launch_filter(hipStream_t stream, const PairwiseArgs& a, const Options& opt) {
     if (a.limbs != 2 || a.d_pad > 32768) return MVS_E_INVALID;
     // opt.filter_variant: tile shape / ring depth of the one-pass filter.
     // Default (-1): the ping-pong kernel on 256 x 256 tiles (half the L2 -> LDS bytes per cell of 128 x 128 tiles; its
     // two wave groups overlap copies and MFMAs: 11.4 -> 10.0 ms at 100k samples against the ring kernel on the same
     // tiles) once the block holds enough tiles to keep 256 CUs busy through the tail, 128 x 128 ring tiles below that.
-    int v = opt.filter_variant;
-    if (v < 0) {
-        const double tiles = (double)(a.row_end - a.row_begin) * (double)(a.col_end - a.col_begin) / 65536.0 *
-                             (a.symmetric ? 0.5 : 1.0);
-        v = tiles >= 4096.0 ? 8 : 0;
-    }
+    const int v = filter_variant_for(a, opt);
     switch (v) {
         case 7: return launch_pp<2, 5>(stream, a);   // ping-pong wave groups, 256 x 256, 5-stage ring (all 160 KiB of LDS)
         case 8: return launch_pp<2, 4>(stream, a);   // the same on a 4-stage ring
         case 9: return launch_pp<2, 4, 0, 0, 2>(stream, a);    // two phases per slice
         case 10: return launch_pp<2, 4, 2, 0, 2>(stream, a);   // two phases, copy / read order by wave parity
+        case 40: return launch_pp<2, 4, 0, 0, 1, 1>(stream, a);   // variant 8 with non-temporal column-panel copies
+        case 41: return launch_pp<2, 4, 0, 0, 1, 2>(stream, a);   // ... non-temporal row-panel copies
+        case 42: return launch_pp<2, 4, 0, 0, 1, 3>(stream, a);   // ... both
 #ifdef MVS_ABLATIONS
         case 31: return launch_pp<2, 4, 0, 1>(stream, a);
         case 32: return launch_pp<2, 4, 0, 2>(stream, a);
@@ -1709,6 +1840,35 @@ int launch_filter(hipStream_t stream, const PairwiseArgs& a, const Options& opt)
         case 6: return launch_mfma_variant<1, false, 2, 3, 2, 4, 1>(stream, a);            // 3-stage ring, 3 workgroups / CU
         default: return launch_mfma_variant<1, false, 2, 4, 2, 4, 1>(stream, a);           // 128 x 128, waves 64 x 32
     }
+}
+
+// variant the filter launcher picks (launch_filter) for this block
+static int filter_variant_for(const PairwiseArgs& a, const Options& opt) {
+    int v = opt.filter_variant;
+    if (v < 0) {
+        const double tiles = (double)(a.row_end - a.row_begin) * (double)(a.col_end - a.col_begin) / 65536.0 *
+                             (a.symmetric ? 0.5 : 1.0);
+        v = tiles >= 4096.0 ? 8 : 0;
+    }
+    return v;
+}
+
+int64_t filter_region_count(const PairwiseArgs& a, const Options& opt) {
+    if (opt.cand_regions == 0) return 0;
+    const int v = filter_variant_for(a, opt);
+    const bool pp = (v >= 7 && v <= 10) || (v >= 40 && v <= 42) || (v >= 31 && v <= 33);
+    if (!pp) return 0;                       // the ring kernels' epilogue appends with the per-wave atomic
+    const int64_t rows = a.row_end - a.row_begin, cols = a.col_end - a.col_begin;
+    if (rows <= 0 || cols <= 0) return 0;
+    const int64_t n_tr = (rows + 255) / 256, n_tc = (cols + 255) / 256;
+    return ((n_tr + 15) / 16) * ((n_tc + 15) / 16) * 256 * 8;      // workgroups of the launch x 8 waves
+}
+
+int launch_cand_gather(hipStream_t stream, const PairwiseArgs& a, int64_t n_regions) {
+    if (n_regions <= 0) return 0;
+    hipLaunchKernelGGL(k_cand_gather, dim3((unsigned)((n_regions + 255) / 256)), dim3(256), 0, stream, a,
+                       (unsigned long long)n_regions);
+    return 0;
 }
 
 int launch_exact_pairs(hipStream_t stream, const PairwiseArgs& a, const Options& opt) {

@@ -38,6 +38,8 @@ if mode == "fail" and rank == 1:
     sys.exit(7)
 if mode == "fail" and rank == 0:
     time.sleep(60)          # a rank left inside a collective by the one that died
+if rank == 0:
+    print("[Gloo] Rank 0 is connected to 2 peer ranks")      # a library that announces itself on stdout
 print("noise from rank %d" % rank if rank else json.dumps({"world": world, "argv": sys.argv[1:]}))
 '''
 
@@ -55,6 +57,7 @@ def test_launcher_relays_rank0_line_and_worst_exit_code(tmp_path, capfd):
     lines = [l for l in out.splitlines() if l.strip()]
     assert len(lines) == 1 and json.loads(lines[0]) == {"world": 3, "argv": ["ok", "--steps", "2"]}
     assert "noise from rank 1" in err and "noise from rank 2" in err      # other ranks never write to the bench line's stream
+    assert "[Gloo] Rank 0" in err
     t0 = time.monotonic()
     rc = launch_workers(2, ["fail"], script=str(stub), env=env, grace_s=0.5)
     out, err = capfd.readouterr()
