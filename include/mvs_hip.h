@@ -36,6 +36,7 @@ extern "C" {
 #define MVS_E_CAPACITY   3   /* output buffer too small; the needed size is reported */
 #define MVS_E_NOMEM      4   /* host or device allocation failed */
 #define MVS_E_RANGE      5   /* input outside the supported numeric range */
+#define MVS_E_ABORTED    6   /* a caller's callback asked to stop */
 
 #define MVS_MEM_HOST     0
 #define MVS_MEM_DEVICE   1
@@ -241,6 +242,33 @@ int mvs_sketch_set_destroy(mvs_sketch_set* set);
 int mvs_pairwise_rows(mvs_ctx* ctx, const mvs_sketch_set* set, const double* norms_sq, int mem_norms,
                       int keep_mode, int64_t row_begin, int64_t row_end, mvs_cell* cells,
                       int64_t capacity, int mem_cells, int64_t* n_cells);
+
+/* The same comparison with the result STREAMED out in row blocks instead of returned in one caller-sized buffer -- what a
+ * shard writer wants (src/pairwise_comp_optimized.cpp:974-990 keeps all of `all_results` in RAM and then groups it by row;
+ * its writer, :718-736, needs per row only the ascending columns and q).  Rows [row_begin,row_end) against all columns;
+ * the kept cells come back as CSR pieces of consecutive whole rows, in ascending row order, each piece exactly once:
+ *     row r of a piece (row_begin <= r < row_end) holds cells row_ptr[r - row_begin] .. row_ptr[r - row_begin + 1] of
+ *     col[] (ascending) and q[]; q16 replaces q (which is then NULL) in the one case where a value does not fit 8 bits
+ *     (a negative Jaccard estimate from a norms file that does not belong to the vectors).
+ * The arrays live in pinned host memory of the library and are valid only during the callback.  The callback runs on a
+ * worker thread of the library, one call at a time, while the device computes and downloads the next pieces; a
+ * non-zero return stops the comparison (MVS_E_ABORTED).  Empty rows are covered too (pieces with n_cells 0 occur).
+ * Nothing is ever computed twice for lack of space: the two-stage comparison sizes its output from the candidate count
+ * between its stages; where the exact kernel runs, the rows are cut into blocks whose worst case fits
+ * `device_budget_bytes` of HBM (0: a quarter of what is free), each using the symmetric schedule inside its own square.
+ * *n_cells (optional) receives the number of kept cells delivered.  Synchronous. */
+typedef struct {
+    int64_t row_begin, row_end;
+    int64_t n_cells;
+    const int64_t* row_ptr;
+    const int32_t* col;
+    const uint8_t* q;
+    const uint16_t* q16;
+} mvs_row_block;
+typedef int (*mvs_row_block_cb)(void* user, const mvs_row_block* block);
+int mvs_pairwise_stream(mvs_ctx* ctx, const mvs_sketch_set* set, const double* norms_sq, int mem_norms, int keep_mode,
+                        int64_t row_begin, int64_t row_end, size_t device_budget_bytes, mvs_row_block_cb cb, void* user,
+                        int64_t* n_cells);
 
 /* One rectangular block of the comparison -- rows [row_begin,row_end) x columns [col_begin,col_end) -- for
  * schedules that split a shard's work by column block (metagenome_vector_sketches_amd/parallel.py: with G

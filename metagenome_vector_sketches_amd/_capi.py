@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # MVS_HIP_LIBRARY: profiling tools point this at the ablation build (make -C csrc ablations); nothing else should
 LIB_PATH = os.environ.get("MVS_HIP_LIBRARY") or os.path.join(_HERE, "libmvs_hip.so")
 
-MVS_OK, MVS_E_INVALID, MVS_E_HIP, MVS_E_CAPACITY, MVS_E_NOMEM, MVS_E_RANGE = 0, 1, 2, 3, 4, 5
+MVS_OK, MVS_E_INVALID, MVS_E_HIP, MVS_E_CAPACITY, MVS_E_NOMEM, MVS_E_RANGE, MVS_E_ABORTED = 0, 1, 2, 3, 4, 5, 6
 MEM_HOST, MEM_DEVICE = 0, 1
 KEEP_INT32, KEEP_INT16 = 0, 1
 LIMBS_K3 = 0x103
@@ -24,6 +24,16 @@ CELL_DTYPE = np.dtype([("row", "<i4"), ("col", "<i4"), ("dot", "<i4"), ("q", "<i
 # every symbol include/mvs_hip.h declares: (name, restype, argtypes)
 _c = ctypes
 _P = _c.c_void_p
+
+
+class RowBlock(ctypes.Structure):
+    """mvs_row_block: one CSR piece of the streamed comparison result"""
+    _fields_ = [("row_begin", _c.c_int64), ("row_end", _c.c_int64), ("n_cells", _c.c_int64),
+                ("row_ptr", _c.POINTER(_c.c_int64)), ("col", _c.POINTER(_c.c_int32)),
+                ("q", _c.POINTER(_c.c_uint8)), ("q16", _c.POINTER(_c.c_uint16))]
+
+
+ROW_BLOCK_CB = ctypes.CFUNCTYPE(_c.c_int, _P, _c.POINTER(RowBlock))
 SYMBOLS = [
     ("mvs_version", _c.c_char_p, []),
     ("mvs_last_error", _c.c_char_p, []),
@@ -62,6 +72,8 @@ SYMBOLS = [
     ("mvs_sketch_set_destroy", _c.c_int, [_P]),
     ("mvs_pairwise_rows", _c.c_int, [_P, _P, _P, _c.c_int, _c.c_int, _c.c_int64, _c.c_int64, _P, _c.c_int64,
                                       _c.c_int, _c.POINTER(_c.c_int64)]),
+    ("mvs_pairwise_stream", _c.c_int, [_P, _P, _P, _c.c_int, _c.c_int, _c.c_int64, _c.c_int64, _c.c_size_t, ROW_BLOCK_CB, _P,
+                                        _c.POINTER(_c.c_int64)]),
     ("mvs_pairwise_block", _c.c_int, [_P, _P, _P, _c.c_int, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int,
                                        _P, _c.c_int64, _c.POINTER(_c.c_int64)]),
     ("mvs_cells_sort", _c.c_int, [_P, _P, _c.c_int64, _P]),
@@ -488,6 +500,60 @@ class Context:
                 continue
             _check(rc)
             return cells[:count.value], count.value
+
+    def pairwise_stream(self, sset, norms_sq, on_block=None, row_begin=0, row_end=None, keep_mode=KEEP_INT32,
+                        device_budget_bytes=0):
+        """mvs_pairwise_stream: the kept cells of rows [row_begin, row_end) in CSR pieces of whole rows, ascending.
+        on_block(row_begin, row_end, row_ptr, col, q) is called per piece with numpy COPIES (q is uint8, or uint16 in the
+        mismatched-norms case); a truthy return stops the comparison (MvsError MVS_E_ABORTED).  Without on_block the
+        pieces are collected: returns (row_ptr int64 [rows + 1], col int32 [n], q [n], n)."""
+        if row_end is None:
+            row_end = sset.n
+        np_, nm, nk = _buf(norms_sq) if _is_torch(norms_sq) else _buf(norms_sq, np.float64)
+        parts, errors = [], []
+
+        def trampoline(_user, bp):
+            try:
+                b = bp.contents
+                rows, n = b.row_end - b.row_begin, b.n_cells
+                rp = np.ctypeslib.as_array(b.row_ptr, shape=(rows + 1,)).copy()
+                col = np.ctypeslib.as_array(b.col, shape=(n,)).copy() if n else np.empty(0, np.int32)
+                if n == 0:
+                    q = np.empty(0, np.uint8)
+                elif b.q:
+                    q = np.ctypeslib.as_array(b.q, shape=(n,)).copy()
+                else:
+                    q = np.ctypeslib.as_array(b.q16, shape=(n,)).copy()
+                if on_block is not None:
+                    return 1 if on_block(b.row_begin, b.row_end, rp, col, q) else 0
+                parts.append((b.row_begin, b.row_end, rp, col, q))
+                return 0
+            except BaseException as e:      # noqa: BLE001 -- an exception must not unwind through the C frames
+                errors.append(e)
+                return -1
+
+        cb = ROW_BLOCK_CB(trampoline)
+        count = _c.c_int64()
+        rc = self.lib.mvs_pairwise_stream(self._h, sset._h, np_, nm, keep_mode, int(row_begin), int(row_end),
+                                          int(device_budget_bytes), cb, None, ctypes.byref(count))
+        if errors:
+            raise errors[0]
+        _check(rc)
+        if on_block is not None:
+            return count.value
+        rows = row_end - row_begin
+        row_ptr = np.zeros(rows + 1, dtype=np.int64)
+        at, expect = 0, row_begin
+        for (b0, b1, rp, col, q) in parts:
+            assert b0 == expect and rp[0] == 0, "pieces must arrive in ascending row order, each row once"
+            row_ptr[b0 - row_begin:b1 - row_begin + 1] = rp + at
+            at += int(rp[-1])
+            expect = b1
+        assert expect == row_end and at == count.value
+        wide = any(p[4].dtype == np.uint16 for p in parts)
+        col = np.concatenate([p[3] for p in parts]) if parts else np.empty(0, np.int32)
+        q = np.concatenate([p[4].astype(np.uint16 if wide else np.uint8) for p in parts]) if parts else np.empty(0, np.uint8)
+        return row_ptr, col, q, count.value
 
     def pairwise_block(self, sset, norms_sq, row_begin, row_end, col_begin, col_end, flags, cells, n_cells,
                        keep_mode=KEEP_INT32):

@@ -176,6 +176,46 @@ int main(int argc, char* argv[]) {
         CHECK(mvs_host::read_shard(dir + "many/", back) && back.size() == cells.size());
         for (size_t i = 0; i < cells.size(); i += 97)
             CHECK(back[i].row == cells[i].row && back[i].col == cells[i].col && back[i].q == cells[i].q);
+        // the streaming writer, fed the same cells as CSR pieces of uneven sizes (rows without cells in between, empty
+        // pieces, 8-bit and 16-bit q arrays): the same three files byte for byte
+        {
+            mvs_host::ShardWriter w(dir + "stream/", 5);
+            const int64_t n_rows_total = 40000 + 300;                    // trailing rows without cells
+            std::vector<int64_t> first_cell((size_t)n_rows_total + 1, (int64_t)cells.size());
+            for (size_t i = cells.size(); i-- > 0;) first_cell[(size_t)cells[i].row] = (int64_t)i;
+            for (int64_t r = n_rows_total - 1; r >= 0; --r)
+                if (first_cell[(size_t)r] == (int64_t)cells.size() || first_cell[(size_t)r] > first_cell[(size_t)r + 1])
+                    first_cell[(size_t)r] = std::min(first_cell[(size_t)r], first_cell[(size_t)r + 1]);
+            int piece = 0;
+            for (int64_t r0 = 0; r0 < n_rows_total; ++piece) {
+                const int64_t r1 = std::min<int64_t>(n_rows_total, r0 + (piece % 3 == 0 ? 1 : (piece % 3 == 1 ? 7777 : 0)));
+                const int64_t c0 = first_cell[(size_t)r0], c1 = first_cell[(size_t)r1];
+                std::vector<int64_t> rp((size_t)(r1 - r0) + 1);
+                for (int64_t r = r0; r <= r1; ++r) rp[(size_t)(r - r0)] = first_cell[(size_t)r] - c0;
+                std::vector<int32_t> col((size_t)(c1 - c0));
+                std::vector<uint8_t> q8((size_t)(c1 - c0));
+                std::vector<uint16_t> q16((size_t)(c1 - c0));
+                for (int64_t k = c0; k < c1; ++k) {
+                    col[(size_t)(k - c0)] = cells[(size_t)k].col;
+                    q8[(size_t)(k - c0)] = (uint8_t)cells[(size_t)k].q;
+                    q16[(size_t)(k - c0)] = (uint16_t)cells[(size_t)k].q;
+                }
+                mvs_row_block b{};
+                b.row_begin = r0;
+                b.row_end = r1;
+                b.n_cells = c1 - c0;
+                b.row_ptr = rp.data();
+                b.col = col.data();
+                if (piece % 2) b.q = q8.data();
+                else b.q16 = q16.data();
+                w.add(b);
+                r0 = r1;
+            }
+            const mvs_host::ShardStats ss = w.finish();
+            CHECK(ss.jac_space == s1.jac_space && ss.ngh_space == s1.ngh_space && ss.rows == s1.rows && w.cells() == cells.size());
+            for (const char* f : {"matrix.bin", "row_index.bin", "neighbor_start.bin"})
+                CHECK(slurp(dir + "one/" + f) == slurp(dir + "stream/" + f));
+        }
     }
     std::filesystem::remove_all(dir);
     // hash text parsing: dedup, stop at the first bad token, lines without ':' skipped

@@ -496,6 +496,137 @@ inline ShardStats write_shard(const std::string& folder, const mvs_cell* cells, 
     return st;
 }
 
+// The same shard written piece by piece: add() takes CSR pieces of consecutive whole rows in ascending row order
+// (mvs_row_block, what mvs_pairwise_stream delivers) and appends their rows to matrix.bin at once; only the per-row
+// directory (row id, byte offset, first column) stays in memory until finish() writes row_index.bin and
+// neighbor_start.bin.  The files are byte for byte what write_shard() writes for the same cells.
+class ShardWriter {
+public:
+    explicit ShardWriter(const std::string& folder, unsigned threads = 0) : folder_(folder), threads_(threads) {
+        if (!fs::exists(folder_)) fs::create_directories(folder_);
+        bin_out_.open(folder_ + "matrix.bin", std::ios::binary);
+        if (threads_ == 0) threads_ = std::max(1u, std::thread::hardware_concurrency());
+    }
+
+    void add(const mvs_row_block& b) {
+        const int64_t rows = b.row_end - b.row_begin;
+        if (rows < 0 || b.row_begin < next_row_) throw std::runtime_error("ShardWriter: pieces must come in ascending row order");
+        next_row_ = b.row_end;
+        cells_ += (uint64_t)b.n_cells;
+        std::vector<int64_t> live;                                  // rows of the piece that hold cells
+        for (int64_t r = 0; r < rows; ++r)
+            if (b.row_ptr[r + 1] > b.row_ptr[r]) live.push_back(r);
+        const size_t n_rows = live.size();
+        if (n_rows == 0) return;
+        const size_t first = row_vec_.size();
+        row_vec_.resize(first + n_rows);
+        start_neighbor_.resize(first + n_rows);
+        curr_pos_vec_.resize(first + n_rows);
+        unsigned threads = (unsigned)std::min<size_t>(threads_, std::max<size_t>(1, n_rows / 4096));
+        threads = std::max(1u, threads);
+        struct Part {
+            std::string bytes;
+            uint64_t jac_space = 0, ngh_space = 0;
+            std::string error;
+        };
+        std::vector<Part> parts(threads);
+        auto encode_part = [&](unsigned t) {
+            Part& part = parts[t];
+            std::ostringstream os(std::ios::binary);
+            const size_t r0 = n_rows * t / threads, r1 = n_rows * (t + 1) / threads;
+            std::vector<uint16_t> jac;
+            std::vector<uint64_t> delta;
+            for (size_t r = r0; r < r1; ++r) {
+                const int64_t i = b.row_ptr[live[r]], j = b.row_ptr[live[r] + 1];
+                row_vec_[first + r] = (uint32_t)(b.row_begin + live[r]);
+                curr_pos_vec_[first + r] = (uint64_t)os.tellp();        // relative to this part; rebased below
+                start_neighbor_[first + r] = (uint32_t)b.col[i];
+                jac.resize((size_t)(j - i));
+                delta.resize((size_t)(j - i - 1));
+                for (int64_t k = i; k < j; ++k) {
+                    jac[(size_t)(k - i)] = b.q ? (uint16_t)b.q[k] : b.q16[k];
+                    if (k > i) {
+                        if (b.col[k] <= b.col[k - 1]) {
+                            part.error = "ShardWriter: columns not ascending";
+                            return;
+                        }
+                        delta[(size_t)(k - i - 1)] = (uint64_t)(b.col[k] - b.col[k - 1]);
+                    }
+                }
+                mvs_codec::compact_vector cv_jc;
+                cv_jc.build(jac.begin(), jac.size());
+                cv_jc.save(os);
+                part.jac_space += cv_jc.num_bytes();
+                if (jac.size() > 1) {                     // :732 a single-entry row has no delta sequence
+                    mvs_codec::rice_sequence rs_delta;
+                    rs_delta.encode(delta.begin(), delta.size());
+                    rs_delta.save(os);
+                    part.ngh_space += rs_delta.num_bytes();
+                }
+            }
+            part.bytes = os.str();
+        };
+        auto work = [&](unsigned t) {
+            try {
+                encode_part(t);
+            } catch (const std::exception& e) {
+                parts[t].error = std::string("ShardWriter: ") + e.what();
+            } catch (...) {
+                parts[t].error = "ShardWriter: unknown error in an encoder thread";
+            }
+        };
+        if (threads == 1) {
+            work(0);
+        } else {
+            std::vector<std::thread> pool;
+            for (unsigned t = 0; t < threads; ++t) pool.emplace_back(work, t);
+            for (auto& th : pool) th.join();
+        }
+        for (unsigned t = 0; t < threads; ++t) {
+            if (!parts[t].error.empty()) throw std::runtime_error(parts[t].error);
+            const size_t r0 = n_rows * t / threads, r1 = n_rows * (t + 1) / threads;
+            for (size_t r = r0; r < r1; ++r) curr_pos_vec_[first + r] += pos_;
+            bin_out_.write(parts[t].bytes.data(), (std::streamsize)parts[t].bytes.size());
+            pos_ += parts[t].bytes.size();
+            stats_.jac_space += parts[t].jac_space;
+            stats_.ngh_space += parts[t].ngh_space;
+        }
+    }
+
+    uint64_t cells() const { return cells_; }
+
+    ShardStats finish() {
+        bin_out_.close();
+        std::ofstream index_out(folder_ + "row_index.bin", std::ios::binary);
+        stats_.rows = row_vec_.size();
+        mvs_codec::compact_vector cv_rows;                          // row ids, then byte-offset deltas (:769-783)
+        cv_rows.build(row_vec_.begin(), row_vec_.size());
+        cv_rows.save(index_out);
+        std::vector<uint64_t> pos_delta(curr_pos_vec_.empty() ? 0 : curr_pos_vec_.size() - 1);
+        for (size_t k = 1; k < curr_pos_vec_.size(); ++k) pos_delta[k - 1] = curr_pos_vec_[k] - curr_pos_vec_[k - 1];
+        mvs_codec::compact_vector cv_cps;
+        cv_cps.build(pos_delta.begin(), pos_delta.size());
+        cv_cps.save(index_out);
+        index_out.close();
+        std::ofstream ngh_out(folder_ + "neighbor_start.bin", std::ios::binary);
+        mvs_codec::rice_sequence rs_start;
+        rs_start.encode(start_neighbor_.begin(), start_neighbor_.size());
+        rs_start.save(ngh_out);
+        stats_.ngh_space += rs_start.num_bytes();
+        return stats_;
+    }
+
+private:
+    std::string folder_;
+    unsigned threads_;
+    std::ofstream bin_out_;
+    uint64_t pos_ = 0, cells_ = 0;
+    int64_t next_row_ = 0;
+    std::vector<uint32_t> row_vec_, start_neighbor_;
+    std::vector<uint64_t> curr_pos_vec_;
+    ShardStats stats_;
+};
+
 // decode a shard folder back into (row, col, q) triples in file order -- what the reader's
 // load_neighbors_for_rows_jaccard_wo_sort (src/read_pc_mat_cmp.cpp:597-671) reconstructs
 inline bool read_shard(const std::string& folder, std::vector<mvs_cell>& out) {

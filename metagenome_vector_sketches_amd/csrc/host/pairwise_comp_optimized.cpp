@@ -275,24 +275,22 @@ struct Staging {
     }
 };
 
-// rows [b, e) against all columns; grows the staging buffer, then halves the range, when it is too small
-static int compare_rows(Gpu& g, const std::vector<double>& n2, int keep_mode, int64_t b, int64_t e, Staging& st,
-                        std::vector<mvs_cell>& all) {
-    if (b >= e) return 0;
-    int64_t cnt = 0;
-    const int rc = mvs_pairwise_rows(g.ctx, g.set, n2.data(), MVS_MEM_HOST, keep_mode, b, e, st.p.get(),
-                                     (int64_t)st.cap, MVS_MEM_HOST, &cnt);
-    if (rc == MVS_E_CAPACITY) {
-        if ((size_t)cnt <= st.limit || e - b == 1) {
-            st.reserve((size_t)cnt);                      // a single row is never split
-            return compare_rows(g, n2, keep_mode, b, e, st, all);
-        }
-        const int64_t mid = b + (e - b) / 2;
-        int r = compare_rows(g, n2, keep_mode, b, mid, st, all);
-        return r ? r : compare_rows(g, n2, keep_mode, mid, e, st, all);
+// Legacy int16 output only: rows [b, e) against all columns as a list of cells WITH their dot products, in row blocks
+// whose worst case (every cell kept) fits the staging buffer -- a call can then never report MVS_E_CAPACITY, so nothing
+// is ever compared twice; the price is the symmetric schedule across blocks (each block still uses it inside its own
+// square).
+static int compare_rows(Gpu& g, const std::vector<double>& n2, int keep_mode, int64_t b, int64_t e, int64_t n_total,
+                        Staging& st, std::vector<mvs_cell>& all) {
+    const int64_t block = std::max<int64_t>(1, (int64_t)(st.limit / (size_t)std::max<int64_t>(n_total, 1)));
+    st.reserve((size_t)(std::min(block, std::max<int64_t>(e - b, 1)) * n_total));
+    for (int64_t rb = b; rb < e; rb += block) {
+        const int64_t re = std::min(e, rb + block);
+        int64_t cnt = 0;
+        if (mvs_pairwise_rows(g.ctx, g.set, n2.data(), MVS_MEM_HOST, keep_mode, rb, re, st.p.get(), (int64_t)st.cap,
+                              MVS_MEM_HOST, &cnt) != MVS_OK)
+            return gpu_fail("pairwise comparison");
+        all.insert(all.end(), st.p.get(), st.p.get() + cnt);
     }
-    if (rc != MVS_OK) return gpu_fail("pairwise comparison");
-    all.insert(all.end(), st.p.get(), st.p.get() + cnt);
     return 0;
 }
 
@@ -403,32 +401,60 @@ int main(int argc, char* argv[]) {
         lap("load vectors.bin");
     }
 
-    // kept-cell staging: --max_memory_gb bounds it (16 bytes per cell, a quarter of the budget, at least 1M
-    // cells); it starts at 64 cells per row of the shard and grows on demand
-    double budget = o.max_memory_gb > 0 ? o.max_memory_gb : 1.0;
-    Staging staging;
-    staging.limit = (size_t)std::min<double>(budget * 1024.0 * 1024.0 * 1024.0 / 16.0 / 4.0, 256e6);
-    staging.limit = std::max<size_t>(staging.limit, 1u << 20);
-    staging.reserve(std::min(staging.limit, std::max<size_t>(1u << 20, (size_t)(end_row - begin_row) * 64)));
-    std::vector<mvs_cell> all_results;
     db.norms_sq.resize((size_t)total_vectors);
-    rc = compare_rows(g, db.norms_sq, int16 ? MVS_KEEP_INT16 : MVS_KEEP_INT32, begin_row, end_row, staging,
-                      all_results);
-    if (rc) return rc;
-    lap("compare");
-    if (int16) {                                                                  // _16bits.cpp:419-423
-        auto end_time = std::chrono::high_resolution_clock::now();
+    const int keep_mode = int16 ? MVS_KEEP_INT16 : MVS_KEEP_INT32;
+    if (int16 && legacy16_output()) {
+        // The reference's own output for an int16 DB (_16bits.cpp:251-323, :426) stores round(dot / d) per cell: the one
+        // consumer that needs the dot products, so this path keeps the cell list (mvs_pairwise_rows) instead of the
+        // streamed (column, q) pieces.  --max_memory_gb bounds the staging buffer (16 bytes per cell, a quarter of it).
+        double budget = o.max_memory_gb > 0 ? o.max_memory_gb : 1.0;
+        Staging staging;
+        staging.limit = (size_t)std::min<double>(budget * 1024.0 * 1024.0 * 1024.0 / 16.0 / 4.0, 256e6);
+        staging.limit = std::max<size_t>(staging.limit, 1u << 20);
+        std::vector<mvs_cell> all_results;
+        rc = compare_rows(g, db.norms_sq, keep_mode, begin_row, end_row, total_vectors, staging, all_results);
+        if (rc) return rc;
+        lap("compare");
+        auto end_time = std::chrono::high_resolution_clock::now();                  // _16bits.cpp:419-423
         auto duration = std::chrono::duration_cast<std::chrono::milliseconds>(end_time - start_time);
         std::cout << "Total computation time: " << duration.count() << " ms" << std::endl;
         std::cout << "Total results: " << all_results.size() << std::endl;
-    }
-    if (int16 && legacy16_output()) {   // the reference's own output for an int16 DB (_16bits.cpp:251-323, :426)
         write_shard_legacy16(shard_folder, all_results.data(), all_results.size(), dimension);
         lap("write shard (legacy int16 format)");
         return 0;
     }
-    const ShardStats st = write_shard(shard_folder, all_results.data(), all_results.size());          // :990
-    lap("write shard");
+    // The comparison streams its result out in CSR pieces of whole rows (ascending); the writer appends each piece to
+    // matrix.bin while the device computes and downloads the next one.  Where the reference keeps every kept cell of the
+    // shard in RAM (`all_results`, :974-980) this holds two pinned pieces and the per-row directory.
+    struct Sink {
+        ShardWriter writer;
+        std::string error;
+        static int on_block(void* user, const mvs_row_block* b) {
+            Sink* self = static_cast<Sink*>(user);
+            try {
+                self->writer.add(*b);
+                return 0;
+            } catch (const std::exception& e) {
+                self->error = e.what();
+                return 1;
+            }
+        }
+    } sink{ShardWriter(shard_folder), std::string()};
+    int64_t n_kept = 0;
+    if (mvs_pairwise_stream(g.ctx, g.set, db.norms_sq.data(), MVS_MEM_HOST, keep_mode, begin_row, end_row, 0, &Sink::on_block,
+                            &sink, &n_kept) != MVS_OK) {
+        if (!sink.error.empty()) std::cerr << "pairwise_comp_optimized: " << sink.error << std::endl;
+        return gpu_fail("pairwise comparison");
+    }
+    lap("compare + shard rows (streamed)");
+    if (int16) {                                                                  // _16bits.cpp:419-423
+        auto end_time = std::chrono::high_resolution_clock::now();
+        auto duration = std::chrono::duration_cast<std::chrono::milliseconds>(end_time - start_time);
+        std::cout << "Total computation time: " << duration.count() << " ms" << std::endl;
+        std::cout << "Total results: " << n_kept << std::endl;
+    }
+    const ShardStats st = sink.writer.finish();                                                      // :990
+    lap("shard index files");
     std::cout << "Jac space: " << st.jac_space << " ngh space: " << st.ngh_space << std::endl;        // :808
     if (!int16) {                                                                 // :993-996
         auto end_time = std::chrono::high_resolution_clock::now();

@@ -2,7 +2,10 @@
 // kernel orchestration.  No compute happens on the host here and there is no CPU fallback.
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
+#include <deque>
 #include <dlfcn.h>
+#include <mutex>
 
 #include <cstdarg>
 #include <cstdio>
@@ -41,6 +44,18 @@ struct mvs_ctx {
     void* pw_rows = nullptr;    size_t pw_rows_bytes = 0;
     void* pw_fmeta = nullptr;   size_t pw_fmeta_bytes = 0;
     void* pw_cand = nullptr;    size_t pw_cand_bytes = 0;
+    // streamed output (mvs_pairwise_stream): packed kept cells raw / sorted, their CSR form, the download side
+    void* st_raw = nullptr;     size_t st_raw_bytes = 0;
+    void* st_sorted = nullptr;  size_t st_sorted_bytes = 0;
+    void* st_col = nullptr;     size_t st_col_bytes = 0;
+    void* st_q = nullptr;       size_t st_q_bytes = 0;      // 8-bit q, or 16-bit when a block needs it
+    void* st_rowptr = nullptr;  size_t st_rowptr_bytes = 0;
+    hipStream_t dl_stream = nullptr;
+    void* dl_pinned[2] = {nullptr, nullptr};
+    size_t dl_bytes = 0;
+    hipEvent_t dl_done[2] = {nullptr, nullptr};   // download into pinned buffer i has completed
+    hipEvent_t dl_block = nullptr;                // last download of a row block has completed (its device arrays are free)
+    hipEvent_t dl_ready = nullptr;                // the CSR arrays of a row block are final on the compute stream
     void* pw_chdr = nullptr;    size_t pw_chdr_bytes = 0;   // candidate regions of the ping-pong filter: counts, entries
     void* pw_cent = nullptr;    size_t pw_cent_bytes = 0;
     unsigned long long coarse_id = 0, coarse_gen = 0;
@@ -377,6 +392,15 @@ int mvs_ctx_destroy(mvs_ctx* c) {
     if (c->pw_rows) (void)hipFree(c->pw_rows);
     if (c->pw_fmeta) (void)hipFree(c->pw_fmeta);
     if (c->pw_cand) (void)hipFree(c->pw_cand);
+    for (void* p : {c->st_raw, c->st_sorted, c->st_col, c->st_q, c->st_rowptr})
+        if (p) (void)hipFree(p);
+    for (int i = 0; i < 2; ++i) {
+        if (c->dl_pinned[i]) (void)hipHostFree(c->dl_pinned[i]);
+        if (c->dl_done[i]) (void)hipEventDestroy(c->dl_done[i]);
+    }
+    if (c->dl_block) (void)hipEventDestroy(c->dl_block);
+    if (c->dl_ready) (void)hipEventDestroy(c->dl_ready);
+    if (c->dl_stream) (void)hipStreamDestroy(c->dl_stream);
     if (c->pw_chdr) (void)hipFree(c->pw_chdr);
     if (c->pw_cent) (void)hipFree(c->pw_cent);
     for (int i = 0; i < 2; ++i) {
@@ -1057,9 +1081,23 @@ int prepare_coarse(mvs_ctx* c, const mvs_sketch_set* s) {
 // One comparison of rows [rb,re) x columns [cb,ce) appending to `raw` (device) after the first `start`
 // cells; the running count is left in c->d_counter[0].  Two-stage (filter + exact re-check of the
 // candidates) when the set allows it, otherwise the exact MFMA / vector-ALU kernel on every cell.
+// Streamed output (mvs_pairwise_stream): kept cells as packed 64-bit words (mvs_internal.h: PairwiseArgs::packed) in a
+// grow-only buffer of the context that the launch sizes itself, so that a comparison never has to be repeated because its
+// output did not fit: the two-stage comparison sizes it from the candidate count between the filter and the re-check
+// (a kept cell is a candidate or the mirror image of one), the exact kernel's caller sizes the row block for the worst case.
+struct PackedOut {
+    void** buf;
+    size_t* bytes;
+    int64_t row0;              // rows are stored relative to this one
+    int shift;                 // row field starts at this bit (16 bits of q, then the column)
+    bool two_stage_only;       // do not fall back to the exact kernel: return kNeedExact and let the caller plan row blocks
+};
+constexpr int kNeedExact = 100;   // internal status of pairwise_launch (never leaves the library)
+
 int pairwise_launch(mvs_ctx* c, const mvs_sketch_set* s, const double* d_n2, int keep_mode, int64_t rb, int64_t re,
                     int64_t cb, int64_t ce, bool symmetric, bool mirror_all, mvs_cell* raw, int64_t capacity,
-                    unsigned long long start, unsigned long long* count, double keep_coeff = 0.05) {
+                    unsigned long long start, unsigned long long* count, double keep_coeff = 0.05,
+                    const PackedOut* po = nullptr) {
     // *count: the cell count if this call already had to synchronise for it, ~0 otherwise (read d_counter[0])
     *count = ~0ULL;
     mvs::PairwiseArgs a{};
@@ -1078,6 +1116,13 @@ int pairwise_launch(mvs_ctx* c, const mvs_sketch_set* s, const double* d_n2, int
     a.keep_coeff = keep_coeff;
     a.cells = raw;
     a.capacity = (unsigned long long)capacity;
+    if (po) {
+        a.cells = nullptr;
+        a.packed = (unsigned long long*)*po->buf;
+        a.capacity = *po->bytes / 8;
+        a.pack_row0 = po->row0;
+        a.pack_shift = po->shift;
+    }
     a.counter = c->d_counter;
     a.dots = nullptr;
     a.mirror_all = mirror_all ? 1 : 0;
@@ -1139,6 +1184,8 @@ int pairwise_launch(mvs_ctx* c, const mvs_sketch_set* s, const double* d_n2, int
             forced ? ~0ULL : (unsigned long long)std::min(268435456.0, std::max(65536.0, block_cells / 128.0));
         int64_t cand_want = std::max<int64_t>(std::max<int64_t>(1 << 20, capacity), (int64_t)(block_cells / 4096.0));
         if (!forced) cand_want = std::min<int64_t>(cand_want, (int64_t)limit);
+        if (po && !forced) cand_want = (int64_t)limit;   // streamed output: the list holds whatever the filter may pass on,
+                                                         // so the filter never runs twice (beyond the limit it gives up)
         rc = ensure_buf(c, &c->pw_cand, &c->pw_cand_bytes, (size_t)cand_want * sizeof(int2));
         if (rc) return rc;
         a.coarse = (const int8_t*)c->pw_coarse;
@@ -1179,6 +1226,18 @@ int pairwise_launch(mvs_ctx* c, const mvs_sketch_set* s, const double* d_n2, int
                 rc = check_kernel("k_cand_gather");
                 if (rc) return rc;
             }
+            unsigned long long back[3] = {0, 0, 0};   // cell count, (debug slot), candidate count
+            if (po) {
+                // the output is sized between the two stages: every kept cell is a candidate or its mirror image
+                HIP_TRY(hipMemcpyAsync(back, c->d_counter, 24, hipMemcpyDeviceToHost, c->stream));
+                HIP_TRY(hipStreamSynchronize(c->stream));
+                if (back[2] <= limit && back[2] <= a.cand_capacity) {
+                    rc = ensure_buf(c, po->buf, po->bytes, (size_t)(start + 2 * back[2] + 64) * 8);
+                    if (rc) return rc;
+                    a.packed = (unsigned long long*)*po->buf;
+                    a.capacity = *po->bytes / 8;
+                }
+            }
             rc = mvs::launch_exact_pairs(c->stream, a, c->opt);
             if (rc) return fail(rc, "exact re-check launch rejected");
             rc = check_kernel("k_exact_pairs");
@@ -1187,7 +1246,6 @@ int pairwise_launch(mvs_ctx* c, const mvs_sketch_set* s, const double* d_n2, int
                 HIP_TRY(hipEventRecord(c->ev[3], c->stream));
                 c->ev_valid[1] = c->ev_valid[2] = c->ev_valid[3] = true;
             }
-            unsigned long long back[3] = {0, 0, 0};   // cell count, (debug slot), candidate count
             HIP_TRY(hipMemcpyAsync(back, c->d_counter, 24, hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(hipStreamSynchronize(c->stream));
             const unsigned long long n_cand = back[2];
@@ -1206,6 +1264,7 @@ int pairwise_launch(mvs_ctx* c, const mvs_sketch_set* s, const double* d_n2, int
         }
     }
     c->last_candidates = 0;
+    if (po && po->two_stage_only) return kNeedExact;
     rc = ensure_buf(c, &c->pw_thr, &c->pw_thr_bytes, (size_t)s->n_alloc * 4);
     if (rc) return rc;
     mvs::launch_cand_thr(c->stream, d_n2, s->n, s->n_alloc, s->d, keep_coeff, (int32_t*)c->pw_thr);
@@ -1306,6 +1365,356 @@ int mvs_pairwise_rows(mvs_ctx* c, const mvs_sketch_set* s, const double* norms_s
     }
     // device output: the sort is queued on the context's stream; *n_cells is already final
     return MVS_OK;
+}
+
+// -------------------------------------------------------------------------------------------------
+// streamed output
+// -------------------------------------------------------------------------------------------------
+namespace {
+
+int bits_for(int64_t max_value) {          // bits that hold 0 .. max_value
+    int b = 1;
+    while (b < 63 && (max_value >> b) != 0) ++b;
+    return b;
+}
+
+// Hand-over between the thread that drives the GPU and the one that runs the caller's callback: two pinned buffers,
+// a queue of filled ones.  The callback therefore runs beside the next block's kernels and downloads.
+struct StreamOut {
+    struct Item {
+        int slot;
+        int64_t row_begin, row_end, n_cells;
+        std::vector<int64_t> row_ptr;      // rebased to the block's first cell
+        bool wide;
+    };
+    mvs_ctx* c;
+    mvs_row_block_cb cb;
+    void* user;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<Item> queue;
+    bool slot_busy[2] = {false, false};
+    bool closing = false;
+    int cb_status = 0;                     // first non-zero return of the callback
+    std::string error;
+    std::thread worker;
+
+    void run() {
+        (void)hipSetDevice(c->device);
+        for (;;) {
+            Item it;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return closing || !queue.empty(); });
+                if (queue.empty()) return;
+                it = std::move(queue.front());
+                queue.pop_front();
+            }
+            int status = 0;
+            const hipError_t e = hipEventSynchronize(c->dl_done[it.slot]);
+            if (e != hipSuccess) {
+                std::lock_guard<std::mutex> lk(mu);
+                if (error.empty()) error = std::string("download failed: ") + hipGetErrorString(e);
+            } else {
+                bool skip;
+                {
+                    std::lock_guard<std::mutex> lk(mu);
+                    skip = cb_status != 0 || !error.empty();
+                }
+                if (!skip) {
+                    mvs_row_block b{};
+                    b.row_begin = it.row_begin;
+                    b.row_end = it.row_end;
+                    b.n_cells = it.n_cells;
+                    b.row_ptr = it.row_ptr.data();
+                    const char* base = static_cast<const char*>(c->dl_pinned[it.slot]);
+                    b.col = reinterpret_cast<const int32_t*>(base);
+                    const char* qbase = base + (size_t)it.n_cells * 4;
+                    b.q = it.wide ? nullptr : reinterpret_cast<const uint8_t*>(qbase);
+                    b.q16 = it.wide ? reinterpret_cast<const uint16_t*>(qbase) : nullptr;
+                    try {
+                        status = cb(user, &b);
+                    } catch (...) {            // a C++ callback that throws: no exception crosses the C boundary
+                        status = -1;
+                    }
+                }
+            }
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                if (status != 0 && cb_status == 0) cb_status = status;
+                slot_busy[it.slot] = false;
+            }
+            cv.notify_all();
+        }
+    }
+    int acquire_slot() {                    // blocks until one of the two pinned buffers is free
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return !slot_busy[0] || !slot_busy[1]; });
+        const int sl = slot_busy[0] ? 1 : 0;
+        slot_busy[sl] = true;
+        return sl;
+    }
+    void release_slot(int sl) {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            slot_busy[sl] = false;
+        }
+        cv.notify_all();
+    }
+    void push(Item&& it) {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            queue.push_back(std::move(it));
+        }
+        cv.notify_all();
+    }
+    bool failed() {
+        std::lock_guard<std::mutex> lk(mu);
+        return cb_status != 0 || !error.empty();
+    }
+    void close() {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            closing = true;
+        }
+        cv.notify_all();
+        if (worker.joinable()) worker.join();
+    }
+    ~StreamOut() { close(); }
+};
+
+int ensure_download_side(mvs_ctx* c, size_t bytes) {
+    if (!c->dl_stream) {
+        HIP_TRY(hipStreamCreateWithFlags(&c->dl_stream, hipStreamNonBlocking));
+        for (int i = 0; i < 2; ++i) HIP_TRY(hipEventCreateWithFlags(&c->dl_done[i], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&c->dl_block, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&c->dl_ready, hipEventDisableTiming));
+    }
+    if (c->dl_bytes >= bytes) return MVS_OK;
+    HIP_TRY(hipStreamSynchronize(c->dl_stream));
+    for (int i = 0; i < 2; ++i) {
+        if (c->dl_pinned[i]) HIP_TRY(hipHostFree(c->dl_pinned[i]));
+        c->dl_pinned[i] = nullptr;
+    }
+    c->dl_bytes = 0;
+    for (int i = 0; i < 2; ++i) HIP_TRY(hipHostMalloc(&c->dl_pinned[i], bytes, hipHostMallocDefault));
+    c->dl_bytes = bytes;
+    return MVS_OK;
+}
+
+// n packed cells of rows [rb, re) sit in c->st_raw: sort, CSR on the device, then out through the two pinned buffers in
+// pieces of whole rows.  `first`: no earlier row block of this call has downloads in flight.
+int stream_block_out(mvs_ctx* c, StreamOut& out, int64_t rb, int64_t re, int64_t n, int shift, int col_bits, size_t piece_bytes,
+                     bool first) {
+    const int64_t rows = re - rb;
+    const int row_bits = bits_for(std::max<int64_t>(rows - 1, 1));
+    int rc = ensure_buf(c, &c->st_rowptr, &c->st_rowptr_bytes, (size_t)(rows + 1) * 8);
+    if (rc) return rc;
+    std::vector<int64_t> row_ptr((size_t)rows + 1, 0);
+    bool wide = false;
+    if (n > 0) {
+        rc = ensure_buf(c, &c->st_sorted, &c->st_sorted_bytes, (size_t)n * 8);
+        if (rc) return rc;
+        size_t need = 0;
+        rc = mvs::sort_packed(c->stream, (unsigned long long*)c->st_raw, (unsigned long long*)c->st_sorted, n, 16, shift + row_bits,
+                              nullptr, 0, &need);
+        if (rc) return fail(rc, "sort sizing failed");
+        rc = ensure_buf(c, &c->pw_sort, &c->pw_sort_bytes, need);
+        if (rc) return rc;
+        rc = mvs::sort_packed(c->stream, (unsigned long long*)c->st_raw, (unsigned long long*)c->st_sorted, n, 16, shift + row_bits,
+                              c->pw_sort, c->pw_sort_bytes, nullptr);
+        if (rc) return fail(rc, "sort of the kept cells failed");
+        // the previous block's downloads read st_col / st_q: they must be through before these are rewritten
+        if (!first) HIP_TRY(hipStreamWaitEvent(c->stream, c->dl_block, 0));
+        rc = ensure_buf(c, &c->st_col, &c->st_col_bytes, (size_t)n * 4);
+        if (rc) return rc;
+        rc = ensure_buf(c, &c->st_q, &c->st_q_bytes, (size_t)n);
+        if (rc) return rc;
+        unsigned int* d_wide = reinterpret_cast<unsigned int*>(c->d_counter + 3);
+        HIP_TRY(hipMemsetAsync(d_wide, 0, 4, c->stream));
+        const unsigned long long col_mask = (1ULL << col_bits) - 1ULL;
+        mvs::launch_packed_csr(c->stream, (const unsigned long long*)c->st_sorted, n, shift, rows, col_mask,
+                               (long long*)c->st_rowptr, (int32_t*)c->st_col, (uint8_t*)c->st_q, nullptr, d_wide);
+        rc = check_kernel("k_packed_csr");
+        if (rc) return rc;
+        unsigned int h_wide = 0;
+        HIP_TRY(hipMemcpyAsync(row_ptr.data(), c->st_rowptr, (size_t)(rows + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(&h_wide, d_wide, 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (h_wide) {                      // some q needs 16 bits (norms that do not belong to the vectors): redo the q array
+            wide = true;
+            rc = ensure_buf(c, &c->st_q, &c->st_q_bytes, (size_t)n * 2);
+            if (rc) return rc;
+            mvs::launch_packed_csr(c->stream, (const unsigned long long*)c->st_sorted, n, shift, rows, col_mask, nullptr,
+                                   (int32_t*)c->st_col, nullptr, (uint16_t*)c->st_q, nullptr);
+            rc = check_kernel("k_packed_csr(16-bit q)");
+            if (rc) return rc;
+        }
+        if (row_ptr[(size_t)rows] != n) return fail(MVS_E_HIP, "internal: row index of the sorted cells is inconsistent");
+    }
+    HIP_TRY(hipEventRecord(c->dl_ready, c->stream));
+    const size_t cell_bytes = wide ? 6 : 5;
+    const int64_t piece_cells = std::max<int64_t>(1, (int64_t)(piece_bytes / cell_bytes));
+    // a piece = as many whole rows as fit piece_bytes; one row alone may exceed that
+    auto piece_end = [&](int64_t r0) {
+        int64_t r1 = r0 + 1;
+        const int64_t c0 = row_ptr[(size_t)r0];
+        if (row_ptr[(size_t)r1] - c0 <= piece_cells) {
+            const int64_t* end = std::upper_bound(row_ptr.data() + r1, row_ptr.data() + rows + 1, c0 + piece_cells);
+            r1 = std::max<int64_t>(r1, (end - row_ptr.data()) - 1);
+        }
+        return r1;
+    };
+    // the pinned buffers must hold the block's largest piece: they are only ever replaced while both are idle
+    size_t need_bytes = std::min<size_t>(piece_bytes, std::max<size_t>((size_t)n * cell_bytes, 1u << 20));
+    for (int64_t r0 = 0; r0 < rows;) {
+        const int64_t r1 = piece_end(r0);
+        need_bytes = std::max(need_bytes, (size_t)(row_ptr[(size_t)r1] - row_ptr[(size_t)r0]) * cell_bytes);
+        r0 = r1;
+    }
+    if (c->dl_bytes < need_bytes) {
+        const int a0 = out.acquire_slot(), a1 = out.acquire_slot();       // both: every earlier piece has been consumed
+        rc = ensure_download_side(c, need_bytes);
+        out.release_slot(a0);
+        out.release_slot(a1);
+        if (rc) return rc;
+    }
+    for (int64_t r0 = 0; r0 < rows;) {
+        const int64_t r1 = piece_end(r0);
+        const int64_t c0 = row_ptr[(size_t)r0];
+        const int64_t cells = row_ptr[(size_t)r1] - c0;
+        if (out.failed()) return MVS_OK;                        // the caller reports the callback's status
+        const int sl = out.acquire_slot();
+        StreamOut::Item it;
+        it.slot = sl;
+        it.row_begin = rb + r0;
+        it.row_end = rb + r1;
+        it.n_cells = cells;
+        it.wide = wide;
+        it.row_ptr.resize((size_t)(r1 - r0) + 1);
+        for (int64_t r = r0; r <= r1; ++r) it.row_ptr[(size_t)(r - r0)] = row_ptr[(size_t)r] - c0;
+        hipError_t e = hipStreamWaitEvent(c->dl_stream, c->dl_ready, 0);
+        char* dst = static_cast<char*>(c->dl_pinned[sl]);
+        if (e == hipSuccess && cells > 0) {
+            e = hipMemcpyAsync(dst, (const char*)c->st_col + (size_t)c0 * 4, (size_t)cells * 4, hipMemcpyDeviceToHost, c->dl_stream);
+            if (e == hipSuccess)
+                e = hipMemcpyAsync(dst + (size_t)cells * 4, (const char*)c->st_q + (size_t)c0 * (wide ? 2 : 1),
+                                   (size_t)cells * (wide ? 2 : 1), hipMemcpyDeviceToHost, c->dl_stream);
+        }
+        if (e == hipSuccess) e = hipEventRecord(c->dl_done[sl], c->dl_stream);
+        if (e != hipSuccess) {
+            out.release_slot(sl);
+            return fail(MVS_E_HIP, "download of a row block: %s", hipGetErrorString(e));
+        }
+        out.push(std::move(it));
+        r0 = r1;
+    }
+    HIP_TRY(hipEventRecord(c->dl_block, c->dl_stream));
+    return MVS_OK;
+}
+
+}  // namespace
+
+int mvs_pairwise_stream(mvs_ctx* c, const mvs_sketch_set* s, const double* norms_sq, int mem_norms, int keep_mode,
+                        int64_t row_begin, int64_t row_end, size_t device_budget_bytes, mvs_row_block_cb cb, void* user,
+                        int64_t* n_cells) {
+    if (!c || !s || !cb) return fail(MVS_E_INVALID, "NULL argument");
+    const Range range(c, "mvs_pairwise_stream");
+    if (n_cells) *n_cells = 0;
+    if (!mem_ok(mem_norms) || (keep_mode != MVS_KEEP_INT32 && keep_mode != MVS_KEEP_INT16)) return fail(MVS_E_INVALID, "bad argument");
+    if (row_begin < 0 || row_end > s->n || row_begin > row_end)
+        return fail(MVS_E_INVALID, "row range [%lld,%lld) outside [0,%lld)", (long long)row_begin, (long long)row_end, (long long)s->n);
+    if (row_begin == row_end || s->n == 0) return MVS_OK;
+    if (!norms_sq) return fail(MVS_E_INVALID, "norms_sq is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    DevBuf dn;
+    const double* d_n2 = norms_sq;
+    if (mem_norms == MVS_MEM_HOST) {
+        HIP_TRY(dn.alloc((size_t)s->n * 8));
+        HIP_TRY(hipMemcpyAsync(dn.p, norms_sq, (size_t)s->n * 8, hipMemcpyHostToDevice, c->stream));
+        d_n2 = (const double*)dn.p;
+    }
+    // Device budget for the kept cells of one row block (raw + sorted words, CSR arrays: 21-22 bytes per cell): a quarter of
+    // what is free now unless the caller says otherwise.  Only a block that goes through the exact kernel is planned
+    // against it (worst case: every cell kept); the two-stage comparison's output is sized from its candidate count.
+    size_t budget = device_budget_bytes;
+    if (budget == 0) {
+        size_t free_b = 0, total_b = 0;
+        HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+        budget = free_b / 4;
+    }
+    const int64_t budget_cells = std::max<int64_t>(1 << 16, (int64_t)(budget / 22));
+    const size_t piece_bytes = 32u << 20;                       // pinned buffer size: pinning costs ~0.3 ms per MiB
+    const int col_bits = bits_for(std::max<int64_t>(s->n - 1, 1));
+    const int shift = 16 + col_bits;
+    int rc = ensure_download_side(c, 1u << 20);
+    if (rc) return rc;
+    StreamOut out;
+    out.c = c;
+    out.cb = cb;
+    out.user = user;
+    out.worker = std::thread([&out] { out.run(); });
+    int64_t total = 0;
+    auto finish = [&](int status) {
+        out.close();                                            // every delivered block has been consumed
+        (void)hipStreamSynchronize(c->dl_stream);
+        if (n_cells) *n_cells = total;
+        if (status != MVS_OK) return status;
+        if (!out.error.empty()) return fail(MVS_E_HIP, "%s", out.error.c_str());
+        if (out.cb_status != 0) return fail(MVS_E_ABORTED, "the row-block callback returned %d", out.cb_status);
+        return MVS_OK;
+    };
+    const int64_t rows_all = row_end - row_begin;
+    // Plan A: the whole row range as ONE symmetric block through the two-stage comparison (its kept cells are few: they
+    // stay on the device until the block is sorted).  Needs the row field to fit the packed word.
+    bool need_exact = true;
+    if (shift + bits_for(std::max<int64_t>(rows_all - 1, 1)) <= 64) {
+        PackedOut po{&c->st_raw, &c->st_raw_bytes, row_begin, shift, true};
+        rc = ensure_buf(c, &c->st_raw, &c->st_raw_bytes, 1u << 20);
+        if (rc) return finish(rc);
+        unsigned long long got = 0;
+        rc = pairwise_launch(c, s, d_n2, keep_mode, row_begin, row_end, 0, s->n, true, false, nullptr, 0, 0, &got, 0.05, &po);
+        if (rc == MVS_OK) {
+            need_exact = false;
+            if ((size_t)got * 8 > c->st_raw_bytes) return finish(fail(MVS_E_HIP, "internal: kept cells beyond the sized output"));
+            total = (int64_t)got;
+            rc = stream_block_out(c, out, row_begin, row_end, (int64_t)got, shift, col_bits, piece_bytes, true);
+            return finish(rc);
+        }
+        if (rc != kNeedExact) return finish(rc);
+    }
+    // Plan B: the exact kernel, in row blocks whose worst case (every cell kept) fits the budget; block borders on
+    // multiples of 256 rows so that every block uses the symmetric schedule inside its own square.
+    (void)need_exact;
+    int64_t block_rows = std::max<int64_t>(256, budget_cells / std::max<int64_t>(s->n, 1) / 256 * 256);
+    while (shift + bits_for(std::max<int64_t>(block_rows - 1, 1)) > 64 && block_rows > 256) block_rows /= 2;
+    bool first = true;
+    for (int64_t rb = row_begin; rb < row_end;) {
+        const int64_t re = std::min(row_end, (rb / 256) * 256 + block_rows);
+        const int64_t worst = (re - rb) * s->n;
+        rc = ensure_buf(c, &c->st_raw, &c->st_raw_bytes, (size_t)worst * 8);
+        if (rc) return finish(rc);
+        PackedOut po{&c->st_raw, &c->st_raw_bytes, rb, shift, false};
+        unsigned long long got = 0;
+        const int saved = c->opt.pairwise_filter;
+        c->opt.pairwise_filter = 0;                             // plan A has decided: the exact kernel does these blocks
+        rc = pairwise_launch(c, s, d_n2, keep_mode, rb, re, 0, s->n, true, false, nullptr, 0, 0, &got, 0.05, &po);
+        c->opt.pairwise_filter = saved;
+        if (rc) return finish(rc);
+        if (got == ~0ULL) {
+            hipError_t e = hipMemcpyAsync(&got, c->d_counter, 8, hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+            if (e != hipSuccess) return finish(fail(MVS_E_HIP, "reading the cell count: %s", hipGetErrorString(e)));
+        }
+        if ((int64_t)got > worst) return finish(fail(MVS_E_HIP, "internal: more kept cells than cells"));
+        total += (int64_t)got;
+        rc = stream_block_out(c, out, rb, re, (int64_t)got, shift, col_bits, piece_bytes, first);
+        if (rc) return finish(rc);
+        if (out.failed()) break;
+        first = false;
+        rb = re;
+    }
+    return finish(MVS_OK);
 }
 
 int mvs_pairwise_block(mvs_ctx* c, const mvs_sketch_set* s, const double* norms_sq, int keep_mode, int64_t row_begin,

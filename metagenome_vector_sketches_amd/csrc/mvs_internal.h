@@ -75,6 +75,11 @@ struct PairwiseArgs {
     mvs_cell* cells;
     unsigned long long capacity;
     unsigned long long* counter;  // number of kept cells (may exceed capacity)
+    // streamed output (mvs_pairwise_stream): when non-NULL a kept cell is ONE word in `packed` instead of an mvs_cell:
+    // (row - pack_row0) << pack_shift | col << 16 | q (16 bits) -- sorts by (row, col) as an integer
+    unsigned long long* packed;
+    int64_t pack_row0;
+    int pack_shift;
     // dense outputs (dots mode)
     int32_t* dots;                // (row_end-row_begin) x (col_end-col_begin)
     int mirror_all;               // 1: every kept (row, col) is appended as (col, row) too (the transposed
@@ -140,6 +145,13 @@ int launch_exact_pairs(hipStream_t stream, const PairwiseArgs& a, const Options&
 // the variant it would pick appends with atomics only; k_cand_gather moves the regions' contents into the candidate list
 int64_t filter_region_count(const PairwiseArgs& a, const Options& opt);
 int launch_cand_gather(hipStream_t stream, const PairwiseArgs& a, int64_t n_regions);
+// packed cells of the streamed output: radix sort on the (row, col) bits, then CSR arrays (row_ptr over `rows` rows,
+// col, q as 8 bits -- *d_wide set if some q needs 16 -- or as 16 bits when d_q16 is given)
+int sort_packed(hipStream_t stream, unsigned long long* d_in, unsigned long long* d_out, int64_t n, int begin_bit, int end_bit,
+                void* d_scratch, size_t scratch_bytes, size_t* scratch_needed);
+int launch_packed_csr(hipStream_t stream, const unsigned long long* d_keys, int64_t n, int shift, int64_t rows,
+                      unsigned long long col_mask, long long* d_row_ptr, int32_t* d_col, uint8_t* d_q8, uint16_t* d_q16,
+                      unsigned int* d_wide);
 // sort cells by (row, col); tmp buffers owned by the caller
 int sort_cells(hipStream_t stream, mvs_cell* d_cells, mvs_cell* d_tmp, int64_t n, void* d_scratch,
                size_t scratch_bytes, size_t* scratch_needed, const Options& opt);

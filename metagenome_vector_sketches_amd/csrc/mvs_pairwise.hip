@@ -99,6 +99,26 @@ __device__ __forceinline__ int32_t quantize_cell(int32_t P, int d, double n2r, d
     return (int32_t)(uint16_t)(long long)r;
 }
 
+// One kept cell into the output at `slot`: the 16-byte mvs_cell of the C ABI, or -- when the caller streams its results
+// out (mvs_pairwise_stream) -- ONE 64-bit word  (row - pack_row0) << pack_shift | col << 16 | q  that sorts by (row, col)
+// as an integer and carries everything the shard writer needs (src/pairwise_comp_optimized.cpp:718-736 uses the column
+// deltas and q only); half the bytes to write, sort and move.
+__device__ __forceinline__ void store_cell(const PairwiseArgs& a, unsigned long long slot, int32_t row, int32_t col, int32_t P,
+                                           int32_t q) {
+    if (slot >= a.capacity) return;
+    if (a.packed) {
+        a.packed[slot] = ((unsigned long long)(unsigned)(row - (int32_t)a.pack_row0) << a.pack_shift) |
+                         ((unsigned long long)(unsigned)col << 16) | (unsigned long long)(unsigned)(q & 0xffff);
+    } else {
+        mvs_cell c;
+        c.row = row;
+        c.col = col;
+        c.dot = P;
+        c.q = q;
+        a.cells[slot] = c;
+    }
+}
+
 // Append the kept cells of one wave (one atomic per wave).  mirror: the cell (col, row) is appended too --
 // dot, keep test and quantised Jaccard are symmetric in (row, col) bit for bit (fp add commutes).
 __device__ __forceinline__ void emit_cell(const PairwiseArgs& a, bool keep, bool mirror, int32_t row, int32_t col,
@@ -113,17 +133,9 @@ __device__ __forceinline__ void emit_cell(const PairwiseArgs& a, bool keep, bool
     if (keep) {
         const unsigned long long below = (1ULL << lane) - 1ULL;
         const unsigned long long slot = base + (unsigned long long)(__popcll(mask & below) + __popcll(mmask & below));
-        mvs_cell c;
-        c.row = row;
-        c.col = col;
-        c.dot = P;
-        c.q = quantize_cell(P, a.d, a.norms_sq[row], a.norms_sq[col]);
-        if (slot < a.capacity) a.cells[slot] = c;
-        if (mirror && slot + 1 < a.capacity) {
-            c.row = col;
-            c.col = row;
-            a.cells[slot + 1] = c;
-        }
+        const int32_t q = quantize_cell(P, a.d, a.norms_sq[row], a.norms_sq[col]);
+        store_cell(a, slot, row, col, P, q);
+        if (mirror) store_cell(a, slot + 1, col, row, P, q);
     }
 }
 
@@ -145,17 +157,11 @@ __device__ __forceinline__ unsigned long long wave_reserve(unsigned long long* c
 // one kept cell (and its mirror image) at `slot`, which advances
 __device__ __forceinline__ void write_cell(const PairwiseArgs& a, unsigned long long& slot, bool mirror, int32_t row,
                                            int32_t col, int32_t P) {
-    mvs_cell c;
-    c.row = row;
-    c.col = col;
-    c.dot = P;
-    c.q = quantize_cell(P, a.d, a.norms_sq[row], a.norms_sq[col]);
-    if (slot < a.capacity) a.cells[slot] = c;
+    const int32_t q = quantize_cell(P, a.d, a.norms_sq[row], a.norms_sq[col]);
+    store_cell(a, slot, row, col, P, q);
     ++slot;
     if (mirror) {
-        c.row = col;
-        c.col = row;
-        if (slot < a.capacity) a.cells[slot] = c;
+        store_cell(a, slot, col, row, P, q);
         ++slot;
     }
 }
@@ -1647,6 +1653,41 @@ __global__ __launch_bounds__(256) void k_exact_pairs_tree(const PairwiseArgs a) 
     }
 }
 
+// ---- streamed output: sorted packed cells -> CSR (row_ptr, col, q) ----
+// row_ptr[r] = index of the first cell whose row is >= r, r in [0, rows]; keys sorted ascending, row = key >> shift.
+// One thread per row, a binary search each: no slow case whether rows are empty or hold millions of cells.
+__global__ __launch_bounds__(256) void k_packed_row_ptr(const unsigned long long* __restrict__ keys, unsigned long long n,
+                                                        int shift, long long rows, long long* __restrict__ row_ptr) {
+    const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (r > rows) return;
+    unsigned long long lo = 0, hi = n;                       // first index in [0, n] whose row is >= r
+    while (lo < hi) {
+        const unsigned long long mid = lo + ((hi - lo) >> 1);
+        if ((long long)(keys[mid] >> shift) < r) lo = mid + 1;
+        else hi = mid;
+    }
+    row_ptr[r] = (long long)lo;
+}
+
+// col / q of every cell; *wide is set when some q does not fit 8 bits (only a norms file that does not belong to the
+// vectors does that: a negative Jaccard estimate casts to a 16-bit value) -- the caller then takes
+// the 16-bit array instead
+__global__ __launch_bounds__(256) void k_packed_unpack(const unsigned long long* __restrict__ keys, unsigned long long n,
+                                                       unsigned long long col_mask, int32_t* __restrict__ col,
+                                                       uint8_t* __restrict__ q8, uint16_t* __restrict__ q16,
+                                                       unsigned int* __restrict__ wide) {
+    const unsigned long long i = (unsigned long long)blockIdx.x * 256ull + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long k = keys[i];
+    const unsigned q = (unsigned)(k & 0xffffu);
+    col[i] = (int32_t)((k >> 16) & col_mask);
+    if (q16) q16[i] = (uint16_t)q;
+    else {
+        q8[i] = (uint8_t)q;
+        if (q > 255u) *wide = 1u;                 // benign race: every writer stores the same value
+    }
+}
+
 struct CellLess {
     __host__ __device__ bool operator()(const mvs_cell& x, const mvs_cell& y) const {
         return x.row < y.row || (x.row == y.row && x.col < y.col);
@@ -1914,6 +1955,30 @@ int launch_pairwise(hipStream_t stream, const PairwiseArgs& a, int mode, int alg
         else
             hipLaunchKernelGGL(k_pairwise_valu<1>, grid, dim3(256), 0, stream, s);
     }
+    return 0;
+}
+
+int sort_packed(hipStream_t stream, unsigned long long* d_in, unsigned long long* d_out, int64_t n, int begin_bit, int end_bit,
+                void* d_scratch, size_t scratch_bytes, size_t* scratch_needed) {
+    size_t need = 0;
+    hipError_t e = rocprim::radix_sort_keys(nullptr, need, d_in, d_out, (size_t)n, (unsigned)begin_bit, (unsigned)end_bit, stream);
+    if (e != hipSuccess) return MVS_E_HIP;
+    if (scratch_needed) *scratch_needed = need;
+    if (d_scratch == nullptr) return 0;
+    if (scratch_bytes < need) return MVS_E_CAPACITY;
+    e = rocprim::radix_sort_keys(d_scratch, need, d_in, d_out, (size_t)n, (unsigned)begin_bit, (unsigned)end_bit, stream);
+    return e == hipSuccess ? 0 : MVS_E_HIP;
+}
+
+int launch_packed_csr(hipStream_t stream, const unsigned long long* d_keys, int64_t n, int shift, int64_t rows,
+                      unsigned long long col_mask, long long* d_row_ptr, int32_t* d_col, uint8_t* d_q8, uint16_t* d_q16,
+                      unsigned int* d_wide) {
+    if (d_row_ptr)
+        hipLaunchKernelGGL(k_packed_row_ptr, dim3((unsigned)((rows + 1 + 255) / 256)), dim3(256), 0, stream, d_keys,
+                           (unsigned long long)n, shift, (long long)rows, d_row_ptr);
+    if (n > 0 && d_col)
+        hipLaunchKernelGGL(k_packed_unpack, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_keys, (unsigned long long)n,
+                           col_mask, d_col, d_q8, d_q16, d_wide);
     return 0;
 }
 

@@ -1,0 +1,156 @@
+"""GPU: mvs_pairwise_stream -- the comparison with its result streamed out as CSR pieces of whole rows -- against
+mvs_pairwise_rows (the cell list) and the oracle, on every path the library can take for a row range: the two-stage
+comparison with its output sized from the candidate count, the exact kernel on one block, the exact kernel on several row
+blocks planned against a small device budget, dense results, the int16 keep test, q values beyond 8 bits."""
+import numpy as np
+import pytest
+
+from metagenome_vector_sketches_amd import _capi, synth
+from oracle import pyoracle as orc
+
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("restore_options")]
+
+
+def _n2(sk):
+    return np.array([orc.norm_sq_from_text(orc.format_norm(orc.norm(row))) for row in sk.astype(np.int32)])
+
+
+def _triples(row_ptr, col, q, row_begin=0):
+    rows = np.repeat(np.arange(len(row_ptr) - 1, dtype=np.int64) + row_begin, np.diff(row_ptr))
+    return np.stack([rows, col.astype(np.int64), q.astype(np.int64)], axis=1)
+
+
+def _cells_triples(cells):
+    return np.stack([cells["row"].astype(np.int64), cells["col"].astype(np.int64), cells["q"].astype(np.int64)], axis=1)
+
+
+@pytest.mark.parametrize("filt", [0, 2])
+@pytest.mark.parametrize("keep", [_capi.KEEP_INT32, _capi.KEEP_INT16])
+def test_stream_equals_cell_list_and_oracle(ctx, filt, keep):
+    sk = synth.make_sketches_numpy(900, 512, 3000, seed=5, cluster=8)
+    n2 = _n2(sk)
+    ctx.set_option("pairwise_filter", filt)
+    ss = ctx.sketch_set(sk)
+    cells, cnt = ctx.pairwise_rows(ss, n2, keep_mode=keep)
+    if keep == _capi.KEEP_INT32:            # (the oracle applies the floating keep test to int16 sketches only)
+        want = orc.pairwise_rows(sk, n2, chunk=192, threads=8)
+        want = want[np.lexsort((want["col"], want["row"]))]
+        assert np.array_equal(_cells_triples(cells), _cells_triples(want))
+    assert cnt > 900 * 6
+    row_ptr, col, q, n = ctx.pairwise_stream(ss, n2, keep_mode=keep)
+    assert n == cnt and q.dtype == np.uint8 and (ctx.pairwise_candidates() > 0) == (filt == 2)
+    assert np.array_equal(_triples(row_ptr, col, q), _cells_triples(cells))
+    # a shard of the rows, pieces seen one by one
+    seen = []
+    n_part = ctx.pairwise_stream(ss, n2, on_block=lambda b, e, rp, c, qq: seen.append((b, e, rp, c, qq)) and None,
+                                 row_begin=300, row_end=777, keep_mode=keep)
+    assert seen[0][0] == 300 and seen[-1][1] == 777 and all(a[1] == b[0] for a, b in zip(seen, seen[1:]))
+    got = np.concatenate([_triples(rp, c, qq, b) for (b, e, rp, c, qq) in seen])
+    sel = (cells["row"] >= 300) & (cells["row"] < 777)
+    assert n_part == int(sel.sum()) and np.array_equal(got, _cells_triples(cells[sel]))
+    ss.close()
+
+
+def test_stream_toy_db(ctx, gold):
+    """the reference's toy DB (61 samples, 35 % of the cells kept): exact kernel, one block"""
+    n2 = np.array([orc.norm_sq_from_text(l.split()[1]) for l in gold.norm_lines()])
+    ss = ctx.sketch_set(gold.vectors)
+    row_ptr, col, q, n = ctx.pairwise_stream(ss, n2)
+    want = sorted((r, c, qq) for r, c, _, qq in gold.cells())
+    assert n == 1291 and [tuple(int(x) for x in t) for t in _triples(row_ptr, col, q)] == want
+    ss.close()
+
+
+@pytest.mark.parametrize("filt", [1, 2])
+def test_stream_dense_result_in_row_blocks(ctx, filt):
+    """clusters of 1000 samples: a third of all cells are kept.  The filter (when it runs) gives up past 1/128 of the
+    cells in its list and the exact kernel does the rows in blocks whose worst case fits the budget given here (2 MB:
+    blocks of 256 rows) -- nothing is compared twice and the pieces still cover every row once, in order."""
+    n, d = 3000, 256
+    sk = synth.make_sketches_numpy(n, d, 3000, seed=77, cluster=1000, shared=0.6)
+    n2 = _n2(sk)
+    ctx.set_option("pairwise_filter", filt)
+    ss = ctx.sketch_set(sk)
+    cells, cnt = ctx.pairwise_rows(ss, n2)
+    assert cnt > n * n // 4
+    pieces = []
+    n_s = ctx.pairwise_stream(ss, n2, on_block=lambda b, e, rp, c, qq: pieces.append((b, e, rp, c, qq)) and None,
+                              device_budget_bytes=2 << 20)
+    assert n_s == cnt and pieces[0][0] == 0 and pieces[-1][1] == n
+    assert all(a[1] == b[0] for a, b in zip(pieces, pieces[1:])) and len(pieces) >= n // 256
+    got = np.concatenate([_triples(rp, c, qq, b) for (b, e, rp, c, qq) in pieces])
+    assert np.array_equal(got, _cells_triples(cells))
+    # and with the default budget: one block
+    row_ptr, col, q, n_one = ctx.pairwise_stream(ss, n2)
+    assert n_one == cnt and np.array_equal(_triples(row_ptr, col, q), _cells_triples(cells))
+    ss.close()
+
+
+def test_stream_q_beyond_8_bits_and_empty_rows(ctx):
+    """norms that do not belong to the vectors make the Jaccard estimate negative for the pairs of sample 3 with the
+    large samples: the reference's uint16 cast gives q = 65536 + round(255 J) there; such a piece
+    comes with 16-bit q values.  Rows 10..19 have huge norms: they keep nothing and appear as empty rows."""
+    rng = np.random.default_rng(11)
+    sk = rng.integers(-400, 401, size=(40, 256), dtype=np.int32)
+    sk[20:] = sk[:20] * 3 // 2                      # related pairs (i, i + 20)
+    n2 = _n2(sk)
+    n2[3] = 1e-3
+    n2[23] *= 1.05
+    n2[10:20] = 1e12
+    n2[30:40] = 1e12
+    ss = ctx.sketch_set(sk)
+    cells, cnt = ctx.pairwise_rows(ss, n2)
+    want = orc.pairwise_rows(sk, n2, chunk=192, threads=4)
+    want = want[np.lexsort((want["col"], want["row"]))]
+    assert np.array_equal(_cells_triples(cells), _cells_triples(want))
+    assert cnt > 0 and int(cells["q"].max()) > 255
+    row_ptr, col, q, n = ctx.pairwise_stream(ss, n2)
+    assert n == cnt and q.dtype == np.uint16
+    assert np.array_equal(_triples(row_ptr, col, q), _cells_triples(cells))
+    assert np.all(np.diff(row_ptr)[10:20] == 0)
+    ss.close()
+
+
+def test_stream_callback_can_stop_and_errors_surface(ctx):
+    sk = synth.make_sketches_numpy(600, 256, 3000, seed=9, cluster=8)
+    n2 = _n2(sk)
+    ss = ctx.sketch_set(sk)
+    with pytest.raises(_capi.MvsError) as ei:
+        ctx.pairwise_stream(ss, n2, on_block=lambda *a: True)
+    assert ei.value.code == _capi.MVS_E_ABORTED
+
+    def boom(*a):
+        raise KeyError("from the callback")
+    with pytest.raises(KeyError):
+        ctx.pairwise_stream(ss, n2, on_block=boom)
+    row_ptr, col, q, n = ctx.pairwise_stream(ss, n2)           # the context is fine afterwards
+    cells, cnt = ctx.pairwise_rows(ss, n2)
+    assert n == cnt and np.array_equal(_triples(row_ptr, col, q), _cells_triples(cells))
+    ss.close()
+
+
+def test_stream_100k_two_stage_matches_cell_list(ctx):
+    """BASELINE.json configs[2] size: the two-stage comparison with its output sized between the stages; pieces of 32 MiB"""
+    import torch
+    n, d = 100_000, 2048
+    sk = synth.make_sketches_torch(n, d, 50_000, seed=2345, device="cuda")
+    ssq = torch.empty(n, dtype=torch.int64, device="cuda")
+    ctx.set_stream(torch.cuda.current_stream())
+    try:
+        ctx.sumsq(sk, out=ssq)
+        n2 = np.array([orc.norm_sq_from_text(orc.format_norm(float(x))) for x in np.sqrt(ssq.cpu().numpy() / d)])
+        n2_t = torch.from_numpy(n2).to("cuda")
+        ss = ctx.sketch_set(sk)
+        del sk
+        cells_t = torch.empty((n * 24, 4), dtype=torch.int32, device="cuda")
+        _, cnt = ctx.pairwise_rows(ss, n2_t, cells_out=cells_t)
+        torch.cuda.synchronize()
+        cells = cells_t[:cnt].cpu().numpy()
+        row_ptr, col, q, n_s = ctx.pairwise_stream(ss, n2_t)
+        assert ctx.pairwise_candidates() > 0
+        ss.close()
+    finally:
+        ctx.set_stream(None)
+    assert n_s == cnt and cnt >= 16 * n
+    got = _triples(row_ptr, col, q)
+    assert np.array_equal(got, cells[:, [0, 1, 3]].astype(np.int64))
