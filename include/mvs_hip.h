@@ -270,6 +270,12 @@ int mvs_pairwise_stream(mvs_ctx* ctx, const mvs_sketch_set* set, const double* n
                         int64_t row_begin, int64_t row_end, size_t device_budget_bytes, mvs_row_block_cb cb, void* user,
                         int64_t* n_cells);
 
+/* What the most recent mvs_pairwise_stream of the context did: time of its comparison kernels summed over the row blocks
+ * (0 unless mvs_ctx_set_timing is on), bytes handed to the callback, row blocks computed, pieces delivered, and whether
+ * the two-stage comparison (1) or the exact kernel in row blocks (0) produced them.  Any pointer may be NULL. */
+int mvs_ctx_stream_stats(const mvs_ctx* ctx, double* kernel_ms, int64_t* bytes_out, int64_t* row_blocks, int64_t* pieces,
+                         int* two_stage);
+
 /* One rectangular block of the comparison -- rows [row_begin,row_end) x columns [col_begin,col_end) -- for
  * schedules that split a shard's work by column block (metagenome_vector_sketches_amd/parallel.py: with G
  * shards every unordered pair of row blocks is compared ONCE and the mirrored cells are exchanged).

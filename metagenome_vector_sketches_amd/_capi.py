@@ -74,6 +74,8 @@ SYMBOLS = [
                                       _c.c_int, _c.POINTER(_c.c_int64)]),
     ("mvs_pairwise_stream", _c.c_int, [_P, _P, _P, _c.c_int, _c.c_int, _c.c_int64, _c.c_int64, _c.c_size_t, ROW_BLOCK_CB, _P,
                                         _c.POINTER(_c.c_int64)]),
+    ("mvs_ctx_stream_stats", _c.c_int, [_P, _c.POINTER(_c.c_double), _c.POINTER(_c.c_int64), _c.POINTER(_c.c_int64),
+                                         _c.POINTER(_c.c_int64), _c.POINTER(_c.c_int)]),
     ("mvs_pairwise_block", _c.c_int, [_P, _P, _P, _c.c_int, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int,
                                        _P, _c.c_int64, _c.POINTER(_c.c_int64)]),
     ("mvs_cells_sort", _c.c_int, [_P, _P, _c.c_int64, _P]),
@@ -554,6 +556,13 @@ class Context:
         col = np.concatenate([p[3] for p in parts]) if parts else np.empty(0, np.int32)
         q = np.concatenate([p[4].astype(np.uint16 if wide else np.uint8) for p in parts]) if parts else np.empty(0, np.uint8)
         return row_ptr, col, q, count.value
+
+    def stream_stats(self):
+        """what the last pairwise_stream did: dict(kernel_ms, bytes, row_blocks, pieces, two_stage)"""
+        k, b, r, p_, t = _c.c_double(), _c.c_int64(), _c.c_int64(), _c.c_int64(), _c.c_int()
+        _check(self.lib.mvs_ctx_stream_stats(self._h, ctypes.byref(k), ctypes.byref(b), ctypes.byref(r), ctypes.byref(p_),
+                                             ctypes.byref(t)))
+        return {"kernel_ms": k.value, "bytes": b.value, "row_blocks": r.value, "pieces": p_.value, "two_stage": bool(t.value)}
 
     def pairwise_block(self, sset, norms_sq, row_begin, row_end, col_begin, col_end, flags, cells, n_cells,
                        keep_mode=KEEP_INT32):

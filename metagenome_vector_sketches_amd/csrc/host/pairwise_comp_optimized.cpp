@@ -375,6 +375,7 @@ int main(int argc, char* argv[]) {
     if (getenv("MVS_DEVICE")) device = pick_device();
     else if (mvs_device_count(&ndev) == MVS_OK && ndev > 0) device = o.shard_idx % ndev;
     if (mvs_ctx_create(device, &g.ctx) != MVS_OK) return gpu_fail("creating context");
+    if (stage_timing) mvs_ctx_set_timing(g.ctx, 1);
     lap("context");
     // MVS_COLLECTIVE=rccl|files: the shard processes of the job exchange their row blocks instead of each reading
     // the whole file
@@ -447,6 +448,15 @@ int main(int argc, char* argv[]) {
         return gpu_fail("pairwise comparison");
     }
     lap("compare + shard rows (streamed)");
+    if (stage_timing) {
+        double kms = 0.0;
+        int64_t bytes = 0, blocks = 0, pieces = 0;
+        int two = 0;
+        mvs_ctx_stream_stats(g.ctx, &kms, &bytes, &blocks, &pieces, &two);
+        std::cerr << "[stream] comparison kernels " << kms << " ms in " << blocks << " row block(s) ("
+                  << (two ? "two-stage" : "exact kernel") << "), " << n_kept << " kept cells = " << bytes << " bytes in "
+                  << pieces << " piece(s)" << std::endl;
+    }
     if (int16) {                                                                  // _16bits.cpp:419-423
         auto end_time = std::chrono::high_resolution_clock::now();
         auto duration = std::chrono::duration_cast<std::chrono::milliseconds>(end_time - start_time);

@@ -47,15 +47,20 @@ struct mvs_ctx {
     // streamed output (mvs_pairwise_stream): packed kept cells raw / sorted, their CSR form, the download side
     void* st_raw = nullptr;     size_t st_raw_bytes = 0;
     void* st_sorted = nullptr;  size_t st_sorted_bytes = 0;
-    void* st_col = nullptr;     size_t st_col_bytes = 0;
-    void* st_q = nullptr;       size_t st_q_bytes = 0;      // 8-bit q, or 16-bit when a block needs it
+    void* st_col[2] = {nullptr, nullptr};     size_t st_col_bytes[2] = {0, 0};   // CSR arrays of two row blocks: one is
+    void* st_q[2] = {nullptr, nullptr};       size_t st_q_bytes[2] = {0, 0};     // downloaded while the next is built
     void* st_rowptr = nullptr;  size_t st_rowptr_bytes = 0;
+    void* st_counts = nullptr;  size_t st_counts_bytes = 0;
+    void* st_dense = nullptr;   size_t st_dense_bytes = 0;  // dense results: one byte per cell (mvs_internal.h)
     hipStream_t dl_stream = nullptr;
     void* dl_pinned[2] = {nullptr, nullptr};
     size_t dl_bytes = 0;
     hipEvent_t dl_done[2] = {nullptr, nullptr};   // download into pinned buffer i has completed
-    hipEvent_t dl_block = nullptr;                // last download of a row block has completed (its device arrays are free)
+    hipEvent_t dl_block[2] = {nullptr, nullptr};  // the downloads out of CSR array set i have completed
     hipEvent_t dl_ready = nullptr;                // the CSR arrays of a row block are final on the compute stream
+    // what the last mvs_pairwise_stream did (mvs_ctx_stream_stats)
+    double st_kernel_ms = 0.0;                    // comparison kernels, summed over the row blocks (timing enabled)
+    long long st_bytes = 0, st_blocks = 0, st_pieces = 0, st_two_stage = 0;
     void* pw_chdr = nullptr;    size_t pw_chdr_bytes = 0;   // candidate regions of the ping-pong filter: counts, entries
     void* pw_cent = nullptr;    size_t pw_cent_bytes = 0;
     unsigned long long coarse_id = 0, coarse_gen = 0;
@@ -230,6 +235,8 @@ const OptionSpec kOptions[] = {
     {"pairwise_map", &mvs::Options::pairwise_map, nullptr, 0, 2},
     {"coarse_radix", &mvs::Options::coarse_radix, nullptr, 0, 1},
     {"cand_regions", &mvs::Options::cand_regions, nullptr, 0, 1},
+    {"stream_dense", &mvs::Options::stream_dense, nullptr, 0, 1},
+    {"stream_block_rows", &mvs::Options::stream_block_rows, nullptr, 0, 1 << 30},
     {"pairwise_block_cells", nullptr, &mvs::Options::pairwise_block_cells, 1, (1LL << 62)},
 };
 
@@ -392,13 +399,14 @@ int mvs_ctx_destroy(mvs_ctx* c) {
     if (c->pw_rows) (void)hipFree(c->pw_rows);
     if (c->pw_fmeta) (void)hipFree(c->pw_fmeta);
     if (c->pw_cand) (void)hipFree(c->pw_cand);
-    for (void* p : {c->st_raw, c->st_sorted, c->st_col, c->st_q, c->st_rowptr})
+    for (void* p : {c->st_raw, c->st_sorted, c->st_col[0], c->st_col[1], c->st_q[0], c->st_q[1], c->st_rowptr, c->st_counts,
+                    c->st_dense})
         if (p) (void)hipFree(p);
     for (int i = 0; i < 2; ++i) {
         if (c->dl_pinned[i]) (void)hipHostFree(c->dl_pinned[i]);
         if (c->dl_done[i]) (void)hipEventDestroy(c->dl_done[i]);
+        if (c->dl_block[i]) (void)hipEventDestroy(c->dl_block[i]);
     }
-    if (c->dl_block) (void)hipEventDestroy(c->dl_block);
     if (c->dl_ready) (void)hipEventDestroy(c->dl_ready);
     if (c->dl_stream) (void)hipStreamDestroy(c->dl_stream);
     if (c->pw_chdr) (void)hipFree(c->pw_chdr);
@@ -1094,10 +1102,20 @@ struct PackedOut {
 };
 constexpr int kNeedExact = 100;   // internal status of pairwise_launch (never leaves the library)
 
+// Streamed output where the result is dense: the exact kernel writes one byte per cell (q or 0) into a row-major matrix
+// instead of appending to a list; [sym_begin, sym_end) is the square the symmetric schedule works in -- larger than the
+// launch's own rows when a caller walks a shard block by block and lets the mirror images land in later blocks' rows.
+struct DenseOut {
+    uint8_t* matrix;
+    int64_t row0, ld;
+    int64_t sym_begin, sym_end;
+    unsigned int* flag;
+};
+
 int pairwise_launch(mvs_ctx* c, const mvs_sketch_set* s, const double* d_n2, int keep_mode, int64_t rb, int64_t re,
                     int64_t cb, int64_t ce, bool symmetric, bool mirror_all, mvs_cell* raw, int64_t capacity,
                     unsigned long long start, unsigned long long* count, double keep_coeff = 0.05,
-                    const PackedOut* po = nullptr) {
+                    const PackedOut* po = nullptr, const DenseOut* dn = nullptr) {
     // *count: the cell count if this call already had to synchronise for it, ~0 otherwise (read d_counter[0])
     *count = ~0ULL;
     mvs::PairwiseArgs a{};
@@ -1109,8 +1127,18 @@ int pairwise_launch(mvs_ctx* c, const mvs_sketch_set* s, const double* d_n2, int
     a.limbs = s->limbs;
     a.row_begin = rb;
     a.row_end = re;
+    a.sym_begin = rb;
+    a.sym_end = re;
     a.col_begin = cb;
     a.col_end = ce;
+    if (dn) {
+        a.dense = dn->matrix;
+        a.dense_row0 = dn->row0;
+        a.dense_ld = dn->ld;
+        a.dense_flag = dn->flag;
+        a.sym_begin = dn->sym_begin;
+        a.sym_end = dn->sym_end;
+    }
     a.norms_sq = d_n2;
     a.keep_mode = keep_mode;
     a.keep_coeff = keep_coeff;
@@ -1486,8 +1514,10 @@ struct StreamOut {
 int ensure_download_side(mvs_ctx* c, size_t bytes) {
     if (!c->dl_stream) {
         HIP_TRY(hipStreamCreateWithFlags(&c->dl_stream, hipStreamNonBlocking));
-        for (int i = 0; i < 2; ++i) HIP_TRY(hipEventCreateWithFlags(&c->dl_done[i], hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&c->dl_block, hipEventDisableTiming));
+        for (int i = 0; i < 2; ++i) {
+            HIP_TRY(hipEventCreateWithFlags(&c->dl_done[i], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&c->dl_block[i], hipEventDisableTiming));
+        }
         HIP_TRY(hipEventCreateWithFlags(&c->dl_ready, hipEventDisableTiming));
     }
     if (c->dl_bytes >= bytes) return MVS_OK;
@@ -1502,57 +1532,126 @@ int ensure_download_side(mvs_ctx* c, size_t bytes) {
     return MVS_OK;
 }
 
-// n packed cells of rows [rb, re) sit in c->st_raw: sort, CSR on the device, then out through the two pinned buffers in
-// pieces of whole rows.  `first`: no earlier row block of this call has downloads in flight.
-int stream_block_out(mvs_ctx* c, StreamOut& out, int64_t rb, int64_t re, int64_t n, int shift, int col_bits, size_t piece_bytes,
-                     bool first) {
+// A row block on its way out: its CSR arrays sit in set `set` of the context (device), row_ptr is on the host.
+struct BlockCsr {
+    int64_t rb = 0, re = 0, n = 0;
+    std::vector<int64_t> row_ptr;      // re - rb + 1 entries
+    bool wide = false;                 // q is 16 bits wide in this block
+    int set = 0;
+};
+
+// before the CSR arrays of set `set` are rewritten: the downloads of the block that used them last (two blocks ago) are through
+int claim_csr_set(mvs_ctx* c, int set, int64_t block_index, int64_t n, bool wide) {
+    if (block_index >= 2) HIP_TRY(hipStreamWaitEvent(c->stream, c->dl_block[set], 0));
+    int rc = ensure_buf(c, &c->st_col[set], &c->st_col_bytes[set], (size_t)std::max<int64_t>(n, 1) * 4);
+    if (rc) return rc;
+    return ensure_buf(c, &c->st_q[set], &c->st_q_bytes[set], (size_t)std::max<int64_t>(n, 1) * (wide ? 2 : 1));
+}
+
+// n packed cells of rows [rb, re) sit in c->st_raw: radix sort on the (row, col) bits, then row_ptr / col / q
+int csr_from_packed(mvs_ctx* c, int64_t rb, int64_t re, int64_t n, int shift, int col_bits, int64_t block_index, BlockCsr& out) {
     const int64_t rows = re - rb;
     const int row_bits = bits_for(std::max<int64_t>(rows - 1, 1));
+    out.rb = rb;
+    out.re = re;
+    out.n = n;
+    out.wide = false;
+    out.set = (int)(block_index & 1);
+    out.row_ptr.assign((size_t)rows + 1, 0);
+    if (n == 0) {
+        HIP_TRY(hipEventRecord(c->dl_ready, c->stream));
+        return MVS_OK;
+    }
     int rc = ensure_buf(c, &c->st_rowptr, &c->st_rowptr_bytes, (size_t)(rows + 1) * 8);
     if (rc) return rc;
-    std::vector<int64_t> row_ptr((size_t)rows + 1, 0);
-    bool wide = false;
-    if (n > 0) {
-        rc = ensure_buf(c, &c->st_sorted, &c->st_sorted_bytes, (size_t)n * 8);
+    rc = ensure_buf(c, &c->st_sorted, &c->st_sorted_bytes, (size_t)n * 8);
+    if (rc) return rc;
+    size_t need = 0;
+    rc = mvs::sort_packed(c->stream, (unsigned long long*)c->st_raw, (unsigned long long*)c->st_sorted, n, 16, shift + row_bits,
+                          nullptr, 0, &need);
+    if (rc) return fail(rc, "sort sizing failed");
+    rc = ensure_buf(c, &c->pw_sort, &c->pw_sort_bytes, need);
+    if (rc) return rc;
+    rc = mvs::sort_packed(c->stream, (unsigned long long*)c->st_raw, (unsigned long long*)c->st_sorted, n, 16, shift + row_bits,
+                          c->pw_sort, c->pw_sort_bytes, nullptr);
+    if (rc) return fail(rc, "sort of the kept cells failed");
+    rc = claim_csr_set(c, out.set, block_index, n, false);
+    if (rc) return rc;
+    unsigned int* d_wide = reinterpret_cast<unsigned int*>(c->d_counter + 3);
+    HIP_TRY(hipMemsetAsync(d_wide, 0, 4, c->stream));
+    const unsigned long long col_mask = (1ULL << col_bits) - 1ULL;
+    mvs::launch_packed_csr(c->stream, (const unsigned long long*)c->st_sorted, n, shift, rows, col_mask, (long long*)c->st_rowptr,
+                           (int32_t*)c->st_col[out.set], (uint8_t*)c->st_q[out.set], nullptr, d_wide);
+    rc = check_kernel("k_packed_csr");
+    if (rc) return rc;
+    unsigned int h_wide = 0;
+    HIP_TRY(hipMemcpyAsync(out.row_ptr.data(), c->st_rowptr, (size_t)(rows + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(&h_wide, d_wide, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (h_wide) {                      // some q needs 16 bits (norms that do not belong to the vectors): redo the q array
+        out.wide = true;
+        rc = ensure_buf(c, &c->st_q[out.set], &c->st_q_bytes[out.set], (size_t)n * 2);
         if (rc) return rc;
-        size_t need = 0;
-        rc = mvs::sort_packed(c->stream, (unsigned long long*)c->st_raw, (unsigned long long*)c->st_sorted, n, 16, shift + row_bits,
-                              nullptr, 0, &need);
-        if (rc) return fail(rc, "sort sizing failed");
-        rc = ensure_buf(c, &c->pw_sort, &c->pw_sort_bytes, need);
+        mvs::launch_packed_csr(c->stream, (const unsigned long long*)c->st_sorted, n, shift, rows, col_mask, nullptr,
+                               (int32_t*)c->st_col[out.set], nullptr, (uint16_t*)c->st_q[out.set], nullptr);
+        rc = check_kernel("k_packed_csr(16-bit q)");
         if (rc) return rc;
-        rc = mvs::sort_packed(c->stream, (unsigned long long*)c->st_raw, (unsigned long long*)c->st_sorted, n, 16, shift + row_bits,
-                              c->pw_sort, c->pw_sort_bytes, nullptr);
-        if (rc) return fail(rc, "sort of the kept cells failed");
-        // the previous block's downloads read st_col / st_q: they must be through before these are rewritten
-        if (!first) HIP_TRY(hipStreamWaitEvent(c->stream, c->dl_block, 0));
-        rc = ensure_buf(c, &c->st_col, &c->st_col_bytes, (size_t)n * 4);
-        if (rc) return rc;
-        rc = ensure_buf(c, &c->st_q, &c->st_q_bytes, (size_t)n);
-        if (rc) return rc;
-        unsigned int* d_wide = reinterpret_cast<unsigned int*>(c->d_counter + 3);
-        HIP_TRY(hipMemsetAsync(d_wide, 0, 4, c->stream));
-        const unsigned long long col_mask = (1ULL << col_bits) - 1ULL;
-        mvs::launch_packed_csr(c->stream, (const unsigned long long*)c->st_sorted, n, shift, rows, col_mask,
-                               (long long*)c->st_rowptr, (int32_t*)c->st_col, (uint8_t*)c->st_q, nullptr, d_wide);
-        rc = check_kernel("k_packed_csr");
-        if (rc) return rc;
-        unsigned int h_wide = 0;
-        HIP_TRY(hipMemcpyAsync(row_ptr.data(), c->st_rowptr, (size_t)(rows + 1) * 8, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipMemcpyAsync(&h_wide, d_wide, 4, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        if (h_wide) {                      // some q needs 16 bits (norms that do not belong to the vectors): redo the q array
-            wide = true;
-            rc = ensure_buf(c, &c->st_q, &c->st_q_bytes, (size_t)n * 2);
-            if (rc) return rc;
-            mvs::launch_packed_csr(c->stream, (const unsigned long long*)c->st_sorted, n, shift, rows, col_mask, nullptr,
-                                   (int32_t*)c->st_col, nullptr, (uint16_t*)c->st_q, nullptr);
-            rc = check_kernel("k_packed_csr(16-bit q)");
-            if (rc) return rc;
-        }
-        if (row_ptr[(size_t)rows] != n) return fail(MVS_E_HIP, "internal: row index of the sorted cells is inconsistent");
     }
+    if (out.row_ptr[(size_t)rows] != n) return fail(MVS_E_HIP, "internal: row index of the sorted cells is inconsistent");
+    HIP_TRY(hipEventRecord(c->dl_ready, c->stream));          // the downloads of this block wait for exactly this point
+    return MVS_OK;
+}
+
+// rows [rb, re) of the dense byte matrix (first row dense_row0, leading dimension ld) are final: count, scan, fill.
+// *odd: some kept cell of the launches so far has a q the byte cannot hold -- the caller redoes the block as a list.
+int csr_from_dense(mvs_ctx* c, int64_t rb, int64_t re, int64_t n_cols, int64_t dense_row0, int64_t ld, int64_t block_index,
+                   BlockCsr& out, bool* odd) {
+    const int64_t rows = re - rb;
+    out.rb = rb;
+    out.re = re;
+    out.wide = false;
+    out.set = (int)(block_index & 1);
+    out.row_ptr.assign((size_t)rows + 1, 0);
+    int rc = ensure_buf(c, &c->st_rowptr, &c->st_rowptr_bytes, (size_t)(rows + 1) * 8);
+    if (rc) return rc;
+    rc = ensure_buf(c, &c->st_counts, &c->st_counts_bytes, (size_t)(rows + 1) * 8);
+    if (rc) return rc;
+    const uint8_t* first = (const uint8_t*)c->st_dense + (size_t)(rb - dense_row0) * (size_t)ld;
+    HIP_TRY(hipMemsetAsync((char*)c->st_counts + (size_t)rows * 8, 0, 8, c->stream));
+    mvs::launch_dense_count(c->stream, first, ld, n_cols, rows, (long long*)c->st_counts);
+    rc = check_kernel("k_dense_count");
+    if (rc) return rc;
+    size_t need = 0;
+    rc = mvs::dense_row_ptr(c->stream, (long long*)c->st_counts, (long long*)c->st_rowptr, rows, nullptr, 0, &need);
+    if (rc) return fail(rc, "scan sizing failed");
+    rc = ensure_buf(c, &c->pw_sort, &c->pw_sort_bytes, need);
+    if (rc) return rc;
+    rc = mvs::dense_row_ptr(c->stream, (long long*)c->st_counts, (long long*)c->st_rowptr, rows, c->pw_sort, c->pw_sort_bytes, nullptr);
+    if (rc) return fail(rc, "scan of the row counts failed");
+    unsigned int h_odd = 0;
+    HIP_TRY(hipMemcpyAsync(out.row_ptr.data(), c->st_rowptr, (size_t)(rows + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(&h_odd, c->d_counter + 4, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    *odd = h_odd != 0;
+    if (*odd) return MVS_OK;
+    out.n = out.row_ptr[(size_t)rows];
+    rc = claim_csr_set(c, out.set, block_index, out.n, false);
+    if (rc) return rc;
+    mvs::launch_dense_fill(c->stream, first, ld, n_cols, rows, (const long long*)c->st_rowptr, (int32_t*)c->st_col[out.set],
+                           (uint8_t*)c->st_q[out.set]);
+    rc = check_kernel("k_dense_fill");
+    if (rc) return rc;
     HIP_TRY(hipEventRecord(c->dl_ready, c->stream));
+    return MVS_OK;
+}
+
+// the block's CSR arrays out through the two pinned buffers, in pieces of whole rows; the host blocks here only on the
+// pinned buffers (the device is free to run the next block's comparison meanwhile)
+int feed_block(mvs_ctx* c, StreamOut& out, const BlockCsr& b, size_t piece_bytes) {
+    const int64_t rows = b.re - b.rb, n = b.n;
+    const std::vector<int64_t>& row_ptr = b.row_ptr;
+    const bool wide = b.wide;
+    int rc = MVS_OK;
     const size_t cell_bytes = wide ? 6 : 5;
     const int64_t piece_cells = std::max<int64_t>(1, (int64_t)(piece_bytes / cell_bytes));
     // a piece = as many whole rows as fit piece_bytes; one row alone may exceed that
@@ -1587,8 +1686,8 @@ int stream_block_out(mvs_ctx* c, StreamOut& out, int64_t rb, int64_t re, int64_t
         const int sl = out.acquire_slot();
         StreamOut::Item it;
         it.slot = sl;
-        it.row_begin = rb + r0;
-        it.row_end = rb + r1;
+        it.row_begin = b.rb + r0;
+        it.row_end = b.rb + r1;
         it.n_cells = cells;
         it.wide = wide;
         it.row_ptr.resize((size_t)(r1 - r0) + 1);
@@ -1596,9 +1695,10 @@ int stream_block_out(mvs_ctx* c, StreamOut& out, int64_t rb, int64_t re, int64_t
         hipError_t e = hipStreamWaitEvent(c->dl_stream, c->dl_ready, 0);
         char* dst = static_cast<char*>(c->dl_pinned[sl]);
         if (e == hipSuccess && cells > 0) {
-            e = hipMemcpyAsync(dst, (const char*)c->st_col + (size_t)c0 * 4, (size_t)cells * 4, hipMemcpyDeviceToHost, c->dl_stream);
+            e = hipMemcpyAsync(dst, (const char*)c->st_col[b.set] + (size_t)c0 * 4, (size_t)cells * 4, hipMemcpyDeviceToHost,
+                               c->dl_stream);
             if (e == hipSuccess)
-                e = hipMemcpyAsync(dst + (size_t)cells * 4, (const char*)c->st_q + (size_t)c0 * (wide ? 2 : 1),
+                e = hipMemcpyAsync(dst + (size_t)cells * 4, (const char*)c->st_q[b.set] + (size_t)c0 * (wide ? 2 : 1),
                                    (size_t)cells * (wide ? 2 : 1), hipMemcpyDeviceToHost, c->dl_stream);
         }
         if (e == hipSuccess) e = hipEventRecord(c->dl_done[sl], c->dl_stream);
@@ -1607,9 +1707,11 @@ int stream_block_out(mvs_ctx* c, StreamOut& out, int64_t rb, int64_t re, int64_t
             return fail(MVS_E_HIP, "download of a row block: %s", hipGetErrorString(e));
         }
         out.push(std::move(it));
+        ++c->st_pieces;
+        c->st_bytes += (long long)((size_t)cells * cell_bytes);
         r0 = r1;
     }
-    HIP_TRY(hipEventRecord(c->dl_block, c->dl_stream));
+    HIP_TRY(hipEventRecord(c->dl_block[b.set], c->dl_stream));
     return MVS_OK;
 }
 
@@ -1639,16 +1741,32 @@ int mvs_pairwise_stream(mvs_ctx* c, const mvs_sketch_set* s, const double* norms
     // against it (worst case: every cell kept); the two-stage comparison's output is sized from its candidate count.
     size_t budget = device_budget_bytes;
     if (budget == 0) {
+        // Default: a quarter of what is free, but no more than 2^30 worst-case cells per block (8 GiB of packed words):
+        // where the exact kernel runs the result is dense and the link, not the kernel, sets the pace -- blocks of that
+        // size keep the head of the pipeline (first block computed, nothing to download yet) short.
         size_t free_b = 0, total_b = 0;
         HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-        budget = free_b / 4;
+        budget = std::min<size_t>(free_b / 4, (size_t)22 << 30);
     }
     const int64_t budget_cells = std::max<int64_t>(1 << 16, (int64_t)(budget / 22));
+    // the dense byte matrix (one byte per cell of a row block) may take more: a third of what is free unless the caller set a budget
+    size_t dense_budget = device_budget_bytes;
+    if (dense_budget == 0) {
+        size_t free_b = 0, total_b = 0;
+        HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+        dense_budget = free_b / 3;
+    }
     const size_t piece_bytes = 32u << 20;                       // pinned buffer size: pinning costs ~0.3 ms per MiB
     const int col_bits = bits_for(std::max<int64_t>(s->n - 1, 1));
     const int shift = 16 + col_bits;
     int rc = ensure_download_side(c, 1u << 20);
     if (rc) return rc;
+    c->st_kernel_ms = 0.0;
+    c->st_bytes = c->st_blocks = c->st_pieces = c->st_two_stage = 0;
+    auto add_kernel_ms = [&]() {
+        float ms = 0.0f;
+        if (c->timing && c->ev_valid[1] && hipEventElapsedTime(&ms, c->ev[2], c->ev[3]) == hipSuccess) c->st_kernel_ms += ms;
+    };
     StreamOut out;
     out.c = c;
     out.cb = cb;
@@ -1678,43 +1796,155 @@ int mvs_pairwise_stream(mvs_ctx* c, const mvs_sketch_set* s, const double* norms
             need_exact = false;
             if ((size_t)got * 8 > c->st_raw_bytes) return finish(fail(MVS_E_HIP, "internal: kept cells beyond the sized output"));
             total = (int64_t)got;
-            rc = stream_block_out(c, out, row_begin, row_end, (int64_t)got, shift, col_bits, piece_bytes, true);
+            add_kernel_ms();
+            c->st_blocks = 1;
+            c->st_two_stage = 1;
+            BlockCsr blk;
+            rc = csr_from_packed(c, row_begin, row_end, (int64_t)got, shift, col_bits, 0, blk);
+            if (rc == MVS_OK) rc = feed_block(c, out, blk, piece_bytes);
             return finish(rc);
         }
         if (rc != kNeedExact) return finish(rc);
     }
-    // Plan B: the exact kernel, in row blocks whose worst case (every cell kept) fits the budget; block borders on
-    // multiples of 256 rows so that every block uses the symmetric schedule inside its own square.
     (void)need_exact;
-    int64_t block_rows = std::max<int64_t>(256, budget_cells / std::max<int64_t>(s->n, 1) / 256 * 256);
-    while (shift + bits_for(std::max<int64_t>(block_rows - 1, 1)) > 64 && block_rows > 256) block_rows /= 2;
-    bool first = true;
+    // Plan B: the exact kernel in row blocks, software-pipelined -- block k+1 is launched before block k's pieces are fed
+    // to the link, so comparison and download overlap.  Two ways for a block's cells to leave the kernel:
+    //  * dense (two limbs on the ping-pong kernel): one byte per cell in a row-major matrix, rows -> CSR by a count /
+    //    scan / fill pass, no list and no sort.  If the matrix of ALL the rows fits the budget the blocks share it and the
+    //    symmetric schedule spans the whole square: a block's launch computes its tiles on and above the diagonal and
+    //    writes the mirror images into later blocks' rows, so block k is final when launch k is.  Otherwise the matrix
+    //    holds one block at a time and the symmetric schedule works inside each block's own square only;
+    //  * packed list (any other kernel): blocks whose worst case -- every cell kept -- fits the budget.
+    mvs::PairwiseArgs probe{};
+    probe.limbs = s->limbs;
+    probe.d_pad = s->d_pad;
+    const bool dense_ok = mvs::exact_kernel_writes_dense(probe, c->opt) && c->opt.stream_dense != 0;
+    const int64_t ld = (s->n + 127) / 128 * 128;
+    bool dense = dense_ok, whole = false;
+    int64_t block_rows = 0;
+    const bool aligned = row_begin % 128 == 0;                      // the symmetric schedule needs the tile grids to line up
+    if (dense) {
+        whole = aligned && (size_t)rows_all * (size_t)ld <= dense_budget;
+        if (whole) {
+            block_rows = std::max<int64_t>(2048, (rows_all / 16 + 255) / 256 * 256);
+        } else {
+            block_rows = (int64_t)(dense_budget / (size_t)ld) / 256 * 256;
+            if (block_rows < 256) dense = false;                     // not even 256 rows of bytes: list blocks instead
+        }
+        if (dense && c->opt.stream_block_rows > 0)                   // tests: many small blocks on small inputs
+            block_rows = std::min<int64_t>(block_rows, std::max<int64_t>(256, (int64_t)c->opt.stream_block_rows / 256 * 256));
+    }
+    if (!dense) {
+        block_rows = std::max<int64_t>(256, budget_cells / std::max<int64_t>(s->n, 1) / 256 * 256);
+        while (shift + bits_for(std::max<int64_t>(block_rows - 1, 1)) > 64 && block_rows > 256) block_rows /= 2;
+    }
+    std::vector<std::pair<int64_t, int64_t>> blocks;
     for (int64_t rb = row_begin; rb < row_end;) {
         const int64_t re = std::min(row_end, (rb / 256) * 256 + block_rows);
-        const int64_t worst = (re - rb) * s->n;
-        rc = ensure_buf(c, &c->st_raw, &c->st_raw_bytes, (size_t)worst * 8);
-        if (rc) return finish(rc);
-        PackedOut po{&c->st_raw, &c->st_raw_bytes, rb, shift, false};
-        unsigned long long got = 0;
-        const int saved = c->opt.pairwise_filter;
-        c->opt.pairwise_filter = 0;                             // plan A has decided: the exact kernel does these blocks
-        rc = pairwise_launch(c, s, d_n2, keep_mode, rb, re, 0, s->n, true, false, nullptr, 0, 0, &got, 0.05, &po);
-        c->opt.pairwise_filter = saved;
-        if (rc) return finish(rc);
-        if (got == ~0ULL) {
-            hipError_t e = hipMemcpyAsync(&got, c->d_counter, 8, hipMemcpyDeviceToHost, c->stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-            if (e != hipSuccess) return finish(fail(MVS_E_HIP, "reading the cell count: %s", hipGetErrorString(e)));
-        }
-        if ((int64_t)got > worst) return finish(fail(MVS_E_HIP, "internal: more kept cells than cells"));
-        total += (int64_t)got;
-        rc = stream_block_out(c, out, rb, re, (int64_t)got, shift, col_bits, piece_bytes, first);
-        if (rc) return finish(rc);
-        if (out.failed()) break;
-        first = false;
+        blocks.emplace_back(rb, re);
         rb = re;
     }
+    if (dense) {
+        const size_t bytes = (size_t)(whole ? rows_all : std::min(block_rows + 256, rows_all)) * (size_t)ld;
+        rc = ensure_buf(c, &c->st_dense, &c->st_dense_bytes, bytes);
+        if (rc) return finish(rc);
+        hipError_t e = hipMemsetAsync(c->d_counter + 4, 0, 8, c->stream);      // the "q beyond a byte" flag
+        if (e != hipSuccess) return finish(fail(MVS_E_HIP, "hipMemsetAsync: %s", hipGetErrorString(e)));
+    }
+    const int saved_filter = c->opt.pairwise_filter;
+    auto launch = [&](size_t k, bool as_dense) -> int {
+        const int64_t rb = blocks[k].first, re = blocks[k].second;
+        unsigned long long got = 0;
+        c->opt.pairwise_filter = 0;                                 // plan A has decided: the exact kernel does these blocks
+        int r;
+        if (as_dense) {
+            DenseOut dn{(uint8_t*)c->st_dense, whole ? row_begin : rb, ld, whole ? row_begin : rb, whole ? row_end : re,
+                        reinterpret_cast<unsigned int*>(c->d_counter + 4)};
+            r = pairwise_launch(c, s, d_n2, keep_mode, rb, re, 0, s->n, true, false, nullptr, 0, 0, &got, 0.05, nullptr, &dn);
+        } else {
+            const int64_t worst = (re - rb) * s->n;
+            r = ensure_buf(c, &c->st_raw, &c->st_raw_bytes, (size_t)worst * 8);
+            if (r == MVS_OK) {
+                PackedOut po{&c->st_raw, &c->st_raw_bytes, rb, shift, false};
+                r = pairwise_launch(c, s, d_n2, keep_mode, rb, re, 0, s->n, true, false, nullptr, 0, 0, &got, 0.05, &po);
+            }
+        }
+        c->opt.pairwise_filter = saved_filter;
+        return r;
+    };
+    auto packed_count = [&](size_t k, int64_t* n) -> int {
+        unsigned long long got = 0;
+        hipError_t e = hipMemcpyAsync(&got, c->d_counter, 8, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) return fail(MVS_E_HIP, "reading the cell count: %s", hipGetErrorString(e));
+        if ((int64_t)got > (blocks[k].second - blocks[k].first) * s->n) return fail(MVS_E_HIP, "internal: more kept cells than cells");
+        *n = (int64_t)got;
+        return MVS_OK;
+    };
+    if (!blocks.empty()) {
+        rc = launch(0, dense);
+        if (rc) return finish(rc);
+    }
+    for (size_t k = 0; k < blocks.size(); ++k) {
+        const int64_t rb = blocks[k].first, re = blocks[k].second;
+        BlockCsr blk;
+        bool next_launched = false;
+        if (dense) {
+            bool odd = false;
+            rc = csr_from_dense(c, rb, re, s->n, whole ? row_begin : rb, ld, (int64_t)k, blk, &odd);
+            if (rc) return finish(rc);
+            add_kernel_ms();
+            if (odd) {
+                // a kept cell whose q a byte cannot hold (norms that do not belong to the vectors): this block and the
+                // rest go through the packed list, each block inside its own square -- the one case where a block is
+                // compared a second time
+                dense = false;
+                int64_t br = std::max<int64_t>(256, budget_cells / std::max<int64_t>(s->n, 1) / 256 * 256);
+                while (shift + bits_for(std::max<int64_t>(br - 1, 1)) > 64 && br > 256) br /= 2;
+                std::vector<std::pair<int64_t, int64_t>> rest(blocks.begin(), blocks.begin() + (long)k);
+                for (int64_t b0 = rb; b0 < row_end;) {
+                    const int64_t b1 = std::min(row_end, (b0 / 256) * 256 + br);
+                    rest.emplace_back(b0, b1);
+                    b0 = b1;
+                }
+                blocks.swap(rest);
+                rc = launch(k, false);
+                if (rc) return finish(rc);
+                --k;                                                   // take the block again, as a list this time
+                continue;
+            }
+        } else {
+            int64_t n = 0;
+            rc = packed_count(k, &n);
+            if (rc) return finish(rc);
+            add_kernel_ms();
+            rc = csr_from_packed(c, rb, re, n, shift, col_bits, (int64_t)k, blk);
+            if (rc) return finish(rc);
+        }
+        total += blk.n;
+        ++c->st_blocks;
+        if (k + 1 < blocks.size() && !out.failed()) {                  // the next block computes while this one is fed to the link
+            rc = launch(k + 1, dense);
+            if (rc) return finish(rc);
+            next_launched = true;
+        }
+        rc = feed_block(c, out, blk, piece_bytes);
+        if (rc) return finish(rc);
+        if (out.failed()) break;
+        (void)next_launched;
+    }
     return finish(MVS_OK);
+}
+
+int mvs_ctx_stream_stats(const mvs_ctx* c, double* kernel_ms, int64_t* bytes_out, int64_t* row_blocks, int64_t* pieces,
+                         int* two_stage) {
+    if (!c) return fail(MVS_E_INVALID, "ctx is NULL");
+    if (kernel_ms) *kernel_ms = c->st_kernel_ms;
+    if (bytes_out) *bytes_out = c->st_bytes;
+    if (row_blocks) *row_blocks = c->st_blocks;
+    if (pieces) *pieces = c->st_pieces;
+    if (two_stage) *two_stage = (int)c->st_two_stage;
+    return MVS_OK;
 }
 
 int mvs_pairwise_block(mvs_ctx* c, const mvs_sketch_set* s, const double* norms_sq, int keep_mode, int64_t row_begin,

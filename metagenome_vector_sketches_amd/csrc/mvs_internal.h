@@ -49,6 +49,8 @@ struct Options {
     int enable_k3 = 0;              // 1: mvs_sketch_set_create picks the three-plane Karatsuba code for |v| <= 8127
     int pairwise_map = 0;           // sub-patch an XCD takes in k_pairwise_pp: 0 = 4 rows x 8 cols, 1 = 8 x 4, 2 = 2 x 16
     int coarse_radix = 1;           // radix of the filter's coarse plane: 1 = smallest residual (default), 0 = ceil(max|v| / 127)
+    int stream_dense = 1;           // mvs_pairwise_stream, exact kernel: 1 = dense byte matrix + count / scan / fill, 0 = packed list + sort
+    int stream_block_rows = 0;      // > 0: upper bound on the rows of a dense row block (tests); 0 = by the budget
     int cand_regions = 1;           // 1: filter waves leave up to 8 candidates in a region of their own (no atomic to wait for)
     int comm_timeout_s = 600;       // file transport: how long a rank waits for a peer's block before it gives up
     double pairwise_block_cells = 1099511627776.0;   // row-chunk bound of mvs_pairwise_rows (2^40 cells)
@@ -66,6 +68,8 @@ struct PairwiseArgs {
     int d_pad;
     int limbs;              // limb code (see kLimbsK3)
     int64_t row_begin, row_end;   // row range of this call
+    int64_t sym_begin, sym_end;   // symmetric schedule: the square whose lower triangle is skipped and produced by mirroring
+                                  // (the call's own row range unless a caller walks a larger square block by block)
     int64_t col_begin, col_end;   // column range (dots) / [0,n) for the comparison
     // comparison outputs
     const double* norms_sq;       // n
@@ -80,6 +84,12 @@ struct PairwiseArgs {
     unsigned long long* packed;
     int64_t pack_row0;
     int pack_shift;
+    // dense output (mvs_pairwise_stream where the two-limb exact kernel runs): one byte per cell, q or 0, row-major with
+    // leading dimension dense_ld (a multiple of 128), row dense_row0 first; *dense_flag is set when a kept cell's q is
+    // not in 1..255 (the byte cannot say so: the caller redoes that block through the packed list)
+    uint8_t* dense;
+    int64_t dense_row0, dense_ld;
+    unsigned int* dense_flag;
     // dense outputs (dots mode)
     int32_t* dots;                // (row_end-row_begin) x (col_end-col_begin)
     int mirror_all;               // 1: every kept (row, col) is appended as (col, row) too (the transposed
@@ -152,6 +162,14 @@ int sort_packed(hipStream_t stream, unsigned long long* d_in, unsigned long long
 int launch_packed_csr(hipStream_t stream, const unsigned long long* d_keys, int64_t n, int shift, int64_t rows,
                       unsigned long long col_mask, long long* d_row_ptr, int32_t* d_col, uint8_t* d_q8, uint16_t* d_q16,
                       unsigned int* d_wide);
+int launch_dense_count(hipStream_t stream, const uint8_t* d_dense, int64_t ld, int64_t n_cols, int64_t rows, long long* d_counts);
+int dense_row_ptr(hipStream_t stream, long long* d_counts, long long* d_row_ptr, int64_t rows, void* d_scratch, size_t scratch_bytes,
+                  size_t* scratch_needed);
+int launch_dense_fill(hipStream_t stream, const uint8_t* d_dense, int64_t ld, int64_t n_cols, int64_t rows, const long long* d_row_ptr,
+                      int32_t* d_col, uint8_t* d_q);
+// true when launch_pairwise would run the kernel whose epilogue can write the dense byte matrix (two base-256 limbs on the
+// ping-pong kernel)
+bool exact_kernel_writes_dense(const PairwiseArgs& a, const Options& opt);
 // sort cells by (row, col); tmp buffers owned by the caller
 int sort_cells(hipStream_t stream, mvs_cell* d_cells, mvs_cell* d_tmp, int64_t n, void* d_scratch,
                size_t scratch_bytes, size_t* scratch_needed, const Options& opt);

@@ -33,6 +33,7 @@
 
 #include <rocprim/device/device_merge_sort.hpp>
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
 
 namespace mvs {
 
@@ -232,8 +233,8 @@ __global__ __launch_bounds__(WM * WN * 64, (AT * BT > 2 ? 1 : 2)) void k_pairwis
     // strictly above the diagonal that holds their transposes (DESIGN.md K2 has the covering argument).
     bool mirror_tile = false;
     if (MODE != 1 && a.symmetric) {
-        if (j0 >= a.row_begin && j0 + TN <= i0) return;
-        mirror_tile = j0 >= i0 + TM && j0 < a.row_end;
+        if (j0 >= a.sym_begin && j0 + TN <= i0) return;
+        mirror_tile = j0 >= i0 + TM && j0 < a.sym_end;
     }
     if constexpr (MODE == 2) {   // the filter is not paying on this block (see cand_limit): stop wasting time
         if (*reinterpret_cast<volatile const unsigned int*>(a.cand_stop) != 0u) return;
@@ -443,7 +444,7 @@ __global__ __launch_bounds__(WM * WN * 64, (AT * BT > 2 ? 1 : 2)) void k_pairwis
                 const float4 mj = fcol[col_l];
                 const float bj = mj.z + mj.w;
                 const v2f wj = {mj.y, mj.y}, sj = {mj.x, mj.x}, npj = {-mj.w, -mj.w}, nbj = {-bj, -bj};
-                const bool in_square = a.symmetric && col >= a.row_begin && col < a.row_end;
+                const bool in_square = a.symmetric && col >= a.sym_begin && col < a.sym_end;
                 // rows above this one fail the triangle test: col >= row  <=>  row_l <= col_l + delta (columns
                 // outside the square are not restricted)
                 const int row_max = (TRI && in_square) ? col_l + delta : 0x7fffffff;
@@ -494,7 +495,7 @@ __global__ __launch_bounds__(WM * WN * 64, (AT * BT > 2 ? 1 : 2)) void k_pairwis
         for (int u = 0; u < BT; ++u) {
             const int col_l = (wn * BT + u) * 32 + fr;
             const int64_t col = j0 + col_l;
-            const bool in_square = a.symmetric && col >= a.row_begin && col < a.row_end;
+            const bool in_square = a.symmetric && col >= a.sym_begin && col < a.sym_end;
             const int cd = col_l + delta;
 #pragma unroll
             for (int t = 0; t < AT; ++t) {
@@ -555,7 +556,7 @@ __global__ __launch_bounds__(WM * WN * 64, (AT * BT > 2 ? 1 : 2)) void k_pairwis
     for (int u = 0; u < BT; ++u) {
         const int col_l = (wn * BT + u) * 32 + fr;
         const int64_t col = j0 + col_l;
-        const bool mirror = a.mirror_all || (mirror_tile && col < a.row_end);
+        const bool mirror = a.mirror_all || (mirror_tile && col < a.sym_end);
 #pragma unroll
         for (int t = 0; t < AT; ++t) {
             unsigned m16 = 0;
@@ -581,7 +582,7 @@ __global__ __launch_bounds__(WM * WN * 64, (AT * BT > 2 ? 1 : 2)) void k_pairwis
 #pragma unroll
     for (int u = 0; u < BT; ++u) {
         const int64_t col = j0 + (wn * BT + u) * 32 + fr;
-        const bool mirror = a.mirror_all || (mirror_tile && col < a.row_end);
+        const bool mirror = a.mirror_all || (mirror_tile && col < a.sym_end);
 #pragma unroll
         for (int t = 0; t < AT; ++t) {
             const unsigned m = masks[(u * AT + t) * 64];   // this lane's own word
@@ -638,6 +639,58 @@ __device__ __forceinline__ void epilogue_exact16(const PairwiseArgs& a, v4i (&ac
         }
         return;
     }
+    if (a.dense) {
+        // Dense results (mvs_pairwise_stream where the exact kernel runs): no list, no counter -- every cell of the tile
+        // gets a byte in a row-major matrix, q for a kept cell and 0 otherwise, and a later pass turns rows into CSR.
+        // The tile is staged in LDS twice, as it is and transposed (a lane holds four consecutive rows of one column:
+        // one ds_write_b32 of the transposed image), so that both the tile and -- above the diagonal of the symmetric
+        // square -- its mirror image leave as whole 128-byte lines.
+        constexpr int LD = 144;                                             // LDS row stride (bytes)
+        uint8_t* tile = reinterpret_cast<uint8_t*>(smem) + 2048;            // behind thr[256]
+        uint8_t* tileT = tile + 128 * LD;
+        bool odd = false;                                                   // a kept cell whose q is not in 1..255
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int col_l = wn * 32 + u * 16 + fr;
+            const int64_t col = j0 + col_l;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                unsigned packed = 0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row_l = wm * 64 + t * 16 + fq * 4 + r;
+                    const int64_t row = i0 + row_l;
+                    const int32_t P = dot_of(t, u, r);
+                    const bool cand = P >= thr[row_l] + thr[TM + col_l];
+                    unsigned q8 = 0;
+                    if (__any(cand)) {
+                        if (cand && row < a.row_end && col < a.col_end &&
+                            keep_cell(P, a.d, a.norms_sq[row], a.norms_sq[col], a.keep_mode, a.keep_coeff)) {
+                            const int32_t q = quantize_cell(P, a.d, a.norms_sq[row], a.norms_sq[col]);
+                            odd = odd || q <= 0 || q > 255;
+                            q8 = (unsigned)q & 0xffu;
+                        }
+                    }
+                    tile[row_l * LD + col_l] = (uint8_t)q8;
+                    packed |= q8 << (8 * r);
+                }
+                if (mirror_tile) *reinterpret_cast<unsigned*>(tileT + col_l * LD + wm * 64 + t * 16 + fq * 4) = packed;
+            }
+        }
+        if (__any(odd) && lane == 0) *a.dense_flag = 1u;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int idx = tid + 512 * j, rl = idx >> 3, seg = idx & 7;    // 128 rows x 8 segments of 16 bytes
+            if (i0 + rl < a.row_end)
+                *reinterpret_cast<v4i*>(a.dense + (i0 + rl - a.dense_row0) * a.dense_ld + j0 + seg * 16) =
+                    *reinterpret_cast<const v4i*>(tile + rl * LD + seg * 16);
+            if (mirror_tile && j0 + rl < a.sym_end)                          // row j0 + rl of the matrix, columns i0 ..
+                *reinterpret_cast<v4i*>(a.dense + (j0 + rl - a.dense_row0) * a.dense_ld + i0 + seg * 16) =
+                    *reinterpret_cast<const v4i*>(tileT + rl * LD + seg * 16);
+        }
+        return;
+    }
     // pass 1: keep masks (16 cells per lane and column) parked in LDS; pass 2: one atomic per wave, then the writes
     unsigned* masks = reinterpret_cast<unsigned*>(smem + (TM + TN) * 4) + wave * 128 + lane;
     unsigned mine = 0;
@@ -645,7 +698,7 @@ __device__ __forceinline__ void epilogue_exact16(const PairwiseArgs& a, v4i (&ac
     for (int u = 0; u < 2; ++u) {
         const int col_l = wn * 32 + u * 16 + fr;
         const int64_t col = j0 + col_l;
-        const bool mirror = a.mirror_all || (mirror_tile && col < a.row_end);
+        const bool mirror = a.mirror_all || (mirror_tile && col < a.sym_end);
         unsigned m16 = 0;
 #pragma unroll
         for (int t = 0; t < 4; ++t)
@@ -670,7 +723,7 @@ __device__ __forceinline__ void epilogue_exact16(const PairwiseArgs& a, v4i (&ac
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         const int64_t col = j0 + wn * 32 + u * 16 + fr;
-        const bool mirror = a.mirror_all || (mirror_tile && col < a.row_end);
+        const bool mirror = a.mirror_all || (mirror_tile && col < a.sym_end);
         const unsigned m = masks[u * 64];   // this lane's own word
         if (__ballot(m != 0) == 0ULL) continue;
 #pragma unroll
@@ -697,8 +750,8 @@ __global__ __launch_bounds__(512, 2) void k_pairwise_mfma16(const PairwiseArgs a
     const int64_t i0 = a.row_begin + (int64_t)tc.tr * TM, j0 = a.col_begin + (int64_t)tc.tc * TN;
     bool mirror_tile = false;
     if (MODE == 0 && a.symmetric) {
-        if (j0 >= a.row_begin && j0 + TN <= i0) return;
-        mirror_tile = j0 >= i0 + TM && j0 < a.row_end;
+        if (j0 >= a.sym_begin && j0 + TN <= i0) return;
+        mirror_tile = j0 >= i0 + TM && j0 < a.sym_end;
     }
     const int8_t* src[kPPW];
 #pragma unroll
@@ -867,7 +920,7 @@ __device__ __forceinline__ void epilogue_filter16(const PairwiseArgs& a, v4i (&a
         const int col_l = wn * 64 + u * 16 + fr;
         const int64_t col = j0 + col_l;
         bop[u] = colc[fq * PS + col_l];
-        const bool in_square = a.symmetric && col >= a.row_begin && col < a.row_end;
+        const bool in_square = a.symmetric && col >= a.sym_begin && col < a.sym_end;
         row_max[u] = (straddle && in_square) ? col_l + delta : 0x7fffffff;   // col >= row  <=>  row_l <= col_l + delta
     }
     // Candidates are rare (1.5e-5 of the cells), so the sweep first only asks "does any lane pass in this row block"
@@ -972,7 +1025,7 @@ __device__ __forceinline__ void epilogue_filter16(const PairwiseArgs& a, v4i (&a
     for (int u = 0; u < 4; ++u) {
         const int col_l = wn * 64 + u * 16 + fr;
         const int64_t col = j0 + col_l;
-        const bool in_square = a.symmetric && col >= a.row_begin && col < a.row_end;
+        const bool in_square = a.symmetric && col >= a.sym_begin && col < a.sym_end;
         const int cd = col_l + delta;
         unsigned m = m32[u];
         while (m) {
@@ -1058,8 +1111,8 @@ __global__ __launch_bounds__(512, 2) void k_pairwise_pp(const PairwiseArgs a, in
     const int64_t i0 = a.row_begin + (int64_t)tc.tr * TM, j0 = a.col_begin + (int64_t)tc.tc * TN;
     bool mirror_tile = false;
     if (MODE != 1 && a.symmetric) {
-        if (j0 >= a.row_begin && j0 + TN <= i0) return;
-        mirror_tile = j0 >= i0 + TM && j0 < a.row_end;
+        if (j0 >= a.sym_begin && j0 + TN <= i0) return;
+        mirror_tile = j0 >= i0 + TM && j0 < a.sym_end;
     }
     if constexpr (MODE == 2) {
         if (*reinterpret_cast<volatile const unsigned int*>(a.cand_stop) != 0u) return;
@@ -1688,6 +1741,82 @@ __global__ __launch_bounds__(256) void k_packed_unpack(const unsigned long long*
     }
 }
 
+// ---- dense byte matrix (see epilogue_exact16) -> CSR ----
+// nonzero bytes of 16: one bit per byte
+__device__ __forceinline__ unsigned nz_mask16(const v4i w) {
+    unsigned m = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const unsigned x = (unsigned)w[i];
+        m |= ((x & 0xffu) ? 1u : 0u) << (4 * i) | ((x & 0xff00u) ? 2u : 0u) << (4 * i) | ((x & 0xff0000u) ? 4u : 0u) << (4 * i) |
+             ((x & 0xff000000u) ? 8u : 0u) << (4 * i);
+    }
+    return m;
+}
+
+// counts[r] = kept cells of row r: one workgroup per row
+__global__ __launch_bounds__(256) void k_dense_count(const uint8_t* __restrict__ dense, long long ld, long long n_cols,
+                                                     long long* __restrict__ counts) {
+    __shared__ unsigned part[4];
+    const uint8_t* row = dense + (long long)blockIdx.x * ld;
+    unsigned c = 0;
+    for (long long k = (long long)threadIdx.x * 16; k < n_cols; k += 256 * 16) {
+        unsigned m = nz_mask16(*reinterpret_cast<const v4i*>(row + k));
+        if (k + 16 > n_cols) m &= (1u << (n_cols - k)) - 1u;                  // columns beyond the last sample
+        c += (unsigned)__popc(m);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) counts[blockIdx.x] = (long long)(part[0] + part[1] + part[2] + part[3]);
+}
+
+// col / q of row r at row_ptr[r]: one workgroup per row, 4 KiB of the row per step, positions by a block-wide prefix sum
+__global__ __launch_bounds__(256) void k_dense_fill(const uint8_t* __restrict__ dense, long long ld, long long n_cols,
+                                                    const long long* __restrict__ row_ptr, int32_t* __restrict__ col,
+                                                    uint8_t* __restrict__ q) {
+    __shared__ unsigned wsum[4];
+    const uint8_t* row = dense + (long long)blockIdx.x * ld;
+    long long base = row_ptr[blockIdx.x];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (long long k0 = 0; k0 < n_cols; k0 += 256 * 16) {
+        const long long k = k0 + (long long)threadIdx.x * 16;
+        v4i wv = v4i{0, 0, 0, 0};
+        unsigned m = 0;
+        if (k < n_cols) {
+            wv = *reinterpret_cast<const v4i*>(row + k);
+            m = nz_mask16(wv);
+            if (k + 16 > n_cols) m &= (1u << (n_cols - k)) - 1u;
+        }
+        const unsigned mine = (unsigned)__popc(m);
+        unsigned incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned up = (unsigned)__shfl_up((int)incl, o, 64);
+            if (lane >= o) incl += up;
+        }
+        __syncthreads();                                          // wsum of the previous step has been read
+        if (lane == 63) wsum[w] = incl;
+        __syncthreads();
+        unsigned before = 0, total = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            before += i < w ? wsum[i] : 0u;
+            total += wsum[i];
+        }
+        long long at = base + before + (incl - mine);
+        while (m) {
+            const int b = __ffs((int)m) - 1;
+            m &= m - 1;
+            col[at] = (int32_t)(k + b);
+            q[at] = (uint8_t)((unsigned)wv[b >> 2] >> (8 * (b & 3)));
+            ++at;
+        }
+        base += total;
+    }
+}
+
 struct CellLess {
     __host__ __device__ bool operator()(const mvs_cell& x, const mvs_cell& y) const {
         return x.row < y.row || (x.row == y.row && x.col < y.col);
@@ -1930,6 +2059,11 @@ int launch_exact_pairs(hipStream_t stream, const PairwiseArgs& a, const Options&
     return 0;
 }
 
+bool exact_kernel_writes_dense(const PairwiseArgs& a, const Options& opt) {
+    const int v = pairwise_variant(opt);
+    return a.limbs == 2 && a.d_pad <= 32768 && v >= 6 && v <= 9;      // the kernels that end in epilogue_exact16
+}
+
 int launch_pairwise(hipStream_t stream, const PairwiseArgs& a, int mode, int algo, const Options& opt) {
     // int32 accumulators hold up to two limb-pair products per k: exact while 2 * 128 * 128 * d_pad < 2^31;
     // longer sketches take the vector-ALU path, which wraps mod 2^32 by construction
@@ -1979,6 +2113,34 @@ int launch_packed_csr(hipStream_t stream, const unsigned long long* d_keys, int6
     if (n > 0 && d_col)
         hipLaunchKernelGGL(k_packed_unpack, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_keys, (unsigned long long)n,
                            col_mask, d_col, d_q8, d_q16, d_wide);
+    return 0;
+}
+
+// rows [0, rows) of a dense byte matrix -> counts, row_ptr (exclusive scan, row_ptr[rows] = total), then col / q
+int launch_dense_count(hipStream_t stream, const uint8_t* d_dense, int64_t ld, int64_t n_cols, int64_t rows, long long* d_counts) {
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(k_dense_count, dim3((unsigned)rows), dim3(256), 0, stream, d_dense, (long long)ld, (long long)n_cols, d_counts);
+    return 0;
+}
+
+int dense_row_ptr(hipStream_t stream, long long* d_counts, long long* d_row_ptr, int64_t rows, void* d_scratch, size_t scratch_bytes,
+                  size_t* scratch_needed) {
+    // counts has rows + 1 entries, the last one 0: the exclusive scan of all of them ends with the total
+    size_t need = 0;
+    hipError_t e = rocprim::exclusive_scan(nullptr, need, d_counts, d_row_ptr, 0LL, (size_t)rows + 1, rocprim::plus<long long>(), stream);
+    if (e != hipSuccess) return MVS_E_HIP;
+    if (scratch_needed) *scratch_needed = need;
+    if (d_scratch == nullptr) return 0;
+    if (scratch_bytes < need) return MVS_E_CAPACITY;
+    e = rocprim::exclusive_scan(d_scratch, need, d_counts, d_row_ptr, 0LL, (size_t)rows + 1, rocprim::plus<long long>(), stream);
+    return e == hipSuccess ? 0 : MVS_E_HIP;
+}
+
+int launch_dense_fill(hipStream_t stream, const uint8_t* d_dense, int64_t ld, int64_t n_cols, int64_t rows, const long long* d_row_ptr,
+                      int32_t* d_col, uint8_t* d_q) {
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(k_dense_fill, dim3((unsigned)rows), dim3(256), 0, stream, d_dense, (long long)ld, (long long)n_cols, d_row_ptr,
+                       d_col, d_q);
     return 0;
 }
 

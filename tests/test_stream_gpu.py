@@ -61,11 +61,15 @@ def test_stream_toy_db(ctx, gold):
     ss.close()
 
 
-@pytest.mark.parametrize("filt", [1, 2])
-def test_stream_dense_result_in_row_blocks(ctx, filt):
+@pytest.mark.parametrize("filt", [0, 1])
+@pytest.mark.parametrize("mode", ["dense-per-block", "dense-whole-square", "packed-list"])
+def test_stream_dense_result_in_row_blocks(ctx, filt, mode):
     """clusters of 1000 samples: a third of all cells are kept.  The filter (when it runs) gives up past 1/128 of the
-    cells in its list and the exact kernel does the rows in blocks whose worst case fits the budget given here (2 MB:
-    blocks of 256 rows) -- nothing is compared twice and the pieces still cover every row once, in order."""
+    cells in its list and the exact kernel does the rows in blocks -- nothing is compared twice and the pieces still
+    cover every row once, in order.  The three ways a block's cells leave the exact kernel:
+      dense-per-block     one byte per cell, the matrix holds one block (budget 2 MB: blocks of 512 rows)
+      dense-whole-square  one matrix for all rows, blocks of 256 rows, mirror images land in later blocks' rows
+      packed-list         64-bit words + radix sort (what other limb codes get), blocks sized for the worst case"""
     n, d = 3000, 256
     sk = synth.make_sketches_numpy(n, d, 3000, seed=77, cluster=1000, shared=0.6)
     n2 = _n2(sk)
@@ -73,14 +77,32 @@ def test_stream_dense_result_in_row_blocks(ctx, filt):
     ss = ctx.sketch_set(sk)
     cells, cnt = ctx.pairwise_rows(ss, n2)
     assert cnt > n * n // 4
-    pieces = []
-    n_s = ctx.pairwise_stream(ss, n2, on_block=lambda b, e, rp, c, qq: pieces.append((b, e, rp, c, qq)) and None,
-                              device_budget_bytes=2 << 20)
-    assert n_s == cnt and pieces[0][0] == 0 and pieces[-1][1] == n
-    assert all(a[1] == b[0] for a, b in zip(pieces, pieces[1:])) and len(pieces) >= n // 256
-    got = np.concatenate([_triples(rp, c, qq, b) for (b, e, rp, c, qq) in pieces])
-    assert np.array_equal(got, _cells_triples(cells))
-    # and with the default budget: one block
+    budget = 0
+    if mode == "dense-per-block":
+        budget = 2 << 20
+    elif mode == "dense-whole-square":
+        ctx.set_option("stream_block_rows", 256)
+    else:
+        ctx.set_option("stream_dense", 0)
+        budget = 16 << 20
+    try:
+        pieces = []
+        n_s = ctx.pairwise_stream(ss, n2, on_block=lambda b, e, rp, c, qq: pieces.append((b, e, rp, c, qq)) and None,
+                                  device_budget_bytes=budget)
+        st = ctx.stream_stats()
+        assert n_s == cnt and pieces[0][0] == 0 and pieces[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(pieces, pieces[1:]))
+        assert st["row_blocks"] >= {"dense-per-block": 5, "dense-whole-square": 11, "packed-list": 3}[mode] and not st["two_stage"]
+        got = np.concatenate([_triples(rp, c, qq, b) for (b, e, rp, c, qq) in pieces])
+        assert np.array_equal(got, _cells_triples(cells))
+        # a shard that does not start on a tile border
+        row_ptr, col, q, n_sh = ctx.pairwise_stream(ss, n2, row_begin=777, row_end=2222, device_budget_bytes=budget)
+        sel = (cells["row"] >= 777) & (cells["row"] < 2222)
+        assert n_sh == int(sel.sum()) and np.array_equal(_triples(row_ptr, col, q, 777), _cells_triples(cells[sel]))
+    finally:
+        ctx.set_option("stream_block_rows", 0)
+        ctx.set_option("stream_dense", 1)
+    # and with the defaults: one block
     row_ptr, col, q, n_one = ctx.pairwise_stream(ss, n2)
     assert n_one == cnt and np.array_equal(_triples(row_ptr, col, q), _cells_triples(cells))
     ss.close()

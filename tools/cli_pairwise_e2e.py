@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """End-to-end timing of `pairwise_comp_optimized` on a synthesised DB (one shard = all rows), with the per-stage
-wall times the executable prints under MVS_STAGE_TIMING=1.   python tools/cli_pairwise_e2e.py [N] [d] [runs]"""
+wall times the executable prints under MVS_STAGE_TIMING=1.   python tools/cli_pairwise_e2e.py [N] [d] [runs] [cluster]
+cluster: related samples per cluster (default 16; N/10 keeps 10 % of all cells)"""
 import os
 import shutil
 import subprocess
@@ -20,13 +21,14 @@ BIN = os.path.join(ROOT, "metagenome_vector_sketches_amd", "bin")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000
 d = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
 runs = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+cluster = int(sys.argv[4]) if len(sys.argv) > 4 else 16
 w = tempfile.mkdtemp(prefix="mvs_pairwise_e2e_")
 try:
     t0 = time.perf_counter()
     db = w + "/db/"
     os.makedirs(db)
     ctx = pkg.Context(0)
-    sk = synth.make_sketches_torch(n, d, 50_000, seed=2345, device="cuda")
+    sk = synth.make_sketches_torch(n, d, 50_000, seed=2345, device="cuda", cluster=cluster)
     ss = torch.empty(n, dtype=torch.int64, device="cuda")
     ctx.set_stream(torch.cuda.current_stream())
     ctx.sumsq(sk, out=ss)
@@ -54,6 +56,9 @@ try:
         size = sum(os.path.getsize(os.path.join(out, "shard_0", f)) for f in os.listdir(os.path.join(out, "shard_0")))
         print("run %d: %.3f s wall; %s; shard files %.1f MB" % (run, dt, "; ".join(own), size / 1e6), flush=True)
         print("   " + " | ".join(l[8:] for l in r.stderr.split("\n") if l.startswith("[stage]")), flush=True)
+        for l in r.stderr.split("\n"):
+            if l.startswith("[stream]"):
+                print("   " + l, flush=True)
         shutil.rmtree(out)
 finally:
     shutil.rmtree(w, ignore_errors=True)
