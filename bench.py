@@ -177,6 +177,9 @@ def main():
     ap.add_argument("--cluster", type=int, default=16, help="related samples per cluster (256: the dense variant)")
     ap.add_argument("--lognormal-sigma", type=float, default=0.0,
                     help="> 0: ragged samples, sizes ~ lognormal(ln hashes, sigma) clipped to [100, 2e6] (SURVEY 8d)")
+    ap.add_argument("--stream-samples", type=int, default=30_000,
+                    help="N=1: size of the streamed-output leg at the density of the reference's toy set (clusters of N/3 "
+                         "samples: a third of all cells kept), mvs_pairwise_stream with a counting callback; 0 skips it")
     ap.add_argument("--overlap-parts", type=int, default=2,
                     help="N > 1: pieces the rank's samples are projected in; the all-gather of a finished piece's limb "
                          "planes runs beside the projection of the next (1: no overlap)")
@@ -420,6 +423,9 @@ def main():
         res["pairwise"] = pw.pop("leg")
         res["roofline_pairwise"] = pw.pop("roofline")
 
+    if args.stream_samples and world == 1:
+        res["streamed_dense"] = stream_leg(ctx, dev, args.stream_samples, args.pairwise_dim, NH)
+
     if args.host_input and world == 1:
         h_host = hashes.cpu().numpy().view(np.uint64)                                      # pageable, as a caller's vector would be
         o_host = np.asarray(offsets)
@@ -612,6 +618,68 @@ def pairwise_leg(ctx, dev, n, d, nh, reps):
            "limbs": limbs, "two_stage": two, "exact": ex,
            "exact_cells_per_s": cells_total / (ex["wall_ms"] * 1e-3)}
     return {"workload": "configs[2]: %d synthetic samples, d=%d, pairwise" % (n, d), "leg": leg, "roofline": roof}
+
+
+def stream_leg(ctx, dev, n, d, nh, reps=3):
+    """The comparison with a DENSE result -- clusters of n/3 samples, a third of all cells kept, the density of the
+    reference's own toy set (1291 of 3721) -- streamed to the host as CSR pieces (mvs_pairwise_stream; the callback only
+    counts): compare + download wall against the comparison kernels' own time and against the bare link time of the same
+    bytes (pinned D2H in 32 MiB pieces), i.e. how much of the run the PCIe link accounts for."""
+    import ctypes
+    import torch
+    from metagenome_vector_sketches_amd import _capi, synth
+    cluster = max(16, n // 3)
+    sk = synth.make_sketches_torch(n, d, nh, seed=2345, device=dev, cluster=cluster)
+    ss = torch.empty(n, dtype=torch.int64, device=dev)
+    ctx.sumsq(sk, out=ss)
+    n2 = torch.from_numpy(fast_norm_sq(ss.cpu().numpy(), d)).to(dev)
+    sset = ctx.sketch_set(sk)
+    del sk
+    seen = {"cells": 0, "rows": 0}
+
+    def count(_user, bp):
+        b = bp.contents
+        seen["cells"] += b.n_cells
+        seen["rows"] += b.row_end - b.row_begin
+        return 0
+    cb = _capi.ROW_BLOCK_CB(count)
+    walls, stats = [], None
+    for r in range(reps + 1):
+        seen.update(cells=0, rows=0)
+        cnt = ctypes.c_int64()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        rc = ctx.lib.mvs_pairwise_stream(ctx._h, sset._h, n2.data_ptr(), _capi.MEM_DEVICE, _capi.KEEP_INT32, 0, n, 0, cb, None,
+                                         ctypes.byref(cnt))
+        wall = (time.perf_counter() - t0) * 1e3
+        if rc != 0 or seen["cells"] != cnt.value or seen["rows"] != n:
+            raise SystemExit("streamed comparison failed: rc %d, %d of %d cells, %d of %d rows" %
+                             (rc, seen["cells"], cnt.value, seen["rows"], n))
+        if r:
+            walls.append(wall)
+            stats = ctx.stream_stats()
+    sset.close()
+    nbytes = max(stats["bytes"], 1)
+    piece = min(nbytes, 32 << 20)
+    src = torch.empty(piece, dtype=torch.uint8, device=dev)
+    dst = [torch.empty(piece, dtype=torch.uint8).pin_memory() for _ in range(2)]
+    link = []
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range((nbytes + piece - 1) // piece):
+            dst[i & 1].copy_(src, non_blocking=True)
+        torch.cuda.synchronize()
+        link.append((time.perf_counter() - t0) * 1e3)
+    wall = float(np.mean(walls))
+    return {"workload": "%d synthetic samples in clusters of %d, d=%d: all-vs-all streamed to the host as CSR pieces" % (n, cluster, d),
+            "kept_cells": int(cnt.value), "density": cnt.value / float(n) / n, "wall_ms": wall,
+            "comparison_kernels_ms": stats["kernel_ms"], "row_blocks": stats["row_blocks"], "pieces": stats["pieces"],
+            "path": "two-stage" if stats["two_stage"] else "exact kernel, dense byte matrix -> CSR on the device",
+            "bytes_to_host": int(nbytes), "bytes_per_kept_cell": nbytes / max(cnt.value, 1),
+            "bare_link_ms": min(link), "link_GBps": nbytes / (min(link) * 1e-3) / 1e9,
+            "pcie_share_of_wall": min(link) / wall, "wall_over_max_kernel_link": wall / max(stats["kernel_ms"], min(link)),
+            "cells_per_s": float(n) * n / (wall * 1e-3), "kept_cells_per_s": cnt.value / (wall * 1e-3)}
 
 
 def usable_cores(visible):
