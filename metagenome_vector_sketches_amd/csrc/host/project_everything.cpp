@@ -133,13 +133,40 @@ static int sketch(const std::string& hash_file, std::string index_folder, int di
         lap_t = t;
     };
 
-    // the device context (0.1-0.2 s of runtime start-up) comes up while the text is parsed
-    mvs_ctx* ctx = nullptr;
-    int ctx_rc = MVS_OK;
-    std::string ctx_err;
+    // The device contexts (0.1-0.2 s of runtime start-up each) come up while the text is parsed: one per visible GPU --
+    // the reference's OpenMP loop over samples (:289-298) becomes one host thread per GPU, each projecting a contiguous
+    // range of samples with about the same number of hashes.  MVS_DEVICE pins the work to one device;
+    // MVS_SKETCH_CONTEXTS=k asks for k contexts (cycling over the devices: k = 2 on a one-GPU box runs the multi-context
+    // path on device 0).
+    std::vector<int> devices;
+    {
+        int ndev = 0;
+        if (getenv("MVS_DEVICE") || mvs_device_count(&ndev) != MVS_OK || ndev <= 0) {
+            devices.push_back(pick_device());
+        } else {
+            int want = ndev;
+            if (const char* e = getenv("MVS_SKETCH_CONTEXTS")) want = std::max(1, std::min(64, atoi(e)));
+            for (int i = 0; i < want; ++i) devices.push_back(i % ndev);
+        }
+    }
+    const size_t n_ctx = devices.size();
+    std::vector<mvs_ctx*> ctxs(n_ctx, nullptr);
+    std::vector<int> ctx_rcs(n_ctx, MVS_OK);
+    std::vector<std::string> ctx_errs(n_ctx);
+    auto destroy_all = [&]() {
+        for (mvs_ctx*& c : ctxs) {
+            if (c) mvs_ctx_destroy(c);
+            c = nullptr;
+        }
+    };
     std::thread ctx_thread([&]() {
-        ctx_rc = mvs_ctx_create(pick_device(), &ctx);
-        if (ctx_rc != MVS_OK) ctx_err = mvs_last_error();   // the message is per thread
+        std::vector<std::thread> pool;
+        for (size_t g = 0; g < n_ctx; ++g)
+            pool.emplace_back([&, g]() {
+                ctx_rcs[g] = mvs_ctx_create(devices[g], &ctxs[g]);
+                if (ctx_rcs[g] != MVS_OK) ctx_errs[g] = mvs_last_error();   // the message is per thread
+            });
+        for (auto& th : pool) th.join();
     });
     // the parsed form of an unchanged hash file is kept next to it (<hash_file>.csr): mapped instead of parsed again
     HashSets sets;
@@ -166,7 +193,7 @@ static int sketch(const std::string& hash_file, std::string index_folder, int di
         } catch (const std::exception& e) {
             ctx_thread.join();
             std::cerr << "project_everything: reading " << hash_file << ": " << e.what() << std::endl;
-            if (ctx) mvs_ctx_destroy(ctx);
+            destroy_all();
             return 2;
         }
         if (parsed && !getenv("MVS_NO_CSR_CACHE")) (void)write_csr_cache(hash_file, sets);
@@ -174,35 +201,69 @@ static int sketch(const std::string& hash_file, std::string index_folder, int di
     ctx_thread.join();
     if (!parsed) {                                                                                     // :258-262
         std::cerr << "Error opening " << hash_file << " for reading." << std::endl;
-        if (ctx) mvs_ctx_destroy(ctx);
+        destroy_all();
         return 0;   // the reference returns from sketch() and exits 0
     }
     lap("hash sets (text or cache) + device context");
     const int64_t n = (int64_t)sets.names.size();
     std::cout << "Loaded " << n << " hash sets from " << hash_file << std::endl;                       // :284
-    if (ctx_rc != MVS_OK) {
-        std::cerr << "project_everything: " << ctx_err << std::endl;
-        return 2;
-    }
-    std::vector<int32_t> vectors((size_t)n * (size_t)dimension);
-    std::vector<int64_t> sumsq((size_t)n);
-    // batches bound the device footprint (hash lists of ~1M-hash samples x thousands of samples)
-    const int64_t kMaxBatchHashes = 1LL << 28;   // 2 GiB of hashes per launch
-    for (int64_t s0 = 0; s0 < n;) {
-        int64_t s1 = s0 + 1;
-        while (s1 < n && sets.offsets[s1 + 1] - sets.offsets[s0] <= kMaxBatchHashes) ++s1;
-        std::vector<int64_t> offs((size_t)(s1 - s0 + 1));
-        for (int64_t s = s0; s <= s1; ++s) offs[(size_t)(s - s0)] = sets.offsets[s] - sets.offsets[s0];
-        int64_t max_abs = 0;   // not needed here; the statistics come out of the projection kernel for free
-        const int rc = mvs_project_csr_stats(ctx, sets.hashes.data() + sets.offsets[s0], MVS_MEM_HOST, offs.data(), s1 - s0,
-                                             dimension, vectors.data() + (size_t)s0 * dimension, MVS_MEM_HOST,
-                                             sumsq.data() + s0, &max_abs);
-        if (rc != MVS_OK) {
-            std::cerr << "project_everything: " << mvs_last_error() << std::endl;
-            mvs_ctx_destroy(ctx);
+    for (size_t g = 0; g < n_ctx; ++g)
+        if (ctx_rcs[g] != MVS_OK) {
+            std::cerr << "project_everything: " << ctx_errs[g] << std::endl;
+            destroy_all();
             return 2;
         }
-        s0 = s1;
+    mvs_ctx* ctx = ctxs[0];
+    std::vector<int32_t> vectors((size_t)n * (size_t)dimension);
+    std::vector<int64_t> sumsq((size_t)n);
+    // sample ranges with about the same number of hashes each: range g ends where the running hash count passes g + 1 shares
+    std::vector<int64_t> cut(n_ctx + 1, n);
+    cut[0] = 0;
+    {
+        const int64_t total_hashes = sets.offsets[(size_t)n];
+        for (size_t g = 1; g < n_ctx; ++g) {
+            const int64_t target = (int64_t)((double)total_hashes * (double)g / (double)n_ctx);
+            cut[g] = std::lower_bound(sets.offsets.begin(), sets.offsets.begin() + n, target) - sets.offsets.begin();
+            cut[g] = std::max(cut[g], cut[g - 1]);
+        }
+    }
+    // batches bound the device footprint (hash lists of ~1M-hash samples x thousands of samples)
+    const int64_t kMaxBatchHashes = 1LL << 28;   // 2 GiB of hashes per launch
+    std::vector<std::string> errors(n_ctx);
+    auto project_range = [&](size_t g) {
+        for (int64_t s0 = cut[g]; s0 < cut[g + 1];) {
+            int64_t s1 = s0 + 1;
+            while (s1 < cut[g + 1] && sets.offsets[s1 + 1] - sets.offsets[s0] <= kMaxBatchHashes) ++s1;
+            std::vector<int64_t> offs((size_t)(s1 - s0 + 1));
+            for (int64_t s = s0; s <= s1; ++s) offs[(size_t)(s - s0)] = sets.offsets[s] - sets.offsets[s0];
+            int64_t max_abs = 0;   // not needed here; the statistics come out of the projection kernel for free
+            const int rc = mvs_project_csr_stats(ctxs[g], sets.hashes.data() + sets.offsets[s0], MVS_MEM_HOST, offs.data(), s1 - s0,
+                                                 dimension, vectors.data() + (size_t)s0 * dimension, MVS_MEM_HOST,
+                                                 sumsq.data() + s0, &max_abs);
+            if (rc != MVS_OK) {
+                errors[g] = mvs_last_error();
+                return;
+            }
+            s0 = s1;
+        }
+    };
+    if (n_ctx == 1) {
+        project_range(0);
+    } else {
+        std::vector<std::thread> pool;
+        for (size_t g = 0; g < n_ctx; ++g) pool.emplace_back(project_range, g);
+        for (auto& th : pool) th.join();
+    }
+    for (size_t g = 0; g < n_ctx; ++g)
+        if (!errors[g].empty()) {
+            std::cerr << "project_everything: " << errors[g] << std::endl;
+            destroy_all();
+            return 2;
+        }
+    if (stage_timing && n_ctx > 1) {
+        std::cerr << "[stage] " << n_ctx << " contexts, samples per context:";
+        for (size_t g = 0; g < n_ctx; ++g) std::cerr << " " << (cut[g + 1] - cut[g]) << " (device " << devices[g] << ")";
+        std::cerr << std::endl;
     }
     lap("projection (upload, kernels, download)");
     for (int64_t i = 0; i < n; ++i)                                                                    // :294-297
@@ -249,7 +310,7 @@ static int sketch(const std::string& hash_file, std::string index_folder, int di
         }
     }
     lap("progress lines + DB files");
-    mvs_ctx_destroy(ctx);
+    destroy_all();
     lap("context teardown");
     return status;
 }

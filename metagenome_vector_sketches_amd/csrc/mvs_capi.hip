@@ -376,7 +376,8 @@ int mvs_ctx_create(int device, mvs_ctx** out) {
         mvs_ctx_destroy(c);
         return fail(MVS_E_HIP, "hipEventCreate failed");
     }
-    if (hipMalloc((void**)&c->d_counter, 512) != hipSuccess) {   // 8 counter slots; +256 B: the filter's stop flag
+    // 8 counter slots; +256 B: the filter's stop flag; +1024 B: the re-check's eight round counters, 64 B apart
+    if (hipMalloc((void**)&c->d_counter, 2048) != hipSuccess) {
         mvs_ctx_destroy(c);
         return fail(MVS_E_HIP, "hipMalloc failed");
     }
@@ -1221,6 +1222,7 @@ int pairwise_launch(mvs_ctx* c, const mvs_sketch_set* s, const double* d_n2, int
         a.cand_counter = c->d_counter + 2;
         a.cand_limit = limit;
         a.cand_stop = reinterpret_cast<unsigned int*>(c->d_counter + 32);
+        a.recheck_queue = c->d_counter + 128;
         const int64_t n_regions = mvs::filter_region_count(a, c->opt);
         if (n_regions > 0) {
             rc = ensure_buf(c, &c->pw_chdr, &c->pw_chdr_bytes, (size_t)n_regions * 4);
@@ -1240,6 +1242,7 @@ int pairwise_launch(mvs_ctx* c, const mvs_sketch_set* s, const double* d_n2, int
                 rc = set_count();
                 if (rc) return rc;
             }
+            HIP_TRY(hipMemsetAsync(a.recheck_queue, 0, 512, c->stream));
             if (n_regions > 0) HIP_TRY(hipMemsetAsync(a.cand_hdr, 0, (size_t)n_regions * 4, c->stream));
             if (c->timing) HIP_TRY(hipEventRecord(c->ev[2], c->stream));
             rc = mvs::launch_filter(c->stream, a, c->opt);

@@ -111,6 +111,7 @@ struct PairwiseArgs {
                                      //    k_pairwise_pp {XCC / HW id, start, end, k-loop end, epilogue phases} on the
                                      //    100 MHz realtime clock; the library dumps them to /tmp/mvs_stamps.bin
                                      //    (tools/exp/stamps.py reads that)
+    unsigned long long* recheck_queue;   // 8 zeroed counters, 64 bytes apart: the re-check hands its rounds out per XCD
     unsigned int* cand_hdr;          // per (workgroup, wave) region of the ping-pong filter: number of candidates the wave
     int2* cand_ent;                  //    left in its kCandRegion entries (0: none, or it went to the list itself)
     unsigned int* cand_stop;         // set by the wave that takes the counter past the limit; lives on its own cache

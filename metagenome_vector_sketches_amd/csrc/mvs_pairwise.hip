@@ -1679,18 +1679,35 @@ __global__ __launch_bounds__(256) void k_exact_pairs_tree(const PairwiseArgs a) 
     if (n_cand > a.cand_limit) return;
     if (n_cand > a.cand_capacity) n_cand = a.cand_capacity;
     // Work split: the list is cut into chunks of 64 rounds (4096 pairs) and chunk c belongs to XCD label c % 8
-    // (blockIdx.x % 8: the workgroups that share an L2), whose waves stride over the rounds of its chunks.  A chunk keeps
-    // neighbours of the list -- pairs of the same tile, which share rows -- in one L2; dealing the chunks out round robin
-    // keeps the XCDs level whatever the order of the list (one contiguous eighth each did not: the pairs of the
-    // diagonal tiles' clusters are cheap L2 hits and sit together, chance pairs cost two rows from HBM each).
+    // (blockIdx.x % 8: the workgroups that share an L2).  A chunk keeps neighbours of the list -- pairs of the same tile,
+    // which share rows -- in one L2.  Within an XCD the rounds are handed out by a counter, not by a fixed stride: the
+    // pairs of the diagonal tiles' clusters are cheap L2 hits, a chance pair costs two rows from HBM, and where the list
+    // holds one kind after the other (the filter's waves leave their few chance candidates in regions that are
+    // gathered behind the others) a fixed assignment left the HBM-bound rounds to a fifth of the waves: 0.80 -> 1.07 ms.
+    // The next index is drawn before the current round is worked on, so the atomic's latency hides behind the loads.
     const unsigned long long rounds = (n_cand + 63) / 64;
     const unsigned long long xcd = blockIdx.x & 7;
+    const unsigned long long last = n_cand;
+    // Every wave's first round is its own index (no atomic: at 100k samples the grid holds more waves than there are
+    // rounds, and the hardware's block dispatch is the queue); only where an XCD has more rounds than waves do the waves
+    // come back to the counter for more (same-address atomics cost ~20 ns each: 2048 waves asking just to learn that
+    // nothing is left would be 40 us).
+    unsigned long long* queue = a.recheck_queue + xcd * 8;     // one counter per XCD, 64 bytes apart
     const unsigned long long waves = (unsigned long long)(gridDim.x >> 3) * 4;
     const unsigned long long wid = (unsigned long long)(blockIdx.x >> 3) * 4 + (threadIdx.x >> 6);
-    const unsigned long long last = n_cand;
-    for (unsigned long long i = wid;; i += waves) {            // i: index among this XCD's rounds
-        const unsigned long long round = ((i >> 6) * 8 + xcd) * 64 + (i & 63);
-        if (round >= rounds) break;                            // round grows with i (the stride is a multiple of 64)
+    const bool more = ((rounds + 63) / 64 + 7) / 8 * 64 > waves;      // some XCD may own more rounds than it has waves
+    auto round_of = [&](unsigned long long i) { return ((i >> 6) * 8 + xcd) * 64 + (i & 63); };
+    auto draw = [&]() -> unsigned long long {
+        if (!more) return ~0ULL;
+        unsigned long long i = 0;
+        if (lane == 0) i = atomicAdd(queue, 1ULL);
+        i = (unsigned long long)__shfl((long long)i, 0, 64);
+        return round_of(i + waves);
+    };
+    for (unsigned long long next = round_of(wid);;) {
+        const unsigned long long round = next;
+        if (round >= rounds) break;                            // the counter only grows: every later draw is beyond too
+        next = draw();
         const unsigned long long base = round * 64;
         const unsigned long long mine = base + lane;
         const bool have = mine < last;
@@ -2048,7 +2065,7 @@ int launch_exact_pairs(hipStream_t stream, const PairwiseArgs& a, const Options&
     // round, one shuffle butterfly per pair (10-15 % faster than 16 per round or a quarter wave per pair)
     const dim3 grid(256 * 16), block(256);
     if (opt.exact_variant == 3) {
-        hipLaunchKernelGGL(k_exact_pairs_tree, grid, block, 0, stream, a);
+        hipLaunchKernelGGL(k_exact_pairs_tree, dim3(256 * 24), block, 0, stream, a);
         return 0;
     }
     switch (opt.exact_variant) {

@@ -64,6 +64,30 @@ def test_sketch_db_files(toy_db, gold):
     assert lines[-1].startswith(gold.kat["sketch_stdout_last_prefix"] + ": ") and lines[-1].endswith(" seconds")
 
 
+@pytest.mark.parametrize("contexts", [2, 3, 61, 64])
+def test_sketch_on_several_contexts(toy_db, gold, tmp_path, contexts):
+    """one host thread and one device context per GPU, each projecting a contiguous range of samples with about the same
+    number of hashes (the reference's OpenMP loop over samples, src/project_everything.cpp:289-298).  On the one-GPU box
+    MVS_SKETCH_CONTEXTS puts the contexts on device 0; the toy set's sizes are very uneven (3 .. 80 772 hashes), so some
+    ranges are empty with many contexts.  Same files, same stdout order as with one context."""
+    d, db, stdout = toy_db
+    out = str(tmp_path / "db_multi")
+    env = dict(os.environ, MVS_SKETCH_CONTEXTS=str(contexts), MVS_STAGE_TIMING="1")
+    env.pop("MVS_DEVICE", None)
+    r = subprocess.run([os.path.join(BIN, "project_everything"), "sketch", str(d / "toy_hashes.txt"), out, "-d", "2048"],
+                       capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    assert "%d contexts, samples per context:" % contexts in r.stderr
+    for f in ("vectors.bin", "vector_norms.txt", "dimension.txt", "dtype.txt"):
+        assert open(os.path.join(out, f), "rb").read() == open(os.path.join(db, f), "rb").read(), f
+    assert [l for l in r.stdout.split("\n") if l.startswith("Projected")] == [l for l in stdout.split("\n") if l.startswith("Projected")]
+    # MVS_DEVICE pins the work to one context
+    r = subprocess.run([os.path.join(BIN, "project_everything"), "sketch", str(d / "toy_hashes.txt"), out, "-d", "2048"],
+                       capture_output=True, text=True, env=dict(env, MVS_DEVICE="0"))
+    assert r.returncode == 0 and "contexts, samples per context" not in r.stderr
+    assert open(os.path.join(out, "vectors.bin"), "rb").read() == open(os.path.join(db, "vectors.bin"), "rb").read()
+
+
 def test_sketch_int16_and_dimension(toy_db, gold, tmp_path):
     d, db, _ = toy_db
     r = run(os.path.join(BIN, "project_everything"), "sketch", str(d / "toy_hashes.txt"), str(tmp_path / "db16"),
