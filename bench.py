@@ -35,9 +35,10 @@ INT8_MFMA_PEAK_TOPS = 5000.0   # dense int8 MFMA = 2x bf16 = ~5 POP/s
 FP64_MATRIX_PEAK_TFLOPS = 78.6  # nominal fp64 matrix peak of the part (datasheet figure, not measured here)
 VALU_INT_PEAK_TOPS = 78.6      # 256 CU x 4 SIMD-32 x 32 lanes x 2.4 GHz int32 lane-ops/s (MI355X_MICROARCH.md)
 VALU_ISSUE_PEAK_GIPS = 1228.8  # wave64 VALU instructions/s: 1024 SIMDs x 2.4 GHz / 2 cycles per instruction
-K1_VALU_PER_HASH_BLOCK = 22.4  # VALU instructions per (hash, 64-dim block) and lane in k_project (four blocks per wave
-                               # sharing the first splitmix64 round): SQ_INSTS_VALU of the PMC pass,
-                               # profiles/r02_c1_pmc_summary.txt: 5.596e9 per launch = 22.4 x 1.6e10 / 64 (22.9 in round 1)
+K1_VALU_PER_HASH_BLOCK = 22.4  # fallback only: VALU instructions per (hash, 64-dim block) and lane in k_project as counted in
+                               # round 2 (SQ_INSTS_VALU 5.596e9 per launch = 22.4 x 1.6e10 / 64).  The figure reported is
+                               # read from the newest profiles/rNN_pmc_traffic.json while its kernel_source_sha matches the
+                               # sources this run was built from (k1_valu_per_hash_block()).
 
 
 def source_sha():
@@ -52,16 +53,32 @@ def source_sha():
     return h.hexdigest()[:16]
 
 
+def pmc_file():
+    """the newest profiles/rNN_pmc_traffic.json (by round number) -> (relative path, parsed) or (None, None)"""
+    import glob
+    import re
+    best = None
+    for path in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")):
+        m = re.match(r"r(\d+)_pmc_traffic\.json$", os.path.basename(path))
+        if m and (best is None or int(m.group(1)) > best[0]):
+            best = (int(m.group(1)), path)
+    if best is None:
+        return None, None
+    try:
+        with open(best[1]) as f:
+            return "profiles/" + os.path.basename(best[1]), json.load(f)
+    except Exception:   # noqa: BLE001
+        return None, None
+
+
 def pmc_traffic(workload_key):
     """HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (rocprofv3 cannot run inside this
     process) -> ({kernel: bytes}, provenance).  Dropped (None) unless the file was collected on this workload AND on
     these kernel sources."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    name, pmc = pmc_file()
     try:
-        with open(path) as f:
-            pmc = json.load(f)
         ent = pmc["workloads"][workload_key]
-        prov = {"file": "profiles/r02_pmc_traffic.json", "kernel_source_sha": pmc.get("kernel_source_sha"),
+        prov = {"file": name, "kernel_source_sha": pmc.get("kernel_source_sha"),
                 "collected": pmc.get("collected"), "command": ent.get("command")}
         if pmc.get("kernel_source_sha") != source_sha():
             prov["dropped"] = "kernel sources changed since the counters were collected (now %s)" % source_sha()
@@ -69,6 +86,20 @@ def pmc_traffic(workload_key):
         return {k: v["hbm_bytes_per_launch_corrected"] for k, v in ent["kernels"].items()}, prov
     except Exception as e:   # no file yet / other workload
         return {}, {"file": None, "dropped": "no PMC pass for this workload (%s)" % type(e).__name__}
+
+
+def k1_valu_per_hash_block(total_hashes, blocks):
+    """VALU instructions per (hash, 64-dim block) and lane of k_project = SQ_INSTS_VALU per launch of the configs[1] PMC
+    pass / (hashes x blocks / 64 lanes) -> (value, provenance).  Taken from the counter file only while it was collected
+    on these kernel sources; otherwise the round-2 constant, and the provenance says so."""
+    name, pmc = pmc_file()
+    try:
+        if pmc.get("kernel_source_sha") != source_sha():
+            return K1_VALU_PER_HASH_BLOCK, "round-2 constant (kernel sources changed since %s was collected)" % name
+        v = pmc["workloads"]["configs[1]"]["kernels"]["k_project"]["SQ_INSTS_VALU_per_launch"]
+        return v / (total_hashes * blocks / 64.0), "%s: SQ_INSTS_VALU %.4g per launch" % (name, v)
+    except Exception as e:   # noqa: BLE001
+        return K1_VALU_PER_HASH_BLOCK, "round-2 constant (no counter file: %s)" % type(e).__name__
 
 
 def fast_norm_sq(sumsq, d):
@@ -360,7 +391,11 @@ def main():
     k2_flops = 2.0 * D * S * N_total         # this rank's rows x all columns
     default_workload = (S, NH, D, world, args.cluster, args.lognormal_sigma) == (10_000, 50_000, 2048, 1, 16, 0.0)
     traffic, traffic_src = pmc_traffic("configs[1]") if default_workload else ({}, {"file": None, "dropped": "non-default workload"})
-    k1_valu_instr = total_hashes * ((D + 63) // 64) / 64.0 * K1_VALU_PER_HASH_BLOCK     # wave64 VALU instructions per launch
+    if default_workload:
+        k1_vphb, k1_vphb_src = k1_valu_per_hash_block(total_hashes, (D + 63) // 64)
+    else:
+        k1_vphb, k1_vphb_src = K1_VALU_PER_HASH_BLOCK, "round-2 constant (non-default workload)"
+    k1_valu_instr = total_hashes * ((D + 63) // 64) / 64.0 * k1_vphb     # wave64 VALU instructions per launch
     res = {
         "metric": "samples projected/sec + pairwise Jaccard cells/sec, d=2048, 1/2/4/8 GPUs",
         "value": samples_per_s,
@@ -403,9 +438,10 @@ def main():
                                 "unit": "G wave64 VALU instructions/s",
                                 "frac": k1_valu_instr / (k1 * 1e-3) / 1e9 / VALU_ISSUE_PEAK_GIPS,
                                 "instructions_per_launch": k1_valu_instr,
+                                "instructions_per_hash_block": k1_vphb, "instructions_source": k1_vphb_src,
                                 "note": "%.1f VALU instructions per (hash, 64-dim block) x 2 cycles each on a SIMD-32 "
                                         "at 2.4 GHz nominal; the hash's 64-bit multiplies and shifts issue at 4 cycles, "
-                                        "which is what keeps this fraction near one half" % K1_VALU_PER_HASH_BLOCK,
+                                        "which is what keeps this fraction near one half" % k1_vphb,
                                 # NOT a roofline fraction: bit-slicing does 64 sign-accumulations in ~4.4 instructions
                                 "sign_accumulations_per_s_T": k1_intops / (k1 * 1e-3) / 1e12,
                                 "int32_lane_op_peak_T": VALU_INT_PEAK_TOPS},

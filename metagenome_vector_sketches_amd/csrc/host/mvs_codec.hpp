@@ -74,6 +74,14 @@ public:
         It it = begin;
         for (uint64_t i = 0; i < n; ++i, ++it) set(i, (uint64_t)*it);
     }
+    // for a producer that computes its values on the fly: prepare(n, width), then put(i, v) for every i exactly once
+    void prepare(uint64_t n, uint64_t width) {
+        if (width == 0 || width > 64) throw std::invalid_argument("compact_vector: width");
+        m_size = n;
+        m_width = width;
+        m_data.assign((n * width + 63) / 64, 0);
+    }
+    void put(uint64_t i, uint64_t v) { set(i, v); }
     uint64_t size() const { return m_size; }
     uint64_t width() const { return m_width; }
     uint64_t access(uint64_t i) const {
@@ -114,31 +122,32 @@ public:
     void encode(It begin, uint64_t n) {
         m_size = n;
         // k = floor(log2(mean)): the classic choice, within half a bit of optimal for geometric data
-        long double sum = 0;
+        unsigned __int128 sum = 0;                            // exact (the mean's floor is what fixes k)
         It it = begin;
-        for (uint64_t i = 0; i < n; ++i, ++it) sum += (long double)(uint64_t)*it;
-        const uint64_t mean = n ? (uint64_t)(sum / (long double)n) : 0;
+        for (uint64_t i = 0; i < n; ++i, ++it) sum += (uint64_t)*it;
+        const uint64_t mean = n ? (uint64_t)(sum / n) : 0;
         m_k = mean > 1 ? bit_width(mean) - 1 : 0;
         if (m_k > 48) m_k = 48;
-        std::vector<uint64_t> lows;
-        lows.reserve(n);
-        m_high.clear();
+        // the unary part holds sum(v >> k) zeros and n terminators: sized once, the low bits go straight into their vector
+        uint64_t high_bits = n;
+        it = begin;
+        for (uint64_t i = 0; i < n; ++i, ++it) high_bits += m_k ? ((uint64_t)*it >> m_k) : (uint64_t)*it;
+        m_high.assign((high_bits + 63) / 64, 0);
         m_samples.clear();
+        m_samples.reserve((n + 63) / 64);
+        if (m_k) m_low.prepare(n, m_k);
+        const uint64_t low_mask = m_k ? ((1ULL << m_k) - 1) : 0;
         uint64_t bitpos = 0;
         it = begin;
         for (uint64_t i = 0; i < n; ++i, ++it) {
             const uint64_t v = (uint64_t)*it;
             if ((i & 63) == 0) m_samples.push_back(bitpos);
-            const uint64_t q = m_k ? (v >> m_k) : v;
-            lows.push_back(m_k ? (v & ((1ULL << m_k) - 1)) : 0);
-            bitpos += q;                          // q zeros
-            const uint64_t w = bitpos >> 6;
-            if (m_high.size() <= w) m_high.resize(w + 1, 0);
-            m_high[w] |= 1ULL << (bitpos & 63);   // terminator
+            bitpos += m_k ? (v >> m_k) : v;                   // q zeros
+            m_high[bitpos >> 6] |= 1ULL << (bitpos & 63);     // terminator
             ++bitpos;
+            if (m_k) m_low.put(i, v & low_mask);
         }
         m_high_bits = bitpos;
-        if (m_k) m_low.build(lows.begin(), n, m_k);
     }
     uint64_t size() const { return m_size; }
     uint64_t access(uint64_t i) const {

@@ -53,8 +53,8 @@ struct mvs_ctx {
     void* st_counts = nullptr;  size_t st_counts_bytes = 0;
     void* st_dense = nullptr;   size_t st_dense_bytes = 0;  // dense results: one byte per cell (mvs_internal.h)
     hipStream_t dl_stream = nullptr;
-    void* dl_pinned[2] = {nullptr, nullptr};
-    size_t dl_bytes = 0;
+    void* dl_pinned[2] = {nullptr, nullptr};      // pinned host buffers, each allocated (and grown) when first needed:
+    size_t dl_bytes[2] = {0, 0};                  // pinning costs ~0.3 ms per MiB, a one-piece result needs only one
     hipEvent_t dl_done[2] = {nullptr, nullptr};   // download into pinned buffer i has completed
     hipEvent_t dl_block[2] = {nullptr, nullptr};  // the downloads out of CSR array set i have completed
     hipEvent_t dl_ready = nullptr;                // the CSR arrays of a row block are final on the compute stream
@@ -235,6 +235,8 @@ const OptionSpec kOptions[] = {
     {"pairwise_map", &mvs::Options::pairwise_map, nullptr, 0, 2},
     {"coarse_radix", &mvs::Options::coarse_radix, nullptr, 0, 1},
     {"cand_regions", &mvs::Options::cand_regions, nullptr, 0, 1},
+    {"recheck_mode", &mvs::Options::recheck_mode, nullptr, 0, 3},
+    {"recheck_blocks", &mvs::Options::recheck_blocks, nullptr, 1, 64},
     {"stream_dense", &mvs::Options::stream_dense, nullptr, 0, 1},
     {"stream_block_rows", &mvs::Options::stream_block_rows, nullptr, 0, 1 << 30},
     {"pairwise_block_cells", nullptr, &mvs::Options::pairwise_block_cells, 1, (1LL << 62)},
@@ -1223,6 +1225,7 @@ int pairwise_launch(mvs_ctx* c, const mvs_sketch_set* s, const double* d_n2, int
         a.cand_limit = limit;
         a.cand_stop = reinterpret_cast<unsigned int*>(c->d_counter + 32);
         a.recheck_queue = c->d_counter + 128;
+        a.recheck_mode = c->opt.recheck_mode;
         const int64_t n_regions = mvs::filter_region_count(a, c->opt);
         if (n_regions > 0) {
             rc = ensure_buf(c, &c->pw_chdr, &c->pw_chdr_bytes, (size_t)n_regions * 4);
@@ -1514,7 +1517,7 @@ struct StreamOut {
     ~StreamOut() { close(); }
 };
 
-int ensure_download_side(mvs_ctx* c, size_t bytes) {
+int ensure_download_side(mvs_ctx* c) {
     if (!c->dl_stream) {
         HIP_TRY(hipStreamCreateWithFlags(&c->dl_stream, hipStreamNonBlocking));
         for (int i = 0; i < 2; ++i) {
@@ -1523,15 +1526,17 @@ int ensure_download_side(mvs_ctx* c, size_t bytes) {
         }
         HIP_TRY(hipEventCreateWithFlags(&c->dl_ready, hipEventDisableTiming));
     }
-    if (c->dl_bytes >= bytes) return MVS_OK;
-    HIP_TRY(hipStreamSynchronize(c->dl_stream));
-    for (int i = 0; i < 2; ++i) {
-        if (c->dl_pinned[i]) HIP_TRY(hipHostFree(c->dl_pinned[i]));
-        c->dl_pinned[i] = nullptr;
-    }
-    c->dl_bytes = 0;
-    for (int i = 0; i < 2; ++i) HIP_TRY(hipHostMalloc(&c->dl_pinned[i], bytes, hipHostMallocDefault));
-    c->dl_bytes = bytes;
+    return MVS_OK;
+}
+
+// pinned buffer `slot` holds at least `bytes`; called by the producer while it owns the slot (nobody reads it)
+int ensure_pinned_slot(mvs_ctx* c, int slot, size_t bytes) {
+    if (c->dl_bytes[slot] >= bytes) return MVS_OK;
+    if (c->dl_pinned[slot]) HIP_TRY(hipHostFree(c->dl_pinned[slot]));
+    c->dl_pinned[slot] = nullptr;
+    c->dl_bytes[slot] = 0;
+    HIP_TRY(hipHostMalloc(&c->dl_pinned[slot], bytes, hipHostMallocDefault));
+    c->dl_bytes[slot] = bytes;
     return MVS_OK;
 }
 
@@ -1667,19 +1672,12 @@ int feed_block(mvs_ctx* c, StreamOut& out, const BlockCsr& b, size_t piece_bytes
         }
         return r1;
     };
-    // the pinned buffers must hold the block's largest piece: they are only ever replaced while both are idle
-    size_t need_bytes = std::min<size_t>(piece_bytes, std::max<size_t>((size_t)n * cell_bytes, 1u << 20));
+    // a pinned buffer is sized for the block's largest piece when the producer takes it (it is idle then)
+    size_t need_bytes = std::min<size_t>(piece_bytes, std::max<size_t>((size_t)n * cell_bytes, 1u << 16));
     for (int64_t r0 = 0; r0 < rows;) {
         const int64_t r1 = piece_end(r0);
         need_bytes = std::max(need_bytes, (size_t)(row_ptr[(size_t)r1] - row_ptr[(size_t)r0]) * cell_bytes);
         r0 = r1;
-    }
-    if (c->dl_bytes < need_bytes) {
-        const int a0 = out.acquire_slot(), a1 = out.acquire_slot();       // both: every earlier piece has been consumed
-        rc = ensure_download_side(c, need_bytes);
-        out.release_slot(a0);
-        out.release_slot(a1);
-        if (rc) return rc;
     }
     for (int64_t r0 = 0; r0 < rows;) {
         const int64_t r1 = piece_end(r0);
@@ -1687,6 +1685,11 @@ int feed_block(mvs_ctx* c, StreamOut& out, const BlockCsr& b, size_t piece_bytes
         const int64_t cells = row_ptr[(size_t)r1] - c0;
         if (out.failed()) return MVS_OK;                        // the caller reports the callback's status
         const int sl = out.acquire_slot();
+        rc = ensure_pinned_slot(c, sl, need_bytes);
+        if (rc) {
+            out.release_slot(sl);
+            return rc;
+        }
         StreamOut::Item it;
         it.slot = sl;
         it.row_begin = b.rb + r0;
@@ -1762,7 +1765,7 @@ int mvs_pairwise_stream(mvs_ctx* c, const mvs_sketch_set* s, const double* norms
     const size_t piece_bytes = 32u << 20;                       // pinned buffer size: pinning costs ~0.3 ms per MiB
     const int col_bits = bits_for(std::max<int64_t>(s->n - 1, 1));
     const int shift = 16 + col_bits;
-    int rc = ensure_download_side(c, 1u << 20);
+    int rc = ensure_download_side(c);
     if (rc) return rc;
     c->st_kernel_ms = 0.0;
     c->st_bytes = c->st_blocks = c->st_pieces = c->st_two_stage = 0;

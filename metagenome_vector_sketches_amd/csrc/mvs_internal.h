@@ -51,6 +51,8 @@ struct Options {
     int coarse_radix = 1;           // radix of the filter's coarse plane: 1 = smallest residual (default), 0 = ceil(max|v| / 127)
     int stream_dense = 1;           // mvs_pairwise_stream, exact kernel: 1 = dense byte matrix + count / scan / fill, 0 = packed list + sort
     int stream_block_rows = 0;      // > 0: upper bound on the rows of a dense row block (tests); 0 = by the budget
+    int recheck_mode = 1;           // re-check work split: 1 first round fixed + per-XCD counter, 2 counter only, 0 fixed stride, 3 eighths
+    int recheck_blocks = 24;        // re-check grid in units of 256 workgroups (24: one round per wave at 100k samples)
     int cand_regions = 1;           // 1: filter waves leave up to 8 candidates in a region of their own (no atomic to wait for)
     int comm_timeout_s = 600;       // file transport: how long a rank waits for a peer's block before it gives up
     double pairwise_block_cells = 1099511627776.0;   // row-chunk bound of mvs_pairwise_rows (2^40 cells)
@@ -111,6 +113,7 @@ struct PairwiseArgs {
                                      //    k_pairwise_pp {XCC / HW id, start, end, k-loop end, epilogue phases} on the
                                      //    100 MHz realtime clock; the library dumps them to /tmp/mvs_stamps.bin
                                      //    (tools/exp/stamps.py reads that)
+    int recheck_mode;                    // work split of k_exact_pairs_tree (see there)
     unsigned long long* recheck_queue;   // 8 zeroed counters, 64 bytes apart: the re-check hands its rounds out per XCD
     unsigned int* cand_hdr;          // per (workgroup, wave) region of the ping-pong filter: number of candidates the wave
     int2* cand_ent;                  //    left in its kCandRegion entries (0: none, or it went to the list itself)

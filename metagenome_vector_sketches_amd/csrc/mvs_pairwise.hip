@@ -1655,11 +1655,59 @@ struct PairDots {
         }
         return (uint32_t)acc0 + ((uint32_t)acc1 << 8) + ((uint32_t)acc2 << 16);
     }
+    // Four consecutive pairs at once: ONE loop over k that loads all four pairs' limb rows before any of them is
+    // consumed -- 16 loads of 16 bytes in flight per lane, written out so that it does not depend on how the compiler
+    // feels about interleaving four copies of partial() (it did in round 2, 132 registers, and stopped doing so after an
+    // unrelated edit of the caller's loop: 70 registers, the pairs one after the other, 0.80 -> 1.00 ms on 1.26 M pairs).
+    // Returns the level-2 node of the tree (the four partial dots merged with three exchanges).  Pairs beyond the
+    // round's count read rows 0 / 0 (their lanes' pr is zero): harmless, their results are never used.
+    __device__ __forceinline__ uint32_t quad() {
+        const int q0 = next;
+        next += 4;
+        if (q0 >= cnt) return 0u;                             // wave-uniform
+        const int64_t stride = 2 * (int64_t)a.d_pad;
+        const int8_t* ri[4];
+        const int8_t* rj[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int row = __shfl(pr.x, q0 + p, 64), col = __shfl(pr.y, q0 + p, 64) & 0x7fffffff;
+            ri[p] = a.planes + (int64_t)row * stride;
+            rj[p] = a.planes + (int64_t)col * stride;
+        }
+        int acc0[4] = {0, 0, 0, 0}, acc1[4] = {0, 0, 0, 0}, acc2[4] = {0, 0, 0, 0};
+        for (int k = lane * 16; k < a.d_pad; k += 1024) {
+            v4i li[4], hi[4], lj[4], hj[4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                li[p] = *reinterpret_cast<const v4i*>(ri[p] + k);
+                hi[p] = *reinterpret_cast<const v4i*>(ri[p] + a.d_pad + k);
+                lj[p] = *reinterpret_cast<const v4i*>(rj[p] + k);
+                hj[p] = *reinterpret_cast<const v4i*>(rj[p] + a.d_pad + k);
+            }
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc0[p] = __builtin_amdgcn_sdot4(li[p][e], lj[p][e], acc0[p], false);
+                    acc1[p] = __builtin_amdgcn_sdot4(li[p][e], hj[p][e], acc1[p], false);
+                    acc1[p] = __builtin_amdgcn_sdot4(hi[p][e], lj[p][e], acc1[p], false);
+                    acc2[p] = __builtin_amdgcn_sdot4(hi[p][e], hj[p][e], acc2[p], false);
+                }
+        }
+        uint32_t part[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) part[p] = (uint32_t)acc0[p] + ((uint32_t)acc1[p] << 8) + ((uint32_t)acc2[p] << 16);
+        const bool up0 = lane & 1, up1 = (lane >> 1) & 1;
+        const uint32_t m01 = (up0 ? part[1] : part[0]) + (uint32_t)__shfl_xor((int)(up0 ? part[0] : part[1]), 1, 64);
+        const uint32_t m23 = (up0 ? part[3] : part[2]) + (uint32_t)__shfl_xor((int)(up0 ? part[2] : part[3]), 1, 64);
+        return (up1 ? m23 : m01) + (uint32_t)__shfl_xor((int)(up1 ? m01 : m23), 2, 64);
+    }
     template <int LEVEL>
     __device__ __forceinline__ uint32_t tree() {              // sums of 2^LEVEL consecutive pairs, spread over the lanes
-        if constexpr (LEVEL == 0) {
-            return partial();
+        if constexpr (LEVEL == 2) {
+            return quad();
         } else {
+            static_assert(LEVEL > 2, "the tree's leaves are quads");
             if (next >= cnt) {                                // nothing left in this subtree (wave-uniform)
                 next += 1 << LEVEL;
                 return 0u;
@@ -1673,6 +1721,7 @@ struct PairDots {
     }
 };
 
+template <int RMODE>
 __global__ __launch_bounds__(256) void k_exact_pairs_tree(const PairwiseArgs a) {
     const int lane = threadIdx.x & 63;
     unsigned long long n_cand = *a.cand_counter;
@@ -1688,25 +1737,35 @@ __global__ __launch_bounds__(256) void k_exact_pairs_tree(const PairwiseArgs a) 
     const unsigned long long rounds = (n_cand + 63) / 64;
     const unsigned long long xcd = blockIdx.x & 7;
     const unsigned long long last = n_cand;
-    // Every wave's first round is its own index (no atomic: at 100k samples the grid holds more waves than there are
-    // rounds, and the hardware's block dispatch is the queue); only where an XCD has more rounds than waves do the waves
-    // come back to the counter for more (same-address atomics cost ~20 ns each: 2048 waves asking just to learn that
-    // nothing is left would be 40 us).
+    // recheck_mode 1 (default): every wave's first round is its own index, later rounds come from the XCD's counter (same-
+    // address atomics cost ~20 ns each, so a wave does not ask just to learn that nothing is left when the grid already
+    // covers every round); 2: every round from the counter; 0: fixed stride over the XCD's rounds; 3: one contiguous eighth
+    // of the list per XCD, fixed stride (round 2's split).
     unsigned long long* queue = a.recheck_queue + xcd * 8;     // one counter per XCD, 64 bytes apart
     const unsigned long long waves = (unsigned long long)(gridDim.x >> 3) * 4;
     const unsigned long long wid = (unsigned long long)(blockIdx.x >> 3) * 4 + (threadIdx.x >> 6);
-    const bool more = ((rounds + 63) / 64 + 7) / 8 * 64 > waves;      // some XCD may own more rounds than it has waves
-    auto round_of = [&](unsigned long long i) { return ((i >> 6) * 8 + xcd) * 64 + (i & 63); };
+    constexpr int mode = RMODE;
+    const unsigned long long per_xcd = (rounds + 7) / 8;      // mode 3
+    const bool more = mode == 2 || (mode == 1 && ((rounds + 63) / 64 + 7) / 8 * 64 > waves);
+    auto round_of = [&](unsigned long long i) -> unsigned long long {
+        if (mode == 3) return i < per_xcd ? xcd * per_xcd + i : ~0ULL;
+        return ((i >> 6) * 8 + xcd) * 64 + (i & 63);
+    };
+    unsigned long long fixed = wid;                             // modes 0 / 3: the wave's next index
     auto draw = [&]() -> unsigned long long {
+        if (mode == 0 || mode == 3) {
+            fixed += waves;
+            return round_of(fixed);
+        }
         if (!more) return ~0ULL;
         unsigned long long i = 0;
         if (lane == 0) i = atomicAdd(queue, 1ULL);
         i = (unsigned long long)__shfl((long long)i, 0, 64);
-        return round_of(i + waves);
+        return round_of(i + (mode == 1 ? waves : 0ULL));
     };
-    for (unsigned long long next = round_of(wid);;) {
+    for (unsigned long long next = mode == 2 ? draw() : round_of(wid);;) {
         const unsigned long long round = next;
-        if (round >= rounds) break;                            // the counter only grows: every later draw is beyond too
+        if (round >= rounds) break;                            // indices only grow: every later one is beyond too
         next = draw();
         const unsigned long long base = round * 64;
         const unsigned long long mine = base + lane;
@@ -2065,7 +2124,13 @@ int launch_exact_pairs(hipStream_t stream, const PairwiseArgs& a, const Options&
     // round, one shuffle butterfly per pair (10-15 % faster than 16 per round or a quarter wave per pair)
     const dim3 grid(256 * 16), block(256);
     if (opt.exact_variant == 3) {
-        hipLaunchKernelGGL(k_exact_pairs_tree, dim3(256 * 24), block, 0, stream, a);
+        const dim3 g(256u * (unsigned)(opt.recheck_blocks > 0 ? opt.recheck_blocks : 16));
+        switch (opt.recheck_mode) {
+            case 0: hipLaunchKernelGGL(k_exact_pairs_tree<0>, g, block, 0, stream, a); break;
+            case 2: hipLaunchKernelGGL(k_exact_pairs_tree<2>, g, block, 0, stream, a); break;
+            case 3: hipLaunchKernelGGL(k_exact_pairs_tree<3>, g, block, 0, stream, a); break;
+            default: hipLaunchKernelGGL(k_exact_pairs_tree<1>, g, block, 0, stream, a); break;
+        }
         return 0;
     }
     switch (opt.exact_variant) {

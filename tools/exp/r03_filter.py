@@ -60,6 +60,12 @@ quick = os.environ.get("R03_QUICK") == "1"
 for rnd in range(2):                       # twice: the order effect of a warming chip is visible
     run("real", "sketches cand_regions=0 (atomic per wave)", sset, n2, cand_regions=0)
     run("real", "sketches cand_regions=1 (default)", sset, n2, cand_regions=1)
+    if os.environ.get("R03_RECHECK") == "1":
+        for reg in (1, 0):
+            for mode in (0, 1, 2, 3):
+                for blocks in (8, 16, 24, 32):
+                    run("real", "regions=%d recheck_mode=%d blocks=%d" % (reg, mode, blocks), sset, n2, cand_regions=reg,
+                        recheck_mode=mode, recheck_blocks=blocks)
     if quick:
         continue
     for fv in (8, 40, 41, 42):

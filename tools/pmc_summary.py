@@ -92,6 +92,9 @@ def main():
                 if c in ("FETCH_SIZE", "WRITE_SIZE") and k.startswith("k_"):
                     kernels.setdefault(k, {})[c + "_KiB_raw"] = sum(v) / len(v)
                     kernels[k]["launches_" + c] = len(v)
+            for (k, c), v in agg.items():        # instruction / conflict counts bench.py and the docs quote, same passes
+                if c in ("SQ_INSTS_VALU", "SQ_INSTS_VALU_MFMA_I8", "SQ_LDS_BANK_CONFLICT", "SQ_INSTS_LDS") and k in kernels:
+                    kernels[k][c + "_per_launch"] = sum(v) / len(v)
             for k, e in kernels.items():
                 e["hbm_bytes_per_launch_corrected"] = 2048.0 * e.get("FETCH_SIZE_KiB_raw", 0.0) + 1024.0 * e.get("WRITE_SIZE_KiB_raw", 0.0)
             out["workloads"][key] = {"command": cmd, "kernels": kernels}
