@@ -17,6 +17,8 @@
 #include <iterator>
 #include <sstream>
 #include <string>
+#include <condition_variable>
+#include <deque>
 #include <exception>
 #include <mutex>
 #include <thread>
@@ -506,7 +508,26 @@ public:
         if (!fs::exists(folder_)) fs::create_directories(folder_);
         bin_out_.open(folder_ + "matrix.bin", std::ios::binary);
         if (threads_ == 0) threads_ = std::max(1u, std::thread::hardware_concurrency());
+        // matrix.bin is written by a thread of its own: the encoded rows of a piece go to the file while the next piece
+        // is being encoded (at most a few pieces wait in the queue)
+        file_thread_ = std::thread([this] {
+            for (;;) {
+                std::string bytes;
+                {
+                    std::unique_lock<std::mutex> lk(mu_);
+                    cv_.wait(lk, [this] { return closing_ || !pending_.empty(); });
+                    if (pending_.empty()) return;
+                    bytes = std::move(pending_.front());
+                    pending_.pop_front();
+                }
+                cv_.notify_all();
+                bin_out_.write(bytes.data(), (std::streamsize)bytes.size());
+            }
+        });
     }
+    ShardWriter(const ShardWriter&) = delete;
+    ShardWriter& operator=(const ShardWriter&) = delete;
+    ~ShardWriter() { stop_file_thread(); }
 
     void add(const mvs_row_block& b) {
         const int64_t rows = b.row_end - b.row_begin;
@@ -522,8 +543,22 @@ public:
         row_vec_.resize(first + n_rows);
         start_neighbor_.resize(first + n_rows);
         curr_pos_vec_.resize(first + n_rows);
-        unsigned threads = (unsigned)std::min<size_t>(threads_, std::max<size_t>(1, n_rows / 4096));
-        threads = std::max(1u, threads);
+        // encoder threads by the piece's CELLS (a dense piece is a few hundred rows of ten thousand cells each), every
+        // thread a contiguous run of rows holding about the same number of cells
+        unsigned threads = (unsigned)std::min<size_t>(threads_, std::max<size_t>(1, (size_t)b.n_cells / 32768));
+        threads = (unsigned)std::min<size_t>(std::max(1u, threads), n_rows);
+        std::vector<size_t> cut(threads + 1, n_rows);
+        cut[0] = 0;
+        for (unsigned t = 1; t < threads; ++t) {
+            const int64_t target = b.n_cells / threads * t;
+            size_t lo = cut[t - 1], hi = n_rows;
+            while (lo < hi) {                                       // first live row whose first cell is at or past the target
+                const size_t mid = (lo + hi) / 2;
+                if (b.row_ptr[live[mid]] < target) lo = mid + 1;
+                else hi = mid;
+            }
+            cut[t] = lo;
+        }
         struct Part {
             std::string bytes;
             uint64_t jac_space = 0, ngh_space = 0;
@@ -533,7 +568,7 @@ public:
         auto encode_part = [&](unsigned t) {
             Part& part = parts[t];
             std::ostringstream os(std::ios::binary);
-            const size_t r0 = n_rows * t / threads, r1 = n_rows * (t + 1) / threads;
+            const size_t r0 = cut[t], r1 = cut[t + 1];
             std::vector<uint16_t> jac;
             std::vector<uint64_t> delta;
             for (size_t r = r0; r < r1; ++r) {
@@ -584,10 +619,15 @@ public:
         }
         for (unsigned t = 0; t < threads; ++t) {
             if (!parts[t].error.empty()) throw std::runtime_error(parts[t].error);
-            const size_t r0 = n_rows * t / threads, r1 = n_rows * (t + 1) / threads;
+            const size_t r0 = cut[t], r1 = cut[t + 1];
             for (size_t r = r0; r < r1; ++r) curr_pos_vec_[first + r] += pos_;
-            bin_out_.write(parts[t].bytes.data(), (std::streamsize)parts[t].bytes.size());
             pos_ += parts[t].bytes.size();
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [this] { return pending_.size() < 64; });
+                pending_.push_back(std::move(parts[t].bytes));
+            }
+            cv_.notify_all();
             stats_.jac_space += parts[t].jac_space;
             stats_.ngh_space += parts[t].ngh_space;
         }
@@ -596,6 +636,7 @@ public:
     uint64_t cells() const { return cells_; }
 
     ShardStats finish() {
+        stop_file_thread();
         bin_out_.close();
         std::ofstream index_out(folder_ + "row_index.bin", std::ios::binary);
         stats_.rows = row_vec_.size();
@@ -617,9 +658,22 @@ public:
     }
 
 private:
+    void stop_file_thread() {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            closing_ = true;
+        }
+        cv_.notify_all();
+        if (file_thread_.joinable()) file_thread_.join();
+    }
     std::string folder_;
     unsigned threads_;
     std::ofstream bin_out_;
+    std::thread file_thread_;
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::deque<std::string> pending_;
+    bool closing_ = false;
     uint64_t pos_ = 0, cells_ = 0;
     int64_t next_row_ = 0;
     std::vector<uint32_t> row_vec_, start_neighbor_;
