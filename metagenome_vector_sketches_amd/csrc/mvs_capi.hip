@@ -1723,9 +1723,28 @@ int feed_block(mvs_ctx* c, StreamOut& out, const BlockCsr& b, size_t piece_bytes
 
 }  // namespace
 
+namespace {
+int pairwise_stream_impl(mvs_ctx* c, const mvs_sketch_set* s, const double* norms_sq, int mem_norms, int keep_mode,
+                         int64_t row_begin, int64_t row_end, size_t device_budget_bytes, mvs_row_block_cb cb, void* user,
+                         int64_t* n_cells);
+}
+
 int mvs_pairwise_stream(mvs_ctx* c, const mvs_sketch_set* s, const double* norms_sq, int mem_norms, int keep_mode,
                         int64_t row_begin, int64_t row_end, size_t device_budget_bytes, mvs_row_block_cb cb, void* user,
                         int64_t* n_cells) {
+    try {       // the host side keeps per-row directories in std::vector: no exception may cross the C boundary
+        return pairwise_stream_impl(c, s, norms_sq, mem_norms, keep_mode, row_begin, row_end, device_budget_bytes, cb, user, n_cells);
+    } catch (const std::bad_alloc&) {
+        return fail(MVS_E_NOMEM, "out of host memory while streaming the comparison result");
+    } catch (const std::exception& e) {
+        return fail(MVS_E_HIP, "mvs_pairwise_stream: %s", e.what());
+    }
+}
+
+namespace {
+int pairwise_stream_impl(mvs_ctx* c, const mvs_sketch_set* s, const double* norms_sq, int mem_norms, int keep_mode,
+                         int64_t row_begin, int64_t row_end, size_t device_budget_bytes, mvs_row_block_cb cb, void* user,
+                         int64_t* n_cells) {
     if (!c || !s || !cb) return fail(MVS_E_INVALID, "NULL argument");
     const Range range(c, "mvs_pairwise_stream");
     if (n_cells) *n_cells = 0;
@@ -1941,6 +1960,7 @@ int mvs_pairwise_stream(mvs_ctx* c, const mvs_sketch_set* s, const double* norms
     }
     return finish(MVS_OK);
 }
+}  // namespace
 
 int mvs_ctx_stream_stats(const mvs_ctx* c, double* kernel_ms, int64_t* bytes_out, int64_t* row_blocks, int64_t* pieces,
                          int* two_stage) {
