@@ -176,7 +176,7 @@ int ensure_buf(mvs_ctx* c, void** p, size_t* have, size_t bytes) {
         *p = nullptr;
         *have = 0;
     }
-    const size_t want = bytes + bytes / 4 + 4096;   // head room: avoid regrowing on small changes
+    const size_t want = bytes + std::min<size_t>(bytes / 4, (size_t)256 << 20) + 4096;   // head room: avoid regrowing on small changes
     if (hipMalloc(p, want) != hipSuccess) return fail(MVS_E_NOMEM, "hipMalloc of %zu bytes failed", want);
     *have = want;
     return MVS_OK;

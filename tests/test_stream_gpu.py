@@ -176,3 +176,34 @@ def test_stream_100k_two_stage_matches_cell_list(ctx):
     assert n_s == cnt and cnt >= 16 * n
     got = _triples(row_ptr, col, q)
     assert np.array_equal(got, cells[:, [0, 1, 3]].astype(np.int64))
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_stream_random_shapes(ctx, seed):
+    """random sizes, dimensions that are not multiples of the tile edges, cluster sizes from sparse to dense, a random row
+    range, a random budget (so that dense blocks, whole-square symmetry and the packed list all come up): the streamed
+    pieces always equal the cell list"""
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.integers(40, 900))
+    d = int(rng.choice([64, 100, 192, 256, 520]))
+    cluster = int(rng.choice([4, 16, max(4, n // 5), max(4, n // 2)]))
+    sk = synth.make_sketches_numpy(n, d, int(rng.choice([300, 3000, 40000])), seed=seed, cluster=cluster,
+                                   shared=float(rng.choice([0.3, 0.6])))
+    n2 = _n2(sk)
+    ctx.set_option("pairwise_filter", int(rng.choice([0, 1, 2])))
+    ctx.set_option("stream_dense", int(rng.choice([0, 1, 1])))
+    ctx.set_option("stream_block_rows", int(rng.choice([0, 256, 512])))
+    try:
+        ss = ctx.sketch_set(sk)
+        cells, cnt = ctx.pairwise_rows(ss, n2)
+        rb = int(rng.integers(0, n // 2))
+        re = int(rng.integers(rb, n + 1))
+        budget = int(rng.choice([0, 1 << 18, 1 << 20, 1 << 22]))
+        row_ptr, col, q, n_s = ctx.pairwise_stream(ss, n2, row_begin=rb, row_end=re, device_budget_bytes=budget)
+        sel = (cells["row"] >= rb) & (cells["row"] < re)
+        assert n_s == int(sel.sum())
+        assert np.array_equal(_triples(row_ptr, col, q, rb), _cells_triples(cells[sel]))
+        ss.close()
+    finally:
+        ctx.set_option("stream_dense", 1)
+        ctx.set_option("stream_block_rows", 0)
