@@ -127,7 +127,7 @@ def fast_norm_sq(sumsq, d):
     return out * out
 
 
-def launch_workers(n, argv, script=None, python=None, env=None, poll_s=0.05, grace_s=20.0):
+def launch_workers(n, argv, script=None, python=None, env=None, poll_s=0.05, grace_s=20.0, deadline_s=None):
     """`bench.py --gpus N` started WITHOUT a launcher (no RANK / WORLD_SIZE in the environment): this process becomes
     the parent of N fresh workers -- the same script with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT
     set, one per GPU, which is the reference's own way of distributing (one process per shard,
@@ -158,10 +158,16 @@ def launch_workers(n, argv, script=None, python=None, env=None, poll_s=0.05, gra
     reader = threading.Thread(target=lambda: out0.extend(procs[0].stdout.read().decode("utf-8", "replace").splitlines()))
     reader.start()
     first_fail = None
+    if deadline_s is None:          # a collective that never completes (RCCL has no timeout) must not hold the caller for ever
+        deadline_s = float(os.environ.get("MVS_BENCH_DEADLINE_S", "1500"))
+    t_start = time.monotonic()
     while any(p.poll() is None for p in procs):
         codes = [p.poll() for p in procs]
         if first_fail is None and any(c not in (None, 0) for c in codes):
             first_fail = time.monotonic()
+        if first_fail is None and time.monotonic() - t_start > deadline_s:
+            print("bench.py: workers still running after %.0f s: terminating them" % deadline_s, file=sys.stderr)
+            first_fail = time.monotonic() - grace_s
         if first_fail is not None and time.monotonic() - first_fail > grace_s:
             for p in procs:
                 if p.poll() is None:
@@ -178,7 +184,7 @@ def launch_workers(n, argv, script=None, python=None, env=None, poll_s=0.05, gra
     for line in out0:       # stdout carries the bench line and nothing else (gloo, for one, announces itself on stdout)
         print(line, flush=True, file=sys.stdout if line.lstrip().startswith("{") else sys.stderr)
     codes = [p.returncode for p in procs]
-    worst = 0
+    worst = 124 if (time.monotonic() - t_start > deadline_s and all(c == 0 for c in codes)) else 0
     for c in codes:
         if c != 0:
             worst = max(worst, c if c > 0 else 128 - c)      # killed by signal s: 128 + s, as a shell reports it

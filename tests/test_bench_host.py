@@ -38,6 +38,8 @@ if mode == "fail" and rank == 1:
     sys.exit(7)
 if mode == "fail" and rank == 0:
     time.sleep(60)          # a rank left inside a collective by the one that died
+if mode == "hang":
+    time.sleep(60)          # every rank inside a collective that never completes
 if rank == 0:
     print("[Gloo] Rank 0 is connected to 2 peer ranks")      # a library that announces itself on stdout
 print("noise from rank %d" % rank if rank else json.dumps({"world": world, "argv": sys.argv[1:]}))
@@ -63,6 +65,10 @@ def test_launcher_relays_rank0_line_and_worst_exit_code(tmp_path, capfd):
     out, err = capfd.readouterr()
     assert rc != 0 and time.monotonic() - t0 < 30                         # rank 0 was not waited for for a minute
     assert "worker exit codes" in err and not out.strip()
+    t0 = time.monotonic()
+    rc = launch_workers(2, ["hang"], script=str(stub), env=env, grace_s=0.2, deadline_s=1.0)
+    out, err = capfd.readouterr()
+    assert rc != 0 and time.monotonic() - t0 < 30 and "still running after" in err and not out.strip()
 
 
 def test_bench_parent_does_not_import_torch_before_launching(tmp_path):
