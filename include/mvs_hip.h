@@ -270,6 +270,31 @@ int mvs_pairwise_stream(mvs_ctx* ctx, const mvs_sketch_set* set, const double* n
                         int64_t row_begin, int64_t row_end, size_t device_budget_bytes, mvs_row_block_cb cb, void* user,
                         int64_t* n_cells);
 
+/* mvs_pairwise_stream with the rows already ENCODED on the device in this build's shard codec
+ * (metagenome_vector_sketches_amd/csrc/host/mvs_codec.hpp; the reference's writer, src/pairwise_comp_optimized.cpp:718-736,
+ * stores per row a compact_vector of the q values and, when the row holds more than one cell, a rice_sequence of the
+ * column deltas -- through the `bits` library, which is absent from the reference tree, so the byte layout is this
+ * build's own).  A piece covers rows [row_begin, row_end) and carries, for its n_rows rows that hold cells (ascending):
+ * their ids, their first columns (what goes into neighbor_start.bin), the byte offset of each row's record inside
+ * `bytes`, the size of its compact_vector (the "Jac space" statistic of :808) and the records themselves, back to back --
+ * exactly the bytes the host writer appends to matrix.bin for the same rows (tests compare the files).  Same delivery
+ * rules as mvs_pairwise_stream.  1.4 bytes per kept cell cross the link instead of 5, and no host thread touches a cell. */
+typedef struct {
+    int64_t row_begin, row_end;
+    int64_t n_cells;
+    int64_t n_rows;
+    const uint32_t* rows;
+    const uint32_t* first_col;
+    const uint64_t* offset;
+    const uint32_t* jac_bytes;
+    const uint8_t* bytes;
+    int64_t n_bytes;
+} mvs_encoded_rows;
+typedef int (*mvs_encoded_rows_cb)(void* user, const mvs_encoded_rows* piece);
+int mvs_pairwise_stream_encoded(mvs_ctx* ctx, const mvs_sketch_set* set, const double* norms_sq, int mem_norms, int keep_mode,
+                                int64_t row_begin, int64_t row_end, size_t device_budget_bytes, mvs_encoded_rows_cb cb,
+                                void* user, int64_t* n_cells);
+
 /* What the most recent mvs_pairwise_stream of the context did: time of its comparison kernels summed over the row blocks
  * (0 unless mvs_ctx_set_timing is on), bytes handed to the callback, row blocks computed, pieces delivered, and whether
  * the two-stage comparison (1) or the exact kernel in row blocks (0) produced them.  Any pointer may be NULL. */

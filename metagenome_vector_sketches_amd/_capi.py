@@ -34,6 +34,17 @@ class RowBlock(ctypes.Structure):
 
 
 ROW_BLOCK_CB = ctypes.CFUNCTYPE(_c.c_int, _P, _c.POINTER(RowBlock))
+
+
+class EncodedRows(ctypes.Structure):
+    """mvs_encoded_rows: one piece of the streamed comparison result with its rows encoded in the shard codec"""
+    _fields_ = [("row_begin", _c.c_int64), ("row_end", _c.c_int64), ("n_cells", _c.c_int64), ("n_rows", _c.c_int64),
+                ("rows", _c.POINTER(_c.c_uint32)), ("first_col", _c.POINTER(_c.c_uint32)),
+                ("offset", _c.POINTER(_c.c_uint64)), ("jac_bytes", _c.POINTER(_c.c_uint32)),
+                ("bytes", _c.POINTER(_c.c_uint8)), ("n_bytes", _c.c_int64)]
+
+
+ENCODED_ROWS_CB = ctypes.CFUNCTYPE(_c.c_int, _P, _c.POINTER(EncodedRows))
 SYMBOLS = [
     ("mvs_version", _c.c_char_p, []),
     ("mvs_last_error", _c.c_char_p, []),
@@ -74,6 +85,8 @@ SYMBOLS = [
                                       _c.c_int, _c.POINTER(_c.c_int64)]),
     ("mvs_pairwise_stream", _c.c_int, [_P, _P, _P, _c.c_int, _c.c_int, _c.c_int64, _c.c_int64, _c.c_size_t, ROW_BLOCK_CB, _P,
                                         _c.POINTER(_c.c_int64)]),
+    ("mvs_pairwise_stream_encoded", _c.c_int, [_P, _P, _P, _c.c_int, _c.c_int, _c.c_int64, _c.c_int64, _c.c_size_t,
+                                                ENCODED_ROWS_CB, _P, _c.POINTER(_c.c_int64)]),
     ("mvs_ctx_stream_stats", _c.c_int, [_P, _c.POINTER(_c.c_double), _c.POINTER(_c.c_int64), _c.POINTER(_c.c_int64),
                                          _c.POINTER(_c.c_int64), _c.POINTER(_c.c_int)]),
     ("mvs_pairwise_block", _c.c_int, [_P, _P, _P, _c.c_int, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int,
@@ -556,6 +569,48 @@ class Context:
         col = np.concatenate([p[3] for p in parts]) if parts else np.empty(0, np.int32)
         q = np.concatenate([p[4].astype(np.uint16 if wide else np.uint8) for p in parts]) if parts else np.empty(0, np.uint8)
         return row_ptr, col, q, count.value
+
+    def pairwise_stream_encoded(self, sset, norms_sq, row_begin=0, row_end=None, keep_mode=KEEP_INT32, device_budget_bytes=0):
+        """mvs_pairwise_stream_encoded, pieces collected: returns dict(rows uint32 [R], first_col uint32 [R], offset uint64
+        [R] into `bytes`, jac_bytes uint32 [R], bytes uint8 [B] = what the shard writer appends to matrix.bin, n_cells)"""
+        if row_end is None:
+            row_end = sset.n
+        np_, nm, nk = _buf(norms_sq) if _is_torch(norms_sq) else _buf(norms_sq, np.float64)
+        parts, errors = [], []
+
+        def trampoline(_user, bp):
+            try:
+                b = bp.contents
+                r, nb = b.n_rows, b.n_bytes
+
+                def arr(ptr, n, dt):
+                    return np.ctypeslib.as_array(ptr, shape=(n,)).copy() if n else np.empty(0, dt)
+                parts.append((b.row_begin, b.row_end, arr(b.rows, r, np.uint32), arr(b.first_col, r, np.uint32),
+                              arr(b.offset, r, np.uint64), arr(b.jac_bytes, r, np.uint32), arr(b.bytes, nb, np.uint8), b.n_cells))
+                return 0
+            except BaseException as e:      # noqa: BLE001
+                errors.append(e)
+                return -1
+
+        cb = ENCODED_ROWS_CB(trampoline)
+        count = _c.c_int64()
+        rc = self.lib.mvs_pairwise_stream_encoded(self._h, sset._h, np_, nm, keep_mode, int(row_begin), int(row_end),
+                                                  int(device_budget_bytes), cb, None, ctypes.byref(count))
+        if errors:
+            raise errors[0]
+        _check(rc)
+        expect, at = row_begin, 0
+        offs = []
+        for p in parts:
+            assert p[0] == expect, "pieces must arrive in ascending row order"
+            expect = p[1]
+            offs.append(p[4] + np.uint64(at))
+            at += len(p[6])
+        assert expect == row_end and sum(p[7] for p in parts) == count.value
+        cat = lambda i, dt: np.concatenate([p[i] for p in parts]) if parts else np.empty(0, dt)   # noqa: E731
+        return {"rows": cat(2, np.uint32), "first_col": cat(3, np.uint32),
+                "offset": np.concatenate(offs) if offs else np.empty(0, np.uint64), "jac_bytes": cat(5, np.uint32),
+                "bytes": cat(6, np.uint8), "n_cells": count.value, "pieces": len(parts)}
 
     def stream_stats(self):
         """what the last pairwise_stream did: dict(kernel_ms, bytes, row_blocks, pieces, two_stage)"""

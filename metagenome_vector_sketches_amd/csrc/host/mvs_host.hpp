@@ -633,6 +633,31 @@ public:
         }
     }
 
+    // The same for a piece whose rows the device has already encoded (mvs_pairwise_stream_encoded): the records go to the
+    // file as they are, the directory entries are rebased to the file position.
+    void add_encoded(const mvs_encoded_rows& b) {
+        if (b.row_begin < next_row_) throw std::runtime_error("ShardWriter: pieces must come in ascending row order");
+        next_row_ = b.row_end;
+        cells_ += (uint64_t)b.n_cells;
+        if (b.n_rows == 0) return;
+        uint64_t jac = 0;
+        for (int64_t r = 0; r < b.n_rows; ++r) {
+            row_vec_.push_back(b.rows[r]);
+            start_neighbor_.push_back(b.first_col[r]);
+            curr_pos_vec_.push_back(pos_ + b.offset[r]);
+            jac += b.jac_bytes[r];
+        }
+        stats_.jac_space += jac;
+        stats_.ngh_space += (uint64_t)b.n_bytes - jac;
+        pos_ += (uint64_t)b.n_bytes;
+        {
+            std::unique_lock<std::mutex> lk(mu_);
+            cv_.wait(lk, [this] { return pending_.size() < 64; });
+            pending_.emplace_back(reinterpret_cast<const char*>(b.bytes), (size_t)b.n_bytes);   // the pinned buffer is only valid during the call
+        }
+        cv_.notify_all();
+    }
+
     uint64_t cells() const { return cells_; }
 
     ShardStats finish() {

@@ -440,10 +440,29 @@ int main(int argc, char* argv[]) {
                 return 1;
             }
         }
+        static int on_encoded(void* user, const mvs_encoded_rows* b) {
+            Sink* self = static_cast<Sink*>(user);
+            try {
+                self->writer.add_encoded(*b);
+                return 0;
+            } catch (const std::exception& e) {
+                self->error = e.what();
+                return 1;
+            }
+        }
     } sink{ShardWriter(shard_folder), std::string()};
     int64_t n_kept = 0;
-    if (mvs_pairwise_stream(g.ctx, g.set, db.norms_sq.data(), MVS_MEM_HOST, keep_mode, begin_row, end_row, 0, &Sink::on_block,
-                            &sink, &n_kept) != MVS_OK) {
+    // The rows are encoded in the shard codec ON THE DEVICE (1.4 bytes per kept cell on the link instead of 5, no host
+    // thread touches a cell); MVS_SHARD_ENCODER=host streams (column, q) pieces and encodes them on the host threads
+    // instead -- the same files, byte for byte.
+    const char* enc = getenv("MVS_SHARD_ENCODER");
+    const bool host_encoder = enc && std::string(enc) == "host";
+    const int stream_rc =
+        host_encoder ? mvs_pairwise_stream(g.ctx, g.set, db.norms_sq.data(), MVS_MEM_HOST, keep_mode, begin_row, end_row, 0,
+                                           &Sink::on_block, &sink, &n_kept)
+                     : mvs_pairwise_stream_encoded(g.ctx, g.set, db.norms_sq.data(), MVS_MEM_HOST, keep_mode, begin_row, end_row, 0,
+                                                   &Sink::on_encoded, &sink, &n_kept);
+    if (stream_rc != MVS_OK) {
         if (!sink.error.empty()) std::cerr << "pairwise_comp_optimized: " << sink.error << std::endl;
         return gpu_fail("pairwise comparison");
     }
@@ -455,7 +474,7 @@ int main(int argc, char* argv[]) {
         mvs_ctx_stream_stats(g.ctx, &kms, &bytes, &blocks, &pieces, &two);
         std::cerr << "[stream] comparison kernels " << kms << " ms in " << blocks << " row block(s) ("
                   << (two ? "two-stage" : "exact kernel") << "), " << n_kept << " kept cells = " << bytes << " bytes in "
-                  << pieces << " piece(s)" << std::endl;
+                  << pieces << " piece(s), rows encoded on the " << (host_encoder ? "host" : "device") << std::endl;
     }
     if (int16) {                                                                  // _16bits.cpp:419-423
         auto end_time = std::chrono::high_resolution_clock::now();

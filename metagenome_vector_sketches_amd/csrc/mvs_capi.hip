@@ -15,6 +15,7 @@
 #include <thread>
 #include <vector>
 
+#include "mvs_encode.h"
 #include "mvs_internal.h"
 
 struct mvs_ctx {
@@ -52,6 +53,13 @@ struct mvs_ctx {
     void* st_rowptr = nullptr;  size_t st_rowptr_bytes = 0;
     void* st_counts = nullptr;  size_t st_counts_bytes = 0;
     void* st_dense = nullptr;   size_t st_dense_bytes = 0;  // dense results: one byte per cell (mvs_internal.h)
+    // rows encoded on the device (mvs_pairwise_stream_encoded): per-row sizes / offsets / directory, the records themselves
+    void* en_size = nullptr;    size_t en_size_bytes = 0;
+    void* en_off = nullptr;     size_t en_off_bytes = 0;
+    void* en_jac = nullptr;     size_t en_jac_bytes = 0;
+    void* en_first = nullptr;   size_t en_first_bytes = 0;
+    void* en_par = nullptr;     size_t en_par_bytes = 0;
+    void* st_enc[2] = {nullptr, nullptr};     size_t st_enc_bytes[2] = {0, 0};
     hipStream_t dl_stream = nullptr;
     void* dl_pinned[2] = {nullptr, nullptr};      // pinned host buffers, each allocated (and grown) when first needed:
     size_t dl_bytes[2] = {0, 0};                  // pinning costs ~0.3 ms per MiB, a one-piece result needs only one
@@ -403,7 +411,7 @@ int mvs_ctx_destroy(mvs_ctx* c) {
     if (c->pw_fmeta) (void)hipFree(c->pw_fmeta);
     if (c->pw_cand) (void)hipFree(c->pw_cand);
     for (void* p : {c->st_raw, c->st_sorted, c->st_col[0], c->st_col[1], c->st_q[0], c->st_q[1], c->st_rowptr, c->st_counts,
-                    c->st_dense})
+                    c->st_dense, c->en_size, c->en_off, c->en_jac, c->en_first, c->en_par, c->st_enc[0], c->st_enc[1]})
         if (p) (void)hipFree(p);
     for (int i = 0; i < 2; ++i) {
         if (c->dl_pinned[i]) (void)hipHostFree(c->dl_pinned[i]);
@@ -1420,9 +1428,14 @@ struct StreamOut {
         int64_t row_begin, row_end, n_cells;
         std::vector<int64_t> row_ptr;      // rebased to the block's first cell
         bool wide;
+        // encoded pieces: the directory of the piece's non-empty rows, the records' byte count
+        std::vector<uint32_t> rows, first_col, jac_bytes;
+        std::vector<uint64_t> offset;
+        int64_t n_bytes = 0;
     };
     mvs_ctx* c;
-    mvs_row_block_cb cb;
+    mvs_row_block_cb cb = nullptr;
+    mvs_encoded_rows_cb ecb = nullptr;     // set instead of cb by mvs_pairwise_stream_encoded
     void* user;
     std::mutex mu;
     std::condition_variable cv;
@@ -1455,7 +1468,24 @@ struct StreamOut {
                     std::lock_guard<std::mutex> lk(mu);
                     skip = cb_status != 0 || !error.empty();
                 }
-                if (!skip) {
+                if (!skip && ecb) {
+                    mvs_encoded_rows b{};
+                    b.row_begin = it.row_begin;
+                    b.row_end = it.row_end;
+                    b.n_cells = it.n_cells;
+                    b.n_rows = (int64_t)it.rows.size();
+                    b.rows = it.rows.data();
+                    b.first_col = it.first_col.data();
+                    b.offset = it.offset.data();
+                    b.jac_bytes = it.jac_bytes.data();
+                    b.bytes = static_cast<const uint8_t*>(c->dl_pinned[it.slot]);
+                    b.n_bytes = it.n_bytes;
+                    try {
+                        status = ecb(user, &b);
+                    } catch (...) {
+                        status = -1;
+                    }
+                } else if (!skip) {
                     mvs_row_block b{};
                     b.row_begin = it.row_begin;
                     b.row_end = it.row_end;
@@ -1546,7 +1576,59 @@ struct BlockCsr {
     std::vector<int64_t> row_ptr;      // re - rb + 1 entries
     bool wide = false;                 // q is 16 bits wide in this block
     int set = 0;
+    // rows encoded on the device: byte offset of every row's record (rows + 1 entries), directory values per row
+    bool encoded = false;
+    std::vector<uint64_t> enc_off;
+    std::vector<uint32_t> enc_jac, enc_first;
 };
+
+// The CSR arrays of `b` (set b.set) -> the rows' shard records in c->st_enc[b.set], directory on the host
+int encode_block(mvs_ctx* c, BlockCsr& b) {
+    const int64_t rows = b.re - b.rb;
+    b.encoded = true;
+    b.enc_off.assign((size_t)rows + 1, 0);
+    b.enc_jac.assign((size_t)rows, 0);
+    b.enc_first.assign((size_t)rows, 0);
+    if (b.n == 0 || rows == 0) {
+        HIP_TRY(hipEventRecord(c->dl_ready, c->stream));
+        return MVS_OK;
+    }
+    int rc = ensure_buf(c, &c->en_size, &c->en_size_bytes, (size_t)(rows + 1) * 8);
+    if (rc == MVS_OK) rc = ensure_buf(c, &c->en_off, &c->en_off_bytes, (size_t)(rows + 1) * 8);
+    if (rc == MVS_OK) rc = ensure_buf(c, &c->en_jac, &c->en_jac_bytes, (size_t)rows * 4);
+    if (rc == MVS_OK) rc = ensure_buf(c, &c->en_first, &c->en_first_bytes, (size_t)rows * 4);
+    if (rc == MVS_OK) rc = ensure_buf(c, &c->en_par, &c->en_par_bytes, (size_t)rows * sizeof(mvs::EncRow));
+    if (rc) return rc;
+    const int qb = b.wide ? 2 : 1;
+    HIP_TRY(hipMemsetAsync((char*)c->en_size + (size_t)rows * 8, 0, 8, c->stream));
+    mvs::launch_encode_sizes(c->stream, (const long long*)c->st_rowptr, (const int32_t*)c->st_col[b.set], c->st_q[b.set], qb, rows,
+                             (unsigned long long*)c->en_size, (unsigned int*)c->en_jac, (unsigned int*)c->en_first,
+                             (mvs::EncRow*)c->en_par);
+    rc = check_kernel("k_enc_size");
+    if (rc) return rc;
+    size_t need = 0;
+    rc = mvs::encode_offsets(c->stream, (unsigned long long*)c->en_size, (unsigned long long*)c->en_off, rows, nullptr, 0, &need);
+    if (rc) return fail(rc, "scan sizing failed");
+    rc = ensure_buf(c, &c->pw_sort, &c->pw_sort_bytes, need);
+    if (rc) return rc;
+    rc = mvs::encode_offsets(c->stream, (unsigned long long*)c->en_size, (unsigned long long*)c->en_off, rows, c->pw_sort,
+                             c->pw_sort_bytes, nullptr);
+    if (rc) return fail(rc, "scan of the record sizes failed");
+    HIP_TRY(hipMemcpyAsync(b.enc_off.data(), c->en_off, (size_t)(rows + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(b.enc_jac.data(), c->en_jac, (size_t)rows * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(b.enc_first.data(), c->en_first, (size_t)rows * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const size_t total = (size_t)b.enc_off[(size_t)rows];
+    rc = ensure_buf(c, &c->st_enc[b.set], &c->st_enc_bytes[b.set], std::max<size_t>(total, 8));
+    if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(c->st_enc[b.set], 0, total, c->stream));       // the unary parts are OR-ed into zeroed words
+    mvs::launch_encode_fill(c->stream, (const long long*)c->st_rowptr, (const int32_t*)c->st_col[b.set], c->st_q[b.set], qb, rows,
+                            (const unsigned long long*)c->en_off, (const mvs::EncRow*)c->en_par, (unsigned char*)c->st_enc[b.set]);
+    rc = check_kernel("k_enc_fill");
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(c->dl_ready, c->stream));
+    return MVS_OK;
+}
 
 // before the CSR arrays of set `set` are rewritten: the downloads of the block that used them last (two blocks ago) are through
 int claim_csr_set(mvs_ctx* c, int set, int64_t block_index, int64_t n, bool wide) {
@@ -1721,19 +1803,81 @@ int feed_block(mvs_ctx* c, StreamOut& out, const BlockCsr& b, size_t piece_bytes
     return MVS_OK;
 }
 
+// the block's encoded records out through the pinned buffers, in pieces of whole rows of at most piece_bytes
+int feed_encoded(mvs_ctx* c, StreamOut& out, const BlockCsr& b, size_t piece_bytes) {
+    const int64_t rows = b.re - b.rb;
+    const std::vector<uint64_t>& off = b.enc_off;
+    auto piece_end = [&](int64_t r0) {
+        int64_t r1 = r0 + 1;
+        const uint64_t o0 = off[(size_t)r0];
+        if (off[(size_t)r1] - o0 <= piece_bytes) {
+            const uint64_t* end = std::upper_bound(off.data() + r1, off.data() + rows + 1, o0 + (uint64_t)piece_bytes);
+            r1 = std::max<int64_t>(r1, (end - off.data()) - 1);
+        }
+        return r1;
+    };
+    size_t need_bytes = std::min<size_t>(piece_bytes, std::max<size_t>((size_t)off[(size_t)rows], 1u << 16));
+    for (int64_t r0 = 0; r0 < rows;) {
+        const int64_t r1 = piece_end(r0);
+        need_bytes = std::max(need_bytes, (size_t)(off[(size_t)r1] - off[(size_t)r0]));
+        r0 = r1;
+    }
+    int rc = MVS_OK;
+    for (int64_t r0 = 0; r0 < rows;) {
+        const int64_t r1 = piece_end(r0);
+        const uint64_t o0 = off[(size_t)r0], bytes = off[(size_t)r1] - o0;
+        if (out.failed()) return MVS_OK;
+        const int sl = out.acquire_slot();
+        rc = ensure_pinned_slot(c, sl, need_bytes);
+        if (rc) {
+            out.release_slot(sl);
+            return rc;
+        }
+        StreamOut::Item it;
+        it.slot = sl;
+        it.row_begin = b.rb + r0;
+        it.row_end = b.rb + r1;
+        it.n_cells = b.row_ptr[(size_t)r1] - b.row_ptr[(size_t)r0];
+        it.wide = b.wide;
+        it.n_bytes = (int64_t)bytes;
+        for (int64_t r = r0; r < r1; ++r)
+            if (b.row_ptr[(size_t)r + 1] > b.row_ptr[(size_t)r]) {
+                it.rows.push_back((uint32_t)(b.rb + r));
+                it.first_col.push_back(b.enc_first[(size_t)r]);
+                it.jac_bytes.push_back(b.enc_jac[(size_t)r]);
+                it.offset.push_back(off[(size_t)r] - o0);
+            }
+        hipError_t e = hipStreamWaitEvent(c->dl_stream, c->dl_ready, 0);
+        if (e == hipSuccess && bytes > 0)
+            e = hipMemcpyAsync(c->dl_pinned[sl], (const char*)c->st_enc[b.set] + o0, (size_t)bytes, hipMemcpyDeviceToHost, c->dl_stream);
+        if (e == hipSuccess) e = hipEventRecord(c->dl_done[sl], c->dl_stream);
+        if (e != hipSuccess) {
+            out.release_slot(sl);
+            return fail(MVS_E_HIP, "download of encoded rows: %s", hipGetErrorString(e));
+        }
+        out.push(std::move(it));
+        ++c->st_pieces;
+        c->st_bytes += (long long)bytes;
+        r0 = r1;
+    }
+    HIP_TRY(hipEventRecord(c->dl_block[b.set], c->dl_stream));
+    return MVS_OK;
+}
+
 }  // namespace
 
 namespace {
 int pairwise_stream_impl(mvs_ctx* c, const mvs_sketch_set* s, const double* norms_sq, int mem_norms, int keep_mode,
-                         int64_t row_begin, int64_t row_end, size_t device_budget_bytes, mvs_row_block_cb cb, void* user,
-                         int64_t* n_cells);
+                         int64_t row_begin, int64_t row_end, size_t device_budget_bytes, mvs_row_block_cb cb,
+                         mvs_encoded_rows_cb ecb, void* user, int64_t* n_cells);
 }
 
 int mvs_pairwise_stream(mvs_ctx* c, const mvs_sketch_set* s, const double* norms_sq, int mem_norms, int keep_mode,
                         int64_t row_begin, int64_t row_end, size_t device_budget_bytes, mvs_row_block_cb cb, void* user,
                         int64_t* n_cells) {
     try {       // the host side keeps per-row directories in std::vector: no exception may cross the C boundary
-        return pairwise_stream_impl(c, s, norms_sq, mem_norms, keep_mode, row_begin, row_end, device_budget_bytes, cb, user, n_cells);
+        return pairwise_stream_impl(c, s, norms_sq, mem_norms, keep_mode, row_begin, row_end, device_budget_bytes, cb, nullptr, user,
+                                    n_cells);
     } catch (const std::bad_alloc&) {
         return fail(MVS_E_NOMEM, "out of host memory while streaming the comparison result");
     } catch (const std::exception& e) {
@@ -1741,11 +1885,24 @@ int mvs_pairwise_stream(mvs_ctx* c, const mvs_sketch_set* s, const double* norms
     }
 }
 
+int mvs_pairwise_stream_encoded(mvs_ctx* c, const mvs_sketch_set* s, const double* norms_sq, int mem_norms, int keep_mode,
+                                int64_t row_begin, int64_t row_end, size_t device_budget_bytes, mvs_encoded_rows_cb cb, void* user,
+                                int64_t* n_cells) {
+    try {
+        return pairwise_stream_impl(c, s, norms_sq, mem_norms, keep_mode, row_begin, row_end, device_budget_bytes, nullptr, cb, user,
+                                    n_cells);
+    } catch (const std::bad_alloc&) {
+        return fail(MVS_E_NOMEM, "out of host memory while streaming the comparison result");
+    } catch (const std::exception& e) {
+        return fail(MVS_E_HIP, "mvs_pairwise_stream_encoded: %s", e.what());
+    }
+}
+
 namespace {
 int pairwise_stream_impl(mvs_ctx* c, const mvs_sketch_set* s, const double* norms_sq, int mem_norms, int keep_mode,
-                         int64_t row_begin, int64_t row_end, size_t device_budget_bytes, mvs_row_block_cb cb, void* user,
-                         int64_t* n_cells) {
-    if (!c || !s || !cb) return fail(MVS_E_INVALID, "NULL argument");
+                         int64_t row_begin, int64_t row_end, size_t device_budget_bytes, mvs_row_block_cb cb,
+                         mvs_encoded_rows_cb ecb, void* user, int64_t* n_cells) {
+    if (!c || !s || (!cb && !ecb)) return fail(MVS_E_INVALID, "NULL argument");
     const Range range(c, "mvs_pairwise_stream");
     if (n_cells) *n_cells = 0;
     if (!mem_ok(mem_norms) || (keep_mode != MVS_KEEP_INT32 && keep_mode != MVS_KEEP_INT16)) return fail(MVS_E_INVALID, "bad argument");
@@ -1795,7 +1952,14 @@ int pairwise_stream_impl(mvs_ctx* c, const mvs_sketch_set* s, const double* norm
     StreamOut out;
     out.c = c;
     out.cb = cb;
+    out.ecb = ecb;
     out.user = user;
+    // a block's way out, in two steps so that the next block's comparison can be queued between them: prepare = the
+    // device-side work that is left (encoding the rows, where the caller asked for that), deliver = pieces to the link
+    auto prepare = [&](BlockCsr& blk) -> int { return ecb ? encode_block(c, blk) : MVS_OK; };
+    auto deliver = [&](BlockCsr& blk) -> int {
+        return ecb ? feed_encoded(c, out, blk, piece_bytes) : feed_block(c, out, blk, piece_bytes);
+    };
     out.worker = std::thread([&out] { out.run(); });
     int64_t total = 0;
     auto finish = [&](int status) {
@@ -1826,7 +1990,8 @@ int pairwise_stream_impl(mvs_ctx* c, const mvs_sketch_set* s, const double* norm
             c->st_two_stage = 1;
             BlockCsr blk;
             rc = csr_from_packed(c, row_begin, row_end, (int64_t)got, shift, col_bits, 0, blk);
-            if (rc == MVS_OK) rc = feed_block(c, out, blk, piece_bytes);
+            if (rc == MVS_OK) rc = prepare(blk);
+            if (rc == MVS_OK) rc = deliver(blk);
             return finish(rc);
         }
         if (rc != kNeedExact) return finish(rc);
@@ -1948,12 +2113,14 @@ int pairwise_stream_impl(mvs_ctx* c, const mvs_sketch_set* s, const double* norm
         }
         total += blk.n;
         ++c->st_blocks;
+        rc = prepare(blk);
+        if (rc) return finish(rc);
         if (k + 1 < blocks.size() && !out.failed()) {                  // the next block computes while this one is fed to the link
             rc = launch(k + 1, dense);
             if (rc) return finish(rc);
             next_launched = true;
         }
-        rc = feed_block(c, out, blk, piece_bytes);
+        rc = deliver(blk);
         if (rc) return finish(rc);
         if (out.failed()) break;
         (void)next_launched;

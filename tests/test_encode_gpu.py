@@ -1,0 +1,171 @@
+"""GPU: the shard codec on the device (mvs_pairwise_stream_encoded, csrc/mvs_encode.hip).
+
+Two independent checks of the encoded rows:
+  * a decoder written here from the documented layout (csrc/host/mvs_codec.hpp: compact_vector = [size][width][n_words]
+    [words], rice_sequence = [size][k][low compact_vector if k][n_high_bits][n_words][high words][n_samples][samples]) turns
+    the bytes back into (row, col, q) triples, which must equal the cell list of mvs_pairwise_rows;
+  * the executable writes the same three shard files, byte for byte, whether the rows are encoded on the device (default) or
+    by the host encoder (MVS_SHARD_ENCODER=host, the C++ mvs_codec classes)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from metagenome_vector_sketches_amd import synth
+from oracle import pyoracle as orc
+
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("restore_options")]
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "metagenome_vector_sketches_amd", "bin")
+
+
+def _n2(sk):
+    return np.array([orc.norm_sq_from_text(orc.format_norm(orc.norm(row))) for row in sk.astype(np.int32)])
+
+
+class Words:
+    def __init__(self, buf, at):
+        self.w = np.frombuffer(buf, dtype="<u8")
+        self.i = at // 8
+
+    def take(self, n=1):
+        out = self.w[self.i:self.i + n]
+        self.i += n
+        return out if n > 1 else int(out[0])
+
+
+def _bits(words, pos, width):
+    if width == 0:
+        return 0
+    w, off = pos >> 6, pos & 63
+    v = int(words[w]) >> off
+    if off + width > 64:
+        v |= int(words[w + 1]) << (64 - off)
+    return v & ((1 << width) - 1)
+
+
+def _compact_vector(s):
+    n, width, nw = s.take(), s.take(), s.take()
+    assert nw == (n * width + 63) // 64 and 1 <= width <= 64
+    words = s.take(nw) if nw > 1 else np.array([s.take()] if nw else [], dtype="<u8")
+    return [_bits(words, i * width, width) for i in range(n)]
+
+
+def _rice(s):
+    n, k = s.take(), s.take()
+    low = _compact_vector(s) if k else [0] * n
+    high_bits, nw = s.take(), s.take()
+    assert nw == (high_bits + 63) // 64
+    words = s.take(nw) if nw > 1 else np.array([s.take()] if nw else [], dtype="<u8")
+    ns = s.take()
+    assert ns == (n + 63) // 64
+    samples = [int(x) for x in (s.take(ns) if ns > 1 else ([s.take()] if ns else []))]
+    out, pos = [], 0
+    for i in range(n):
+        if i % 64 == 0:
+            assert samples[i // 64] == pos
+        q = 0
+        while not (int(words[pos >> 6]) >> (pos & 63)) & 1:
+            q += 1
+            pos += 1
+        pos += 1
+        out.append((q << k) | low[i])
+    assert pos == high_bits
+    return out
+
+
+def _decode(enc):
+    buf = enc["bytes"].tobytes()
+    triples, sizes = [], np.diff(np.append(enc["offset"], np.uint64(len(buf)))).astype(np.int64)
+    for row, first, off, jac, size in zip(enc["rows"], enc["first_col"], enc["offset"], enc["jac_bytes"], sizes):
+        s = Words(buf, int(off))
+        q = _compact_vector(s)
+        assert (s.i * 8 - int(off)) == int(jac)
+        cols = [int(first)]
+        if len(q) > 1:
+            for dlt in _rice(s):
+                cols.append(cols[-1] + dlt)
+        assert len(cols) == len(q) and s.i * 8 - int(off) == size
+        triples += [(int(row), c, v) for c, v in zip(cols, q)]
+    return triples
+
+
+def _cells(cells, rb=0, re=1 << 62):
+    return [(int(c["row"]), int(c["col"]), int(c["q"])) for c in cells if rb <= c["row"] < re]
+
+
+@pytest.mark.parametrize("case", ["sparse", "dense-blocks", "one-limb-packed", "wide-q", "toy"])
+def test_encoded_rows_decode_to_the_cell_list(ctx, gold, case):
+    budget, rb, re = 0, 0, None
+    if case == "sparse":
+        sk = synth.make_sketches_numpy(700, 512, 3000, seed=5, cluster=8)
+        ctx.set_option("pairwise_filter", 2)
+        rb, re = 100, 650
+    elif case == "dense-blocks":       # rows of ~170 cells: several 64-value chunks per row, whole-square dense blocks
+        sk = synth.make_sketches_numpy(1500, 256, 3000, seed=77, cluster=500, shared=0.6)
+        ctx.set_option("stream_block_rows", 256)
+    elif case == "one-limb-packed":    # |v| <= 127: the 32x32x32 kernel, packed list, blocks sized for the worst case
+        sk = np.clip(synth.make_sketches_numpy(600, 256, 300, seed=3, cluster=50, shared=0.6), -127, 127).astype(np.int32)
+        budget = 1 << 20
+    elif case == "wide-q":
+        rng = np.random.default_rng(11)
+        sk = rng.integers(-400, 401, size=(40, 256), dtype=np.int32)
+        sk[20:] = sk[:20] * 3 // 2
+    else:
+        sk = gold.vectors
+    n2 = _n2(sk) if case != "toy" else np.array([orc.norm_sq_from_text(l.split()[1]) for l in gold.norm_lines()])
+    if case == "wide-q":
+        n2[3] = 1e-3
+    try:
+        ss = ctx.sketch_set(sk)
+        cells, cnt = ctx.pairwise_rows(ss, n2)
+        enc = ctx.pairwise_stream_encoded(ss, n2, row_begin=rb, row_end=re, device_budget_bytes=budget)
+        want = _cells(cells, rb, re if re is not None else 1 << 62)
+        assert enc["n_cells"] == len(want) and len(want) > 0
+        assert _decode(enc) == want
+        assert np.all(np.diff(enc["rows"].astype(np.int64)) > 0)
+        if case == "wide-q":
+            assert max(v for _, _, v in want) > 255
+        ss.close()
+    finally:
+        ctx.set_option("stream_block_rows", 0)
+
+
+def _write_db(path, sk):
+    os.makedirs(path)
+    sk.astype("<i4").tofile(os.path.join(path, "vectors.bin"))
+    with open(os.path.join(path, "vector_norms.txt"), "w") as f:
+        f.write("".join("s%d %s\n" % (i, orc.format_norm(orc.norm(r))) for i, r in enumerate(sk)))
+    open(os.path.join(path, "dimension.txt"), "w").write("%d\n" % sk.shape[1])
+    open(os.path.join(path, "dtype.txt"), "w").write("int32\n")
+
+
+@pytest.mark.parametrize("case", ["sparse", "dense", "toy"])
+def test_device_and_host_encoder_write_the_same_files(gold, tmp_path, case):
+    if case == "sparse":
+        sk = synth.make_sketches_numpy(5000, 512, 3000, seed=5, cluster=8)
+    elif case == "dense":
+        sk = synth.make_sketches_numpy(3000, 256, 3000, seed=77, cluster=1000, shared=0.6)
+    else:
+        sk = gold.vectors
+    db = str(tmp_path / "db") + "/"
+    _write_db(db, sk)
+    files = {}
+    for enc in ("device", "host"):
+        out = str(tmp_path / ("idx_" + enc))
+        for shard in range(2):
+            env = dict(os.environ, MVS_SHARD_ENCODER=enc, MVS_STAGE_TIMING="1")
+            r = subprocess.run([os.path.join(BIN, "pairwise_comp_optimized"), "--db", db, "--max_memory_gb", "1", "--num_threads", "4",
+                                "--output_folder", out, "--num_shards", "2", "--shard_idx", str(shard)],
+                               capture_output=True, text=True, env=env)
+            assert r.returncode == 0, r.stderr
+            assert ("rows encoded on the " + enc) in r.stderr
+            for f in ("matrix.bin", "row_index.bin", "neighbor_start.bin"):
+                files[(enc, shard, f)] = open(os.path.join(out, "shard_%d" % shard, f), "rb").read()
+            files[(enc, shard, "stdout")] = [l for l in r.stdout.split("\n") if l.startswith("Jac space")]
+    for (enc, shard, f), data in files.items():
+        if enc == "device":
+            assert data == files[("host", shard, f)], (shard, f)
+            assert len(data) > 0
