@@ -246,6 +246,7 @@ const OptionSpec kOptions[] = {
     {"recheck_mode", &mvs::Options::recheck_mode, nullptr, 0, 3},
     {"recheck_blocks", &mvs::Options::recheck_blocks, nullptr, 1, 64},
     {"stream_dense", &mvs::Options::stream_dense, nullptr, 0, 1},
+    {"encode_stage_words", &mvs::Options::encode_stage_words, nullptr, 1, 64},
     {"stream_block_rows", &mvs::Options::stream_block_rows, nullptr, 0, 1 << 30},
     {"pairwise_block_cells", nullptr, &mvs::Options::pairwise_block_cells, 1, (1LL << 62)},
 };
@@ -1623,7 +1624,8 @@ int encode_block(mvs_ctx* c, BlockCsr& b) {
     if (rc) return rc;
     HIP_TRY(hipMemsetAsync(c->st_enc[b.set], 0, total, c->stream));       // the unary parts are OR-ed into zeroed words
     mvs::launch_encode_fill(c->stream, (const long long*)c->st_rowptr, (const int32_t*)c->st_col[b.set], c->st_q[b.set], qb, rows,
-                            (const unsigned long long*)c->en_off, (const mvs::EncRow*)c->en_par, (unsigned char*)c->st_enc[b.set]);
+                            (const unsigned long long*)c->en_off, (const mvs::EncRow*)c->en_par, (unsigned char*)c->st_enc[b.set],
+                            c->opt.encode_stage_words);
     rc = check_kernel("k_enc_fill");
     if (rc) return rc;
     HIP_TRY(hipEventRecord(c->dl_ready, c->stream));

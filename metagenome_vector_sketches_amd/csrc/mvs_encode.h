@@ -22,9 +22,11 @@ int launch_encode_sizes(hipStream_t stream, const long long* d_row_ptr, const in
 // offsets = exclusive scan of size over rows + 1 entries (size[rows] must be 0): offset[rows] = total bytes
 int encode_offsets(hipStream_t stream, unsigned long long* d_size, unsigned long long* d_offset, int64_t rows, void* d_scratch,
                    size_t scratch_bytes, size_t* scratch_needed);
-// Pass 2, one wave per row: the records, back to back, into d_out (zero-filled by the caller, 8-byte aligned)
+// Pass 2, one wave per row: the records, back to back, into d_out (zero-filled by the caller, 8-byte aligned).
+// stage_words (1..64): words of LDS a chunk of 64 unary codes may span before the kernel falls back to atomics (64; tests
+// lower it to exercise the fallback)
 int launch_encode_fill(hipStream_t stream, const long long* d_row_ptr, const int32_t* d_col, const void* d_q, int q_bytes,
-                       int64_t rows, const unsigned long long* d_offset, const EncRow* d_par, unsigned char* d_out);
+                       int64_t rows, const unsigned long long* d_offset, const EncRow* d_par, unsigned char* d_out, int stage_words);
 
 }  // namespace mvs
 

@@ -50,6 +50,7 @@ struct Options {
     int pairwise_map = 0;           // sub-patch an XCD takes in k_pairwise_pp: 0 = 4 rows x 8 cols, 1 = 8 x 4, 2 = 2 x 16
     int coarse_radix = 1;           // radix of the filter's coarse plane: 1 = smallest residual (default), 0 = ceil(max|v| / 127)
     int stream_dense = 1;           // mvs_pairwise_stream, exact kernel: 1 = dense byte matrix + count / scan / fill, 0 = packed list + sort
+    int encode_stage_words = 64;    // device encoder: LDS words a chunk of unary codes may span before it falls back to atomics (tests)
     int stream_block_rows = 0;      // > 0: upper bound on the rows of a dense row block (tests); 0 = by the budget
     int recheck_mode = 1;           // re-check work split: 1 first round fixed + per-XCD counter, 2 counter only, 0 fixed stride, 3 eighths
     int recheck_blocks = 24;        // re-check grid in units of 256 workgroups (24: one round per wave at 100k samples)

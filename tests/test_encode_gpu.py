@@ -96,16 +96,18 @@ def _cells(cells, rb=0, re=1 << 62):
     return [(int(c["row"]), int(c["col"]), int(c["q"])) for c in cells if rb <= c["row"] < re]
 
 
-@pytest.mark.parametrize("case", ["sparse", "dense-blocks", "one-limb-packed", "wide-q", "toy"])
+@pytest.mark.parametrize("case", ["sparse", "dense-blocks", "dense-small-stage", "one-limb-packed", "wide-q", "toy"])
 def test_encoded_rows_decode_to_the_cell_list(ctx, gold, case):
     budget, rb, re = 0, 0, None
     if case == "sparse":
         sk = synth.make_sketches_numpy(700, 512, 3000, seed=5, cluster=8)
         ctx.set_option("pairwise_filter", 2)
         rb, re = 100, 650
-    elif case == "dense-blocks":       # rows of ~170 cells: several 64-value chunks per row, whole-square dense blocks
+    elif case in ("dense-blocks", "dense-small-stage"):   # rows of ~500 cells: several 64-value chunks per row
         sk = synth.make_sketches_numpy(1500, 256, 3000, seed=77, cluster=500, shared=0.6)
         ctx.set_option("stream_block_rows", 256)
+        if case == "dense-small-stage":    # a stage of one word: most chunks of unary codes take the atomics fall-back
+            ctx.set_option("encode_stage_words", 1)
     elif case == "one-limb-packed":    # |v| <= 127: the 32x32x32 kernel, packed list, blocks sized for the worst case
         sk = np.clip(synth.make_sketches_numpy(600, 256, 300, seed=3, cluster=50, shared=0.6), -127, 127).astype(np.int32)
         budget = 1 << 20
@@ -131,6 +133,7 @@ def test_encoded_rows_decode_to_the_cell_list(ctx, gold, case):
         ss.close()
     finally:
         ctx.set_option("stream_block_rows", 0)
+        ctx.set_option("encode_stage_words", 64)
 
 
 def _write_db(path, sk):

@@ -18,6 +18,7 @@ from metagenome_vector_sketches_amd import _capi, synth
 
 n, d, cluster = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 reps = int(sys.argv[4]) if len(sys.argv) > 4 else 3
+encoded = len(sys.argv) > 5 and sys.argv[5] == "encoded"     # rows encoded in the shard codec on the device
 ctx = pkg.Context(0)
 ctx.set_stream(torch.cuda.current_stream())
 ctx.set_timing(True)
@@ -38,15 +39,15 @@ def count(_user, bp):
     return 0
 
 
-cb = _capi.ROW_BLOCK_CB(count)
+cb = (_capi.ENCODED_ROWS_CB if encoded else _capi.ROW_BLOCK_CB)(count)
+entry = ctx.lib.mvs_pairwise_stream_encoded if encoded else ctx.lib.mvs_pairwise_stream
 res = []
 for r in range(reps + 1):
     seen.update(cells=0, pieces=0, rows=0)
     cnt = ctypes.c_int64()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    rc = ctx.lib.mvs_pairwise_stream(ctx._h, sset._h, n2.data_ptr(), _capi.MEM_DEVICE, _capi.KEEP_INT32, 0, n, 0, cb, None,
-                                     ctypes.byref(cnt))
+    rc = entry(ctx._h, sset._h, n2.data_ptr(), _capi.MEM_DEVICE, _capi.KEEP_INT32, 0, n, 0, cb, None, ctypes.byref(cnt))
     wall = time.perf_counter() - t0
     assert rc == 0, ctx.lib.mvs_last_error()
     st = ctx.stream_stats()
@@ -71,7 +72,7 @@ for _ in range(3):
     link.append((time.perf_counter() - t0) * 1e3)
 wall = float(np.mean([w for w, _ in res]))
 kern = float(np.mean([s["kernel_ms"] for _, s in res]))
-out = {"n": n, "d": d, "cluster": cluster, "kept_cells": int(cnt.value), "density": cnt.value / float(n) / n,
+out = {"n": n, "d": d, "cluster": cluster, "form": "encoded rows" if encoded else "CSR (col int32, q uint8)", "kept_cells": int(cnt.value), "density": cnt.value / float(n) / n,
        "wall_ms": wall, "kernels_ms": kern, "bytes": int(nbytes), "link_ms": min(link),
        "link_GBps": nbytes / (min(link) * 1e-3) / 1e9, "wall_over_max_kernel_link": wall / max(kern, min(link)),
        "cells_per_s": float(n) * n / (wall * 1e-3), "kept_cells_per_s": cnt.value / (wall * 1e-3),
