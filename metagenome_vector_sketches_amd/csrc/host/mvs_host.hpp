@@ -506,28 +506,43 @@ class ShardWriter {
 public:
     explicit ShardWriter(const std::string& folder, unsigned threads = 0) : folder_(folder), threads_(threads) {
         if (!fs::exists(folder_)) fs::create_directories(folder_);
-        bin_out_.open(folder_ + "matrix.bin", std::ios::binary);
+        bin_fd_ = ::open((folder_ + "matrix.bin").c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+        if (bin_fd_ < 0) throw std::runtime_error("ShardWriter: cannot create " + folder_ + "matrix.bin");
         if (threads_ == 0) threads_ = std::max(1u, std::thread::hardware_concurrency());
-        // matrix.bin is written by a thread of its own: the encoded rows of a piece go to the file while the next piece
-        // is being encoded (at most a few pieces wait in the queue)
-        file_thread_ = std::thread([this] {
-            for (;;) {
-                std::string bytes;
-                {
-                    std::unique_lock<std::mutex> lk(mu_);
-                    cv_.wait(lk, [this] { return closing_ || !pending_.empty(); });
-                    if (pending_.empty()) return;
-                    bytes = std::move(pending_.front());
-                    pending_.pop_front();
+        // matrix.bin is written by a few threads of its own (pwrite at the position every run of bytes is known to have):
+        // the encoded rows of a piece go to the file while the next piece is being encoded or downloaded, and one thread
+        // copying into the page cache would be what bounds a dense shard (1.4 GB at ~3 GB/s)
+        for (int t = 0; t < 4; ++t)
+            file_threads_.emplace_back([this] {
+                for (;;) {
+                    Job job;
+                    {
+                        std::unique_lock<std::mutex> lk(mu_);
+                        cv_.wait(lk, [this] { return closing_ || !pending_.empty(); });
+                        if (pending_.empty()) return;
+                        job = std::move(pending_.front());
+                        pending_.pop_front();
+                    }
+                    cv_.notify_all();
+                    size_t done = 0;
+                    while (done < job.bytes.size()) {
+                        const ssize_t w = ::pwrite(bin_fd_, job.bytes.data() + done, job.bytes.size() - done, (off_t)(job.pos + done));
+                        if (w <= 0) {
+                            std::lock_guard<std::mutex> lk(mu_);
+                            write_failed_ = true;
+                            break;
+                        }
+                        done += (size_t)w;
+                    }
                 }
-                cv_.notify_all();
-                bin_out_.write(bytes.data(), (std::streamsize)bytes.size());
-            }
-        });
+            });
     }
     ShardWriter(const ShardWriter&) = delete;
     ShardWriter& operator=(const ShardWriter&) = delete;
-    ~ShardWriter() { stop_file_thread(); }
+    ~ShardWriter() {
+        stop_file_threads();
+        if (bin_fd_ >= 0) ::close(bin_fd_);
+    }
 
     void add(const mvs_row_block& b) {
         const int64_t rows = b.row_end - b.row_begin;
@@ -621,13 +636,9 @@ public:
             if (!parts[t].error.empty()) throw std::runtime_error(parts[t].error);
             const size_t r0 = cut[t], r1 = cut[t + 1];
             for (size_t r = r0; r < r1; ++r) curr_pos_vec_[first + r] += pos_;
+            const uint64_t at = pos_;
             pos_ += parts[t].bytes.size();
-            {
-                std::unique_lock<std::mutex> lk(mu_);
-                cv_.wait(lk, [this] { return pending_.size() < 64; });
-                pending_.push_back(std::move(parts[t].bytes));
-            }
-            cv_.notify_all();
+            enqueue(at, std::move(parts[t].bytes));
             stats_.jac_space += parts[t].jac_space;
             stats_.ngh_space += parts[t].ngh_space;
         }
@@ -649,20 +660,22 @@ public:
         }
         stats_.jac_space += jac;
         stats_.ngh_space += (uint64_t)b.n_bytes - jac;
+        // the pinned buffer is only valid during the call: the piece is copied once, in a few runs so that the file threads
+        // share it
+        const uint64_t at = pos_;
         pos_ += (uint64_t)b.n_bytes;
-        {
-            std::unique_lock<std::mutex> lk(mu_);
-            cv_.wait(lk, [this] { return pending_.size() < 64; });
-            pending_.emplace_back(reinterpret_cast<const char*>(b.bytes), (size_t)b.n_bytes);   // the pinned buffer is only valid during the call
-        }
-        cv_.notify_all();
+        const size_t run = 8u << 20;
+        for (size_t o = 0; o < (size_t)b.n_bytes; o += run)
+            enqueue(at + o, std::string(reinterpret_cast<const char*>(b.bytes) + o, std::min(run, (size_t)b.n_bytes - o)));
     }
 
     uint64_t cells() const { return cells_; }
 
     ShardStats finish() {
-        stop_file_thread();
-        bin_out_.close();
+        stop_file_threads();
+        if (bin_fd_ >= 0) ::close(bin_fd_);
+        bin_fd_ = -1;
+        if (write_failed_) throw std::runtime_error("ShardWriter: writing " + folder_ + "matrix.bin failed");
         std::ofstream index_out(folder_ + "row_index.bin", std::ios::binary);
         stats_.rows = row_vec_.size();
         mvs_codec::compact_vector cv_rows;                          // row ids, then byte-offset deltas (:769-783)
@@ -683,22 +696,36 @@ public:
     }
 
 private:
-    void stop_file_thread() {
+    struct Job {
+        uint64_t pos = 0;
+        std::string bytes;
+    };
+    void enqueue(uint64_t pos, std::string&& bytes) {
+        if (bytes.empty()) return;
+        {
+            std::unique_lock<std::mutex> lk(mu_);
+            cv_.wait(lk, [this] { return pending_.size() < 64; });
+            pending_.push_back(Job{pos, std::move(bytes)});
+        }
+        cv_.notify_all();
+    }
+    void stop_file_threads() {
         {
             std::lock_guard<std::mutex> lk(mu_);
             closing_ = true;
         }
         cv_.notify_all();
-        if (file_thread_.joinable()) file_thread_.join();
+        for (auto& th : file_threads_)
+            if (th.joinable()) th.join();
     }
     std::string folder_;
     unsigned threads_;
-    std::ofstream bin_out_;
-    std::thread file_thread_;
+    int bin_fd_ = -1;
+    std::vector<std::thread> file_threads_;
     std::mutex mu_;
     std::condition_variable cv_;
-    std::deque<std::string> pending_;
-    bool closing_ = false;
+    std::deque<Job> pending_;
+    bool closing_ = false, write_failed_ = false;
     uint64_t pos_ = 0, cells_ = 0;
     int64_t next_row_ = 0;
     std::vector<uint32_t> row_vec_, start_neighbor_;
