@@ -700,6 +700,22 @@ def stream_leg(ctx, dev, n, d, nh, reps=3):
         if r:
             walls.append(wall)
             stats = ctx.stream_stats()
+    # the same rows ENCODED on the device in the shard codec (what the executable does): fewer bytes, no host work per cell
+    ecb = _capi.ENCODED_ROWS_CB(count)
+    ewalls, estats = [], None
+    for r in range(reps + 1):
+        seen.update(cells=0, rows=0)
+        cnt2 = ctypes.c_int64()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        rc = ctx.lib.mvs_pairwise_stream_encoded(ctx._h, sset._h, n2.data_ptr(), _capi.MEM_DEVICE, _capi.KEEP_INT32, 0, n, 0, ecb,
+                                                 None, ctypes.byref(cnt2))
+        ewall = (time.perf_counter() - t0) * 1e3
+        if rc != 0 or cnt2.value != cnt.value or seen["rows"] != n:
+            raise SystemExit("streamed comparison (encoded rows) failed: rc %d, %d of %d cells" % (rc, cnt2.value, cnt.value))
+        if r:
+            ewalls.append(ewall)
+            estats = ctx.stream_stats()
     sset.close()
     nbytes = max(stats["bytes"], 1)
     piece = min(nbytes, 32 << 20)
@@ -721,7 +737,12 @@ def stream_leg(ctx, dev, n, d, nh, reps=3):
             "bytes_to_host": int(nbytes), "bytes_per_kept_cell": nbytes / max(cnt.value, 1),
             "bare_link_ms": min(link), "link_GBps": nbytes / (min(link) * 1e-3) / 1e9,
             "pcie_share_of_wall": min(link) / wall, "wall_over_max_kernel_link": wall / max(stats["kernel_ms"], min(link)),
-            "cells_per_s": float(n) * n / (wall * 1e-3), "kept_cells_per_s": cnt.value / (wall * 1e-3)}
+            "cells_per_s": float(n) * n / (wall * 1e-3), "kept_cells_per_s": cnt.value / (wall * 1e-3),
+            "encoded_rows": {"what": "mvs_pairwise_stream_encoded: rows in the shard codec (compact_vector of q + rice_sequence of the "
+                                     "column deltas) encoded on the device, the bytes matrix.bin holds",
+                             "wall_ms": float(np.mean(ewalls)), "bytes_to_host": int(estats["bytes"]),
+                             "bytes_per_kept_cell": estats["bytes"] / max(cnt.value, 1),
+                             "kept_cells_per_s": cnt.value / (float(np.mean(ewalls)) * 1e-3)}}
 
 
 def usable_cores(visible):
