@@ -208,6 +208,7 @@ class Comm:
 
     def __init__(self, ctx, handle, keep=None):
         self.ctx, self._h, self._keep = ctx, handle, keep
+        ctx._comms.add(self)             # a communicator holds a pointer to its context: closed before the context is
         r, w, k = _c.c_int(), _c.c_int(), _c.c_int()
         _check(ctx.lib.mvs_comm_info(handle, r, w, k))
         self.rank, self.world, self.is_rccl = r.value, w.value, bool(k.value)
@@ -271,6 +272,7 @@ class Context:
         self._h = h
         self.device = device
         self._sets = weakref.WeakSet()   # sketch sets hold a pointer to the context: close them first
+        self._comms = weakref.WeakSet()  # communicators likewise
         if stream is not None:
             self.set_stream(stream)
 
@@ -278,6 +280,8 @@ class Context:
         if getattr(self, "_h", None):
             for s in list(self._sets):
                 s.close()
+            for m in list(self._comms):
+                m.close()
             self.lib.mvs_ctx_destroy(self._h)
             self._h = None
 
