@@ -260,6 +260,15 @@ def main():
     ctx.set_timing(True)
     from metagenome_vector_sketches_amd import parallel, _capi
     coll, coll_note = None, None
+
+    def shutdown():
+        """collective teardown while every rank is still alive: the native communicator (ncclCommDestroy, or the file
+        transport's last hand-shake) before the process group"""
+        comm = getattr(coll, "comm", None)
+        if comm is not None:
+            comm.close()
+        if world > 1:
+            dist.destroy_process_group()
     if world > 1:
         # The data path's collectives go through the C ABI's communicator.  It gets a context of its own on a SIDE stream
         # so that the exchange of the rows a rank has finished can run beside the projection of the rest (parallel.py:
@@ -293,8 +302,7 @@ def main():
         res = strong_scaling(args, ctx, dev, rank, world, dist if world > 1 else None, coll, coll_note)
         if rank == 0:
             print(json.dumps(res))
-        if world > 1:
-            dist.destroy_process_group()
+        shutdown()
         return
 
     # ---- synthetic input, resident in HBM ----
@@ -378,8 +386,7 @@ def main():
         kept_total = state["cnt"]
 
     if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
+        shutdown()
         return
 
     ms_per_step = elapsed / args.steps * 1e3
@@ -500,8 +507,7 @@ def main():
             res["pairwise"]["vs_cpu_port_all_cores"] = res["pairwise"]["cells_per_s"] / res["cpu_baseline"]["pairwise_cells_per_s"]
 
     print(json.dumps(res))
-    if world > 1:
-        dist.destroy_process_group()
+    shutdown()
 
 
 def comm_facts(coll, world):

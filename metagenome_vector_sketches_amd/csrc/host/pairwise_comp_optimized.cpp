@@ -4,6 +4,7 @@
 //
 //   pairwise_comp_optimized --db D/ --max_memory_gb G --num_threads T --output_folder O
 //                           --num_shards S --shard_idx k [--start_shard a] [--end_shard b] [--help]
+//   (extension: --shard_idx -1 computes ALL S shards from this one process on all visible GPUs)
 //
 // Multi-GPU: the reference runs one process per shard and every process re-reads the whole vectors.bin
 // (src/pairwise_comp_optimized.cpp:953,962).  Started the same way -- one process per shard, --shard_idx k on GPU
@@ -18,6 +19,7 @@
 // build's own (the reference's `bits` library is not available); the int16 DB path writes the active
 // shard format instead of the legacy EF+zstd one.
 #include <chrono>
+#include <functional>
 #include <memory>
 
 #include "mvs_host.hpp"
@@ -294,6 +296,127 @@ static int compare_rows(Gpu& g, const std::vector<double>& n2, int keep_mode, in
     return 0;
 }
 
+// One shard: rows [begin_row, end_row) against all columns, streamed into <shard_folder>.  The comparison hands over CSR
+// pieces of whole rows (ascending) -- by default with the rows already encoded in the shard codec ON THE DEVICE (1.4 bytes
+// per kept cell on the link instead of 5, no host thread touches a cell); MVS_SHARD_ENCODER=host takes (column, q) pieces
+// and encodes them on the host threads instead: the same files, byte for byte.  Where the reference keeps every kept cell
+// of the shard in RAM (`all_results`, :974-980) this holds two pinned pieces and the per-row directory.
+static int stream_shard(Gpu& g, const std::vector<double>& norms_sq, int keep_mode, int64_t begin_row, int64_t end_row,
+                        const std::string& shard_folder, bool stage_timing, int64_t* n_kept, ShardStats* stats,
+                        const std::function<void(const char*)>& lap) {
+    struct Sink {
+        ShardWriter writer;
+        std::string error;
+        static int on_block(void* user, const mvs_row_block* b) {
+            Sink* self = static_cast<Sink*>(user);
+            try {
+                self->writer.add(*b);
+                return 0;
+            } catch (const std::exception& e) {
+                self->error = e.what();
+                return 1;
+            }
+        }
+        static int on_encoded(void* user, const mvs_encoded_rows* b) {
+            Sink* self = static_cast<Sink*>(user);
+            try {
+                self->writer.add_encoded(*b);
+                return 0;
+            } catch (const std::exception& e) {
+                self->error = e.what();
+                return 1;
+            }
+        }
+    } sink{ShardWriter(shard_folder), std::string()};
+    const char* enc = getenv("MVS_SHARD_ENCODER");
+    const bool host_encoder = enc && std::string(enc) == "host";
+    const int stream_rc =
+        host_encoder ? mvs_pairwise_stream(g.ctx, g.set, norms_sq.data(), MVS_MEM_HOST, keep_mode, begin_row, end_row, 0,
+                                           &Sink::on_block, &sink, n_kept)
+                     : mvs_pairwise_stream_encoded(g.ctx, g.set, norms_sq.data(), MVS_MEM_HOST, keep_mode, begin_row, end_row, 0,
+                                                   &Sink::on_encoded, &sink, n_kept);
+    if (stream_rc != MVS_OK) {
+        if (!sink.error.empty()) std::cerr << "pairwise_comp_optimized: " << sink.error << std::endl;
+        return gpu_fail("pairwise comparison");
+    }
+    lap("compare + shard rows (streamed)");
+    if (stage_timing) {
+        double kms = 0.0;
+        int64_t bytes = 0, blocks = 0, pieces = 0;
+        int two = 0;
+        mvs_ctx_stream_stats(g.ctx, &kms, &bytes, &blocks, &pieces, &two);
+        std::cerr << "[stream] comparison kernels " << kms << " ms in " << blocks << " row block(s) ("
+                  << (two ? "two-stage" : "exact kernel") << "), " << *n_kept << " kept cells = " << bytes << " bytes in "
+                  << pieces << " piece(s), rows encoded on the " << (host_encoder ? "host" : "device") << std::endl;
+    }
+    try {
+        *stats = sink.writer.finish();                                                              // :990
+    } catch (const std::exception& e) {
+        std::cerr << "pairwise_comp_optimized: " << e.what() << std::endl;
+        return 2;
+    }
+    lap("shard index files");
+    return 0;
+}
+
+// --shard_idx -1 (an extension: the reference needs one process per shard): ALL shards from this one process, on all
+// visible GPUs -- one device context and host thread per GPU, the whole vectors.bin resident on each (what each of the
+// reference's shard processes reads too, :953-962), shard s computed by GPU s mod G.  MVS_DEVICE pins the work to one
+// device; MVS_PAIRWISE_CONTEXTS=k asks for k contexts (cycling over the devices: k = 2 on a one-GPU box runs the
+// multi-context path on device 0).
+static int run_all_shards(const Options& o, const std::string& output_folder, const std::string& matrix_file, int elem_bytes,
+                          int64_t total_vectors, int dimension, const std::vector<double>& norms_sq, int keep_mode, bool stage_timing) {
+    std::vector<int> devices;
+    {
+        int ndev = 0;
+        if (getenv("MVS_DEVICE") || mvs_device_count(&ndev) != MVS_OK || ndev <= 0) {
+            devices.push_back(pick_device());
+        } else {
+            int want = std::min(ndev, std::max(1, o.num_shards));
+            if (const char* e = getenv("MVS_PAIRWISE_CONTEXTS")) want = std::max(1, std::min(64, atoi(e)));
+            for (int i = 0; i < want; ++i) devices.push_back(i % ndev);
+        }
+    }
+    const size_t n_ctx = devices.size();
+    std::mutex out_mu;
+    std::vector<int> status(n_ctx, 0);
+    auto work = [&](size_t gi) {
+        Gpu g;
+        if (mvs_ctx_create(devices[gi], &g.ctx) != MVS_OK) {
+            std::lock_guard<std::mutex> lk(out_mu);
+            status[gi] = gpu_fail("creating context");
+            return;
+        }
+        if (stage_timing) mvs_ctx_set_timing(g.ctx, 1);
+        int rc = load_db(g, matrix_file, elem_bytes, total_vectors, dimension);
+        for (int shard = (int)gi; shard < o.num_shards && !rc; shard += (int)n_ctx) {
+            const std::string shard_folder = output_folder + "shard_" + std::to_string(shard) + "/";
+            int64_t b = 0, e = 0, kept = 0;
+            mvs_shard_rows(total_vectors, o.num_shards, shard, &b, &e);
+            {
+                std::lock_guard<std::mutex> lk(out_mu);
+                std::cout << "Shard " << shard << " processing rows " << b << " to " << e << std::endl;   // :941
+            }
+            ShardStats st;
+            rc = stream_shard(g, norms_sq, keep_mode, b, e, shard_folder, stage_timing, &kept, &st, [](const char*) {});
+            std::lock_guard<std::mutex> lk(out_mu);
+            if (!rc) std::cout << "Jac space: " << st.jac_space << " ngh space: " << st.ngh_space << std::endl;   // :808
+        }
+        status[gi] = rc;
+    };
+    if (n_ctx == 1) {
+        work(0);
+    } else {
+        std::vector<std::thread> pool;
+        for (size_t gi = 0; gi < n_ctx; ++gi) pool.emplace_back(work, gi);
+        for (auto& th : pool) th.join();
+    }
+    if (stage_timing) std::cerr << "[stage] " << o.num_shards << " shards on " << n_ctx << " context(s)" << std::endl;
+    for (int rc : status)
+        if (rc) return rc;
+    return 0;
+}
+
 int main(int argc, char* argv[]) {
     Options o;
     if (!parse(argc, argv, o) || o.show_help) {                                   // :846-850
@@ -355,6 +478,20 @@ int main(int argc, char* argv[]) {
     }
     auto start_time = std::chrono::high_resolution_clock::now();                  // :918
 
+    if (o.shard_idx == -1) {
+        if (int16 && legacy16_output()) {
+            std::cerr << "pairwise_comp_optimized: --shard_idx -1 (all shards) writes the active shard format only" << std::endl;
+            return 1;
+        }
+        db.norms_sq.resize((size_t)total_vectors);
+        const int rc_all = run_all_shards(o, output_folder, matrix_file, elem_bytes, total_vectors, dimension, db.norms_sq,
+                                          int16 ? MVS_KEEP_INT16 : MVS_KEEP_INT32, getenv("MVS_STAGE_TIMING") != nullptr);
+        if (rc_all) return rc_all;
+        auto end_time = std::chrono::high_resolution_clock::now();
+        auto duration = std::chrono::duration_cast<std::chrono::milliseconds>(end_time - start_time);
+        std::cout << "Total computation time: " << duration.count() << " ms" << std::endl;
+        return 0;
+    }
     const std::string shard_folder = output_folder + "shard_" + std::to_string(o.shard_idx) + "/";   // :932-935
     if (!fs::exists(shard_folder)) fs::create_directories(shard_folder);
     int64_t begin_row = 0, end_row = 0;
@@ -424,66 +561,16 @@ int main(int argc, char* argv[]) {
         lap("write shard (legacy int16 format)");
         return 0;
     }
-    // The comparison streams its result out in CSR pieces of whole rows (ascending); the writer appends each piece to
-    // matrix.bin while the device computes and downloads the next one.  Where the reference keeps every kept cell of the
-    // shard in RAM (`all_results`, :974-980) this holds two pinned pieces and the per-row directory.
-    struct Sink {
-        ShardWriter writer;
-        std::string error;
-        static int on_block(void* user, const mvs_row_block* b) {
-            Sink* self = static_cast<Sink*>(user);
-            try {
-                self->writer.add(*b);
-                return 0;
-            } catch (const std::exception& e) {
-                self->error = e.what();
-                return 1;
-            }
-        }
-        static int on_encoded(void* user, const mvs_encoded_rows* b) {
-            Sink* self = static_cast<Sink*>(user);
-            try {
-                self->writer.add_encoded(*b);
-                return 0;
-            } catch (const std::exception& e) {
-                self->error = e.what();
-                return 1;
-            }
-        }
-    } sink{ShardWriter(shard_folder), std::string()};
     int64_t n_kept = 0;
-    // The rows are encoded in the shard codec ON THE DEVICE (1.4 bytes per kept cell on the link instead of 5, no host
-    // thread touches a cell); MVS_SHARD_ENCODER=host streams (column, q) pieces and encodes them on the host threads
-    // instead -- the same files, byte for byte.
-    const char* enc = getenv("MVS_SHARD_ENCODER");
-    const bool host_encoder = enc && std::string(enc) == "host";
-    const int stream_rc =
-        host_encoder ? mvs_pairwise_stream(g.ctx, g.set, db.norms_sq.data(), MVS_MEM_HOST, keep_mode, begin_row, end_row, 0,
-                                           &Sink::on_block, &sink, &n_kept)
-                     : mvs_pairwise_stream_encoded(g.ctx, g.set, db.norms_sq.data(), MVS_MEM_HOST, keep_mode, begin_row, end_row, 0,
-                                                   &Sink::on_encoded, &sink, &n_kept);
-    if (stream_rc != MVS_OK) {
-        if (!sink.error.empty()) std::cerr << "pairwise_comp_optimized: " << sink.error << std::endl;
-        return gpu_fail("pairwise comparison");
-    }
-    lap("compare + shard rows (streamed)");
-    if (stage_timing) {
-        double kms = 0.0;
-        int64_t bytes = 0, blocks = 0, pieces = 0;
-        int two = 0;
-        mvs_ctx_stream_stats(g.ctx, &kms, &bytes, &blocks, &pieces, &two);
-        std::cerr << "[stream] comparison kernels " << kms << " ms in " << blocks << " row block(s) ("
-                  << (two ? "two-stage" : "exact kernel") << "), " << n_kept << " kept cells = " << bytes << " bytes in "
-                  << pieces << " piece(s), rows encoded on the " << (host_encoder ? "host" : "device") << std::endl;
-    }
+    ShardStats st;
+    rc = stream_shard(g, db.norms_sq, keep_mode, begin_row, end_row, shard_folder, stage_timing, &n_kept, &st, lap);
+    if (rc) return rc;
     if (int16) {                                                                  // _16bits.cpp:419-423
         auto end_time = std::chrono::high_resolution_clock::now();
         auto duration = std::chrono::duration_cast<std::chrono::milliseconds>(end_time - start_time);
         std::cout << "Total computation time: " << duration.count() << " ms" << std::endl;
         std::cout << "Total results: " << n_kept << std::endl;
     }
-    const ShardStats st = sink.writer.finish();                                                      // :990
-    lap("shard index files");
     std::cout << "Jac space: " << st.jac_space << " ngh space: " << st.ngh_space << std::endl;        // :808
     if (!int16) {                                                                 // :993-996
         auto end_time = std::chrono::high_resolution_clock::now();

@@ -174,6 +174,37 @@ def test_pairwise_on_reference_db(gold, tmp_path):
     assert got == want
 
 
+@pytest.mark.parametrize("contexts", [1, 2, 5])
+def test_pairwise_all_shards_from_one_process(gold, tmp_path, contexts):
+    """--shard_idx -1 (extension): all shards from one process, one device context and host thread per GPU, shard s on GPU
+    s mod G (MVS_PAIRWISE_CONTEXTS puts the contexts on device 0 of the one-GPU box): the same shard files as one process
+    per shard, which is how the reference distributes (src/pairwise_comp_optimized.cpp:937-940)"""
+    db = str(tmp_path / "refdb") + "/"
+    _write_ref_db(db, gold)
+    exe = os.path.join(BIN, "pairwise_comp_optimized")
+    ref = str(tmp_path / "per_shard")
+    for k in range(3):
+        r = run(exe, "--db", db, "--max_memory_gb", "12", "--num_threads", "8", "--output_folder", ref, "--num_shards", "3",
+                "--shard_idx", str(k))
+        assert r.returncode == 0, r.stderr
+    out = str(tmp_path / "all")
+    env = dict(os.environ, MVS_PAIRWISE_CONTEXTS=str(contexts), MVS_STAGE_TIMING="1")
+    env.pop("MVS_DEVICE", None)
+    r = subprocess.run([exe, "--db", db, "--max_memory_gb", "12", "--num_threads", "8", "--output_folder", out, "--num_shards", "3",
+                        "--shard_idx", "-1"], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    assert "3 shards on %d context(s)" % contexts in r.stderr
+    lines = r.stdout.strip().split("\n")
+    assert sum(l.startswith("Shard ") for l in lines) == 3 and sum(l.startswith("Jac space") for l in lines) == 3
+    assert lines[-1].startswith("Total computation time: ")
+    for k in range(3):
+        for f in ("matrix.bin", "row_index.bin", "neighbor_start.bin"):
+            a = open(os.path.join(out, "shard_%d" % k, f), "rb").read()
+            assert a == open(os.path.join(ref, "shard_%d" % k, f), "rb").read() and len(a) > 0, (k, f)
+    want = sorted((r_, c, q) for r_, c, _, q in gold.cells())
+    assert sum((_dump(os.path.join(out, "shard_%d" % k)) for k in range(3)), []) == want
+
+
 def test_pairwise_int16_db(gold, tmp_path):
     db = str(tmp_path / "refdb16") + "/"
     _write_ref_db(db, gold, "int16")
