@@ -162,22 +162,35 @@ bool read_u64(const std::string& p, unsigned long long* v) {
     return ok;
 }
 
-// this rank's files of any job under the prefix: "<prefix>_<anything>_<rank>" and "..._<rank>.<suffix>"
+// this rank's files of any job under the prefix -- exactly the names this transport creates, nothing else that happens
+// to share the prefix: <prefix>_<seq>_<rank>, <prefix>_hello_<rank>, <prefix>_ready_<rank>, each optionally followed by
+// ".part" (a write in progress) or ".ack<peer>"
 void remove_own_files(const std::string& prefix, int rank) {
     const size_t slash = prefix.find_last_of('/');
     const std::string dir = slash == std::string::npos ? "." : prefix.substr(0, slash + 1);
     const std::string stem = (slash == std::string::npos ? prefix : prefix.substr(slash + 1)) + "_";
     const std::string mine = "_" + std::to_string(rank);
+    auto all_digits = [](const std::string& t) {
+        if (t.empty()) return false;
+        for (char ch : t)
+            if (ch < '0' || ch > '9') return false;
+        return true;
+    };
     DIR* d = ::opendir(dir.c_str());
     if (!d) return;
     std::vector<std::string> victims;
     while (dirent* e = ::readdir(d)) {
         const std::string name = e->d_name;
-        if (name.compare(0, stem.size(), stem) != 0) continue;
+        if (name.size() <= stem.size() || name.compare(0, stem.size(), stem) != 0) continue;
         const size_t dot = name.find('.', stem.size());
-        const std::string core = name.substr(0, dot);                       // without ".part" / ".ackN"
-        if (core.size() >= stem.size() - 1 + mine.size() && core.compare(core.size() - mine.size(), mine.size(), mine) == 0)
-            victims.push_back((slash == std::string::npos ? std::string() : dir) + name);
+        const std::string core = name.substr(stem.size(), dot == std::string::npos ? std::string::npos : dot - stem.size());
+        const std::string suffix = dot == std::string::npos ? std::string() : name.substr(dot);
+        if (core.size() <= mine.size() || core.compare(core.size() - mine.size(), mine.size(), mine) != 0) continue;
+        const std::string kind = core.substr(0, core.size() - mine.size());          // "<seq>", "hello" or "ready"
+        if (!(all_digits(kind) || kind == "hello" || kind == "ready")) continue;
+        if (!(suffix.empty() || suffix == ".part" || (suffix.compare(0, 4, ".ack") == 0 && all_digits(suffix.substr(4)))))
+            continue;
+        victims.push_back((slash == std::string::npos ? std::string() : dir) + name);
     }
     ::closedir(d);
     for (const std::string& v : victims) ::unlink(v.c_str());
