@@ -188,8 +188,9 @@ void remove_own_files(const std::string& prefix, int rank) {
         if (core.size() <= mine.size() || core.compare(core.size() - mine.size(), mine.size(), mine) != 0) continue;
         const std::string kind = core.substr(0, core.size() - mine.size());          // "<seq>", "hello" or "ready"
         if (!(all_digits(kind) || kind == "hello" || kind == "ready")) continue;
-        if (!(suffix.empty() || suffix == ".part" || (suffix.compare(0, 4, ".ack") == 0 && all_digits(suffix.substr(4)))))
-            continue;
+        std::string sfx = suffix;
+        if (sfx.size() >= 5 && sfx.compare(sfx.size() - 5, 5, ".part") == 0) sfx.erase(sfx.size() - 5);   // a write in progress
+        if (!(sfx.empty() || (sfx.compare(0, 4, ".ack") == 0 && all_digits(sfx.substr(4))))) continue;
         victims.push_back((slash == std::string::npos ? std::string() : dir) + name);
     }
     ::closedir(d);
