@@ -136,6 +136,29 @@ def test_encoded_rows_decode_to_the_cell_list(ctx, gold, case):
         ctx.set_option("encode_stage_words", 64)
 
 
+@pytest.mark.parametrize("cluster", [2, 63, 64, 65, 128, 129, 193])
+def test_encoded_rows_at_chunk_borders(ctx, cluster):
+    """rows of exactly `cluster` cells (the encoder packs a row in chunks of 64 values: full chunks, one value more, one less,
+    several chunks), columns consecutive (Rice parameter 0) in one run, and with a second cluster far away in the same row
+    set (larger deltas, parameter > 0)"""
+    n = cluster * 3
+    sk = synth.make_sketches_numpy(n, 256, 3000, seed=cluster, cluster=cluster, shared=0.7)
+    n2 = _n2(sk)
+    ss = ctx.sketch_set(sk)
+    cells, cnt = ctx.pairwise_rows(ss, n2)
+    assert cnt >= n * cluster
+    enc = ctx.pairwise_stream_encoded(ss, n2)
+    assert enc["n_cells"] == cnt and _decode(enc) == _cells(cells)
+    ss.close()
+    # every second sample: the kept columns of a row are now 2 apart (a different Rice parameter)
+    idx = np.arange(0, n, 2)
+    ss = ctx.sketch_set(np.ascontiguousarray(sk[idx]))
+    cells, cnt = ctx.pairwise_rows(ss, n2[idx])
+    enc = ctx.pairwise_stream_encoded(ss, n2[idx])
+    assert enc["n_cells"] == cnt and _decode(enc) == _cells(cells)
+    ss.close()
+
+
 def _write_db(path, sk):
     os.makedirs(path)
     sk.astype("<i4").tofile(os.path.join(path, "vectors.bin"))
