@@ -514,8 +514,8 @@ def test_baseline_config5_full_size(ctx, tmp_path):
         mates incl. itself with q = 255, indices in range);
       * the exact kernel on a 65 536-row stripe gives the stripe's cells of the two-stage run bit for bit;
       * 24 rows against the oracle, column slab by column slab (the sketches go through the host 100k rows at a time);
-      * the executable on the same DB (written slab-wise, 8.2 GB vectors.bin) with --num_shards 8 and a staging
-        budget small enough that compare_rows() splits the shard's rows: same cells as the library call."""
+      * the executable on the same DB (written slab-wise, 8.2 GB vectors.bin) with --num_shards 8 (the shard's ~2.4 M kept
+        cells streamed out as device-encoded rows): same cells as the library call."""
     import subprocess
     import torch
     n, d = 1_000_000, 2048
@@ -571,7 +571,7 @@ def test_baseline_config5_full_size(ctx, tmp_path):
     lo, hi = np.searchsorted(rows, [q0, q0 + 24])
     assert sorted(want) == [tuple(int(x) for x in c) for c in two[lo:hi]]
 
-    # the executable, one of 8 shards, staging budget of 1M cells (< the shard's ~2.4M): rows are split
+    # the executable, one of 8 shards: ~2.4M kept cells streamed out through the pinned buffers
     db = str(tmp_path / "db1m") + "/"
     os.makedirs(db)
     with open(db + "vectors.bin", "wb") as f:
@@ -596,7 +596,7 @@ def test_baseline_config5_full_size(ctx, tmp_path):
     assert r.returncode == 0, r.stderr
     got = np.array([[int(t) for t in l.split()] for l in r.stdout.strip().split("\n") if l], dtype=np.int64)
     lo, hi = np.searchsorted(rows, [375_000, 500_000])
-    assert hi - lo > 1_000_000 and len(got) == hi - lo                       # more cells than the staging budget
+    assert hi - lo > 1_000_000 and len(got) == hi - lo
     assert np.array_equal(got, two[lo:hi][:, [0, 1, 3]].astype(np.int64))
 
 
