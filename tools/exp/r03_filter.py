@@ -93,7 +93,11 @@ if abl:
 zset.close()
 
 # what the operand VALUES cost: the same sketches with every entry made non-negative (|v|), and scaled down
-for label, sk in (("|v| (no sign changes)", real.abs()), ("v >> 2 (two fewer significant bits)", real >> 2)):
+# offset-coded operands: every entry shifted so that the coarse values centre on +32 / +64 instead of 0 (what an offset
+# coding of the coarse plane would feed the matrix cores; the radix grows with max|v|, so the spread shrinks a little)
+for label, sk in (("|v| (no sign changes)", real.abs()), ("v >> 2 (two fewer significant bits)", real >> 2),
+                  ("v + 32 m (coarse values centred on ~ +25)", real + 32 * 9), ("v + 64 m (centred on ~ +40)", real + 64 * 9),
+                  ("v + 300 m (all positive, narrow)", real + 300 * 9), ("-|v|", -real.abs())):
     s2, m2 = prep(sk.contiguous(), 1e6)
     run(label, "sketches " + label, s2, m2)
     s2.close()
