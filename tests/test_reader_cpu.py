@@ -178,6 +178,8 @@ def test_reader_and_codec_under_address_sanitizer(toy_index, gold, tmp_path):
     asan = os.path.join(BIN, "asan")
     r = run(os.path.join(asan, "mvs_codec_selftest"))
     assert r.returncode == 0 and "mvs_codec_selftest ok" in r.stdout, r.stderr
+    r = run(os.path.join(asan, "mvs_codec_selftest_tsan"))      # the shard writer's threads under ThreadSanitizer
+    assert r.returncode == 0 and "mvs_codec_selftest ok" in r.stdout and "ThreadSanitizer" not in r.stderr, r.stderr
     qf = tmp_path / "q.txt"
     qf.write_text("DRR000821\n10\nNOT_THERE\n")
     r = run(os.path.join(asan, "query_pc_mat"), "--matrix", idx[3], "--db", db, "--query_file", str(qf), "--top", "5")
