@@ -207,3 +207,13 @@ def test_stream_random_shapes(ctx, seed):
     finally:
         ctx.set_option("stream_dense", 1)
         ctx.set_option("stream_block_rows", 0)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_stream_fuzz_seeded(ctx, seed):
+    """a fixed handful of tests/fuzz_stream.py's random cases (sketch set x request x library switches): cell list vs the
+    oracle, CSR pieces and decoded device-encoded rows vs the cell list"""
+    import fuzz_stream
+    rng = np.random.default_rng(424242 + seed)
+    info = fuzz_stream.run_case(ctx, rng, max_n=900)
+    assert info["cells"] >= 0
