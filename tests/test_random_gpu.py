@@ -120,3 +120,13 @@ def test_blocks_and_search_two_stage_vs_exact(ctx, monkeypatch, seed):
         q0 = int(rng.integers(0, n - 8))
         both(lambda: ctx.search_block(ss, n2_t, j, q0, q0 + 8, 0, n, cells_t))
     ss.close()
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_projection_fuzz_seeded(ctx, seed):
+    """a fixed handful of tests/fuzz_project.py's random cases: sample sizes around the batch / unit borders, odd
+    dimensions, adversarial hash families (2^64 wrap, the shared round's carry hazard, consecutive runs), every kernel
+    variant, host / device input, fused statistics -- all against the oracle"""
+    import fuzz_project
+    info = fuzz_project.run_case(ctx, np.random.default_rng(515151 + seed), max_total=250_000)
+    assert info["samples"] >= 1
