@@ -66,6 +66,8 @@ struct mvs_ctx {
     hipEvent_t dl_done[2] = {nullptr, nullptr};   // download into pinned buffer i has completed
     hipEvent_t dl_block[2] = {nullptr, nullptr};  // the downloads out of CSR array set i have completed
     hipEvent_t dl_ready = nullptr;                // the CSR arrays of a row block are final on the compute stream
+    hipStream_t post_stream = nullptr;            // dense row blocks -> CSR / encoded rows beside the next block's comparison
+    hipEvent_t cmp_done = nullptr;                // the comparison launch of the block about to be post-processed is through
     // what the last mvs_pairwise_stream did (mvs_ctx_stream_stats)
     double st_kernel_ms = 0.0;                    // comparison kernels, summed over the row blocks (timing enabled)
     long long st_bytes = 0, st_blocks = 0, st_pieces = 0, st_two_stage = 0;
@@ -245,7 +247,7 @@ const OptionSpec kOptions[] = {
     {"cand_regions", &mvs::Options::cand_regions, nullptr, 0, 1},
     {"recheck_mode", &mvs::Options::recheck_mode, nullptr, 0, 3},
     {"recheck_blocks", &mvs::Options::recheck_blocks, nullptr, 1, 64},
-    {"stream_dense", &mvs::Options::stream_dense, nullptr, 0, 1},
+    {"stream_dense", &mvs::Options::stream_dense, nullptr, 0, 2},
     {"encode_stage_words", &mvs::Options::encode_stage_words, nullptr, 1, 64},
     {"stream_block_rows", &mvs::Options::stream_block_rows, nullptr, 0, 1 << 30},
     {"pairwise_block_cells", nullptr, &mvs::Options::pairwise_block_cells, 1, (1LL << 62)},
@@ -421,6 +423,8 @@ int mvs_ctx_destroy(mvs_ctx* c) {
     }
     if (c->dl_ready) (void)hipEventDestroy(c->dl_ready);
     if (c->dl_stream) (void)hipStreamDestroy(c->dl_stream);
+    if (c->post_stream) (void)hipStreamDestroy(c->post_stream);
+    if (c->cmp_done) (void)hipEventDestroy(c->cmp_done);
     if (c->pw_chdr) (void)hipFree(c->pw_chdr);
     if (c->pw_cent) (void)hipFree(c->pw_cent);
     for (int i = 0; i < 2; ++i) {
@@ -1556,6 +1560,8 @@ int ensure_download_side(mvs_ctx* c) {
             HIP_TRY(hipEventCreateWithFlags(&c->dl_block[i], hipEventDisableTiming));
         }
         HIP_TRY(hipEventCreateWithFlags(&c->dl_ready, hipEventDisableTiming));
+        HIP_TRY(hipStreamCreateWithFlags(&c->post_stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&c->cmp_done, hipEventDisableTiming));
     }
     return MVS_OK;
 }
@@ -1583,15 +1589,16 @@ struct BlockCsr {
     std::vector<uint32_t> enc_jac, enc_first;
 };
 
-// The CSR arrays of `b` (set b.set) -> the rows' shard records in c->st_enc[b.set], directory on the host
-int encode_block(mvs_ctx* c, BlockCsr& b) {
+// The CSR arrays of `b` (set b.set) -> the rows' shard records in c->st_enc[b.set], directory on the host; on stream `ps`
+// (the context's stream, or the side stream on which a dense block is post-processed beside the next comparison)
+int encode_block(mvs_ctx* c, BlockCsr& b, hipStream_t ps) {
     const int64_t rows = b.re - b.rb;
     b.encoded = true;
     b.enc_off.assign((size_t)rows + 1, 0);
     b.enc_jac.assign((size_t)rows, 0);
     b.enc_first.assign((size_t)rows, 0);
     if (b.n == 0 || rows == 0) {
-        HIP_TRY(hipEventRecord(c->dl_ready, c->stream));
+        HIP_TRY(hipEventRecord(c->dl_ready, ps));
         return MVS_OK;
     }
     int rc = ensure_buf(c, &c->en_size, &c->en_size_bytes, (size_t)(rows + 1) * 8);
@@ -1601,40 +1608,40 @@ int encode_block(mvs_ctx* c, BlockCsr& b) {
     if (rc == MVS_OK) rc = ensure_buf(c, &c->en_par, &c->en_par_bytes, (size_t)rows * sizeof(mvs::EncRow));
     if (rc) return rc;
     const int qb = b.wide ? 2 : 1;
-    HIP_TRY(hipMemsetAsync((char*)c->en_size + (size_t)rows * 8, 0, 8, c->stream));
-    mvs::launch_encode_sizes(c->stream, (const long long*)c->st_rowptr, (const int32_t*)c->st_col[b.set], c->st_q[b.set], qb, rows,
+    HIP_TRY(hipMemsetAsync((char*)c->en_size + (size_t)rows * 8, 0, 8, ps));
+    mvs::launch_encode_sizes(ps, (const long long*)c->st_rowptr, (const int32_t*)c->st_col[b.set], c->st_q[b.set], qb, rows,
                              (unsigned long long*)c->en_size, (unsigned int*)c->en_jac, (unsigned int*)c->en_first,
                              (mvs::EncRow*)c->en_par);
     rc = check_kernel("k_enc_size");
     if (rc) return rc;
     size_t need = 0;
-    rc = mvs::encode_offsets(c->stream, (unsigned long long*)c->en_size, (unsigned long long*)c->en_off, rows, nullptr, 0, &need);
+    rc = mvs::encode_offsets(ps, (unsigned long long*)c->en_size, (unsigned long long*)c->en_off, rows, nullptr, 0, &need);
     if (rc) return fail(rc, "scan sizing failed");
     rc = ensure_buf(c, &c->pw_sort, &c->pw_sort_bytes, need);
     if (rc) return rc;
-    rc = mvs::encode_offsets(c->stream, (unsigned long long*)c->en_size, (unsigned long long*)c->en_off, rows, c->pw_sort,
+    rc = mvs::encode_offsets(ps, (unsigned long long*)c->en_size, (unsigned long long*)c->en_off, rows, c->pw_sort,
                              c->pw_sort_bytes, nullptr);
     if (rc) return fail(rc, "scan of the record sizes failed");
-    HIP_TRY(hipMemcpyAsync(b.enc_off.data(), c->en_off, (size_t)(rows + 1) * 8, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(b.enc_jac.data(), c->en_jac, (size_t)rows * 4, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(b.enc_first.data(), c->en_first, (size_t)rows * 4, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpyAsync(b.enc_off.data(), c->en_off, (size_t)(rows + 1) * 8, hipMemcpyDeviceToHost, ps));
+    HIP_TRY(hipMemcpyAsync(b.enc_jac.data(), c->en_jac, (size_t)rows * 4, hipMemcpyDeviceToHost, ps));
+    HIP_TRY(hipMemcpyAsync(b.enc_first.data(), c->en_first, (size_t)rows * 4, hipMemcpyDeviceToHost, ps));
+    HIP_TRY(hipStreamSynchronize(ps));
     const size_t total = (size_t)b.enc_off[(size_t)rows];
     rc = ensure_buf(c, &c->st_enc[b.set], &c->st_enc_bytes[b.set], std::max<size_t>(total, 8));
     if (rc) return rc;
-    HIP_TRY(hipMemsetAsync(c->st_enc[b.set], 0, total, c->stream));       // the unary parts are OR-ed into zeroed words
-    mvs::launch_encode_fill(c->stream, (const long long*)c->st_rowptr, (const int32_t*)c->st_col[b.set], c->st_q[b.set], qb, rows,
+    HIP_TRY(hipMemsetAsync(c->st_enc[b.set], 0, total, ps));       // the unary parts are OR-ed into zeroed words
+    mvs::launch_encode_fill(ps, (const long long*)c->st_rowptr, (const int32_t*)c->st_col[b.set], c->st_q[b.set], qb, rows,
                             (const unsigned long long*)c->en_off, (const mvs::EncRow*)c->en_par, (unsigned char*)c->st_enc[b.set],
                             c->opt.encode_stage_words);
     rc = check_kernel("k_enc_fill");
     if (rc) return rc;
-    HIP_TRY(hipEventRecord(c->dl_ready, c->stream));
+    HIP_TRY(hipEventRecord(c->dl_ready, ps));
     return MVS_OK;
 }
 
 // before the CSR arrays of set `set` are rewritten: the downloads of the block that used them last (two blocks ago) are through
-int claim_csr_set(mvs_ctx* c, int set, int64_t block_index, int64_t n, bool wide) {
-    if (block_index >= 2) HIP_TRY(hipStreamWaitEvent(c->stream, c->dl_block[set], 0));
+int claim_csr_set(mvs_ctx* c, int set, int64_t block_index, int64_t n, bool wide, hipStream_t ps) {
+    if (block_index >= 2) HIP_TRY(hipStreamWaitEvent(ps, c->dl_block[set], 0));
     int rc = ensure_buf(c, &c->st_col[set], &c->st_col_bytes[set], (size_t)std::max<int64_t>(n, 1) * 4);
     if (rc) return rc;
     return ensure_buf(c, &c->st_q[set], &c->st_q_bytes[set], (size_t)std::max<int64_t>(n, 1) * (wide ? 2 : 1));
@@ -1667,7 +1674,7 @@ int csr_from_packed(mvs_ctx* c, int64_t rb, int64_t re, int64_t n, int shift, in
     rc = mvs::sort_packed(c->stream, (unsigned long long*)c->st_raw, (unsigned long long*)c->st_sorted, n, 16, shift + row_bits,
                           c->pw_sort, c->pw_sort_bytes, nullptr);
     if (rc) return fail(rc, "sort of the kept cells failed");
-    rc = claim_csr_set(c, out.set, block_index, n, false);
+    rc = claim_csr_set(c, out.set, block_index, n, false, c->stream);
     if (rc) return rc;
     unsigned int* d_wide = reinterpret_cast<unsigned int*>(c->d_counter + 3);
     HIP_TRY(hipMemsetAsync(d_wide, 0, 4, c->stream));
@@ -1697,7 +1704,7 @@ int csr_from_packed(mvs_ctx* c, int64_t rb, int64_t re, int64_t n, int shift, in
 // rows [rb, re) of the dense byte matrix (first row dense_row0, leading dimension ld) are final: count, scan, fill.
 // *odd: some kept cell of the launches so far has a q the byte cannot hold -- the caller redoes the block as a list.
 int csr_from_dense(mvs_ctx* c, int64_t rb, int64_t re, int64_t n_cols, int64_t dense_row0, int64_t ld, int64_t block_index,
-                   BlockCsr& out, bool* odd) {
+                   BlockCsr& out, bool* odd, hipStream_t ps) {
     const int64_t rows = re - rb;
     out.rb = rb;
     out.re = re;
@@ -1709,31 +1716,31 @@ int csr_from_dense(mvs_ctx* c, int64_t rb, int64_t re, int64_t n_cols, int64_t d
     rc = ensure_buf(c, &c->st_counts, &c->st_counts_bytes, (size_t)(rows + 1) * 8);
     if (rc) return rc;
     const uint8_t* first = (const uint8_t*)c->st_dense + (size_t)(rb - dense_row0) * (size_t)ld;
-    HIP_TRY(hipMemsetAsync((char*)c->st_counts + (size_t)rows * 8, 0, 8, c->stream));
-    mvs::launch_dense_count(c->stream, first, ld, n_cols, rows, (long long*)c->st_counts);
+    HIP_TRY(hipMemsetAsync((char*)c->st_counts + (size_t)rows * 8, 0, 8, ps));
+    mvs::launch_dense_count(ps, first, ld, n_cols, rows, (long long*)c->st_counts);
     rc = check_kernel("k_dense_count");
     if (rc) return rc;
     size_t need = 0;
-    rc = mvs::dense_row_ptr(c->stream, (long long*)c->st_counts, (long long*)c->st_rowptr, rows, nullptr, 0, &need);
+    rc = mvs::dense_row_ptr(ps, (long long*)c->st_counts, (long long*)c->st_rowptr, rows, nullptr, 0, &need);
     if (rc) return fail(rc, "scan sizing failed");
     rc = ensure_buf(c, &c->pw_sort, &c->pw_sort_bytes, need);
     if (rc) return rc;
-    rc = mvs::dense_row_ptr(c->stream, (long long*)c->st_counts, (long long*)c->st_rowptr, rows, c->pw_sort, c->pw_sort_bytes, nullptr);
+    rc = mvs::dense_row_ptr(ps, (long long*)c->st_counts, (long long*)c->st_rowptr, rows, c->pw_sort, c->pw_sort_bytes, nullptr);
     if (rc) return fail(rc, "scan of the row counts failed");
     unsigned int h_odd = 0;
-    HIP_TRY(hipMemcpyAsync(out.row_ptr.data(), c->st_rowptr, (size_t)(rows + 1) * 8, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(&h_odd, c->d_counter + 4, 4, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpyAsync(out.row_ptr.data(), c->st_rowptr, (size_t)(rows + 1) * 8, hipMemcpyDeviceToHost, ps));
+    HIP_TRY(hipMemcpyAsync(&h_odd, c->d_counter + 4, 4, hipMemcpyDeviceToHost, ps));
+    HIP_TRY(hipStreamSynchronize(ps));
     *odd = h_odd != 0;
     if (*odd) return MVS_OK;
     out.n = out.row_ptr[(size_t)rows];
-    rc = claim_csr_set(c, out.set, block_index, out.n, false);
+    rc = claim_csr_set(c, out.set, block_index, out.n, false, ps);
     if (rc) return rc;
-    mvs::launch_dense_fill(c->stream, first, ld, n_cols, rows, (const long long*)c->st_rowptr, (int32_t*)c->st_col[out.set],
+    mvs::launch_dense_fill(ps, first, ld, n_cols, rows, (const long long*)c->st_rowptr, (int32_t*)c->st_col[out.set],
                            (uint8_t*)c->st_q[out.set]);
     rc = check_kernel("k_dense_fill");
     if (rc) return rc;
-    HIP_TRY(hipEventRecord(c->dl_ready, c->stream));
+    HIP_TRY(hipEventRecord(c->dl_ready, ps));
     return MVS_OK;
 }
 
@@ -1958,7 +1965,9 @@ int pairwise_stream_impl(mvs_ctx* c, const mvs_sketch_set* s, const double* norm
     out.user = user;
     // a block's way out, in two steps so that the next block's comparison can be queued between them: prepare = the
     // device-side work that is left (encoding the rows, where the caller asked for that), deliver = pieces to the link
-    auto prepare = [&](BlockCsr& blk) -> int { return ecb ? encode_block(c, blk) : MVS_OK; };
+    hipStream_t ps = c->stream;                                // where a block is turned into CSR / encoded rows (see `side`)
+    bool side = false;
+    auto prepare = [&](BlockCsr& blk) -> int { return ecb ? encode_block(c, blk, ps) : MVS_OK; };
     auto deliver = [&](BlockCsr& blk) -> int {
         return ecb ? feed_encoded(c, out, blk, piece_bytes) : feed_block(c, out, blk, piece_bytes);
     };
@@ -1967,6 +1976,7 @@ int pairwise_stream_impl(mvs_ctx* c, const mvs_sketch_set* s, const double* norm
     auto finish = [&](int status) {
         out.close();                                            // every delivered block has been consumed
         (void)hipStreamSynchronize(c->dl_stream);
+        if (side) (void)hipStreamSynchronize(c->post_stream);
         if (n_cells) *n_cells = total;
         if (status != MVS_OK) return status;
         if (!out.error.empty()) return fail(MVS_E_HIP, "%s", out.error.c_str());
@@ -2073,6 +2083,12 @@ int pairwise_stream_impl(mvs_ctx* c, const mvs_sketch_set* s, const double* norm
         *n = (int64_t)got;
         return MVS_OK;
     };
+    // Blocks of ONE shared matrix: block k's rows are final when launch k is and launch k + 1 never touches them (its
+    // mirror images land in later blocks' rows), so block k is counted / scanned / filled / encoded on a SIDE stream while
+    // launch k + 1 already runs on the context's stream -- memory-bound passes beside a matrix-core-bound kernel instead
+    // of between two of them.  (stream_dense = 2: everything on the context's stream, one after the other.)
+    side = dense && whole && c->opt.stream_dense == 1 && blocks.size() > 1;
+    if (side) ps = c->post_stream;
     if (!blocks.empty()) {
         rc = launch(0, dense);
         if (rc) return finish(rc);
@@ -2081,12 +2097,31 @@ int pairwise_stream_impl(mvs_ctx* c, const mvs_sketch_set* s, const double* norm
         const int64_t rb = blocks[k].first, re = blocks[k].second;
         BlockCsr blk;
         bool next_launched = false;
+        if (side) {
+            hipError_t e = hipEventRecord(c->cmp_done, c->stream);              // launch k is the last thing queued there
+            if (e == hipSuccess) e = hipStreamWaitEvent(ps, c->cmp_done, 0);
+            if (e != hipSuccess) return finish(fail(MVS_E_HIP, "ordering the side stream: %s", hipGetErrorString(e)));
+            if (c->timing && c->ev_valid[1]) {                                   // launch k's time, before its events are reused
+                (void)hipEventSynchronize(c->ev[3]);
+                add_kernel_ms();
+            }
+            if (k + 1 < blocks.size() && !out.failed()) {
+                rc = launch(k + 1, true);
+                if (rc) return finish(rc);
+                next_launched = true;
+            }
+        }
         if (dense) {
             bool odd = false;
-            rc = csr_from_dense(c, rb, re, s->n, whole ? row_begin : rb, ld, (int64_t)k, blk, &odd);
+            rc = csr_from_dense(c, rb, re, s->n, whole ? row_begin : rb, ld, (int64_t)k, blk, &odd, ps);
             if (rc) return finish(rc);
-            add_kernel_ms();
+            if (!side) add_kernel_ms();
             if (odd) {
+                if (side) {                 // back to one stream; a launch already queued for block k + 1 is wasted, not wrong
+                    (void)hipStreamSynchronize(c->stream);
+                    side = false;
+                    ps = c->stream;
+                }
                 // a kept cell whose q a byte cannot hold (norms that do not belong to the vectors): this block and the
                 // rest go through the packed list, each block inside its own square -- the one case where a block is
                 // compared a second time
@@ -2117,7 +2152,7 @@ int pairwise_stream_impl(mvs_ctx* c, const mvs_sketch_set* s, const double* norm
         ++c->st_blocks;
         rc = prepare(blk);
         if (rc) return finish(rc);
-        if (k + 1 < blocks.size() && !out.failed()) {                  // the next block computes while this one is fed to the link
+        if (!next_launched && k + 1 < blocks.size() && !out.failed()) {   // the next block computes while this one is fed to the link
             rc = launch(k + 1, dense);
             if (rc) return finish(rc);
             next_launched = true;

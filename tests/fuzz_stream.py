@@ -83,7 +83,7 @@ def run_case(ctx, rng, max_n, decode_limit=150_000, log=None):
     re = n if rng.random() < 0.4 else int(rng.integers(rb, n + 1))
     budget = 0 if rng.random() < 0.4 else int(rng.choice([1 << 16, 1 << 20, 4 << 20, 64 << 20]))
     opts = {"pairwise_filter": filt,
-            "stream_dense": int(rng.random() < 0.8),
+            "stream_dense": int(rng.choice([0, 1, 1, 1, 2])),        # 0 packed list, 1 dense + side stream, 2 dense, one stream
             "stream_block_rows": int(rng.choice([0, 0, 64, 128, 200, 512])),
             "encode_stage_words": int(rng.choice([64, 64, 64, 8, 1])),
             "pairwise_symmetric": int(rng.random() < 0.85)}

@@ -62,13 +62,14 @@ def test_stream_toy_db(ctx, gold):
 
 
 @pytest.mark.parametrize("filt", [0, 1])
-@pytest.mark.parametrize("mode", ["dense-per-block", "dense-whole-square", "packed-list"])
+@pytest.mark.parametrize("mode", ["dense-per-block", "dense-whole-square", "dense-whole-square-one-stream", "packed-list"])
 def test_stream_dense_result_in_row_blocks(ctx, filt, mode):
     """clusters of 1000 samples: a third of all cells are kept.  The filter (when it runs) gives up past 1/128 of the
     cells in its list and the exact kernel does the rows in blocks -- nothing is compared twice and the pieces still
     cover every row once, in order.  The three ways a block's cells leave the exact kernel:
       dense-per-block     one byte per cell, the matrix holds one block (budget 2 MB: blocks of 512 rows)
-      dense-whole-square  one matrix for all rows, blocks of 256 rows, mirror images land in later blocks' rows
+      dense-whole-square  one matrix for all rows, blocks of 256 rows, mirror images land in later blocks' rows; block k
+                          becomes CSR on a side stream while launch k + 1 runs (-one-stream: stream_dense = 2, in series)
       packed-list         64-bit words + radix sort (what other limb codes get), blocks sized for the worst case"""
     n, d = 3000, 256
     sk = synth.make_sketches_numpy(n, d, 3000, seed=77, cluster=1000, shared=0.6)
@@ -80,8 +81,10 @@ def test_stream_dense_result_in_row_blocks(ctx, filt, mode):
     budget = 0
     if mode == "dense-per-block":
         budget = 2 << 20
-    elif mode == "dense-whole-square":
+    elif mode.startswith("dense-whole-square"):
         ctx.set_option("stream_block_rows", 256)
+        if mode.endswith("one-stream"):
+            ctx.set_option("stream_dense", 2)
     else:
         ctx.set_option("stream_dense", 0)
         budget = 16 << 20
@@ -92,7 +95,7 @@ def test_stream_dense_result_in_row_blocks(ctx, filt, mode):
         st = ctx.stream_stats()
         assert n_s == cnt and pieces[0][0] == 0 and pieces[-1][1] == n
         assert all(a[1] == b[0] for a, b in zip(pieces, pieces[1:]))
-        assert st["row_blocks"] >= {"dense-per-block": 5, "dense-whole-square": 11, "packed-list": 3}[mode] and not st["two_stage"]
+        assert st["row_blocks"] >= {"dense-per-block": 5, "dense-whole-square": 11, "dense-whole-square-one-stream": 11, "packed-list": 3}[mode] and not st["two_stage"]
         got = np.concatenate([_triples(rp, c, qq, b) for (b, e, rp, c, qq) in pieces])
         assert np.array_equal(got, _cells_triples(cells))
         # a shard that does not start on a tile border
