@@ -33,7 +33,7 @@ using u64 = unsigned long long;
 
 __device__ __forceinline__ unsigned bit_width_u64(u64 v) { return v ? 64u - (unsigned)__builtin_clzll(v) : 0u; }
 
-// One wave per row (workgroup = one wave, so __syncthreads is a wave-local fence for the LDS staging).
+// One wave per row (workgroup = one wave).
 template <typename Q>
 __global__ __launch_bounds__(64) void k_enc_size(const long long* __restrict__ row_ptr, const int32_t* __restrict__ col,
                                                  const Q* __restrict__ q, u64* __restrict__ size, unsigned* __restrict__ jac,
@@ -85,85 +85,108 @@ __global__ __launch_bounds__(64) void k_enc_size(const long long* __restrict__ r
     }
 }
 
-// `count` values of `width` bits each (value of index i from get(i)) into dst: chunks of 64 values = `width` whole words
-template <typename Get>
-__device__ __forceinline__ void pack_values(u64* __restrict__ dst, u64 count, unsigned width, int lane, u64* stage, Get get) {
-    const u64 mask = width >= 64 ? ~0ULL : ((1ULL << width) - 1ULL);
-    for (u64 c0 = 0; c0 < count; c0 += 64) {
-        if ((unsigned)lane < width) stage[lane] = 0;
-        __syncthreads();
-        const u64 i = c0 + (u64)lane;
-        if (i < count) {
-            const u64 v = get(i) & mask;
-            const unsigned p = (unsigned)lane * width, w = p >> 6, off = p & 63u;
-            atomicOr(&stage[w], v << off);
-            if (off + width > 64) atomicOr(&stage[w + 1], v >> (64 - off));
-        }
-        __syncthreads();
-        const u64 rem = count - c0 < 64 ? count - c0 : 64;
-        const unsigned words = (unsigned)((rem * width + 63) / 64);
-        if ((unsigned)lane < words) dst[(c0 / 64) * width + (u64)lane] = stage[lane];
-        __syncthreads();
+// The workgroup IS one wave, and a wave's LDS operations execute in the order it issued them: between a phase that writes a
+// stage and one that reads it nothing has to be waited for, the compiler just must not move LDS accesses across the line.
+// (__syncthreads() would also do, but hipcc puts `s_waitcnt vmcnt(0)` in front of a barrier: the global loads the fill loop
+// keeps in flight for LATER chunks would be drained at every chunk, which is exactly the latency the loop is built to hide.)
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// value v (already masked to `width` bits) of slot `lane` into a zeroed stage of `width` words: bytes and shorts are plain
+// stores (a lane owns its byte), other widths OR their bits in
+__device__ __forceinline__ void stage_put(u64* stage, int lane, unsigned width, u64 v) {
+    if (width == 8) {
+        reinterpret_cast<unsigned char*>(stage)[lane] = (unsigned char)v;
+    } else if (width == 16) {
+        reinterpret_cast<unsigned short*>(stage)[lane] = (unsigned short)v;
+    } else {
+        const unsigned p = (unsigned)lane * width, w = p >> 6, off = p & 63u;
+        atomicOr(&stage[w], v << off);
+        if (off + width > 64) atomicOr(&stage[w + 1], v >> (64 - off));
     }
 }
 
+// Pass 2.  ONE loop over the row's chunks of 64 cells does all three containers of the record -- the q values, the low
+// bits of the column deltas, their unary quotients -- so the columns are read once, and the loads run ahead of their use
+// (columns two chunks, q one chunk): a wave's chunks depend on each other only through the bit position of the unary part,
+// and with the loads inside that chain the kernel was bound by their latency (12 ms for 1e9 cells, 157 chunks per row one
+// after the other; 3 passes over the row).  The LDS stages alternate between two sets (a chunk zeroes the set the previous one does not read).
 template <typename Q>
 __global__ __launch_bounds__(64) void k_enc_fill(const long long* __restrict__ row_ptr, const int32_t* __restrict__ col,
                                                  const Q* __restrict__ q, const u64* __restrict__ offset,
                                                  const EncRow* __restrict__ par, unsigned char* __restrict__ out, unsigned stage_words) {
-    __shared__ u64 stage[64];
+    __shared__ u64 st_q[2][64], st_l[2][64], st_h[2][64];
     const long long r = blockIdx.x;
     const int lane = threadIdx.x;
     const long long b = row_ptr[r], e = row_ptr[r + 1];
     const u64 n = (u64)(e - b);
     if (n == 0) return;
     const EncRow pr = par[r];
+    const unsigned wq = pr.wq, k = pr.k;
     u64* w = reinterpret_cast<u64*>(out + offset[r]);
-    const u64 wq_words = (n * pr.wq + 63) / 64;
-    if (lane == 0) {                                                     // compact_vector header
-        w[0] = n;
-        w[1] = pr.wq;
-        w[2] = wq_words;
-    }
-    pack_values(w + 3, n, pr.wq, lane, stage, [&](u64 i) { return (u64)q[b + (long long)i]; });
-    if (n < 2) return;                                                   // :732 a single-entry row has no delta sequence
-    const u64 nr = n - 1;
-    const unsigned k = pr.k;
-    u64* z = w + 3 + wq_words;
-    u64 idx = 2;
-    if (lane == 0) {
-        z[0] = nr;
-        z[1] = k;
-    }
-    auto delta = [&](u64 j) { return (u64)(unsigned)(col[b + (long long)j + 1] - col[b + (long long)j]); };
-    if (k) {
-        const u64 low_words = (nr * k + 63) / 64;
-        if (lane == 0) {
-            z[2] = nr;
-            z[3] = k;
-            z[4] = low_words;
-        }
-        pack_values(z + 5, nr, k, lane, stage, delta);
-        idx = 5 + low_words;
-    }
+    const u64 wq_words = (n * wq + 63) / 64;
+    const u64 nr = n - 1;                                                // deltas; :732 a single-entry row has no delta sequence
+    u64* qdst = w + 3;
+    u64* z = qdst + wq_words;                                            // the rice_sequence (n >= 2)
+    const u64 low_words = k ? (nr * k + 63) / 64 : 0;
+    const u64 idx = k ? 5 + low_words : 2;
+    u64* ldst = z + 5;
     const u64 hw = (pr.high_bits + 63) / 64, ns = (nr + 63) / 64;
     u64* high = z + idx + 2;
     u64* samples = high + hw + 1;
     if (lane == 0) {
-        z[idx] = pr.high_bits;
-        z[idx + 1] = hw;
-        high[hw] = ns;
+        w[0] = n;                                                        // compact_vector header
+        w[1] = wq;
+        w[2] = wq_words;
+        if (n >= 2) {
+            z[0] = nr;
+            z[1] = k;
+            if (k) {
+                z[2] = nr;
+                z[3] = k;
+                z[4] = low_words;
+            }
+            z[idx] = pr.high_bits;
+            z[idx + 1] = hw;
+            high[hw] = ns;
+        }
     }
-    // unary part: element j sits at bit (sum over i < j of (quotient_i + 1)) + quotient_j; a wave prefix sum per chunk of 64.
-    // A chunk's bits are collected in LDS and leave as whole words; the word a chunk ends in (shared with the next chunk
+    const u64 qmask = wq >= 64 ? ~0ULL : ((1ULL << wq) - 1ULL), lmask = (1ULL << k) - 1ULL;
+    // loads beyond the row are clamped into it (their values are never used): a conditional load is a branch, and hipcc
+    // waits for the load at the end of the branch -- no load would stay in flight across the chunk
+    auto ld_col = [&](u64 i) -> int { return col[b + (long long)(i < n ? i : nr)]; };
+    auto ld_q = [&](u64 i) -> unsigned { return (unsigned)q[b + (long long)(i < n ? i : nr)]; };
+    // The loads of chunk t + 2 are issued while chunk t is packed.  Three register sets take turns (the loop is unrolled by
+    // three with the roles rotated) -- handing the values down at the end of an iteration would be register moves that wait
+    // for the loads.
+    int cA = ld_col((u64)lane), cB = ld_col(64 + (u64)lane), cC = 0;
+    unsigned qA = ld_q((u64)lane), qB = ld_q(64 + (u64)lane), qC = 0;
+    // unary part: element j sits at bit (sum over i < j of (quotient_i + 1)) + quotient_j; a wave prefix sum per chunk.  A
+    // chunk's bits are collected in LDS and leave as whole words; the word a chunk ends in (shared with the next chunk
     // unless it ends on a word border) is carried over instead of written.  (One global atomic OR per element, the first
     // version, cost 60 ms on 1e9 cells: atomics execute at the memory side, 64 bytes of traffic each.)  A chunk whose
-    // quotients are so large that it spans more words than the stage holds falls back to the atomics.
+    // quotients are so large that it spans more words than the stage holds ORs its bits into memory (zeroed by the caller),
+    // and so does every later chunk of the row: the word they start in may already hold bits there.
     u64 base = 0, carry = 0;                                             // carry: the bits of word base >> 6 set so far
-    for (u64 c0 = 0; c0 < nr; c0 += 64) {
-        const u64 j = c0 + (u64)lane;
-        const u64 quot = j < nr ? (delta(j) >> k) : 0;
-        const u64 len = j < nr ? quot + 1 : 0;
+    bool direct = false;
+    auto chunk = [&](u64 c0, int c_cur, int c_nxt, int& c_ld, unsigned q_cur, unsigned& q_ld) __attribute__((always_inline)) {
+        c_ld = ld_col(c0 + 128 + (u64)lane);                             // in flight while this chunk and the next are packed
+        q_ld = ld_q(c0 + 128 + (u64)lane);
+        const unsigned it = (unsigned)(c0 >> 6);
+        u64* sq = st_q[it & 1];
+        u64* sl = st_l[it & 1];
+        u64* sh = st_h[it & 1];
+        const u64 i = c0 + (u64)lane;
+        int succ = __shfl_down(c_cur, 1, 64);
+        const int edge = __shfl(c_nxt, 0, 64);
+        if (lane == 63) succ = edge;
+        const bool has_d = i < nr;
+        const u64 dlt = has_d ? (u64)(unsigned)(succ - c_cur) : 0;
+        const u64 quot = dlt >> k;
+        const u64 len = has_d ? quot + 1 : 0;
         u64 incl = len;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
@@ -171,51 +194,55 @@ __global__ __launch_bounds__(64) void k_enc_fill(const long long* __restrict__ r
             if (lane >= o) incl += up;
         }
         const u64 total = (u64)__shfl((long long)incl, 63, 64);
-        if (lane == 0) samples[c0 / 64] = base;
-        const u64 w0 = base >> 6, nw = ((base & 63) + total + 63) / 64;   // the words this chunk touches
-        if (nw <= (u64)stage_words) {
-            if ((u64)lane < nw) stage[lane] = lane == 0 ? carry : 0;
-            __syncthreads();
-            if (j < nr) {
-                const u64 pos = (base & 63) + (incl - len) + quot;       // relative to word w0
-                atomicOr(&stage[pos >> 6], 1ULL << (pos & 63));
-            }
-            __syncthreads();
-            const bool ends_on_border = ((base + total) & 63) == 0;
-            const u64 full = ends_on_border ? nw : nw - 1;               // words that no later chunk adds to
-            if ((u64)lane < full) high[w0 + (u64)lane] = stage[lane];
-            carry = ends_on_border ? 0 : stage[nw - 1];
-            __syncthreads();
-        } else {
-            if (lane == 0 && carry) atomicOr(&high[w0], carry);
-            if (j < nr) {
-                const u64 pos = base + (incl - len) + quot;
-                atomicOr(&high[pos >> 6], 1ULL << (pos & 63));
-            }
-            carry = 0;                                                   // whatever this chunk's last word holds is in memory
-            base += total;
-            // the next chunk starts in a word that already holds bits in memory: it must OR, not store -- force the atomics
-            // path for the rest of the row by keeping every later chunk away from plain stores of that word
-            for (u64 c1 = c0 + 64; c1 < nr; c1 += 64) {
-                const u64 jj = c1 + (u64)lane;
-                const u64 qq = jj < nr ? (delta(jj) >> k) : 0;
-                const u64 ll = jj < nr ? qq + 1 : 0;
-                u64 in2 = ll;
-#pragma unroll
-                for (int o = 1; o < 64; o <<= 1) {
-                    const u64 up = (u64)__shfl_up((long long)in2, o, 64);
-                    if (lane >= o) in2 += up;
+        const bool chunk_has_d = c0 < nr;
+        const u64 w0 = base >> 6, nw = ((base & 63) + total + 63) / 64;   // the words this chunk's unary codes touch
+        const bool staged = chunk_has_d && !direct && nw <= (u64)stage_words;
+        if ((unsigned)lane < wq) sq[lane] = 0;
+        if ((unsigned)lane < k) sl[lane] = 0;
+        if (staged && (u64)lane < nw) sh[lane] = lane == 0 ? carry : 0;
+        wave_sync();
+        if (i < n) stage_put(sq, lane, wq, (u64)q_cur & qmask);
+        if (k && has_d) stage_put(sl, lane, k, dlt & lmask);
+        if (chunk_has_d) {
+            if (lane == 0) samples[c0 / 64] = base;
+            if (staged) {
+                if (has_d) {
+                    const u64 pos = (base & 63) + (incl - len) + quot;   // relative to word w0
+                    atomicOr(&sh[pos >> 6], 1ULL << (pos & 63));
                 }
-                if (lane == 0) samples[c1 / 64] = base;
-                if (jj < nr) {
-                    const u64 pos = base + (in2 - ll) + qq;
+            } else {
+                if (!direct) {
+                    if (lane == 0 && carry) atomicOr(&high[w0], carry);
+                    carry = 0;
+                    direct = true;
+                }
+                if (has_d) {
+                    const u64 pos = base + (incl - len) + quot;
                     atomicOr(&high[pos >> 6], 1ULL << (pos & 63));
                 }
-                base += (u64)__shfl((long long)in2, 63, 64);
             }
-            return;
+        }
+        wave_sync();
+        const u64 rem = n - c0 < 64 ? n - c0 : 64;
+        if ((u64)lane < (rem * wq + 63) / 64) qdst[(c0 / 64) * wq + (u64)lane] = sq[lane];
+        if (k && chunk_has_d) {
+            const u64 remd = nr - c0 < 64 ? nr - c0 : 64;
+            if ((u64)lane < (remd * k + 63) / 64) ldst[(c0 / 64) * k + (u64)lane] = sl[lane];
+        }
+        if (staged) {
+            const bool ends_on_border = ((base + total) & 63) == 0;
+            const u64 full = ends_on_border ? nw : nw - 1;               // words that no later chunk adds to
+            if ((u64)lane < full) high[w0 + (u64)lane] = sh[lane];
+            carry = ends_on_border ? 0 : sh[nw - 1];
         }
         base += total;
+    };
+    for (u64 c0 = 0; c0 < n; c0 += 192) {
+        chunk(c0, cA, cB, cC, qA, qC);
+        if (c0 + 64 >= n) break;
+        chunk(c0 + 64, cB, cC, cA, qB, qA);
+        if (c0 + 128 >= n) break;
+        chunk(c0 + 128, cC, cA, cB, qC, qB);
     }
     if (lane == 0 && carry) high[base >> 6] = carry;
 }
