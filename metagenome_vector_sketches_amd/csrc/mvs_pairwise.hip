@@ -73,6 +73,9 @@ __device__ __forceinline__ TileCoord map_tile(unsigned b, unsigned patch_row, in
     } else if (map_mode == 2) {   // 2-row x 16-col sub-patches
         t.tr = spr * 16 + (int)x * 2 + (int)(ql >> 4);
         t.tc = spc * 16 + (int)(ql & 15u);
+    } else if (map_mode == 3) {   // 16-row x 2-col sub-patches: grids of ONE patch row (a few query rows against a whole
+        t.tr = spr * 16 + (int)(ql & 15u);          // database) -- with sub-patches that split the rows, a grid of <= 4 tile
+        t.tc = spc * 16 + (int)x * 2 + (int)(ql >> 4);   // rows keeps 2 of the 8 XCDs busy (launchers: skinny_map, < 16 tile rows)
     } else {
         t.tr = spr * 16 + (int)(x >> 1) * 4 + (int)(ql >> 3);
         t.tc = spc * 16 + (int)(x & 1u) * 8 + (int)(ql & 7u);
@@ -215,7 +218,7 @@ __global__ __launch_bounds__(WM * WN * 64, (AT * BT > 2 ? 1 : 2)) void k_pairwis
     static_assert(kPieces % kWavesT == 0, "stage must split evenly over the waves");
     static_assert(TM % TN == 0 || TN % TM == 0, "tile edges must nest");
 
-    const TileCoord tc = map_tile(blockIdx.x, blockIdx.y, n_tr, n_tc);
+    const TileCoord tc = map_tile(blockIdx.x, blockIdx.y, n_tr, n_tc, a.map_mode);
     (void)n_spc;
     if (!tc.valid) return;
 
@@ -741,7 +744,7 @@ __global__ __launch_bounds__(512, 2) void k_pairwise_mfma16(const PairwiseArgs a
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int L = 2, TM = 128, TN = 128, kWavesT = 8, WN = 4;
     constexpr int kRegion = L * TM * kSK, kStage = 2 * kRegion, kPPW = kStage / 1024 / kWavesT;   // 4
-    const TileCoord tc = map_tile(blockIdx.x, blockIdx.y, n_tr, n_tc);
+    const TileCoord tc = map_tile(blockIdx.x, blockIdx.y, n_tr, n_tc, a.map_mode);
     (void)n_spc;
     if (!tc.valid) return;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1848,22 +1851,26 @@ __global__ __launch_bounds__(256) void k_dense_count(const uint8_t* __restrict__
     if (threadIdx.x == 0) counts[blockIdx.x] = (long long)(part[0] + part[1] + part[2] + part[3]);
 }
 
-// col / q of row r at row_ptr[r]: one workgroup per row, 4 KiB of the row per step, positions by a block-wide prefix sum
+// col / q of row r at row_ptr[r]: one workgroup per row, 8 KiB of the row per step (32 bytes per thread: the loop is bound by
+// the latency of a step -- load, block-wide prefix sum, stores whose number the compiler cannot count, so every step drains
+// them --, and twice the bytes per step is half the steps), positions by a block-wide prefix sum
 __global__ __launch_bounds__(256) void k_dense_fill(const uint8_t* __restrict__ dense, long long ld, long long n_cols,
                                                     const long long* __restrict__ row_ptr, int32_t* __restrict__ col,
                                                     uint8_t* __restrict__ q) {
-    __shared__ unsigned wsum[4];
+    __shared__ unsigned wsum[2][4];
     const uint8_t* row = dense + (long long)blockIdx.x * ld;
     long long base = row_ptr[blockIdx.x];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    for (long long k0 = 0; k0 < n_cols; k0 += 256 * 16) {
-        const long long k = k0 + (long long)threadIdx.x * 16;
-        v4i wv = v4i{0, 0, 0, 0};
+    unsigned step = 0;
+    for (long long k0 = 0; k0 < n_cols; k0 += 256 * 32, ++step) {
+        const long long k = k0 + (long long)threadIdx.x * 32;
+        v4i wv[2] = {v4i{0, 0, 0, 0}, v4i{0, 0, 0, 0}};
         unsigned m = 0;
-        if (k < n_cols) {
-            wv = *reinterpret_cast<const v4i*>(row + k);
-            m = nz_mask16(wv);
-            if (k + 16 > n_cols) m &= (1u << (n_cols - k)) - 1u;
+        if (k < n_cols) {                                         // ld is a multiple of 128: both halves are inside the row
+            wv[0] = *reinterpret_cast<const v4i*>(row + k);
+            wv[1] = *reinterpret_cast<const v4i*>(row + k + 16);
+            m = nz_mask16(wv[0]) | (nz_mask16(wv[1]) << 16);
+            if (k + 32 > n_cols) m &= (unsigned)((1ULL << (n_cols - k)) - 1ULL);   // columns beyond the last sample
         }
         const unsigned mine = (unsigned)__popc(m);
         unsigned incl = mine;
@@ -1872,21 +1879,22 @@ __global__ __launch_bounds__(256) void k_dense_fill(const uint8_t* __restrict__ 
             const unsigned up = (unsigned)__shfl_up((int)incl, o, 64);
             if (lane >= o) incl += up;
         }
-        __syncthreads();                                          // wsum of the previous step has been read
-        if (lane == 63) wsum[w] = incl;
+        unsigned* ws = wsum[step & 1];                            // two sets: one barrier per step
+        if (lane == 63) ws[w] = incl;
         __syncthreads();
         unsigned before = 0, total = 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            before += i < w ? wsum[i] : 0u;
-            total += wsum[i];
+            before += i < w ? ws[i] : 0u;
+            total += ws[i];
         }
         long long at = base + before + (incl - mine);
         while (m) {
             const int b = __ffs((int)m) - 1;
             m &= m - 1;
+            const v4i half = b < 16 ? wv[0] : wv[1];
             col[at] = (int32_t)(k + b);
-            q[at] = (uint8_t)((unsigned)wv[b >> 2] >> (8 * (b & 3)));
+            q[at] = (uint8_t)((unsigned)half[(b >> 2) & 3] >> (8 * (b & 3)));
             ++at;
         }
         base += total;
@@ -1911,6 +1919,15 @@ inline int pairwise_variant(const Options& opt) {
     return (opt.pairwise_variant < 0 || opt.pairwise_variant > 9) ? 8 : opt.pairwise_variant;
 }
 
+// A block whose tile grid is less than one patch (16 tile rows) high and not under the symmetric schedule: the XCDs split
+// the patch by columns (map_tile mode 3).  The default map's 4 x 8 sub-patches split the ROWS of a patch over the XCDs: with
+// <= 4 tile rows 2 of the 8 XCDs have tiles (filter pass, queries x 10^6 samples: 1024 queries 6.9 -> 1.9 ms, 2048 queries
+// 6.9 -> 3.6 ms).  From 16 tile rows on the default map uses every XCD and reuses panels better (4096 queries: 7.0 ms
+// against 7.3 ms with mode 3).
+inline void skinny_map(PairwiseArgs& b, int n_tr) {
+    if (!b.symmetric && n_tr < 16 && b.map_mode == 0) b.map_mode = 3;
+}
+
 template <int L, bool KARA, int MODE, int NST, int WM, int WN, int BT, int AT = 2, bool DBUF = (BT == 1), int ABL = 0>
 int launch_mfma_variant(hipStream_t stream, const PairwiseArgs& a) {
     constexpr int TM = WM * AT * 32, TN = WN * BT * 32;
@@ -1923,6 +1940,7 @@ int launch_mfma_variant(hipStream_t stream, const PairwiseArgs& a) {
     PairwiseArgs b = a;
     // the symmetric schedule needs the row and column tile grids to share their origin modulo TM
     if (b.symmetric && ((a.row_begin - a.col_begin) % TM != 0 || TM % TN != 0 || a.mirror_all)) b.symmetric = 0;
+    skinny_map(b, n_tr);
     hipError_t e = hipFuncSetAttribute(
         reinterpret_cast<const void*>(&k_pairwise_mfma<L, KARA, MODE, NST, WM, WN, BT, AT, DBUF, ABL>),
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1943,6 +1961,7 @@ int launch_mfma16(hipStream_t stream, const PairwiseArgs& a) {
     const size_t lds = (size_t)NST * 2 * (TM + TN) * kSK;
     PairwiseArgs b = a;
     if (b.symmetric && ((a.row_begin - a.col_begin) % TM != 0 || a.mirror_all)) b.symmetric = 0;
+    skinny_map(b, n_tr);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pairwise_mfma16<MODE, NST>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return MVS_E_HIP;
@@ -1962,6 +1981,7 @@ int launch_pp(hipStream_t stream, const PairwiseArgs& a) {
     const size_t lds = (size_t)NST * G::kStage;
     PairwiseArgs b = a;
     if (b.symmetric && ((a.row_begin - a.col_begin) % G::TM != 0 || a.mirror_all)) b.symmetric = 0;
+    skinny_map(b, n_tr);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pairwise_pp<MODE, NST, ORDER, ABL, PH, NT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return MVS_E_HIP;
