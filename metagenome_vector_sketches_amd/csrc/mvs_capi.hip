@@ -1205,11 +1205,12 @@ int pairwise_launch(mvs_ctx* c, const mvs_sketch_set* s, const double* d_n2, int
     int rc = MVS_OK;
     const double block_cells = (double)(re - rb) * (double)(ce - cb);
     // A few rows against everything (a search with a handful of queries) on a set whose coarse plane does not exist yet:
-    // building the plane reads all the limb planes once, which is all the exact kernel needs for such a block.
+    // building the plane reads all the limb planes once, which is all the exact kernel needs for such a block.  Up to 16
+    // rows the exact path is a streaming kernel that runs at HBM speed (k_pairwise_skinny): nothing to filter for.
     const bool coarse_cached = c->coarse_id == s->id && c->coarse_gen == s->gen && c->coarse_mode == c->opt.coarse_radix;
     bool two_stage = filter_mode != 0 && s->limbs == 2 && s->d_pad <= 32768 &&
                      (filter_mode == 2 ||   // forced: also on small blocks and on sets it was found not to pay for
-                      (block_cells >= 4194304.0 && (coarse_cached || re - rb >= 1024) &&
+                      (block_cells >= 4194304.0 && re - rb > 16 && (coarse_cached || re - rb >= 1024) &&
                        !(c->filter_off_id == s->id && c->filter_off_coeff == keep_coeff)));
     if (two_stage) {
         rc = prepare_coarse(c, s);

@@ -49,7 +49,8 @@ struct Options {
     int enable_k3 = 0;              // 1: mvs_sketch_set_create picks the three-plane Karatsuba code for |v| <= 8127
     int pairwise_map = 0;           // sub-patch an XCD takes in k_pairwise_pp: 0 = 4 rows x 8 cols, 1 = 8 x 4, 2 = 2 x 16
     int coarse_radix = 1;           // radix of the filter's coarse plane: 1 = smallest residual (default), 0 = ceil(max|v| / 127)
-    int stream_dense = 1;           // mvs_pairwise_stream, exact kernel: 1 = dense byte matrix + count / scan / fill, 0 = packed list + sort
+    int stream_dense = 1;           // mvs_pairwise_stream, exact kernel: 1 = dense byte matrix + count / scan / fill (on a side
+                                    // stream beside the next block's launch; 2 = on the context's stream), 0 = packed list + sort
     int encode_stage_words = 64;    // device encoder: LDS words a chunk of unary codes may span before it falls back to atomics (tests)
     int stream_block_rows = 0;      // > 0: upper bound on the rows of a dense row block (tests); 0 = by the budget
     int recheck_mode = 1;           // re-check work split: 1 first round fixed + per-XCD counter, 2 counter only, 0 fixed stride, 3 eighths
@@ -101,7 +102,8 @@ struct PairwiseArgs {
                                   //    produced by mirroring the kept cells of their transposes
     int debug_flags;              // profiling ablations (-DMVS_ABLATIONS builds only): 1 skip k-loop, 2 skip epilogue,
                                   // 4 filter epilogue: injected candidates instead of the accumulators' verdict
-    int map_mode;                 // workgroup -> tile map of k_pairwise_pp: 0 = 4 x 8 sub-patch per XCD, 1 = 8 x 4, 2 = 2 x 16
+    int map_mode;                 // workgroup -> tile map: 0 = 4 x 8 sub-patch per XCD, 1 = 8 x 4, 2 = 2 x 16 (option pairwise_map),
+                                  // 3 = 16 x 2 (set by the launchers for blocks less than 16 tile rows high)
     // two-stage comparison (coarse filter + exact re-check, see "filter" in mvs_pairwise.hip)
     const int8_t* coarse;         // [row * d_pad + k], c = round(v / radix[row]), |c| <= 127
     const float4* fmeta;          // n_alloc: per-row filter constants {s, w, a, p}

@@ -28,6 +28,7 @@
 //     taking a 4 x 8 sub-patch, so that one XCD's L2 serves 12 operand panels to 32 tiles.
 #include "mvs_internal.h"
 
+#include <algorithm>
 #include <cstring>
 #include <type_traits>
 
@@ -1323,6 +1324,79 @@ __global__ __launch_bounds__(256) void k_pairwise_valu(const PairwiseArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// A handful of rows against many columns (a search: q query sketches x the whole database), two base-256 limbs.
+// The MFMA kernels fetch 64-byte k-slices of 256 rows per step -- a pattern that lives on L2 reuse in the all-vs-all case
+// and has none here (1-256 rows x 10^6 columns: 3.1 ms for 4.1 GB of limb planes, 1.3 TB/s).  This kernel streams instead:
+// the rows' limb planes sit in LDS, a wave takes one column at a time and reads its limb rows front to back (1 KiB per load
+// instruction, the re-check kernel's access pattern), every lane forms its part of all QT dots with v_dot4_i32_i8, and a
+// transposing butterfly (QT - 1 + log2(64 / QT) exchanges instead of 6 QT) leaves the total of row q in the lanes whose
+// upper bits spell q.  QT = rows rounded up to a power of two, <= 16 here (the rows beyond the block are zeros in LDS).
+// ---------------------------------------------------------------------------------------------------
+template <int QT>
+__global__ __launch_bounds__(512) void k_pairwise_skinny(const PairwiseArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    static_assert(QT >= 1 && QT <= 16 && (QT & (QT - 1)) == 0, "rows per pass");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nq = (int)(a.row_end - a.row_begin);
+    const int64_t stride = 2 * (int64_t)a.d_pad;
+    for (int64_t x = (int64_t)tid * 16; x < QT * stride; x += 512 * 16) {
+        const int q = (int)(x / stride);
+        v4i v = v4i{0, 0, 0, 0};
+        if (q < nq) v = *reinterpret_cast<const v4i*>(a.planes + (a.row_begin + q) * stride + (x - q * stride));
+        *reinterpret_cast<v4i*>(smem + x) = v;
+    }
+    __syncthreads();
+    constexpr int kShift = QT == 1 ? 6 : QT == 2 ? 5 : QT == 4 ? 4 : QT == 8 ? 3 : 2;   // 6 - log2(QT)
+    const int my_q = (lane >> kShift) & (QT - 1);                 // the row whose total this lane ends up with
+    const bool speaker = (lane & ((1 << kShift) - 1)) == 0 && my_q < nq;
+    const int64_t n_waves = (int64_t)gridDim.x * 8, wid = (int64_t)blockIdx.x * 8 + wave;
+    for (int64_t col = a.col_begin + wid; col < a.col_end; col += n_waves) {   // wave-uniform
+        const int8_t* rj = a.planes + col * stride;
+        int acc0[QT], acc1[QT], acc2[QT];
+#pragma unroll
+        for (int q = 0; q < QT; ++q) acc0[q] = acc1[q] = acc2[q] = 0;
+        for (int k = lane * 16; k < a.d_pad; k += 1024) {
+            const v4i lj = *reinterpret_cast<const v4i*>(rj + k);
+            const v4i hj = *reinterpret_cast<const v4i*>(rj + a.d_pad + k);
+#pragma unroll
+            for (int q = 0; q < QT; ++q) {
+                const v4i li = *reinterpret_cast<const v4i*>(smem + q * stride + k);
+                const v4i hi = *reinterpret_cast<const v4i*>(smem + q * stride + a.d_pad + k);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc0[q] = __builtin_amdgcn_sdot4(li[e], lj[e], acc0[q], false);
+                    acc1[q] = __builtin_amdgcn_sdot4(li[e], hj[e], acc1[q], false);
+                    acc1[q] = __builtin_amdgcn_sdot4(hi[e], lj[e], acc1[q], false);
+                    acc2[q] = __builtin_amdgcn_sdot4(hi[e], hj[e], acc2[q], false);
+                }
+            }
+        }
+        uint32_t part[QT];
+#pragma unroll
+        for (int q = 0; q < QT; ++q) part[q] = (uint32_t)acc0[q] + ((uint32_t)acc1[q] << 8) + ((uint32_t)acc2[q] << 16);
+        // halve the rows a lane is responsible for while doubling the lanes behind each value
+        int m = 32;
+#pragma unroll
+        for (int n = QT; n > 1; n >>= 1, m >>= 1) {
+            const bool upper = (lane & m) != 0;
+#pragma unroll
+            for (int i = 0; i < n / 2; ++i) {
+                const uint32_t send = upper ? part[i] : part[i + n / 2];
+                const uint32_t keepv = upper ? part[i + n / 2] : part[i];
+                part[i] = keepv + (uint32_t)__shfl_xor((int)send, m, 64);
+            }
+        }
+#pragma unroll
+        for (; m >= 1; m >>= 1) part[0] += (uint32_t)__shfl_xor((int)part[0], m, 64);
+        const int32_t P = (int32_t)part[0];
+        const int32_t row = (int32_t)a.row_begin + my_q;
+        bool keep = false;
+        if (speaker) keep = keep_cell(P, a.d, a.norms_sq[row], a.norms_sq[col], a.keep_mode, a.keep_coeff);
+        emit_cell(a, keep, a.mirror_all != 0, row, (int32_t)col, P, lane);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // helpers: max |v|, limb split, candidate thresholds
 // ---------------------------------------------------------------------------------------------------
 template <typename T>
@@ -2166,7 +2240,43 @@ bool exact_kernel_writes_dense(const PairwiseArgs& a, const Options& opt) {
     return a.limbs == 2 && a.d_pad <= 32768 && v >= 6 && v <= 9;      // the kernels that end in epilogue_exact16
 }
 
+// rows <= 16, two base-256 limbs, kept cells as a list: the streaming kernel.  Returns -1 when the block is not its kind.
+template <int QT>
+static int launch_skinny_qt(hipStream_t stream, const PairwiseArgs& a, size_t lds) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pairwise_skinny<QT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return MVS_E_HIP;
+    const unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(4, (size_t)(160 * 1024) / std::max<size_t>(lds, 1)));
+    const int64_t cols = a.col_end - a.col_begin;
+    const unsigned blocks = (unsigned)std::min<int64_t>(256 * per_cu, (cols + 7) / 8);
+    hipLaunchKernelGGL(k_pairwise_skinny<QT>, dim3(blocks), dim3(512), lds, stream, a);
+    return 0;
+}
+
+static int launch_skinny(hipStream_t stream, const PairwiseArgs& a, const Options& opt) {
+    const int64_t rows = a.row_end - a.row_begin, cols = a.col_end - a.col_begin;
+    // up to 16 rows: 10^6 columns x 2048 in 0.65 ms (1 row: 6.3 TB/s), 0.73 (4), 1.85 (16: bound by the v_dot4 rate); 32 rows
+    // would take 3.9 ms against the MFMA kernel's 3.1
+    if (a.limbs != 2 || rows < 1 || rows > 16 || cols < 1024 || a.dense != nullptr) return -1;
+    if (opt.pairwise_variant != 8) return -1;                     // the caller asked for another MFMA kernel by number (8: default)
+    int qt = 1;
+    while (qt < rows) qt *= 2;
+    const size_t lds = (size_t)qt * 2 * (size_t)a.d_pad;
+    if (lds > 144 * 1024 || a.d_pad > 32768) return -1;
+    switch (qt) {
+        case 1: return launch_skinny_qt<1>(stream, a, lds);
+        case 2: return launch_skinny_qt<2>(stream, a, lds);
+        case 4: return launch_skinny_qt<4>(stream, a, lds);
+        case 8: return launch_skinny_qt<8>(stream, a, lds);
+        default: return launch_skinny_qt<16>(stream, a, lds);
+    }
+}
+
 int launch_pairwise(hipStream_t stream, const PairwiseArgs& a, int mode, int algo, const Options& opt) {
+    if (mode == 0 && algo == 0) {
+        const int r = launch_skinny(stream, a, opt);
+        if (r >= 0) return r;
+    }
     // int32 accumulators hold up to two limb-pair products per k: exact while 2 * 128 * 128 * d_pad < 2^31;
     // longer sketches take the vector-ALU path, which wraps mod 2^32 by construction
     if (algo == 0 && (a.limbs <= 2 || is_k3(a.limbs)) && a.d_pad <= 32768) {

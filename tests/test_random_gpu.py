@@ -130,3 +130,52 @@ def test_projection_fuzz_seeded(ctx, seed):
     import fuzz_project
     info = fuzz_project.run_case(ctx, np.random.default_rng(515151 + seed), max_total=250_000)
     assert info["samples"] >= 1
+
+
+@pytest.mark.parametrize("rows", [1, 2, 3, 5, 8, 13, 16, 17, 33])
+def test_few_rows_against_many_columns(ctx, rows):
+    """blocks of 1..16 rows x >= 1024 columns take the streaming kernel (k_pairwise_skinny: rows in LDS, one wave per
+    column); more rows and an explicitly chosen MFMA kernel (pairwise_variant 6) do not.  Plain, mirror-all and symmetric
+    blocks, both keep tests, a search: the oracle's cells (int32 keep test) and the MFMA kernel's (everything).  (Entries up
+    to 30000 at d = 2048 make the dots wrap mod 2^32, like the reference's int32 product: both sides must agree there too.)"""
+    import torch
+    rng = np.random.default_rng(7000 + rows)
+    n = int(rng.integers(1100, 1700))
+    d = int(rng.choice([100, 256, 1000, 2048]))
+    hi = int(rng.choice([300, 2000, 30000]))
+    base = rng.integers(-hi, hi + 1, size=(n // 7 + 1, d))
+    sk = base[rng.integers(0, len(base), size=n)] + rng.integers(-max(1, hi // 6), max(1, hi // 6) + 1, size=(n, d))
+    sk = np.clip(sk, -32639, 32639).astype(np.int32)
+    sk[rng.integers(0, n)] = 0
+    n2 = np.array([orc.norm_sq_from_text(orc.format_norm(orc.norm(r))) for r in sk])
+    n2[rng.integers(0, n, size=n // 10)] *= rng.choice([0.5, 0.97, 1.03, 2.0])
+    ss = ctx.sketch_set(sk)
+    assert ss.limbs == 2
+    n2_t = torch.from_numpy(n2).to("cuda")
+    cells_t = torch.empty((rows * n * 2 + 64, 4), dtype=torch.int32, device="cuda")
+
+    def run(fn):
+        out = []
+        for variant in (8, 6):                         # default (streaming kernel where it applies), MFMA ring kernel
+            ctx.set_option("pairwise_variant", variant)
+            cnt = fn()
+            ctx.synchronize()
+            out.append(sorted(map(tuple, cells_t[:cnt].cpu().numpy().tolist())))
+        ctx.set_option("pairwise_variant", 8)
+        assert out[0] == out[1], (len(out[0]), len(out[1]))
+        return out[0]
+
+    ctx.set_option("pairwise_filter", 0)
+    for rb in (0, int(rng.integers(1, n - rows)), n - rows):
+        re = rb + rows
+        got = run(lambda: ctx.pairwise_block(ss, n2_t, rb, re, 0, n, 0, cells_t, 0))
+        want = orc.pairwise_rows(sk, n2, row_begin=rb, row_end=re, chunk=192, threads=8)
+        assert got == sorted(map(tuple, want.tolist()))
+        cb = int(rng.integers(0, 60))
+        run(lambda: ctx.pairwise_block(ss, n2_t, rb, re, cb, n - 3, _capi.BLOCK_MIRROR_ALL, cells_t, 0, keep_mode=_capi.KEEP_INT16))
+        sym = run(lambda: ctx.pairwise_block(ss, n2_t, rb, re, 0, n, _capi.BLOCK_SYMMETRIC, cells_t, 0))
+        assert sym == got
+    ctx.set_option("pairwise_filter", 1)
+    for j in (0.03, 0.3):
+        run(lambda: ctx.search_block(ss, n2_t, j, n - rows, n, 0, n - rows, cells_t))
+    ss.close()
