@@ -1327,11 +1327,32 @@ __global__ __launch_bounds__(256) void k_pairwise_valu(const PairwiseArgs a) {
 // A handful of rows against many columns (a search: q query sketches x the whole database), two base-256 limbs.
 // The MFMA kernels fetch 64-byte k-slices of 256 rows per step -- a pattern that lives on L2 reuse in the all-vs-all case
 // and has none here (1-256 rows x 10^6 columns: 3.1 ms for 4.1 GB of limb planes, 1.3 TB/s).  This kernel streams instead:
-// the rows' limb planes sit in LDS, a wave takes one column at a time and reads its limb rows front to back (1 KiB per load
-// instruction, the re-check kernel's access pattern), every lane forms its part of all QT dots with v_dot4_i32_i8, and a
-// transposing butterfly (QT - 1 + log2(64 / QT) exchanges instead of 6 QT) leaves the total of row q in the lanes whose
-// upper bits spell q.  QT = rows rounded up to a power of two, <= 16 here (the rows beyond the block are zeros in LDS).
+// the rows sit in LDS, a wave takes one column at a time and reads its limb rows front to back (1 KiB per load instruction,
+// the re-check kernel's access pattern), every lane forms its part of all QT dots, and a transposing butterfly (QT - 1 +
+// log2(64 / QT) exchanges instead of 6 QT) leaves the total of row q in the lanes whose upper bits spell q.  The entries of
+// a two-limb set fit int16 (|v| <= 32639), so both sides are re-joined to int16 pairs (the rows once, in LDS; a column's
+// chunk in registers, 8 instructions per 4 entries) and one v_dot2_i32_i16 does the work of four v_dot4_i32_i8 on limbs;
+// its int32 accumulation wraps mod 2^32 exactly like the reference's int32 product.  QT = rows rounded up to a power of two,
+// <= 16 (rows beyond the block are zeros in LDS).
 // ---------------------------------------------------------------------------------------------------
+// two base-256 limb dwords (4 entries: v = lo + 256 hi, lo and hi signed bytes, |v| <= 32639) -> the same entries as int16
+// pairs {v0, v1}, {v2, v3}: low byte = lo, high byte = hi - (lo < 0) (a byte-wise subtraction without borrows between bytes)
+__device__ __forceinline__ void limbs_to_i16(uint32_t lo, uint32_t hi, int& w01, int& w23) {
+    const uint32_t neg = (lo >> 7) & 0x01010101u;
+    const uint32_t hs = ((hi | 0x80808080u) - neg) ^ (~hi & 0x80808080u);
+    w01 = (int)__builtin_amdgcn_perm(hs, lo, 0x05010400u);
+    w23 = (int)__builtin_amdgcn_perm(hs, lo, 0x07030602u);
+}
+
+// c + a.lo * b.lo + a.hi * b.hi on int16 pairs, mod 2^32 (v_dot2_i32_i16).  The operands arrive as scalars on purpose:
+// __builtin_bit_cast applied directly to a vector ELEMENT (bit_cast<v2s>(vec[e])) is folded to element 0 by hipcc 7.2 -- the
+// unrolled loop below then multiplied the first dword of every 16-byte chunk four times (seen in the ISA; the same toolchain
+// fault as in the filter epilogue's maximum, DESIGN.md "toolchain note").
+__device__ __forceinline__ int dot2_i16(int a, int b, int c) {
+    using v2s = __attribute__((ext_vector_type(2))) short;
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(v2s, a), __builtin_bit_cast(v2s, b), c, false);
+}
+
 template <int QT>
 __global__ __launch_bounds__(512) void k_pairwise_skinny(const PairwiseArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1339,11 +1360,25 @@ __global__ __launch_bounds__(512) void k_pairwise_skinny(const PairwiseArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nq = (int)(a.row_end - a.row_begin);
     const int64_t stride = 2 * (int64_t)a.d_pad;
-    for (int64_t x = (int64_t)tid * 16; x < QT * stride; x += 512 * 16) {
-        const int q = (int)(x / stride);
-        v4i v = v4i{0, 0, 0, 0};
-        if (q < nq) v = *reinterpret_cast<const v4i*>(a.planes + (a.row_begin + q) * stride + (x - q * stride));
-        *reinterpret_cast<v4i*>(smem + x) = v;
+    // the rows, as int16 pairs: plane A holds the pairs {v0, v1} of every entry quadruple, plane B the pairs {v2, v3} (any
+    // pairing does, as long as both operands of a dot use the same one); a two-limb set has |v| <= 32639
+    for (int64_t x = (int64_t)tid * 16; x < QT * (int64_t)a.d_pad; x += 512 * 16) {
+        const int q = (int)(x / a.d_pad);
+        const int64_t k = x - (int64_t)q * a.d_pad;
+        v4i wa = v4i{0, 0, 0, 0}, wb = v4i{0, 0, 0, 0};
+        if (q < nq) {
+            const int8_t* ri = a.planes + (a.row_begin + q) * stride;
+            const v4i lo = *reinterpret_cast<const v4i*>(ri + k), hi = *reinterpret_cast<const v4i*>(ri + a.d_pad + k);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                int w01, w23;
+                limbs_to_i16((uint32_t)lo[e], (uint32_t)hi[e], w01, w23);
+                wa[e] = w01;
+                wb[e] = w23;
+            }
+        }
+        *reinterpret_cast<v4i*>(smem + q * stride + k) = wa;
+        *reinterpret_cast<v4i*>(smem + q * stride + a.d_pad + k) = wb;
     }
     __syncthreads();
     constexpr int kShift = QT == 1 ? 6 : QT == 2 ? 5 : QT == 4 ? 4 : QT == 8 ? 3 : 2;   // 6 - log2(QT)
@@ -1352,28 +1387,34 @@ __global__ __launch_bounds__(512) void k_pairwise_skinny(const PairwiseArgs a) {
     const int64_t n_waves = (int64_t)gridDim.x * 8, wid = (int64_t)blockIdx.x * 8 + wave;
     for (int64_t col = a.col_begin + wid; col < a.col_end; col += n_waves) {   // wave-uniform
         const int8_t* rj = a.planes + col * stride;
-        int acc0[QT], acc1[QT], acc2[QT];
+        int acc[QT];
 #pragma unroll
-        for (int q = 0; q < QT; ++q) acc0[q] = acc1[q] = acc2[q] = 0;
+        for (int q = 0; q < QT; ++q) acc[q] = 0;
         for (int k = lane * 16; k < a.d_pad; k += 1024) {
             const v4i lj = *reinterpret_cast<const v4i*>(rj + k);
             const v4i hj = *reinterpret_cast<const v4i*>(rj + a.d_pad + k);
+            v4i ja, jb;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                int w01, w23;
+                limbs_to_i16((uint32_t)lj[e], (uint32_t)hj[e], w01, w23);
+                ja[e] = w01;
+                jb[e] = w23;
+            }
 #pragma unroll
             for (int q = 0; q < QT; ++q) {
-                const v4i li = *reinterpret_cast<const v4i*>(smem + q * stride + k);
-                const v4i hi = *reinterpret_cast<const v4i*>(smem + q * stride + a.d_pad + k);
+                const v4i ia = *reinterpret_cast<const v4i*>(smem + q * stride + k);
+                const v4i ib = *reinterpret_cast<const v4i*>(smem + q * stride + a.d_pad + k);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    acc0[q] = __builtin_amdgcn_sdot4(li[e], lj[e], acc0[q], false);
-                    acc1[q] = __builtin_amdgcn_sdot4(li[e], hj[e], acc1[q], false);
-                    acc1[q] = __builtin_amdgcn_sdot4(hi[e], lj[e], acc1[q], false);
-                    acc2[q] = __builtin_amdgcn_sdot4(hi[e], hj[e], acc2[q], false);
+                for (int e = 0; e < 4; ++e) {                       // int32 accumulation wraps mod 2^32, as the reference's product does
+                    acc[q] = dot2_i16(ia[e], ja[e], acc[q]);
+                    acc[q] = dot2_i16(ib[e], jb[e], acc[q]);
                 }
             }
         }
         uint32_t part[QT];
 #pragma unroll
-        for (int q = 0; q < QT; ++q) part[q] = (uint32_t)acc0[q] + ((uint32_t)acc1[q] << 8) + ((uint32_t)acc2[q] << 16);
+        for (int q = 0; q < QT; ++q) part[q] = (uint32_t)acc[q];
         // halve the rows a lane is responsible for while doubling the lanes behind each value
         int m = 32;
 #pragma unroll
@@ -2255,8 +2296,9 @@ static int launch_skinny_qt(hipStream_t stream, const PairwiseArgs& a, size_t ld
 
 static int launch_skinny(hipStream_t stream, const PairwiseArgs& a, const Options& opt) {
     const int64_t rows = a.row_end - a.row_begin, cols = a.col_end - a.col_begin;
-    // up to 16 rows: 10^6 columns x 2048 in 0.65 ms (1 row: 6.3 TB/s), 0.73 (4), 1.85 (16: bound by the v_dot4 rate); 32 rows
-    // would take 3.9 ms against the MFMA kernel's 3.1
+    // up to 16 rows: 10^6 columns x 2048 in 0.67 ms (1 row: 6.2 TB/s), 0.71 (4), 0.87 (8), 1.44 (16: bound by the rate of
+    // v_dot2_i32_i16, ~12 cycles per wave instruction; with v_dot4_i32_i8 on the limb planes 1.05 / 1.9 ms); 32 rows would
+    // take 2.9 ms, what the MFMA kernel takes
     if (a.limbs != 2 || rows < 1 || rows > 16 || cols < 1024 || a.dense != nullptr) return -1;
     if (opt.pairwise_variant != 8) return -1;                     // the caller asked for another MFMA kernel by number (8: default)
     int qt = 1;

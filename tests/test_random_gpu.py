@@ -132,9 +132,9 @@ def test_projection_fuzz_seeded(ctx, seed):
     assert info["samples"] >= 1
 
 
-@pytest.mark.parametrize("rows", [1, 2, 3, 5, 8, 13, 16, 17, 33])
+@pytest.mark.parametrize("rows", [1, 2, 3, 5, 8, 13, 16, 17, 31, 32, 33])
 def test_few_rows_against_many_columns(ctx, rows):
-    """blocks of 1..16 rows x >= 1024 columns take the streaming kernel (k_pairwise_skinny: rows in LDS, one wave per
+    """blocks of 1..32 rows x >= 1024 columns take the streaming kernel (k_pairwise_skinny: rows in LDS, one wave per
     column); more rows and an explicitly chosen MFMA kernel (pairwise_variant 6) do not.  Plain, mirror-all and symmetric
     blocks, both keep tests, a search: the oracle's cells (int32 keep test) and the MFMA kernel's (everything).  (Entries up
     to 30000 at d = 2048 make the dots wrap mod 2^32, like the reference's int32 product: both sides must agree there too.)"""
