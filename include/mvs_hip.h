@@ -87,13 +87,16 @@ int mvs_ctx_kernel_ms(mvs_ctx* ctx, int which, float* ms);
  * context, in mvs_ctx_create: MVS_<NAME> (upper case) gives an option's initial value; afterwards only
  * mvs_ctx_set_option changes it, so two contexts (or two threads with a context each) never interfere.
  *   pairwise_filter       0 exact kernel on every cell; 1 (default) two-stage comparison for blocks of at least
- *                         2^22 cells of a two-limb set; 2 two-stage whenever the set has two limbs (tests)
+ *                         2^22 cells and more than 16 rows of a two-limb set (fewer than 1024 rows: only if the set's
+ *                         coarse plane is already cached); 2 two-stage whenever the set has two limbs (tests)
  *   filter_variant        kernel of the one-pass filter: -1 (default) by block size, 8 = ping-pong wave groups on
  *                         256 x 256 tiles (7/9/10 its variants), 0 = 128 x 128 ring, 1 = 256 x 256 ring, 3/5/6 other rings
  *   exact_variant         re-check kernel: 3 (default) tree reduction over rounds of 64 pairs, 0 one shuffle butterfly per
  *                         pair, 1 quarter wave per pair, 2 16 pairs per round
  *   pairwise_variant      exact kernel: 8 (default) ping-pong 16x16x64 MFMA for two limbs (7/9 its variants), 6 the ring
- *                         kernel on the same shape, 0-5 32x32x32 tile / ring variants
+ *                         kernel on the same shape, 0-5 32x32x32 tile / ring variants.  With the default, a block of up
+ *                         to 16 rows x at least 1024 columns of a two-limb set (a search with a few queries) goes to a
+ *                         streaming vector-ALU kernel instead (rows in LDS, one wave per column, v_dot2_i32_i16)
  *   pairwise_symmetric    1 (default) skip tiles below the diagonal and mirror; 0 compute every tile
  *   pairwise_block_cells  row-chunk bound of mvs_pairwise_rows, in cells (default 2^40)
  *   sort                  kept-cell sort: 0 (default) by list length, 1 merge sort, 2 radix sort
@@ -101,6 +104,11 @@ int mvs_ctx_kernel_ms(mvs_ctx* ctx, int which, float* ms);
  *   project_variant       projection kernel: 0 (default) by dimension -- 14 = four 64-dim blocks per wave sharing the
  *                         first splitmix64 round when d is a multiple of 256 (>= 512), else 2 or 1 blocks per wave;
  *                         1 / 2 / 12 / 14 force a variant
+ *   stream_dense          mvs_pairwise_stream where the exact kernel runs: 1 (default) one byte per cell in a matrix, a
+ *                         row block turned into CSR / encoded rows on a side stream beside the next block's launch;
+ *                         2 the same on the context's stream, one after the other; 0 packed 64-bit cells + sort
+ *   stream_block_rows, encode_stage_words, pairwise_map, coarse_radix, cand_regions, recheck_mode, recheck_blocks
+ *                         test / experiment switches (DESIGN.md, appendix "switches")
  *   comm_timeout_s        file transport (mvs_comm_create_files / _rendezvous): seconds a rank waits for its peers
  *   markers               1: roctx ranges named after the entry points around mvs_project_csr / mvs_pairwise_rows /
  *                         mvs_pairwise_block (rocprofv3 --marker-trace); libroctx64 is bound at run time
