@@ -187,6 +187,16 @@ class SketchSet:
         eb = self.ctx._elem_bytes(sketches)
         _check(self.ctx.lib.mvs_sketch_set_fill(self._h, p, eb, m, int(row_offset), n))
 
+    def fill_stats(self, sketches, row_offset=0):
+        """fill() that also returns the largest |v| of the rows it re-coded (one upload instead of a max_abs pass and a
+        fill pass; a value beyond what the set's limb count holds means: allocate again with more limbs)"""
+        n, d = sketches.shape
+        p, m, k = _buf(sketches)
+        eb = self.ctx._elem_bytes(sketches)
+        mx = _c.c_int64()
+        _check(self.ctx.lib.mvs_sketch_set_fill_stats(self._h, p, eb, m, int(row_offset), n, ctypes.byref(mx)))
+        return mx.value
+
     def close(self):
         if self._h:
             self.ctx.lib.mvs_sketch_set_destroy(self._h)

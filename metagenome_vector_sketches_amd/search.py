@@ -39,7 +39,8 @@ def read_db(index_folder):
             parts = line.split()
             names.append(parts[0])
             norms.append(float(parts[1]))
-    vec = np.fromfile(index_folder + "vectors.bin", dtype="<i2" if dtype == "int16" else "<i4")
+    # mapped, not read: search_index hands it to the device in row chunks straight from the page cache
+    vec = np.memmap(index_folder + "vectors.bin", dtype="<i2" if dtype == "int16" else "<i4", mode="r")
     return names, np.array(norms, dtype=np.float64), vec.reshape(-1, d)
 
 
@@ -82,10 +83,22 @@ def search_index(index_folder, query_file, j, ctx=None, verbose=True):
         q_sk = torch.empty((nq, d), dtype=torch.int32, device=dev)
         q_ss = torch.empty(nq, dtype=torch.int64, device=dev)
         q_max = ctx.project_csr_stats(flat, offs, d, q_sk, q_ss)
-        db_max = ctx.max_abs(vectors)
-        limbs = _capi.limbs_for_max_abs(max(q_max, db_max))
-        sset = ctx.sketch_set_alloc(n + nq, d, limbs)
-        sset.fill(vectors, 0)
+        # the database goes up once, in row chunks, re-coded for two limbs unless the queries already need more; a chunk
+        # reports its largest |v| with the same upload, and only if that asks for more limbs is the set built again
+        # (the way pairwise_comp_optimized loads vectors.bin)
+        limbs = max(2, _capi.limbs_for_max_abs(q_max))
+        chunk = max(1, (1 << 30) // (d * vectors.dtype.itemsize))
+        while True:
+            sset = ctx.sketch_set_alloc(n + nq, d, limbs)
+            need = limbs
+            for r0 in range(0, n, chunk):
+                need = max(need, _capi.limbs_for_max_abs(sset.fill_stats(vectors[r0:r0 + chunk], r0)))
+                if need > limbs:
+                    break
+            if need == limbs:
+                break
+            sset.close()
+            limbs = need
         sset.fill(q_sk, n)
         qn2 = q_ss.cpu().numpy().astype(np.float64) / d             # query_norm^2 (:120-121, exact here)
         n2 = torch.from_numpy(np.concatenate([norms * norms, qn2])).to(dev)

@@ -52,3 +52,51 @@ def test_search_matches_float64_restatement(ctx, gold, tmp_path):
     assert first[1][0] == gold.names[6] and abs(first[1][1] - 1.0) < 1e-4
     assert first[2][0] == gold.names[6] and 0.4 < first[2][1] < 0.6           # half subsample B of A: J = 0.5
     assert 3 not in first and 4 not in first                                  # disjoint and empty queries: nothing
+
+
+@pytest.mark.parametrize("case", ["int32", "int16", "three-limbs"])
+def test_search_larger_db(ctx, tmp_path, case):
+    """1300 samples (few query rows x >= 1024 columns: the streaming kernel for two-limb sets), an int16 DB, and a DB whose
+    entries need three limbs -- the loader allocates for two, learns the largest |v| from the upload itself and builds the set
+    again.  vectors.bin is mapped and goes up in row chunks.  Scores against the float64 restatement."""
+    from metagenome_vector_sketches_amd import search
+    from oracle import pyoracle as orc
+    rng = np.random.default_rng(77)
+    n, d, per = 1300, 256, 400
+    pools = [rng.integers(0, 2**62, size=per, dtype=np.uint64) for _ in range(n // 10 + 1)]
+    lists = []
+    for i in range(n):                                          # clusters of 10 share 60 % of their hashes
+        own = rng.integers(0, 2**62, size=int(0.4 * per), dtype=np.uint64)
+        lists.append(np.unique(np.concatenate([pools[i // 10][:int(0.6 * per)], own])))
+    offs = np.zeros(n + 1, dtype=np.int64)
+    offs[1:] = np.cumsum([len(x) for x in lists])
+    vec = ctx.project_csr(np.concatenate(lists), offs, d)
+    if case == "three-limbs":
+        vec = vec * 700                                         # |v| up to ~60 000
+        assert np.abs(vec).max() > 32639
+    db = str(tmp_path / "db") + "/"
+    os.makedirs(db)
+    vec.astype("<i2" if case == "int16" else "<i4").tofile(db + "vectors.bin")
+    norms_txt = "".join("s%d %s\n" % (i, orc.format_norm(orc.norm(vec[i]))) for i in range(n))
+    open(db + "vector_norms.txt", "w").write(norms_txt)
+    open(db + "dimension.txt", "w").write("%d\n" % d)
+    open(db + "dtype.txt", "w").write("int16\n" if case == "int16" else "int32\n")
+    qlists = [lists[5], lists[777], lists[1299][::2], rng.integers(0, 2**62, size=300, dtype=np.uint64)]
+    qf = tmp_path / "queries.txt"
+    with open(qf, "w") as f:
+        for k, h in enumerate(qlists):
+            f.write("q%d:" % k + "".join(" %d" % int(x) for x in h) + "\n")
+    # (a DB scaled by 700 against unscaled queries: J(self) = 700 n / (700^2 n + n - 700 n) ~ 1 / 700)
+    j = 0.0004 if case == "three-limbs" else 0.08
+    got = search.search_index(db, str(qf), j, ctx=ctx, verbose=False)
+    norms = np.array([float(l.split(" ")[1]) for l in norms_txt.split("\n") if l])
+    want = []
+    for qi, h in enumerate(qlists):
+        v = orc.project(np.unique(h), d)
+        want += [(qi, "s%d" % k, jac) for k, jac in orc.search_scores(vec, norms, v, d, j)]
+    assert len(want) >= 10
+    assert sorted((a, b) for a, b, _ in got) == sorted((a, b) for a, b, _ in want)
+    gj = {(a, b): c for a, b, c in got}
+    assert all(abs(gj[(a, b)] - c) <= 1e-5 * abs(c) for a, b, c in want)
+    if case != "three-limbs":                                   # (scaled vectors are no projections of anything)
+        assert [b for a, b, _ in got if a == 0][0] == "s5" and [b for a, b, _ in got if a == 1][0] == "s777"
