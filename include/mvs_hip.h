@@ -87,8 +87,9 @@ int mvs_ctx_kernel_ms(mvs_ctx* ctx, int which, float* ms);
  * context, in mvs_ctx_create: MVS_<NAME> (upper case) gives an option's initial value; afterwards only
  * mvs_ctx_set_option changes it, so two contexts (or two threads with a context each) never interfere.
  *   pairwise_filter       0 exact kernel on every cell; 1 (default) two-stage comparison for blocks of at least
- *                         2^22 cells and more than 16 rows of a two-limb set (fewer than 1024 rows: only if the set's
- *                         coarse plane is already cached); 2 two-stage whenever the set has two limbs (tests)
+ *                         2^22 cells and more than 16 rows of a two-limb set (fewer than 1024 rows: from the second
+ *                         such block on the same set on, or if the set's coarse plane is already cached); 2 two-stage
+ *                         whenever the set has two limbs (tests)
  *   filter_variant        kernel of the one-pass filter: -1 (default) by block size, 8 = ping-pong wave groups on
  *                         256 x 256 tiles (7/9/10 its variants), 0 = 128 x 128 ring, 1 = 256 x 256 ring, 3/5/6 other rings
  *   exact_variant         re-check kernel: 3 (default) tree reduction over rounds of 64 pairs, 0 one shuffle butterfly per

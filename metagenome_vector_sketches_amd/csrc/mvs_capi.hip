@@ -75,6 +75,8 @@ struct mvs_ctx {
     void* pw_cent = nullptr;    size_t pw_cent_bytes = 0;
     unsigned long long coarse_id = 0, coarse_gen = 0;
     int coarse_mode = -1;                   // radix rule (option coarse_radix) the cached plane was built with
+    unsigned long long few_rows_id = 0, few_rows_gen = 0;   // the set whose last comparison was a block of < 1024 rows done by the
+                                                            // exact kernel because no coarse plane existed (pairwise_launch)
     unsigned long long filter_off_id = 0;   // (set, coefficient) for which the filter passed too many pairs
     double filter_off_coeff = 0.0;
     unsigned long long last_candidates = 0; // candidate pairs of the last two-stage comparison (0: exact kernel)
@@ -1204,14 +1206,23 @@ int pairwise_launch(mvs_ctx* c, const mvs_sketch_set* s, const double* d_n2, int
     };
     int rc = MVS_OK;
     const double block_cells = (double)(re - rb) * (double)(ce - cb);
-    // A few rows against everything (a search with a handful of queries) on a set whose coarse plane does not exist yet:
-    // building the plane reads all the limb planes once, which is all the exact kernel needs for such a block.  Up to 16
-    // rows the exact path is a streaming kernel that runs at HBM speed (k_pairwise_skinny): nothing to filter for.
+    // A few rows against everything (a search with a handful of queries; one of very many shards) on a set whose coarse
+    // plane does not exist yet: building the plane reads all the limb planes once, which is all the exact kernel needs for
+    // such a block -- so the FIRST block of fewer than 1024 rows on a set goes to the exact kernel, and only when a second
+    // one follows on the same set (a caller that keeps the set for many such blocks: pairwise_comp_optimized --shard_idx -1
+    // with small shards, repeated searches) is the plane built.  Up to 16 rows the exact path is a streaming kernel that
+    // runs at HBM speed (k_pairwise_skinny): nothing to filter for.
     const bool coarse_cached = c->coarse_id == s->id && c->coarse_gen == s->gen && c->coarse_mode == c->opt.coarse_radix;
+    const bool few_rows = re - rb < 1024;
+    const bool few_rows_again = c->few_rows_id == s->id && c->few_rows_gen == s->gen;
     bool two_stage = filter_mode != 0 && s->limbs == 2 && s->d_pad <= 32768 &&
                      (filter_mode == 2 ||   // forced: also on small blocks and on sets it was found not to pay for
-                      (block_cells >= 4194304.0 && re - rb > 16 && (coarse_cached || re - rb >= 1024) &&
+                      (block_cells >= 4194304.0 && re - rb > 16 && (coarse_cached || !few_rows || few_rows_again) &&
                        !(c->filter_off_id == s->id && c->filter_off_coeff == keep_coeff)));
+    if (!two_stage && few_rows && re - rb > 16 && block_cells >= 4194304.0) {
+        c->few_rows_id = s->id;
+        c->few_rows_gen = s->gen;
+    }
     if (two_stage) {
         rc = prepare_coarse(c, s);
         if (rc) return rc;
