@@ -1966,26 +1966,29 @@ __global__ __launch_bounds__(256) void k_dense_count(const uint8_t* __restrict__
     if (threadIdx.x == 0) counts[blockIdx.x] = (long long)(part[0] + part[1] + part[2] + part[3]);
 }
 
-// col / q of row r at row_ptr[r]: one workgroup per row, 8 KiB of the row per step (32 bytes per thread: the loop is bound by
-// the latency of a step -- load, block-wide prefix sum, stores whose number the compiler cannot count, so every step drains
-// them --, and twice the bytes per step is half the steps), positions by a block-wide prefix sum
+// col / q of row r at row_ptr[r]: one workgroup per row, 4 KiB of the row per step, positions by a block-wide prefix sum.
+// The step's kept cells are gathered in LDS and leave as contiguous runs (thread t writes entries t, t + 256, ...): written
+// straight from the lanes -- every lane a short run of its own, a store instruction touching 64 scattered words -- the
+// kernel wrote 3.3 x its bytes to memory (WRITE_SIZE 1.03 GB per 6250-row block for 0.31 GB of col + q,
+// profiles/r03_c2d_pmc_summary.txt before this change).
 __global__ __launch_bounds__(256) void k_dense_fill(const uint8_t* __restrict__ dense, long long ld, long long n_cols,
                                                     const long long* __restrict__ row_ptr, int32_t* __restrict__ col,
                                                     uint8_t* __restrict__ q) {
     __shared__ unsigned wsum[2][4];
+    __shared__ int32_t s_col[256 * 16];
+    __shared__ uint8_t s_q[256 * 16];
     const uint8_t* row = dense + (long long)blockIdx.x * ld;
     long long base = row_ptr[blockIdx.x];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     unsigned step = 0;
-    for (long long k0 = 0; k0 < n_cols; k0 += 256 * 32, ++step) {
-        const long long k = k0 + (long long)threadIdx.x * 32;
-        v4i wv[2] = {v4i{0, 0, 0, 0}, v4i{0, 0, 0, 0}};
+    for (long long k0 = 0; k0 < n_cols; k0 += 256 * 16, ++step) {
+        const long long k = k0 + (long long)threadIdx.x * 16;
+        v4i wv = v4i{0, 0, 0, 0};
         unsigned m = 0;
-        if (k < n_cols) {                                         // ld is a multiple of 128: both halves are inside the row
-            wv[0] = *reinterpret_cast<const v4i*>(row + k);
-            wv[1] = *reinterpret_cast<const v4i*>(row + k + 16);
-            m = nz_mask16(wv[0]) | (nz_mask16(wv[1]) << 16);
-            if (k + 32 > n_cols) m &= (unsigned)((1ULL << (n_cols - k)) - 1ULL);   // columns beyond the last sample
+        if (k < n_cols) {
+            wv = *reinterpret_cast<const v4i*>(row + k);
+            m = nz_mask16(wv);
+            if (k + 16 > n_cols) m &= (1u << (n_cols - k)) - 1u;   // columns beyond the last sample
         }
         const unsigned mine = (unsigned)__popc(m);
         unsigned incl = mine;
@@ -1994,23 +1997,27 @@ __global__ __launch_bounds__(256) void k_dense_fill(const uint8_t* __restrict__ 
             const unsigned up = (unsigned)__shfl_up((int)incl, o, 64);
             if (lane >= o) incl += up;
         }
-        unsigned* ws = wsum[step & 1];                            // two sets: one barrier per step
+        unsigned* ws = wsum[step & 1];                            // two sets: no barrier between a step's reads and the next step's writes
         if (lane == 63) ws[w] = incl;
-        __syncthreads();
+        __syncthreads();                                          // (also: the previous step's write-out has read s_col / s_q)
         unsigned before = 0, total = 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             before += i < w ? ws[i] : 0u;
             total += ws[i];
         }
-        long long at = base + before + (incl - mine);
+        unsigned at = before + (incl - mine);
         while (m) {
             const int b = __ffs((int)m) - 1;
             m &= m - 1;
-            const v4i half = b < 16 ? wv[0] : wv[1];
-            col[at] = (int32_t)(k + b);
-            q[at] = (uint8_t)((unsigned)half[(b >> 2) & 3] >> (8 * (b & 3)));
+            s_col[at] = (int32_t)(k + b);
+            s_q[at] = (uint8_t)((unsigned)wv[b >> 2] >> (8 * (b & 3)));
             ++at;
+        }
+        __syncthreads();
+        for (unsigned i = threadIdx.x; i < total; i += 256) {
+            col[base + i] = s_col[i];
+            q[base + i] = s_q[i];
         }
         base += total;
     }
