@@ -217,6 +217,9 @@ def main():
     ap.add_argument("--stream-samples", type=int, default=30_000,
                     help="N=1: size of the streamed-output leg at the density of the reference's toy set (clusters of N/3 "
                          "samples: a third of all cells kept), mvs_pairwise_stream with a counting callback; 0 skips it")
+    ap.add_argument("--search-samples", type=int, default=500_000,
+                    help="N=1: database size of the search leg (1 / 16 / 1024 query sketches against that many resident "
+                         "sketches, mvs_search_block); 0 skips it")
     ap.add_argument("--overlap-parts", type=int, default=2,
                     help="N > 1: pieces the rank's samples are projected in; the all-gather of a finished piece's limb "
                          "planes runs beside the projection of the next (1: no overlap)")
@@ -474,6 +477,9 @@ def main():
 
     if args.stream_samples and world == 1:
         res["streamed_dense"] = stream_leg(ctx, dev, args.stream_samples, args.pairwise_dim, NH)
+
+    if args.search_samples and world == 1:
+        res["search"] = search_leg(ctx, dev, args.search_samples, args.pairwise_dim, NH)
 
     if args.host_input and world == 1:
         h_host = hashes.cpu().numpy().view(np.uint64)                                      # pageable, as a caller's vector would be
@@ -749,6 +755,48 @@ def stream_leg(ctx, dev, n, d, nh, reps=3):
                              "wall_ms": float(np.mean(ewalls)), "bytes_to_host": int(estats["bytes"]),
                              "bytes_per_kept_cell": estats["bytes"] / max(cnt.value, 1),
                              "kept_cells_per_s": cnt.value / (float(np.mean(ewalls)) * 1e-3)}}
+
+
+def search_leg(ctx, dev, n, d, nh, reps=5):
+    """SURVEY 8f row 4, device part: q query sketches against n resident database sketches (mvs_search_block; the reference
+    runs FAISS IndexFlatIP on float32 copies on the CPU).  1 and 16 queries take the streaming kernel (k_pairwise_skinny: the
+    limb planes are read once, front to back -- its bound is HBM), 1024 the MFMA kernels on the tile map for skinny
+    blocks.  Algorithmic bytes = the database's limb planes once (2 * d_pad per sketch)."""
+    import torch
+    from metagenome_vector_sketches_amd import synth
+    nq_max = 1024
+    sset = ctx.sketch_set_alloc(n + nq_max, d, 2)
+    ss_all = torch.empty(n + nq_max, dtype=torch.int64, device=dev)
+    step = 100_000
+    for r0 in range(0, n + nq_max, step):                    # database first, the queries are the last rows
+        rows = min(step, n + nq_max - r0)
+        sk = synth.make_sketches_torch(rows, d, nh, seed=4567 + r0, device=dev)
+        ctx.sumsq(sk, out=ss_all[r0:r0 + rows])
+        sset.fill(sk, r0)
+        del sk
+    n2 = ss_all.double() / d
+    cells = torch.empty((1 << 20, 4), dtype=torch.int32, device=dev)
+    plane_bytes = float(n) * sset.d_pad * 2
+    out = {"workload": "%d resident synthetic sketches, d=%d, two limbs: q query sketches against all of them, Jaccard > 0.1"
+                       % (n, d), "algorithmic_bytes": plane_bytes, "queries": {}}
+    for nq in (1, 16, 1024):
+        walls, kern = [], []
+        for r in range(reps + 2):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            hits = ctx.search_block(sset, n2, 0.1, n, n + nq, 0, n, cells)
+            torch.cuda.synchronize()
+            if r >= 2:
+                walls.append((time.perf_counter() - t0) * 1e3)
+                kern.append(ctx.kernel_ms(1))
+        k = float(np.mean(kern))
+        out["queries"][str(nq)] = {"wall_ms": float(np.mean(walls)), "kernel_ms": k, "hits": int(hits),
+                                   "pairs_per_s": float(n) * nq / (float(np.mean(walls)) * 1e-3),
+                                   "two_stage_candidates": int(ctx.pairwise_candidates()),
+                                   "roofline": {"bound": "hbm", "achieved": plane_bytes / (k * 1e-3) / 1e9, "peak": 8000.0,
+                                                "unit": "GB/s", "frac": plane_bytes / (k * 1e-3) / 1e9 / 8000.0}}
+    sset.close()
+    return out
 
 
 def usable_cores(visible):
