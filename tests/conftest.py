@@ -76,6 +76,57 @@ class Golden:
     def norm_lines(self):
         return [l for l in self.norms_txt.split("\n") if l]
 
+    @staticmethod
+    def formula_sketches(n, d, seed, cluster, amp, shared_amp):
+        """the sketches of a ref_pairwise.json case given as a formula (tests/golden/make_golden_pairwise.py wrote the same
+        rows to the vectors.bin the reference functions read): noise(row, k) + shared(cluster(row), k), both uniform
+        integers from a splitmix64 counter"""
+        def mix(x):
+            x = x + np.uint64(0x9e3779b97f4a7c15)
+            x = (x ^ (x >> np.uint64(30))) * np.uint64(0xbf58476d1ce4e5b9)
+            x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94d049bb133111eb)
+            return x ^ (x >> np.uint64(31))
+        with np.errstate(over="ignore"):
+            rows = np.arange(n, dtype=np.uint64)[:, None]
+            ks = np.arange(d, dtype=np.uint64)[None, :]
+            a = mix(np.uint64(seed) * np.uint64(1000003) + rows * np.uint64(65537) + ks)
+            b = mix(np.uint64(seed) * np.uint64(7919) + (rows // np.uint64(cluster)) * np.uint64(2654435761) + ks
+                    + np.uint64(1 << 40))
+        return ((a % np.uint64(2 * amp + 1)).astype(np.int64) - amp
+                + (b % np.uint64(2 * shared_amp + 1)).astype(np.int64) - shared_amp)
+
+    def ref_pairwise_cases(self):
+        """kept cells of the REFERENCE's own pairwise functions (oracle/_ref/ref_pairwise32 / 16, compiled from line ranges
+        of src/pairwise_comp_optimized*.cpp; tests/golden/make_golden_pairwise.py): name -> dict(elem, d, vectors,
+        norm_lines, norms_sq, runs=[dict(max_memory_gb, chunk, num_shards, shard_idx, cells int64 [kept, 3] in the
+        reference's append order, cells_sha256)])"""
+        if getattr(self, "_ref_pairwise", None) is None:
+            with open(os.path.join(GOLD, "ref_pairwise.json")) as f:
+                meta = json.load(f)["cases"]
+            data = np.load(os.path.join(GOLD, "ref_pairwise_inputs.npz"))
+            out = {}
+            for name, c in meta.items():
+                dt = np.int32 if c["elem"] == 4 else np.int16
+                src = c["vectors"]
+                if src == "inline":
+                    vec = data[name]
+                elif src == "toy_db":
+                    vec = self.vectors
+                elif src == "toy_db_int16":
+                    vec = np.clip(self.vectors, -32768, 32767)
+                else:
+                    vec = self.formula_sketches(**{k: v for k, v in src.items() if k != "formula"})
+                n2 = []
+                for l in c["norm_lines"]:
+                    x = float(l.split(" ", 1)[1])          # :893-901 stod(text after the first ' ')
+                    n2.append(x * x)
+                runs = [dict(r, cells=data[r["cells"]]) for r in c["runs"]]
+                out[name] = dict(elem=c["elem"], d=c["d"], vectors=np.ascontiguousarray(vec, dtype=dt),
+                                 norm_lines=c["norm_lines"], norms_sq=np.array(n2, dtype=np.float64), runs=runs)
+                assert out[name]["vectors"].shape == (c["n"], c["d"])
+            self._ref_pairwise = out
+        return self._ref_pairwise
+
 
 @pytest.fixture(scope="session")
 def gold():

@@ -174,6 +174,34 @@ def test_pairwise_on_reference_db(gold, tmp_path):
     assert got == want
 
 
+def test_pairwise_executable_against_the_references_own_functions(gold, tmp_path):
+    """the drop-in executable on the DB folders the reference's own functions were run on (ref_pairwise.json:
+    oracle/_ref/ref_pairwise32 / 16, tests/golden/make_golden_pairwise.py): same --max_memory_gb / --num_shards /
+    --shard_idx, the decoded shard holds exactly the reference's kept (row, col) set.  Norms go through the executable's
+    own text parser (:893-901), the int16 DBs through dtype.txt dispatch (:873-876)."""
+    exe = os.path.join(BIN, "pairwise_comp_optimized")
+    for name, c in gold.ref_pairwise_cases().items():
+        if c["vectors"].shape[0] > 400:
+            continue                                   # the 2100-row formula case runs at library level
+        db = str(tmp_path / name) + "/"
+        os.makedirs(db)
+        c["vectors"].tofile(db + "vectors.bin")
+        open(db + "vector_norms.txt", "w").write("".join(l + "\n" for l in c["norm_lines"]))
+        open(db + "dimension.txt", "w").write("%d\n" % c["d"])
+        open(db + "dtype.txt", "w").write("int32\n" if c["elem"] == 4 else "int16\n")
+        for k, rn in enumerate(c["runs"]):
+            out = str(tmp_path / (name + "_out%d" % k))
+            r = run(exe, "--db", db, "--max_memory_gb", repr(float(rn["max_memory_gb"] or 1)), "--num_threads", "4",
+                    "--output_folder", out, "--num_shards", str(rn["num_shards"]), "--shard_idx", str(rn["shard_idx"]))
+            assert r.returncode == 0, (name, r.stderr)
+            if c["elem"] == 4:
+                assert "Using chunks of size %d" % rn["chunk"] in r.stdout, name
+            want = sorted((x[0], x[1]) for x in rn["cells"].tolist())
+            shard = os.path.join(out, "shard_%d" % rn["shard_idx"])
+            got = [(r_, c_) for r_, c_, _ in _dump(shard)] if want else []
+            assert got == want, (name, k)
+
+
 @pytest.mark.parametrize("contexts", [1, 2, 5])
 def test_pairwise_all_shards_from_one_process(gold, tmp_path, contexts):
     """--shard_idx -1 (extension): all shards from one process, one device context and host thread per GPU, shard s on GPU

@@ -119,6 +119,29 @@ def test_toy_cells_reference_db(ctx, gold, pw_filter):
     ss16.close()
 
 
+def test_kept_cells_equal_the_references_own_functions(ctx, gold, pw_filter):
+    """a5/a6/a10/a11 against REFERENCE output: every run recorded from oracle/_ref/ref_pairwise32 / ref_pairwise16 (the
+    reference's own loaders, product and keep test of both dtypes, compiled from line ranges of its sources:
+    tests/golden/make_golden_pairwise.py) -- toy DB, cells on the keep threshold, products that wrap mod 2^32, NaN /
+    infinite / negative norms, d = 100, shards -- reproduced by the HIP path: the same (row, col, dot), bit for bit, on
+    every comparison path.  The library's order is (row, col); the reference's is its tile loop's (:949-982)."""
+    for name, c in gold.ref_pairwise_cases().items():
+        ss = ctx.sketch_set(c["vectors"])
+        keep = _capi.KEEP_INT32 if c["elem"] == 4 else _capi.KEEP_INT16
+        for run in c["runs"]:
+            b, e = orc.shard_rows(len(c["vectors"]), run["num_shards"], run["shard_idx"])
+            cells, cnt = ctx.pairwise_rows(ss, c["norms_sq"], row_begin=b, row_end=e, keep_mode=keep)
+            got = [(int(x["row"]), int(x["col"]), int(x["dot"])) for x in cells]
+            assert cnt == run["kept"], (name, run["num_shards"], run["shard_idx"])
+            assert got == sorted(tuple(x) for x in run["cells"].tolist()), (name, run["num_shards"], run["shard_idx"])
+        # the streamed form the executable uses carries (row, col, q): the same kept SET
+        row_ptr, col, q, n_stream = ctx.pairwise_stream(ss, c["norms_sq"], keep_mode=keep)
+        whole = [r for r in c["runs"] if r["num_shards"] == 1][0]
+        rows = np.repeat(np.arange(len(row_ptr) - 1), np.diff(row_ptr))
+        assert sorted(zip(rows.tolist(), col.tolist())) == sorted((x[0], x[1]) for x in whole["cells"].tolist()), name
+        ss.close()
+
+
 def test_clustered_synthetic_vs_oracle(ctx, pw_filter):
     """sketches of real (synthetic) hash sets: clusters of 16 with Jaccard ~0.25 -> ~16 kept cells per row"""
     hashes, offsets = synth.make_csr_numpy(400, 3000, seed=5, cluster=16, shared=0.4, lognormal_sigma=0.8)
