@@ -56,6 +56,9 @@ struct Options {
     int recheck_mode = 1;           // re-check work split: 1 first round fixed + per-XCD counter, 2 counter only, 0 fixed stride, 3 eighths
     int recheck_blocks = 24;        // re-check grid in units of 256 workgroups (24: one round per wave at 100k samples)
     int cand_regions = 1;           // 1: filter waves leave up to 8 candidates in a region of their own (no atomic to wait for)
+    int tile_dense_thr = 64;        // ping-pong filter: a wave with more candidates than this flags its 256 x 256 tile for the
+                                    // exact kernel instead of listing them (0: list everything, give up on the block when the
+                                    // list passes 1/128 of its cells -- the behaviour up to round 3)
     int comm_timeout_s = 600;       // file transport: how long a rank waits for a peer's block before it gives up
     double pairwise_block_cells = 1099511627776.0;   // row-chunk bound of mvs_pairwise_rows (2^40 cells)
 };
@@ -122,6 +125,18 @@ struct PairwiseArgs {
     int2* cand_ent;                  //    left in its kCandRegion entries (0: none, or it went to the list itself)
     unsigned int* cand_stop;         // set by the wave that takes the counter past the limit; lives on its own cache
                                      // line (polling the counter itself queues behind its atomics)
+    // Tile-granular two-stage comparison (ping-pong filter on 256 x 256 tiles).  A filter wave that finds more than
+    // tile_dense_thr candidates in its 128 x 64 cells does not list them: it flags its tile, tile_flag[tr * tile_flag_ld +
+    // tc] (tr, tc relative to row_begin / col_begin in units of 256), and the exact ping-pong kernel later computes the
+    // flagged tiles -- and only those -- from tile_list (four 128 x 128 tiles each).  Candidates that other waves of a
+    // flagged tile had already listed are dropped by k_cand_prune before the re-check, so no cell is produced twice.
+    unsigned int* tile_flag;         // NULL: every candidate is listed (ring filters, option tile_dense_thr = 0)
+    int tile_flag_ld;
+    unsigned int tile_dense_thr;
+    unsigned int* tile_flag_count;   // flagged tiles so far; beyond tile_flag_limit the filter raises cand_stop (the result
+    unsigned int tile_flag_limit;    //    is dense nearly everywhere: the exact kernel alone is faster)
+    const int* tile_list;            // k_pairwise_pp<0>: flagged filter tiles (row-major ids), NULL = the whole grid
+    int tile_list_n;
 };
 
 // per-row statistics of the coarse plane: radix m, sum c^2, sum r^2 (r = v - m*c), and whether the row's sum
@@ -162,6 +177,16 @@ int launch_exact_pairs(hipStream_t stream, const PairwiseArgs& a, const Options&
 // the variant it would pick appends with atomics only; k_cand_gather moves the regions' contents into the candidate list
 int64_t filter_region_count(const PairwiseArgs& a, const Options& opt);
 int launch_cand_gather(hipStream_t stream, const PairwiseArgs& a, int64_t n_regions);
+// tile-granular two-stage comparison: does launch_filter pick a kernel that can flag tiles for this block, and the tile
+// grid (256 x 256) it works on; flags -> per-tile-row counts -> row-major list of flagged tile ids (d_list holds the total);
+// candidates whose tile is flagged are dropped (d_out / d_out_count: the pruned list); the exact kernel on a run of the list
+bool filter_flags_tiles(const PairwiseArgs& a, const Options& opt);
+void filter_tile_grid(const PairwiseArgs& a, int* n_tr, int* n_tc);
+int launch_tile_count(hipStream_t stream, const unsigned int* d_flags, int n_tr, int n_tc, int* d_row_count);
+int launch_tile_list(hipStream_t stream, const unsigned int* d_flags, int n_tr, int n_tc, const int* d_row_count, int* d_list);
+int launch_cand_prune(hipStream_t stream, const PairwiseArgs& a, unsigned long long n_cand, int2* d_out,
+                      unsigned long long* d_out_count);
+int launch_exact_tiles(hipStream_t stream, const PairwiseArgs& a, const int* d_list, int n_list, const Options& opt);
 // packed cells of the streamed output: radix sort on the (row, col) bits, then CSR arrays (row_ptr over `rows` rows,
 // col, q as 8 bits -- *d_wide set if some q needs 16 -- or as 16 bits when d_q16 is given)
 int sort_packed(hipStream_t stream, unsigned long long* d_in, unsigned long long* d_out, int64_t n, int begin_bit, int end_bit,
