@@ -79,8 +79,9 @@ int mvs_ctx_synchronize(mvs_ctx* ctx);
 /* Optional kernel timing: when enabled, HIP events are recorded on the context's stream around the
  * dominant kernel of mvs_project_csr (which = 0) and around the comparison kernels of mvs_pairwise_rows /
  * _block / mvs_search_block (which = 1: the whole comparison -- filter + re-check, or the exact kernel;
- * which = 2: the filter kernel alone; which = 3: the re-check kernel alone; 2 and 3 are only recorded by a
- * two-stage comparison).  mvs_ctx_kernel_ms returns the duration of the most recent such launch in ms. */
+ * which = 2: the filter kernel alone; which = 3: the re-check kernel with the list passes in front of it; which = 4:
+ * the exact kernel on the tiles the filter flagged as dense; 2 and 3 are only recorded by a two-stage comparison, 4 only
+ * when it flagged tiles).  mvs_ctx_kernel_ms returns the duration of the most recent such launch in ms. */
 int mvs_ctx_set_timing(mvs_ctx* ctx, int enabled);
 int mvs_ctx_kernel_ms(mvs_ctx* ctx, int which, float* ms);
 /* Tuning / diagnostic options of a context, by name.  The library reads the environment exactly once per
@@ -108,6 +109,9 @@ int mvs_ctx_kernel_ms(mvs_ctx* ctx, int which, float* ms);
  *   stream_dense          mvs_pairwise_stream where the exact kernel runs: 1 (default) one byte per cell in a matrix, a
  *                         row block turned into CSR / encoded rows on a side stream beside the next block's launch;
  *                         2 the same on the context's stream, one after the other; 0 packed 64-bit cells + sort
+ *   tile_dense_thr        two-stage comparison on large blocks: a filter wave (128 x 64 cells) with more candidates than this
+ *                         flags its 256 x 256 tile for the exact kernel instead of listing them (default 64; 0 = list
+ *                         everything and give the whole block to the exact kernel once the list passes 1/128 of its cells)
  *   stream_block_rows, encode_stage_words, pairwise_map, coarse_radix, cand_regions, recheck_mode, recheck_blocks
  *                         test / experiment switches (DESIGN.md, appendix "switches")
  *   comm_timeout_s        file transport (mvs_comm_create_files / _rendezvous): seconds a rank waits for its peers
@@ -124,6 +128,11 @@ int mvs_ctx_get_option(const mvs_ctx* ctx, const char* name, int64_t* value);
  * of candidate pairs its coarse filter passed on to the exact re-check, 0 if the exact kernel ran on
  * every cell (see mvs_pairwise_rows). */
 int mvs_ctx_pairwise_candidates(mvs_ctx* ctx, int64_t* candidates);
+/* The same with the tile-granular part of the two-stage comparison: `flagged_tiles` of the `filter_tiles` 256 x 256 tiles the
+ * filter pass worked on held so many candidates that the exact kernel computed them whole instead (dense regions of the
+ * result; the reference's cost is flat in the density, src/pairwise_comp_optimized.cpp:135-147 -- this keeps ours from
+ * falling off a cliff between "sparse" and "dense").  Any pointer may be NULL. */
+int mvs_ctx_pairwise_stats(mvs_ctx* ctx, int64_t* candidates, int64_t* flagged_tiles, int64_t* filter_tiles);
 
 /* ---- projection ----------------------------------------------------------------------------------
  * Replaces transform_set_into_vector() (src/random_projection.cpp:9-26) called once per sample from
@@ -306,7 +315,8 @@ int mvs_pairwise_stream_encoded(mvs_ctx* ctx, const mvs_sketch_set* set, const d
 
 /* What the most recent mvs_pairwise_stream of the context did: time of its comparison kernels summed over the row blocks
  * (0 unless mvs_ctx_set_timing is on), bytes handed to the callback, row blocks computed, pieces delivered, and whether
- * the two-stage comparison (1) or the exact kernel in row blocks (0) produced them.  Any pointer may be NULL. */
+ * the two-stage comparison produced them as one list (1) or through the dense byte matrix, its flagged tiles computed row
+ * block by row block (2), or the exact kernel alone in row blocks (0).  Any pointer may be NULL. */
 int mvs_ctx_stream_stats(const mvs_ctx* ctx, double* kernel_ms, int64_t* bytes_out, int64_t* row_blocks, int64_t* pieces,
                          int* two_stage);
 

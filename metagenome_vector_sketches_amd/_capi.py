@@ -59,6 +59,7 @@ SYMBOLS = [
     ("mvs_ctx_set_timing", _c.c_int, [_P, _c.c_int]),
     ("mvs_ctx_kernel_ms", _c.c_int, [_P, _c.c_int, _c.POINTER(_c.c_float)]),
     ("mvs_ctx_pairwise_candidates", _c.c_int, [_P, _c.POINTER(_c.c_int64)]),
+    ("mvs_ctx_pairwise_stats", _c.c_int, [_P, _c.POINTER(_c.c_int64), _c.POINTER(_c.c_int64), _c.POINTER(_c.c_int64)]),
     ("mvs_project_csr", _c.c_int, [_P, _P, _c.c_int, _P, _c.c_int64, _c.c_int, _P, _c.c_int]),
     ("mvs_project_csr_stats", _c.c_int, [_P, _P, _c.c_int, _P, _c.c_int64, _c.c_int, _P, _c.c_int, _P,
                                           _c.POINTER(_c.c_int64)]),
@@ -370,6 +371,13 @@ class Context:
         _check(self.lib.mvs_ctx_pairwise_candidates(self._h, ctypes.byref(v)))
         return v.value
 
+    def pairwise_stats(self):
+        """(candidates, flagged_tiles, filter_tiles) of the last two-stage comparison: pairs re-checked one by one, and how
+        many of the filter's 256 x 256 tiles went to the exact kernel whole"""
+        a, b, t = _c.c_int64(), _c.c_int64(), _c.c_int64()
+        _check(self.lib.mvs_ctx_pairwise_stats(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(t)))
+        return a.value, b.value, t.value
+
     # ---- projection ----
     def project_csr(self, hashes, offsets, d, out=None):
         """hashes: uint64 numpy array or torch CUDA tensor (int64 view of the bits is accepted);
@@ -627,11 +635,11 @@ class Context:
                 "bytes": cat(6, np.uint8), "n_cells": count.value, "pieces": len(parts)}
 
     def stream_stats(self):
-        """what the last pairwise_stream did: dict(kernel_ms, bytes, row_blocks, pieces, two_stage)"""
+        """what the last pairwise_stream did: dict(kernel_ms, bytes, row_blocks, pieces, two_stage: 0 exact kernel, 1 two-stage as one list, 2 two-stage through the dense byte matrix)"""
         k, b, r, p_, t = _c.c_double(), _c.c_int64(), _c.c_int64(), _c.c_int64(), _c.c_int()
         _check(self.lib.mvs_ctx_stream_stats(self._h, ctypes.byref(k), ctypes.byref(b), ctypes.byref(r), ctypes.byref(p_),
                                              ctypes.byref(t)))
-        return {"kernel_ms": k.value, "bytes": b.value, "row_blocks": r.value, "pieces": p_.value, "two_stage": bool(t.value)}
+        return {"kernel_ms": k.value, "bytes": b.value, "row_blocks": r.value, "pieces": p_.value, "two_stage": int(t.value)}
 
     def pairwise_block(self, sset, norms_sq, row_begin, row_end, col_begin, col_end, flags, cells, n_cells,
                        keep_mode=KEEP_INT32):

@@ -28,7 +28,7 @@ struct mvs_ctx {
     // event pairs: 0 projection kernel, 1 whole comparison (filter + re-check, or the exact kernel),
     // 2 the filter kernel alone, 3 the re-check kernel alone
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    bool ev_valid[4] = {false, false, false, false};
+    bool ev_valid[5] = {false, false, false, false, false};   // [4]: exact kernel on the flagged tiles (ev[6]..ev[3])
     // reusable device scratch
     void* scratch = nullptr;
     size_t scratch_bytes = 0;
@@ -53,6 +53,9 @@ struct mvs_ctx {
     void* st_rowptr = nullptr;  size_t st_rowptr_bytes = 0;
     void* st_counts = nullptr;  size_t st_counts_bytes = 0;
     void* st_dense = nullptr;   size_t st_dense_bytes = 0;  // dense results: one byte per cell (mvs_internal.h)
+    size_t st_dense_zero = 0;   // the first st_dense_zero bytes of st_dense are zero once the work queued on `stream` is through:
+                                // the tile-granular dense flow needs a cleared matrix, clears it again behind its last block --
+                                // while the link still drains -- and so finds it clean the next time
     // rows encoded on the device (mvs_pairwise_stream_encoded): per-row sizes / offsets / directory, the records themselves
     void* en_size = nullptr;    size_t en_size_bytes = 0;
     void* en_off = nullptr;     size_t en_off_bytes = 0;
@@ -71,6 +74,13 @@ struct mvs_ctx {
     // what the last mvs_pairwise_stream did (mvs_ctx_stream_stats)
     double st_kernel_ms = 0.0;                    // comparison kernels, summed over the row blocks (timing enabled)
     long long st_bytes = 0, st_blocks = 0, st_pieces = 0, st_two_stage = 0;
+    // tile-granular two-stage comparison: tile flags, flagged tiles per tile row, their row-major list (entry 0 = total),
+    // the candidate list without the pairs of flagged tiles
+    void* pw_tflag = nullptr;   size_t pw_tflag_bytes = 0;
+    void* pw_trow = nullptr;    size_t pw_trow_bytes = 0;
+    void* pw_tlist = nullptr;   size_t pw_tlist_bytes = 0;
+    void* pw_cand2 = nullptr;   size_t pw_cand2_bytes = 0;
+    long long last_flagged_tiles = 0, last_filter_tiles = 0;   // of the last two-stage comparison (mvs_ctx_pairwise_stats)
     void* pw_chdr = nullptr;    size_t pw_chdr_bytes = 0;   // candidate regions of the ping-pong filter: counts, entries
     void* pw_cent = nullptr;    size_t pw_cent_bytes = 0;
     unsigned long long coarse_id = 0, coarse_gen = 0;
@@ -252,6 +262,8 @@ const OptionSpec kOptions[] = {
     {"stream_dense", &mvs::Options::stream_dense, nullptr, 0, 2},
     {"encode_stage_words", &mvs::Options::encode_stage_words, nullptr, 1, 64},
     {"stream_block_rows", &mvs::Options::stream_block_rows, nullptr, 0, 1 << 30},
+    {"tile_dense_thr", &mvs::Options::tile_dense_thr, nullptr, 0, 8192},
+    {"stream_list_cells", &mvs::Options::stream_list_cells, nullptr, 0, 1 << 30},
     {"pairwise_block_cells", nullptr, &mvs::Options::pairwise_block_cells, 1, (1LL << 62)},
 };
 
@@ -429,6 +441,8 @@ int mvs_ctx_destroy(mvs_ctx* c) {
     if (c->cmp_done) (void)hipEventDestroy(c->cmp_done);
     if (c->pw_chdr) (void)hipFree(c->pw_chdr);
     if (c->pw_cent) (void)hipFree(c->pw_cent);
+    for (void* p : {c->pw_tflag, c->pw_trow, c->pw_tlist, c->pw_cand2})
+        if (p) (void)hipFree(p);
     for (int i = 0; i < 2; ++i) {
         if (c->up_pinned[i]) (void)hipHostFree(c->up_pinned[i]);
         if (c->up_done[i]) (void)hipEventDestroy(c->up_done[i]);
@@ -492,12 +506,21 @@ int mvs_ctx_pairwise_candidates(mvs_ctx* c, int64_t* candidates) {
     return MVS_OK;
 }
 
+int mvs_ctx_pairwise_stats(mvs_ctx* c, int64_t* candidates, int64_t* flagged_tiles, int64_t* filter_tiles) {
+    if (!c) return fail(MVS_E_INVALID, "ctx is NULL");
+    if (candidates) *candidates = (int64_t)c->last_candidates;
+    if (flagged_tiles) *flagged_tiles = (int64_t)c->last_flagged_tiles;
+    if (filter_tiles) *filter_tiles = (int64_t)c->last_filter_tiles;
+    return MVS_OK;
+}
+
 int mvs_ctx_kernel_ms(mvs_ctx* c, int which, float* ms) {
-    if (!c || !ms || which < 0 || which > 3) return fail(MVS_E_INVALID, "bad argument");
+    if (!c || !ms || which < 0 || which > 4) return fail(MVS_E_INVALID, "bad argument");
     if (!c->ev_valid[which]) return fail(MVS_E_INVALID, "no timing recorded for kernel %d", which);
-    // pairs 2 and 3 share events with pair 1: filter = ev[2]..ev[5], re-check = ev[5]..ev[3]
-    hipEvent_t b = which == 2 ? c->ev[2] : which == 3 ? c->ev[5] : c->ev[2 * which];
-    hipEvent_t e = which == 2 ? c->ev[5] : which == 3 ? c->ev[3] : c->ev[2 * which + 1];
+    // pairs 2, 3 and 4 share events with pair 1: filter = ev[2]..ev[5], re-check (with the gather / tile list / prune
+    // passes in front of it) = ev[5]..ev[7], exact kernel on the flagged tiles (the last such launch) = ev[6]..ev[3]
+    hipEvent_t b = which == 2 ? c->ev[2] : which == 3 ? c->ev[5] : which == 4 ? c->ev[6] : c->ev[2 * which];
+    hipEvent_t e = which == 2 ? c->ev[5] : which == 3 ? c->ev[7] : which == 4 ? c->ev[3] : c->ev[2 * which + 1];
     HIP_TRY(hipEventSynchronize(e));
     HIP_TRY(hipEventElapsedTime(ms, b, e));
     return MVS_OK;
@@ -1130,13 +1153,22 @@ struct DenseOut {
     unsigned int* flag;
 };
 
-int pairwise_launch(mvs_ctx* c, const mvs_sketch_set* s, const double* d_n2, int keep_mode, int64_t rb, int64_t re,
-                    int64_t cb, int64_t ce, bool symmetric, bool mirror_all, mvs_cell* raw, int64_t capacity,
-                    unsigned long long start, unsigned long long* count, double keep_coeff = 0.05,
-                    const PackedOut* po = nullptr, const DenseOut* dn = nullptr) {
-    // *count: the cell count if this call already had to synchronise for it, ~0 otherwise (read d_counter[0])
-    *count = ~0ULL;
-    mvs::PairwiseArgs a{};
+// ---- the two-stage comparison, stage by stage ----
+// What the filter stage leaves for the stages after it.  The stages are separate functions because the streamed output
+// decides BETWEEN them how the kept cells leave the device (a list when they are few, the dense byte matrix when whole
+// regions of the result are dense) and, for the matrix, launches the flagged tiles row block by row block.
+struct TwoStage {
+    mvs::PairwiseArgs a{};            // the filter launch's arguments: candidate list (pruned), tile grid, symmetric square
+    bool tiles = false;               // the filter could flag tiles (tile-granular comparison)
+    int n_tr = 0, n_tc = 0;           // its grid of 256 x 256 tiles
+    unsigned long long n_cand = 0;    // listed candidates (an upper bound once the list has been pruned)
+    int n_flagged = 0;                // flagged tiles
+    std::vector<int> row_first;       // n_tr + 1 entries: where each tile row starts in the row-major list of flagged tiles
+    const int* d_list = nullptr;      // that list on the device
+};
+
+void fill_args(mvs_ctx* c, const mvs_sketch_set* s, const double* d_n2, int keep_mode, int64_t rb, int64_t re, int64_t cb,
+               int64_t ce, bool symmetric, bool mirror_all, double keep_coeff, mvs::PairwiseArgs& a) {
     a.planes = s->planes;
     a.n = s->n;
     a.n_alloc = s->n_alloc;
@@ -1149,6 +1181,245 @@ int pairwise_launch(mvs_ctx* c, const mvs_sketch_set* s, const double* d_n2, int
     a.sym_end = re;
     a.col_begin = cb;
     a.col_end = ce;
+    a.norms_sq = d_n2;
+    a.keep_mode = keep_mode;
+    a.keep_coeff = keep_coeff;
+    a.counter = c->d_counter;
+    a.dots = nullptr;
+    a.mirror_all = mirror_all ? 1 : 0;
+    a.debug_flags = c->opt.pairwise_debug;
+    a.map_mode = c->opt.pairwise_map;
+    a.stamps = nullptr;
+    a.symmetric = (symmetric && c->opt.pairwise_symmetric) ? 1 : 0;   // the launcher checks the alignment
+}
+
+// the running cell count starts at `start` (appending calls)
+int set_cell_count(mvs_ctx* c, unsigned long long start) {
+    c->h_start = start;   // outlives the asynchronous copy
+    if (start == 0) HIP_TRY(hipMemsetAsync(c->d_counter, 0, 8, c->stream));
+    else HIP_TRY(hipMemcpyAsync(c->d_counter, &c->h_start, 8, hipMemcpyHostToDevice, c->stream));
+    return MVS_OK;
+}
+
+// Stage 1: coarse plane, filter constants, the filter pass, candidate regions -> list, tile flags -> list, pruning.
+// `a` comes in with geometry and keep test filled (fill_args); outputs (cells / packed / dense) are the later stages'.
+// hold_all: size the candidate list for whatever the filter may pass on, so that it never runs twice (streamed output).
+// Returns MVS_OK with `ts` filled, kNeedExact when the filter gave up (the exact kernel should do the block), or an error.
+int two_stage_filter(mvs_ctx* c, const mvs_sketch_set* s, const double* d_n2, double keep_coeff, int64_t capacity_hint,
+                     bool hold_all, unsigned long long start, mvs::PairwiseArgs& a, TwoStage& ts) {
+    const double block_cells = (double)(a.row_end - a.row_begin) * (double)(a.col_end - a.col_begin);
+    int rc = prepare_coarse(c, s);
+    if (rc) return rc;
+    rc = ensure_buf(c, &c->pw_fmeta, &c->pw_fmeta_bytes, (size_t)s->n_alloc * sizeof(float4));
+    if (rc) return rc;
+    mvs::launch_filter_meta(c->stream, (const mvs::CoarseRow*)c->pw_rows, d_n2, s->n, s->n_alloc, s->d, keep_coeff,
+                            (float4*)c->pw_fmeta);
+    rc = check_kernel("k_filter_meta");
+    if (rc) return rc;
+    const bool forced = c->opt.pairwise_filter == 2;
+    ts.tiles = mvs::filter_flags_tiles(a, c->opt);
+    mvs::filter_tile_grid(a, &ts.n_tr, &ts.n_tc);
+    // the symmetric schedule computes the tiles on and above the diagonal of the square only
+    const bool sym = a.symmetric && (a.row_begin - a.col_begin) % 256 == 0 && !a.mirror_all;
+    const double sq_tiles = (double)(a.sym_end - a.sym_begin) / 256.0;
+    const double tiles_to_do = std::max(1.0, (double)ts.n_tr * (double)ts.n_tc - (sym ? 0.5 * sq_tiles * (sq_tiles - 1.0) : 0.0));
+    c->last_filter_tiles = (long long)tiles_to_do;
+    c->last_flagged_tiles = 0;
+    // Listing: re-checking a candidate costs about as much as 80-300 cells of the exact kernel (by how well the rows
+    // cache) and the filter pass a third of it.
+    //  * Tile-granular (ping-pong filter): a wave with more than tile_dense_thr candidates flags its 256 x 256 tile for
+    //    the exact kernel, so the list holds at most 8 x tile_dense_thr pairs per tile and needs no global limit; the
+    //    launch stops only when nearly every tile is flagged (the exact kernel alone is then faster: filter + f x exact
+    //    against exact, break-even near f = 0.7), and that set's later blocks skip the filter.
+    //  * Otherwise (ring filters on small blocks, tile_dense_thr = 0): beyond ~1/128 of the block's cells in the list the
+    //    filter tiles and the re-check give up and the exact kernel does the block, as up to round 3.
+    // Forced mode (pairwise_filter = 2, tests) has no limit of either kind.
+    const unsigned long long limit =
+        (forced || ts.tiles) ? ~0ULL : (unsigned long long)std::min(268435456.0, std::max(65536.0, block_cells / 128.0));
+    int64_t cand_want = std::max<int64_t>(std::max<int64_t>(1 << 20, capacity_hint), (int64_t)(block_cells / 4096.0));
+    if (!forced && !ts.tiles) cand_want = std::min<int64_t>(cand_want, (int64_t)limit);
+    if (hold_all && !forced) {
+        if (ts.tiles) cand_want = (int64_t)std::min(268435456.0, std::max(1048576.0, tiles_to_do * 8.0 * (double)c->opt.tile_dense_thr));
+        else cand_want = (int64_t)limit;
+    }
+    rc = ensure_buf(c, &c->pw_cand, &c->pw_cand_bytes, (size_t)cand_want * sizeof(int2));
+    if (rc) return rc;
+    a.coarse = (const int8_t*)c->pw_coarse;
+    a.fmeta = (const float4*)c->pw_fmeta;
+    a.cand_counter = c->d_counter + 2;
+    a.cand_limit = limit;
+    a.cand_stop = reinterpret_cast<unsigned int*>(c->d_counter + 32);
+    a.recheck_queue = c->d_counter + 128;
+    a.recheck_mode = c->opt.recheck_mode;
+    const int64_t n_regions = mvs::filter_region_count(a, c->opt);
+    if (n_regions > 0) {
+        rc = ensure_buf(c, &c->pw_chdr, &c->pw_chdr_bytes, (size_t)n_regions * 4);
+        if (rc) return rc;
+        rc = ensure_buf(c, &c->pw_cent, &c->pw_cent_bytes, (size_t)n_regions * mvs::kCandRegion * sizeof(int2));
+        if (rc) return rc;
+        a.cand_hdr = (unsigned int*)c->pw_chdr;
+        a.cand_ent = (int2*)c->pw_cent;
+    }
+    const size_t n_tiles = (size_t)ts.n_tr * (size_t)ts.n_tc;
+    if (ts.tiles) {
+        rc = ensure_buf(c, &c->pw_tflag, &c->pw_tflag_bytes, n_tiles * 4);
+        if (rc) return rc;
+        rc = ensure_buf(c, &c->pw_trow, &c->pw_trow_bytes, (size_t)ts.n_tr * 4);
+        if (rc) return rc;
+        a.tile_flag = (unsigned int*)c->pw_tflag;
+        a.tile_flag_ld = ts.n_tc;
+        a.tile_dense_thr = (unsigned)c->opt.tile_dense_thr;
+        a.tile_flag_count = reinterpret_cast<unsigned int*>(c->d_counter + 8);
+        a.tile_flag_limit = forced ? 0xffffffffu : (unsigned)std::min(4.0e9, std::max(64.0, 0.7 * tiles_to_do));
+    }
+    std::vector<int> row_count((size_t)(ts.tiles ? ts.n_tr : 0));
+    unsigned long long back[33];
+    for (int attempt = 0;; ++attempt) {
+        a.cand = (int2*)c->pw_cand;
+        a.cand_capacity = c->pw_cand_bytes / sizeof(int2);
+        // cell count, (debug), candidate count, ..., pruned count [6], flagged tiles [8] ... stop flag [32]
+        HIP_TRY(hipMemsetAsync(c->d_counter + 1, 0, 256, c->stream));
+        rc = set_cell_count(c, start);
+        if (rc) return rc;
+        HIP_TRY(hipMemsetAsync(a.recheck_queue, 0, 512, c->stream));
+        if (n_regions > 0) HIP_TRY(hipMemsetAsync(a.cand_hdr, 0, (size_t)n_regions * 4, c->stream));
+        if (ts.tiles) HIP_TRY(hipMemsetAsync(a.tile_flag, 0, n_tiles * 4, c->stream));
+        if (c->timing) HIP_TRY(hipEventRecord(c->ev[2], c->stream));
+        rc = mvs::launch_filter(c->stream, a, c->opt);
+        if (rc) return fail(rc, "filter launch rejected");
+        rc = check_kernel("k_pairwise_mfma(filter)");
+        if (rc) return rc;
+        if (c->timing) HIP_TRY(hipEventRecord(c->ev[5], c->stream));   // closes the filter's interval, opens the re-check's
+        if (n_regions > 0) {   // the waves' own candidate regions -> the list (counted with the re-check)
+            mvs::launch_cand_gather(c->stream, a, n_regions);
+            rc = check_kernel("k_cand_gather");
+            if (rc) return rc;
+        }
+        if (ts.tiles) {
+            mvs::launch_tile_count(c->stream, a.tile_flag, ts.n_tr, ts.n_tc, (int*)c->pw_trow);
+            rc = check_kernel("k_tile_count");
+            if (rc) return rc;
+            HIP_TRY(hipMemcpyAsync(row_count.data(), c->pw_trow, (size_t)ts.n_tr * 4, hipMemcpyDeviceToHost, c->stream));
+        }
+        // one host synchronisation between the stages: the later launches are sized from these counts
+        HIP_TRY(hipMemcpyAsync(back, c->d_counter, sizeof(back), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        ts.n_cand = back[2];
+        c->last_candidates = ts.n_cand;
+        const bool stopped = (back[32] & 0xffffffffULL) != 0;
+        if (stopped || ts.n_cand > limit) {   // not paying: exact kernel now and for this set's later blocks
+            c->filter_off_id = s->id;
+            c->filter_off_coeff = keep_coeff;
+            c->last_candidates = 0;
+            c->last_flagged_tiles = (long long)(back[8] & 0xffffffffULL);
+            return kNeedExact;
+        }
+        if (ts.n_cand <= a.cand_capacity) break;
+        if (attempt >= 2) return fail(MVS_E_HIP, "internal: the candidate list keeps outgrowing its buffer");
+        rc = ensure_buf(c, &c->pw_cand, &c->pw_cand_bytes, (size_t)ts.n_cand * sizeof(int2));
+        if (rc) return rc;
+    }
+    ts.n_flagged = 0;
+    ts.row_first.assign((size_t)ts.n_tr + 1, 0);
+    for (int t = 0; t < (ts.tiles ? ts.n_tr : 0); ++t) {
+        ts.row_first[(size_t)t + 1] = ts.row_first[(size_t)t] + row_count[(size_t)t];
+    }
+    if (ts.tiles) ts.n_flagged = ts.row_first[(size_t)ts.n_tr];
+    c->last_flagged_tiles = ts.n_flagged;
+    if (ts.n_flagged > 0) {
+        rc = ensure_buf(c, &c->pw_tlist, &c->pw_tlist_bytes, ((size_t)ts.n_flagged + 1) * 4);
+        if (rc) return rc;
+        mvs::launch_tile_list(c->stream, a.tile_flag, ts.n_tr, ts.n_tc, (const int*)c->pw_trow, (int*)c->pw_tlist);
+        rc = check_kernel("k_tile_list");
+        if (rc) return rc;
+        ts.d_list = (const int*)c->pw_tlist + 1;
+        if (ts.n_cand > 0) {   // pairs that other waves of a flagged tile listed: those cells come from the exact kernel
+            rc = ensure_buf(c, &c->pw_cand2, &c->pw_cand2_bytes, (size_t)ts.n_cand * sizeof(int2));
+            if (rc) return rc;
+            mvs::launch_cand_prune(c->stream, a, ts.n_cand, (int2*)c->pw_cand2, c->d_counter + 6);
+            rc = check_kernel("k_cand_prune");
+            if (rc) return rc;
+            a.cand = (int2*)c->pw_cand2;
+            a.cand_capacity = c->pw_cand2_bytes / sizeof(int2);
+            a.cand_counter = c->d_counter + 6;
+        }
+        // the exact kernel's integer pre-test constants
+        rc = ensure_buf(c, &c->pw_thr, &c->pw_thr_bytes, (size_t)s->n_alloc * 4);
+        if (rc) return rc;
+        mvs::launch_cand_thr(c->stream, d_n2, s->n, s->n_alloc, s->d, keep_coeff, (int32_t*)c->pw_thr);
+        rc = check_kernel("k_cand_thr");
+        if (rc) return rc;
+        a.cand_thr = (const int32_t*)c->pw_thr;
+    }
+    ts.a = a;
+    return MVS_OK;
+}
+
+// Stage 2: exact re-check of the listed candidates; kept cells go where ts.a's outputs point (cells / packed / dense)
+int two_stage_recheck(mvs_ctx* c, TwoStage& ts) {
+    int rc = mvs::launch_exact_pairs(c->stream, ts.a, c->opt);
+    if (rc) return fail(rc, "exact re-check launch rejected");
+    rc = check_kernel("k_exact_pairs");
+    if (rc) return rc;
+    if (c->timing) {
+        HIP_TRY(hipEventRecord(c->ev[7], c->stream));
+        HIP_TRY(hipEventRecord(c->ev[3], c->stream));
+        c->ev_valid[1] = c->ev_valid[2] = c->ev_valid[3] = true;
+        c->ev_valid[4] = false;
+    }
+    return MVS_OK;
+}
+
+// Stage 3: the exact kernel on flagged tiles [first, first + count) of the row-major list.  `timed`: this launch closes
+// the comparison's timing interval (ev[6] .. ev[3]).
+int two_stage_tiles(mvs_ctx* c, TwoStage& ts, int first, int count, bool timed) {
+    if (count <= 0 && !(timed && ts.n_flagged > 0)) return MVS_OK;
+    if (c->timing && timed) HIP_TRY(hipEventRecord(c->ev[6], c->stream));
+    if (count > 0) {
+        int rc = mvs::launch_exact_tiles(c->stream, ts.a, ts.d_list + first, count, c->opt);
+        if (rc) return fail(rc, "exact tile launch rejected");
+        rc = check_kernel("k_pairwise_pp(tiles)");
+        if (rc) return rc;
+    }
+    if (c->timing && timed) {
+        HIP_TRY(hipEventRecord(c->ev[3], c->stream));
+        c->ev_valid[4] = true;
+    }
+    return MVS_OK;
+}
+
+// may the two-stage comparison run on this block?  (see the comments at the call sites' old home, pairwise_launch)
+bool two_stage_applies(mvs_ctx* c, const mvs_sketch_set* s, int64_t rb, int64_t re, int64_t cb, int64_t ce, double keep_coeff) {
+    const int filter_mode = c->opt.pairwise_filter;
+    const double block_cells = (double)(re - rb) * (double)(ce - cb);
+    // A few rows against everything (a search with a handful of queries; one of very many shards) on a set whose coarse
+    // plane does not exist yet: building the plane reads all the limb planes once, which is all the exact kernel needs for
+    // such a block -- so the FIRST block of fewer than 1024 rows on a set goes to the exact kernel, and only when a second
+    // one follows on the same set (a caller that keeps the set for many such blocks: pairwise_comp_optimized --shard_idx -1
+    // with small shards, repeated searches) is the plane built.  Up to 16 rows the exact path is a streaming kernel that
+    // runs at HBM speed (k_pairwise_skinny): nothing to filter for.
+    const bool coarse_cached = c->coarse_id == s->id && c->coarse_gen == s->gen && c->coarse_mode == c->opt.coarse_radix;
+    const bool few_rows = re - rb < 1024;
+    const bool few_rows_again = c->few_rows_id == s->id && c->few_rows_gen == s->gen;
+    const bool two_stage = filter_mode != 0 && s->limbs == 2 && s->d_pad <= 32768 &&
+                           (filter_mode == 2 ||   // forced: also on small blocks and on sets it was found not to pay for
+                            (block_cells >= 4194304.0 && re - rb > 16 && (coarse_cached || !few_rows || few_rows_again) &&
+                             !(c->filter_off_id == s->id && c->filter_off_coeff == keep_coeff)));
+    if (!two_stage && few_rows && re - rb > 16 && block_cells >= 4194304.0) {
+        c->few_rows_id = s->id;
+        c->few_rows_gen = s->gen;
+    }
+    return two_stage;
+}
+
+int pairwise_launch(mvs_ctx* c, const mvs_sketch_set* s, const double* d_n2, int keep_mode, int64_t rb, int64_t re,
+                    int64_t cb, int64_t ce, bool symmetric, bool mirror_all, mvs_cell* raw, int64_t capacity,
+                    unsigned long long start, unsigned long long* count, double keep_coeff = 0.05,
+                    const PackedOut* po = nullptr, const DenseOut* dn = nullptr) {
+    // *count: the cell count if this call already had to synchronise for it, ~0 otherwise (read d_counter[0])
+    *count = ~0ULL;
+    mvs::PairwiseArgs a{};
+    fill_args(c, s, d_n2, keep_mode, rb, re, cb, ce, symmetric, mirror_all, keep_coeff, a);
     if (dn) {
         a.dense = dn->matrix;
         a.dense_row0 = dn->row0;
@@ -1157,9 +1428,6 @@ int pairwise_launch(mvs_ctx* c, const mvs_sketch_set* s, const double* d_n2, int
         a.sym_begin = dn->sym_begin;
         a.sym_end = dn->sym_end;
     }
-    a.norms_sq = d_n2;
-    a.keep_mode = keep_mode;
-    a.keep_coeff = keep_coeff;
     a.cells = raw;
     a.capacity = (unsigned long long)capacity;
     if (po) {
@@ -1169,12 +1437,6 @@ int pairwise_launch(mvs_ctx* c, const mvs_sketch_set* s, const double* d_n2, int
         a.pack_row0 = po->row0;
         a.pack_shift = po->shift;
     }
-    a.counter = c->d_counter;
-    a.dots = nullptr;
-    a.mirror_all = mirror_all ? 1 : 0;
-    a.debug_flags = c->opt.pairwise_debug;
-    a.map_mode = c->opt.pairwise_map;
-    a.stamps = nullptr;
 #ifdef MVS_ABLATIONS
     // per-workgroup time stamps of k_pairwise_pp (profiling only): one buffer for the process, dumped after the call
     static unsigned long long* g_stamps = nullptr;
@@ -1196,135 +1458,25 @@ int pairwise_launch(mvs_ctx* c, const mvs_sketch_set* s, const double* d_n2, int
         }
     } stamp_dump{a.stamps, stamp_bytes, c->stream};
 #endif
-    a.symmetric = (symmetric && c->opt.pairwise_symmetric) ? 1 : 0;   // the launcher checks the alignment
-    const int filter_mode = c->opt.pairwise_filter;
-    auto set_count = [&]() -> int {
-        c->h_start = start;   // outlives the asynchronous copy
-        if (start == 0) HIP_TRY(hipMemsetAsync(c->d_counter, 0, 8, c->stream));
-        else HIP_TRY(hipMemcpyAsync(c->d_counter, &c->h_start, 8, hipMemcpyHostToDevice, c->stream));
-        return MVS_OK;
-    };
     int rc = MVS_OK;
-    const double block_cells = (double)(re - rb) * (double)(ce - cb);
-    // A few rows against everything (a search with a handful of queries; one of very many shards) on a set whose coarse
-    // plane does not exist yet: building the plane reads all the limb planes once, which is all the exact kernel needs for
-    // such a block -- so the FIRST block of fewer than 1024 rows on a set goes to the exact kernel, and only when a second
-    // one follows on the same set (a caller that keeps the set for many such blocks: pairwise_comp_optimized --shard_idx -1
-    // with small shards, repeated searches) is the plane built.  Up to 16 rows the exact path is a streaming kernel that
-    // runs at HBM speed (k_pairwise_skinny): nothing to filter for.
-    const bool coarse_cached = c->coarse_id == s->id && c->coarse_gen == s->gen && c->coarse_mode == c->opt.coarse_radix;
-    const bool few_rows = re - rb < 1024;
-    const bool few_rows_again = c->few_rows_id == s->id && c->few_rows_gen == s->gen;
-    bool two_stage = filter_mode != 0 && s->limbs == 2 && s->d_pad <= 32768 &&
-                     (filter_mode == 2 ||   // forced: also on small blocks and on sets it was found not to pay for
-                      (block_cells >= 4194304.0 && re - rb > 16 && (coarse_cached || !few_rows || few_rows_again) &&
-                       !(c->filter_off_id == s->id && c->filter_off_coeff == keep_coeff)));
-    if (!two_stage && few_rows && re - rb > 16 && block_cells >= 4194304.0) {
-        c->few_rows_id = s->id;
-        c->few_rows_gen = s->gen;
-    }
-    if (two_stage) {
-        rc = prepare_coarse(c, s);
-        if (rc) return rc;
-        rc = ensure_buf(c, &c->pw_fmeta, &c->pw_fmeta_bytes, (size_t)s->n_alloc * sizeof(float4));
-        if (rc) return rc;
-        mvs::launch_filter_meta(c->stream, (const mvs::CoarseRow*)c->pw_rows, d_n2, s->n, s->n_alloc, s->d, keep_coeff,
-                                (float4*)c->pw_fmeta);
-        rc = check_kernel("k_filter_meta");
-        if (rc) return rc;
-        // Re-checking a candidate costs about as much as 80-300 cells of the exact kernel (by how well the rows
-        // cache) and the filter pass a third of it: beyond ~1/128 of the block's cells in the list the exact
-        // kernel alone is faster (dense results; a search with a very low bound).  The filter tiles and the
-        // re-check give up as soon as the device-side counter passes that limit; the exact kernel then does the
-        // block (and later blocks of the same set).  The list starts at the caller's capacity or 1/4096 of the
-        // block and is regrown to what a run reports it needs.  Forced mode (pairwise_filter = 2, tests) has
-        // no limit.
-        const bool forced = filter_mode == 2;
-        const unsigned long long limit =
-            forced ? ~0ULL : (unsigned long long)std::min(268435456.0, std::max(65536.0, block_cells / 128.0));
-        int64_t cand_want = std::max<int64_t>(std::max<int64_t>(1 << 20, capacity), (int64_t)(block_cells / 4096.0));
-        if (!forced) cand_want = std::min<int64_t>(cand_want, (int64_t)limit);
-        if (po && !forced) cand_want = (int64_t)limit;   // streamed output: the list holds whatever the filter may pass on,
-                                                         // so the filter never runs twice (beyond the limit it gives up)
-        rc = ensure_buf(c, &c->pw_cand, &c->pw_cand_bytes, (size_t)cand_want * sizeof(int2));
-        if (rc) return rc;
-        a.coarse = (const int8_t*)c->pw_coarse;
-        a.fmeta = (const float4*)c->pw_fmeta;
-        a.cand_counter = c->d_counter + 2;
-        a.cand_limit = limit;
-        a.cand_stop = reinterpret_cast<unsigned int*>(c->d_counter + 32);
-        a.recheck_queue = c->d_counter + 128;
-        a.recheck_mode = c->opt.recheck_mode;
-        const int64_t n_regions = mvs::filter_region_count(a, c->opt);
-        if (n_regions > 0) {
-            rc = ensure_buf(c, &c->pw_chdr, &c->pw_chdr_bytes, (size_t)n_regions * 4);
-            if (rc) return rc;
-            rc = ensure_buf(c, &c->pw_cent, &c->pw_cent_bytes, (size_t)n_regions * mvs::kCandRegion * sizeof(int2));
-            if (rc) return rc;
-            a.cand_hdr = (unsigned int*)c->pw_chdr;
-            a.cand_ent = (int2*)c->pw_cent;
-        }
-        for (int attempt = 0; attempt < 3; ++attempt) {
-            a.cand = (int2*)c->pw_cand;
-            a.cand_capacity = c->pw_cand_bytes / sizeof(int2);
-            if (start == 0) {
-                HIP_TRY(hipMemsetAsync(c->d_counter, 0, 264, c->stream));   // cell count, (debug slot), candidate count ... stop flag
-            } else {
-                HIP_TRY(hipMemsetAsync(c->d_counter + 2, 0, 248, c->stream));
-                rc = set_count();
-                if (rc) return rc;
-            }
-            HIP_TRY(hipMemsetAsync(a.recheck_queue, 0, 512, c->stream));
-            if (n_regions > 0) HIP_TRY(hipMemsetAsync(a.cand_hdr, 0, (size_t)n_regions * 4, c->stream));
-            if (c->timing) HIP_TRY(hipEventRecord(c->ev[2], c->stream));
-            rc = mvs::launch_filter(c->stream, a, c->opt);
-            if (rc) return fail(rc, "filter launch rejected");
-            rc = check_kernel("k_pairwise_mfma(filter)");
-            if (rc) return rc;
-            if (c->timing) {   // ev[5] closes the filter's interval and opens the re-check's
-                HIP_TRY(hipEventRecord(c->ev[5], c->stream));
-            }
-            if (n_regions > 0) {   // the waves' own candidate regions -> the list (counted with the re-check)
-                mvs::launch_cand_gather(c->stream, a, n_regions);
-                rc = check_kernel("k_cand_gather");
-                if (rc) return rc;
-            }
-            unsigned long long back[3] = {0, 0, 0};   // cell count, (debug slot), candidate count
+    if (!dn && two_stage_applies(c, s, rb, re, cb, ce, keep_coeff)) {
+        TwoStage ts;
+        rc = two_stage_filter(c, s, d_n2, keep_coeff, capacity, po != nullptr, start, a, ts);
+        if (rc == MVS_OK) {
             if (po) {
-                // the output is sized between the two stages: every kept cell is a candidate or its mirror image
-                HIP_TRY(hipMemcpyAsync(back, c->d_counter, 24, hipMemcpyDeviceToHost, c->stream));
-                HIP_TRY(hipStreamSynchronize(c->stream));
-                if (back[2] <= limit && back[2] <= a.cand_capacity) {
-                    rc = ensure_buf(c, po->buf, po->bytes, (size_t)(start + 2 * back[2] + 64) * 8);
-                    if (rc) return rc;
-                    a.packed = (unsigned long long*)*po->buf;
-                    a.capacity = *po->bytes / 8;
-                }
+                // the output is sized between the stages: a kept cell is a candidate or the mirror image of one, or a cell
+                // of a flagged tile or of its mirror image
+                rc = ensure_buf(c, po->buf, po->bytes,
+                                (size_t)(start + 2 * ts.n_cand + (unsigned long long)ts.n_flagged * 131072ULL + 64) * 8);
+                if (rc) return rc;
+                ts.a.packed = (unsigned long long*)*po->buf;
+                ts.a.capacity = *po->bytes / 8;
             }
-            rc = mvs::launch_exact_pairs(c->stream, a, c->opt);
-            if (rc) return fail(rc, "exact re-check launch rejected");
-            rc = check_kernel("k_exact_pairs");
+            rc = two_stage_recheck(c, ts);
             if (rc) return rc;
-            if (c->timing) {
-                HIP_TRY(hipEventRecord(c->ev[3], c->stream));
-                c->ev_valid[1] = c->ev_valid[2] = c->ev_valid[3] = true;
-            }
-            HIP_TRY(hipMemcpyAsync(back, c->d_counter, 24, hipMemcpyDeviceToHost, c->stream));
-            HIP_TRY(hipStreamSynchronize(c->stream));
-            const unsigned long long n_cand = back[2];
-            c->last_candidates = n_cand;
-            if (n_cand > limit) {   // not paying: exact kernel now and for this set's later blocks
-                c->filter_off_id = s->id;
-                c->filter_off_coeff = keep_coeff;
-                break;
-            }
-            if (n_cand <= a.cand_capacity) {
-                *count = back[0];
-                return MVS_OK;
-            }
-            rc = ensure_buf(c, &c->pw_cand, &c->pw_cand_bytes, (size_t)n_cand * sizeof(int2));
-            if (rc) return rc;
+            return two_stage_tiles(c, ts, 0, ts.n_flagged, true);
         }
+        if (rc != kNeedExact) return rc;
     }
     c->last_candidates = 0;
     if (po && po->two_stage_only) return kNeedExact;
@@ -1334,7 +1486,7 @@ int pairwise_launch(mvs_ctx* c, const mvs_sketch_set* s, const double* d_n2, int
     rc = check_kernel("k_cand_thr");
     if (rc) return rc;
     a.cand_thr = (const int32_t*)c->pw_thr;
-    rc = set_count();
+    rc = set_cell_count(c, start);
     if (rc) return rc;
     if (c->timing) HIP_TRY(hipEventRecord(c->ev[2], c->stream));
     rc = mvs::launch_pairwise(c->stream, a, 0, 0, c->opt);
@@ -1344,7 +1496,7 @@ int pairwise_launch(mvs_ctx* c, const mvs_sketch_set* s, const double* d_n2, int
     if (c->timing) {
         HIP_TRY(hipEventRecord(c->ev[3], c->stream));
         c->ev_valid[1] = true;
-        c->ev_valid[2] = c->ev_valid[3] = false;   // no filter / re-check in this comparison
+        c->ev_valid[2] = c->ev_valid[3] = c->ev_valid[4] = false;   // no filter / re-check in this comparison
     }
     return MVS_OK;
 }
@@ -1970,9 +2122,12 @@ int pairwise_stream_impl(mvs_ctx* c, const mvs_sketch_set* s, const double* norm
     if (rc) return rc;
     c->st_kernel_ms = 0.0;
     c->st_bytes = c->st_blocks = c->st_pieces = c->st_two_stage = 0;
+    bool tiles_phase = false;   // the launches being timed are runs of flagged tiles (ev[6] .. ev[3]), not whole comparisons
     auto add_kernel_ms = [&]() {
         float ms = 0.0f;
-        if (c->timing && c->ev_valid[1] && hipEventElapsedTime(&ms, c->ev[2], c->ev[3]) == hipSuccess) c->st_kernel_ms += ms;
+        if (c->timing && c->ev_valid[1] && hipEventSynchronize(c->ev[3]) == hipSuccess &&
+            hipEventElapsedTime(&ms, tiles_phase ? c->ev[6] : c->ev[2], c->ev[3]) == hipSuccess)
+            c->st_kernel_ms += ms;
     };
     StreamOut out;
     out.c = c;
@@ -2000,31 +2155,65 @@ int pairwise_stream_impl(mvs_ctx* c, const mvs_sketch_set* s, const double* norm
         return MVS_OK;
     };
     const int64_t rows_all = row_end - row_begin;
-    // Plan A: the whole row range as ONE symmetric block through the two-stage comparison (its kept cells are few: they
-    // stay on the device until the block is sorted).  Needs the row field to fit the packed word.
-    bool need_exact = true;
-    if (shift + bits_for(std::max<int64_t>(rows_all - 1, 1)) <= 64) {
-        PackedOut po{&c->st_raw, &c->st_raw_bytes, row_begin, shift, true};
-        rc = ensure_buf(c, &c->st_raw, &c->st_raw_bytes, 1u << 20);
-        if (rc) return finish(rc);
-        unsigned long long got = 0;
-        rc = pairwise_launch(c, s, d_n2, keep_mode, row_begin, row_end, 0, s->n, true, false, nullptr, 0, 0, &got, 0.05, &po);
+    // Plan A: the whole row range as ONE symmetric block through the two-stage comparison.  The filter pass runs once;
+    // what it found decides how the kept cells leave the device:
+    //  * few cells (candidates + cells of flagged tiles): ONE packed list, sorted on the device (needs the row field to
+    //    fit the packed word);
+    //  * whole regions of the result dense (many flagged tiles): the dense byte matrix of plan B, fed by the SAME filter
+    //    pass -- the re-check scatters its kept cells' bytes, the exact kernel writes the flagged tiles (and their mirror
+    //    images) row block by row block, and the blocks are counted / filled / encoded beside the next block's tiles;
+    //  * the filter gave up (nearly everything dense) or does not apply: plan B on the exact kernel alone.
+    bool tile_dense = false;
+    TwoStage ts;
+    const bool fits_word = shift + bits_for(std::max<int64_t>(rows_all - 1, 1)) <= 64;
+    if (two_stage_applies(c, s, row_begin, row_end, 0, s->n, 0.05)) {
+        mvs::PairwiseArgs fa{};
+        fill_args(c, s, d_n2, keep_mode, row_begin, row_end, 0, s->n, true, false, 0.05, fa);
+        rc = two_stage_filter(c, s, d_n2, 0.05, 0, true, 0, fa, ts);
+        if (rc != MVS_OK && rc != kNeedExact) return finish(rc);
         if (rc == MVS_OK) {
-            need_exact = false;
-            if ((size_t)got * 8 > c->st_raw_bytes) return finish(fail(MVS_E_HIP, "internal: kept cells beyond the sized output"));
-            total = (int64_t)got;
-            add_kernel_ms();
-            c->st_blocks = 1;
-            c->st_two_stage = 1;
-            BlockCsr blk;
-            rc = csr_from_packed(c, row_begin, row_end, (int64_t)got, shift, col_bits, 0, blk);
-            if (rc == MVS_OK) rc = prepare(blk);
-            if (rc == MVS_OK) rc = deliver(blk);
-            return finish(rc);
+            const unsigned long long bound = 2 * ts.n_cand + (unsigned long long)ts.n_flagged * 131072ULL;
+            mvs::PairwiseArgs probe0{};
+            probe0.limbs = s->limbs;
+            probe0.d_pad = s->d_pad;
+            const int64_t ld0 = (s->n + 127) / 128 * 128;
+            const bool dense_feasible = mvs::exact_kernel_writes_dense(probe0, c->opt) && c->opt.stream_dense != 0 &&
+                                        row_begin % 256 == 0 && (size_t)rows_all * (size_t)ld0 <= dense_budget;
+            size_t free_b = 0, total_b = 0;
+            HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+            const bool list_fits = fits_word && (double)bound * 22.0 <= (double)free_b * 0.5;
+            // 2^26 cells: below that the list (8 B per cell written, a radix sort over the key bits) is cheaper than
+            // clearing, counting and filling a matrix of rows x n bytes
+            const bool as_list = list_fits && (bound <= (unsigned long long)c->opt.stream_list_cells || !dense_feasible || ts.n_flagged == 0);
+            if (as_list) {
+                rc = ensure_buf(c, &c->st_raw, &c->st_raw_bytes, (size_t)(bound + 64) * 8);
+                if (rc) return finish(rc);
+                ts.a.packed = (unsigned long long*)c->st_raw;
+                ts.a.capacity = c->st_raw_bytes / 8;
+                ts.a.pack_row0 = row_begin;
+                ts.a.pack_shift = shift;
+                rc = two_stage_recheck(c, ts);
+                if (rc == MVS_OK) rc = two_stage_tiles(c, ts, 0, ts.n_flagged, true);
+                if (rc) return finish(rc);
+                unsigned long long got = 0;
+                hipError_t e = hipMemcpyAsync(&got, c->d_counter, 8, hipMemcpyDeviceToHost, c->stream);
+                if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+                if (e != hipSuccess) return finish(fail(MVS_E_HIP, "reading the cell count: %s", hipGetErrorString(e)));
+                if ((size_t)got * 8 > c->st_raw_bytes) return finish(fail(MVS_E_HIP, "internal: kept cells beyond the sized output"));
+                total = (int64_t)got;
+                add_kernel_ms();
+                c->st_blocks = 1;
+                c->st_two_stage = 1;
+                BlockCsr blk;
+                rc = csr_from_packed(c, row_begin, row_end, (int64_t)got, shift, col_bits, 0, blk);
+                if (rc == MVS_OK) rc = prepare(blk);
+                if (rc == MVS_OK) rc = deliver(blk);
+                return finish(rc);
+            }
+            tile_dense = dense_feasible;
+            // neither a list nor the matrix fits: plan B, the exact kernel in row blocks (the filter pass was in vain)
         }
-        if (rc != kNeedExact) return finish(rc);
     }
-    (void)need_exact;
     // Plan B: the exact kernel in row blocks, software-pipelined -- block k+1 is launched before block k's pieces are fed
     // to the link, so comparison and download overlap.  Two ways for a block's cells to leave the kernel:
     //  * dense (two limbs on the ping-pong kernel): one byte per cell in a row-major matrix, rows -> CSR by a count /
@@ -2042,7 +2231,7 @@ int pairwise_stream_impl(mvs_ctx* c, const mvs_sketch_set* s, const double* norm
     int64_t block_rows = 0;
     const bool aligned = row_begin % 128 == 0;                      // the symmetric schedule needs the tile grids to line up
     if (dense) {
-        whole = aligned && (size_t)rows_all * (size_t)ld <= dense_budget;
+        whole = aligned && (size_t)rows_all * (size_t)ld <= dense_budget;   // (tile_dense implies both)
         if (whole) {
             block_rows = std::max<int64_t>(2048, (rows_all / 16 + 255) / 256 * 256);
         } else {
@@ -2057,21 +2246,49 @@ int pairwise_stream_impl(mvs_ctx* c, const mvs_sketch_set* s, const double* norm
         while (shift + bits_for(std::max<int64_t>(block_rows - 1, 1)) > 64 && block_rows > 256) block_rows /= 2;
     }
     std::vector<std::pair<int64_t, int64_t>> blocks;
+    // blocks of one shared matrix start small (1024, 2048, 4096 rows, ...): the link has nothing to do until the first
+    // block has been compared, counted, filled and encoded
+    int64_t ramp = (dense && whole && c->opt.stream_block_rows == 0 && block_rows > 1024) ? 1024 : block_rows;
     for (int64_t rb = row_begin; rb < row_end;) {
-        const int64_t re = std::min(row_end, (rb / 256) * 256 + block_rows);
+        const int64_t re = std::min(row_end, (rb / 256) * 256 + std::min(ramp, block_rows));
         blocks.emplace_back(rb, re);
         rb = re;
+        ramp = std::min(block_rows, ramp * 2);
     }
     if (dense) {
         const size_t bytes = (size_t)(whole ? rows_all : std::min(block_rows + 256, rows_all)) * (size_t)ld;
+        const void* before = c->st_dense;
         rc = ensure_buf(c, &c->st_dense, &c->st_dense_bytes, bytes);
         if (rc) return finish(rc);
+        if (c->st_dense != before) c->st_dense_zero = 0;
         hipError_t e = hipMemsetAsync(c->d_counter + 4, 0, 8, c->stream);      // the "q beyond a byte" flag
         if (e != hipSuccess) return finish(fail(MVS_E_HIP, "hipMemsetAsync: %s", hipGetErrorString(e)));
     }
+    if (tile_dense) {
+        // fed by plan A's filter pass: cells outside the flagged tiles are zero unless the re-check keeps them.  10 GB at
+        // 100k rows: cleared here only when the last user did not leave it clean (see the end of this function)
+        if (c->st_dense_zero < (size_t)rows_all * (size_t)ld) {
+            hipError_t e = hipMemsetAsync(c->st_dense, 0, (size_t)rows_all * (size_t)ld, c->stream);
+            if (e != hipSuccess) return finish(fail(MVS_E_HIP, "hipMemsetAsync: %s", hipGetErrorString(e)));
+        }
+        ts.a.dense = (uint8_t*)c->st_dense;
+        ts.a.dense_row0 = row_begin;
+        ts.a.dense_ld = ld;
+        ts.a.dense_flag = reinterpret_cast<unsigned int*>(c->d_counter + 4);
+        rc = two_stage_recheck(c, ts);
+        if (rc) return finish(rc);
+        add_kernel_ms();                                             // filter + re-check
+        tiles_phase = true;
+        c->st_two_stage = 2;
+    }
+    if (dense) c->st_dense_zero = 0;                                 // about to be written
     const int saved_filter = c->opt.pairwise_filter;
     auto launch = [&](size_t k, bool as_dense) -> int {
         const int64_t rb = blocks[k].first, re = blocks[k].second;
+        if (tile_dense && as_dense) {                                // this block's flagged tiles (tile rows of 256)
+            const int t0 = (int)((rb - row_begin) / 256), t1 = (int)std::min<int64_t>(ts.n_tr, (re - row_begin + 255) / 256);
+            return two_stage_tiles(c, ts, ts.row_first[(size_t)t0], ts.row_first[(size_t)t1] - ts.row_first[(size_t)t0], true);
+        }
         unsigned long long got = 0;
         c->opt.pairwise_filter = 0;                                 // plan A has decided: the exact kernel does these blocks
         int r;
@@ -2142,6 +2359,7 @@ int pairwise_stream_impl(mvs_ctx* c, const mvs_sketch_set* s, const double* norm
                 // rest go through the packed list, each block inside its own square -- the one case where a block is
                 // compared a second time
                 dense = false;
+                tile_dense = tiles_phase = false;
                 int64_t br = std::max<int64_t>(256, budget_cells / std::max<int64_t>(s->n, 1) / 256 * 256);
                 while (shift + bits_for(std::max<int64_t>(br - 1, 1)) > 64 && br > 256) br /= 2;
                 std::vector<std::pair<int64_t, int64_t>> rest(blocks.begin(), blocks.begin() + (long)k);
@@ -2177,6 +2395,17 @@ int pairwise_stream_impl(mvs_ctx* c, const mvs_sketch_set* s, const double* norm
         if (rc) return finish(rc);
         if (out.failed()) break;
         (void)next_launched;
+    }
+    if (tile_dense && !out.failed()) {
+        // leave the matrix clean for the next call: behind the last block's passes, while the link still drains
+        const size_t bytes = (size_t)rows_all * (size_t)ld;
+        hipError_t e = hipSuccess;
+        if (side) {
+            e = hipEventRecord(c->cmp_done, ps);
+            if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, c->cmp_done, 0);
+        }
+        if (e == hipSuccess) e = hipMemsetAsync(c->st_dense, 0, bytes, c->stream);
+        if (e == hipSuccess) c->st_dense_zero = bytes;
     }
     return finish(MVS_OK);
 }

@@ -59,6 +59,9 @@ struct Options {
     int tile_dense_thr = 64;        // ping-pong filter: a wave with more candidates than this flags its 256 x 256 tile for the
                                     // exact kernel instead of listing them (0: list everything, give up on the block when the
                                     // list passes 1/128 of its cells -- the behaviour up to round 3)
+    int stream_list_cells = 1 << 26;   // mvs_pairwise_stream, two-stage comparison: up to this many cells (candidates + cells
+                                    // of flagged tiles, mirror images included) leave as ONE packed list; beyond it the dense
+                                    // byte matrix takes the flagged tiles (tests lower it)
     int comm_timeout_s = 600;       // file transport: how long a rank waits for a peer's block before it gives up
     double pairwise_block_cells = 1099511627776.0;   // row-chunk bound of mvs_pairwise_rows (2^40 cells)
 };

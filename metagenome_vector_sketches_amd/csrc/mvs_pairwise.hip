@@ -128,6 +128,15 @@ __device__ __forceinline__ void store_cell(const PairwiseArgs& a, unsigned long 
 // dot, keep test and quantised Jaccard are symmetric in (row, col) bit for bit (fp add commutes).
 __device__ __forceinline__ void emit_cell(const PairwiseArgs& a, bool keep, bool mirror, int32_t row, int32_t col,
                                           int32_t P, int lane) {
+    if (a.dense) {   // dense byte matrix (the tile-granular comparison's re-check beside flagged tiles): scatter q, no list
+        if (keep) {
+            const int32_t q = quantize_cell(P, a.d, a.norms_sq[row], a.norms_sq[col]);
+            if (q <= 0 || q > 255) *a.dense_flag = 1u;
+            a.dense[((int64_t)row - a.dense_row0) * a.dense_ld + col] = (uint8_t)q;
+            if (mirror) a.dense[((int64_t)col - a.dense_row0) * a.dense_ld + row] = (uint8_t)q;
+        }
+        return;
+    }
     const unsigned long long mask = __ballot(keep);
     if (mask == 0ULL) return;
     const unsigned long long mmask = __ballot(keep && mirror);
@@ -1004,6 +1013,20 @@ __device__ __forceinline__ void epilogue_filter16(const PairwiseArgs& a, v4i (&a
     // (indexed by workgroup and wave: plain stores, nothing to wait for) and k_cand_gather moves the regions' contents
     // into the list afterwards; only a wave with more than that (tiles on the diagonal, dense data) takes the atomic.
     const unsigned total = (unsigned)__shfl((int)incl, 63, 64);
+    // Tile-granular comparison: where this wave's 128 x 64 cells hold more candidates than re-checking them one by one is
+    // worth (a dense region of the result), the whole 256 x 256 tile goes to the exact kernel instead -- the wave flags
+    // the tile and lists nothing; what other waves of the tile list is pruned before the re-check.  The first wave to
+    // flag a tile counts it; when nearly every tile is flagged the filter is not paying and the launch stops.
+    if (a.tile_flag != nullptr && total > a.tile_dense_thr) {
+        if (lane == 0) {
+            const int64_t t = ((i0 - a.row_begin) >> 8) * (int64_t)a.tile_flag_ld + ((j0 - a.col_begin) >> 8);
+            if (atomicExch(a.tile_flag + t, 1u) == 0u) {
+                const unsigned before = atomicAdd(a.tile_flag_count, 1u);
+                if (before + 1u > a.tile_flag_limit) *a.cand_stop = 1u;
+            }
+        }
+        return;
+    }
     const bool to_region = a.cand_hdr != nullptr && total <= (unsigned)kCandRegion;
     unsigned long long slot;
     int2* list;
@@ -1074,6 +1097,81 @@ __global__ __launch_bounds__(256) void k_cand_gather(const PairwiseArgs a, unsig
         if (slot < a.cand_capacity) a.cand[slot] = a.cand_ent[reg * kCandRegion + e];
 }
 
+// ---- tile-granular comparison: flags -> list, candidate pruning ----
+// flagged tiles per tile row (one workgroup per row of the 256 x 256 tile grid)
+__global__ __launch_bounds__(256) void k_tile_count(const unsigned int* __restrict__ flags, int n_tc, int* __restrict__ row_count) {
+    __shared__ int part[4];
+    const unsigned int* row = flags + (size_t)blockIdx.x * n_tc;
+    int mine = 0;
+    for (int t = threadIdx.x; t < n_tc; t += 256) mine += row[t] != 0u;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) row_count[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+}
+
+// row-major list of the flagged tiles' ids (tr * n_tc + tc); workgroup tr sums the counts of the rows before it (the grid
+// has a few thousand rows at most) and writes its own row's ids in column order.  list[-1 .. ] : the caller passes
+// d_list + 1 and gets the total in d_list[0]
+__global__ __launch_bounds__(256) void k_tile_list(const unsigned int* __restrict__ flags, int n_tr, int n_tc,
+                                                   const int* __restrict__ row_count, int* __restrict__ list) {
+    __shared__ int part[4];
+    __shared__ int run;
+    const int tr = blockIdx.x;
+    int before = 0;
+    for (int t = threadIdx.x; t < tr; t += 256) before += row_count[t];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = before;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        run = part[0] + part[1] + part[2] + part[3];
+        if (tr == n_tr - 1) list[-1] = run + row_count[tr];
+    }
+    __syncthreads();
+    const unsigned int* row = flags + (size_t)tr * n_tc;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int t0 = 0; t0 < n_tc; t0 += 256) {
+        const int t = t0 + threadIdx.x;
+        const bool f = t < n_tc && row[t] != 0u;
+        const unsigned long long m = __ballot(f);
+        if (lane == 0) part[w] = __popcll(m);
+        __syncthreads();
+        int pos = run + __popcll(m & ((1ULL << lane) - 1ULL));
+        for (int i = 0; i < w; ++i) pos += part[i];
+        if (f) list[pos] = tr * n_tc + t;
+        __syncthreads();
+        if (threadIdx.x == 0) run += part[0] + part[1] + part[2] + part[3];
+        __syncthreads();
+    }
+}
+
+// the candidate list without the pairs whose tile is flagged (those cells come from the exact kernel): order is kept
+// within a wave's 64 entries, one atomic per wave
+__global__ __launch_bounds__(256) void k_cand_prune(const PairwiseArgs a, unsigned long long n_cand, int2* __restrict__ out,
+                                                    unsigned long long* __restrict__ out_count) {
+    const int lane = threadIdx.x & 63;
+    const unsigned long long waves = (unsigned long long)gridDim.x * 4;
+    for (unsigned long long base = ((unsigned long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64; base < n_cand; base += waves * 64) {
+        const unsigned long long i = base + lane;
+        bool keep = false;
+        int2 pr = make_int2(0, 0);
+        if (i < n_cand) {
+            pr = a.cand[i];
+            const int64_t t = (((int64_t)pr.x - a.row_begin) >> 8) * (int64_t)a.tile_flag_ld +
+                              (((int64_t)(pr.y & 0x7fffffff) - a.col_begin) >> 8);
+            keep = a.tile_flag[t] == 0u;
+        }
+        const unsigned long long m = __ballot(keep);
+        if (m == 0ULL) continue;
+        unsigned long long slot = 0;
+        if (lane == 0) slot = atomicAdd(out_count, (unsigned long long)__popcll(m));
+        slot = (unsigned long long)__shfl((long long)slot, 0, 64) + (unsigned long long)__popcll(m & ((1ULL << lane) - 1ULL));
+        if (keep) out[slot] = pr;
+    }
+}
+
 // ORDER: 0 fragment reads then copies, 1 copies then fragment reads, 2 by wave parity (half the group's waves each
 // way, so that the LDS reads of some overlap the copy issue of the others).  ABL (ablation builds): 1 no MFMA,
 // 2 no copies after the prologue, 3 no fragment reads after the first slice.
@@ -1107,7 +1205,21 @@ __global__ __launch_bounds__(512, 2) void k_pairwise_pp(const PairwiseArgs a, in
         }
     }
 #endif
-    const TileCoord tc = map_tile(blockIdx.x, blockIdx.y, n_tr, n_tc, a.map_mode);
+    TileCoord tc;
+    if (MODE == 0 && a.tile_list != nullptr) {
+        // the flagged tiles of the tile-granular comparison: entry = a 256 x 256 filter tile = four tiles of this kernel,
+        // consecutive indices; XCD label x (blockIdx.x % 8) takes the x-th contiguous eighth of the row-major list, so the
+        // tiles that share row and column panels meet in one L2
+        const unsigned n4 = 4u * (unsigned)a.tile_list_n, per = (n4 + 7u) / 8u;
+        const unsigned idx = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+        if ((blockIdx.x >> 3) >= per || idx >= n4) return;
+        const int entry = a.tile_list[idx >> 2];
+        tc.tr = (entry / a.tile_flag_ld) * 2 + (int)((idx >> 1) & 1u);
+        tc.tc = (entry % a.tile_flag_ld) * 2 + (int)(idx & 1u);
+        tc.valid = tc.tr < n_tr && tc.tc < n_tc;
+    } else {
+        tc = map_tile(blockIdx.x, blockIdx.y, n_tr, n_tc, a.map_mode);
+    }
     if (!tc.valid) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -2256,6 +2368,60 @@ int launch_cand_gather(hipStream_t stream, const PairwiseArgs& a, int64_t n_regi
     if (n_regions <= 0) return 0;
     hipLaunchKernelGGL(k_cand_gather, dim3((unsigned)((n_regions + 255) / 256)), dim3(256), 0, stream, a,
                        (unsigned long long)n_regions);
+    return 0;
+}
+
+bool filter_flags_tiles(const PairwiseArgs& a, const Options& opt) {
+    if (opt.tile_dense_thr <= 0 || a.limbs != 2 || a.d_pad > 32768) return false;
+    const int v = filter_variant_for(a, opt);
+    const bool pp = (v >= 7 && v <= 10) || (v >= 40 && v <= 42);
+    // the flagged tiles go to the ping-pong exact kernel (any other choice of exact kernel by number: list everything)
+    return pp && pairwise_variant(opt) == 8;
+}
+
+void filter_tile_grid(const PairwiseArgs& a, int* n_tr, int* n_tc) {
+    *n_tr = (int)((a.row_end - a.row_begin + 255) / 256);
+    *n_tc = (int)((a.col_end - a.col_begin + 255) / 256);
+}
+
+int launch_tile_count(hipStream_t stream, const unsigned int* d_flags, int n_tr, int n_tc, int* d_row_count) {
+    if (n_tr <= 0) return 0;
+    hipLaunchKernelGGL(k_tile_count, dim3((unsigned)n_tr), dim3(256), 0, stream, d_flags, n_tc, d_row_count);
+    return 0;
+}
+
+int launch_tile_list(hipStream_t stream, const unsigned int* d_flags, int n_tr, int n_tc, const int* d_row_count, int* d_list) {
+    if (n_tr <= 0) return 0;
+    hipLaunchKernelGGL(k_tile_list, dim3((unsigned)n_tr), dim3(256), 0, stream, d_flags, n_tr, n_tc, d_row_count, d_list + 1);
+    return 0;
+}
+
+int launch_cand_prune(hipStream_t stream, const PairwiseArgs& a, unsigned long long n_cand, int2* d_out,
+                      unsigned long long* d_out_count) {
+    if (n_cand == 0) return 0;
+    const unsigned long long blocks = std::min<unsigned long long>(4096ULL, (n_cand + 255) / 256);
+    hipLaunchKernelGGL(k_cand_prune, dim3((unsigned)blocks), dim3(256), 0, stream, a, n_cand, d_out, d_out_count);
+    return 0;
+}
+
+// the exact ping-pong kernel on n_list flagged filter tiles (d_list: their ids in the grid of `a`, which is the filter
+// launch's: same row / column origin and ranges, same symmetric square)
+int launch_exact_tiles(hipStream_t stream, const PairwiseArgs& a, const int* d_list, int n_list, const Options& opt) {
+    if (n_list <= 0) return 0;
+    if (a.limbs != 2 || a.d_pad > 32768 || pairwise_variant(opt) != 8) return MVS_E_INVALID;
+    using G = PpGeom<0>;
+    const int64_t rows = a.row_end - a.row_begin, cols = a.col_end - a.col_begin;
+    const int n_tr = (int)((rows + G::TM - 1) / G::TM), n_tc = (int)((cols + G::TN - 1) / G::TN);
+    PairwiseArgs b = a;
+    if (b.symmetric && ((a.row_begin - a.col_begin) % 256 != 0 || a.mirror_all)) b.symmetric = 0;   // as launch_pp<2> decided
+    b.tile_list = d_list;
+    b.tile_list_n = n_list;
+    const size_t lds = (size_t)4 * G::kStage;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pairwise_pp<0, 4>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return MVS_E_HIP;
+    const unsigned per = (4u * (unsigned)n_list + 7u) / 8u;
+    hipLaunchKernelGGL((k_pairwise_pp<0, 4>), dim3(per * 8u), dim3(512), lds, stream, b, n_tr, n_tc);
     return 0;
 }
 

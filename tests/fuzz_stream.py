@@ -4,7 +4,8 @@
 
 One case = one random sketch set (size, dimension, value range -> limb code, cluster size -> density, norms that belong to
 the vectors or not) and a random way to ask for it (row range, keep test, filter on / off / forced, device budget, row
-blocks, dense byte matrix or packed list, LDS stage of the encoder).  For each case
+blocks, dense byte matrix or packed list, LDS stage of the encoder, tile-granular two-stage comparison with its density
+threshold and its list / matrix switch).  For each case
 
     mvs_pairwise_rows (cell list)  ==  oracle (int32 keep test, whole rows x all columns)
     mvs_pairwise_stream (CSR pieces)  ==  the cell list
@@ -27,7 +28,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 from metagenome_vector_sketches_amd import _capi, synth  # noqa: E402
 from oracle import pyoracle as orc  # noqa: E402
 
-OPTIONS = ("pairwise_filter", "stream_dense", "stream_block_rows", "encode_stage_words", "pairwise_symmetric")
+OPTIONS = ("pairwise_filter", "stream_dense", "stream_block_rows", "encode_stage_words", "pairwise_symmetric", "filter_variant",
+           "tile_dense_thr", "stream_list_cells")
 
 
 def _n2(sk):
@@ -86,7 +88,12 @@ def run_case(ctx, rng, max_n, decode_limit=150_000, log=None):
             "stream_dense": int(rng.choice([0, 1, 1, 1, 2])),        # 0 packed list, 1 dense + side stream, 2 dense, one stream
             "stream_block_rows": int(rng.choice([0, 0, 64, 128, 200, 512])),
             "encode_stage_words": int(rng.choice([64, 64, 64, 8, 1])),
-            "pairwise_symmetric": int(rng.random() < 0.85)}
+            "pairwise_symmetric": int(rng.random() < 0.85),
+            # the tile-granular comparison: the ping-pong filter (large blocks' default) forced on small inputs, a random
+            # density threshold per wave, and a small list bound so that the dense byte matrix takes the flagged tiles
+            "filter_variant": int(rng.choice([-1, -1, 8, 8])),
+            "tile_dense_thr": int(rng.choice([64, 64, 1, 8, 500, 0])),
+            "stream_list_cells": int(rng.choice([1 << 26, 1 << 26, 0, 5000]))}
     info.update(keep=keep, rows=(rb, re), budget=budget, **opts)
     old = {k: ctx.get_option(k) for k in OPTIONS}
     ss = None

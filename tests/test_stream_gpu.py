@@ -111,6 +111,98 @@ def test_stream_dense_result_in_row_blocks(ctx, filt, mode):
     ss.close()
 
 
+def _mixed_density(n_dense, n_sparse, d, seed):
+    """clusters of n_dense / 2 samples (every pair inside one is kept) followed by clusters of 8"""
+    a = synth.make_sketches_numpy(n_dense, d, 3000, seed=seed, cluster=max(2, n_dense // 2), shared=0.6)
+    b = synth.make_sketches_numpy(n_sparse, d, 3000, seed=seed + 1, cluster=8)
+    return np.concatenate([a, b])
+
+
+@pytest.mark.parametrize("mode", ["list", "matrix", "matrix-one-stream", "matrix-one-block"])
+@pytest.mark.parametrize("keep", [_capi.KEEP_INT32, _capi.KEEP_INT16])
+def test_stream_tile_granular_mixed_density(ctx, mode, keep):
+    """Dense regions next to sparse ones (the reference's cost is flat in the density, src/pairwise_comp_optimized.cpp:
+    135-147; ours must not fall off a cliff between the two): the ping-pong filter flags the 256 x 256 tiles whose waves
+    hold more than tile_dense_thr candidates, the exact kernel computes those tiles only, everything else is re-checked
+    pair by pair.  The kept cells leave as ONE packed list (few) or through the dense byte matrix that the same filter
+    pass feeds (many; stream_list_cells lowered to force it): flagged tiles row block by row block, the re-check's cells
+    scattered as bytes.  Every way: the cells of the exact kernel, bit for bit."""
+    n, d = 2900, 256
+    sk = _mixed_density(1300, 1600, d, seed=31)
+    n2 = _n2(sk)
+    ss = ctx.sketch_set(sk)
+    ctx.set_option("pairwise_filter", 0)
+    cells, cnt = ctx.pairwise_rows(ss, n2, keep_mode=keep)              # the exact kernel on every cell
+    if keep == _capi.KEEP_INT32:
+        want = orc.pairwise_rows(sk, n2, chunk=192, threads=8)
+        want = want[np.lexsort((want["col"], want["row"]))]
+        assert np.array_equal(_cells_triples(cells), _cells_triples(want)) and np.array_equal(cells["dot"], want["dot"])
+    ctx.set_option("pairwise_filter", 2)
+    ctx.set_option("filter_variant", 8)
+    cells2, cnt2 = ctx.pairwise_rows(ss, n2, keep_mode=keep)            # cell list through filter + flagged tiles
+    cand, flagged, tiles = ctx.pairwise_stats()
+    assert cnt2 == cnt and np.array_equal(cells2, cells)
+    assert 0 < flagged < tiles and cand > 0                             # both mechanisms had work
+    if mode == "list":
+        ctx.set_option("stream_list_cells", 1 << 26)
+    else:
+        ctx.set_option("stream_list_cells", 1000)
+        ctx.set_option("stream_block_rows", 0 if mode == "matrix-one-block" else 256)
+        if mode == "matrix-one-stream":
+            ctx.set_option("stream_dense", 2)
+    pieces = []
+    n_s = ctx.pairwise_stream(ss, n2, on_block=lambda b, e, rp, c, qq: pieces.append((b, e, rp, c, qq)) and None, keep_mode=keep)
+    st = ctx.stream_stats()
+    assert st["two_stage"] == (1 if mode == "list" else 2)
+    assert st["row_blocks"] >= (1 if mode in ("list", "matrix-one-block") else 11)
+    got = np.concatenate([_triples(rp, c, qq, b) for (b, e, rp, c, qq) in pieces])
+    assert n_s == cnt and np.array_equal(got, _cells_triples(cells))
+    # rows that start on a 256-row border (the matrix can take them) and rows that do not (list)
+    for rb, re in ((512, 2000), (777, 2222)):
+        row_ptr, col, q, n_sh = ctx.pairwise_stream(ss, n2, row_begin=rb, row_end=re, keep_mode=keep)
+        sel = (cells["row"] >= rb) & (cells["row"] < re)
+        assert n_sh == int(sel.sum()) and np.array_equal(_triples(row_ptr, col, q, rb), _cells_triples(cells[sel]))
+    # device-encoded rows ride on the same blocks
+    from test_encode_gpu import _decode
+    enc = ctx.pairwise_stream_encoded(ss, n2, keep_mode=keep)
+    assert enc["n_cells"] == cnt and _decode(enc) == [tuple(int(x) for x in t) for t in _cells_triples(cells)]
+    ss.close()
+
+
+@pytest.mark.parametrize("thr", [1, 8, 64, 500, 8192, 0])
+def test_tile_density_threshold_changes_no_cell(ctx, thr):
+    """tile_dense_thr only moves work between the pair-by-pair re-check and the exact kernel on whole tiles (0: no tile is
+    ever flagged, the behaviour up to round 3): same cells at every setting"""
+    sk = _mixed_density(700, 900, 512, seed=5)
+    n2 = _n2(sk)
+    ss = ctx.sketch_set(sk)
+    ctx.set_option("pairwise_filter", 0)
+    cells, cnt = ctx.pairwise_rows(ss, n2)
+    ctx.set_option("pairwise_filter", 2)
+    ctx.set_option("filter_variant", 8)
+    ctx.set_option("tile_dense_thr", thr)
+    cells2, cnt2 = ctx.pairwise_rows(ss, n2)
+    cand, flagged, tiles = ctx.pairwise_stats()
+    assert cnt2 == cnt and np.array_equal(cells2, cells)
+    assert (flagged == 0) == (thr in (0, 8192)) and cand > 0
+    row_ptr, col, q, n_s = ctx.pairwise_stream(ss, n2)
+    assert n_s == cnt and np.array_equal(_triples(row_ptr, col, q), _cells_triples(cells))
+    # a rectangular block with every cell mirrored (the sharded schedule's kind of block)
+    import torch
+    out = torch.empty((1 << 20, 4), dtype=torch.int32, device="cuda")
+    n2_t = torch.from_numpy(n2).to("cuda")
+    ctx.set_option("pairwise_filter", 0)
+    n_ref = ctx.pairwise_block(ss, n2_t, 0, 512, 512, 1600, _capi.BLOCK_MIRROR_ALL, out, 0)
+    ctx.synchronize()
+    ref = out[:n_ref].cpu().numpy()
+    ctx.set_option("pairwise_filter", 2)
+    n_got = ctx.pairwise_block(ss, n2_t, 0, 512, 512, 1600, _capi.BLOCK_MIRROR_ALL, out, 0)
+    ctx.synchronize()
+    got = out[:n_got].cpu().numpy()
+    assert n_got == n_ref and sorted(map(tuple, got.tolist())) == sorted(map(tuple, ref.tolist()))
+    ss.close()
+
+
 def test_stream_q_beyond_8_bits_and_empty_rows(ctx):
     """norms that do not belong to the vectors make the Jaccard estimate negative for the pairs of sample 3 with the
     large samples: the reference's uint16 cast gives q = 65536 + round(255 J) there; such a piece
