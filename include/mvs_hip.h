@@ -112,6 +112,10 @@ int mvs_ctx_kernel_ms(mvs_ctx* ctx, int which, float* ms);
  *   tile_dense_thr        two-stage comparison on large blocks: a filter wave (128 x 64 cells) with more candidates than this
  *                         flags its 256 x 256 tile for the exact kernel instead of listing them (default 64; 0 = list
  *                         everything and give the whole block to the exact kernel once the list passes 1/128 of its cells)
+ *   stream_list_cells, stream_pipeline
+ *                         mvs_pairwise_stream with the two-stage comparison: up to stream_list_cells kept cells (bound from
+ *                         the filter pass) leave as one sorted list, more through the dense byte matrix; stream_pipeline = 0
+ *                         always filters the whole row range in one pass first (tests)
  *   stream_block_rows, encode_stage_words, pairwise_map, coarse_radix, cand_regions, recheck_mode, recheck_blocks
  *                         test / experiment switches (DESIGN.md, appendix "switches")
  *   comm_timeout_s        file transport (mvs_comm_create_files / _rendezvous): seconds a rank waits for its peers
@@ -315,8 +319,10 @@ int mvs_pairwise_stream_encoded(mvs_ctx* ctx, const mvs_sketch_set* set, const d
 
 /* What the most recent mvs_pairwise_stream of the context did: time of its comparison kernels summed over the row blocks
  * (0 unless mvs_ctx_set_timing is on), bytes handed to the callback, row blocks computed, pieces delivered, and whether
- * the two-stage comparison produced them as one list (1) or through the dense byte matrix, its flagged tiles computed row
- * block by row block (2), or the exact kernel alone in row blocks (0).  Any pointer may be NULL. */
+ * the two-stage comparison produced them as one list (1), through the dense byte matrix after one filter pass over all rows,
+ * its flagged tiles computed row block by row block (2), through the matrix with the filter itself running row block by row
+ * block (3: results that look dense from the first tile row on), or the exact kernel alone in row blocks (0).  Any pointer
+ * may be NULL. */
 int mvs_ctx_stream_stats(const mvs_ctx* ctx, double* kernel_ms, int64_t* bytes_out, int64_t* row_blocks, int64_t* pieces,
                          int* two_stage);
 

@@ -80,6 +80,8 @@ struct mvs_ctx {
     void* pw_trow = nullptr;    size_t pw_trow_bytes = 0;
     void* pw_tlist = nullptr;   size_t pw_tlist_bytes = 0;
     void* pw_cand2 = nullptr;   size_t pw_cand2_bytes = 0;
+    void* pw_ttouch = nullptr;  size_t pw_ttouch_bytes = 0;   // dense byte matrix: tiles the re-check's cells were scattered into,
+    void* pw_tnew = nullptr;    size_t pw_tnew_bytes = 0;     // and the list of those touched for the first time (to be cleared)
     long long last_flagged_tiles = 0, last_filter_tiles = 0;   // of the last two-stage comparison (mvs_ctx_pairwise_stats)
     void* pw_chdr = nullptr;    size_t pw_chdr_bytes = 0;   // candidate regions of the ping-pong filter: counts, entries
     void* pw_cent = nullptr;    size_t pw_cent_bytes = 0;
@@ -264,6 +266,7 @@ const OptionSpec kOptions[] = {
     {"stream_block_rows", &mvs::Options::stream_block_rows, nullptr, 0, 1 << 30},
     {"tile_dense_thr", &mvs::Options::tile_dense_thr, nullptr, 0, 8192},
     {"stream_list_cells", &mvs::Options::stream_list_cells, nullptr, 0, 1 << 30},
+    {"stream_pipeline", &mvs::Options::stream_pipeline, nullptr, 0, 1},
     {"pairwise_block_cells", nullptr, &mvs::Options::pairwise_block_cells, 1, (1LL << 62)},
 };
 
@@ -441,7 +444,7 @@ int mvs_ctx_destroy(mvs_ctx* c) {
     if (c->cmp_done) (void)hipEventDestroy(c->cmp_done);
     if (c->pw_chdr) (void)hipFree(c->pw_chdr);
     if (c->pw_cent) (void)hipFree(c->pw_cent);
-    for (void* p : {c->pw_tflag, c->pw_trow, c->pw_tlist, c->pw_cand2})
+    for (void* p : {c->pw_tflag, c->pw_trow, c->pw_tlist, c->pw_cand2, c->pw_ttouch, c->pw_tnew})
         if (p) (void)hipFree(p);
     for (int i = 0; i < 2; ++i) {
         if (c->up_pinned[i]) (void)hipHostFree(c->up_pinned[i]);
@@ -1165,6 +1168,8 @@ struct TwoStage {
     int n_flagged = 0;                // flagged tiles
     std::vector<int> row_first;       // n_tr + 1 entries: where each tile row starts in the row-major list of flagged tiles
     const int* d_list = nullptr;      // that list on the device
+    unsigned int* ext_flags = nullptr;   // in: tile flags live here (this launch's tile rows of a larger grid) instead of in
+                                         // the context's own array -- the streamed pipeline keeps one array for the whole matrix
 };
 
 void fill_args(mvs_ctx* c, const mvs_sketch_set* s, const double* d_n2, int keep_mode, int64_t rb, int64_t re, int64_t cb,
@@ -1221,8 +1226,10 @@ int two_stage_filter(mvs_ctx* c, const mvs_sketch_set* s, const double* d_n2, do
     mvs::filter_tile_grid(a, &ts.n_tr, &ts.n_tc);
     // the symmetric schedule computes the tiles on and above the diagonal of the square only
     const bool sym = a.symmetric && (a.row_begin - a.col_begin) % 256 == 0 && !a.mirror_all;
-    const double sq_tiles = (double)(a.sym_end - a.sym_begin) / 256.0;
-    const double tiles_to_do = std::max(1.0, (double)ts.n_tr * (double)ts.n_tc - (sym ? 0.5 * sq_tiles * (sq_tiles - 1.0) : 0.0));
+    // (tile row t of the launch skips the tiles strictly below the square's diagonal: (row_begin - sym_begin) / 256 + t of them)
+    const double r0_tiles = (double)(a.row_begin - a.sym_begin) / 256.0;
+    const double tiles_to_do = std::max(1.0, (double)ts.n_tr * (double)ts.n_tc -
+                                                 (sym ? (double)ts.n_tr * r0_tiles + 0.5 * (double)ts.n_tr * (double)(ts.n_tr - 1) : 0.0));
     c->last_filter_tiles = (long long)tiles_to_do;
     c->last_flagged_tiles = 0;
     // Listing: re-checking a candidate costs about as much as 80-300 cells of the exact kernel (by how well the rows
@@ -1262,11 +1269,13 @@ int two_stage_filter(mvs_ctx* c, const mvs_sketch_set* s, const double* d_n2, do
     }
     const size_t n_tiles = (size_t)ts.n_tr * (size_t)ts.n_tc;
     if (ts.tiles) {
-        rc = ensure_buf(c, &c->pw_tflag, &c->pw_tflag_bytes, n_tiles * 4);
-        if (rc) return rc;
+        if (!ts.ext_flags) {
+            rc = ensure_buf(c, &c->pw_tflag, &c->pw_tflag_bytes, n_tiles * 4);
+            if (rc) return rc;
+        }
         rc = ensure_buf(c, &c->pw_trow, &c->pw_trow_bytes, (size_t)ts.n_tr * 4);
         if (rc) return rc;
-        a.tile_flag = (unsigned int*)c->pw_tflag;
+        a.tile_flag = ts.ext_flags ? ts.ext_flags : (unsigned int*)c->pw_tflag;
         a.tile_flag_ld = ts.n_tc;
         a.tile_dense_thr = (unsigned)c->opt.tile_dense_thr;
         a.tile_flag_count = reinterpret_cast<unsigned int*>(c->d_counter + 8);
@@ -1277,8 +1286,11 @@ int two_stage_filter(mvs_ctx* c, const mvs_sketch_set* s, const double* d_n2, do
     for (int attempt = 0;; ++attempt) {
         a.cand = (int2*)c->pw_cand;
         a.cand_capacity = c->pw_cand_bytes / sizeof(int2);
-        // cell count, (debug), candidate count, ..., pruned count [6], flagged tiles [8] ... stop flag [32]
-        HIP_TRY(hipMemsetAsync(c->d_counter + 1, 0, 256, c->stream));
+        // cell count, (debug), candidate count, ..., pruned count [6], flagged tiles [8] ... stop flag [32]; NOT words 3
+        // and 4 (the streamed output's "wide q" and "q beyond a byte" flags: a block's flag must survive the next block's
+        // filter pass, which is queued before the block's rows are read)
+        HIP_TRY(hipMemsetAsync(c->d_counter + 1, 0, 16, c->stream));
+        HIP_TRY(hipMemsetAsync(c->d_counter + 5, 0, 224, c->stream));
         rc = set_cell_count(c, start);
         if (rc) return rc;
         HIP_TRY(hipMemsetAsync(a.recheck_queue, 0, 512, c->stream));
@@ -1373,7 +1385,7 @@ int two_stage_recheck(mvs_ctx* c, TwoStage& ts) {
 // Stage 3: the exact kernel on flagged tiles [first, first + count) of the row-major list.  `timed`: this launch closes
 // the comparison's timing interval (ev[6] .. ev[3]).
 int two_stage_tiles(mvs_ctx* c, TwoStage& ts, int first, int count, bool timed) {
-    if (count <= 0 && !(timed && ts.n_flagged > 0)) return MVS_OK;
+    if (count <= 0 && !timed) return MVS_OK;
     if (c->timing && timed) HIP_TRY(hipEventRecord(c->ev[6], c->stream));
     if (count > 0) {
         int rc = mvs::launch_exact_tiles(c->stream, ts.a, ts.d_list + first, count, c->opt);
@@ -1872,7 +1884,8 @@ int csr_from_packed(mvs_ctx* c, int64_t rb, int64_t re, int64_t n, int shift, in
 // rows [rb, re) of the dense byte matrix (first row dense_row0, leading dimension ld) are final: count, scan, fill.
 // *odd: some kept cell of the launches so far has a q the byte cannot hold -- the caller redoes the block as a list.
 int csr_from_dense(mvs_ctx* c, int64_t rb, int64_t re, int64_t n_cols, int64_t dense_row0, int64_t ld, int64_t block_index,
-                   BlockCsr& out, bool* odd, hipStream_t ps) {
+                   BlockCsr& out, bool* odd, hipStream_t ps, mvs::DenseActive active) {
+    active.row_rel0 = rb - dense_row0;
     const int64_t rows = re - rb;
     out.rb = rb;
     out.re = re;
@@ -1885,7 +1898,7 @@ int csr_from_dense(mvs_ctx* c, int64_t rb, int64_t re, int64_t n_cols, int64_t d
     if (rc) return rc;
     const uint8_t* first = (const uint8_t*)c->st_dense + (size_t)(rb - dense_row0) * (size_t)ld;
     HIP_TRY(hipMemsetAsync((char*)c->st_counts + (size_t)rows * 8, 0, 8, ps));
-    mvs::launch_dense_count(ps, first, ld, n_cols, rows, (long long*)c->st_counts);
+    mvs::launch_dense_count(ps, first, ld, n_cols, rows, (long long*)c->st_counts, active);
     rc = check_kernel("k_dense_count");
     if (rc) return rc;
     size_t need = 0;
@@ -1905,7 +1918,7 @@ int csr_from_dense(mvs_ctx* c, int64_t rb, int64_t re, int64_t n_cols, int64_t d
     rc = claim_csr_set(c, out.set, block_index, out.n, false, ps);
     if (rc) return rc;
     mvs::launch_dense_fill(ps, first, ld, n_cols, rows, (const long long*)c->st_rowptr, (int32_t*)c->st_col[out.set],
-                           (uint8_t*)c->st_q[out.set]);
+                           (uint8_t*)c->st_q[out.set], active);
     rc = check_kernel("k_dense_fill");
     if (rc) return rc;
     HIP_TRY(hipEventRecord(c->dl_ready, ps));
@@ -2155,83 +2168,182 @@ int pairwise_stream_impl(mvs_ctx* c, const mvs_sketch_set* s, const double* norm
         return MVS_OK;
     };
     const int64_t rows_all = row_end - row_begin;
-    // Plan A: the whole row range as ONE symmetric block through the two-stage comparison.  The filter pass runs once;
-    // what it found decides how the kept cells leave the device:
-    //  * few cells (candidates + cells of flagged tiles): ONE packed list, sorted on the device (needs the row field to
-    //    fit the packed word);
-    //  * whole regions of the result dense (many flagged tiles): the dense byte matrix of plan B, fed by the SAME filter
-    //    pass -- the re-check scatters its kept cells' bytes, the exact kernel writes the flagged tiles (and their mirror
-    //    images) row block by row block, and the blocks are counted / filled / encoded beside the next block's tiles;
-    //  * the filter gave up (nearly everything dense) or does not apply: plan B on the exact kernel alone.
-    bool tile_dense = false;
-    TwoStage ts;
+    // ---------------------------------------------------------------------------------------------------------------
+    // How the kept cells leave the device is decided by how dense the result is, which only the filter can tell:
+    //  A. sparse: ONE filter pass over the whole row range, candidates re-checked, the few flagged tiles computed, all kept
+    //     cells in ONE packed list that is sorted on the device (needs the row field to fit the packed word).
+    //  M. dense regions: the dense byte matrix -- one byte per cell, rows -> CSR / encoded rows by count / scan / fill passes
+    //     that read only the tiles that can hold something (flagged by the filter, mirror images of those, touched by the
+    //     re-check's kept cells: nothing else of the matrix is ever cleared or read) -- in row blocks, so that the link is
+    //     fed while the comparison goes on.  Two ways to get there:
+    //       M1 (pipeline): the filter itself runs block by block (first block one tile row: its flagged share tells sparse
+    //          from dense, and costs 1 % of a whole pass when the answer is "sparse"), so a block's rows are final -- and
+    //          on the link -- a millisecond after the call started instead of after the whole filter pass;
+    //       M2: plan A's whole filter pass found too many cells for a list: its flags and candidates feed the matrix, the
+    //          flagged tiles are computed block by block.
+    //  B. the filter does not apply or gave up (nearly every tile dense): the exact kernel in row blocks (dense matrix with
+    //     every tile active, or packed lists), as up to round 3.
+    // ---------------------------------------------------------------------------------------------------------------
     const bool fits_word = shift + bits_for(std::max<int64_t>(rows_all - 1, 1)) <= 64;
-    if (two_stage_applies(c, s, row_begin, row_end, 0, s->n, 0.05)) {
-        mvs::PairwiseArgs fa{};
-        fill_args(c, s, d_n2, keep_mode, row_begin, row_end, 0, s->n, true, false, 0.05, fa);
-        rc = two_stage_filter(c, s, d_n2, 0.05, 0, true, 0, fa, ts);
-        if (rc != MVS_OK && rc != kNeedExact) return finish(rc);
-        if (rc == MVS_OK) {
-            const unsigned long long bound = 2 * ts.n_cand + (unsigned long long)ts.n_flagged * 131072ULL;
-            mvs::PairwiseArgs probe0{};
-            probe0.limbs = s->limbs;
-            probe0.d_pad = s->d_pad;
-            const int64_t ld0 = (s->n + 127) / 128 * 128;
-            const bool dense_feasible = mvs::exact_kernel_writes_dense(probe0, c->opt) && c->opt.stream_dense != 0 &&
-                                        row_begin % 256 == 0 && (size_t)rows_all * (size_t)ld0 <= dense_budget;
-            size_t free_b = 0, total_b = 0;
-            HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-            const bool list_fits = fits_word && (double)bound * 22.0 <= (double)free_b * 0.5;
-            // 2^26 cells: below that the list (8 B per cell written, a radix sort over the key bits) is cheaper than
-            // clearing, counting and filling a matrix of rows x n bytes
-            const bool as_list = list_fits && (bound <= (unsigned long long)c->opt.stream_list_cells || !dense_feasible || ts.n_flagged == 0);
-            if (as_list) {
-                rc = ensure_buf(c, &c->st_raw, &c->st_raw_bytes, (size_t)(bound + 64) * 8);
-                if (rc) return finish(rc);
-                ts.a.packed = (unsigned long long*)c->st_raw;
-                ts.a.capacity = c->st_raw_bytes / 8;
-                ts.a.pack_row0 = row_begin;
-                ts.a.pack_shift = shift;
-                rc = two_stage_recheck(c, ts);
-                if (rc == MVS_OK) rc = two_stage_tiles(c, ts, 0, ts.n_flagged, true);
-                if (rc) return finish(rc);
-                unsigned long long got = 0;
-                hipError_t e = hipMemcpyAsync(&got, c->d_counter, 8, hipMemcpyDeviceToHost, c->stream);
-                if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-                if (e != hipSuccess) return finish(fail(MVS_E_HIP, "reading the cell count: %s", hipGetErrorString(e)));
-                if ((size_t)got * 8 > c->st_raw_bytes) return finish(fail(MVS_E_HIP, "internal: kept cells beyond the sized output"));
-                total = (int64_t)got;
-                add_kernel_ms();
-                c->st_blocks = 1;
-                c->st_two_stage = 1;
-                BlockCsr blk;
-                rc = csr_from_packed(c, row_begin, row_end, (int64_t)got, shift, col_bits, 0, blk);
-                if (rc == MVS_OK) rc = prepare(blk);
-                if (rc == MVS_OK) rc = deliver(blk);
-                return finish(rc);
-            }
-            tile_dense = dense_feasible;
-            // neither a list nor the matrix fits: plan B, the exact kernel in row blocks (the filter pass was in vain)
-        }
-    }
-    // Plan B: the exact kernel in row blocks, software-pipelined -- block k+1 is launched before block k's pieces are fed
-    // to the link, so comparison and download overlap.  Two ways for a block's cells to leave the kernel:
-    //  * dense (two limbs on the ping-pong kernel): one byte per cell in a row-major matrix, rows -> CSR by a count /
-    //    scan / fill pass, no list and no sort.  If the matrix of ALL the rows fits the budget the blocks share it and the
-    //    symmetric schedule spans the whole square: a block's launch computes its tiles on and above the diagonal and
-    //    writes the mirror images into later blocks' rows, so block k is final when launch k is.  Otherwise the matrix
-    //    holds one block at a time and the symmetric schedule works inside each block's own square only;
-    //  * packed list (any other kernel): blocks whose worst case -- every cell kept -- fits the budget.
+    const int64_t ld = (s->n + 127) / 128 * 128;
     mvs::PairwiseArgs probe{};
     probe.limbs = s->limbs;
     probe.d_pad = s->d_pad;
     const bool dense_ok = mvs::exact_kernel_writes_dense(probe, c->opt) && c->opt.stream_dense != 0;
-    const int64_t ld = (s->n + 127) / 128 * 128;
+    const bool matrix_fits = (size_t)rows_all * (size_t)ld <= dense_budget;
+    const bool applies = two_stage_applies(c, s, row_begin, row_end, 0, s->n, 0.05);
+    mvs::PairwiseArgs wa{};                                          // the whole row range as one symmetric block
+    fill_args(c, s, d_n2, keep_mode, row_begin, row_end, 0, s->n, true, false, 0.05, wa);
+    // the matrix flows need the tile grids to line up with the matrix's rows and the packed word to hold a row
+    const bool can_matrix = applies && dense_ok && matrix_fits && fits_word && row_begin % 256 == 0 && mvs::filter_flags_tiles(wa, c->opt);
+    int n_tr_all = 0, n_tc_all = 0;
+    mvs::filter_tile_grid(wa, &n_tr_all, &n_tc_all);
+    const int tile_o = (int)(row_begin / 256);
+    enum { kNone, kM1, kM2 } matrix_mode = kNone;
+    bool probe_gave_up = false;                                      // M1: the first tile row's filter pass stopped (dense everywhere)
+    TwoStage ts;                                                     // M2: the whole pass; M1: the current block's pass
+    mvs::DenseActive active{};                                       // flags == NULL: every tile (plan B)
+    const int saved_variant = c->opt.filter_variant;
+    struct RestoreVariant {                                          // M1 pins the filter kernel the whole range would get
+        mvs_ctx* c; int v;
+        ~RestoreVariant() { c->opt.filter_variant = v; }
+    } restore_variant{c, saved_variant};
+    auto matrix_setup = [&]() -> int {                               // matrix, touch map, list of newly touched tiles
+        const void* before = c->st_dense;
+        int r = ensure_buf(c, &c->st_dense, &c->st_dense_bytes, (size_t)rows_all * (size_t)ld);
+        if (r) return r;
+        if (c->st_dense != before) c->st_dense_zero = 0;
+        const size_t n_tiles = (size_t)n_tr_all * (size_t)n_tc_all;
+        r = ensure_buf(c, &c->pw_ttouch, &c->pw_ttouch_bytes, n_tiles * 4);
+        if (r) return r;
+        r = ensure_buf(c, &c->pw_tnew, &c->pw_tnew_bytes, (n_tiles + 1) * 4);
+        if (r) return r;
+        HIP_TRY(hipMemsetAsync(c->pw_ttouch, 0, n_tiles * 4, c->stream));
+        HIP_TRY(hipMemsetAsync(c->d_counter + 4, 0, 8, c->stream));      // the "q beyond a byte" flag
+        c->st_dense_zero = 0;
+        active.touch = (const unsigned int*)c->pw_ttouch;
+        active.n_tr = n_tr_all;
+        active.n_tc = n_tc_all;
+        active.o = tile_o;
+        active.sym = (c->opt.pairwise_symmetric != 0) ? 1 : 0;
+        return MVS_OK;
+    };
+    // re-check of t's candidates with the kept cells going into the matrix: a packed list first (the re-check decides
+    // which candidates are kept), then mark / clear / scatter (mvs_internal.h: launch_packed_to_dense)
+    auto recheck_into_matrix = [&](TwoStage& t) -> int {
+        int r = ensure_buf(c, &c->st_raw, &c->st_raw_bytes, (size_t)(2 * t.n_cand + 64) * 8);
+        if (r) return r;
+        t.a.dense = nullptr;
+        t.a.packed = (unsigned long long*)c->st_raw;
+        t.a.capacity = c->st_raw_bytes / 8;
+        t.a.pack_row0 = row_begin;
+        t.a.pack_shift = shift;
+        r = two_stage_recheck(c, t);
+        if (r) return r;
+        HIP_TRY(hipMemsetAsync(c->d_counter + 10, 0, 8, c->stream));     // count of newly touched tiles
+        mvs::launch_packed_to_dense(c->stream, (const unsigned long long*)c->st_raw, c->d_counter, shift,
+                                    (1ULL << col_bits) - 1ULL, (uint8_t*)c->st_dense, ld, rows_all, (unsigned int*)c->pw_ttouch, n_tc_all,
+                                    (int*)c->pw_tnew, reinterpret_cast<unsigned int*>(c->d_counter + 10),
+                                    reinterpret_cast<unsigned int*>(c->d_counter + 4));
+        r = check_kernel("k_packed_touch / k_clear_tiles / k_packed_scatter");
+        if (r) return r;
+        // from here on t.a describes the exact kernel's launches on the flagged tiles: bytes of whole tiles into the matrix
+        t.a.packed = nullptr;
+        t.a.dense = (uint8_t*)c->st_dense;
+        t.a.dense_row0 = row_begin;
+        t.a.dense_ld = ld;
+        t.a.dense_flag = reinterpret_cast<unsigned int*>(c->d_counter + 4);
+        return MVS_OK;
+    };
+    // M1, one block: filter its rows (symmetric square = the whole row range), re-check into the matrix, its flagged tiles
+    auto pipeline_filter = [&](int64_t rb, int64_t re, TwoStage& t) -> int {
+        mvs::PairwiseArgs fa{};
+        fill_args(c, s, d_n2, keep_mode, rb, re, 0, s->n, true, false, 0.05, fa);
+        fa.sym_begin = row_begin;
+        fa.sym_end = row_end;
+        t = TwoStage();
+        t.ext_flags = (unsigned int*)c->pw_tflag + (size_t)((rb - row_begin) / 256) * (size_t)n_tc_all;
+        return two_stage_filter(c, s, d_n2, 0.05, 0, true, 0, fa, t);
+    };
+    if (applies) {
+        bool whole_pass = true;
+        if (can_matrix && rows_all > 512 && c->opt.stream_pipeline != 0) {
+            // M1's first block doubles as the probe: one tile row of the filter
+            rc = ensure_buf(c, &c->pw_tflag, &c->pw_tflag_bytes, (size_t)n_tr_all * (size_t)n_tc_all * 4);
+            if (rc) return finish(rc);
+            if (c->opt.filter_variant < 0) c->opt.filter_variant = 8;    // what the whole range gets (filter_flags_tiles said so)
+            rc = pipeline_filter(row_begin, row_begin + 256, ts);
+            if (rc != MVS_OK && rc != kNeedExact) return finish(rc);
+            // share of flagged tiles in this row of tiles, extrapolated to the tiles of the whole pass, as list cells
+            const double tiles_all = std::max(1.0, (double)n_tr_all * (double)n_tc_all - 0.5 * (double)n_tr_all * (double)(n_tr_all - 1));
+            probe_gave_up = rc == kNeedExact;
+            if (probe_gave_up) c->filter_off_id = 0;                     // one tile row is no verdict on the set
+            const double est = probe_gave_up ? 1e30
+                                             : ((double)ts.n_flagged * 131072.0 + 2.0 * (double)ts.n_cand) / (double)n_tc_all * tiles_all;
+            if (est > (double)c->opt.stream_list_cells) {
+                matrix_mode = kM1;
+                whole_pass = false;
+            } else {
+                c->opt.filter_variant = saved_variant;
+            }
+        }
+        if (whole_pass && two_stage_applies(c, s, row_begin, row_end, 0, s->n, 0.05)) {
+            ts = TwoStage();
+            rc = two_stage_filter(c, s, d_n2, 0.05, 0, true, 0, wa, ts);
+            if (rc != MVS_OK && rc != kNeedExact) return finish(rc);
+            if (rc == MVS_OK) {
+                const unsigned long long bound = 2 * ts.n_cand + (unsigned long long)ts.n_flagged * 131072ULL;
+                size_t free_b = 0, total_b = 0;
+                HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+                const bool list_fits = fits_word && (double)bound * 22.0 <= (double)free_b * 0.5;
+                // stream_list_cells (2^26): below that the list (8 B per cell written, a radix sort over the key bits) is
+                // cheaper than counting and filling a matrix of rows x n bytes
+                const bool as_list = list_fits && (bound <= (unsigned long long)c->opt.stream_list_cells || !can_matrix || ts.n_flagged == 0);
+                if (as_list) {
+                    rc = ensure_buf(c, &c->st_raw, &c->st_raw_bytes, (size_t)(bound + 64) * 8);
+                    if (rc) return finish(rc);
+                    ts.a.packed = (unsigned long long*)c->st_raw;
+                    ts.a.capacity = c->st_raw_bytes / 8;
+                    ts.a.pack_row0 = row_begin;
+                    ts.a.pack_shift = shift;
+                    rc = two_stage_recheck(c, ts);
+                    if (rc == MVS_OK) rc = two_stage_tiles(c, ts, 0, ts.n_flagged, true);
+                    if (rc) return finish(rc);
+                    unsigned long long got = 0;
+                    hipError_t e = hipMemcpyAsync(&got, c->d_counter, 8, hipMemcpyDeviceToHost, c->stream);
+                    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+                    if (e != hipSuccess) return finish(fail(MVS_E_HIP, "reading the cell count: %s", hipGetErrorString(e)));
+                    if ((size_t)got * 8 > c->st_raw_bytes) return finish(fail(MVS_E_HIP, "internal: kept cells beyond the sized output"));
+                    total = (int64_t)got;
+                    add_kernel_ms();
+                    c->st_blocks = 1;
+                    c->st_two_stage = 1;
+                    BlockCsr blk;
+                    rc = csr_from_packed(c, row_begin, row_end, (int64_t)got, shift, col_bits, 0, blk);
+                    if (rc == MVS_OK) rc = prepare(blk);
+                    if (rc == MVS_OK) rc = deliver(blk);
+                    return finish(rc);
+                }
+                if (can_matrix) matrix_mode = kM2;
+                // neither a list nor the matrix fits: plan B (the filter pass was in vain)
+            }
+        }
+    }
+    // ---- row blocks ----
+    // Plan B proper: the exact kernel, software-pipelined -- block k+1 is launched before block k's pieces are fed to the
+    // link.  Two ways for a block's cells to leave the kernel:
+    //  * dense (two limbs on the ping-pong kernel): one byte per cell in a row-major matrix.  If the matrix of ALL the rows
+    //    fits the budget the blocks share it and the symmetric schedule spans the whole square: a block's launch computes its
+    //    tiles on and above the diagonal and writes the mirror images into later blocks' rows, so block k is final when
+    //    launch k is.  Otherwise the matrix holds one block at a time and the symmetric schedule works inside each block's
+    //    own square only;
+    //  * packed list (any other kernel): blocks whose worst case -- every cell kept -- fits the budget.
+    // The matrix flows M1 / M2 use the same loop with the shared matrix; only what a block's "launch" is differs.
     bool dense = dense_ok, whole = false;
     int64_t block_rows = 0;
     const bool aligned = row_begin % 128 == 0;                      // the symmetric schedule needs the tile grids to line up
     if (dense) {
-        whole = aligned && (size_t)rows_all * (size_t)ld <= dense_budget;   // (tile_dense implies both)
+        whole = aligned && matrix_fits;                              // (the matrix flows imply both)
         if (whole) {
             block_rows = std::max<int64_t>(2048, (rows_all / 16 + 255) / 256 * 256);
         } else {
@@ -2246,56 +2358,52 @@ int pairwise_stream_impl(mvs_ctx* c, const mvs_sketch_set* s, const double* norm
         while (shift + bits_for(std::max<int64_t>(block_rows - 1, 1)) > 64 && block_rows > 256) block_rows /= 2;
     }
     std::vector<std::pair<int64_t, int64_t>> blocks;
-    // blocks of one shared matrix start small (1024, 2048, 4096 rows, ...): the link has nothing to do until the first
-    // block has been compared, counted, filled and encoded
-    int64_t ramp = (dense && whole && c->opt.stream_block_rows == 0 && block_rows > 1024) ? 1024 : block_rows;
+    // blocks of one shared matrix start small (M1: one tile row, the probe; otherwise 1024 rows) and double: the link has
+    // nothing to do until the first block has been compared, counted, filled and encoded
+    int64_t ramp = block_rows;
+    if (dense && whole && c->opt.stream_block_rows == 0 && block_rows > 1024) ramp = 1024;
+    if (matrix_mode == kM1) ramp = 256;
     for (int64_t rb = row_begin; rb < row_end;) {
         const int64_t re = std::min(row_end, (rb / 256) * 256 + std::min(ramp, block_rows));
         blocks.emplace_back(rb, re);
         rb = re;
         ramp = std::min(block_rows, ramp * 2);
     }
-    if (dense) {
+    if (matrix_mode != kNone) {
+        rc = matrix_setup();
+        if (rc) return finish(rc);
+        active.flags = matrix_mode == kM1 ? (const unsigned int*)c->pw_tflag : (const unsigned int*)ts.a.tile_flag;
+        if (matrix_mode == kM1) {
+            // flags of blocks not yet filtered read as "not flagged"; block 0 has been filtered already (the probe)
+            const size_t done = (size_t)n_tc_all;
+            HIP_TRY(hipMemsetAsync((unsigned int*)c->pw_tflag + done, 0, ((size_t)n_tr_all * (size_t)n_tc_all - done) * 4, c->stream));
+        }
+        if (!probe_gave_up) {
+            rc = recheck_into_matrix(ts);                            // M2: all candidates; M1: block 0's
+            if (rc) return finish(rc);
+            add_kernel_ms();                                         // filter + re-check
+        }
+        c->st_two_stage = matrix_mode == kM1 ? 3 : 2;
+    } else if (dense) {
         const size_t bytes = (size_t)(whole ? rows_all : std::min(block_rows + 256, rows_all)) * (size_t)ld;
         const void* before = c->st_dense;
         rc = ensure_buf(c, &c->st_dense, &c->st_dense_bytes, bytes);
         if (rc) return finish(rc);
-        if (c->st_dense != before) c->st_dense_zero = 0;
+        (void)before;
+        c->st_dense_zero = 0;
         hipError_t e = hipMemsetAsync(c->d_counter + 4, 0, 8, c->stream);      // the "q beyond a byte" flag
         if (e != hipSuccess) return finish(fail(MVS_E_HIP, "hipMemsetAsync: %s", hipGetErrorString(e)));
     }
-    if (tile_dense) {
-        // fed by plan A's filter pass: cells outside the flagged tiles are zero unless the re-check keeps them.  10 GB at
-        // 100k rows: cleared here only when the last user did not leave it clean (see the end of this function)
-        if (c->st_dense_zero < (size_t)rows_all * (size_t)ld) {
-            hipError_t e = hipMemsetAsync(c->st_dense, 0, (size_t)rows_all * (size_t)ld, c->stream);
-            if (e != hipSuccess) return finish(fail(MVS_E_HIP, "hipMemsetAsync: %s", hipGetErrorString(e)));
-        }
-        ts.a.dense = (uint8_t*)c->st_dense;
-        ts.a.dense_row0 = row_begin;
-        ts.a.dense_ld = ld;
-        ts.a.dense_flag = reinterpret_cast<unsigned int*>(c->d_counter + 4);
-        rc = two_stage_recheck(c, ts);
-        if (rc) return finish(rc);
-        add_kernel_ms();                                             // filter + re-check
-        tiles_phase = true;
-        c->st_two_stage = 2;
-    }
-    if (dense) c->st_dense_zero = 0;                                 // about to be written
     const int saved_filter = c->opt.pairwise_filter;
-    auto launch = [&](size_t k, bool as_dense) -> int {
-        const int64_t rb = blocks[k].first, re = blocks[k].second;
-        if (tile_dense && as_dense) {                                // this block's flagged tiles (tile rows of 256)
-            const int t0 = (int)((rb - row_begin) / 256), t1 = (int)std::min<int64_t>(ts.n_tr, (re - row_begin + 255) / 256);
-            return two_stage_tiles(c, ts, ts.row_first[(size_t)t0], ts.row_first[(size_t)t1] - ts.row_first[(size_t)t0], true);
-        }
+    // the exact kernel on every tile of rows [rb, re) (plan B; also a block of M1 whose filter pass gave up)
+    auto launch_exact = [&](int64_t rb, int64_t re, bool as_dense) -> int {
         unsigned long long got = 0;
-        c->opt.pairwise_filter = 0;                                 // plan A has decided: the exact kernel does these blocks
+        c->opt.pairwise_filter = 0;
         int r;
         if (as_dense) {
-            DenseOut dn{(uint8_t*)c->st_dense, whole ? row_begin : rb, ld, whole ? row_begin : rb, whole ? row_end : re,
-                        reinterpret_cast<unsigned int*>(c->d_counter + 4)};
-            r = pairwise_launch(c, s, d_n2, keep_mode, rb, re, 0, s->n, true, false, nullptr, 0, 0, &got, 0.05, nullptr, &dn);
+            DenseOut dno{(uint8_t*)c->st_dense, whole ? row_begin : rb, ld, whole ? row_begin : rb, whole ? row_end : re,
+                         reinterpret_cast<unsigned int*>(c->d_counter + 4)};
+            r = pairwise_launch(c, s, d_n2, keep_mode, rb, re, 0, s->n, true, false, nullptr, 0, 0, &got, 0.05, nullptr, &dno);
         } else {
             const int64_t worst = (re - rb) * s->n;
             r = ensure_buf(c, &c->st_raw, &c->st_raw_bytes, (size_t)worst * 8);
@@ -2306,6 +2414,41 @@ int pairwise_stream_impl(mvs_ctx* c, const mvs_sketch_set* s, const double* norm
         }
         c->opt.pairwise_filter = saved_filter;
         return r;
+    };
+    auto launch = [&](size_t k, bool as_dense) -> int {
+        const int64_t rb = blocks[k].first, re = blocks[k].second;
+        if (matrix_mode == kM2 && as_dense) {                        // this block's share of the whole pass's flagged tiles
+            tiles_phase = true;
+            const int t0 = (int)((rb - row_begin) / 256), t1 = (int)std::min<int64_t>(ts.n_tr, (re - row_begin + 255) / 256);
+            return two_stage_tiles(c, ts, ts.row_first[(size_t)t0], ts.row_first[(size_t)t1] - ts.row_first[(size_t)t0], true);
+        }
+        if (matrix_mode == kM1 && as_dense) {
+            tiles_phase = k == 0 && !probe_gave_up;                  // k > 0 is timed as a whole comparison: ev[2] .. ev[3]
+            int r = k == 0 ? (probe_gave_up ? kNeedExact : MVS_OK) : pipeline_filter(rb, re, ts);
+            if (r == kNeedExact) {
+                // nearly every tile of these rows is dense: the exact kernel on all of them.  Flag the tiles it writes itself
+                // -- outside the square, on and above its diagonal -- so that the row passes read them and their mirror
+                // images; the tiles below the diagonal stay what earlier blocks made of them
+                const int t0 = (int)((rb - row_begin) / 256), t1 = (int)((re - row_begin + 255) / 256);
+                for (int t = t0; t < t1; ++t) {
+                    unsigned int* rowf = (unsigned int*)c->pw_tflag + (size_t)t * (size_t)n_tc_all;
+                    hipError_t e = hipSuccess;
+                    if (tile_o > 0) e = hipMemsetD32Async((hipDeviceptr_t)rowf, 1, (size_t)tile_o, c->stream);
+                    if (e == hipSuccess && t + tile_o < n_tc_all)
+                        e = hipMemsetD32Async((hipDeviceptr_t)(rowf + t + tile_o), 1, (size_t)(n_tc_all - t - tile_o), c->stream);
+                    if (e != hipSuccess) return fail(MVS_E_HIP, "hipMemsetD32Async: %s", hipGetErrorString(e));
+                }
+                c->filter_off_id = 0;                                // a verdict on these rows, not on the set
+                return launch_exact(rb, re, true);
+            }
+            if (r) return r;
+            if (k > 0) {                                             // block 0 was re-checked with the probe
+                r = recheck_into_matrix(ts);
+                if (r) return r;
+            }
+            return two_stage_tiles(c, ts, 0, ts.n_flagged, true);
+        }
+        return launch_exact(rb, re, as_dense);
     };
     auto packed_count = [&](size_t k, int64_t* n) -> int {
         unsigned long long got = 0;
@@ -2334,10 +2477,7 @@ int pairwise_stream_impl(mvs_ctx* c, const mvs_sketch_set* s, const double* norm
             hipError_t e = hipEventRecord(c->cmp_done, c->stream);              // launch k is the last thing queued there
             if (e == hipSuccess) e = hipStreamWaitEvent(ps, c->cmp_done, 0);
             if (e != hipSuccess) return finish(fail(MVS_E_HIP, "ordering the side stream: %s", hipGetErrorString(e)));
-            if (c->timing && c->ev_valid[1]) {                                   // launch k's time, before its events are reused
-                (void)hipEventSynchronize(c->ev[3]);
-                add_kernel_ms();
-            }
+            if (c->timing && c->ev_valid[1]) add_kernel_ms();                    // launch k's time, before its events are reused
             if (k + 1 < blocks.size() && !out.failed()) {
                 rc = launch(k + 1, true);
                 if (rc) return finish(rc);
@@ -2346,7 +2486,7 @@ int pairwise_stream_impl(mvs_ctx* c, const mvs_sketch_set* s, const double* norm
         }
         if (dense) {
             bool odd = false;
-            rc = csr_from_dense(c, rb, re, s->n, whole ? row_begin : rb, ld, (int64_t)k, blk, &odd, ps);
+            rc = csr_from_dense(c, rb, re, s->n, whole ? row_begin : rb, ld, (int64_t)k, blk, &odd, ps, active);
             if (rc) return finish(rc);
             if (!side) add_kernel_ms();
             if (odd) {
@@ -2359,7 +2499,9 @@ int pairwise_stream_impl(mvs_ctx* c, const mvs_sketch_set* s, const double* norm
                 // rest go through the packed list, each block inside its own square -- the one case where a block is
                 // compared a second time
                 dense = false;
-                tile_dense = tiles_phase = false;
+                matrix_mode = kNone;
+                tiles_phase = false;
+                c->opt.filter_variant = saved_variant;
                 int64_t br = std::max<int64_t>(256, budget_cells / std::max<int64_t>(s->n, 1) / 256 * 256);
                 while (shift + bits_for(std::max<int64_t>(br - 1, 1)) > 64 && br > 256) br /= 2;
                 std::vector<std::pair<int64_t, int64_t>> rest(blocks.begin(), blocks.begin() + (long)k);
@@ -2395,17 +2537,6 @@ int pairwise_stream_impl(mvs_ctx* c, const mvs_sketch_set* s, const double* norm
         if (rc) return finish(rc);
         if (out.failed()) break;
         (void)next_launched;
-    }
-    if (tile_dense && !out.failed()) {
-        // leave the matrix clean for the next call: behind the last block's passes, while the link still drains
-        const size_t bytes = (size_t)rows_all * (size_t)ld;
-        hipError_t e = hipSuccess;
-        if (side) {
-            e = hipEventRecord(c->cmp_done, ps);
-            if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, c->cmp_done, 0);
-        }
-        if (e == hipSuccess) e = hipMemsetAsync(c->st_dense, 0, bytes, c->stream);
-        if (e == hipSuccess) c->st_dense_zero = bytes;
     }
     return finish(MVS_OK);
 }

@@ -62,6 +62,9 @@ struct Options {
     int stream_list_cells = 1 << 26;   // mvs_pairwise_stream, two-stage comparison: up to this many cells (candidates + cells
                                     // of flagged tiles, mirror images included) leave as ONE packed list; beyond it the dense
                                     // byte matrix takes the flagged tiles (tests lower it)
+    int stream_pipeline = 1;        // mvs_pairwise_stream: 1 = where the result looks dense (first tile row of the filter) the filter
+                                    // itself runs row block by row block, so the link is fed from the first millisecond; 0 = always
+                                    // one filter pass over the whole row range first (tests)
     int comm_timeout_s = 600;       // file transport: how long a rank waits for a peer's block before it gives up
     double pairwise_block_cells = 1099511627776.0;   // row-chunk bound of mvs_pairwise_rows (2^40 cells)
 };
@@ -142,6 +145,18 @@ struct PairwiseArgs {
     int tile_list_n;
 };
 
+// Which 256 x 256 tiles of the dense byte matrix can hold a kept cell (tile-granular comparison feeding the matrix): the
+// tiles the filter flagged (the exact kernel wrote them whole), their mirror images, and the tiles the re-check's kept
+// cells were scattered into.  The row -> CSR passes read only those; nothing else of the matrix is ever cleared or read.
+struct DenseActive {
+    const unsigned int* flags;   // [n_tr * n_tc] of the matrix's tile grid (rows relative to its first row); NULL: every tile
+    const unsigned int* touch;   // same shape
+    int n_tr, n_tc;
+    int o;                       // tile column of the matrix's first row (row_begin / 256): mirror of (tr, tc) = (tc - o, tr + o)
+    int sym;                     // the symmetric schedule was on: mirror images of flagged tiles exist
+    long long row_rel0;          // first row of the launch, relative to the matrix's first row
+};
+
 // per-row statistics of the coarse plane: radix m, sum c^2, sum r^2 (r = v - m*c), and whether the row's sum
 // of squares reaches 2^31 (its dots may wrap: the filter then passes every pair of that row on to the re-check)
 struct CoarseRow {
@@ -197,11 +212,18 @@ int sort_packed(hipStream_t stream, unsigned long long* d_in, unsigned long long
 int launch_packed_csr(hipStream_t stream, const unsigned long long* d_keys, int64_t n, int shift, int64_t rows,
                       unsigned long long col_mask, long long* d_row_ptr, int32_t* d_col, uint8_t* d_q8, uint16_t* d_q16,
                       unsigned int* d_wide);
-int launch_dense_count(hipStream_t stream, const uint8_t* d_dense, int64_t ld, int64_t n_cols, int64_t rows, long long* d_counts);
+int launch_dense_count(hipStream_t stream, const uint8_t* d_dense, int64_t ld, int64_t n_cols, int64_t rows, long long* d_counts,
+                       const DenseActive& active);
 int dense_row_ptr(hipStream_t stream, long long* d_counts, long long* d_row_ptr, int64_t rows, void* d_scratch, size_t scratch_bytes,
                   size_t* scratch_needed);
 int launch_dense_fill(hipStream_t stream, const uint8_t* d_dense, int64_t ld, int64_t n_cols, int64_t rows, const long long* d_row_ptr,
-                      int32_t* d_col, uint8_t* d_q);
+                      int32_t* d_col, uint8_t* d_q, const DenseActive& active);
+// the re-check's kept cells (packed words, *d_n of them, rows relative to pack_row0 = the matrix's first row) into the dense
+// byte matrix: mark the tiles they fall into (newly touched ones are listed in d_new, count in d_new[-1] .. i.e. d_new_count),
+// clear those tiles, then write the bytes; *d_odd is set when a q is not in 1..255
+int launch_packed_to_dense(hipStream_t stream, const unsigned long long* d_keys, const unsigned long long* d_n, int shift,
+                           unsigned long long col_mask, uint8_t* d_dense, int64_t ld, int64_t matrix_rows, unsigned int* d_touch,
+                           int n_tc, int* d_new, unsigned int* d_new_count, unsigned int* d_odd);
 // true when launch_pairwise would run the kernel whose epilogue can write the dense byte matrix (two base-256 limbs on the
 // ping-pong kernel)
 bool exact_kernel_writes_dense(const PairwiseArgs& a, const Options& opt);

@@ -2060,13 +2060,24 @@ __device__ __forceinline__ unsigned nz_mask16(const v4i w) {
     return m;
 }
 
+// can tile (tr, tc) of the matrix hold a kept cell?  (flag / touch arrays: a few hundred KB, L2 resident)
+__device__ __forceinline__ bool tile_active(const DenseActive& A, int tr, int tc) {
+    if (A.flags == nullptr) return true;
+    const size_t t = (size_t)tr * A.n_tc + tc;
+    if (A.flags[t] != 0u || A.touch[t] != 0u) return true;
+    const int mr = tc - A.o, mc = tr + A.o;                       // the tile whose mirror image this one is
+    return A.sym && mr >= 0 && mr < A.n_tr && mc < A.n_tc && A.flags[(size_t)mr * A.n_tc + mc] != 0u;
+}
+
 // counts[r] = kept cells of row r: one workgroup per row
 __global__ __launch_bounds__(256) void k_dense_count(const uint8_t* __restrict__ dense, long long ld, long long n_cols,
-                                                     long long* __restrict__ counts) {
+                                                     long long* __restrict__ counts, const DenseActive A) {
     __shared__ unsigned part[4];
     const uint8_t* row = dense + (long long)blockIdx.x * ld;
+    const int tr = (int)((A.row_rel0 + blockIdx.x) >> 8);
     unsigned c = 0;
     for (long long k = (long long)threadIdx.x * 16; k < n_cols; k += 256 * 16) {
+        if (!tile_active(A, tr, (int)(k >> 8))) continue;
         unsigned m = nz_mask16(*reinterpret_cast<const v4i*>(row + k));
         if (k + 16 > n_cols) m &= (1u << (n_cols - k)) - 1u;                  // columns beyond the last sample
         c += (unsigned)__popc(m);
@@ -2085,19 +2096,22 @@ __global__ __launch_bounds__(256) void k_dense_count(const uint8_t* __restrict__
 // profiles/r03_c2d_pmc_summary.txt before this change).
 __global__ __launch_bounds__(256) void k_dense_fill(const uint8_t* __restrict__ dense, long long ld, long long n_cols,
                                                     const long long* __restrict__ row_ptr, int32_t* __restrict__ col,
-                                                    uint8_t* __restrict__ q) {
+                                                    uint8_t* __restrict__ q, const DenseActive A) {
     __shared__ unsigned wsum[2][4];
     __shared__ int32_t s_col[256 * 16];
     __shared__ uint8_t s_q[256 * 16];
     const uint8_t* row = dense + (long long)blockIdx.x * ld;
     long long base = row_ptr[blockIdx.x];
+    const long long row_total = row_ptr[blockIdx.x + 1] - base;
+    if (row_total == 0) return;                                   // block-uniform
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int tr = (int)((A.row_rel0 + blockIdx.x) >> 8);
     unsigned step = 0;
     for (long long k0 = 0; k0 < n_cols; k0 += 256 * 16, ++step) {
         const long long k = k0 + (long long)threadIdx.x * 16;
         v4i wv = v4i{0, 0, 0, 0};
         unsigned m = 0;
-        if (k < n_cols) {
+        if (k < n_cols && tile_active(A, tr, (int)(k >> 8))) {
             wv = *reinterpret_cast<const v4i*>(row + k);
             m = nz_mask16(wv);
             if (k + 16 > n_cols) m &= (1u << (n_cols - k)) - 1u;   // columns beyond the last sample
@@ -2132,6 +2146,49 @@ __global__ __launch_bounds__(256) void k_dense_fill(const uint8_t* __restrict__ 
             q[base + i] = s_q[i];
         }
         base += total;
+    }
+}
+
+// ---- the re-check's kept cells (packed words) -> dense byte matrix ----
+// pass 1: mark the tile of every cell; a tile marked for the first time goes on the list of tiles to clear
+__global__ __launch_bounds__(256) void k_packed_touch(const unsigned long long* __restrict__ keys, const unsigned long long* __restrict__ n_ptr,
+                                                      int shift, unsigned long long col_mask, unsigned int* __restrict__ touch, int n_tc,
+                                                      int* __restrict__ new_list, unsigned int* __restrict__ new_count) {
+    const unsigned long long n = *n_ptr;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * 256) {
+        const unsigned long long key = keys[i];
+        const long long row = (long long)(key >> shift), col = (long long)((key >> 16) & col_mask);
+        const size_t t = (size_t)(row >> 8) * n_tc + (size_t)(col >> 8);
+        if (*reinterpret_cast<volatile unsigned int*>(touch + t) != 0u) continue;
+        if (atomicExch(touch + t, 1u) == 0u) new_list[atomicAdd(new_count, 1u)] = (int)t;
+    }
+}
+
+// pass 2: clear the newly touched tiles (256 rows x 256 bytes each, inside the matrix)
+__global__ __launch_bounds__(256) void k_clear_tiles(const int* __restrict__ list, const unsigned int* __restrict__ count, uint8_t* __restrict__ dense,
+                                                     long long ld, long long matrix_rows, int n_tc) {
+    const unsigned n = *count;
+    for (unsigned e = blockIdx.x; e < n; e += gridDim.x) {
+        const int t = list[e];
+        const long long r0 = (long long)(t / n_tc) * 256, c0 = (long long)(t % n_tc) * 256;
+        for (int x = threadIdx.x; x < 256 * 16; x += 256) {
+            const long long r = r0 + (x >> 4), cc = c0 + (x & 15) * 16;
+            if (r < matrix_rows && cc < ld) *reinterpret_cast<v4i*>(dense + r * ld + cc) = v4i{0, 0, 0, 0};
+        }
+    }
+}
+
+// pass 3: the bytes
+__global__ __launch_bounds__(256) void k_packed_scatter(const unsigned long long* __restrict__ keys, const unsigned long long* __restrict__ n_ptr,
+                                                        int shift, unsigned long long col_mask, uint8_t* __restrict__ dense, long long ld,
+                                                        unsigned int* __restrict__ odd) {
+    const unsigned long long n = *n_ptr;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * 256) {
+        const unsigned long long key = keys[i];
+        const long long row = (long long)(key >> shift), col = (long long)((key >> 16) & col_mask);
+        const unsigned q = (unsigned)(key & 0xffffULL);
+        if (q == 0u || q > 255u) *odd = 1u;
+        dense[row * ld + col] = (uint8_t)q;
     }
 }
 
@@ -2544,9 +2601,21 @@ int launch_packed_csr(hipStream_t stream, const unsigned long long* d_keys, int6
 }
 
 // rows [0, rows) of a dense byte matrix -> counts, row_ptr (exclusive scan, row_ptr[rows] = total), then col / q
-int launch_dense_count(hipStream_t stream, const uint8_t* d_dense, int64_t ld, int64_t n_cols, int64_t rows, long long* d_counts) {
+int launch_dense_count(hipStream_t stream, const uint8_t* d_dense, int64_t ld, int64_t n_cols, int64_t rows, long long* d_counts,
+                       const DenseActive& active) {
     if (rows <= 0) return 0;
-    hipLaunchKernelGGL(k_dense_count, dim3((unsigned)rows), dim3(256), 0, stream, d_dense, (long long)ld, (long long)n_cols, d_counts);
+    hipLaunchKernelGGL(k_dense_count, dim3((unsigned)rows), dim3(256), 0, stream, d_dense, (long long)ld, (long long)n_cols, d_counts,
+                       active);
+    return 0;
+}
+
+int launch_packed_to_dense(hipStream_t stream, const unsigned long long* d_keys, const unsigned long long* d_n, int shift,
+                           unsigned long long col_mask, uint8_t* d_dense, int64_t ld, int64_t matrix_rows, unsigned int* d_touch,
+                           int n_tc, int* d_new, unsigned int* d_new_count, unsigned int* d_odd) {
+    hipLaunchKernelGGL(k_packed_touch, dim3(512), dim3(256), 0, stream, d_keys, d_n, shift, col_mask, d_touch, n_tc, d_new, d_new_count);
+    hipLaunchKernelGGL(k_clear_tiles, dim3(2048), dim3(256), 0, stream, (const int*)d_new, (const unsigned int*)d_new_count, d_dense,
+                       (long long)ld, (long long)matrix_rows, n_tc);
+    hipLaunchKernelGGL(k_packed_scatter, dim3(512), dim3(256), 0, stream, d_keys, d_n, shift, col_mask, d_dense, (long long)ld, d_odd);
     return 0;
 }
 
@@ -2564,10 +2633,10 @@ int dense_row_ptr(hipStream_t stream, long long* d_counts, long long* d_row_ptr,
 }
 
 int launch_dense_fill(hipStream_t stream, const uint8_t* d_dense, int64_t ld, int64_t n_cols, int64_t rows, const long long* d_row_ptr,
-                      int32_t* d_col, uint8_t* d_q) {
+                      int32_t* d_col, uint8_t* d_q, const DenseActive& active) {
     if (rows <= 0) return 0;
     hipLaunchKernelGGL(k_dense_fill, dim3((unsigned)rows), dim3(256), 0, stream, d_dense, (long long)ld, (long long)n_cols, d_row_ptr,
-                       d_col, d_q);
+                       d_col, d_q, active);
     return 0;
 }
 

@@ -29,7 +29,7 @@ from metagenome_vector_sketches_amd import _capi, synth  # noqa: E402
 from oracle import pyoracle as orc  # noqa: E402
 
 OPTIONS = ("pairwise_filter", "stream_dense", "stream_block_rows", "encode_stage_words", "pairwise_symmetric", "filter_variant",
-           "tile_dense_thr", "stream_list_cells")
+           "tile_dense_thr", "stream_list_cells", "stream_pipeline")
 
 
 def _n2(sk):
@@ -93,7 +93,8 @@ def run_case(ctx, rng, max_n, decode_limit=150_000, log=None):
             # density threshold per wave, and a small list bound so that the dense byte matrix takes the flagged tiles
             "filter_variant": int(rng.choice([-1, -1, 8, 8])),
             "tile_dense_thr": int(rng.choice([64, 64, 1, 8, 500, 0])),
-            "stream_list_cells": int(rng.choice([1 << 26, 1 << 26, 0, 5000]))}
+            "stream_list_cells": int(rng.choice([1 << 26, 1 << 26, 0, 5000])),
+            "stream_pipeline": int(rng.random() < 0.7)}
     info.update(keep=keep, rows=(rb, re), budget=budget, **opts)
     old = {k: ctx.get_option(k) for k in OPTIONS}
     ss = None

@@ -118,15 +118,18 @@ def _mixed_density(n_dense, n_sparse, d, seed):
     return np.concatenate([a, b])
 
 
-@pytest.mark.parametrize("mode", ["list", "matrix", "matrix-one-stream", "matrix-one-block"])
+@pytest.mark.parametrize("mode", ["list", "matrix", "matrix-one-stream", "matrix-one-block", "pipeline", "pipeline-one-stream",
+                                  "pipeline-big-blocks"])
 @pytest.mark.parametrize("keep", [_capi.KEEP_INT32, _capi.KEEP_INT16])
 def test_stream_tile_granular_mixed_density(ctx, mode, keep):
     """Dense regions next to sparse ones (the reference's cost is flat in the density, src/pairwise_comp_optimized.cpp:
     135-147; ours must not fall off a cliff between the two): the ping-pong filter flags the 256 x 256 tiles whose waves
     hold more than tile_dense_thr candidates, the exact kernel computes those tiles only, everything else is re-checked
-    pair by pair.  The kept cells leave as ONE packed list (few) or through the dense byte matrix that the same filter
-    pass feeds (many; stream_list_cells lowered to force it): flagged tiles row block by row block, the re-check's cells
-    scattered as bytes.  Every way: the cells of the exact kernel, bit for bit."""
+    pair by pair.  The kept cells leave as ONE packed list (few) or through the dense byte matrix (many; stream_list_cells
+    lowered to force it): flagged tiles written whole, the re-check's cells scattered as bytes into tiles cleared on first
+    touch, the row passes reading only tiles that can hold something.  "matrix": one filter pass over all rows feeds it
+    (stream_pipeline = 0), "pipeline": the filter itself runs row block by row block (the default where the first tile row
+    looks dense).  Every way: the cells of the exact kernel, bit for bit."""
     n, d = 2900, 256
     sk = _mixed_density(1300, 1600, d, seed=31)
     n2 = _n2(sk)
@@ -147,14 +150,15 @@ def test_stream_tile_granular_mixed_density(ctx, mode, keep):
         ctx.set_option("stream_list_cells", 1 << 26)
     else:
         ctx.set_option("stream_list_cells", 1000)
-        ctx.set_option("stream_block_rows", 0 if mode == "matrix-one-block" else 256)
-        if mode == "matrix-one-stream":
+        ctx.set_option("stream_pipeline", 1 if mode.startswith("pipeline") else 0)
+        ctx.set_option("stream_block_rows", 0 if mode in ("matrix-one-block", "pipeline-big-blocks") else 256)
+        if mode.endswith("one-stream"):
             ctx.set_option("stream_dense", 2)
     pieces = []
     n_s = ctx.pairwise_stream(ss, n2, on_block=lambda b, e, rp, c, qq: pieces.append((b, e, rp, c, qq)) and None, keep_mode=keep)
     st = ctx.stream_stats()
-    assert st["two_stage"] == (1 if mode == "list" else 2)
-    assert st["row_blocks"] >= (1 if mode in ("list", "matrix-one-block") else 11)
+    assert st["two_stage"] == (1 if mode == "list" else 3 if mode.startswith("pipeline") else 2)
+    assert st["row_blocks"] >= (1 if mode in ("list", "matrix-one-block") else 3 if mode == "pipeline-big-blocks" else 11)
     got = np.concatenate([_triples(rp, c, qq, b) for (b, e, rp, c, qq) in pieces])
     assert n_s == cnt and np.array_equal(got, _cells_triples(cells))
     # rows that start on a 256-row border (the matrix can take them) and rows that do not (list)
