@@ -106,9 +106,10 @@ int mvs_ctx_kernel_ms(mvs_ctx* ctx, int which, float* ms);
  *   project_variant       projection kernel: 0 (default) by dimension -- 14 = four 64-dim blocks per wave sharing the
  *                         first splitmix64 round when d is a multiple of 256 (>= 512), else 2 or 1 blocks per wave;
  *                         1 / 2 / 12 / 14 force a variant
- *   stream_dense          mvs_pairwise_stream where the exact kernel runs: 1 (default) one byte per cell in a matrix, a
- *                         row block turned into CSR / encoded rows on a side stream beside the next block's launch;
- *                         2 the same on the context's stream, one after the other; 0 packed 64-bit cells + sort
+ *   stream_dense          mvs_pairwise_stream, dense results: 1 (default) one byte per cell in a matrix, a row block turned
+ *                         into CSR / encoded rows on a side stream beside the next block's launch where the exact kernel
+ *                         does whole row blocks, on the context's stream where the two-stage comparison feeds the matrix;
+ *                         2 always the context's stream; 3 always the side stream; 0 packed 64-bit cells + sort
  *   tile_dense_thr        two-stage comparison on large blocks: a filter wave (128 x 64 cells) with more candidates than this
  *                         flags its 256 x 256 tile for the exact kernel instead of listing them (default 64; 0 = list
  *                         everything and give the whole block to the exact kernel once the list passes 1/128 of its cells)

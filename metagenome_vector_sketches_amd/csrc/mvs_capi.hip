@@ -4,6 +4,8 @@
 #include <atomic>
 #include <condition_variable>
 #include <deque>
+#include <functional>
+#include <memory>
 #include <dlfcn.h>
 #include <mutex>
 
@@ -12,6 +14,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <chrono>
 #include <thread>
 #include <vector>
 
@@ -68,7 +71,7 @@ struct mvs_ctx {
     size_t dl_bytes[2] = {0, 0};                  // pinning costs ~0.3 ms per MiB, a one-piece result needs only one
     hipEvent_t dl_done[2] = {nullptr, nullptr};   // download into pinned buffer i has completed
     hipEvent_t dl_block[2] = {nullptr, nullptr};  // the downloads out of CSR array set i have completed
-    hipEvent_t dl_ready = nullptr;                // the CSR arrays of a row block are final on the compute stream
+    hipEvent_t dl_ready[2] = {nullptr, nullptr};  // the arrays of the row block in set i are final on the compute stream
     hipStream_t post_stream = nullptr;            // dense row blocks -> CSR / encoded rows beside the next block's comparison
     hipEvent_t cmp_done = nullptr;                // the comparison launch of the block about to be post-processed is through
     // what the last mvs_pairwise_stream did (mvs_ctx_stream_stats)
@@ -261,12 +264,13 @@ const OptionSpec kOptions[] = {
     {"cand_regions", &mvs::Options::cand_regions, nullptr, 0, 1},
     {"recheck_mode", &mvs::Options::recheck_mode, nullptr, 0, 3},
     {"recheck_blocks", &mvs::Options::recheck_blocks, nullptr, 1, 64},
-    {"stream_dense", &mvs::Options::stream_dense, nullptr, 0, 2},
+    {"stream_dense", &mvs::Options::stream_dense, nullptr, 0, 3},
     {"encode_stage_words", &mvs::Options::encode_stage_words, nullptr, 1, 64},
     {"stream_block_rows", &mvs::Options::stream_block_rows, nullptr, 0, 1 << 30},
     {"tile_dense_thr", &mvs::Options::tile_dense_thr, nullptr, 0, 8192},
     {"stream_list_cells", &mvs::Options::stream_list_cells, nullptr, 0, 1 << 30},
     {"stream_pipeline", &mvs::Options::stream_pipeline, nullptr, 0, 1},
+    {"stream_trace", &mvs::Options::stream_trace, nullptr, 0, 1},
     {"pairwise_block_cells", nullptr, &mvs::Options::pairwise_block_cells, 1, (1LL << 62)},
 };
 
@@ -438,7 +442,7 @@ int mvs_ctx_destroy(mvs_ctx* c) {
         if (c->dl_done[i]) (void)hipEventDestroy(c->dl_done[i]);
         if (c->dl_block[i]) (void)hipEventDestroy(c->dl_block[i]);
     }
-    if (c->dl_ready) (void)hipEventDestroy(c->dl_ready);
+    for (hipEvent_t ev : c->dl_ready) if (ev) (void)hipEventDestroy(ev);
     if (c->dl_stream) (void)hipStreamDestroy(c->dl_stream);
     if (c->post_stream) (void)hipStreamDestroy(c->post_stream);
     if (c->cmp_done) (void)hipEventDestroy(c->cmp_done);
@@ -1630,6 +1634,57 @@ struct StreamOut {
     int cb_status = 0;                     // first non-zero return of the callback
     std::string error;
     std::thread worker;
+    // The feeder: hands finished row blocks to the link piece by piece (it blocks on the two pinned buffers), so that the
+    // thread that drives the device never waits for the link -- it runs at most two blocks ahead (the device-side arrays
+    // of a block are double-buffered: set k & 1).
+    std::thread feeder;
+    std::deque<std::function<int()>> feed_queue;
+    bool feed_closing = false;
+    int64_t fed_blocks = 0;                // blocks whose pieces have all been queued on the download stream
+    int feed_rc = 0;
+
+    void feed_run() {
+        (void)hipSetDevice(c->device);
+        for (;;) {
+            std::function<int()> task;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return feed_closing || !feed_queue.empty(); });
+                if (feed_queue.empty()) return;
+                task = std::move(feed_queue.front());
+                feed_queue.pop_front();
+            }
+            const int r = task();
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                if (r != 0 && feed_rc == 0) {
+                    feed_rc = r;
+                    if (error.empty()) error = std::string("feeding the link failed: ") + mvs_last_error();
+                }
+                ++fed_blocks;
+            }
+            cv.notify_all();
+        }
+    }
+    void enqueue_feed(std::function<int()> task) {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            feed_queue.push_back(std::move(task));
+        }
+        cv.notify_all();
+    }
+    void wait_fed(int64_t blocks) {         // until that many blocks have been handed to the download stream
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return fed_blocks >= blocks; });
+    }
+    void close_feeder() {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            feed_closing = true;
+        }
+        cv.notify_all();
+        if (feeder.joinable()) feeder.join();
+    }
 
     void run() {
         (void)hipSetDevice(c->device);
@@ -1729,7 +1784,10 @@ struct StreamOut {
         cv.notify_all();
         if (worker.joinable()) worker.join();
     }
-    ~StreamOut() { close(); }
+    ~StreamOut() {
+        close_feeder();
+        close();
+    }
 };
 
 int ensure_download_side(mvs_ctx* c) {
@@ -1739,7 +1797,7 @@ int ensure_download_side(mvs_ctx* c) {
             HIP_TRY(hipEventCreateWithFlags(&c->dl_done[i], hipEventDisableTiming));
             HIP_TRY(hipEventCreateWithFlags(&c->dl_block[i], hipEventDisableTiming));
         }
-        HIP_TRY(hipEventCreateWithFlags(&c->dl_ready, hipEventDisableTiming));
+        for (int i = 0; i < 2; ++i) HIP_TRY(hipEventCreateWithFlags(&c->dl_ready[i], hipEventDisableTiming));
         HIP_TRY(hipStreamCreateWithFlags(&c->post_stream, hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&c->cmp_done, hipEventDisableTiming));
     }
@@ -1778,7 +1836,7 @@ int encode_block(mvs_ctx* c, BlockCsr& b, hipStream_t ps) {
     b.enc_jac.assign((size_t)rows, 0);
     b.enc_first.assign((size_t)rows, 0);
     if (b.n == 0 || rows == 0) {
-        HIP_TRY(hipEventRecord(c->dl_ready, ps));
+        HIP_TRY(hipEventRecord(c->dl_ready[b.set], ps));
         return MVS_OK;
     }
     int rc = ensure_buf(c, &c->en_size, &c->en_size_bytes, (size_t)(rows + 1) * 8);
@@ -1815,7 +1873,7 @@ int encode_block(mvs_ctx* c, BlockCsr& b, hipStream_t ps) {
                             c->opt.encode_stage_words);
     rc = check_kernel("k_enc_fill");
     if (rc) return rc;
-    HIP_TRY(hipEventRecord(c->dl_ready, ps));
+    HIP_TRY(hipEventRecord(c->dl_ready[b.set], ps));
     return MVS_OK;
 }
 
@@ -1838,7 +1896,7 @@ int csr_from_packed(mvs_ctx* c, int64_t rb, int64_t re, int64_t n, int shift, in
     out.set = (int)(block_index & 1);
     out.row_ptr.assign((size_t)rows + 1, 0);
     if (n == 0) {
-        HIP_TRY(hipEventRecord(c->dl_ready, c->stream));
+        HIP_TRY(hipEventRecord(c->dl_ready[out.set], c->stream));
         return MVS_OK;
     }
     int rc = ensure_buf(c, &c->st_rowptr, &c->st_rowptr_bytes, (size_t)(rows + 1) * 8);
@@ -1877,7 +1935,7 @@ int csr_from_packed(mvs_ctx* c, int64_t rb, int64_t re, int64_t n, int shift, in
         if (rc) return rc;
     }
     if (out.row_ptr[(size_t)rows] != n) return fail(MVS_E_HIP, "internal: row index of the sorted cells is inconsistent");
-    HIP_TRY(hipEventRecord(c->dl_ready, c->stream));          // the downloads of this block wait for exactly this point
+    HIP_TRY(hipEventRecord(c->dl_ready[out.set], c->stream));          // the downloads of this block wait for exactly this point
     return MVS_OK;
 }
 
@@ -1921,7 +1979,7 @@ int csr_from_dense(mvs_ctx* c, int64_t rb, int64_t re, int64_t n_cols, int64_t d
                            (uint8_t*)c->st_q[out.set], active);
     rc = check_kernel("k_dense_fill");
     if (rc) return rc;
-    HIP_TRY(hipEventRecord(c->dl_ready, ps));
+    HIP_TRY(hipEventRecord(c->dl_ready[out.set], ps));
     return MVS_OK;
 }
 
@@ -1970,7 +2028,7 @@ int feed_block(mvs_ctx* c, StreamOut& out, const BlockCsr& b, size_t piece_bytes
         it.wide = wide;
         it.row_ptr.resize((size_t)(r1 - r0) + 1);
         for (int64_t r = r0; r <= r1; ++r) it.row_ptr[(size_t)(r - r0)] = row_ptr[(size_t)r] - c0;
-        hipError_t e = hipStreamWaitEvent(c->dl_stream, c->dl_ready, 0);
+        hipError_t e = hipStreamWaitEvent(c->dl_stream, c->dl_ready[b.set], 0);
         char* dst = static_cast<char*>(c->dl_pinned[sl]);
         if (e == hipSuccess && cells > 0) {
             e = hipMemcpyAsync(dst, (const char*)c->st_col[b.set] + (size_t)c0 * 4, (size_t)cells * 4, hipMemcpyDeviceToHost,
@@ -2037,7 +2095,7 @@ int feed_encoded(mvs_ctx* c, StreamOut& out, const BlockCsr& b, size_t piece_byt
                 it.jac_bytes.push_back(b.enc_jac[(size_t)r]);
                 it.offset.push_back(off[(size_t)r] - o0);
             }
-        hipError_t e = hipStreamWaitEvent(c->dl_stream, c->dl_ready, 0);
+        hipError_t e = hipStreamWaitEvent(c->dl_stream, c->dl_ready[b.set], 0);
         if (e == hipSuccess && bytes > 0)
             e = hipMemcpyAsync(c->dl_pinned[sl], (const char*)c->st_enc[b.set] + o0, (size_t)bytes, hipMemcpyDeviceToHost, c->dl_stream);
         if (e == hipSuccess) e = hipEventRecord(c->dl_done[sl], c->dl_stream);
@@ -2153,14 +2211,46 @@ int pairwise_stream_impl(mvs_ctx* c, const mvs_sketch_set* s, const double* norm
     bool side = false;
     auto prepare = [&](BlockCsr& blk) -> int { return ecb ? encode_block(c, blk, ps) : MVS_OK; };
     auto deliver = [&](BlockCsr& blk) -> int {
-        return ecb ? feed_encoded(c, out, blk, piece_bytes) : feed_block(c, out, blk, piece_bytes);
+        auto sp = std::make_shared<BlockCsr>(std::move(blk));
+        const bool enc = ecb != nullptr;
+        StreamOut* o = &out;
+        out.enqueue_feed([c, o, sp, enc, piece_bytes]() -> int {
+            return enc ? feed_encoded(c, *o, *sp, piece_bytes) : feed_block(c, *o, *sp, piece_bytes);
+        });
+        return MVS_OK;
+    };
+    // the arrays of block k live in set k & 1: before block k is built the feeder must be through with block k - 2
+    auto wait_for_set = [&](int64_t k) {
+        if (k >= 2) out.wait_fed(k - 1);
     };
     out.worker = std::thread([&out] { out.run(); });
+    out.feeder = std::thread([&out] { out.feed_run(); });
     int64_t total = 0;
+    // option stream_trace: where the host is when (ms since the call started)
+    const auto t_call = std::chrono::steady_clock::now();
+    std::vector<std::pair<std::string, double>> trace;
+    auto mark = [&](const char* what, long k) {
+        if (!c->opt.stream_trace) return;
+        char buf[64];
+        snprintf(buf, sizeof buf, "%s[%ld]", what, k);
+        trace.emplace_back(buf, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count());
+    };
     auto finish = [&](int status) {
-        out.close();                                            // every delivered block has been consumed
+        mark("close", -1);
+        out.close_feeder();                                     // every delivered block has been handed to the link
+        out.close();                                            // ... and consumed
         (void)hipStreamSynchronize(c->dl_stream);
         if (side) (void)hipStreamSynchronize(c->post_stream);
+        mark("done", -1);
+        if (c->opt.stream_trace) {
+            std::string line = "[mvs stream trace]";
+            for (auto& t : trace) {
+                char buf[96];
+                snprintf(buf, sizeof buf, " %s %.2f", t.first.c_str(), t.second);
+                line += buf;
+            }
+            fprintf(stderr, "%s\n", line.c_str());
+        }
         if (n_cells) *n_cells = total;
         if (status != MVS_OK) return status;
         if (!out.error.empty()) return fail(MVS_E_HIP, "%s", out.error.c_str());
@@ -2463,12 +2553,15 @@ int pairwise_stream_impl(mvs_ctx* c, const mvs_sketch_set* s, const double* norm
     // mirror images land in later blocks' rows), so block k is counted / scanned / filled / encoded on a SIDE stream while
     // launch k + 1 already runs on the context's stream -- memory-bound passes beside a matrix-core-bound kernel instead
     // of between two of them.  (stream_dense = 2: everything on the context's stream, one after the other.)
-    side = dense && whole && c->opt.stream_dense == 1 && blocks.size() > 1;
+    side = dense && whole && blocks.size() > 1 &&
+           (c->opt.stream_dense == 3 || (c->opt.stream_dense == 1 && matrix_mode == kNone));
     if (side) ps = c->post_stream;
+    mark("setup", -1);
     if (!blocks.empty()) {
         rc = launch(0, dense);
         if (rc) return finish(rc);
     }
+    mark("launched", 0);
     for (size_t k = 0; k < blocks.size(); ++k) {
         const int64_t rb = blocks[k].first, re = blocks[k].second;
         BlockCsr blk;
@@ -2482,12 +2575,15 @@ int pairwise_stream_impl(mvs_ctx* c, const mvs_sketch_set* s, const double* norm
                 rc = launch(k + 1, true);
                 if (rc) return finish(rc);
                 next_launched = true;
+                mark("launched", (long)k + 1);
             }
         }
+        wait_for_set((int64_t)k);
         if (dense) {
             bool odd = false;
             rc = csr_from_dense(c, rb, re, s->n, whole ? row_begin : rb, ld, (int64_t)k, blk, &odd, ps, active);
             if (rc) return finish(rc);
+            mark("csr", (long)k);
             if (!side) add_kernel_ms();
             if (odd) {
                 if (side) {                 // back to one stream; a launch already queued for block k + 1 is wasted, not wrong
@@ -2528,13 +2624,16 @@ int pairwise_stream_impl(mvs_ctx* c, const mvs_sketch_set* s, const double* norm
         ++c->st_blocks;
         rc = prepare(blk);
         if (rc) return finish(rc);
+        mark("enc", (long)k);
         if (!next_launched && k + 1 < blocks.size() && !out.failed()) {   // the next block computes while this one is fed to the link
             rc = launch(k + 1, dense);
             if (rc) return finish(rc);
             next_launched = true;
+            mark("launched", (long)k + 1);
         }
         rc = deliver(blk);
         if (rc) return finish(rc);
+        mark("fed", (long)k);
         if (out.failed()) break;
         (void)next_launched;
     }

@@ -80,12 +80,12 @@ def run_case(ctx, rng, max_n, decode_limit=150_000, log=None):
     sk, n2, info = make_case(rng, max_n)
     n = info["n"]
     keep = _capi.KEEP_INT32 if rng.random() < 0.75 else _capi.KEEP_INT16
-    filt = int(rng.choice([0, 1, 1, 2]))
+    filt = int(rng.choice([0, 1, 2, 2]))
     rb = 0 if rng.random() < 0.4 else int(rng.integers(0, n))
     re = n if rng.random() < 0.4 else int(rng.integers(rb, n + 1))
     budget = 0 if rng.random() < 0.4 else int(rng.choice([1 << 16, 1 << 20, 4 << 20, 64 << 20]))
     opts = {"pairwise_filter": filt,
-            "stream_dense": int(rng.choice([0, 1, 1, 1, 2])),        # 0 packed list, 1 dense + side stream, 2 dense, one stream
+            "stream_dense": int(rng.choice([0, 1, 1, 2, 3])),        # 0 packed list, 1 dense (stream by flow), 2 one stream, 3 side stream
             "stream_block_rows": int(rng.choice([0, 0, 64, 128, 200, 512])),
             "encode_stage_words": int(rng.choice([64, 64, 64, 8, 1])),
             "pairwise_symmetric": int(rng.random() < 0.85),

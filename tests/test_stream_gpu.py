@@ -118,7 +118,7 @@ def _mixed_density(n_dense, n_sparse, d, seed):
     return np.concatenate([a, b])
 
 
-@pytest.mark.parametrize("mode", ["list", "matrix", "matrix-one-stream", "matrix-one-block", "pipeline", "pipeline-one-stream",
+@pytest.mark.parametrize("mode", ["list", "matrix", "matrix-side-stream", "matrix-one-block", "pipeline", "pipeline-side-stream",
                                   "pipeline-big-blocks"])
 @pytest.mark.parametrize("keep", [_capi.KEEP_INT32, _capi.KEEP_INT16])
 def test_stream_tile_granular_mixed_density(ctx, mode, keep):
@@ -152,8 +152,8 @@ def test_stream_tile_granular_mixed_density(ctx, mode, keep):
         ctx.set_option("stream_list_cells", 1000)
         ctx.set_option("stream_pipeline", 1 if mode.startswith("pipeline") else 0)
         ctx.set_option("stream_block_rows", 0 if mode in ("matrix-one-block", "pipeline-big-blocks") else 256)
-        if mode.endswith("one-stream"):
-            ctx.set_option("stream_dense", 2)
+        if mode.endswith("side-stream"):
+            ctx.set_option("stream_dense", 3)
     pieces = []
     n_s = ctx.pairwise_stream(ss, n2, on_block=lambda b, e, rp, c, qq: pieces.append((b, e, rp, c, qq)) and None, keep_mode=keep)
     st = ctx.stream_stats()
