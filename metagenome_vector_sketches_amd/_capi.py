@@ -665,8 +665,11 @@ class Context:
         if nm != MEM_DEVICE or cm != MEM_DEVICE:
             raise ValueError("norms_sq and cells must be device buffers")
         count = _c.c_int64()
-        _check(self.lib.mvs_search_block(self._h, sset._h, np_, float(jaccard_min), row_begin, row_end, col_begin,
-                                         col_end, cp, cells.shape[0], ctypes.byref(count)))
+        rc = self.lib.mvs_search_block(self._h, sset._h, np_, float(jaccard_min), row_begin, row_end, col_begin,
+                                       col_end, cp, cells.shape[0], ctypes.byref(count))
+        if rc == MVS_E_CAPACITY:       # count = the hits there are: the caller can come back with exactly that room
+            raise MvsError(rc, self.lib.mvs_last_error().decode("utf-8", "replace"), needed=count.value)
+        _check(rc)
         return count.value
 
     def cells_sort(self, cells_in, n, cells_out):

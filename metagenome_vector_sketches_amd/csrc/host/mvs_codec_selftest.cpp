@@ -1,6 +1,7 @@
 // mvs_codec_selftest -- CPU-only round-trip checks of mvs_codec.hpp and of the shard writer/reader in
 // mvs_host.hpp (no device needed).  Exit code 0 = all good.
 #include <random>
+#include <set>
 #include <sstream>
 
 #include "mvs_host.hpp"
@@ -267,6 +268,35 @@ int main(int argc, char* argv[]) {
         CHECK(!mvs_host::load_csr_cache(p, hs2));
         std::remove(mvs_host::csr_cache_path(p).c_str());
         std::remove(p.c_str());
+    }
+    // long lines: strictly increasing text skips the sort, shuffled / duplicated text goes through the radix sort -- the
+    // same sorted unique values either way (std::set as the referee); digit strings of 19, 20 and 21 digits around 2^64
+    {
+        std::mt19937_64 rng(11);
+        for (int round = 0; round < 6; ++round) {
+            const size_t n = round < 2 ? 300 : 20000;                     // below / above the radix sort's threshold
+            std::vector<uint64_t> v(n);
+            for (auto& x : v) x = round % 3 == 0 ? rng() : round % 3 == 1 ? rng() % 18446744073709552ULL : rng() % 5000;
+            std::set<uint64_t> want(v.begin(), v.end());
+            for (int order = 0; order < 3; ++order) {
+                std::vector<uint64_t> t(v);
+                if (order == 0) t.assign(want.begin(), want.end());      // increasing: the fast path
+                if (order == 2) t.insert(t.end(), v.begin(), v.begin() + (long)(n / 10));   // duplicates
+                std::string line;
+                for (uint64_t x : t) line += " " + std::to_string(x);
+                std::vector<uint64_t> got;
+                mvs_host::parse_u64_tokens(line.data(), line.data() + line.size(), got);
+                CHECK(got.size() == want.size() && std::equal(got.begin(), got.end(), want.begin()));
+            }
+        }
+        const std::string edge = "9999999999999999999 18446744073709551615 09999999999999999999 18446744073709551616 5";
+        std::vector<uint64_t> got;
+        mvs_host::parse_u64_tokens(edge.data(), edge.data() + edge.size(), got);
+        CHECK(got.size() == 2 && got[0] == 9999999999999999999ULL && got[1] == 18446744073709551615ULL);   // stops at 2^64
+        const std::string lead = "000000000000000000000000000000007 00000000000000000000018446744073709551615 3";
+        got.clear();
+        mvs_host::parse_u64_tokens(lead.data(), lead.data() + lead.size(), got);
+        CHECK(got.size() == 3 && got[0] == 3 && got[1] == 7 && got[2] == 18446744073709551615ULL);         // leading zeros
     }
     CHECK(mvs_host::format_g(56.46254) == "56.4625" && mvs_host::format_g(1234567.0) == "1.23457e+06");
     CHECK(mvs_host::format_g_float(-3.0f) == "-3" && mvs_host::format_g(0.0) == "0");

@@ -6,6 +6,7 @@
 #define MVS_HOST_HPP
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -83,11 +84,64 @@ struct HashSets {
     std::vector<int64_t> offsets;    // names.size() + 1
 };
 
+// Sort + unique of one sample's hashes when the text did not have them in strictly increasing order (the reference's
+// `convert` writes an unordered_set's iteration order, src/project_everything.cpp:222-228).  The projection needs the
+// set, not an order; sorted unique values are what the .csr cache is defined to hold, so the order is kept -- with an LSD
+// radix sort on 11-bit digits over the bits that are actually set (FracMinHash values are < 2^64 / scaled: 5 passes),
+// ~10 ns per value where std::sort takes 60 (that sort was 70 % of the first `sketch` run's parse stage).
+inline void sort_unique_u64(std::vector<uint64_t>& v) {
+    const size_t n = v.size();
+    if (n < 256) {
+        std::sort(v.begin(), v.end());
+    } else {
+        uint64_t any = 0;
+        for (uint64_t x : v) any |= x;
+        int bits = 0;
+        while (bits < 64 && (any >> bits) != 0) ++bits;
+        const int passes = std::max(1, (bits + 10) / 11);
+        static thread_local std::vector<uint64_t> tmp;
+        static thread_local std::vector<uint32_t> hist;
+        tmp.resize(n);
+        hist.assign((size_t)passes * 2048, 0);
+        for (uint64_t x : v)
+            for (int ps = 0; ps < passes; ++ps) ++hist[(size_t)ps * 2048 + ((x >> (11 * ps)) & 2047)];
+        uint64_t* src = v.data();
+        uint64_t* dst = tmp.data();
+        for (int ps = 0; ps < passes; ++ps) {
+            uint32_t* h = hist.data() + (size_t)ps * 2048;
+            uint32_t run = 0;
+            bool one_bucket = false;
+            for (int b = 0; b < 2048; ++b) {
+                const uint32_t c = h[b];
+                one_bucket = one_bucket || c == n;
+                h[b] = run;
+                run += c;
+            }
+            if (one_bucket) continue;                          // every value has the same digit here: nothing moves
+            const int sh = 11 * ps;
+            for (size_t i = 0; i < n; ++i) dst[h[(src[i] >> sh) & 2047]++] = src[i];
+            std::swap(src, dst);
+        }
+        if (src != v.data()) memcpy(v.data(), src, n * sizeof(uint64_t));
+    }
+    v.erase(std::unique(v.begin(), v.end()), v.end());
+}
+
 // Parse whitespace separated unsigned 64-bit integers the way `while (iss >> hash)` does
 // (src/project_everything.cpp:275-279, src/standalone_projection.cpp:32-35): stop at the first token
-// that is not a number in range.  The reference collects them in an unordered_set; sort + unique gives
-// the same set.
+// that is not a number in range.  The reference collects them in an unordered_set; the sorted unique values are
+// the same set.  A line whose values are strictly increasing -- what this repository's `convert` writes -- is
+// unique and sorted as it stands and skips the sort.
 inline void parse_u64_tokens(const char* p, const char* end, std::vector<uint64_t>& out) {
+    out.reserve(out.size() + (size_t)(end - p) / 16 + 4);
+    bool increasing = true, have_prev = false;
+    uint64_t prev = 0;
+    auto push = [&](uint64_t v) {
+        increasing = increasing && (!have_prev || v > prev);
+        prev = v;
+        have_prev = true;
+        out.push_back(v);
+    };
     while (true) {
         while (p < end && (*p == ' ' || *p == '\t' || *p == '\r' || *p == '\v' || *p == '\f')) ++p;
         if (p >= end) break;
@@ -95,24 +149,28 @@ inline void parse_u64_tokens(const char* p, const char* end, std::vector<uint64_
         const bool negate = *p == '-';
         if (*p == '+' || *p == '-') ++p;
         if (p >= end || *p < '0' || *p > '9') break;
+        // up to 19 digits cannot overflow (10^19 < 2^64): only a 20th digit needs the check
         uint64_t v = 0;
         bool overflow = false;
-        while (p < end && *p >= '0' && *p <= '9') {
-            const uint64_t dgt = (uint64_t)(*p - '0');
+        const char* q = p;
+        const char* lim = end - p > 19 ? p + 19 : end;
+        while (q < lim && (unsigned)(*q - '0') <= 9u) v = v * 10 + (uint64_t)(*q++ - '0');
+        while (q < end && (unsigned)(*q - '0') <= 9u) {
+            const uint64_t dgt = (uint64_t)(*q - '0');
             if (v > (UINT64_MAX - dgt) / 10) overflow = true;
             v = v * 10 + dgt;
-            ++p;
+            ++q;
         }
+        p = q;
         if (overflow) break;                                   // failbit in the reference
         if (negate) v = 0 - v;
         if (p < end && !(*p == ' ' || *p == '\t' || *p == '\r' || *p == '\v' || *p == '\f')) {
-            out.push_back(v);                                  // "12abc": 12 is extracted, then the stream fails
+            push(v);                                           // "12abc": 12 is extracted, then the stream fails
             break;
         }
-        out.push_back(v);
+        push(v);
     }
-    std::sort(out.begin(), out.end());
-    out.erase(std::unique(out.begin(), out.end()), out.end());
+    if (!increasing) sort_unique_u64(out);
 }
 
 // One record per line.  with_names: "name: h1 h2 ..." (lines without ':' are skipped,
@@ -252,8 +310,10 @@ inline bool text_identity(const std::string& path, uint64_t& size, int64_t& mtim
     return true;
 }
 
-// best effort: a cache that cannot be written is simply not there next time
-inline bool write_csr_cache(const std::string& hash_file, const HashSets& sets) {
+// best effort: a cache that cannot be written is simply not there next time.  The values (gigabytes: 4 GB for 10k samples
+// of 50k hashes) are written by several threads at their offsets -- the copy into the page cache is what takes the time
+// and one thread moves ~2-5 GB/s; callers that have better things to do run this on a thread of its own.
+inline bool write_csr_cache(const std::string& hash_file, const HashSets& sets, unsigned threads = 0) {
     CsrHeader h{};
     memcpy(h.magic, "MVSCSR01", 8);
     if (!text_identity(hash_file, h.text_size, h.text_mtime_ns)) return false;
@@ -264,18 +324,48 @@ inline bool write_csr_cache(const std::string& hash_file, const HashSets& sets) 
     for (size_t i = 0; i < sets.names.size(); ++i) ends[i] = at += sets.names[i].size();
     h.name_bytes = at;
     const std::string path = csr_cache_path(hash_file), tmp = path + ".part";
-    FILE* f = fopen(tmp.c_str(), "wb");
-    if (!f) return false;
-    bool ok = fwrite(&h, sizeof h, 1, f) == 1;
-    ok = ok && fwrite(sets.offsets.data(), 8, sets.offsets.size(), f) == sets.offsets.size();
-    ok = ok && (ends.empty() || fwrite(ends.data(), 8, ends.size(), f) == ends.size());
-    for (size_t i = 0; ok && i < sets.names.size(); ++i)
-        ok = sets.names[i].empty() || fwrite(sets.names[i].data(), 1, sets.names[i].size(), f) == sets.names[i].size();
-    const char zeros[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (ok && at % 8) ok = fwrite(zeros, 1, 8 - at % 8, f) == 8 - at % 8;
-    ok = ok && (h.values == 0 || fwrite(sets.hashes.data(), 8, h.values, f) == h.values);
-    ok = (fclose(f) == 0) && ok;
-    if (!ok || rename(tmp.c_str(), path.c_str()) != 0) {
+    // head: header, offsets, name ends, names, padding to 8
+    std::string head;
+    head.reserve(sizeof h + sets.offsets.size() * 8 + ends.size() * 8 + (size_t)at + 8);
+    head.append(reinterpret_cast<const char*>(&h), sizeof h);
+    head.append(reinterpret_cast<const char*>(sets.offsets.data()), sets.offsets.size() * 8);
+    head.append(reinterpret_cast<const char*>(ends.data()), ends.size() * 8);
+    for (const std::string& nm : sets.names) head.append(nm);
+    if (at % 8) head.append(8 - at % 8, '\0');
+    const int fd = ::open(tmp.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    if (fd < 0) return false;
+    auto write_at = [fd](const char* p, size_t n, uint64_t off) {
+        while (n) {
+            const ssize_t w = ::pwrite(fd, p, std::min<size_t>(n, (size_t)1 << 30), (off_t)off);
+            if (w <= 0) return false;
+            p += w;
+            n -= (size_t)w;
+            off += (uint64_t)w;
+        }
+        return true;
+    };
+    std::atomic<bool> ok{write_at(head.data(), head.size(), 0)};
+    const size_t value_bytes = (size_t)h.values * 8;
+    if (ok && value_bytes) {
+        if (threads == 0) threads = std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
+        const size_t chunk = (size_t)64 << 20;
+        const size_t n_chunks = (value_bytes + chunk - 1) / chunk;
+        threads = (unsigned)std::min<size_t>(threads, n_chunks);
+        std::atomic<size_t> next{0};
+        const char* base = reinterpret_cast<const char*>(sets.hashes.data());
+        auto work = [&]() {
+            for (size_t i = next++; i < n_chunks && ok; i = next++) {
+                const size_t o = i * chunk, n = std::min(chunk, value_bytes - o);
+                if (!write_at(base + o, n, head.size() + o)) ok = false;
+            }
+        };
+        std::vector<std::thread> pool;
+        for (unsigned t = 1; t < threads; ++t) pool.emplace_back(work);
+        work();
+        for (auto& th : pool) th.join();
+    }
+    const bool closed = ::close(fd) == 0;
+    if (!ok || !closed || rename(tmp.c_str(), path.c_str()) != 0) {
         ::unlink(tmp.c_str());
         return false;
     }

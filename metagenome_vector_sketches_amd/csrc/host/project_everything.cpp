@@ -170,6 +170,10 @@ static int sketch(const std::string& hash_file, std::string index_folder, int di
     });
     // the parsed form of an unchanged hash file is kept next to it (<hash_file>.csr): mapped instead of parsed again
     HashSets sets;
+    struct Joiner {                       // declared after `sets`: joined before `sets` goes away
+        std::thread th;
+        ~Joiner() { if (th.joinable()) th.join(); }
+    } cache_writer;
     bool parsed = load_csr_cache(hash_file, sets);
     if (parsed && sets.hashes.size() > (1u << 24)) {
         // page the mapping in on all host threads now (the context needs ~0.1 s anyway) instead of one fault at a
@@ -196,7 +200,9 @@ static int sketch(const std::string& hash_file, std::string index_folder, int di
             destroy_all();
             return 2;
         }
-        if (parsed && !getenv("MVS_NO_CSR_CACHE")) (void)write_csr_cache(hash_file, sets);
+        // the parsed form goes to <hash_file>.csr beside the projection (4 GB for 10k x 50k hashes: the copy into the page
+        // cache would otherwise be a third of a first run); `sets` outlives the thread, which is joined on every way out
+        if (parsed && !getenv("MVS_NO_CSR_CACHE")) cache_writer.th = std::thread([&]() { (void)write_csr_cache(hash_file, sets); });
     }
     ctx_thread.join();
     if (!parsed) {                                                                                     // :258-262

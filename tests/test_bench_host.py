@@ -82,3 +82,41 @@ def test_bench_parent_does_not_import_torch_before_launching(tmp_path):
     assert launch_line < torch_line
     top = [a.name for n in tree.body if isinstance(n, (ast.Import, ast.ImportFrom)) for a in n.names]
     assert not any(x.startswith("torch") or x.startswith("metagenome") for x in top)
+
+
+def test_search_front_end_takes_the_references_command_lines():
+    """src/jaccard.py:334-346: `index <folder> [-t N]`, `search <index_folder> <query_file> [-j J] [-t N]`, `-v` -- the two
+    command lines of the reference's README run unchanged against metagenome_vector_sketches_amd.search (parser only: no GPU)"""
+    from metagenome_vector_sketches_amd import search
+    p = search.build_parser()
+    a = p.parse_args("index toy_db -t 8".split())                  # README: python3 ../src/jaccard.py index toy_db -t 8
+    assert (a.command, a.output_index, a.threads, a.version) == ("index", "toy_db", 8, False)
+    a = p.parse_args("search toy_db queries.txt -j 0.2 -t 4".split())
+    assert (a.command, a.index_folder, a.query_file, a.j, a.threads) == ("search", "toy_db", "queries.txt", 0.2, 4)
+    assert p.parse_args("search db q".split()).j == 0.1            # the reference's default
+    assert p.parse_args("-v index x".split()).version is True
+    import pytest
+    for bad in ([], ["frobnicate"], ["search", "only_one"], ["index"]):
+        with pytest.raises(SystemExit):
+            p.parse_args(bad)
+
+
+def test_search_index_subcommand_checks_the_folder(tmp_path, capsys):
+    """`index` builds nothing (the search runs on vectors.bin) but validates the folder and prints the reference's line"""
+    import numpy as np
+    from metagenome_vector_sketches_amd import search
+    d = tmp_path / "db"
+    d.mkdir()
+    np.arange(3 * 8, dtype="<i4").tofile(d / "vectors.bin")
+    (d / "dimension.txt").write_text("8\n")
+    (d / "vector_norms.txt").write_text("a 1\nb 2\nc 3\n")
+    (d / "dtype.txt").write_text("int32\n")
+    assert search.main(["index", str(d), "-t", "8"]) == 0
+    out = capsys.readouterr().out
+    assert "Indexed 3 vectors of dimension 8 into " in out and out.startswith("Version: ")
+    assert sorted(p.name for p in d.iterdir()) == ["dimension.txt", "dtype.txt", "vector_norms.txt", "vectors.bin"]   # nothing deleted
+    (d / "vector_norms.txt").write_text("a 1\nb 2\n")
+    import pytest
+    with pytest.raises(ValueError):
+        search.main(["index", str(d)])
+    assert search.main(["-v", "index", str(d)]) == 0 and capsys.readouterr().out.startswith("Version: ")

@@ -100,3 +100,35 @@ def test_search_larger_db(ctx, tmp_path, case):
     assert all(abs(gj[(a, b)] - c) <= 1e-5 * abs(c) for a, b, c in want)
     if case != "three-limbs":                                   # (scaled vectors are no projections of anything)
         assert [b for a, b, _ in got if a == 0][0] == "s5" and [b for a, b, _ in got if a == 1][0] == "s777"
+
+
+def test_search_command_line_resident_index_and_small_hit_buffer(ctx, gold, tmp_path, capsys):
+    """the reference's command line (src/jaccard.py:334-362: `search <index_folder> <query_file> -j J -t N`) end to end,
+    a resident SearchIndex queried in chunks of two queries, and a hit buffer that is too small: the library reports how
+    many hits there are and the block is compared once more with exactly that room -- the same neighbours every way"""
+    import torch
+    from metagenome_vector_sketches_amd import search
+    db = str(tmp_path / "db") + "/"
+    _write_db(db, gold)
+    picks = [gold.names.index("DRR000821"), 6, 10, 20, 33]
+    qf = tmp_path / "queries.txt"
+    with open(qf, "w") as f:
+        for k, i in enumerate(picks):
+            f.write("q%d:" % k + "".join(" %d" % int(x) for x in gold.hashes[gold.offsets[i]:gold.offsets[i + 1]]) + "\n")
+    want = search.search_index(db, str(qf), 0.1, ctx=ctx, verbose=False)
+    assert {a for a, _, _ in want} == set(range(5)) and len(want) > 20
+    assert search.main(["search", db.rstrip("/"), str(qf), "-j", "0.1", "-t", "4"]) == 0
+    out = capsys.readouterr().out.split("\n")
+    assert out[0].startswith("Version: ") and out[1].startswith("Command line:") and "Query 0:" in out
+    first = out[out.index("Query 0:") + 1]
+    assert first.startswith("  Neighbor 0: DRR000821 (jaccard: 1.0000), inner_product: 1.0000 ")
+    assert sum(l.startswith("  Neighbor ") for l in out) == len(want)
+    with search.SearchIndex(db, ctx=ctx, max_queries=2) as idx:
+        assert idx.search(str(qf), 0.1, verbose=False) == want          # three chunks: 2 + 2 + 1 queries
+        idx._hits = torch.empty((4, 4), dtype=torch.int32, device="cuda")
+        assert idx.search(str(qf), 0.1, verbose=False) == want          # too small -> sized from the reported count
+        assert idx._hits.shape[0] > 4
+    # a malformed query line ends the run with the reference's code 332 (:82-84)
+    bad = tmp_path / "bad.txt"
+    bad.write_text("a: 1 2 : 3\n")
+    assert search.main(["search", db, str(bad)]) == 332
