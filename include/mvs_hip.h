@@ -405,6 +405,11 @@ int mvs_comm_create_files(mvs_ctx* ctx, const char* path_prefix, int rank, int w
 int mvs_comm_create_rendezvous(mvs_ctx* ctx, const char* path_prefix, int rank, int world, mvs_comm** comm);
 int mvs_comm_destroy(mvs_comm* comm);
 int mvs_comm_info(const mvs_comm* comm, int* rank, int* world, int* is_rccl);
+/* Which RCCL the library bound at run time: the path of the shared object its collectives come from (dladdr; in a process
+ * that already carries a copy -- PyTorch ships one -- the loader hands back that copy) and ncclGetVersion's number
+ * (e.g. 22105).  Binds the library if that has not happened yet; MVS_E_HIP when no librccl can be loaded.  A measurement
+ * that claims "RCCL over xGMI" should say which RCCL. */
+int mvs_comm_library(char* path, size_t path_len, int* version);
 /* planes: the global plane buffer (mvs_limb_geometry of rows_per_rank * world rows); rank r has filled rows
  * [r * rows_per_rank, (r+1) * rows_per_rank).  After the call (on the stream) every block is present. */
 int mvs_allgather_planes(mvs_ctx* ctx, mvs_comm* comm, int8_t* planes, int64_t rows_per_rank, int limbs, int d_pad);

@@ -59,6 +59,7 @@ SYMBOLS = [
     ("mvs_ctx_set_timing", _c.c_int, [_P, _c.c_int]),
     ("mvs_ctx_kernel_ms", _c.c_int, [_P, _c.c_int, _c.POINTER(_c.c_float)]),
     ("mvs_ctx_pairwise_candidates", _c.c_int, [_P, _c.POINTER(_c.c_int64)]),
+    ("mvs_comm_library", _c.c_int, [_c.c_char_p, _c.c_size_t, _c.POINTER(_c.c_int)]),
     ("mvs_ctx_pairwise_stats", _c.c_int, [_P, _c.POINTER(_c.c_int64), _c.POINTER(_c.c_int64), _c.POINTER(_c.c_int64)]),
     ("mvs_project_csr", _c.c_int, [_P, _P, _c.c_int, _P, _c.c_int64, _c.c_int, _P, _c.c_int]),
     ("mvs_project_csr_stats", _c.c_int, [_P, _P, _c.c_int, _P, _c.c_int64, _c.c_int, _P, _c.c_int, _P,
@@ -264,6 +265,15 @@ class Comm:
             self.close()
         except Exception:
             pass
+
+
+def comm_library():
+    """(path, version) of the RCCL the library's communicators use -- bound at run time; raises MvsError without one"""
+    lib = load_library()
+    buf = ctypes.create_string_buffer(4096)
+    ver = _c.c_int()
+    _check(lib.mvs_comm_library(buf, len(buf), ctypes.byref(ver)))
+    return buf.value.decode("utf-8", "replace"), ver.value
 
 
 def comm_unique_id():

@@ -48,6 +48,9 @@ struct Rccl {
     int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
     int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
+    int (*GetVersion)(int*) = nullptr;
+    std::string path;                // file the symbols came from (dladdr), "" if the loader would not say
+    int version = 0;                 // ncclGetVersion
     std::string error;
 };
 
@@ -75,6 +78,11 @@ Rccl& rccl() {
         r.AllGather = reinterpret_cast<decltype(r.AllGather)>(sym("ncclAllGather"));
         r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(sym("ncclAllReduce"));
         r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+        // which copy did the loader hand back?  (a process that carries PyTorch has its bundled librccl mapped already)
+        r.GetVersion = reinterpret_cast<decltype(r.GetVersion)>(dlsym(r.handle, "ncclGetVersion"));
+        Dl_info info{};
+        if (r.AllGather && dladdr(reinterpret_cast<void*>(r.AllGather), &info) && info.dli_fname) r.path = info.dli_fname;
+        if (r.GetVersion) (void)r.GetVersion(&r.version);
     });
     return r;
 }
@@ -459,6 +467,18 @@ int mvs_comm_destroy(mvs_comm* m) {
         remove_own_files(m->prefix, m->rank);
     }
     delete m;
+    return MVS_OK;
+}
+
+int mvs_comm_library(char* path, size_t path_len, int* version) {
+    Rccl& r = rccl();
+    if (!r.error.empty()) return mvs::capi_fail(MVS_E_HIP, "%s", r.error.c_str());
+    if (path && path_len) {
+        const size_t n = std::min(path_len - 1, r.path.size());
+        memcpy(path, r.path.data(), n);
+        path[n] = 0;
+    }
+    if (version) *version = r.version;
     return MVS_OK;
 }
 
