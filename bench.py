@@ -223,6 +223,11 @@ def main():
     ap.add_argument("--overlap-parts", type=int, default=2,
                     help="N > 1: pieces the rank's samples are projected in; the all-gather of a finished piece's limb "
                          "planes runs beside the projection of the next (1: no overlap)")
+    ap.add_argument("--allow-torch-collectives", action="store_true",
+                    help="N > 1: if the library's own RCCL communicator cannot be created, let torch.distributed's collectives "
+                         "carry the exchange (the line then says so) instead of exiting non-zero.  Without this flag a "
+                         "multi-GPU line is always a measurement of the library's communicator (mvs_comm); rehearsals "
+                         "(MVS_BENCH_REHEARSAL=1: all ranks on one card, file transport) do not need it")
     ap.add_argument("--host-input", action="store_true",
                     help="also time the step with the hash lists handed over as host buffers (PCIe inclusive; "
                          "reported as pcie_inclusive, never as value)")
@@ -292,13 +297,22 @@ def main():
                 dist.broadcast(uid, src=0)
                 comm = ctx_comm.comm_rccl(bytes(uid.cpu().numpy().tobytes()), rank, world)
             coll = parallel.NativeCollectives(comm, stream=side)
-        except Exception as e:      # noqa: BLE001 -- any failure here must not take the benchmark down
-            coll_note = "native communicator failed (%s: %s); torch.distributed carries the exchange" % (type(e).__name__, e)
-            coll = parallel.TorchCollectives(dist, rank, world, stream=side)
-        ok = torch.tensor([1 if isinstance(coll, parallel.NativeCollectives) else 0], device=dev)
+        except Exception as e:      # noqa: BLE001 -- reported below: every rank must reach the agreement first
+            coll_note = "native communicator failed (%s: %s)" % (type(e).__name__, e)
+            coll = None
+        ok = torch.tensor([1 if coll is not None else 0], device=dev)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        if int(ok.item()) == 0 and isinstance(coll, parallel.NativeCollectives):   # all ranks use the same transport
-            coll_note = "another rank could not create the native communicator; torch.distributed carries the exchange"
+        if int(ok.item()) == 0:   # all ranks use the same transport
+            if coll is not None:
+                coll.comm.close()
+                coll_note = "another rank could not create the native communicator"
+            if not args.allow_torch_collectives:
+                # a scaling line must not silently measure another communicator: fail, loudly, on every rank
+                print("bench.py rank %d: %s -- not falling back (pass --allow-torch-collectives to measure with "
+                      "torch.distributed's collectives instead)" % (rank, coll_note), file=sys.stderr)
+                dist.destroy_process_group()
+                sys.exit(3)
+            coll_note += "; torch.distributed carries the exchange (--allow-torch-collectives)"
             coll = parallel.TorchCollectives(dist, rank, world, stream=side)
 
     if args.config != 2:
@@ -523,7 +537,14 @@ def comm_facts(coll, world):
     comm = getattr(coll, "comm", None)
     if comm is None:
         return {"rccl_ranks": 0, "comm_world": world if coll is not None else 1}
-    return {"rccl_ranks": comm.world if comm.is_rccl else 0, "comm_world": comm.world, "comm_rank0": comm.rank}
+    facts = {"rccl_ranks": comm.world if comm.is_rccl else 0, "comm_world": comm.world, "comm_rank0": comm.rank}
+    if comm.is_rccl:           # which RCCL: the file the library's dlopen bound (mvs_comm_library) and its version
+        try:
+            from metagenome_vector_sketches_amd import _capi
+            facts["rccl_library"], facts["rccl_version"] = _capi.comm_library()
+        except Exception as e:      # noqa: BLE001
+            facts["rccl_library"] = "unknown (%s)" % e
+    return facts
 
 
 def strong_scaling(args, ctx, dev, rank, world, dist, coll, coll_note):

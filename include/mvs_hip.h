@@ -403,6 +403,10 @@ int mvs_comm_create_files(mvs_ctx* ctx, const char* path_prefix, int rank, int w
  * removed again, then mvs_comm_create.  Replaces "rank 0 leaves the id in a file": a file a previous job left behind
  * can no longer be taken for this job's id. */
 int mvs_comm_create_rendezvous(mvs_ctx* ctx, const char* path_prefix, int rank, int world, mvs_comm** comm);
+/* Collective semantics of the file transport (mvs_comm_create_files / _rendezvous): creation is a blocking handshake --
+ * every rank must be inside its create call at the same time (ranks created one after the other from ONE thread would
+ * wait for each other until comm_timeout_s); destruction is local once the communicator has carried at least one exchange,
+ * otherwise it waits up to 10 s for the peers so that nobody is left polling for this rank's handshake files. */
 int mvs_comm_destroy(mvs_comm* comm);
 int mvs_comm_info(const mvs_comm* comm, int* rank, int* world, int* is_rccl);
 /* Which RCCL the library bound at run time: the path of the shared object its collectives come from (dladdr; in a process

@@ -216,6 +216,26 @@ int main(int argc, char* argv[]) {
             CHECK(ss.jac_space == s1.jac_space && ss.ngh_space == s1.ngh_space && ss.rows == s1.rows && w.cells() == cells.size());
             for (const char* f : {"matrix.bin", "row_index.bin", "neighbor_start.bin"})
                 CHECK(slurp(dir + "one/" + f) == slurp(dir + "stream/" + f));
+            // a writer that never reaches finish() (the comparison failed half way) leaves the shard that was there
+            // untouched and nothing half-written behind
+            {
+                mvs_host::ShardWriter w2(dir + "stream/", 2);
+                const int64_t rp2[2] = {0, 1};
+                const int32_t col2[1] = {0};
+                const uint8_t q2[1] = {255};
+                mvs_row_block b2{};
+                b2.row_begin = 0;
+                b2.row_end = 1;
+                b2.n_cells = 1;
+                b2.row_ptr = rp2;
+                b2.col = col2;
+                b2.q = q2;
+                w2.add(b2);
+            }
+            for (const char* f : {"matrix.bin", "row_index.bin", "neighbor_start.bin"}) {
+                CHECK(slurp(dir + "one/" + f) == slurp(dir + "stream/" + f));
+                CHECK(!std::filesystem::exists(dir + "stream/" + f + ".part"));
+            }
         }
     }
     std::filesystem::remove_all(dir);

@@ -594,14 +594,37 @@ inline ShardStats write_shard(const std::string& folder, const mvs_cell* cells, 
 // neighbor_start.bin.  The files are byte for byte what write_shard() writes for the same cells.
 class ShardWriter {
 public:
+    // The three files are written under ".part" names and renamed in finish(): a comparison that fails half way (out of
+    // memory, a device error, an aborted callback) leaves a shard that was there before untouched, as the reference does --
+    // it only opens its output once all results exist (src/pairwise_comp_optimized.cpp:645-817 runs after the tile loop).
     explicit ShardWriter(const std::string& folder, unsigned threads = 0) : folder_(folder), threads_(threads) {
         if (!fs::exists(folder_)) fs::create_directories(folder_);
-        bin_fd_ = ::open((folder_ + "matrix.bin").c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
-        if (bin_fd_ < 0) throw std::runtime_error("ShardWriter: cannot create " + folder_ + "matrix.bin");
+        bin_fd_ = ::open((folder_ + "matrix.bin.part").c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+        if (bin_fd_ < 0) throw std::runtime_error("ShardWriter: cannot create " + folder_ + "matrix.bin.part");
         if (threads_ == 0) threads_ = std::max(1u, std::thread::hardware_concurrency());
         // matrix.bin is written by a few threads of its own (pwrite at the position every run of bytes is known to have):
         // the encoded rows of a piece go to the file while the next piece is being encoded or downloaded, and one thread
         // copying into the page cache would be what bounds a dense shard (1.4 GB at ~3 GB/s)
+        try {
+            spawn_file_threads();
+        } catch (...) {                    // a thread that could not start: the ones that did must not outlive the object
+            stop_file_threads();
+            ::close(bin_fd_);
+            ::unlink((folder_ + "matrix.bin.part").c_str());
+            throw;
+        }
+    }
+    ShardWriter(const ShardWriter&) = delete;
+    ShardWriter& operator=(const ShardWriter&) = delete;
+    ~ShardWriter() {
+        stop_file_threads();
+        if (bin_fd_ >= 0) ::close(bin_fd_);
+        if (!finished_)                    // finish() did not complete: nothing half-written stays behind
+            for (const char* f : {"matrix.bin.part", "row_index.bin.part", "neighbor_start.bin.part"}) ::unlink((folder_ + f).c_str());
+    }
+
+private:
+    void spawn_file_threads() {
         for (int t = 0; t < 4; ++t)
             file_threads_.emplace_back([this] {
                 for (;;) {
@@ -627,13 +650,8 @@ public:
                 }
             });
     }
-    ShardWriter(const ShardWriter&) = delete;
-    ShardWriter& operator=(const ShardWriter&) = delete;
-    ~ShardWriter() {
-        stop_file_threads();
-        if (bin_fd_ >= 0) ::close(bin_fd_);
-    }
 
+public:
     void add(const mvs_row_block& b) {
         const int64_t rows = b.row_end - b.row_begin;
         if (rows < 0 || b.row_begin < next_row_) throw std::runtime_error("ShardWriter: pieces must come in ascending row order");
@@ -766,7 +784,7 @@ public:
         if (bin_fd_ >= 0) ::close(bin_fd_);
         bin_fd_ = -1;
         if (write_failed_) throw std::runtime_error("ShardWriter: writing " + folder_ + "matrix.bin failed");
-        std::ofstream index_out(folder_ + "row_index.bin", std::ios::binary);
+        std::ofstream index_out(folder_ + "row_index.bin.part", std::ios::binary);
         stats_.rows = row_vec_.size();
         mvs_codec::compact_vector cv_rows;                          // row ids, then byte-offset deltas (:769-783)
         cv_rows.build(row_vec_.begin(), row_vec_.size());
@@ -777,11 +795,17 @@ public:
         cv_cps.build(pos_delta.begin(), pos_delta.size());
         cv_cps.save(index_out);
         index_out.close();
-        std::ofstream ngh_out(folder_ + "neighbor_start.bin", std::ios::binary);
+        std::ofstream ngh_out(folder_ + "neighbor_start.bin.part", std::ios::binary);
         mvs_codec::rice_sequence rs_start;
         rs_start.encode(start_neighbor_.begin(), start_neighbor_.size());
         rs_start.save(ngh_out);
+        ngh_out.close();
+        if (!index_out || !ngh_out) throw std::runtime_error("ShardWriter: writing the index files of " + folder_ + " failed");
         stats_.ngh_space += rs_start.num_bytes();
+        for (const char* f : {"matrix.bin", "row_index.bin", "neighbor_start.bin"})
+            if (::rename((folder_ + f + ".part").c_str(), (folder_ + f).c_str()) != 0)
+                throw std::runtime_error("ShardWriter: cannot rename " + folder_ + f + ".part");
+        finished_ = true;
         return stats_;
     }
 
@@ -815,7 +839,7 @@ private:
     std::mutex mu_;
     std::condition_variable cv_;
     std::deque<Job> pending_;
-    bool closing_ = false, write_failed_ = false;
+    bool closing_ = false, write_failed_ = false, finished_ = false;
     uint64_t pos_ = 0, cells_ = 0;
     int64_t next_row_ = 0;
     std::vector<uint32_t> row_vec_, start_neighbor_;

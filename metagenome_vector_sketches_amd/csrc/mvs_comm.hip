@@ -93,6 +93,7 @@ struct mvs_comm {
     mvs_ctx* ctx = nullptr;
     int rank = 0, world = 1;
     void* nccl = nullptr;            // ncclComm_t, or NULL for a callback communicator
+    long long exchanges_done = 0;    // file transport: exchanges that completed (every peer read this rank's block)
     mvs_comm_callbacks cb{};         // used when nccl == NULL
     // file transport (mvs_comm_create_files): exchange through <prefix>_<seq>_<rank> files
     std::string prefix;
@@ -289,6 +290,7 @@ int files_exchange(mvs_comm* m, const void* mine, size_t bytes, char* all, doubl
         ::unlink(ack.c_str());
     }
     ::unlink(own.c_str());                 // on the error paths too: nothing of this rank stays behind
+    if (!rc) ++m->exchanges_done;
     return rc;
 }
 
@@ -457,9 +459,12 @@ int mvs_comm_destroy(mvs_comm* m) {
         (void)hipFree(m->pack);
     }
     if (!m->prefix.empty()) {
-        // a last (empty) exchange: once it is through every rank has finished the handshake and read every block, so
-        // the hello / ready files can go; a peer that died does not hold this rank for more than a few seconds
-        if (m->world > 1) {
+        // The hello / ready files may go once every peer is past the creation handshake, and every block of this rank
+        // has been read when its exchange returned (files_exchange waits for the acknowledgements).  A completed exchange
+        // proves the former -- nobody can send a block before the handshake is through -- so only a communicator that
+        // never exchanged anything needs a last (empty) exchange here; shard processes that finish minutes apart
+        // (pairwise_comp_optimized with MVS_COLLECTIVE=files) no longer wait for each other at exit.
+        if (m->world > 1 && m->exchanges_done == 0) {
             char none = 0;
             std::vector<char> all((size_t)m->world);
             (void)files_exchange(m, &none, 0, all.data(), m->timeout_s < 10.0 ? m->timeout_s : 10.0);

@@ -2418,7 +2418,10 @@ int64_t filter_region_count(const PairwiseArgs& a, const Options& opt) {
     const int64_t rows = a.row_end - a.row_begin, cols = a.col_end - a.col_begin;
     if (rows <= 0 || cols <= 0) return 0;
     const int64_t n_tr = (rows + 255) / 256, n_tc = (cols + 255) / 256;
-    return ((n_tr + 15) / 16) * ((n_tc + 15) / 16) * 256 * 8;      // workgroups of the launch x 8 waves
+    const int64_t n = ((n_tr + 15) / 16) * ((n_tc + 15) / 16) * 256 * 8;      // workgroups of the launch x 8 waves
+    // one 64-byte region + header per wave of the padded grid: 68 B x 123 M for a single 1M x 1M block (8 GB, all of it
+    // cleared and scanned per attempt).  Beyond 8 M regions (a 180k x 180k block) the waves append with the atomic.
+    return n <= (8 << 20) ? n : 0;
 }
 
 int launch_cand_gather(hipStream_t stream, const PairwiseArgs& a, int64_t n_regions) {

@@ -379,7 +379,12 @@ class ShardedComparison:
         max_abs = st["max_abs"]
         if world > 1:
             max_abs = self.coll.allreduce_max(max_abs, st["sk"])
-        if self.ops.limbs_for(max_abs) != limbs:
+        need = self.ops.limbs_for(max_abs)
+        # planes coded with MORE base-256 limbs than the data needs are still exact (the high limbs are zero); only a guess
+        # that is too small -- or a guess / need in the three-plane Karatsuba code, which is a different encoding -- forces
+        # the step to be redone (max|v| <= 127 against the guess of two limbs used to redo split and exchange)
+        plain = need <= 4 and limbs <= 4
+        if (need > limbs) if plain else (need != limbs):
             # the guess does not hold (on some rank): every rank takes this branch and redoes the step the plain way
             if self._side() is not None:
                 import torch

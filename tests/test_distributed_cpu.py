@@ -104,6 +104,7 @@ def _worker(rank, world, port, n, d, out_dir):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from metagenome_vector_sketches_amd import parallel
+    from oracle import pyoracle as orc_mod
     sk, n2 = _make(n, d, seed=99)
     b, e = parallel.shard_rows(n, world, rank)
     sc = parallel.ShardedComparison(OracleOps(), rank, world, dist)
@@ -132,6 +133,21 @@ def _worker(rank, world, port, n, d, out_dir):
     sc.feed(0, (n + world - 1) // world, int(np.abs(sk[b:e]).max()) if rank == world - 1 else 1)
     _, cnt5, info5 = sc.finish(cells_out=out)
     assert cnt5 == cnt and np.array_equal(out[:cnt5].numpy(), plain) and "did not hold" in info5["overlap"]
+    # a guess that is too LARGE is no reason to redo anything: one-limb data (max |v| <= 127) coded with the default guess
+    # of two limbs keeps the overlapped exchange -- same cells as the plain run, which picks one limb
+    small = np.clip(sk, -100, 100).astype(np.int32)
+    n2s = np.array([orc_mod.norm_sq_from_text(orc_mod.format_norm(orc_mod.norm(r))) for r in small])
+    out_s = torch.empty((n * n, 4), dtype=torch.int32)
+    _, cnt_s, info_s = sc.run(small[b:e], n2s[b:e], n, cells_out=out_s)
+    want_s = out_s[:cnt_s].numpy().copy()
+    assert info_s["limbs"] == 1
+    sc.begin(torch.from_numpy(small[b:e].copy()), n2s[b:e], n)
+    for (p0, p1) in bounds:
+        q0, q1 = min(p0, e - b), min(p1, e - b)
+        sc.feed(p0, p1, int(np.abs(small[b + q0:b + q1]).max()) if q1 > q0 else 0)
+    _, cnt_s2, info_s2 = sc.finish(cells_out=out_s)
+    assert info_s2["limbs"] == 2 and info_s2["overlap"].startswith("exchange of a part"), info_s2
+    assert cnt_s2 == cnt_s and np.array_equal(out_s[:cnt_s2].numpy(), want_s)
     # an output buffer that holds exactly this shard (the mirrored cells in flight live in internal buffers)
     tight = torch.empty((cnt, 4), dtype=torch.int32)
     _, cnt6, _ = sc.run(sk[b:e], n2[b:e], n, cells_out=tight)

@@ -160,6 +160,52 @@ def test_rccl_communicator_first_contact():
     ctx.close()
 
 
+def test_rccl_beside_torchs_nccl_backend(tmp_path):
+    """8-GPU readiness that one card can check: a process that has ALREADY initialised torch.distributed's nccl backend (as
+    every bench.py rank has: the barrier and the id broadcast go through it) creates the library's own RCCL communicator
+    from an id that travelled through a torch collective, and runs its collectives.  Both use the same librccl -- the
+    loader hands the library's dlopen the copy torch has mapped -- which mvs_comm_library reports; the bench line carries
+    it (config.rccl_library / rccl_version)."""
+    import subprocess
+    script = tmp_path / "coexist.py"
+    script.write_text('''
+import os, sys, json
+sys.path.insert(0, %r)
+import torch
+import torch.distributed as dist
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29611", RANK="0", WORLD_SIZE="1")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+x = torch.ones(4, device="cuda")
+dist.all_reduce(x)                                   # torch's communicator exists and has done work
+import metagenome_vector_sketches_amd as pkg
+from metagenome_vector_sketches_amd import _capi
+ctx = pkg.Context(0)
+uid = torch.zeros(_capi.COMM_ID_BYTES, dtype=torch.uint8, device="cuda")
+uid.copy_(torch.frombuffer(bytearray(_capi.comm_unique_id()), dtype=torch.uint8))
+dist.broadcast(uid, src=0)                           # the way bench.py hands the id to the other ranks
+comm = ctx.comm_rccl(bytes(uid.cpu().numpy().tobytes()), 0, 1)
+buf = torch.arange(4096, dtype=torch.int8, device="cuda")
+comm.allgather_bytes(buf, 4096)
+ctx.synchronize()
+ok = bool(torch.equal(buf.cpu(), torch.arange(4096, dtype=torch.int8))) and comm.allreduce_max(7) == 7
+dist.all_reduce(x)                                   # and torch's still works afterwards
+torch.cuda.synchronize()
+path, version = _capi.comm_library()
+mapped = [l.split()[-1] for l in open("/proc/self/maps") if "librccl" in l]
+comm.close(); ctx.close(); dist.destroy_process_group()
+print(json.dumps({"ok": ok, "is_rccl": True, "x": float(x[0]), "path": path, "version": version, "mapped": sorted(set(mapped))}))
+''' % ROOT)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    import json
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["ok"] and d["x"] == 1.0 and d["version"] >= 20000
+    assert os.path.basename(d["path"]).startswith("librccl") and d["path"] in d["mapped"]
+    assert len(d["mapped"]) == 1, d["mapped"]          # ONE copy of RCCL in the process, shared by torch and the library
+
+
 def _bare_bench(extra, timeout=600):
     """`python3 bench.py --gpus 2 ...` exactly as the round driver types it for a SCALE run -- no launcher, no RANK /
     WORLD_SIZE in the environment -- with MVS_BENCH_REHEARSAL=1 putting both ranks on the one card (gloo + the file
