@@ -89,13 +89,14 @@ struct HashSets {
 // set, not an order; sorted unique values are what the .csr cache is defined to hold, so the order is kept -- with an LSD
 // radix sort on 11-bit digits over the bits that are actually set (FracMinHash values are < 2^64 / scaled: 5 passes),
 // ~10 ns per value where std::sort takes 60 (that sort was 70 % of the first `sketch` run's parse stage).
-inline void sort_unique_u64(std::vector<uint64_t>& v) {
-    const size_t n = v.size();
+inline void sort_unique_u64(std::vector<uint64_t>& vec, size_t first = 0) {   // the values from index `first` on
+    const size_t n = vec.size() - first;
+    uint64_t* const v = vec.data() + first;
     if (n < 256) {
-        std::sort(v.begin(), v.end());
+        std::sort(v, v + n);
     } else {
         uint64_t any = 0;
-        for (uint64_t x : v) any |= x;
+        for (size_t i = 0; i < n; ++i) any |= v[i];
         int bits = 0;
         while (bits < 64 && (any >> bits) != 0) ++bits;
         const int passes = std::max(1, (bits + 10) / 11);
@@ -103,9 +104,9 @@ inline void sort_unique_u64(std::vector<uint64_t>& v) {
         static thread_local std::vector<uint32_t> hist;
         tmp.resize(n);
         hist.assign((size_t)passes * 2048, 0);
-        for (uint64_t x : v)
-            for (int ps = 0; ps < passes; ++ps) ++hist[(size_t)ps * 2048 + ((x >> (11 * ps)) & 2047)];
-        uint64_t* src = v.data();
+        for (size_t i = 0; i < n; ++i)
+            for (int ps = 0; ps < passes; ++ps) ++hist[(size_t)ps * 2048 + ((v[i] >> (11 * ps)) & 2047)];
+        uint64_t* src = v;
         uint64_t* dst = tmp.data();
         for (int ps = 0; ps < passes; ++ps) {
             uint32_t* h = hist.data() + (size_t)ps * 2048;
@@ -122,18 +123,20 @@ inline void sort_unique_u64(std::vector<uint64_t>& v) {
             for (size_t i = 0; i < n; ++i) dst[h[(src[i] >> sh) & 2047]++] = src[i];
             std::swap(src, dst);
         }
-        if (src != v.data()) memcpy(v.data(), src, n * sizeof(uint64_t));
+        if (src != v) memcpy(v, src, n * sizeof(uint64_t));
     }
-    v.erase(std::unique(v.begin(), v.end()), v.end());
+    vec.erase(std::unique(vec.begin() + (long)first, vec.end()), vec.end());
 }
 
 // Parse whitespace separated unsigned 64-bit integers the way `while (iss >> hash)` does
 // (src/project_everything.cpp:275-279, src/standalone_projection.cpp:32-35): stop at the first token
 // that is not a number in range.  The reference collects them in an unordered_set; the sorted unique values are
 // the same set.  A line whose values are strictly increasing -- what this repository's `convert` writes -- is
-// unique and sorted as it stands and skips the sort.
+// unique and sorted as it stands and skips the sort.  The values are APPENDED to `out` (a caller that parses many lines
+// into one arena pays for no per-line allocation); only the appended ones are sorted.
 inline void parse_u64_tokens(const char* p, const char* end, std::vector<uint64_t>& out) {
-    out.reserve(out.size() + (size_t)(end - p) / 16 + 4);
+    const size_t first = out.size();
+    if (out.capacity() - out.size() < (size_t)(end - p) / 16 + 4) out.reserve(std::max(out.capacity() * 2, out.size() + (size_t)(end - p) / 16 + 4));
     bool increasing = true, have_prev = false;
     uint64_t prev = 0;
     auto push = [&](uint64_t v) {
@@ -170,7 +173,7 @@ inline void parse_u64_tokens(const char* p, const char* end, std::vector<uint64_
         }
         push(v);
     }
-    if (!increasing) sort_unique_u64(out);
+    if (!increasing) sort_unique_u64(out, first);
 }
 
 // One record per line.  with_names: "name: h1 h2 ..." (lines without ':' are skipped,
@@ -237,7 +240,6 @@ inline bool read_hash_file(const std::string& path, bool with_names, HashSets& o
     if (pos < size) add_line(pos, size);
 
     const size_t n = recs.size();
-    std::vector<std::vector<uint64_t>> sets(n);
     threads = (unsigned)std::min<size_t>(threads, std::max<size_t>(1, n));
     // an exception in a worker (bad_alloc on a huge line) must not end in std::terminate: it is carried to the caller
     std::exception_ptr worker_error;
@@ -255,8 +257,31 @@ inline bool read_hash_file(const std::string& path, bool with_names, HashSets& o
             });
         for (auto& th : pool) th.join();
     };
+    // Every worker takes a CONTIGUOUS run of lines holding about the same number of text bytes and parses it into ONE
+    // arena (no allocation per sample: half a billion values in 10k vectors meant 4 GB of fresh, zeroed pages before the
+    // copy into the flat array touched another 4 GB); the flat array is then the arenas one after the other.
+    std::vector<size_t> cut(threads + 1, n);
+    cut[0] = 0;
+    for (unsigned t = 1; t < threads; ++t) {
+        const size_t target = size / threads * t;
+        size_t lo = cut[t - 1], hi = n;
+        while (lo < hi) {
+            const size_t mid = (lo + hi) / 2;
+            if (recs[mid].b < target) lo = mid + 1;
+            else hi = mid;
+        }
+        cut[t] = lo;
+    }
+    std::vector<std::vector<uint64_t>> arena(threads);
+    std::vector<int64_t> counts(n, 0);
     run([&](unsigned t) {
-        for (size_t i = t; i < n; i += threads) parse_u64_tokens(buf + recs[i].colon + 1, buf + recs[i].e, sets[i]);
+        std::vector<uint64_t>& a = arena[t];
+        if (cut[t + 1] > cut[t]) a.reserve((recs[cut[t + 1] - 1].e - recs[cut[t]].b) / 16 + 16);
+        for (size_t i = cut[t]; i < cut[t + 1]; ++i) {
+            const size_t before = a.size();
+            parse_u64_tokens(buf + recs[i].colon + 1, buf + recs[i].e, a);
+            counts[i] = (int64_t)(a.size() - before);
+        }
     });
     if (worker_error) {
         if (size) ::munmap((void*)buf, size);
@@ -264,18 +289,17 @@ inline bool read_hash_file(const std::string& path, bool with_names, HashSets& o
     }
     out.names.resize(n);
     out.offsets.assign(n + 1, 0);
-    for (size_t i = 0; i < n; ++i) out.offsets[i + 1] = out.offsets[i] + (int64_t)sets[i].size();
+    for (size_t i = 0; i < n; ++i) out.offsets[i + 1] = out.offsets[i] + counts[i];
     if (!out.hashes.reset((size_t)out.offsets[n])) {
         if (size) ::munmap((void*)buf, size);
         return false;
     }
     uint64_t* flat = out.hashes.data();
     run([&](unsigned t) {
-        for (size_t i = t; i < n; i += threads) {
-            if (!sets[i].empty()) memcpy(flat + out.offsets[i], sets[i].data(), sets[i].size() * 8);
-            std::vector<uint64_t>().swap(sets[i]);
-            if (with_names) out.names[i].assign(buf + recs[i].b, recs[i].colon - recs[i].b);
-        }
+        if (!arena[t].empty()) memcpy(flat + out.offsets[cut[t]], arena[t].data(), arena[t].size() * 8);
+        std::vector<uint64_t>().swap(arena[t]);
+        if (with_names)
+            for (size_t i = cut[t]; i < cut[t + 1]; ++i) out.names[i].assign(buf + recs[i].b, recs[i].colon - recs[i].b);
     });
     if (size) ::munmap((void*)buf, size);
     if (worker_error) std::rethrow_exception(worker_error);

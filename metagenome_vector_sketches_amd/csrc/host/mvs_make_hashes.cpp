@@ -1,7 +1,10 @@
 // mvs_make_hashes -- writes a synthetic hash text file in the format `project_everything sketch` reads
 // ("name: h1 h2 ...\n", SURVEY.md 8d: unique-ish u64 below 2^64 / 1000, clusters of 16 samples sharing 40 % of their
 // hashes).  Test / measurement helper only: formatting half a billion numbers is far too slow in Python.
-//   mvs_make_hashes <out.txt> <samples> <hashes per sample> [seed]
+//   mvs_make_hashes <out.txt> <samples> <hashes per sample> [seed] [sorted]
+// "sorted": every line's values ascending and unique (what this repository's `convert` writes); default: in generation
+// order (what an unordered_set dump looks like to a reader: the reference's `convert`)
+#include <algorithm>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -23,6 +26,7 @@ int main(int argc, char** argv) {
     }
     const long n = std::atol(argv[2]), h = std::atol(argv[3]);
     const uint64_t seed = argc > 4 ? std::strtoull(argv[4], nullptr, 10) : 1234;
+    const bool sorted = argc > 5 && std::string(argv[5]) == "sorted";
     const uint64_t max_hash = 18446744073709552ULL;
     const long shared = (long)(0.4 * (double)h + 0.5);
     FILE* f = std::fopen(argv[1], "wb");
@@ -46,11 +50,18 @@ int main(int argc, char** argv) {
                     line.clear();
                     line.reserve((size_t)h * 19 + 32);
                     line += "sample" + std::to_string(s) + ":";
+                    std::vector<uint64_t> vals((size_t)h);
                     for (long j = 0; j < h; ++j) {
                         // the first `shared` hashes come from the cluster's pool, the rest are private to the sample
                         const uint64_t key = j < shared ? ((uint64_t)(s / 16) << 40) ^ (uint64_t)j ^ 0xabcdef0000000000ULL
                                                         : ((uint64_t)s << 32) ^ (uint64_t)j;
-                        uint64_t v = mix(mix(key) ^ seed) % max_hash;
+                        vals[(size_t)j] = mix(mix(key) ^ seed) % max_hash;
+                    }
+                    if (sorted) {
+                        std::sort(vals.begin(), vals.end());
+                        vals.erase(std::unique(vals.begin(), vals.end()), vals.end());
+                    }
+                    for (uint64_t v : vals) {
                         int len = 0;
                         do {
                             num[len++] = (char)('0' + v % 10);
