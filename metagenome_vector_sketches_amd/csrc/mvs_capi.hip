@@ -271,6 +271,7 @@ const OptionSpec kOptions[] = {
     {"stream_list_cells", &mvs::Options::stream_list_cells, nullptr, 0, 1 << 30},
     {"stream_pipeline", &mvs::Options::stream_pipeline, nullptr, 0, 1},
     {"stream_trace", &mvs::Options::stream_trace, nullptr, 0, 1},
+    {"search_stream", &mvs::Options::search_stream, nullptr, 0, 1},
     {"pairwise_block_cells", nullptr, &mvs::Options::pairwise_block_cells, 1, (1LL << 62)},
 };
 
@@ -1405,7 +1406,8 @@ int two_stage_tiles(mvs_ctx* c, TwoStage& ts, int first, int count, bool timed) 
 }
 
 // may the two-stage comparison run on this block?  (see the comments at the call sites' old home, pairwise_launch)
-bool two_stage_applies(mvs_ctx* c, const mvs_sketch_set* s, int64_t rb, int64_t re, int64_t cb, int64_t ce, double keep_coeff) {
+bool two_stage_applies(mvs_ctx* c, const mvs_sketch_set* s, int64_t rb, int64_t re, int64_t cb, int64_t ce, double keep_coeff,
+                       bool symmetric = true) {
     const int filter_mode = c->opt.pairwise_filter;
     const double block_cells = (double)(re - rb) * (double)(ce - cb);
     // A few rows against everything (a search with a handful of queries; one of very many shards) on a set whose coarse
@@ -1417,11 +1419,24 @@ bool two_stage_applies(mvs_ctx* c, const mvs_sketch_set* s, int64_t rb, int64_t 
     const bool coarse_cached = c->coarse_id == s->id && c->coarse_gen == s->gen && c->coarse_mode == c->opt.coarse_radix;
     const bool few_rows = re - rb < 1024;
     const bool few_rows_again = c->few_rows_id == s->id && c->few_rows_gen == s->gen;
+    // ... unless the coarse plane is there already: the streaming filter then reads half the bytes the streaming exact kernel
+    // does (one coarse plane against two limb planes) and has the matrix cores for the products (16 rows x 10^6 columns:
+    // 1.44 ms exact)
+    mvs::PairwiseArgs probe{};
+    probe.limbs = s->limbs;
+    probe.d_pad = s->d_pad;
+    probe.row_begin = rb;
+    probe.row_end = re;
+    probe.col_begin = cb;
+    probe.col_end = ce;
+    probe.symmetric = (symmetric && c->opt.pairwise_symmetric) ? 1 : 0;
+    const bool streams = mvs::filter_streams_rows(probe, c->opt);
     const bool two_stage = filter_mode != 0 && s->limbs == 2 && s->d_pad <= 32768 &&
                            (filter_mode == 2 ||   // forced: also on small blocks and on sets it was found not to pay for
-                            (block_cells >= 4194304.0 && re - rb > 16 && (coarse_cached || !few_rows || few_rows_again) &&
+                            (block_cells >= 4194304.0 && (re - rb > 16 || (streams && coarse_cached)) &&
+                             (coarse_cached || !few_rows || few_rows_again) &&
                              !(c->filter_off_id == s->id && c->filter_off_coeff == keep_coeff)));
-    if (!two_stage && few_rows && re - rb > 16 && block_cells >= 4194304.0) {
+    if (!two_stage && few_rows && (re - rb > 16 || streams) && block_cells >= 4194304.0) {
         c->few_rows_id = s->id;
         c->few_rows_gen = s->gen;
     }
@@ -1475,7 +1490,7 @@ int pairwise_launch(mvs_ctx* c, const mvs_sketch_set* s, const double* d_n2, int
     } stamp_dump{a.stamps, stamp_bytes, c->stream};
 #endif
     int rc = MVS_OK;
-    if (!dn && two_stage_applies(c, s, rb, re, cb, ce, keep_coeff)) {
+    if (!dn && two_stage_applies(c, s, rb, re, cb, ce, keep_coeff, symmetric)) {
         TwoStage ts;
         rc = two_stage_filter(c, s, d_n2, keep_coeff, capacity, po != nullptr, start, a, ts);
         if (rc == MVS_OK) {
@@ -2214,7 +2229,7 @@ int pairwise_stream_impl(mvs_ctx* c, const mvs_sketch_set* s, const double* norm
         auto sp = std::make_shared<BlockCsr>(std::move(blk));
         const bool enc = ecb != nullptr;
         StreamOut* o = &out;
-        out.enqueue_feed([c, o, sp, enc, piece_bytes]() -> int {
+        out.enqueue_feed([c, o, sp, enc]() -> int {
             return enc ? feed_encoded(c, *o, *sp, piece_bytes) : feed_block(c, *o, *sp, piece_bytes);
         });
         return MVS_OK;

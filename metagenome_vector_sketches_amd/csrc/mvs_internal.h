@@ -70,6 +70,8 @@ struct Options {
                                     // the link is the bottleneck: CSR pieces; measured slower for encoded rows, where the device
                                     // is: 20 filter passes with a host round trip each); 0 (default) = one filter pass over the
                                     // whole row range first
+    int search_stream = 1;          // blocks of < 1024 rows x >= 4096 columns outside the symmetric schedule: 1 = the streaming
+                                    // filter (rows resident in LDS, columns streamed into the matrix cores), 0 = the tile kernels
     int stream_trace = 0;           // 1: mvs_pairwise_stream prints the host-side time line of its row blocks to stderr
     int comm_timeout_s = 600;       // file transport: how long a rank waits for a peer's block before it gives up
     double pairwise_block_cells = 1099511627776.0;   // row-chunk bound of mvs_pairwise_rows (2^40 cells)
@@ -205,6 +207,8 @@ int launch_cand_gather(hipStream_t stream, const PairwiseArgs& a, int64_t n_regi
 // grid (256 x 256) it works on; flags -> per-tile-row counts -> row-major list of flagged tile ids (d_list holds the total);
 // candidates whose tile is flagged are dropped (d_out / d_out_count: the pruned list); the exact kernel on a run of the list
 bool filter_flags_tiles(const PairwiseArgs& a, const Options& opt);
+// true when launch_filter would take the streaming search filter for this block (few rows, many columns, no symmetry)
+bool filter_streams_rows(const PairwiseArgs& a, const Options& opt);
 void filter_tile_grid(const PairwiseArgs& a, int* n_tr, int* n_tc);
 int launch_tile_count(hipStream_t stream, const unsigned int* d_flags, int n_tr, int n_tc, int* d_row_count);
 int launch_tile_list(hipStream_t stream, const unsigned int* d_flags, int n_tr, int n_tc, const int* d_row_count, int* d_list);

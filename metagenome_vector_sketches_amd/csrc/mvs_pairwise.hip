@@ -1097,6 +1097,160 @@ __global__ __launch_bounds__(256) void k_cand_gather(const PairwiseArgs a, unsig
         if (slot < a.cand_capacity) a.cand[slot] = a.cand_ent[reg * kCandRegion + e];
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// Streaming filter for a few rows against very many columns (a search: 1 .. 1023 query sketches against a resident
+// database; one of very many shards).  The tile kernels above fetch 64-byte k-slices of 256 columns per workgroup
+// through LDS and live on L2 reuse between neighbouring tiles; a block a few rows high has none, and they ran at
+// 1.3-3 TB/s of the 8 TB/s HBM peak.  Here the ROWS are resident -- the coarse plane of 16 * RB
+// query rows in LDS (row stride d_pad + 16 bytes: the 16 rows a ds_read_b128 touches fall into 16 different bank groups) --
+// and the COLUMNS stream: a lane loads 16 consecutive k-bytes of one column's coarse row straight from global memory,
+// which is exactly the B fragment of v_mfma_i32_16x16x64_i8 (column = lane & 15, k quarter = lane >> 4), three k-slices
+// of four column blocks in flight per wave (12 KiB; 8 waves per CU).  Per k-slice a wave reads RB A fragments from LDS
+// and issues 4 * RB MFMAs on 4 column blocks, so LDS traffic is a quarter of what one column block per fragment would need.
+// HBM traffic = the coarse plane once per group of 16 * RB rows; the workgroups of different groups that walk the same
+// columns sit on the same XCD and start together, so the groups after the first mostly hit in that XCD's L2.
+// Epilogue: the filter's threshold test (k_filter_meta) per cell, candidates appended with one atomic per wave.
+// Not for the symmetric schedule (a block inside its own square has thousands of rows).
+// ---------------------------------------------------------------------------------------------------
+template <int RB>
+__global__ __launch_bounds__(512) void k_search_filter(const PairwiseArgs a, int groups, long long chunks_total) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int QG = 16 * RB;
+    const int stride = a.d_pad + 16;
+    int8_t* As = reinterpret_cast<int8_t*>(smem);
+    float4* rowc = reinterpret_cast<float4*>(smem + (size_t)QG * stride);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // walkers of the column chunks x row groups.  map 0: the groups of one walker sit on ONE XCD (consecutive workgroups of
+    // an XCD: they start together and share its L2); map 1: on consecutive XCDs (they meet in the memory-side cache)
+    int g, slot, slots;
+    unsigned xcd;
+    if (a.map_mode == 1) {
+        g = (int)(blockIdx.x % (unsigned)groups);
+        slot = (int)(blockIdx.x / (unsigned)groups);
+        slots = (int)(gridDim.x / (unsigned)groups);
+        xcd = 0;
+    } else {
+        xcd = blockIdx.x & 7u;
+        const unsigned j = blockIdx.x >> 3;
+        g = (int)(j % (unsigned)groups);
+        slot = (int)(j / (unsigned)groups);
+        slots = (int)((gridDim.x >> 3) / (unsigned)groups);
+    }
+    const long long chunk_first = a.map_mode == 1 ? slot : (long long)slot * 8 + xcd;
+    const long long chunk_step = a.map_mode == 1 ? slots : 8LL * slots;
+    const int64_t q0 = a.row_begin + (int64_t)g * QG;
+    {   // the group's rows of the coarse plane -> LDS (rows beyond the block: zeros, and a threshold nothing passes)
+        const int per_row = a.d_pad / 16;
+        for (int idx = tid; idx < QG * per_row; idx += 512) {
+            const int r = idx / per_row, c16 = idx - r * per_row;
+            v4i v = v4i{0, 0, 0, 0};
+            if (q0 + r < a.row_end) v = *reinterpret_cast<const v4i*>(a.coarse + (q0 + r) * (int64_t)a.d_pad + c16 * 16);
+            *reinterpret_cast<v4i*>(As + (size_t)r * stride + c16 * 16) = v;
+        }
+        if (tid < QG) rowc[tid] = q0 + tid < a.row_end ? a.fmeta[q0 + tid] : make_float4(__builtin_inff(), 0.0f, 0.0f, 0.0f);
+    }
+    __syncthreads();
+    const int fr = lane & 15, fq = lane >> 4;
+    const int nk = a.d_pad / kSK;
+    const int8_t* a_base = As + (size_t)fr * stride + fq * 16;
+    for (long long chunk = chunk_first; chunk < chunks_total; chunk += chunk_step) {
+        if (*reinterpret_cast<volatile const unsigned int*>(a.cand_stop) != 0u) break;
+        const int64_t c0 = a.col_begin + chunk * 512 + wave * 64;
+        const int8_t* bp[4];
+        float4 cm[4];
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) {
+            const int64_t col = c0 + cb * 16 + fr;
+            const int64_t cl = col < a.n_alloc ? col : a.n_alloc - 1;          // loads stay inside the plane
+            bp[cb] = a.coarse + cl * (int64_t)a.d_pad + fq * 16;
+            cm[cb] = col < a.col_end ? a.fmeta[cl] : make_float4(__builtin_inff(), 0.0f, 0.0f, 0.0f);
+        }
+        v4i acc[RB][4];
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) acc[rb][cb] = v4i{0, 0, 0, 0};
+        v4i b0[4], b1[4], b2[4];
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) {
+            b0[cb] = *reinterpret_cast<const v4i*>(bp[cb]);
+            b1[cb] = *reinterpret_cast<const v4i*>(bp[cb] + (nk > 1 ? kSK : 0));
+        }
+        auto step = [&](int ks, v4i (&cur)[4], v4i (&nxt)[4]) {
+            // the slice two ahead goes into the buffer that was consumed one step ago (clamped at the end: a harmless reload)
+            const int kn = ks + 2 < nk ? ks + 2 : nk - 1;
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) nxt[cb] = *reinterpret_cast<const v4i*>(bp[cb] + kn * kSK);
+            v4i fa[RB];
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) fa[rb] = *reinterpret_cast<const v4i*>(a_base + (size_t)rb * 16 * stride + ks * kSK);
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb)
+                    acc[rb][cb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[rb], cur[cb], acc[rb][cb], 0, 0, 0);
+        };
+        int ks = 0;
+        for (; ks + 3 <= nk; ks += 3) {
+            step(ks, b0, b2);
+            step(ks + 1, b1, b0);
+            step(ks + 2, b2, b1);
+        }
+        if (ks < nk) step(ks, b0, b2);
+        if (ks + 1 < nk) step(ks + 1, b1, b0);
+        // ---- threshold test (same expression as the tile filters': four fused operations per cell) ----
+        unsigned mine = 0;
+        unsigned long long hit[RB];          // bit cb * 4 + r of word rb: cell (row rb*16 + fq*4 + r, column block cb) passes
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+            unsigned m16 = 0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float4 rc = rowc[rb * 16 + fq * 4 + r];
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb) {
+                    float t = rc.x * cm[cb].y;
+                    t = fmaf(rc.y, cm[cb].x, t);
+                    t = fmaf(rc.z, -cm[cb].w, t);
+                    t = fmaf(rc.w, -(cm[cb].z + cm[cb].w), t);
+                    m16 |= ((float)acc[rb][cb][r] > t) ? 1u << (cb * 4 + r) : 0u;
+                }
+            }
+            hit[rb] = m16;
+            mine += (unsigned)__popc(m16);
+        }
+        if (__ballot(mine != 0) == 0ULL) continue;
+        unsigned incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned up = (unsigned)__shfl_up((int)incl, o, 64);
+            if (lane >= o) incl += up;
+        }
+        unsigned long long base = 0;
+        if (lane == 63) {
+            base = atomicAdd(a.cand_counter, (unsigned long long)incl);
+            if (base + incl > a.cand_limit) *a.cand_stop = 1u;
+        }
+        base = __shfl(base, 63, 64);
+        unsigned long long out = base + (incl - mine);
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+            unsigned m = (unsigned)hit[rb];
+            while (m) {
+                const int b = __ffs((int)m) - 1;
+                m &= m - 1;
+                const int64_t col = c0 + (b >> 2) * 16 + fr;
+                const int64_t row = q0 + rb * 16 + fq * 4 + (b & 3);
+                if (out < a.cand_capacity)
+                    a.cand[out] = make_int2((int32_t)row, a.mirror_all ? (int)((unsigned)col | 0x80000000u) : (int)col);
+                ++out;
+            }
+        }
+    }
+}
+
 // ---- tile-granular comparison: flags -> list, candidate pruning ----
 // flagged tiles per tile row (one workgroup per row of the 256 x 256 tile grid)
 __global__ __launch_bounds__(256) void k_tile_count(const unsigned int* __restrict__ flags, int n_tc, int* __restrict__ row_count) {
@@ -2362,6 +2516,7 @@ int launch_filter_meta(hipStream_t stream, const CoarseRow* d_rows, const double
 }
 
 static int filter_variant_for(const PairwiseArgs& a, const Options& opt);
+static int launch_search_filter(hipStream_t stream, const PairwiseArgs& a);
 
 int launch_filter(hipStream_t stream, const PairwiseArgs& a, const Options& opt) {
     if (a.limbs != 2 || a.d_pad > 32768) return MVS_E_INVALID;
@@ -2371,6 +2526,7 @@ int launch_filter(hipStream_t stream, const PairwiseArgs& a, const Options& opt)
     // tiles) once the block holds enough tiles to keep 256 CUs busy through the tail, 128 x 128 ring tiles below that.
     const int v = filter_variant_for(a, opt);
     switch (v) {
+        case 50: return launch_search_filter(stream, a);
         case 7: return launch_pp<2, 5>(stream, a);   // ping-pong wave groups, 256 x 256, 5-stage ring (all 160 KiB of LDS)
         case 8: return launch_pp<2, 4>(stream, a);   // the same on a 4-stage ring
         case 9: return launch_pp<2, 4, 0, 0, 2>(stream, a);    // two phases per slice
@@ -2399,9 +2555,49 @@ int launch_filter(hipStream_t stream, const PairwiseArgs& a, const Options& opt)
     }
 }
 
+// row blocks of 16 the streaming search filter keeps resident for this sketch length (0: the rows do not fit the LDS)
+static int search_filter_rb(const PairwiseArgs& a) {
+    for (int rb : {4, 2, 1})
+        if ((size_t)16 * rb * ((size_t)a.d_pad + 16) + (size_t)16 * rb * sizeof(float4) <= (size_t)150 * 1024) return rb;
+    return 0;
+}
+
+template <int RB>
+static int launch_search_filter_rb(hipStream_t stream, const PairwiseArgs& a) {
+    const int64_t rows = a.row_end - a.row_begin, cols = a.col_end - a.col_begin;
+    const int groups = (int)((rows + 16 * RB - 1) / (16 * RB));
+    const long long chunks = (cols + 511) / 512;
+    // one workgroup per CU (its LDS holds the group's rows); per XCD `slots` column walkers x `groups` row groups
+    const int slots = std::max(1, std::min<int>(32 / std::max(1, groups) + (32 % std::max(1, groups) ? 1 : 0), (int)((chunks + 7) / 8)));
+    const size_t lds = (size_t)16 * RB * ((size_t)a.d_pad + 16) + (size_t)16 * RB * sizeof(float4);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_search_filter<RB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return MVS_E_HIP;
+    hipLaunchKernelGGL(k_search_filter<RB>, dim3(8u * (unsigned)slots * (unsigned)groups), dim3(512), lds, stream, a, groups, chunks);
+    return 0;
+}
+
+static int launch_search_filter(hipStream_t stream, const PairwiseArgs& a) {
+    switch (search_filter_rb(a)) {
+        case 4: return launch_search_filter_rb<4>(stream, a);
+        case 2: return launch_search_filter_rb<2>(stream, a);
+        case 1: return launch_search_filter_rb<1>(stream, a);
+        default: return MVS_E_INVALID;
+    }
+}
+
 // variant the filter launcher picks (launch_filter) for this block
 static int filter_variant_for(const PairwiseArgs& a, const Options& opt) {
     int v = opt.filter_variant;
+    // 50: the streaming search filter -- a block of few rows that is not under the symmetric schedule, against at least
+    // 4096 columns (option search_stream = 0 leaves such blocks to the tile kernels).  Few = up to 320 when the kernel is
+    // picked by size: 64 resident rows read the coarse plane once (10^6 columns: 0.39 ms, 5.2 TB/s), every further group
+    // of 64 reads it again and the groups share an XCD's L2 only in part (256 rows: 1.0 ms against 1.28 ms on 256 x 256
+    // tiles, 512 rows: 1.86 against ~1.5); asked for by number (filter_variant 50) it takes up to 1023 rows.
+    const int64_t few = v == 50 ? 1023 : 320;
+    if ((v < 0 || v == 50) && opt.search_stream != 0 && !a.symmetric && a.row_end - a.row_begin <= few &&
+        a.col_end - a.col_begin >= 4096 && search_filter_rb(a) > 0)
+        return 50;
+    if (v == 50) v = -1;
     if (v < 0) {
         const double tiles = (double)(a.row_end - a.row_begin) * (double)(a.col_end - a.col_begin) / 65536.0 *
                              (a.symmetric ? 0.5 : 1.0);
@@ -2429,6 +2625,10 @@ int launch_cand_gather(hipStream_t stream, const PairwiseArgs& a, int64_t n_regi
     hipLaunchKernelGGL(k_cand_gather, dim3((unsigned)((n_regions + 255) / 256)), dim3(256), 0, stream, a,
                        (unsigned long long)n_regions);
     return 0;
+}
+
+bool filter_streams_rows(const PairwiseArgs& a, const Options& opt) {
+    return a.limbs == 2 && a.d_pad <= 32768 && filter_variant_for(a, opt) == 50;
 }
 
 bool filter_flags_tiles(const PairwiseArgs& a, const Options& opt) {

@@ -132,3 +132,56 @@ def test_search_command_line_resident_index_and_small_hit_buffer(ctx, gold, tmp_
     bad = tmp_path / "bad.txt"
     bad.write_text("a: 1 2 : 3\n")
     assert search.main(["search", db, str(bad)]) == 332
+
+
+@pytest.mark.usefixtures("restore_options")
+@pytest.mark.parametrize("d,n_db", [(2048, 6000), (2100, 4500), (4096, 4300), (9000, 4200), (512, 9000)])
+def test_streaming_search_filter_equals_exact_kernel(ctx, d, n_db):
+    """k_search_filter -- the query rows' coarse plane resident in LDS (64 / 32 / 16 rows by sketch length), the database
+    columns streamed from global memory straight into the matrix cores -- as the first stage of searches and of
+    rectangular blocks with 1 .. 1023 rows against >= 4096 columns: the same hits as the exact kernel, for query counts
+    around every group size, column ranges that start and end off the 512-column chunks, both keep tests, mirrored
+    blocks.  (Reference semantics: src/jaccard.py:117-200; scores are checked against the restatement above.)"""
+    import torch
+    from metagenome_vector_sketches_amd import _capi, synth
+    from oracle import pyoracle as orc
+    nq_max = 1023
+    sk = synth.make_sketches_numpy(n_db + nq_max, d, 3000, seed=d, cluster=12)
+    # queries = the last rows; make them relatives of database rows so that there are hits
+    rng = np.random.default_rng(d)
+    for q in range(nq_max):
+        src = int(rng.integers(0, n_db))
+        sk[n_db + q] = sk[src] if q % 3 == 0 else (sk[src] + synth.make_sketches_numpy(1, d, 1500, seed=q)[0])
+    sk[n_db + 7] = 0                                                   # an empty query
+    n2 = np.array([orc.norm_sq_from_text(orc.format_norm(orc.norm(r))) for r in sk])
+    ss = ctx.sketch_set(sk)
+    assert ss.limbs == 2
+    n2_t = torch.from_numpy(n2).to("cuda")
+    cells = torch.empty((1 << 21, 4), dtype=torch.int32, device="cuda")
+
+    def run(fn):
+        out = []
+        for filt, stream in ((2, 1), (0, 1), (2, 0)):               # streaming filter, exact kernel, tile filter
+            ctx.set_option("pairwise_filter", filt)
+            ctx.set_option("search_stream", stream)
+            ctx.set_option("filter_variant", 50 if stream else -1)  # by number: up to 1023 rows (by size: up to 320)
+            cnt = fn()
+            ctx.synchronize()
+            out.append((sorted(map(tuple, cells[:cnt].cpu().numpy().tolist())), ctx.pairwise_candidates()))
+        assert out[0][0] == out[1][0] == out[2][0]
+        assert out[0][1] > 0 and out[1][1] == 0                      # the two-stage comparison ran / did not run
+        return out[0][0]
+
+    total = 0
+    for nq in (1, 5, 16, 17, 33, 64, 65, 200, 1023):
+        got = run(lambda: ctx.search_block(ss, n2_t, 0.1, n_db, n_db + nq, 0, n_db, cells))
+        total += len(got)
+        assert all(n_db <= r < n_db + nq and 0 <= c < n_db for r, c, _, _ in got)
+    assert total > 300
+    # a column range off the chunk grid, and a low bound (many hits per wave)
+    run(lambda: ctx.search_block(ss, n2_t, 0.02, n_db + 3, n_db + 90, 117, n_db - 55, cells))
+    # plain and mirrored rectangular blocks through mvs_pairwise_block (reference keep tests, :135-147 / _16bits.cpp:218)
+    for flags in (0, _capi.BLOCK_MIRROR_ALL):
+        for keep in (_capi.KEEP_INT32, _capi.KEEP_INT16):
+            run(lambda: ctx.pairwise_block(ss, n2_t, n_db, n_db + 300, 0, n_db, flags, cells, 0, keep_mode=keep))
+    ss.close()
