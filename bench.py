@@ -217,8 +217,11 @@ def main():
     ap.add_argument("--stream-samples", type=int, default=30_000,
                     help="N=1: size of the streamed-output leg at the density of the reference's toy set (clusters of N/3 "
                          "samples: a third of all cells kept), mvs_pairwise_stream with a counting callback; 0 skips it")
+    ap.add_argument("--density-samples", type=int, default=100_000,
+                    help="N=1: size of the density leg (clusters of 16 / 1024 / 10000 related samples: sparse to 10 %% of the "
+                         "cells kept, streamed as device-encoded rows); 0 skips it")
     ap.add_argument("--search-samples", type=int, default=500_000,
-                    help="N=1: database size of the search leg (1 / 16 / 1024 query sketches against that many resident "
+                    help="N=1: database size of the search leg (1 / 16 / 64 / 256 / 1024 query sketches against that many resident "
                          "sketches, mvs_search_block); 0 skips it")
     ap.add_argument("--overlap-parts", type=int, default=2,
                     help="N > 1: pieces the rank's samples are projected in; the all-gather of a finished piece's limb "
@@ -492,6 +495,8 @@ def main():
     if args.stream_samples and world == 1:
         res["streamed_dense"] = stream_leg(ctx, dev, args.stream_samples, args.pairwise_dim, NH)
 
+    if args.density_samples and world == 1:
+        res["density"] = density_leg(ctx, dev, args.density_samples, args.pairwise_dim, NH)
     if args.search_samples and world == 1:
         res["search"] = search_leg(ctx, dev, args.search_samples, args.pairwise_dim, NH)
 
@@ -644,7 +649,7 @@ def pairwise_leg(ctx, dev, n, d, nh, reps):
             for _ in range(3):
                 _, cnt = ctx.pairwise_rows(sset, n2, cells_out=cells)
             torch.cuda.synchronize()
-            wall, kern, filt_ms, chk_ms = [], [], [], []
+            wall, kern, filt_ms, chk_ms, tile_ms = [], [], [], [], []
             for _ in range(r):
                 t1 = time.perf_counter()
                 _, cnt = ctx.pairwise_rows(sset, n2, cells_out=cells)
@@ -654,12 +659,20 @@ def pairwise_leg(ctx, dev, n, d, nh, reps):
                 if filt:
                     filt_ms.append(ctx.kernel_ms(2))
                     chk_ms.append(ctx.kernel_ms(3))
+                    try:
+                        tile_ms.append(ctx.kernel_ms(4))
+                    except Exception:      # noqa: BLE001 -- no tile was flagged
+                        pass
             out[name] = {"reps": r, "wall_ms": float(np.mean(wall)), "wall_ms_min": float(np.min(wall)),
                          "kernels_ms": float(np.mean(kern)), "kept_cells": int(cnt),
                          "candidates": ctx.pairwise_candidates()}
             if filt:
                 out[name]["filter_kernel_ms"] = float(np.mean(filt_ms))
                 out[name]["recheck_kernel_ms"] = float(np.mean(chk_ms))
+                # tile-granular comparison: the 256 x 256 tiles whose waves held more than tile_dense_thr candidates went to
+                # the exact kernel whole (here: the diagonal tiles, where the clusters of 16 sit)
+                _, out[name]["flagged_tiles"], out[name]["filter_tiles"] = ctx.pairwise_stats()
+                out[name]["flagged_tiles_kernel_ms"] = float(np.mean(tile_ms)) if tile_ms else 0.0
     limbs = sset.limbs
     sset.close()
     cells_total = float(n) * n
@@ -693,6 +706,66 @@ def pairwise_leg(ctx, dev, n, d, nh, reps):
            "limbs": limbs, "two_stage": two, "exact": ex,
            "exact_cells_per_s": cells_total / (ex["wall_ms"] * 1e-3)}
     return {"workload": "configs[2]: %d synthetic samples, d=%d, pairwise" % (n, d), "leg": leg, "roofline": roof}
+
+
+def density_leg(ctx, dev, n, d, nh, clusters=(16, 1024, 10000), reps=2):
+    """the comparison between "sparse" and "dense".  n samples in clusters of c related samples, c from
+    16 (0.016 % of the cells kept) to n / 10 (10 %), streamed out as device-encoded rows (what the executable does); per
+    point the comparison kernels' time, candidates and flagged tiles, against
+        bound = two-stage kernels of the sparse point + flagged share of the tiles x exact kernel on every tile.
+    The reference's cost is flat in the density (src/pairwise_comp_optimized.cpp:135-147); up to round 3 ours jumped from
+    10 to 32+ ms once 1/128 of the cells were candidates."""
+    import ctypes
+    import torch
+    from metagenome_vector_sketches_amd import _capi, synth
+    seen = {"cells": 0}
+
+    def count(_user, bp):
+        seen["cells"] += bp.contents.n_cells
+        return 0
+    ecb = _capi.ENCODED_ROWS_CB(count)
+
+    def stream(sset, n2):
+        best = None
+        for r in range(reps + 1):
+            seen["cells"] = 0
+            cnt = ctypes.c_int64()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            rc = ctx.lib.mvs_pairwise_stream_encoded(ctx._h, sset._h, n2.data_ptr(), _capi.MEM_DEVICE, _capi.KEEP_INT32, 0, n, 0,
+                                                     ecb, None, ctypes.byref(cnt))
+            wall = (time.perf_counter() - t0) * 1e3
+            if rc != 0 or seen["cells"] != cnt.value:
+                raise SystemExit("density leg: streamed comparison failed (rc %d)" % rc)
+            st = ctx.stream_stats()
+            if r and (best is None or wall < best["wall_ms"]):
+                best = {"wall_ms": wall, "kernels_ms": st["kernel_ms"], "bytes_to_host": st["bytes"], "row_blocks": st["row_blocks"],
+                        "path": int(st["two_stage"]), "kept_cells": int(cnt.value)}
+        return best
+    points, exact_ms, sparse_ms = [], None, None
+    for c in clusters:
+        sk = synth.make_sketches_torch(n, d, nh, seed=2345, device=dev, cluster=c)
+        ss = torch.empty(n, dtype=torch.int64, device=dev)
+        ctx.sumsq(sk, out=ss)
+        n2 = torch.from_numpy(fast_norm_sq(ss.cpu().numpy(), d)).to(dev)
+        sset = ctx.sketch_set(sk)
+        del sk
+        if exact_ms is None:
+            with ctx.options(pairwise_filter=0):
+                exact_ms = stream(sset, n2)["kernels_ms"]
+        p = stream(sset, n2)
+        cand, flagged, tiles = ctx.pairwise_stats()
+        if sparse_ms is None:
+            sparse_ms = p["kernels_ms"]
+        bound = sparse_ms + flagged / max(tiles, 1) * exact_ms
+        p.update(cluster=c, density=p["kept_cells"] / float(n) / n, candidates=cand, flagged_tiles=flagged, filter_tiles=tiles,
+                 bound_ms=bound, kernels_over_bound=p["kernels_ms"] / bound)
+        points.append(p)
+        sset.close()
+        del sset
+        torch.cuda.empty_cache()
+    return {"workload": "%d synthetic samples, d=%d, clusters of c samples, rows encoded on the device and streamed to the host"
+                        % (n, d), "exact_kernel_every_tile_ms": exact_ms, "points": points}
 
 
 def stream_leg(ctx, dev, n, d, nh, reps=3):
@@ -766,7 +839,12 @@ def stream_leg(ctx, dev, n, d, nh, reps=3):
     return {"workload": "%d synthetic samples in clusters of %d, d=%d: all-vs-all streamed to the host as CSR pieces" % (n, cluster, d),
             "kept_cells": int(cnt.value), "density": cnt.value / float(n) / n, "wall_ms": wall,
             "comparison_kernels_ms": stats["kernel_ms"], "row_blocks": stats["row_blocks"], "pieces": stats["pieces"],
-            "path": "two-stage" if stats["two_stage"] else "exact kernel, dense byte matrix -> CSR on the device",
+            "path": {0: "exact kernel on every tile, dense byte matrix -> CSR on the device",
+                     1: "two-stage comparison, one packed list sorted on the device",
+                     2: "two-stage comparison feeding the dense byte matrix: flagged tiles by the exact kernel row block by row "
+                        "block, the re-check's cells scattered, row passes over the tiles that can hold cells",
+                     3: "the same with the filter itself running row block by row block"}[int(stats["two_stage"])],
+            "candidates_flagged_filter_tiles": list(ctx.pairwise_stats()),
             "bytes_to_host": int(nbytes), "bytes_per_kept_cell": nbytes / max(cnt.value, 1),
             "bare_link_ms": min(link), "link_GBps": nbytes / (min(link) * 1e-3) / 1e9,
             "pcie_share_of_wall": min(link) / wall, "wall_over_max_kernel_link": wall / max(stats["kernel_ms"], min(link)),
@@ -780,27 +858,42 @@ def stream_leg(ctx, dev, n, d, nh, reps=3):
 
 def search_leg(ctx, dev, n, d, nh, reps=5):
     """SURVEY 8f row 4, device part: q query sketches against n resident database sketches (mvs_search_block; the reference
-    runs FAISS IndexFlatIP on float32 copies on the CPU).  1 and 16 queries take the streaming kernel (k_pairwise_skinny: the
-    limb planes are read once, front to back -- its bound is HBM), 1024 the MFMA kernels on the tile map for skinny
-    blocks.  Algorithmic bytes = the database's limb planes once (2 * d_pad per sketch)."""
+    runs FAISS IndexFlatIP on float32 copies on the CPU, src/jaccard.py:117-200).  Every tenth query is a database sample
+    (every twentieth an exact copy, the others a copy + an independent sample: Jaccard ~ 0.5), so the hit path is timed
+    too.  The set stays resident, as a search service would keep it: from the second search on the coarse plane exists and
+    up to 320 queries go through the streaming filter (k_search_filter: the query rows' coarse plane in LDS, the database's
+    coarse plane streamed once per group of 64 rows into the matrix cores) + exact re-check of its candidates; 1024
+    queries take the tile filter.  Per row the roofline of the dominant kernel: HBM with the bytes that kernel has to read
+    once (the coarse plane, d_pad per sketch; the exact streaming kernel would need both limb planes), or MFMA with
+    2 d q N flops where the matrix cores are the nearer bound."""
     import torch
     from metagenome_vector_sketches_amd import synth
     nq_max = 1024
     sset = ctx.sketch_set_alloc(n + nq_max, d, 2)
     ss_all = torch.empty(n + nq_max, dtype=torch.int64, device=dev)
     step = 100_000
-    for r0 in range(0, n + nq_max, step):                    # database first, the queries are the last rows
-        rows = min(step, n + nq_max - r0)
+    donors = None
+    for r0 in range(0, n, step):                             # the database
+        rows = min(step, n - r0)
         sk = synth.make_sketches_torch(rows, d, nh, seed=4567 + r0, device=dev)
+        if donors is None:
+            donors = sk[:nq_max // 10 + 1].clone()
         ctx.sumsq(sk, out=ss_all[r0:r0 + rows])
         sset.fill(sk, r0)
         del sk
+    q_sk = synth.make_sketches_torch(nq_max, d, nh, seed=99, device=dev)          # the queries are the last rows
+    for k, qi in enumerate(range(0, nq_max, 10)):
+        q_sk[qi] = donors[k] if k % 2 == 0 else donors[k] + q_sk[qi]
+    ctx.sumsq(q_sk, out=ss_all[n:])
+    sset.fill(q_sk, n)
+    del q_sk, donors
     n2 = ss_all.double() / d
     cells = torch.empty((1 << 20, 4), dtype=torch.int32, device=dev)
-    plane_bytes = float(n) * sset.d_pad * 2
-    out = {"workload": "%d resident synthetic sketches, d=%d, two limbs: q query sketches against all of them, Jaccard > 0.1"
-                       % (n, d), "algorithmic_bytes": plane_bytes, "queries": {}}
-    for nq in (1, 16, 1024):
+    coarse_bytes = float(n) * sset.d_pad
+    out = {"workload": "%d resident synthetic sketches, d=%d, two limbs: q query sketches (a tenth of them database samples) "
+                       "against all of them, Jaccard > 0.1" % (n, d),
+           "algorithmic_bytes": coarse_bytes, "limb_plane_bytes": 2 * coarse_bytes, "queries": {}}
+    for nq in (1, 16, 64, 256, 1024):
         walls, kern = [], []
         for r in range(reps + 2):
             torch.cuda.synchronize()
@@ -811,11 +904,22 @@ def search_leg(ctx, dev, n, d, nh, reps=5):
                 walls.append((time.perf_counter() - t0) * 1e3)
                 kern.append(ctx.kernel_ms(1))
         k = float(np.mean(kern))
-        out["queries"][str(nq)] = {"wall_ms": float(np.mean(walls)), "kernel_ms": k, "hits": int(hits),
-                                   "pairs_per_s": float(n) * nq / (float(np.mean(walls)) * 1e-3),
-                                   "two_stage_candidates": int(ctx.pairwise_candidates()),
-                                   "roofline": {"bound": "hbm", "achieved": plane_bytes / (k * 1e-3) / 1e9, "peak": 8000.0,
-                                                "unit": "GB/s", "frac": plane_bytes / (k * 1e-3) / 1e9 / 8000.0}}
+        cand = int(ctx.pairwise_candidates())
+        rec = {"wall_ms": float(np.mean(walls)), "kernel_ms": k, "hits": int(hits),
+               "pairs_per_s": float(n) * nq / (float(np.mean(walls)) * 1e-3), "two_stage_candidates": cand}
+        if cand:
+            rec["filter_ms"], rec["recheck_ms"] = float(ctx.kernel_ms(2)), float(ctx.kernel_ms(3))
+        kt = rec.get("filter_ms", k)                          # the dominant kernel's own time
+        hbm = coarse_bytes * (1 if cand else 2) / (kt * 1e-3) / 1e9
+        flop = 2.0 * d * nq * float(n) / (kt * 1e-3) / 1e12
+        if flop / 5000.0 > hbm / 8000.0:
+            rec["roofline"] = {"bound": "mfma", "achieved": flop, "peak": 5000.0, "unit": "TFLOP/s", "frac": flop / 5000.0,
+                               "kernel": "filter on the coarse plane (int8 MFMA), 2 d q N operations"}
+        else:
+            rec["roofline"] = {"bound": "hbm", "achieved": hbm, "peak": 8000.0, "unit": "GB/s", "frac": hbm / 8000.0,
+                               "kernel": ("streaming filter: the coarse plane once" if cand else
+                                          "streaming exact kernel: both limb planes once")}
+        out["queries"][str(nq)] = rec
     sset.close()
     return out
 

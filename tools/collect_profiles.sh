@@ -34,7 +34,7 @@ run_set() {   # name, command...
     echo "$*" > "$OUT/${name}_pmc/command.txt"
 }
 
-if want c1; then run_set c1 python3 "$REPO/bench.py" --steps 3 --warmup 2 --no-cpu-baseline --pairwise-samples 0 --stream-samples 0 --search-samples 0 || exit 1; fi
+if want c1; then run_set c1 python3 "$REPO/bench.py" --steps 3 --warmup 2 --no-cpu-baseline --pairwise-samples 0 --stream-samples 0 --search-samples 0 --density-samples 0 || exit 1; fi
 if want c2; then export MVS_PAIRWISE_FILTER=1; run_set c2 python3 "$REPO/tools/run_pairwise.py" 100000 2048 4 || exit 1; unset MVS_PAIRWISE_FILTER; fi
 if want c2x; then export MVS_PAIRWISE_FILTER=0; run_set c2x python3 "$REPO/tools/run_pairwise.py" 100000 2048 3 || exit 1; unset MVS_PAIRWISE_FILTER; fi
 if want c2d; then run_set c2d python3 "$REPO/tools/stream_bench.py" 100000 2048 10000 2 || exit 1; fi
