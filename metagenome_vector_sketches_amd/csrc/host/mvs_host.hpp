@@ -136,7 +136,9 @@ inline void sort_unique_u64(std::vector<uint64_t>& vec, size_t first = 0) {   //
 // into one arena pays for no per-line allocation); only the appended ones are sorted.
 inline void parse_u64_tokens(const char* p, const char* end, std::vector<uint64_t>& out) {
     const size_t first = out.size();
-    if (out.capacity() - out.size() < (size_t)(end - p) / 16 + 4) out.reserve(std::max(out.capacity() * 2, out.size() + (size_t)(end - p) / 16 + 4));
+    if (first == 0 && out.capacity() == 0) out.reserve((size_t)(end - p) / 16 + 4);   // a fresh vector: one allocation for a typical line
+    // (a caller's arena is reserved by the caller; past that, push_back's doubling -- a reserve() by estimate here made
+    // every arena reallocate on its last lines: 17-19 characters per hash leave 0.5 % of a bytes / 16 estimate unused)
     bool increasing = true, have_prev = false;
     uint64_t prev = 0;
     auto push = [&](uint64_t v) {
@@ -240,6 +242,9 @@ inline bool read_hash_file(const std::string& path, bool with_names, HashSets& o
     if (pos < size) add_line(pos, size);
 
     const size_t n = recs.size();
+    // (one vector per sample, lines dealt round robin: parsing every worker's contiguous share of the text into one arena
+    // -- no allocation per sample -- measured 0.3-0.5 s SLOWER on 10k x 50k hashes, same box, tools/exp/sketch_ab.py)
+    std::vector<std::vector<uint64_t>> sets(n);
     threads = (unsigned)std::min<size_t>(threads, std::max<size_t>(1, n));
     // an exception in a worker (bad_alloc on a huge line) must not end in std::terminate: it is carried to the caller
     std::exception_ptr worker_error;
@@ -257,31 +262,8 @@ inline bool read_hash_file(const std::string& path, bool with_names, HashSets& o
             });
         for (auto& th : pool) th.join();
     };
-    // Every worker takes a CONTIGUOUS run of lines holding about the same number of text bytes and parses it into ONE
-    // arena (no allocation per sample: half a billion values in 10k vectors meant 4 GB of fresh, zeroed pages before the
-    // copy into the flat array touched another 4 GB); the flat array is then the arenas one after the other.
-    std::vector<size_t> cut(threads + 1, n);
-    cut[0] = 0;
-    for (unsigned t = 1; t < threads; ++t) {
-        const size_t target = size / threads * t;
-        size_t lo = cut[t - 1], hi = n;
-        while (lo < hi) {
-            const size_t mid = (lo + hi) / 2;
-            if (recs[mid].b < target) lo = mid + 1;
-            else hi = mid;
-        }
-        cut[t] = lo;
-    }
-    std::vector<std::vector<uint64_t>> arena(threads);
-    std::vector<int64_t> counts(n, 0);
     run([&](unsigned t) {
-        std::vector<uint64_t>& a = arena[t];
-        if (cut[t + 1] > cut[t]) a.reserve((recs[cut[t + 1] - 1].e - recs[cut[t]].b) / 16 + 16);
-        for (size_t i = cut[t]; i < cut[t + 1]; ++i) {
-            const size_t before = a.size();
-            parse_u64_tokens(buf + recs[i].colon + 1, buf + recs[i].e, a);
-            counts[i] = (int64_t)(a.size() - before);
-        }
+        for (size_t i = t; i < n; i += threads) parse_u64_tokens(buf + recs[i].colon + 1, buf + recs[i].e, sets[i]);
     });
     if (worker_error) {
         if (size) ::munmap((void*)buf, size);
@@ -289,17 +271,18 @@ inline bool read_hash_file(const std::string& path, bool with_names, HashSets& o
     }
     out.names.resize(n);
     out.offsets.assign(n + 1, 0);
-    for (size_t i = 0; i < n; ++i) out.offsets[i + 1] = out.offsets[i] + counts[i];
+    for (size_t i = 0; i < n; ++i) out.offsets[i + 1] = out.offsets[i] + (int64_t)sets[i].size();
     if (!out.hashes.reset((size_t)out.offsets[n])) {
         if (size) ::munmap((void*)buf, size);
         return false;
     }
     uint64_t* flat = out.hashes.data();
     run([&](unsigned t) {
-        if (!arena[t].empty()) memcpy(flat + out.offsets[cut[t]], arena[t].data(), arena[t].size() * 8);
-        std::vector<uint64_t>().swap(arena[t]);
-        if (with_names)
-            for (size_t i = cut[t]; i < cut[t + 1]; ++i) out.names[i].assign(buf + recs[i].b, recs[i].colon - recs[i].b);
+        for (size_t i = t; i < n; i += threads) {
+            if (!sets[i].empty()) memcpy(flat + out.offsets[i], sets[i].data(), sets[i].size() * 8);
+            std::vector<uint64_t>().swap(sets[i]);
+            if (with_names) out.names[i].assign(buf + recs[i].b, recs[i].colon - recs[i].b);
+        }
     });
     if (size) ::munmap((void*)buf, size);
     if (worker_error) std::rethrow_exception(worker_error);

@@ -279,7 +279,7 @@ int apply_option(mvs::Options& o, const OptionSpec& sp, long long v) {
 #ifndef MVS_ABLATIONS
     if (sp.ifield == &mvs::Options::pairwise_debug && v != 0)
         return fail(MVS_E_INVALID, "pairwise_debug needs a library built with -DMVS_ABLATIONS");
-    if (sp.ifield == &mvs::Options::filter_variant && v >= 11)
+    if (sp.ifield == &mvs::Options::filter_variant && v >= 11 && v <= 33)
         return fail(MVS_E_INVALID, "filter_variant %lld is a k-loop ablation: needs -DMVS_ABLATIONS", v);
 #endif
     if (v < sp.lo || v > sp.hi) return fail(MVS_E_INVALID, "option %s: %lld outside [%lld, %lld]", sp.name, v, sp.lo, sp.hi);
