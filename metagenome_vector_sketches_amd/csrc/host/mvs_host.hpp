@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -203,6 +204,13 @@ inline bool read_hash_file(const std::string& path, bool with_names, HashSets& o
     }
     ::close(fd);
     if (threads == 0) threads = std::max(1u, std::thread::hardware_concurrency());
+    const bool lap_on = getenv("MVS_STAGE_TIMING") != nullptr;
+    auto lap_t = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        const auto t = std::chrono::steady_clock::now();
+        if (lap_on) std::cerr << "[stage]   read_hash_file: " << what << " " << std::chrono::duration<double>(t - lap_t).count() << " s" << std::endl;
+        lap_t = t;
+    };
 
     // line table: each worker scans one slice of the file for '\n'.  std::getline yields a final record
     // without '\n' if there is text after the last newline and no extra record for a trailing newline.
@@ -240,6 +248,7 @@ inline bool read_hash_file(const std::string& path, bool with_names, HashSets& o
             pos = e + 1;
         }
     if (pos < size) add_line(pos, size);
+    lap("line table");
 
     const size_t n = recs.size();
     // (one vector per sample, lines dealt round robin: parsing every worker's contiguous share of the text into one arena
@@ -269,6 +278,7 @@ inline bool read_hash_file(const std::string& path, bool with_names, HashSets& o
         if (size) ::munmap((void*)buf, size);
         std::rethrow_exception(worker_error);
     }
+    lap("tokens -> values");
     out.names.resize(n);
     out.offsets.assign(n + 1, 0);
     for (size_t i = 0; i < n; ++i) out.offsets[i + 1] = out.offsets[i] + (int64_t)sets[i].size();
@@ -284,7 +294,9 @@ inline bool read_hash_file(const std::string& path, bool with_names, HashSets& o
             if (with_names) out.names[i].assign(buf + recs[i].b, recs[i].colon - recs[i].b);
         }
     });
+    lap("flat copy");
     if (size) ::munmap((void*)buf, size);
+    lap("unmap");
     if (worker_error) std::rethrow_exception(worker_error);
     return true;
 }
@@ -354,7 +366,7 @@ inline bool write_csr_cache(const std::string& hash_file, const HashSets& sets, 
     std::atomic<bool> ok{write_at(head.data(), head.size(), 0)};
     const size_t value_bytes = (size_t)h.values * 8;
     if (ok && value_bytes) {
-        if (threads == 0) threads = std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
+        if (threads == 0) threads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
         const size_t chunk = (size_t)64 << 20;
         const size_t n_chunks = (value_bytes + chunk - 1) / chunk;
         threads = (unsigned)std::min<size_t>(threads, n_chunks);
