@@ -5,11 +5,13 @@
 # Workloads:  c1  = configs[1] step (bench.py without the configs[2] leg)
 #             c2  = configs[2] pairwise, two-stage comparison (tools/run_pairwise.py 100000 2048)
 #             c2x = configs[2] pairwise, exact kernel on every cell (MVS_PAIRWISE_FILTER=0)
-#             c2d = 100k x 2048 with a 10 %-dense result streamed out (tools/stream_bench.py: dense byte matrix -> CSR)
+#             c2d = 100k x 2048 with a 10 %-dense result streamed out (tools/stream_bench.py: two-stage comparison feeding the
+#                   dense byte matrix, rows encoded on the device)
+#             srch = 64 query sketches against 10^6 resident sketches (tools/search_bench.py: k_search_filter + re-check)
 # The profiled program itself follows `--` (no env / sh wrapper); counters are collected in their own passes.
 set -u
-TAG=${1:-r03}
-WORKLOADS=${2:-"c1 c2 c2x c2d"}
+TAG=${1:-r04}
+WORKLOADS=${2:-"c1 c2 c2x c2d srch"}
 want() { case " $WORKLOADS " in *" $1 "*) return 0;; *) return 1;; esac; }
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/$TAG
@@ -37,10 +39,11 @@ run_set() {   # name, command...
 if want c1; then run_set c1 python3 "$REPO/bench.py" --steps 3 --warmup 2 --no-cpu-baseline --pairwise-samples 0 --stream-samples 0 --search-samples 0 --density-samples 0 || exit 1; fi
 if want c2; then export MVS_PAIRWISE_FILTER=1; run_set c2 python3 "$REPO/tools/run_pairwise.py" 100000 2048 4 || exit 1; unset MVS_PAIRWISE_FILTER; fi
 if want c2x; then export MVS_PAIRWISE_FILTER=0; run_set c2x python3 "$REPO/tools/run_pairwise.py" 100000 2048 3 || exit 1; unset MVS_PAIRWISE_FILTER; fi
-if want c2d; then run_set c2d python3 "$REPO/tools/stream_bench.py" 100000 2048 10000 2 || exit 1; fi
+if want c2d; then run_set c2d python3 "$REPO/tools/stream_bench.py" 100000 2048 10000 2 encoded || exit 1; fi
+if want srch; then run_set srch python3 "$REPO/tools/search_bench.py" 1000000 2048 64 6 || exit 1; fi
 
 cd "$REPO"
-for w in c1 c2 c2x c2d; do
+for w in c1 c2 c2x c2d srch; do
     [ -d "$OUT/${w}_stats" ] || continue
     python3 tools/pmc_summary.py --stats "$OUT/${w}_stats" > "$OUT/${w}_kernel_stats.txt"
     python3 tools/pmc_summary.py "$OUT/${w}_pmc" > "$OUT/${w}_pmc_summary.txt"
@@ -51,6 +54,7 @@ SPECS=""
 [ -d "$OUT/c2_pmc" ] && SPECS="$SPECS configs[2]=$OUT/c2_pmc"
 [ -d "$OUT/c2x_pmc" ] && SPECS="$SPECS configs[2]-exact=$OUT/c2x_pmc"
 [ -d "$OUT/c2d_pmc" ] && SPECS="$SPECS dense-100k=$OUT/c2d_pmc"
+[ -d "$OUT/srch_pmc" ] && SPECS="$SPECS search-64x1M=$OUT/srch_pmc"
 python3 tools/pmc_summary.py --traffic "$OUT/pmc_traffic.json" $SPECS
 # keep the merged-back payload small: the raw per-dispatch CSVs of the PMC passes are summarised above
 find "$OUT" -name "*_counter_collection.csv" -size +4M -delete
