@@ -1433,10 +1433,10 @@ bool two_stage_applies(mvs_ctx* c, const mvs_sketch_set* s, int64_t rb, int64_t 
     const bool streams = mvs::filter_streams_rows(probe, c->opt);
     const bool two_stage = filter_mode != 0 && s->limbs == 2 && s->d_pad <= 32768 &&
                            (filter_mode == 2 ||   // forced: also on small blocks and on sets it was found not to pay for
-                            (block_cells >= 4194304.0 && (re - rb > 16 || (streams && coarse_cached)) &&
+                            ((block_cells >= 4194304.0 || streams) && (re - rb > 16 || (streams && (coarse_cached || few_rows_again))) &&
                              (coarse_cached || !few_rows || few_rows_again) &&
                              !(c->filter_off_id == s->id && c->filter_off_coeff == keep_coeff)));
-    if (!two_stage && few_rows && (re - rb > 16 || streams) && block_cells >= 4194304.0) {
+    if (!two_stage && few_rows && (re - rb > 16 || streams) && (block_cells >= 4194304.0 || streams)) {
         c->few_rows_id = s->id;
         c->few_rows_gen = s->gen;
     }

@@ -42,7 +42,10 @@ for j in (0.1, 0.05):
             ts.append((time.perf_counter() - t0) * 1e3)
             ks.append(ctx.kernel_ms(1))
     cand = ctx.pairwise_candidates()
-    stages = "two-stage: filter %.3f ms + re-check %.3f ms, %d candidates" % (ctx.kernel_ms(2), ctx.kernel_ms(3), cand) if cand else "exact kernel"
+    try:                                    # the filter's interval exists only when the two-stage comparison ran
+        stages = "two-stage: filter %.3f ms + re-check %.3f ms, %d candidates" % (ctx.kernel_ms(2), ctx.kernel_ms(3), cand)
+    except Exception:                       # noqa: BLE001
+        stages = "exact kernel"
     planes_gb = (n + nq) * sset.d_pad * 2 / 1e9
     print("N %d d %d queries %d j > %.2f: %d hits, wall %.3f ms (min %.3f), kernels %.3f ms, %.2f GB of limb planes => %.2f TB/s, %.3g pairs/s (%s)"
           % (n, d, nq, j, cnt, np.mean(ts), np.min(ts), np.mean(ks), planes_gb, planes_gb / (np.mean(ks) * 1e-3) / 1e3,
