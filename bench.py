@@ -763,7 +763,9 @@ def density_leg(ctx, dev, n, d, nh, clusters=(16, 1024, 10000), reps=2):
         points.append(p)
         sset.close()
         del sset
-        torch.cuda.empty_cache()
+        # (no torch.cuda.empty_cache() here: handing torch's cached blocks back to the driver between the points makes the
+        # NEXT stream's device-to-host copies run at ~30 instead of 55 GB/s on this stack -- 10 % point 55 ms instead of 38,
+        # same kernels; tools/exp/link_state3.py variant E)
     return {"workload": "%d synthetic samples, d=%d, clusters of c samples, rows encoded on the device and streamed to the host"
                         % (n, d), "exact_kernel_every_tile_ms": exact_ms, "points": points}
 
