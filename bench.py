@@ -990,6 +990,37 @@ def reference_sketch_leg(hashes, o_all, S, D, cores, orc, ns=128):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def reference_pairwise_leg(skp, n2_text_lines, D, cores, orc, port_cells, n=4096):
+    """-> dict for cpu_baseline.detail.pairwise.reference_functions: the reference's OWN block loader, int32 Eigen product and
+    keep test (oracle/_ref/ref_pairwise32: src/pairwise_comp_optimized.cpp:33-160 compiled from line ranges, loop restated in
+    oracle/ref_pairwise_driver.inc) on the first n sketches, --max_memory_gb 12 (chunk 192), all cores: its rate calibrates the
+    port, and its kept (i, j, P) list must equal the port's."""
+    import shutil
+    import subprocess
+    import tempfile
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "oracle", "_ref", "ref_pairwise32")
+    if not os.path.exists(exe):
+        return {"available": False, "why": "oracle/_ref/ref_pairwise32 not built (needs /root/reference at build time)"}
+    tmp = tempfile.mkdtemp(prefix="mvs_refpw_")
+    try:
+        np.ascontiguousarray(skp[:n], dtype="<i4").tofile(os.path.join(tmp, "vectors.bin"))
+        with open(os.path.join(tmp, "vector_norms.txt"), "w") as f:
+            f.write("".join("s%d %s\n" % (i, t) for i, t in enumerate(n2_text_lines[:n])))
+        t0 = time.perf_counter()
+        r = subprocess.run([exe, os.path.join(tmp, "vectors.bin"), os.path.join(tmp, "vector_norms.txt"), str(D), "12.0", "1", "0",
+                            str(cores)], capture_output=True, text=True, timeout=600)
+        wall = time.perf_counter() - t0
+        if r.returncode != 0:
+            return {"available": False, "why": "reference functions failed: " + r.stderr[-200:]}
+        got = np.array([[int(t) for t in line.split()] for line in r.stdout.splitlines() if line], dtype=np.int64).reshape(-1, 3)
+        want = np.stack([port_cells["row"], port_cells["col"], port_cells["dot"]], axis=1).astype(np.int64).reshape(-1, 3)
+        return {"available": True, "samples": n, "threads": cores, "wall_s": wall, "cells_per_s": float(n) * n / wall,
+                "kept": int(len(got)), "kept_cells_equal_to_port_in_order": bool(np.array_equal(got, want)),
+                "note": "whole process: tile loads from the file, Eigen int32 product, keep test, printing the kept cells"}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def cpu_baseline(hashes, offsets, S, NH, D, dev):
     """The oracle (CPU port of the reference path, kind "port") timed on this host's cores on bounded samples of the
     same workloads, as BASELINE.md section 3 lays out: projection and pairwise each with 8 threads (the reference's
@@ -1054,6 +1085,19 @@ def cpu_baseline(hashes, offsets, S, NH, D, dev):
             "extrapolated_1M_x_2048_s": 1e12 / r16}
         best_pw = max(best_pw, r4, r16)
 
+    # ---- the reference's own pairwise functions on the same first 4096 sketches (calibration + parity on this host) ----
+    try:
+        c4_all = orc.pairwise_rows(skp[:4096], n2[:4096], chunk=192, threads=cores, native=True)
+        # the norms as vector_norms.txt would carry them: "%g" of sqrt(sum v^2 / d); their squares are n2 (fast_norm_sq)
+        n2_lines = ["%g" % x for x in np.sqrt((skp[:4096].astype(np.int64) ** 2).sum(1).astype(np.float64) / D)]
+        assert np.array_equal(np.array([float(t) ** 2 for t in n2_lines]), n2[:4096])
+        detail["pairwise"]["reference_functions"] = reference_pairwise_leg(skp, n2_lines, D, cores, orc, c4_all)
+        rf = detail["pairwise"]["reference_functions"]
+        if rf.get("available"):
+            rf["port_over_reference"] = detail["pairwise"]["%d_threads" % thr_list[-1]]["N4096_cells_per_s"] / rf["cells_per_s"]
+    except Exception as e:      # noqa: BLE001 -- a calibration leg must not take the bench line down
+        detail["pairwise"]["reference_functions"] = {"available": False, "why": repr(e)}
+
     # ---- configs[0]: the reference's toy set, 8 threads, sketch + all-vs-all (fixture committed under tests/golden) ----
     try:
         g = np.load(os.path.join(ROOT, "tests", "golden", "toy_hashes.npz"))
@@ -1075,8 +1119,10 @@ def cpu_baseline(hashes, offsets, S, NH, D, dev):
     t_job = S / best_proj + float(S) * S / best_pw
     detail["seconds_spent"] = time.perf_counter() - t_begin
     detail["calibration"] = ("projection port calibrated against the reference binary in the dev container (BASELINE.md "
-                             "section 3 table: 1.0-2.2x the reference's speed, the faster port is used); pairwise port NOT "
-                             "calibrated against the reference (unbuildable: `bits` submodule absent)")
+                             "section 3 table: 1.0-2.2x the reference's speed, the faster port is used) and on this host "
+                             "(detail.projection.reference_binary); pairwise port calibrated on this host against the reference's "
+                             "own loader / Eigen product / keep test compiled from line ranges (detail.pairwise.reference_functions: "
+                             "port_over_reference); the reference's writers need the absent `bits` submodule and are in neither")
     detail["host_threads_visible"] = visible
     try:                                                  # state the host CPU the baseline ran on
         with open("/proc/cpuinfo") as f:
