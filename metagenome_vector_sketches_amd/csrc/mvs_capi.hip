@@ -56,6 +56,9 @@ struct mvs_ctx {
     void* st_rowptr = nullptr;  size_t st_rowptr_bytes = 0;
     void* st_counts = nullptr;  size_t st_counts_bytes = 0;
     void* st_dense = nullptr;   size_t st_dense_bytes = 0;  // dense results: one byte per cell (mvs_internal.h)
+    void* rb_pinned = nullptr;  size_t rb_bytes = 0;        // pinned landing zone of the small per-block read-backs (row index,
+                                                            // record offsets, counters): a copy into pageable memory makes the
+                                                            // runtime stage and block per copy -- 5 of them per row block
     size_t st_dense_zero = 0;   // the first st_dense_zero bytes of st_dense are zero once the work queued on `stream` is through:
                                 // the tile-granular dense flow needs a cleared matrix, clears it again behind its last block --
                                 // while the link still drains -- and so finds it clean the next time
@@ -206,6 +209,39 @@ int ensure_buf(mvs_ctx* c, void** p, size_t* have, size_t bytes) {
     const size_t want = bytes + std::min<size_t>(bytes / 4, (size_t)256 << 20) + 4096;   // head room: avoid regrowing on small changes
     if (hipMalloc(p, want) != hipSuccess) return fail(MVS_E_NOMEM, "hipMalloc of %zu bytes failed", want);
     *have = want;
+    return MVS_OK;
+}
+
+// Several small device -> host read-backs with ONE synchronisation: the copies land in a pinned buffer of the context (a copy
+// into pageable memory is staged by the runtime and blocks the host once per copy), the stream is synchronised once, then
+// the values are copied out.  Only the thread that drives the context's comparison calls this.
+struct ReadBack {
+    void* dst;
+    const void* src;
+    size_t bytes;
+};
+int read_back(mvs_ctx* c, hipStream_t st, std::initializer_list<ReadBack> items) {
+    size_t total = 0;
+    for (const ReadBack& it : items) total += (it.bytes + 63) & ~(size_t)63;
+    if (c->rb_bytes < total) {
+        if (c->rb_pinned) HIP_TRY(hipHostFree(c->rb_pinned));
+        c->rb_pinned = nullptr;
+        c->rb_bytes = 0;
+        const size_t want = std::max<size_t>(total * 2, (size_t)1 << 20);
+        HIP_TRY(hipHostMalloc(&c->rb_pinned, want, hipHostMallocDefault));
+        c->rb_bytes = want;
+    }
+    size_t at = 0;
+    for (const ReadBack& it : items) {
+        if (it.bytes) HIP_TRY(hipMemcpyAsync((char*)c->rb_pinned + at, it.src, it.bytes, hipMemcpyDeviceToHost, st));
+        at += (it.bytes + 63) & ~(size_t)63;
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    at = 0;
+    for (const ReadBack& it : items) {
+        if (it.bytes) memcpy(it.dst, (const char*)c->rb_pinned + at, it.bytes);
+        at += (it.bytes + 63) & ~(size_t)63;
+    }
     return MVS_OK;
 }
 
@@ -451,6 +487,7 @@ int mvs_ctx_destroy(mvs_ctx* c) {
     if (c->pw_cent) (void)hipFree(c->pw_cent);
     for (void* p : {c->pw_tflag, c->pw_trow, c->pw_tlist, c->pw_cand2, c->pw_ttouch, c->pw_tnew})
         if (p) (void)hipFree(p);
+    if (c->rb_pinned) (void)hipHostFree(c->rb_pinned);
     for (int i = 0; i < 2; ++i) {
         if (c->up_pinned[i]) (void)hipHostFree(c->up_pinned[i]);
         if (c->up_done[i]) (void)hipEventDestroy(c->up_done[i]);
@@ -1316,11 +1353,11 @@ int two_stage_filter(mvs_ctx* c, const mvs_sketch_set* s, const double* d_n2, do
             mvs::launch_tile_count(c->stream, a.tile_flag, ts.n_tr, ts.n_tc, (int*)c->pw_trow);
             rc = check_kernel("k_tile_count");
             if (rc) return rc;
-            HIP_TRY(hipMemcpyAsync(row_count.data(), c->pw_trow, (size_t)ts.n_tr * 4, hipMemcpyDeviceToHost, c->stream));
         }
         // one host synchronisation between the stages: the later launches are sized from these counts
-        HIP_TRY(hipMemcpyAsync(back, c->d_counter, sizeof(back), hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
+        rc = read_back(c, c->stream, {{back, c->d_counter, sizeof(back)},
+                                      {row_count.data(), c->pw_trow, ts.tiles ? (size_t)ts.n_tr * 4 : 0}});
+        if (rc) return rc;
         ts.n_cand = back[2];
         c->last_candidates = ts.n_cand;
         const bool stopped = (back[32] & 0xffffffffULL) != 0;
@@ -1875,10 +1912,10 @@ int encode_block(mvs_ctx* c, BlockCsr& b, hipStream_t ps) {
     rc = mvs::encode_offsets(ps, (unsigned long long*)c->en_size, (unsigned long long*)c->en_off, rows, c->pw_sort,
                              c->pw_sort_bytes, nullptr);
     if (rc) return fail(rc, "scan of the record sizes failed");
-    HIP_TRY(hipMemcpyAsync(b.enc_off.data(), c->en_off, (size_t)(rows + 1) * 8, hipMemcpyDeviceToHost, ps));
-    HIP_TRY(hipMemcpyAsync(b.enc_jac.data(), c->en_jac, (size_t)rows * 4, hipMemcpyDeviceToHost, ps));
-    HIP_TRY(hipMemcpyAsync(b.enc_first.data(), c->en_first, (size_t)rows * 4, hipMemcpyDeviceToHost, ps));
-    HIP_TRY(hipStreamSynchronize(ps));
+    rc = read_back(c, ps, {{b.enc_off.data(), c->en_off, (size_t)(rows + 1) * 8},
+                           {b.enc_jac.data(), c->en_jac, (size_t)rows * 4},
+                           {b.enc_first.data(), c->en_first, (size_t)rows * 4}});
+    if (rc) return rc;
     const size_t total = (size_t)b.enc_off[(size_t)rows];
     rc = ensure_buf(c, &c->st_enc[b.set], &c->st_enc_bytes[b.set], std::max<size_t>(total, 8));
     if (rc) return rc;
@@ -1982,9 +2019,8 @@ int csr_from_dense(mvs_ctx* c, int64_t rb, int64_t re, int64_t n_cols, int64_t d
     rc = mvs::dense_row_ptr(ps, (long long*)c->st_counts, (long long*)c->st_rowptr, rows, c->pw_sort, c->pw_sort_bytes, nullptr);
     if (rc) return fail(rc, "scan of the row counts failed");
     unsigned int h_odd = 0;
-    HIP_TRY(hipMemcpyAsync(out.row_ptr.data(), c->st_rowptr, (size_t)(rows + 1) * 8, hipMemcpyDeviceToHost, ps));
-    HIP_TRY(hipMemcpyAsync(&h_odd, c->d_counter + 4, 4, hipMemcpyDeviceToHost, ps));
-    HIP_TRY(hipStreamSynchronize(ps));
+    rc = read_back(c, ps, {{out.row_ptr.data(), c->st_rowptr, (size_t)(rows + 1) * 8}, {&h_odd, c->d_counter + 4, 4}});
+    if (rc) return rc;
     *odd = h_odd != 0;
     if (*odd) return MVS_OK;
     out.n = out.row_ptr[(size_t)rows];
