@@ -316,3 +316,58 @@ def test_stream_fuzz_seeded(ctx, seed):
     rng = np.random.default_rng(424242 + seed)
     info = fuzz_stream.run_case(ctx, rng, max_n=900)
     assert info["cells"] >= 0
+
+
+@pytest.mark.parametrize("clusters", [1, 3])
+def test_stream_large_block_dense_everywhere_or_a_third(ctx, clusters):
+    """a block large enough for the ping-pong filter by size (24 576 samples: > 4096 tiles), default options.  One cluster:
+    every cell is kept, every tile would be flagged -- the filter stops once 70 % of its tiles are, and the exact kernel
+    does the shard (path 0).  Three clusters: a third of the tiles is flagged, below the stop mark -- the tile-granular
+    comparison feeds the dense byte matrix (path 2).  Either way the stream equals the exact kernel's (pairwise_filter = 0):
+    cell count, per-piece order, and checksums over (row, col, q) of all 3-6 * 10^8 cells."""
+    import ctypes
+    import torch
+    n, d = 24_576, 256
+    sk = synth.make_sketches_torch(n, d, 50_000, seed=7, device="cuda", cluster=n // clusters, shared=0.8)
+    ssq = torch.empty(n, dtype=torch.int64, device="cuda")
+    ctx.set_stream(torch.cuda.current_stream())
+    try:
+        ctx.sumsq(sk, out=ssq)
+        n2 = np.array([orc.norm_sq_from_text(orc.format_norm(float(x))) for x in np.sqrt(ssq.cpu().numpy() / d)])
+        n2_t = torch.from_numpy(n2).to("cuda")
+        ss = ctx.sketch_set(sk)
+        del sk
+
+        def run():
+            seen = {"cells": 0, "rows": 0, "sum_col": 0, "sum_rcq": 0, "diag": 0, "next_row": 0, "ordered": True}
+
+            def count(_user, bp):
+                b = bp.contents
+                seen["ordered"] = seen["ordered"] and b.row_begin == seen["next_row"]
+                seen["next_row"] = b.row_end
+                seen["cells"] += b.n_cells
+                seen["rows"] += b.row_end - b.row_begin
+                rp = np.ctypeslib.as_array(b.row_ptr, shape=(b.row_end - b.row_begin + 1,))
+                col = np.ctypeslib.as_array(b.col, shape=(b.n_cells,)).astype(np.int64)
+                q = np.ctypeslib.as_array(b.q, shape=(b.n_cells,)).astype(np.int64)
+                rows = np.repeat(np.arange(b.row_begin, b.row_end, dtype=np.int64), np.diff(rp))
+                seen["sum_col"] += int(col.sum())
+                seen["sum_rcq"] += int(((rows * 31 + col * 7 + 1) * q % 1000003).sum())
+                seen["diag"] += int((q[rows == col] == 255).sum())
+                return 0
+            cb = _capi.ROW_BLOCK_CB(count)
+            cnt = ctypes.c_int64()
+            rc = ctx.lib.mvs_pairwise_stream(ctx._h, ss._h, n2_t.data_ptr(), _capi.MEM_DEVICE, _capi.KEEP_INT32, 0, n, 0, cb, None,
+                                             ctypes.byref(cnt))
+            assert rc == 0, ctx.lib.mvs_last_error()
+            assert cnt.value == seen["cells"] and seen["rows"] == n and seen["ordered"]
+            return seen, ctx.stream_stats()["two_stage"]
+        got, path = run()
+        ctx.set_option("pairwise_filter", 0)
+        want, path0 = run()
+        ss.close()
+    finally:
+        ctx.set_stream(None)
+    m = n // clusters
+    assert path0 == 0 and path == (0 if clusters == 1 else 2)
+    assert got == want and got["cells"] >= clusters * m * m and got["diag"] == n
