@@ -2418,10 +2418,14 @@ int pairwise_stream_impl(mvs_ctx* c, const mvs_sketch_set* s, const double* norm
             // share of flagged tiles in this row of tiles, extrapolated to the tiles of the whole pass, as list cells
             const double tiles_all = std::max(1.0, (double)n_tr_all * (double)n_tc_all - 0.5 * (double)n_tr_all * (double)(n_tr_all - 1));
             probe_gave_up = rc == kNeedExact;
-            if (probe_gave_up) c->filter_off_id = 0;                     // one tile row is no verdict on the set
             const double est = probe_gave_up ? 1e30
                                              : ((double)ts.n_flagged * 131072.0 + 2.0 * (double)ts.n_cand) / (double)n_tc_all * tiles_all;
-            if (est > (double)c->opt.stream_list_cells) {
+            if (probe_gave_up) {
+                // more than 70 % of the first tile row is dense: its cluster alone covers half of the matrix -- no further
+                // filter pass, the exact kernel does the shard (plan B; the set is marked, two_stage_filter did that)
+                whole_pass = false;
+                c->opt.filter_variant = saved_variant;
+            } else if (est > (double)c->opt.stream_list_cells) {
                 matrix_mode = kM1;
                 whole_pass = false;
             } else {
@@ -2535,6 +2539,25 @@ int pairwise_stream_impl(mvs_ctx* c, const mvs_sketch_set* s, const double* norm
         hipError_t e = hipMemsetAsync(c->d_counter + 4, 0, 8, c->stream);      // the "q beyond a byte" flag
         if (e != hipSuccess) return finish(fail(MVS_E_HIP, "hipMemsetAsync: %s", hipGetErrorString(e)));
     }
+    // M1: which blocks open a filter segment.  Segment 0 is the probe (one tile row); the others end where 4 %, 16 % and 45 %
+    // of the rows are done -- by the tiles of the symmetric square that is 8 %, 22 %, 40 % and 30 % of the filter's work --
+    // option stream_block_rows (tests) makes every block a segment of its own.
+    std::vector<char> seg_first(blocks.size(), 0);
+    int64_t seg_row0 = row_begin;
+    bool seg_exact = false;
+    if (matrix_mode == kM1) {
+        const double marks[3] = {0.04, 0.16, 0.45};   // (0.05 / 0.3, 0.03 / 0.12 / 0.3, 0.1 / 0.4 measure the same within 2 %)
+        int next_mark = 0;
+        for (size_t k = 0; k < blocks.size(); ++k) {
+            const double done = (double)(blocks[k].first - row_begin) / (double)rows_all;
+            bool opens = k <= 1 || c->opt.stream_block_rows > 0;
+            while (next_mark < 3 && done >= marks[next_mark]) {
+                opens = true;
+                ++next_mark;
+            }
+            seg_first[k] = opens ? 1 : 0;
+        }
+    }
     const int saved_filter = c->opt.pairwise_filter;
     // the exact kernel on every tile of rows [rb, re) (plan B; also a block of M1 whose filter pass gave up)
     auto launch_exact = [&](int64_t rb, int64_t re, bool as_dense) -> int {
@@ -2564,8 +2587,26 @@ int pairwise_stream_impl(mvs_ctx* c, const mvs_sketch_set* s, const double* norm
             return two_stage_tiles(c, ts, ts.row_first[(size_t)t0], ts.row_first[(size_t)t1] - ts.row_first[(size_t)t0], true);
         }
         if (matrix_mode == kM1 && as_dense) {
-            tiles_phase = k == 0 && !probe_gave_up;                  // k > 0 is timed as a whole comparison: ev[2] .. ev[3]
-            int r = k == 0 ? (probe_gave_up ? kNeedExact : MVS_OK) : pipeline_filter(rb, re, ts);
+            // The filter runs per SEGMENT of consecutive row blocks (seg_first: the blocks that open one; the probe's tile
+            // row is segment 0): few passes -- each costs a launch over the whole column range and a host round trip -- yet
+            // the first rows are final, and on the link, a millisecond after the call started.
+            int r = MVS_OK;
+            const bool opens = k < seg_first.size() && seg_first[k];
+            if (k == 0) {
+                r = probe_gave_up ? kNeedExact : MVS_OK;
+                seg_row0 = rb;
+                seg_exact = probe_gave_up;
+            } else if (opens) {
+                size_t last = k;
+                while (last + 1 < blocks.size() && !seg_first[last + 1]) ++last;
+                r = pipeline_filter(rb, blocks[last].second, ts);
+                seg_row0 = rb;
+                seg_exact = r == kNeedExact;
+                if (r == MVS_OK) r = recheck_into_matrix(ts);
+            } else if (seg_exact) {
+                r = kNeedExact;
+            }
+            tiles_phase = !(opens && k > 0) && !seg_exact;           // a block that opens a segment is timed ev[2] .. ev[3]
             if (r == kNeedExact) {
                 // nearly every tile of these rows is dense: the exact kernel on all of them.  Flag the tiles it writes itself
                 // -- outside the square, on and above its diagonal -- so that the row passes read them and their mirror
@@ -2583,11 +2624,9 @@ int pairwise_stream_impl(mvs_ctx* c, const mvs_sketch_set* s, const double* norm
                 return launch_exact(rb, re, true);
             }
             if (r) return r;
-            if (k > 0) {                                             // block 0 was re-checked with the probe
-                r = recheck_into_matrix(ts);
-                if (r) return r;
-            }
-            return two_stage_tiles(c, ts, 0, ts.n_flagged, true);
+            // this block's share of the segment's flagged tiles (tile rows relative to the segment's first row)
+            const int t0 = (int)((rb - seg_row0) / 256), t1 = (int)std::min<int64_t>(ts.n_tr, (re - seg_row0 + 255) / 256);
+            return two_stage_tiles(c, ts, ts.row_first[(size_t)t0], ts.row_first[(size_t)t1] - ts.row_first[(size_t)t0], true);
         }
         return launch_exact(rb, re, as_dense);
     };
@@ -2605,7 +2644,7 @@ int pairwise_stream_impl(mvs_ctx* c, const mvs_sketch_set* s, const double* norm
     // launch k + 1 already runs on the context's stream -- memory-bound passes beside a matrix-core-bound kernel instead
     // of between two of them.  (stream_dense = 2: everything on the context's stream, one after the other.)
     side = dense && whole && blocks.size() > 1 &&
-           (c->opt.stream_dense == 3 || (c->opt.stream_dense == 1 && matrix_mode == kNone));
+           (c->opt.stream_dense == 3 || (c->opt.stream_dense == 1 && matrix_mode != kM2));
     if (side) ps = c->post_stream;
     mark("setup", -1);
     if (!blocks.empty()) {

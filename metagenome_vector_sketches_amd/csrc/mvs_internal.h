@@ -50,10 +50,10 @@ struct Options {
     int pairwise_map = 0;           // sub-patch an XCD takes in k_pairwise_pp: 0 = 4 rows x 8 cols, 1 = 8 x 4, 2 = 2 x 16
     int coarse_radix = 1;           // radix of the filter's coarse plane: 1 = smallest residual (default), 0 = ceil(max|v| / 127)
     int stream_dense = 1;           // mvs_pairwise_stream, dense results: 1 = dense byte matrix + count / scan / fill -- on a side
-                                    // stream beside the next block's launch where the exact kernel does whole row blocks, on the
-                                    // context's stream where the two-stage comparison feeds the matrix (its short tile launches
-                                    // lose more to the contention than the bubbles cost); 2 = always the context's stream;
-                                    // 3 = always the side stream; 0 = packed list + sort
+                                    // stream beside the next block's launch (exact kernel on whole row blocks; segmented filter),
+                                    // on the context's stream where ONE filter pass feeds the matrix (short tile launches lose more
+                                    // to the contention than the bubbles cost: 38.4 against 41.6 ms); 2 = always the context's
+                                    // stream; 3 = always the side stream; 0 = packed list + sort
     int encode_stage_words = 64;    // device encoder: LDS words a chunk of unary codes may span before it falls back to atomics (tests)
     int stream_block_rows = 0;      // > 0: upper bound on the rows of a dense row block (tests); 0 = by the budget
     int recheck_mode = 1;           // re-check work split: 1 first round fixed + per-XCD counter, 2 counter only, 0 fixed stride, 3 eighths
@@ -65,12 +65,12 @@ struct Options {
     int stream_list_cells = 1 << 26;   // mvs_pairwise_stream, two-stage comparison: up to this many cells (candidates + cells
                                     // of flagged tiles, mirror images included) leave as ONE packed list; beyond it the dense
                                     // byte matrix takes the flagged tiles (tests lower it)
-    int stream_pipeline = 0;        // mvs_pairwise_stream: 1 = where the result looks dense (first tile row of the filter) the filter
-                                    // itself runs row block by row block, so the link is fed from the first millisecond (pays when
-                                    // the link is the bottleneck: CSR pieces; measured slower for encoded rows, where the device
-                                    // is: 20 filter passes with a host round trip each); 0 (default) = one filter pass over the
-                                    // whole row range first
-    int search_stream = 1;          // blocks of < 1024 rows x >= 4096 columns outside the symmetric schedule: 1 = the streaming
+    int stream_pipeline = 1;        // mvs_pairwise_stream: 1 (default) = where the result looks dense (first tile row of the filter:
+                                    // the probe, 1 % of a pass) the filter runs per SEGMENT of row blocks (5 passes), so the first
+                                    // rows are final -- and on the link -- a millisecond after the call started (10 % dense 100k:
+                                    // encoded rows 37.4 against 38.4 ms, CSR pieces 94.5 against 102.9 ms = 1.02 x the link);
+                                    // 0 = always one filter pass over the whole row range first
+    int search_stream = 1;          // blocks of few rows x >= 4096 columns outside the symmetric schedule: 1 = the streaming
                                     // filter (rows resident in LDS, columns streamed into the matrix cores), 0 = the tile kernels
     int stream_trace = 0;           // 1: mvs_pairwise_stream prints the host-side time line of its row blocks to stderr
     int comm_timeout_s = 600;       // file transport: how long a rank waits for a peer's block before it gives up

@@ -322,8 +322,9 @@ def test_stream_fuzz_seeded(ctx, seed):
 def test_stream_large_block_dense_everywhere_or_a_third(ctx, clusters):
     """a block large enough for the ping-pong filter by size (24 576 samples: > 4096 tiles), default options.  One cluster:
     every cell is kept, every tile would be flagged -- the filter stops once 70 % of its tiles are, and the exact kernel
-    does the shard (path 0).  Three clusters: a third of the tiles is flagged, below the stop mark -- the tile-granular
-    comparison feeds the dense byte matrix (path 2).  Either way the stream equals the exact kernel's (pairwise_filter = 0):
+    does the shard (path 0; with the segmented filter the first tile row alone says so).  Three clusters: a third of the
+    tiles is flagged, below the stop mark -- the tile-granular comparison feeds the dense byte matrix (path 3: filter per
+    segment of row blocks; path 2 with stream_pipeline = 0: one filter pass).  Either way the stream equals the exact kernel's (pairwise_filter = 0):
     cell count, per-piece order, and checksums over (row, col, q) of all 3-6 * 10^8 cells."""
     import ctypes
     import torch
@@ -363,11 +364,13 @@ def test_stream_large_block_dense_everywhere_or_a_third(ctx, clusters):
             assert cnt.value == seen["cells"] and seen["rows"] == n and seen["ordered"]
             return seen, ctx.stream_stats()["two_stage"]
         got, path = run()
+        ctx.set_option("stream_pipeline", 0)
+        got2, path2 = run()
         ctx.set_option("pairwise_filter", 0)
         want, path0 = run()
         ss.close()
     finally:
         ctx.set_stream(None)
     m = n // clusters
-    assert path0 == 0 and path == (0 if clusters == 1 else 2)
-    assert got == want and got["cells"] >= clusters * m * m and got["diag"] == n
+    assert path0 == 0 and path == (0 if clusters == 1 else 3) and path2 == (0 if clusters == 1 else 2)
+    assert got == want and got2 == want and got["cells"] >= clusters * m * m and got["diag"] == n
