@@ -2490,7 +2490,7 @@ int pairwise_stream_impl(mvs_ctx* c, const mvs_sketch_set* s, const double* norm
     if (dense) {
         whole = aligned && matrix_fits;                              // (the matrix flows imply both)
         if (whole) {
-            block_rows = std::max<int64_t>(2048, (rows_all / 16 + 255) / 256 * 256);
+            block_rows = std::max<int64_t>(2048, (rows_all / 16 + 255) / 256 * 256);   // (1/12 .. 1/6 of the rows measure the same or worse)
         } else {
             block_rows = (int64_t)(dense_budget / (size_t)ld) / 256 * 256;
             if (block_rows < 256) dense = false;                     // not even 256 rows of bytes: list blocks instead
