@@ -187,13 +187,16 @@ __global__ __launch_bounds__(64) void k_enc_fill(const long long* __restrict__ r
         const u64 dlt = has_d ? (u64)(unsigned)(succ - c_cur) : 0;
         const u64 quot = dlt >> k;
         const u64 len = has_d ? quot + 1 : 0;
-        u64 incl = len;
+        // 32-bit prefix sum: the quotients of a ROW sum to less than 2 n (k = floor(log2(mean delta))), so a chunk's to less
+        // than 2^32 -- half the cross-lane traffic of a 64-bit scan
+        unsigned incl32 = (unsigned)len;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
-            const u64 up = (u64)__shfl_up((long long)incl, o, 64);
-            if (lane >= o) incl += up;
+            const unsigned up = (unsigned)__shfl_up((int)incl32, o, 64);
+            if (lane >= o) incl32 += up;
         }
-        const u64 total = (u64)__shfl((long long)incl, 63, 64);
+        const u64 incl = incl32;
+        const u64 total = (u64)(unsigned)__shfl((int)incl32, 63, 64);
         const bool chunk_has_d = c0 < nr;
         const u64 w0 = base >> 6, nw = ((base & 63) + total + 63) / 64;   // the words this chunk's unary codes touch
         const bool staged = chunk_has_d && !direct && nw <= (u64)stage_words;
