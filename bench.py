@@ -1087,11 +1087,13 @@ def cpu_baseline(hashes, offsets, S, NH, D, dev):
 
     # ---- the reference's own pairwise functions on the same first 4096 sketches (calibration + parity on this host) ----
     try:
-        c4_all = orc.pairwise_rows(skp[:4096], n2[:4096], chunk=192, threads=cores, native=True)
-        # the norms as vector_norms.txt would carry them: "%g" of sqrt(sum v^2 / d); their squares are n2 (fast_norm_sq)
+        # the norms as vector_norms.txt would carry them: "%g" of sqrt(sum v^2 / d); both sides get the squares of the
+        # parsed text (stod(text)^2, :893-901)
         n2_lines = ["%g" % x for x in np.sqrt((skp[:4096].astype(np.int64) ** 2).sum(1).astype(np.float64) / D)]
-        assert np.array_equal(np.array([float(t) ** 2 for t in n2_lines]), n2[:4096])
+        n2_ref = np.array([float(t) * float(t) for t in n2_lines])
+        c4_all = orc.pairwise_rows(skp[:4096], n2_ref, chunk=192, threads=cores, native=True)
         detail["pairwise"]["reference_functions"] = reference_pairwise_leg(skp, n2_lines, D, cores, orc, c4_all)
+        detail["pairwise"]["reference_functions"]["norms_equal_to_fast_norm_sq"] = bool(np.array_equal(n2_ref, n2[:4096]))
         rf = detail["pairwise"]["reference_functions"]
         if rf.get("available"):
             rf["port_over_reference"] = detail["pairwise"]["%d_threads" % thr_list[-1]]["N4096_cells_per_s"] / rf["cells_per_s"]
