@@ -1119,6 +1119,17 @@ def cpu_baseline(hashes, offsets, S, NH, D, dev):
         detail["toy_8_threads"] = {"error": repr(e)}
 
     t_job = S / best_proj + float(S) * S / best_pw
+    # the same job priced with the REFERENCE's own code where it could be built (oracle/_ref): its `sketch` executable (text
+    # parse + OpenMP projection, as it times itself) and its own pairwise functions (tile loads, Eigen int32 product, keep test)
+    ref_value = None
+    try:
+        rp = detail["projection"]["reference_binary"].get("samples_per_s")
+        rf = detail["pairwise"]["reference_functions"].get("cells_per_s")
+        if rp and rf:
+            ref_value = S / (S / rp + float(S) * S / rf)
+    except Exception:      # noqa: BLE001
+        pass
+    detail["value_with_reference_code"] = ref_value
     detail["seconds_spent"] = time.perf_counter() - t_begin
     detail["calibration"] = ("projection port calibrated against the reference binary in the dev container (BASELINE.md "
                              "section 3 table: 1.0-2.2x the reference's speed, the faster port is used) and on this host "
@@ -1133,7 +1144,7 @@ def cpu_baseline(hashes, offsets, S, NH, D, dev):
     except Exception:   # noqa: BLE001
         detail["host_cpu_model"] = None
     return {"value": S / t_job, "unit": "samples/s (projected and compared all-vs-all)", "cores": cores,
-            "kind": "port",
+            "kind": "port", "value_reference": ref_value,
             "sample": "projection: %s samples x %d hashes per thread count %s, faster of the literal and the restructured "
                       "port, and the reference's own sketch executable on 128 samples where oracle/_ref is present "
                       "(detail.projection.reference_binary); pairwise: N=4096 full square and a row stripe of N=16384, d=%d, chunk 192; toy set with 8 "
