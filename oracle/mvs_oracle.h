@@ -9,10 +9,15 @@
  *   projection half  -- PINNED: checked bit-exact against the reference binaries built from
  *                       /root/reference into oracle/_ref/ (oracle/Makefile) and against the
  *                       known-answer values recorded in SURVEY.md section 4.
- *   pairwise half    -- the reference translation unit needs the absent `bits` submodule and
- *                       is unbuildable here; pinned only by the values SURVEY.md section 4 records
- *                       from the survey session (toy kept-cell count 1291/3721, rows 6 and 20,
- *                       int16 count 1293).  Codec bytes: parity unpinned.
+ *   pairwise half    -- the reference translation units need the absent `bits` submodule and are
+ *                       unbuildable as a whole, but their bits-free functions are not: loaders, int32 /
+ *                       int16 products and keep tests (src/pairwise_comp_optimized.cpp:33-160,
+ *                       _16bits.cpp:40-244) and the first lines of both writers (Jaccard quantiser :654-672;
+ *                       round(dot / d) _16bits.cpp:260-280) are compiled from line ranges into
+ *                       oracle/_ref/ref_pairwise32 / ref_pairwise16 (oracle/Makefile ref_pairwise) and this
+ *                       restatement reproduces their output cell for cell, in order, on 23 recorded runs
+ *                       (tests/golden/ref_pairwise.json): PINNED.  What the writers hand to bits:: after
+ *                       those lines is out of reach.  Codec bytes: parity unpinned.
  *
  * Every function cites the reference file:line it restates (paths relative to /root/reference).
  */

@@ -99,7 +99,10 @@ class Golden:
         """kept cells of the REFERENCE's own pairwise functions (oracle/_ref/ref_pairwise32 / 16, compiled from line ranges
         of src/pairwise_comp_optimized*.cpp; tests/golden/make_golden_pairwise.py): name -> dict(elem, d, vectors,
         norm_lines, norms_sq, runs=[dict(max_memory_gb, chunk, num_shards, shard_idx, cells int64 [kept, 3] in the
-        reference's append order, cells_sha256)])"""
+        reference's append order, cells_sha256)], writer_head=dict(cells int64 [kept, 3] = (row, col, q) for int32 DBs /
+        (row, col, round(dot / d)) for int16 DBs as the bits-free first lines of the reference's writers compute them
+        (:654-672, _16bits.cpp:260-280), in the writer's emission order; row_order; undefined = cells whose Jaccard is NaN
+        in the reference (uint16(round(NaN)) is undefined behaviour there)))"""
         if getattr(self, "_ref_pairwise", None) is None:
             with open(os.path.join(GOLD, "ref_pairwise.json")) as f:
                 meta = json.load(f)["cases"]
@@ -121,8 +124,12 @@ class Golden:
                     x = float(l.split(" ", 1)[1])          # :893-901 stod(text after the first ' ')
                     n2.append(x * x)
                 runs = [dict(r, cells=data[r["cells"]]) for r in c["runs"]]
+                wh = c["writer_head"]
+                head = dict(cells=data[wh["cells"]], row_order=wh["row_order"],
+                            undefined={tuple(x) for x in wh["undefined_in_reference"]})
                 out[name] = dict(elem=c["elem"], d=c["d"], vectors=np.ascontiguousarray(vec, dtype=dt),
-                                 norm_lines=c["norm_lines"], norms_sq=np.array(n2, dtype=np.float64), runs=runs)
+                                 norm_lines=c["norm_lines"], norms_sq=np.array(n2, dtype=np.float64), runs=runs,
+                                 writer_head=head)
                 assert out[name]["vectors"].shape == (c["n"], c["d"])
             self._ref_pairwise = out
         return self._ref_pairwise

@@ -11,7 +11,14 @@ Outputs (data only):
   tests/golden/ref_pairwise.json        cases: dtype, d, norm text lines, runs [{max_memory_gb|-, shards, digest of the cells}]
   tests/golden/ref_pairwise_inputs.npz  the sketch matrices of the cases that are not the toy DB or a formula, and
                                         every run's kept cells (int64 [kept, 3] = i, j, P in the reference's order)
-  tests/golden/toy_pairwise_cells*.txt  (row, col, dot) now REFERENCE output; q stays the oracle's (a9 unpinned)
+                                        and "rows/<case>": the same cells through the bits-free first lines of the
+                                        reference's WRITERS (`rows` mode of the drivers): (row, col, q) -- the Jaccard
+                                        quantiser of src/pairwise_comp_optimized.cpp:654-672 -- for int32 DBs,
+                                        (row, col, round(dot / d)) -- _16bits.cpp:260-280 -- for int16 DBs, in the writer's
+                                        emission order
+  tests/golden/toy_pairwise_cells*.txt  (row, col, dot) REFERENCE output; the int32 list's q column REFERENCE output too
+                                        (writer head); the int16 list's q is this repository's extension (the reference's
+                                        int16 writer stores round(dot / d), never a Jaccard byte)
   kat.json: provenance updated
 
 Run:  make -C oracle ref && python tests/golden/make_golden_pairwise.py
@@ -65,12 +72,17 @@ def write_db(folder, vectors, norm_lines):
         f.write("".join(l + "\n" for l in norm_lines))
 
 
-def run_ref(folder, elem, d, max_memory_gb, num_shards, shard_idx, threads=1):
+def run_ref(folder, elem, d, max_memory_gb, num_shards, shard_idx, threads=1, rows=False):
+    """rows=False: kept cells (i, j, P) in append order; rows=True: the same cells through the bits-free head of the
+    reference's writer -- (row, col, q) for int32 DBs (:654-672), (row, col, round(dot / d)) for int16 DBs
+    (_16bits.cpp:260-280) -- in the order the writer would emit them (its unordered_map's iteration order)"""
     exe = os.path.join(REFBIN, "ref_pairwise32" if elem == 4 else "ref_pairwise16")
     cmd = [exe, os.path.join(folder, "vectors.bin"), os.path.join(folder, "vector_norms.txt"), str(d)]
     if elem == 4:
         cmd.append(repr(float(max_memory_gb)))
     cmd += [str(num_shards), str(shard_idx), str(threads)]
+    if rows:
+        cmd.append("rows")
     out = subprocess.run(cmd, check=True, capture_output=True, text=True).stdout
     return [[int(t) for t in line.split()] for line in out.split("\n") if line]
 
@@ -136,6 +148,36 @@ def main():
                                     "".join("%d %d %d\n" % tuple(c) for c in cells).encode()).hexdigest()})
             print("  %-22s gb=%-5s shards=%d/%d chunk=%-6d kept %6d of %d   == oracle, same order"
                   % (name, gb, k, shards, chunk_of(elem, d, gb), len(cells), len(vectors) ** 2 // shards))
+        # the writer's head on the first (whole) run: quantised Jaccard / rounded dot per cell, rows in the writer's order
+        gb, shards, k = runs[0]
+        assert shards == 1
+        wr = run_ref(folder, elem, d, gb, shards, k, threads=1, rows=True)
+        cells, qs = oracle_cells(vectors, norm_lines, elem, d, gb, shards, k)
+        n2 = [norm_sq(l) for l in norm_lines]
+        if elem == 4:
+            want = {(r, c): q for (r, c, _), q in zip(cells, qs)}
+        else:                                  # std::round: half away from zero
+            want = {(r, c): int(np.sign(dot) * np.floor(abs(dot) / d + 0.5)) for (r, c, dot) in cells}
+        undefined = set()
+        for r, c, q in wr:
+            j_nan = elem == 4 and not np.isfinite(n2[r] + n2[c])
+            if want.get((r, c)) != q:
+                if j_nan:                     # NaN / infinite norms: uint16(round(NaN)) is undefined behaviour in the reference
+                    undefined.add((r, c))
+                    continue
+                sys.exit("ORACLE != REFERENCE WRITER HEAD in case %s: cell (%d, %d) reference %d oracle %s"
+                         % (name, r, c, q, want.get((r, c))))
+        assert len(wr) == len(cells) and {(r, c) for r, c, _ in wr} == set(want)
+        by_row = {}
+        for r, c, q in wr:
+            by_row.setdefault(r, []).append(c)
+        assert all(v == sorted(v) for v in by_row.values())          # columns ascending within a row (:720 asserts it)
+        inputs["rows/%s" % name] = np.array(wr, dtype=np.int64).reshape(-1, 3)
+        rec["writer_head"] = {"cells": "rows/%s" % name, "what": "(row, col, q)" if elem == 4 else "(row, col, round(dot / d))",
+                              "row_order": list(dict.fromkeys(r for r, _, _ in wr)),
+                              "undefined_in_reference": sorted(undefined)}
+        print("  %-22s writer head: %d cells, %d rows in the writer's order, == oracle%s"
+              % (name, len(wr), len(by_row), " (%d cells with non-finite norms excluded)" % len(undefined) if undefined else ""))
         cases[name] = rec
 
     # 1. the reference's toy set (DB written by the reference's own `sketch`)
@@ -218,17 +260,20 @@ def main():
     for elem, fn, case, head in ((4, "toy_pairwise_cells.txt", "toy_int32",
                                   "# row_name col_name dot q   (int32 path, chunk 192, 1 shard; row/col/dot = the "
                                   "reference's own compute_sparse_dot_products_optimized via oracle/_ref/ref_pairwise32; "
-                                  "q = oracle, unpinned)\n"),
+                                  "q = the reference's own quantiser lines :654-672 via the same binary's rows mode)\n"),
                                  (2, "toy_pairwise_cells_int16.txt", "toy_int16",
                                   "# row_name col_name dot q   (int16 path: floating keep test; row/col/dot = the "
                                   "reference's own compute_sparse_dot_products_optimized_16 via oracle/_ref/ref_pairwise16; "
-                                  "q = oracle, unpinned)\n")):
+                                  "q = oracle: the Jaccard byte for an int16 DB is this repository's extension)\n")):
         cells = inputs[cases[case]["runs"][0]["cells"]].tolist()
         vec = toy if elem == 4 else toy16
         _, q = oracle_cells(vec, toy_norm_lines, elem, 2048, 12, 1, 0)
         old = open(os.path.join(GOLD, fn)).read().split("\n")[1:]
         new = ["%s %s %d %d" % (names[r], names[c], dot, qq) for (r, c, dot), qq in zip(cells, q)]
         assert [l for l in old if l] == new, "toy cell list changed"      # the oracle's list WAS right: now it is pinned
+        if elem == 4:                                                      # q column == the reference's quantiser lines
+            wq = {(r, c): qq for r, c, qq in inputs["rows/toy_int32"].tolist()}
+            assert [wq[(r, c)] for r, c, _ in cells] == [int(x) for x in q]
         with open(os.path.join(GOLD, fn), "w") as f:
             f.write(head + "".join(l + "\n" for l in new))
     assert cases["toy_int32"]["runs"][0]["kept"] == 1291 and cases["toy_int16"]["runs"][0]["kept"] == 1293
@@ -237,21 +282,29 @@ def main():
         json.dump({"provenance": "oracle/_ref/ref_pairwise32 + ref_pairwise16: the reference's own functions "
                                  "(src/pairwise_comp_optimized.cpp:33-160, src/pairwise_comp_optimized_16bits.cpp:40-244) "
                                  "compiled from line ranges by `make -C oracle ref_pairwise`; driver loop restated from "
-                                 ":893-982 / _16bits.cpp:343-416 (oracle/ref_pairwise_driver.inc); generated by "
+                                 ":893-982 / _16bits.cpp:343-416 (oracle/ref_pairwise_driver.inc); writer_head = the same "
+                                 "cells through the bits-free first lines of the writers (:654-672 Jaccard quantiser; "
+                                 "_16bits.cpp:260-264 + :274-280 grouping and round(dot / d)), included as reference text "
+                                 "by the same recipe; generated by "
                                  "tests/golden/make_golden_pairwise.py",
                    "cases": cases}, f, separators=(",", ":"))
     np.savez_compressed(os.path.join(GOLD, "ref_pairwise_inputs.npz"), **inputs)
     with open(os.path.join(GOLD, "kat.json")) as f:
         kat = json.load(f)
     prov = {k: v for k, v in kat["provenance"].items() if not k.startswith("oracle-generated")
-            and not k.startswith("reference functions")}
+            and not k.startswith("reference functions")}      # (both "reference functions ..." keys are rewritten below)
     prov["reference functions compiled from line ranges (oracle/_ref/ref_pairwise32, ref_pairwise16: load_matrix_block, "
          "compute_sparse_dot_products_optimized, Matrix16, load_matrix_block_int16, "
          "compute_sparse_dot_products_optimized_16)"] = [
         "ref_pairwise.json (every case: kept cells (i, j, P) in the reference's order)",
         "toy_pairwise_cells.txt, toy_pairwise_cells_int16.txt: columns row, col, dot"]
-    prov["oracle-generated (oracle/mvs_oracle.c; NOT reference output -- the writers need the absent bits submodule)"] = [
-        "toy_pairwise_cells.txt, toy_pairwise_cells_int16.txt: column q only"]
+    prov["reference functions + the bits-free first lines of the reference's writers (src/pairwise_comp_optimized.cpp:654-672 "
+         "Jaccard quantiser; _16bits.cpp:260-264, :274-280 round(dot / d)), same binaries in rows mode"] = [
+        "ref_pairwise.json writer_head / ref_pairwise_inputs.npz rows/<case> (every case)",
+        "toy_pairwise_cells.txt: column q"]
+    prov["oracle-generated (oracle/mvs_oracle.c; NOT reference output -- the reference's int16 writer stores round(dot / d), "
+         "a Jaccard byte for an int16 DB is this repository's extension)"] = [
+        "toy_pairwise_cells_int16.txt: column q only"]
     kat["provenance"] = prov
     with open(os.path.join(GOLD, "kat.json"), "w") as f:
         json.dump(kat, f, indent=1, sort_keys=True)

@@ -198,8 +198,23 @@ def test_pairwise_executable_against_the_references_own_functions(gold, tmp_path
                 assert "Using chunks of size %d" % rn["chunk"] in r.stdout, name
             want = sorted((x[0], x[1]) for x in rn["cells"].tolist())
             shard = os.path.join(out, "shard_%d" % rn["shard_idx"])
-            got = [(r_, c_) for r_, c_, _ in _dump(shard)] if want else []
-            assert got == want, (name, k)
+            dumped = _dump(shard) if want else []
+            assert [(r_, c_) for r_, c_, _ in dumped] == want, (name, k)
+            head = c["writer_head"]
+            if c["elem"] == 4 and rn["num_shards"] == 1:
+                # a9: the decoded q of every cell == the reference's own quantiser lines (:654-672), 16-bit rows included
+                assert dumped == sorted(tuple(x) for x in head["cells"].tolist() if (x[0], x[1]) not in head["undefined"]), name
+        if c["elem"] == 2:
+            # a12: the legacy int16 output's values == the reference's own round(dot / d) lines (_16bits.cpp:274-280)
+            out = str(tmp_path / (name + "_legacy"))
+            r = subprocess.run([exe, "--db", db, "--max_memory_gb", "1", "--num_threads", "4", "--output_folder", out,
+                                "--num_shards", "1", "--shard_idx", "0"], capture_output=True, text=True,
+                               env=dict(os.environ, MVS_INT16_LEGACY_OUTPUT="1"))
+            assert r.returncode == 0, (name, r.stderr)
+            rr = run(os.path.join(BIN, "mvs_dump_matrix"), os.path.join(out, "shard_0"), "--legacy16")
+            assert rr.returncode == 0, rr.stderr
+            got = [tuple(int(t) for t in l.split()) for l in rr.stdout.strip().split("\n") if l]
+            assert got == sorted(tuple(x) for x in c["writer_head"]["cells"].tolist()), name
 
 
 @pytest.mark.parametrize("contexts", [1, 2, 5])

@@ -209,12 +209,56 @@ def test_pairwise_restatement_equals_the_references_own_functions(gold):
             assert hashlib.sha256(text.encode()).hexdigest() == run["cells_sha256"], name
 
 
+def test_quantiser_restatement_equals_the_references_writer_head(gold):
+    """a9 / a12 arithmetic pinned: the same binaries in `rows` mode pass the kept cells through the bits-free first lines
+    of the reference's WRITERS, included as reference text by the recipe -- src/pairwise_comp_optimized.cpp:654-672
+    (inter = P / d, J = inter / (n2r + n2c - inter), min(J, 1), q = uint16(round(255 J)), grouped by row) and
+    _16bits.cpp:260-264 + :274-280 (grouping, round(dot / d)).  The restatement's q / rounded dot equal the reference's for
+    every cell of every case; the columns of a row come out ascending (what :720 relies on).  What follows those lines in
+    the writers (bits:: codecs, file bytes) stays unpinned."""
+    cases = gold.ref_pairwise_cases()
+    n_cells = 0
+    for name, c in cases.items():
+        head = c["writer_head"]
+        whole = [r for r in c["runs"] if r["num_shards"] == 1][0]
+        got = orc.pairwise_rows(c["vectors"], c["norms_sq"], chunk=whole["chunk"], threads=4)
+        if c["elem"] == 4:
+            mine = {(int(x["row"]), int(x["col"])): int(x["q"]) for x in got}
+        else:                                       # std::round: half away from zero (_16bits.cpp:277)
+            d = c["d"]
+            mine = {(int(x["row"]), int(x["col"])): int(np.sign(int(x["dot"])) * np.floor(abs(int(x["dot"])) / d + 0.5))
+                    for x in got}
+        ref = {(r, col): v for r, col, v in head["cells"].tolist() if (r, col) not in head["undefined"]}
+        assert set(mine) - head["undefined"] == set(ref), name
+        assert all(mine[k] == v for k, v in ref.items()), name
+        rows = head["cells"][:, 0].tolist()
+        assert list(dict.fromkeys(rows)) == head["row_order"] and len(set(rows)) == len(head["row_order"])   # rows contiguous
+        for r in head["row_order"]:
+            cols = head["cells"][head["cells"][:, 0] == r, 1]
+            assert np.all(np.diff(cols) > 0), (name, r)
+        n_cells += len(ref)
+    assert n_cells > 40000
+    # the pin spans the scale: the threshold's q = 13 ... the diagonal's 255, and 16-bit values where wrapped products or
+    # odd norms make J negative (uint16(round(255 J)) = 65536 - ..., which the 8-bit-or-16-bit row containers of :718-736 carry)
+    qs = np.concatenate([c["writer_head"]["cells"][:, 2] for c in cases.values() if c["elem"] == 4])
+    assert qs.min() == 13 and 255 in qs and qs.max() > 65000 and len(np.unique(qs)) > 100
+
+
 def test_toy_cell_fixture_carries_reference_provenance(gold):
-    """toy_pairwise_cells*.txt: (row, col, dot) are the reference functions' output (ref_pairwise.json toy runs); only the
-    q column is the oracle's (the writer that quantises needs the absent bits submodule: a9 / a12 stay unpinned)"""
+    """toy_pairwise_cells*.txt: (row, col, dot) are the reference functions' output (ref_pairwise.json toy runs); the int32
+    list's q column is the reference's own quantiser lines (writer head); the int16 list's q is this repository's extension
+    (the reference's int16 writer stores round(dot / d))"""
     cases = gold.ref_pairwise_cases()
     for int16, case in ((False, "toy_int32"), (True, "toy_int16")):
         ref = cases[case]["runs"][0]["cells"]
         assert [(r, c, dot) for r, c, dot, _ in gold.cells(int16=int16)] == [tuple(x) for x in ref.tolist()]
+    wq = {(r, c): q for r, c, q in cases["toy_int32"]["writer_head"]["cells"].tolist()}
+    assert all(wq[(r, c)] == q for r, c, _, q in gold.cells()) and len(wq) == 1291
     prov = gold.kat["provenance"]
     assert any(k.startswith("reference functions compiled from line ranges") for k in prov)
+    assert any("654-672" in k and "toy_pairwise_cells.txt: column q" in v for k, v in prov.items())
+    # SURVEY section 4's 14 (col, q) pins (stand-in build) agree with the reference-text pin
+    by_name = {(gold.names[r], gold.names[c]): q for (r, c), q in wq.items()}
+    for rname, pin in gold.kat["survey_pairwise_pins"].items():
+        for cname, q in zip(pin["cols"], pin["q"]):
+            assert by_name[(rname, cname)] == q

@@ -139,6 +139,16 @@ def test_kept_cells_equal_the_references_own_functions(ctx, gold, pw_filter):
         whole = [r for r in c["runs"] if r["num_shards"] == 1][0]
         rows = np.repeat(np.arange(len(row_ptr) - 1), np.diff(row_ptr))
         assert sorted(zip(rows.tolist(), col.tolist())) == sorted((x[0], x[1]) for x in whole["cells"].tolist()), name
+        # a9 arithmetic against REFERENCE output: q of every cell == the reference's own quantiser lines (:654-672, the
+        # binaries' rows mode), from the cell list's epilogue and from the streamed form; 16-bit values included
+        head = c["writer_head"]
+        if c["elem"] == 4:
+            ref_q = {(r, cc): v for r, cc, v in head["cells"].tolist() if (r, cc) not in head["undefined"]}
+            cells, _ = ctx.pairwise_rows(ss, c["norms_sq"], keep_mode=keep)
+            assert {(int(x["row"]), int(x["col"])): int(x["q"]) for x in cells
+                    if (int(x["row"]), int(x["col"])) not in head["undefined"]} == ref_q, name
+            assert {k: v for k, v in zip(zip(rows.tolist(), col.tolist()), q.tolist())
+                    if k not in head["undefined"]} == ref_q, name
         ss.close()
 
 
