@@ -318,6 +318,108 @@ int main(int argc, char* argv[]) {
         mvs_host::parse_u64_tokens(lead.data(), lead.data() + lead.size(), got);
         CHECK(got.size() == 3 && got[0] == 3 && got[1] == 7 && got[2] == 18446744073709551615ULL);         // leading zeros
     }
+    // the vectorised line parser against the scalar one, which defines the behaviour: random lines of digits and blanks
+    // with every token length from 1 to 22 digits, values around 2^64, runs of blanks, line lengths around multiples of
+    // 64 -- and lines with things the fast path must hand back (signs, tabs, letters, '\r', bytes above 127)
+    {
+        std::mt19937_64 rng(77);
+        size_t fast_lines = 0;
+        for (int round = 0; round < 4000; ++round) {
+            std::string body;
+            const int tokens = (int)(rng() % 40);
+            const bool dirty = round % 5 == 4, wide = round % 3 == 0;       // wide: tokens the fast path hands back
+            for (int t = 0; t < tokens; ++t) {
+                body += std::string(1 + (rng() % 8 == 0 ? rng() % 3 : 0), ' ');
+                const int kind = (int)(rng() % 12);
+                if (kind == 0) body += "18446744073709551615";
+                else if (kind == 1 && wide) body += rng() % 4 ? "18446744073709551616" : "18450000000000000000";
+                else if (kind == 2) body += std::string(rng() % (wide ? 6 : 1), '0') + std::to_string(rng());
+                else {
+                    const int len = 1 + (int)(rng() % (wide ? 22 : 19));
+                    for (int k = 0; k < len; ++k) body += (char)('0' + rng() % 10);
+                }
+                if (dirty && rng() % 6 == 0) body += std::string(1, "\t-+x\r\x80:"[rng() % 7]);
+            }
+            if (rng() % 3 == 0) body += " ";
+            if (rng() % 7 == 0) body += "\r";
+            while (rng() % 2 && body.size() % 64 != 0 && body.size() < 4096) body += " 7";     // some lengths on 64-byte marks
+            const std::string padded = std::string(32, '#') + body + std::string(96, '\n');
+            const char* b = padded.data() + 32;
+            const char* e = b + body.size();
+            const size_t room = mvs_host::count_token_starts(b, e);
+            CHECK(room == mvs_host::count_token_starts_scalar(b, e));
+            std::vector<uint64_t> want(room + 1, 0xdead), got(room + 1, 0xdead);
+            bool inc_w = true, inc_g = true;
+            const size_t nw = mvs_host::parse_u64_raw_scalar(b, e, want.data(), inc_w);
+            const size_t ng = mvs_host::parse_u64_raw(b, e, padded.data(), padded.data() + padded.size(), got.data(), inc_g);
+            CHECK(nw <= room && ng == nw && inc_w == inc_g);
+            CHECK(std::equal(want.begin(), want.begin() + (long)nw, got.begin()));
+#if defined(__x86_64__)
+            if (mvs_host::host_has_avx2()) {
+                size_t nf = 0;
+                bool inc_f = true;
+                std::vector<uint64_t> scratch(room + 1);
+                const char* e2 = e;
+                while (e2 > b && (e2[-1] == '\r' || e2[-1] == ' ')) --e2;
+                fast_lines += mvs_host::parse_u64_line_avx2(b, e2, scratch.data(), nf, inc_f) ? 1 : 0;
+            }
+#endif
+        }
+#if defined(__x86_64__)
+        if (mvs_host::host_has_avx2()) CHECK(fast_lines > 1500 && fast_lines < 3500);   // both outcomes are exercised
+#endif
+        // the sort's two routes: evenly spread values (top bits + insertion sweep) and values that crowd together (full sort)
+        for (int shape = 0; shape < 4; ++shape) {
+            std::vector<uint64_t> v(30000);
+            for (auto& x : v)
+                x = shape == 0 ? rng() : shape == 1 ? (rng() % 1000) << 40 | (rng() % 50) : shape == 2 ? (1ULL << 63) + rng() % 40000
+                                                                                                       : rng() % 18446744073709552ULL;
+            std::set<uint64_t> want(v.begin(), v.end());
+            const size_t k = mvs_host::sort_unique_u64(v.data(), v.size());
+            CHECK(k == want.size() && std::equal(v.begin(), v.begin() + (long)k, want.begin()));
+        }
+    }
+    // read_hash_file writing the cache while it parses: the same sets as without, the cache loads; with lines that fall
+    // short of their room (a duplicate, a bad token: the file is then written from the finished sets) and without (the
+    // writers' own path); with a thread handed back and without; nothing is left behind when no cache is asked for
+    for (int gaps = 0; gaps < 2; ++gaps) {
+        const std::string p = "/tmp/mvs_codec_selftest_hashes2.txt";
+        std::mt19937_64 rng(5);
+        {
+            std::ofstream f(p);
+            for (int i = 0; i < 40; ++i) {
+                f << "s" << i << ":";
+                const int k = i == 7 ? 0 : 1 + (int)(rng() % 3000);
+                for (int j = 0; j < k; ++j) f << " " << (i % 3 == 0 ? (uint64_t)j * 977 + 5 : (rng() % 18446744073709552ULL) | 1);
+                if (gaps && i == 11) f << " 6 6 6";
+                if (gaps && i == 13) f << " 12x 99 100";
+                f << "\n";
+            }
+            f << "not a record\nlast: 3 2 1";
+        }
+        mvs_host::HashSets plain, direct, loaded;
+        CHECK(mvs_host::read_hash_file(p, true, plain, 3));
+        CHECK(!std::filesystem::exists(mvs_host::csr_cache_path(p)));
+        if (gaps) {
+            CHECK(mvs_host::read_hash_file(p, true, direct, 3, p));
+        } else {
+            std::thread writer;
+            CHECK(mvs_host::read_hash_file(p, true, direct, 3, p, &writer));
+            CHECK(writer.joinable());
+            writer.join();
+        }
+        CHECK(!std::filesystem::exists(mvs_host::csr_cache_path(p) + ".part"));
+        CHECK(mvs_host::load_csr_cache(p, loaded));
+        CHECK(plain.names.size() == 41 && plain.names[40] == "last" && plain.offsets[41] - plain.offsets[40] == 3);
+        for (const mvs_host::HashSets* o : {&direct, &loaded}) {
+            CHECK(o->names == plain.names && o->offsets == plain.offsets && o->hashes.size() == plain.hashes.size());
+            for (size_t i = 0; i < plain.hashes.size(); ++i) CHECK(o->hashes[i] == plain.hashes[i]);
+        }
+        for (size_t i = 0; i + 1 < plain.offsets.size(); ++i)
+            for (int64_t j = plain.offsets[i] + 1; j < plain.offsets[i + 1]; ++j) CHECK(plain.hashes[(size_t)j - 1] < plain.hashes[(size_t)j]);
+        std::remove(mvs_host::csr_cache_path(p).c_str());
+        std::remove(p.c_str());
+    }
     CHECK(mvs_host::format_g(56.46254) == "56.4625" && mvs_host::format_g(1234567.0) == "1.23457e+06");
     CHECK(mvs_host::format_g_float(-3.0f) == "-3" && mvs_host::format_g(0.0) == "0");
     std::cout << "mvs_codec_selftest ok" << std::endl;

@@ -17,6 +17,7 @@
 #include <fstream>
 #include <iostream>
 #include <iterator>
+#include <memory>
 #include <sstream>
 #include <string>
 #include <condition_variable>
@@ -31,6 +32,9 @@
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 
 #include "../../../include/mvs_hip.h"
 #include "mvs_codec.hpp"
@@ -85,28 +89,58 @@ struct HashSets {
     std::vector<int64_t> offsets;    // names.size() + 1
 };
 
+// ---------------------------------------------------------------------------------------------------
+// Binary CSR cache of a hash text file: "<hash_file>.csr" next to it.  Parsing the text is what bounds
+// `project_everything sketch` end to end (src/project_everything.cpp:264-281 parses serially; here all host threads
+// parse, and it still is 10-100x the device time), so the parsed form -- names, offsets, unique sorted u64 values,
+// exactly what read_hash_file() returns -- is kept and mapped on the next run (read_hash_file() writes it while it parses
+// when asked to; write_csr_cache() writes one from sets in memory).  The cache is valid only for the
+// text file it was made from (size and modification time are recorded); anything else falls back to the text.
+//   header (64 B): magic "MVSCSR01", u64 text size, i64 text mtime (ns), u64 samples, u64 values, u64 name bytes
+//   i64 offsets[samples + 1], u64 name_ends[samples], names, padding to 8, u64 values[]
+// ---------------------------------------------------------------------------------------------------
+struct CsrHeader {
+    char magic[8];
+    uint64_t text_size;
+    int64_t text_mtime_ns;
+    uint64_t samples, values, name_bytes;
+    uint64_t reserved[2];
+};
+static_assert(sizeof(CsrHeader) == 64, "header layout");
+
+inline std::string csr_cache_path(const std::string& hash_file) { return hash_file + ".csr"; }
+
+inline bool text_identity(const std::string& path, uint64_t& size, int64_t& mtime_ns) {
+    struct stat st;
+    if (::stat(path.c_str(), &st) != 0 || !S_ISREG(st.st_mode)) return false;
+    size = (uint64_t)st.st_size;
+    mtime_ns = (int64_t)st.st_mtim.tv_sec * 1000000000LL + st.st_mtim.tv_nsec;
+    return true;
+}
+
 // Sort + unique of one sample's hashes when the text did not have them in strictly increasing order (the reference's
 // `convert` writes an unordered_set's iteration order, src/project_everything.cpp:222-228).  The projection needs the
 // set, not an order; sorted unique values are what the .csr cache is defined to hold, so the order is kept -- with an LSD
 // radix sort on 11-bit digits over the bits that are actually set (FracMinHash values are < 2^64 / scaled: 5 passes),
 // ~10 ns per value where std::sort takes 60 (that sort was 70 % of the first `sketch` run's parse stage).
-inline void sort_unique_u64(std::vector<uint64_t>& vec, size_t first = 0) {   // the values from index `first` on
-    const size_t n = vec.size() - first;
-    uint64_t* const v = vec.data() + first;
+// Returns the number of unique values, which are left sorted at v[0 .. return).
+inline size_t sort_unique_u64(uint64_t* v, size_t n) {
     if (n < 256) {
         std::sort(v, v + n);
-    } else {
-        uint64_t any = 0;
-        for (size_t i = 0; i < n; ++i) any |= v[i];
-        int bits = 0;
-        while (bits < 64 && (any >> bits) != 0) ++bits;
-        const int passes = std::max(1, (bits + 10) / 11);
-        static thread_local std::vector<uint64_t> tmp;
-        static thread_local std::vector<uint32_t> hist;
-        tmp.resize(n);
+        return (size_t)(std::unique(v, v + n) - v);
+    }
+    uint64_t any = 0;
+    for (size_t i = 0; i < n; ++i) any |= v[i];
+    int bits = 0;
+    while (bits < 64 && (any >> bits) != 0) ++bits;
+    static thread_local std::vector<uint64_t> tmp;
+    static thread_local std::vector<uint32_t> hist;
+    tmp.resize(n);
+    // LSD passes over the 11-bit digits at the given shifts (ascending); v holds the result
+    auto radix = [&](const int* shifts, int passes) {
         hist.assign((size_t)passes * 2048, 0);
         for (size_t i = 0; i < n; ++i)
-            for (int ps = 0; ps < passes; ++ps) ++hist[(size_t)ps * 2048 + ((v[i] >> (11 * ps)) & 2047)];
+            for (int ps = 0; ps < passes; ++ps) ++hist[(size_t)ps * 2048 + ((v[i] >> shifts[ps]) & 2047)];
         uint64_t* src = v;
         uint64_t* dst = tmp.data();
         for (int ps = 0; ps < passes; ++ps) {
@@ -120,33 +154,68 @@ inline void sort_unique_u64(std::vector<uint64_t>& vec, size_t first = 0) {   //
                 run += c;
             }
             if (one_bucket) continue;                          // every value has the same digit here: nothing moves
-            const int sh = 11 * ps;
+            const int sh = shifts[ps];
             for (size_t i = 0; i < n; ++i) dst[h[(src[i] >> sh) & 2047]++] = src[i];
             std::swap(src, dst);
         }
         if (src != v) memcpy(v, src, n * sizeof(uint64_t));
+    };
+    bool sorted = false;
+    if (bits > 22 && n < ((size_t)1 << 21)) {
+        // Hash values are spread evenly: the top 22 bits alone put fewer than 2^21 of them in order but for a few
+        // neighbours, which one insertion sweep settles -- two passes instead of five or six.  A sweep that has to move
+        // more than a few places per value (values that crowd together) is given up for the full sort.
+        const int top[2] = {bits - 22, bits - 11};
+        radix(top, 2);
+        size_t moved = 0;
+        const size_t budget = 4 * n;
+        size_t i = 1;
+        for (; i < n && moved <= budget; ++i) {
+            const uint64_t x = v[i];
+            size_t j = i;
+            while (j > 0 && v[j - 1] > x) {
+                v[j] = v[j - 1];
+                --j;
+            }
+            v[j] = x;
+            moved += i - j;
+        }
+        sorted = i == n && moved <= budget;
     }
-    vec.erase(std::unique(vec.begin() + (long)first, vec.end()), vec.end());
+    if (!sorted) {
+        int all[6];
+        const int passes = std::max(1, (bits + 10) / 11);
+        for (int ps = 0; ps < passes; ++ps) all[ps] = 11 * ps;
+        radix(all, passes);
+    }
+    return (size_t)(std::unique(v, v + n) - v);
+}
+
+// An upper bound of the number of values parse_u64_raw() extracts from [p, end): every extracted value starts at a
+// character above ' ' that follows one at or below ' ' (or the start).  All the parser's whitespace is at or below ' ';
+// treating more characters as blanks can only count more starts.
+inline size_t count_token_starts_scalar(const char* p, const char* end) {
+    size_t count = 0;
+    bool prev_blank = true;
+    for (; p < end; ++p) {
+        const bool blank = (signed char)*p < 0x21;
+        count += (size_t)(!blank && prev_blank);
+        prev_blank = blank;
+    }
+    return count;
 }
 
 // Parse whitespace separated unsigned 64-bit integers the way `while (iss >> hash)` does
 // (src/project_everything.cpp:275-279, src/standalone_projection.cpp:32-35): stop at the first token
-// that is not a number in range.  The reference collects them in an unordered_set; the sorted unique values are
-// the same set.  A line whose values are strictly increasing -- what this repository's `convert` writes -- is
-// unique and sorted as it stands and skips the sort.  The values are APPENDED to `out` (a caller that parses many lines
-// into one arena pays for no per-line allocation); only the appended ones are sorted.
-inline void parse_u64_tokens(const char* p, const char* end, std::vector<uint64_t>& out) {
-    const size_t first = out.size();
-    if (first == 0 && out.capacity() == 0) out.reserve((size_t)(end - p) / 16 + 4);   // a fresh vector: one allocation for a typical line
-    // (a caller's arena is reserved by the caller; past that, push_back's doubling -- a reserve() by estimate here made
-    // every arena reallocate on its last lines: 17-19 characters per hash leave 0.5 % of a bytes / 16 estimate unused)
-    bool increasing = true, have_prev = false;
+// that is not a number in range.  Values are stored at dst in text order (the caller provides room for
+// count_token_starts() of them); `increasing` is cleared when they are not strictly increasing.
+inline size_t parse_u64_raw_scalar(const char* p, const char* end, uint64_t* dst, bool& increasing) {
+    size_t n = 0;
     uint64_t prev = 0;
     auto push = [&](uint64_t v) {
-        increasing = increasing && (!have_prev || v > prev);
+        increasing = increasing && (n == 0 || v > prev);
         prev = v;
-        have_prev = true;
-        out.push_back(v);
+        dst[n++] = v;
     };
     while (true) {
         while (p < end && (*p == ' ' || *p == '\t' || *p == '\r' || *p == '\v' || *p == '\f')) ++p;
@@ -176,13 +245,167 @@ inline void parse_u64_tokens(const char* p, const char* end, std::vector<uint64_
         }
         push(v);
     }
-    if (!increasing) sort_unique_u64(out, first);
+    return n;
 }
+
+#if defined(__x86_64__)
+#define MVS_HOST_AVX2 __attribute__((target("avx2,bmi,popcnt")))
+MVS_HOST_AVX2 inline size_t count_token_starts_avx2(const char* p, const char* end) {
+    size_t count = 0;
+    uint32_t carry = 1;                                       // the start counts as "after a blank"
+    const __m256i lim = _mm256_set1_epi8(0x21);
+    for (; end - p >= 32; p += 32) {
+        const __m256i c = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(p));
+        const uint32_t w = (uint32_t)_mm256_movemask_epi8(_mm256_cmpgt_epi8(lim, c));    // (signed char) c < 0x21
+        count += (size_t)__builtin_popcount(~w & ((w << 1) | carry));
+        carry = w >> 31;
+    }
+    bool prev_blank = carry != 0;
+    for (; p < end; ++p) {
+        const bool blank = (signed char)*p < 0x21;
+        count += (size_t)(!blank && prev_blank);
+        prev_blank = blank;
+    }
+    return count;
+}
+
+// the value of the (up to 16) digits that end at pos: three multiply-adds
+MVS_HOST_AVX2 inline uint64_t last_digits16_avx2(const char* pos, size_t len) {
+    alignas(16) static const uint8_t keep_tail[32] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,
+                                                      255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255};
+    __m128i c = _mm_sub_epi8(_mm_loadu_si128(reinterpret_cast<const __m128i*>(pos - 16)), _mm_set1_epi8('0'));
+    c = _mm_and_si128(c, _mm_loadu_si128(reinterpret_cast<const __m128i*>(keep_tail + len)));
+    const __m128i t1 = _mm_maddubs_epi16(c, _mm_set1_epi16(0x010a));          // bytes (10, 1): pairs of digits -> 0..99
+    const __m128i t2 = _mm_madd_epi16(t1, _mm_set1_epi32(0x00010064));        // words (100, 1): -> 0..9999
+    const __m128i t3 = _mm_packus_epi32(t2, t2);
+    const __m128i t4 = _mm_madd_epi16(t3, _mm_set1_epi32(0x00012710));        // words (10000, 1): -> 0..99999999
+    const uint64_t both = (uint64_t)_mm_cvtsi128_si64(t4);
+    return (both & 0xffffffffu) * 100000000ull + (both >> 32);
+}
+
+// digits [tok, pos) -> value; false: more than 20 digits or a value >= 2^64
+MVS_HOST_AVX2 inline bool digits_to_u64_avx2(const char* tok, const char* pos, uint64_t& v) {
+    const size_t len = (size_t)(pos - tok);
+    if (len <= 16) {
+        v = last_digits16_avx2(pos, len);
+        return true;
+    }
+    if (len > 20) return false;
+    uint64_t hi = 0;
+    for (const char* q = tok; q < pos - 16; ++q) hi = hi * 10 + (uint64_t)(*q - '0');
+    const uint64_t lo = last_digits16_avx2(pos, 16);
+    if (hi > 1844 || (hi == 1844 && lo > 6744073709551615ull)) return false;
+    v = hi * 10000000000000000ull + lo;
+    return true;
+}
+
+// The common line -- decimal digits and blanks, nothing else, tokens of at most 20 digits in range -- without a
+// branch per character: 64 bytes give one bit mask of the non-digits, every set bit ends a token, and a token's last 16
+// digits are converted with three multiply-adds (the wider ones, up to four leading digits, by hand).  Returns false
+// when the line holds anything else (a sign, a tab, a letter, 21 digits, a value >= 2^64): the caller then parses the
+// whole line with parse_u64_raw_scalar(), which defines the behaviour.  The loads reach up to 63 bytes past `end` and 16
+// bytes in front of a token: the caller guarantees map_begin + 16 <= p and end + 64 <= map_end.
+MVS_HOST_AVX2 inline bool parse_u64_line_avx2(const char* p, const char* end, uint64_t* dst, size_t& n_out, bool& increasing) {
+    const __m256i below0 = _mm256_set1_epi8('0' - 1), above9 = _mm256_set1_epi8('9' + 1), blank = _mm256_set1_epi8(' ');
+    size_t n = 0;
+    uint64_t prev = 0, v = 0;
+    bool inc = true;
+    const char* tok = p;
+    for (const char* b = p; b < end; b += 64) {
+        const __m256i c0 = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(b));
+        const __m256i c1 = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(b + 32));
+        const uint64_t d0 = (uint32_t)_mm256_movemask_epi8(_mm256_and_si256(_mm256_cmpgt_epi8(c0, below0), _mm256_cmpgt_epi8(above9, c0)));
+        const uint64_t d1 = (uint32_t)_mm256_movemask_epi8(_mm256_and_si256(_mm256_cmpgt_epi8(c1, below0), _mm256_cmpgt_epi8(above9, c1)));
+        const uint64_t s0 = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(c0, blank));
+        const uint64_t s1 = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(c1, blank));
+        const size_t len = (size_t)(end - b);
+        const uint64_t valid = len >= 64 ? ~0ull : ((1ull << len) - 1);
+        uint64_t nd = ~(d0 | (d1 << 32)) & valid;
+        if (nd != ((s0 | (s1 << 32)) & valid)) return false;
+        if (len < 64) nd |= 1ull << len;                       // the end of the line ends the last token
+        while (nd) {
+            const char* pos = b + __builtin_ctzll(nd);
+            nd &= nd - 1;
+            if (pos > tok) {
+                if (!digits_to_u64_avx2(tok, pos, v)) return false;
+                inc = inc && (n == 0 || v > prev);
+                prev = v;
+                dst[n++] = v;
+            }
+            tok = pos + 1;
+        }
+    }
+    if (tok < end) {                                           // a line whose length is a multiple of 64
+        if (!digits_to_u64_avx2(tok, end, v)) return false;
+        inc = inc && (n == 0 || v > prev);
+        dst[n++] = v;
+    }
+    n_out = n;
+    increasing = increasing && inc;
+    return true;
+}
+
+inline bool host_has_avx2() {
+    static const bool yes = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("bmi") && __builtin_cpu_supports("popcnt") &&
+                            !getenv("MVS_HOST_NO_SIMD");
+    return yes;
+}
+#else
+inline bool host_has_avx2() { return false; }
+#endif
+
+inline size_t count_token_starts(const char* p, const char* end) {
+#if defined(__x86_64__)
+    if (host_has_avx2()) return count_token_starts_avx2(p, end);
+#endif
+    return count_token_starts_scalar(p, end);
+}
+
+// [p, end) -> dst (room for count_token_starts(p, end) values), in text order.  map_begin / map_end: the readable range
+// around the line (the vectorised path reads 16 bytes in front of a token and up to 63 bytes past the line).
+inline size_t parse_u64_raw(const char* p, const char* end, const char* map_begin, const char* map_end, uint64_t* dst, bool& increasing) {
+#if defined(__x86_64__)
+    if (host_has_avx2() && p - map_begin >= 16 && map_end - end >= 64) {
+        const char* e = end;
+        while (e > p && (e[-1] == '\r' || e[-1] == ' ')) --e;             // "\r\n" files; trailing blanks
+        size_t n = 0;
+        bool inc = increasing;
+        if (parse_u64_line_avx2(p, e, dst, n, inc)) {
+            increasing = inc;
+            return n;
+        }
+    }
+#endif
+    return parse_u64_raw_scalar(p, end, dst, increasing);
+}
+
+// The sorted unique values of a line, APPENDED to `out` (a line whose values are strictly increasing -- what this
+// repository's `convert` writes -- is unique and sorted as it stands and skips the sort).
+inline void parse_u64_tokens(const char* p, const char* end, std::vector<uint64_t>& out) {
+    const size_t first = out.size();
+    out.resize(first + count_token_starts(p, end));
+    bool increasing = true;
+    size_t n = parse_u64_raw(p, end, p, end, out.data() + first, increasing);     // no slack around a bare string: scalar
+    if (!increasing) n = sort_unique_u64(out.data() + first, n);
+    out.resize(first + n);
+}
+
+inline bool write_csr_cache(const std::string& hash_file, const HashSets& sets, unsigned threads = 0);
 
 // One record per line.  with_names: "name: h1 h2 ..." (lines without ':' are skipped,
 // src/project_everything.cpp:267-270); otherwise every line is a hash list
 // (src/standalone_projection.cpp:28-35).
-inline bool read_hash_file(const std::string& path, bool with_names, HashSets& out, unsigned threads = 0) {
+// cache_for: when not empty, the binary cache "<cache_for>.csr" (above) is written WHILE the text is parsed: a line's
+// values have their final place in the flat array -- and in the file -- before the line is parsed (pass 1 counts), so a
+// few writer threads copy finished runs of lines into the page cache behind the parsers (4 GB for 10k samples of 50k
+// hashes, at the ~5 GB/s the kernel takes them: started after the parse, beside the projection, that copy was what a first
+// `sketch` run waited for at its end).  If a line turns out shorter than its room (a duplicate, a bad token) the file is
+// written from the finished sets instead.  cache_writer: the thread that completes the cache (it may outlive this call
+// and reads `out`: join it before `out` goes away); without one the call returns when the cache is complete.
+// (Parsing straight into a MAP_SHARED mapping of the cache file -- no copy at all -- took 8 s instead of 0.5 s on the GPU
+// box's file system: a write fault per 4 KiB page of a file mapping, 16 threads deep.)
+inline bool read_hash_file(const std::string& path, bool with_names, HashSets& out, unsigned threads = 0,
+                           const std::string& cache_for = std::string(), std::thread* cache_writer = nullptr) {
     // the file is mapped, not copied: hash lists run to gigabytes of text
     const int fd = ::open(path.c_str(), O_RDONLY);
     if (fd < 0) return false;
@@ -203,6 +426,9 @@ inline bool read_hash_file(const std::string& path, bool with_names, HashSets& o
         buf = (const char*)m;
     }
     ::close(fd);
+    // the mapping is readable up to the end of its last page (zero filled past the end of the file)
+    const size_t page = (size_t)std::max<long>(4096, sysconf(_SC_PAGESIZE));
+    const char* const map_end = buf ? buf + (size + page - 1) / page * page : nullptr;
     if (threads == 0) threads = std::max(1u, std::thread::hardware_concurrency());
     const bool lap_on = getenv("MVS_STAGE_TIMING") != nullptr;
     auto lap_t = std::chrono::steady_clock::now();
@@ -211,6 +437,11 @@ inline bool read_hash_file(const std::string& path, bool with_names, HashSets& o
         if (lap_on) std::cerr << "[stage]   read_hash_file: " << what << " " << std::chrono::duration<double>(t - lap_t).count() << " s" << std::endl;
         lap_t = t;
     };
+    struct Unmap {
+        const char* b;
+        size_t n;
+        ~Unmap() { if (b && n) ::munmap((void*)b, n); }
+    } unmap_text{buf, size};
 
     // line table: each worker scans one slice of the file for '\n'.  std::getline yields a final record
     // without '\n' if there is text after the last newline and no extra record for a trailing newline.
@@ -251,11 +482,8 @@ inline bool read_hash_file(const std::string& path, bool with_names, HashSets& o
     lap("line table");
 
     const size_t n = recs.size();
-    // (one vector per sample, lines dealt round robin: parsing every worker's contiguous share of the text into one arena
-    // -- no allocation per sample -- measured 0.3-0.5 s SLOWER on 10k x 50k hashes, same box, tools/exp/sketch_ab.py)
-    std::vector<std::vector<uint64_t>> sets(n);
     threads = (unsigned)std::min<size_t>(threads, std::max<size_t>(1, n));
-    // an exception in a worker (bad_alloc on a huge line) must not end in std::terminate: it is carried to the caller
+    // an exception in a worker must not end in std::terminate: it is carried to the caller
     std::exception_ptr worker_error;
     std::mutex worker_mutex;
     auto run = [&](auto&& body) {
@@ -271,68 +499,198 @@ inline bool read_hash_file(const std::string& path, bool with_names, HashSets& o
             });
         for (auto& th : pool) th.join();
     };
-    run([&](unsigned t) {
-        for (size_t i = t; i < n; i += threads) parse_u64_tokens(buf + recs[i].colon + 1, buf + recs[i].e, sets[i]);
+    // pass 1: an upper bound of every line's value count (exact for well-formed lines without duplicates) fixes where the
+    // line's values go in the flat array, so that pass 2 can parse them in place (no buffer per sample, no copy into the
+    // flat array afterwards)
+    std::vector<int64_t> room(n + 1, 0);
+    std::atomic<size_t> next_line{0};
+    const size_t grain = std::max<size_t>(1, n / ((size_t)threads * 32));
+    auto for_lines = [&](auto&& body) {
+        next_line = 0;
+        run([&](unsigned) {
+            for (size_t i0 = next_line.fetch_add(grain); i0 < n; i0 = next_line.fetch_add(grain))
+                for (size_t i = i0; i < std::min(n, i0 + grain); ++i) body(i);
+        });
+    };
+    for_lines([&](size_t i) { room[i + 1] = (int64_t)count_token_starts(buf + recs[i].colon + 1, buf + recs[i].e); });
+    if (worker_error) std::rethrow_exception(worker_error);
+    for (size_t i = 0; i < n; ++i) room[i + 1] += room[i];
+    const size_t total_room = (size_t)room[n];
+    lap("count");
+
+    const size_t map_len = std::max<size_t>(total_room * 8, 8);
+    void* base = ::mmap(nullptr, map_len, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (base == MAP_FAILED) return false;
+    ::madvise(base, map_len, MADV_HUGEPAGE);
+    uint64_t* const flat = reinterpret_cast<uint64_t*>(base);
+
+    // the cache writers' shared state lives on the heap: the finishing thread may outlive this call
+    struct CacheJob {
+        std::string text, part;
+        CsrHeader head{};
+        int fd = -1;
+        size_t head_bytes = 0, n = 0;
+        const uint64_t* flat = nullptr;
+        std::vector<int64_t> room;                             // copy: final offsets when no line falls short
+        std::unique_ptr<std::atomic<int64_t>[]> got;           // -1 until line i is parsed, then its value count
+        std::mutex claim;
+        size_t next = 0;
+        std::atomic<bool> stop{false}, bad{false};             // stop: give up quietly; bad: a short line or a write error
+        std::mutex m;
+        std::condition_variable cv;
+        int parse_state = 0;                                   // 1: `out` is complete, 2: the parse failed
+        std::vector<std::thread> helpers;
+    };
+    std::shared_ptr<CacheJob> job;
+    uint64_t name_bytes = 0;
+    if (with_names)
+        for (size_t i = 0; i < n; ++i) name_bytes += recs[i].colon - recs[i].b;
+    std::unique_ptr<std::atomic<int64_t>[]> got_owner(new std::atomic<int64_t>[n ? n : 1]);
+    std::atomic<int64_t>* got = got_owner.get();
+    for (size_t i = 0; i < n; ++i) got[i].store(-1, std::memory_order_relaxed);
+    if (!cache_for.empty() && with_names && total_room) {
+        job = std::make_shared<CacheJob>();
+        job->text = cache_for;
+        job->part = csr_cache_path(cache_for) + ".part";
+        if (text_identity(cache_for, job->head.text_size, job->head.text_mtime_ns))
+            job->fd = ::open(job->part.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+        if (job->fd < 0) {
+            job.reset();
+        } else {
+            job->head_bytes = sizeof(CsrHeader) + (n + 1) * 8 + n * 8 + (size_t)((name_bytes + 7) / 8 * 8);
+            job->n = n;
+            job->flat = flat;
+            job->room = room;
+            job->got = std::move(got_owner);
+            auto writer = [](std::shared_ptr<CacheJob> j) {
+                // claim the next run of finished lines (up to 32 MiB), copy it into the file at its final place
+                while (!j->stop && !j->bad) {
+                    size_t i0, i1;
+                    {
+                        std::unique_lock<std::mutex> lock(j->claim);
+                        i0 = j->next;
+                        if (i0 >= j->n) return;
+                        int64_t g;
+                        while ((g = j->got[i0].load(std::memory_order_acquire)) < 0) {
+                            if (j->stop || j->bad) return;
+                            std::this_thread::sleep_for(std::chrono::microseconds(200));
+                        }
+                        i1 = i0;
+                        while (i1 < j->n && (g = j->got[i1].load(std::memory_order_acquire)) >= 0 &&
+                               (j->room[i1] - j->room[i0]) * 8 < (32 << 20)) {
+                            if (g != j->room[i1 + 1] - j->room[i1]) {          // a short line: every later offset moves
+                                j->bad = true;
+                                return;
+                            }
+                            ++i1;
+                        }
+                        j->next = i1;
+                    }
+                    const char* src = reinterpret_cast<const char*>(j->flat + j->room[i0]);
+                    size_t left = (size_t)(j->room[i1] - j->room[i0]) * 8;
+                    uint64_t off = j->head_bytes + (uint64_t)j->room[i0] * 8;
+                    while (left) {
+                        const ssize_t w = ::pwrite(j->fd, src, left, (off_t)off);
+                        if (w <= 0) {
+                            j->bad = true;
+                            return;
+                        }
+                        src += w;
+                        left -= (size_t)w;
+                        off += (uint64_t)w;
+                    }
+                }
+            };
+            for (int t = 0; t < 3; ++t) job->helpers.emplace_back(writer, job);
+            got = job->got.get();
+        }
+    }
+    // ends the cache job on the way out of a failed parse
+    auto abandon_cache = [&]() {
+        if (!job) return;
+        job->stop = true;
+        for (auto& th : job->helpers) th.join();
+        ::close(job->fd);
+        ::unlink(job->part.c_str());
+        job.reset();
+    };
+
+    // pass 2: parse every line in place; sort + unique where the text was not strictly increasing
+    for_lines([&](size_t i) {
+        bool increasing = true;
+        uint64_t* dst = flat + room[i];
+        size_t k = parse_u64_raw(buf + recs[i].colon + 1, buf + recs[i].e, buf, map_end, dst, increasing);
+        if (!increasing) k = sort_unique_u64(dst, k);
+        got[i].store((int64_t)k, std::memory_order_release);
     });
     if (worker_error) {
-        if (size) ::munmap((void*)buf, size);
+        abandon_cache();
+        ::munmap(base, map_len);
         std::rethrow_exception(worker_error);
     }
     lap("tokens -> values");
-    out.names.resize(n);
+    // lines that gave fewer values than their room (a bad token, duplicates): close the gaps (the cache writers have
+    // stopped at the first of them and touch nothing from there on)
     out.offsets.assign(n + 1, 0);
-    for (size_t i = 0; i < n; ++i) out.offsets[i + 1] = out.offsets[i] + (int64_t)sets[i].size();
-    if (!out.hashes.reset((size_t)out.offsets[n])) {
-        if (size) ::munmap((void*)buf, size);
-        return false;
-    }
-    uint64_t* flat = out.hashes.data();
-    run([&](unsigned t) {
-        for (size_t i = t; i < n; i += threads) {
-            if (!sets[i].empty()) memcpy(flat + out.offsets[i], sets[i].data(), sets[i].size() * 8);
-            std::vector<uint64_t>().swap(sets[i]);
-            if (with_names) out.names[i].assign(buf + recs[i].b, recs[i].colon - recs[i].b);
+    for (size_t i = 0; i < n; ++i) out.offsets[i + 1] = out.offsets[i] + got[i].load(std::memory_order_relaxed);
+    const size_t total = (size_t)out.offsets[n];
+    if (total != total_room) {
+        if (job) {
+            job->bad = true;
+            for (auto& th : job->helpers) th.join();          // nobody reads the flat array while it is compacted
+            job->helpers.clear();
         }
-    });
-    lap("flat copy");
-    if (size) ::munmap((void*)buf, size);
-    lap("unmap");
-    if (worker_error) std::rethrow_exception(worker_error);
-    return true;
-}
-
-// ---------------------------------------------------------------------------------------------------
-// Binary CSR cache of a hash text file: "<hash_file>.csr" next to it.  Parsing the text is what bounds
-// `project_everything sketch` end to end (src/project_everything.cpp:264-281 parses serially; here all host threads
-// parse, and it still is 10-100x the device time), so the parsed form -- names, offsets, unique sorted u64 values,
-// exactly what read_hash_file() returns -- is kept and mapped on the next run.  The cache is valid only for the
-// text file it was made from (size and modification time are recorded); anything else falls back to the text.
-//   header (64 B): magic "MVSCSR01", u64 text size, i64 text mtime (ns), u64 samples, u64 values, u64 name bytes
-//   i64 offsets[samples + 1], u64 name_ends[samples], names, padding to 8, u64 values[]
-// ---------------------------------------------------------------------------------------------------
-struct CsrHeader {
-    char magic[8];
-    uint64_t text_size;
-    int64_t text_mtime_ns;
-    uint64_t samples, values, name_bytes;
-    uint64_t reserved[2];
-};
-static_assert(sizeof(CsrHeader) == 64, "header layout");
-
-inline std::string csr_cache_path(const std::string& hash_file) { return hash_file + ".csr"; }
-
-inline bool text_identity(const std::string& path, uint64_t& size, int64_t& mtime_ns) {
-    struct stat st;
-    if (::stat(path.c_str(), &st) != 0 || !S_ISREG(st.st_mode)) return false;
-    size = (uint64_t)st.st_size;
-    mtime_ns = (int64_t)st.st_mtim.tv_sec * 1000000000LL + st.st_mtim.tv_nsec;
+        for (size_t i = 0; i < n; ++i) {
+            const int64_t g = out.offsets[i + 1] - out.offsets[i];
+            if (out.offsets[i] != room[i] && g) memmove(flat + out.offsets[i], flat + room[i], (size_t)g * 8);
+        }
+    }
+    out.names.assign(n, std::string());
+    if (with_names)
+        for (size_t i = 0; i < n; ++i) out.names[i].assign(buf + recs[i].b, recs[i].colon - recs[i].b);
+    out.hashes.adopt_mapping(base, map_len, flat, total);
+    lap("offsets, names");
+    if (job) {
+        // the finisher: waits for the writers, then either completes the file (head + rename) or, if a line fell short or
+        // a write failed, writes the cache from the finished sets
+        const HashSets* sets = &out;
+        std::thread finisher([job, sets, name_bytes]() {
+            for (auto& th : job->helpers) th.join();
+            bool ok = !job->bad && !job->stop;
+            if (ok) {
+                CsrHeader h = job->head;
+                memcpy(h.magic, "MVSCSR01", 8);
+                h.samples = sets->names.size();
+                h.values = sets->hashes.size();
+                h.name_bytes = name_bytes;
+                std::string head;
+                head.reserve(job->head_bytes);
+                head.append(reinterpret_cast<const char*>(&h), sizeof h);
+                head.append(reinterpret_cast<const char*>(sets->offsets.data()), sets->offsets.size() * 8);
+                uint64_t at = 0;
+                for (const std::string& nm : sets->names) {
+                    at += nm.size();
+                    head.append(reinterpret_cast<const char*>(&at), 8);
+                }
+                for (const std::string& nm : sets->names) head.append(nm);
+                if (at % 8) head.append(8 - at % 8, '\0');
+                ok = head.size() == job->head_bytes && ::pwrite(job->fd, head.data(), head.size(), 0) == (ssize_t)head.size();
+            }
+            ok = (::close(job->fd) == 0) && ok;
+            if (ok && ::rename(job->part.c_str(), csr_cache_path(job->text).c_str()) == 0) return;
+            ::unlink(job->part.c_str());
+            if (job->bad && !job->stop) (void)write_csr_cache(job->text, *sets, 0);
+        });
+        if (cache_writer) *cache_writer = std::move(finisher);
+        else finisher.join();
+    }
     return true;
 }
 
 // best effort: a cache that cannot be written is simply not there next time.  The values (gigabytes: 4 GB for 10k samples
 // of 50k hashes) are written by several threads at their offsets -- the copy into the page cache is what takes the time
 // and one thread moves ~2-5 GB/s; callers that have better things to do run this on a thread of its own.
-inline bool write_csr_cache(const std::string& hash_file, const HashSets& sets, unsigned threads = 0) {
+inline bool write_csr_cache(const std::string& hash_file, const HashSets& sets, unsigned threads) {
     CsrHeader h{};
     memcpy(h.magic, "MVSCSR01", 8);
     if (!text_identity(hash_file, h.text_size, h.text_mtime_ns)) return false;

@@ -193,16 +193,17 @@ static int sketch(const std::string& hash_file, std::string index_folder, int di
     }
     if (!parsed) {
         try {
-            parsed = read_hash_file(hash_file, true, sets);
+            // <hash_file>.csr is written while the text is parsed (mvs_host.hpp; 4 GB for 10k x 50k hashes: started after
+            // the parse, that copy into the page cache was what a first run waited for at its end); what is left of it
+            // runs beside the projection, `cache_writer` is joined on every way out
+            parsed = read_hash_file(hash_file, true, sets, 0, getenv("MVS_NO_CSR_CACHE") ? std::string() : hash_file,
+                                    &cache_writer.th);
         } catch (const std::exception& e) {
             ctx_thread.join();
             std::cerr << "project_everything: reading " << hash_file << ": " << e.what() << std::endl;
             destroy_all();
             return 2;
         }
-        // the parsed form goes to <hash_file>.csr beside the projection (4 GB for 10k x 50k hashes: the copy into the page
-        // cache would otherwise be a third of a first run); `sets` outlives the thread, which is joined on every way out
-        if (parsed && !getenv("MVS_NO_CSR_CACHE")) cache_writer.th = std::thread([&]() { (void)write_csr_cache(hash_file, sets); });
     }
     ctx_thread.join();
     if (!parsed) {                                                                                     // :258-262
