@@ -45,6 +45,8 @@ struct mvs_ctx {
     // two-stage comparison: coarse plane + row statistics of the set `coarse_id` (generation `coarse_gen`),
     // per-call filter constants, candidate list
     void* pw_coarse = nullptr;  size_t pw_coarse_bytes = 0;
+    void* pw_coarse_fm = nullptr;  size_t pw_coarse_fm_bytes = 0;   // fragment-major copy (streaming search filters), built on demand
+    bool coarse_fm_valid = false;           // ... of the cached plane
     void* pw_rows = nullptr;    size_t pw_rows_bytes = 0;
     void* pw_fmeta = nullptr;   size_t pw_fmeta_bytes = 0;
     void* pw_cand = nullptr;    size_t pw_cand_bytes = 0;
@@ -308,6 +310,7 @@ const OptionSpec kOptions[] = {
     {"stream_pipeline", &mvs::Options::stream_pipeline, nullptr, 0, 1},
     {"stream_trace", &mvs::Options::stream_trace, nullptr, 0, 1},
     {"search_stream", &mvs::Options::search_stream, nullptr, 0, 1},
+    {"search_fm", &mvs::Options::search_fm, nullptr, 0, 1},
     {"pairwise_block_cells", nullptr, &mvs::Options::pairwise_block_cells, 1, (1LL << 62)},
 };
 
@@ -468,6 +471,7 @@ int mvs_ctx_destroy(mvs_ctx* c) {
     if (c->pw_out) (void)hipFree(c->pw_out);
     if (c->stage) (void)hipFree(c->stage);
     if (c->pw_coarse) (void)hipFree(c->pw_coarse);
+    if (c->pw_coarse_fm) (void)hipFree(c->pw_coarse_fm);
     if (c->pw_rows) (void)hipFree(c->pw_rows);
     if (c->pw_fmeta) (void)hipFree(c->pw_fmeta);
     if (c->pw_cand) (void)hipFree(c->pw_cand);
@@ -1158,6 +1162,7 @@ namespace {
 int prepare_coarse(mvs_ctx* c, const mvs_sketch_set* s) {
     if (c->coarse_id == s->id && c->coarse_gen == s->gen && c->coarse_mode == c->opt.coarse_radix) return MVS_OK;
     c->coarse_id = 0;
+    c->coarse_fm_valid = false;
     int rc = ensure_buf(c, &c->pw_coarse, &c->pw_coarse_bytes, (size_t)s->n_alloc * (size_t)s->d_pad);
     if (rc) return rc;
     rc = ensure_buf(c, &c->pw_rows, &c->pw_rows_bytes, (size_t)s->n_alloc * sizeof(mvs::CoarseRow));
@@ -1169,6 +1174,19 @@ int prepare_coarse(mvs_ctx* c, const mvs_sketch_set* s) {
     c->coarse_id = s->id;
     c->coarse_gen = s->gen;
     c->coarse_mode = c->opt.coarse_radix;
+    return MVS_OK;
+}
+
+// the fragment-major copy of the cached coarse plane (after prepare_coarse), built the first time a streaming search filter
+// runs on the set
+int prepare_coarse_fm(mvs_ctx* c, const mvs_sketch_set* s) {
+    if (c->coarse_fm_valid) return MVS_OK;
+    int rc = ensure_buf(c, &c->pw_coarse_fm, &c->pw_coarse_fm_bytes, (size_t)s->n_alloc * (size_t)s->d_pad);
+    if (rc) return rc;
+    mvs::launch_coarse_fm(c->stream, (const int8_t*)c->pw_coarse, s->n_alloc, s->d_pad, (int8_t*)c->pw_coarse_fm);
+    rc = check_kernel("k_coarse_fm");
+    if (rc) return rc;
+    c->coarse_fm_valid = true;
     return MVS_OK;
 }
 
@@ -1294,6 +1312,12 @@ int two_stage_filter(mvs_ctx* c, const mvs_sketch_set* s, const double* d_n2, do
     rc = ensure_buf(c, &c->pw_cand, &c->pw_cand_bytes, (size_t)cand_want * sizeof(int2));
     if (rc) return rc;
     a.coarse = (const int8_t*)c->pw_coarse;
+    a.coarse_fm = nullptr;
+    if (c->opt.search_fm && mvs::filter_streams(a, c->opt)) {
+        rc = prepare_coarse_fm(c, s);
+        if (rc) return rc;
+        a.coarse_fm = (const int8_t*)c->pw_coarse_fm;
+    }
     a.fmeta = (const float4*)c->pw_fmeta;
     a.cand_counter = c->d_counter + 2;
     a.cand_limit = limit;

@@ -70,6 +70,8 @@ struct Options {
                                     // rows are final -- and on the link -- a millisecond after the call started (10 % dense 100k:
                                     // encoded rows 37.4 against 38.4 ms, CSR pieces 94.5 against 102.9 ms = 1.02 x the link);
                                     // 0 = always one filter pass over the whole row range first
+    int search_fm = 1;              // the streaming search filter streams from the fragment-major copy of the coarse plane (0: from
+                                    // the row-major plane, as up to round 4's first version)
     int search_stream = 1;          // blocks of few rows x >= 4096 columns outside the symmetric schedule: 1 = the streaming
                                     // filter (rows resident in LDS, columns streamed into the matrix cores), 0 = the tile kernels
     int stream_trace = 0;           // 1: mvs_pairwise_stream prints the host-side time line of its row blocks to stderr
@@ -123,6 +125,10 @@ struct PairwiseArgs {
                                   // 3 = 16 x 2 (set by the launchers for blocks less than 16 tile rows high)
     // two-stage comparison (coarse filter + exact re-check, see "filter" in mvs_pairwise.hip)
     const int8_t* coarse;         // [row * d_pad + k], c = round(v / radix[row]), |c| <= 127
+    const int8_t* coarse_fm;      // the same values fragment-major, or NULL: [(row / 16 * (d_pad / 64) + k / 64) * 1024 + lane * 16],
+                                  // lane = (k / 16 % 4) * 16 + row % 16 -- 1 KiB = one B fragment of v_mfma_i32_16x16x64_i8 for 16
+                                  // rows and 64 k values, what a wave of the streaming search filter loads with ONE coalesced
+                                  // instruction (from the row-major plane the same instruction touches 16 rows, 64 bytes each)
     const float4* fmeta;          // n_alloc: per-row filter constants {s, w, a, p}
     int2* cand;                   // candidate list: {row, col | mirror << 31}
     unsigned long long cand_capacity;
@@ -195,6 +201,8 @@ int launch_pairwise(hipStream_t stream, const PairwiseArgs& a, int mode, int alg
 // that appends candidate pairs, and the exact re-check of the candidates that appends kept cells
 int launch_coarse_build(hipStream_t stream, const int8_t* d_planes, int64_t n, int64_t n_alloc, int d_pad,
                         int8_t* d_coarse, CoarseRow* d_rows, int radix_mode);
+// fragment-major copy of the coarse plane (PairwiseArgs::coarse_fm)
+int launch_coarse_fm(hipStream_t stream, const int8_t* d_coarse, int64_t n_alloc, int d_pad, int8_t* d_fm);
 int launch_filter_meta(hipStream_t stream, const CoarseRow* d_rows, const double* d_norms_sq, int64_t n,
                        int64_t n_alloc, int d, double coeff, float4* d_meta);
 int launch_filter(hipStream_t stream, const PairwiseArgs& a, const Options& opt);
@@ -209,6 +217,8 @@ int launch_cand_gather(hipStream_t stream, const PairwiseArgs& a, int64_t n_regi
 bool filter_flags_tiles(const PairwiseArgs& a, const Options& opt);
 // true when launch_filter would take the streaming search filter for this block (few rows, many columns, no symmetry)
 bool filter_streams_rows(const PairwiseArgs& a, const Options& opt);
+// ... (the streaming search filter reads the fragment-major coarse plane)
+bool filter_streams(const PairwiseArgs& a, const Options& opt);
 void filter_tile_grid(const PairwiseArgs& a, int* n_tr, int* n_tc);
 int launch_tile_count(hipStream_t stream, const unsigned int* d_flags, int n_tr, int n_tc, int* d_row_count);
 int launch_tile_list(hipStream_t stream, const unsigned int* d_flags, int n_tr, int n_tc, const int* d_row_count, int* d_list);

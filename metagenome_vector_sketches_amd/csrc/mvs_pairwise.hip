@@ -1155,17 +1155,23 @@ __global__ __launch_bounds__(512) void k_search_filter(const PairwiseArgs a, int
     const int fr = lane & 15, fq = lane >> 4;
     const int nk = a.d_pad / kSK;
     const int8_t* a_base = As + (size_t)fr * stride + fq * 16;
+    // the chunk grid starts at a multiple of 16 columns (a block of 16 columns is one unit of the fragment-major plane);
+    // columns in front of col_begin get the threshold nothing passes, like those beyond col_end
+    const int64_t col_base = a.col_begin & ~(int64_t)15;
+    const bool fm = a.coarse_fm != nullptr;
+    const int kstep = fm ? 1024 : kSK;                                         // bytes from one k-slice to the next
     for (long long chunk = chunk_first; chunk < chunks_total; chunk += chunk_step) {
         if (*reinterpret_cast<volatile const unsigned int*>(a.cand_stop) != 0u) break;
-        const int64_t c0 = a.col_begin + chunk * 512 + wave * 64;
+        const int64_t c0 = col_base + chunk * 512 + wave * 64;
         const int8_t* bp[4];
         float4 cm[4];
 #pragma unroll
         for (int cb = 0; cb < 4; ++cb) {
             const int64_t col = c0 + cb * 16 + fr;
             const int64_t cl = col < a.n_alloc ? col : a.n_alloc - 1;          // loads stay inside the plane
-            bp[cb] = a.coarse + cl * (int64_t)a.d_pad + fq * 16;
-            cm[cb] = col < a.col_end ? a.fmeta[cl] : make_float4(__builtin_inff(), 0.0f, 0.0f, 0.0f);
+            const int64_t blk = (c0 + cb * 16 < a.n_alloc ? c0 + cb * 16 : a.n_alloc - 16) >> 4;
+            bp[cb] = fm ? a.coarse_fm + blk * (int64_t)nk * 1024 + lane * 16 : a.coarse + cl * (int64_t)a.d_pad + fq * 16;
+            cm[cb] = col >= a.col_begin && col < a.col_end ? a.fmeta[cl] : make_float4(__builtin_inff(), 0.0f, 0.0f, 0.0f);
         }
         v4i acc[RB][4];
 #pragma unroll
@@ -1176,13 +1182,13 @@ __global__ __launch_bounds__(512) void k_search_filter(const PairwiseArgs a, int
 #pragma unroll
         for (int cb = 0; cb < 4; ++cb) {
             b0[cb] = *reinterpret_cast<const v4i*>(bp[cb]);
-            b1[cb] = *reinterpret_cast<const v4i*>(bp[cb] + (nk > 1 ? kSK : 0));
+            b1[cb] = *reinterpret_cast<const v4i*>(bp[cb] + (nk > 1 ? kstep : 0));
         }
         auto step = [&](int ks, v4i (&cur)[4], v4i (&nxt)[4]) {
             // the slice two ahead goes into the buffer that was consumed one step ago (clamped at the end: a harmless reload)
             const int kn = ks + 2 < nk ? ks + 2 : nk - 1;
 #pragma unroll
-            for (int cb = 0; cb < 4; ++cb) nxt[cb] = *reinterpret_cast<const v4i*>(bp[cb] + kn * kSK);
+            for (int cb = 0; cb < 4; ++cb) nxt[cb] = *reinterpret_cast<const v4i*>(bp[cb] + (size_t)kn * kstep);
             v4i fa[RB];
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) fa[rb] = *reinterpret_cast<const v4i*>(a_base + (size_t)rb * 16 * stride + ks * kSK);
@@ -2508,6 +2514,28 @@ int launch_coarse_build(hipStream_t stream, const int8_t* d_planes, int64_t n, i
     return 0;
 }
 
+// row-major coarse plane -> fragment-major (PairwiseArgs::coarse_fm): one wave per KiB, written as whole lines
+__global__ __launch_bounds__(256) void k_coarse_fm(const int8_t* __restrict__ coarse, long long chunks, int nk, int d_pad,
+                                                   int8_t* __restrict__ fm) {
+    const int lane = threadIdx.x & 63;
+    const int fr = lane & 15, fq = lane >> 4;
+    for (long long ch = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); ch < chunks; ch += (long long)gridDim.x * 4) {
+        const long long blk = ch / nk;
+        const int ks = (int)(ch - blk * nk);
+        const v4i v = *reinterpret_cast<const v4i*>(coarse + (blk * 16 + fr) * (long long)d_pad + ks * 64 + fq * 16);
+        *reinterpret_cast<v4i*>(fm + ch * 1024 + lane * 16) = v;
+    }
+}
+
+int launch_coarse_fm(hipStream_t stream, const int8_t* d_coarse, int64_t n_alloc, int d_pad, int8_t* d_fm) {
+    if (n_alloc <= 0) return 0;
+    const int nk = d_pad / 64;
+    const long long chunks = (long long)(n_alloc / 16) * nk;
+    const unsigned grid = (unsigned)std::min<long long>((chunks + 3) / 4, 65536);
+    hipLaunchKernelGGL(k_coarse_fm, dim3(grid), dim3(256), 0, stream, d_coarse, chunks, nk, d_pad, d_fm);
+    return 0;
+}
+
 int launch_filter_meta(hipStream_t stream, const CoarseRow* d_rows, const double* d_norms_sq, int64_t n,
                        int64_t n_alloc, int d, double coeff, float4* d_meta) {
     hipLaunchKernelGGL(k_filter_meta, dim3((unsigned)((n_alloc + 255) / 256)), dim3(256), 0, stream, d_rows,
@@ -2564,9 +2592,9 @@ static int search_filter_rb(const PairwiseArgs& a) {
 
 template <int RB>
 static int launch_search_filter_rb(hipStream_t stream, const PairwiseArgs& a) {
-    const int64_t rows = a.row_end - a.row_begin, cols = a.col_end - a.col_begin;
+    const int64_t rows = a.row_end - a.row_begin;
     const int groups = (int)((rows + 16 * RB - 1) / (16 * RB));
-    const long long chunks = (cols + 511) / 512;
+    const long long chunks = (a.col_end - (a.col_begin & ~(int64_t)15) + 511) / 512;   // the chunk grid starts on a multiple of 16
     // one workgroup per CU (its LDS holds the group's rows); per XCD `slots` column walkers x `groups` row groups
     const int slots = std::max(1, std::min<int>(32 / std::max(1, groups) + (32 % std::max(1, groups) ? 1 : 0), (int)((chunks + 7) / 8)));
     const size_t lds = (size_t)16 * RB * ((size_t)a.d_pad + 16) + (size_t)16 * RB * sizeof(float4);
@@ -2589,11 +2617,13 @@ static int launch_search_filter(hipStream_t stream, const PairwiseArgs& a) {
 static int filter_variant_for(const PairwiseArgs& a, const Options& opt) {
     int v = opt.filter_variant;
     // 50: the streaming search filter -- a block of few rows that is not under the symmetric schedule, against at least
-    // 4096 columns (option search_stream = 0 leaves such blocks to the tile kernels).  Few = up to 320 when the kernel is
-    // picked by size: 64 resident rows read the coarse plane once (10^6 columns: 0.39 ms, 5.2 TB/s), every further group
-    // of 64 reads it again and the groups share an XCD's L2 only in part (256 rows: 1.0 ms against 1.28 ms on 256 x 256
-    // tiles, 512 rows: 1.86 against ~1.5); asked for by number (filter_variant 50) it takes up to 1023 rows.
-    const int64_t few = v == 50 ? 1023 : 320;
+    // 4096 columns (option search_stream = 0 leaves such blocks to the tile kernels).  Few = up to 512 when the kernel is
+    // picked by size: 64 resident rows read the coarse plane once (10^6 columns: 0.35 ms), every further group of 64 reads
+    // it again, mostly from the XCD's L2 -- streamed from the fragment-major plane 256 rows take 0.65 ms and 512 rows 1.18 ms
+    // (1.0 and 1.83 ms from the row-major plane; the 256 x 256 tile filter 1.3 and ~1.5 ms); beyond eight groups the grid no
+    // longer fits the 256 CUs in one round (640 rows: 2.2 ms against 1.6 ms on tiles, 1023 rows 2.2 against 1.9); asked for
+    // by number (filter_variant 50) it takes up to 1023 rows.
+    const int64_t few = v == 50 ? 1023 : 512;
     if ((v < 0 || v == 50) && opt.search_stream != 0 && !a.symmetric && a.row_end - a.row_begin <= few &&
         a.col_end - a.col_begin >= 4096 && search_filter_rb(a) > 0)
         return 50;
@@ -2630,6 +2660,8 @@ int launch_cand_gather(hipStream_t stream, const PairwiseArgs& a, int64_t n_regi
 bool filter_streams_rows(const PairwiseArgs& a, const Options& opt) {
     return a.limbs == 2 && a.d_pad <= 32768 && filter_variant_for(a, opt) == 50;
 }
+
+bool filter_streams(const PairwiseArgs& a, const Options& opt) { return filter_streams_rows(a, opt); }
 
 bool filter_flags_tiles(const PairwiseArgs& a, const Options& opt) {
     if (opt.tile_dense_thr <= 0 || a.limbs != 2 || a.d_pad > 32768) return false;

@@ -138,7 +138,8 @@ def test_search_command_line_resident_index_and_small_hit_buffer(ctx, gold, tmp_
 @pytest.mark.parametrize("d,n_db", [(2048, 6000), (2100, 4500), (4096, 4300), (9000, 4200), (512, 9000)])
 def test_streaming_search_filter_equals_exact_kernel(ctx, d, n_db):
     """k_search_filter -- the query rows' coarse plane resident in LDS (64 / 32 / 16 rows by sketch length), the database
-    columns streamed from global memory straight into the matrix cores -- as the first stage of searches and of
+    columns streamed from global memory (fragment-major copy of the coarse plane: one coalesced KiB per wave instruction)
+    straight into the matrix cores -- as the first stage of searches and of
     rectangular blocks with 1 .. 1023 rows against >= 4096 columns: the same hits as the exact kernel, for query counts
     around every group size, column ranges that start and end off the 512-column chunks, both keep tests, mirrored
     blocks.  (Reference semantics: src/jaccard.py:117-200; scores are checked against the restatement above.)"""
@@ -161,19 +162,23 @@ def test_streaming_search_filter_equals_exact_kernel(ctx, d, n_db):
 
     def run(fn):
         out = []
-        for filt, stream in ((2, 1), (0, 1), (2, 0)):               # streaming filter, exact kernel, tile filter
+        # streaming filter (rows resident), exact kernel, tile filter; last field: the streamed columns come from the
+        # fragment-major copy of the coarse plane (1) or from the row-major plane (0)
+        for filt, stream, variant, fm in ((2, 1, 50, 1), (0, 1, -1, 1), (2, 0, -1, 1), (2, 1, 50, 0), (2, 1, -1, 1)):
             ctx.set_option("pairwise_filter", filt)
             ctx.set_option("search_stream", stream)
-            ctx.set_option("filter_variant", 50 if stream else -1)  # by number: up to 1023 rows (by size: up to 320)
+            ctx.set_option("search_fm", fm)
+            ctx.set_option("filter_variant", variant)    # 50 by number: up to 1023 rows (by size: up to 512)
             cnt = fn()
             ctx.synchronize()
             out.append((sorted(map(tuple, cells[:cnt].cpu().numpy().tolist())), ctx.pairwise_candidates()))
-        assert out[0][0] == out[1][0] == out[2][0]
+        assert all(o[0] == out[1][0] for o in out)
         assert out[0][1] > 0 and out[1][1] == 0                      # the two-stage comparison ran / did not run
+        assert out[3][1] == out[0][1]                                # either plane layout: the same candidates
         return out[0][0]
 
     total = 0
-    for nq in (1, 5, 16, 17, 33, 64, 65, 200, 1023):
+    for nq in (1, 5, 16, 17, 33, 64, 65, 128, 129, 200, 256, 300, 385, 512, 513, 1023):
         got = run(lambda: ctx.search_block(ss, n2_t, 0.1, n_db, n_db + nq, 0, n_db, cells))
         total += len(got)
         assert all(n_db <= r < n_db + nq and 0 <= c < n_db for r, c, _, _ in got)
