@@ -217,7 +217,7 @@ int launch_cand_gather(hipStream_t stream, const PairwiseArgs& a, int64_t n_regi
 bool filter_flags_tiles(const PairwiseArgs& a, const Options& opt);
 // true when launch_filter would take the streaming search filter for this block (few rows, many columns, no symmetry)
 bool filter_streams_rows(const PairwiseArgs& a, const Options& opt);
-// ... (the streaming search filter reads the fragment-major coarse plane)
+// ... or another filter kernel that reads the fragment-major coarse plane (the ping-pong tile filter)
 bool filter_streams(const PairwiseArgs& a, const Options& opt);
 void filter_tile_grid(const PairwiseArgs& a, int* n_tr, int* n_tc);
 int launch_tile_count(hipStream_t stream, const unsigned int* d_flags, int n_tr, int n_tc, int* d_row_count);

@@ -1394,6 +1394,12 @@ __global__ __launch_bounds__(512, 2) void k_pairwise_pp(const PairwiseArgs a, in
         if (*reinterpret_cast<volatile const unsigned int*>(a.cand_stop) != 0u) return;
     }
     // ---- LDS-DMA sources: piece = 16 LDS rows of 64 B, lane -> row piece*16 + lane/4, 16-byte slot lane%4 ----
+    // FM (filter, fragment-major coarse plane, tile origins on multiples of 16 samples): a piece is ONE contiguous KiB of
+    // the plane -- 16 samples x 64 k values in fragment order -- so a copy instruction touches 8 whole lines instead of 16
+    // half lines, its LDS image is the fragment itself (lane l's 16 bytes at l * 16: no swizzle, no bank conflict) and the
+    // next k-slice is 1 KiB further on
+    const bool fmode = MODE == 2 && a.coarse_fm != nullptr && (((a.row_begin | a.col_begin) & 15) == 0);
+    const int kstep = fmode ? 1024 : kSK;
     const int8_t* src[kPPW];
 #pragma unroll
     for (int p = 0; p < kPPW; ++p) {
@@ -1404,6 +1410,10 @@ __global__ __launch_bounds__(512, 2) void k_pairwise_pp(const PairwiseArgs a, in
         const int c = (lane & 3) ^ swz16(s);
         const int64_t sample = (is_b ? j0 : i0) + s;
         src[p] = (MODE == 2 ? a.coarse : a.planes) + (sample * L + limb) * (int64_t)a.d_pad + c * 16;
+        if (fmode) {
+            const int64_t blk = ((is_b ? j0 : i0) + ((wave * kPPW + p) * 16 - (is_b ? L * TM : 0))) >> 4;
+            src[p] = a.coarse_fm + blk * (int64_t)(a.d_pad / kSK) * 1024 + lane * 16;
+        }
     }
     // waves 0-3 copy the A region (pieces 0..15), waves 4-7 the B region: the policy is wave-uniform
     const bool nt_wave = NT == 3 || (NT == 1 && wave >= 4) || (NT == 2 && wave < 4);
@@ -1422,11 +1432,11 @@ __global__ __launch_bounds__(512, 2) void k_pairwise_pp(const PairwiseArgs a, in
     int a_off[8], b_off[4];
 #pragma unroll
     for (int i = 0; i < 8; ++i)
-        a_off[i] = MODE == 2 ? (wm * 128 + i * 16 + fr) * kSK + coff
+        a_off[i] = MODE == 2 ? (fmode ? (wm * 8 + i) * 1024 + lane * 16 : (wm * 128 + i * 16 + fr) * kSK + coff)
                              : ((i & 1) * TM + wm * 64 + (i >> 1) * 16 + fr) * kSK + coff;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-        b_off[i] = kRegion + (MODE == 2 ? (wn * 64 + i * 16 + fr) * kSK + coff
+        b_off[i] = kRegion + (MODE == 2 ? (fmode ? (wn * 4 + i) * 1024 + lane * 16 : (wn * 64 + i * 16 + fr) * kSK + coff)
                                         : ((i & 1) * TN + wn * 32 + (i >> 1) * 16 + fr) * kSK + coff);
     float4 fm = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     if constexpr (MODE == 2) {   // the epilogue's row / column constants: one per thread, on their way during the k-loop
@@ -1447,7 +1457,7 @@ __global__ __launch_bounds__(512, 2) void k_pairwise_pp(const PairwiseArgs a, in
 #endif
 #pragma unroll
     for (int st = 0; st < D; ++st)
-        if (st < nk) stage_copy(st, st * kSK);
+        if (st < nk) stage_copy(st, st * kstep);
     {   // slice 0 has landed <=> only the copies of the slices issued after it are outstanding
         const int younger = (nk < D ? nk : D) - 1;
         if (younger >= 2) wait_vmcnt<2 * kPPW>();
@@ -1468,7 +1478,7 @@ __global__ __launch_bounds__(512, 2) void k_pairwise_pp(const PairwiseArgs a, in
                 if (s + D < nk && ABL != 2) {
 #pragma unroll
                     for (int p = ph * CP; p < (ph + 1) * CP; ++p)
-                        copy_piece(src[p] + (s + D) * kSK, smem + fill * kStage + (wave * kPPW + p) * 1024);
+                        copy_piece(src[p] + (s + D) * kstep, smem + fill * kStage + (wave * kPPW + p) * 1024);
                 }
             };
             if (copies_first) copies();
@@ -2661,7 +2671,11 @@ bool filter_streams_rows(const PairwiseArgs& a, const Options& opt) {
     return a.limbs == 2 && a.d_pad <= 32768 && filter_variant_for(a, opt) == 50;
 }
 
-bool filter_streams(const PairwiseArgs& a, const Options& opt) { return filter_streams_rows(a, opt); }
+bool filter_streams(const PairwiseArgs& a, const Options& opt) {
+    if (a.limbs != 2 || a.d_pad > 32768) return false;
+    const int v = filter_variant_for(a, opt);
+    return v == 50 || (v >= 7 && v <= 10) || (v >= 40 && v <= 42);      // the streaming search filter, the ping-pong tile filter
+}
 
 bool filter_flags_tiles(const PairwiseArgs& a, const Options& opt) {
     if (opt.tile_dense_thr <= 0 || a.limbs != 2 || a.d_pad > 32768) return false;
