@@ -46,6 +46,8 @@ struct mvs_ctx {
     // per-call filter constants, candidate list
     void* pw_coarse = nullptr;  size_t pw_coarse_bytes = 0;
     void* pw_coarse_fm = nullptr;  size_t pw_coarse_fm_bytes = 0;   // fragment-major copy (streaming search filters), built on demand
+    void* pw_planes_fm = nullptr;  size_t pw_planes_fm_bytes = 0;   // fragment-major copy of the limb planes of set planes_fm_id
+    unsigned long long planes_fm_id = 0, planes_fm_gen = 0;         // (generation planes_fm_gen), for the ping-pong exact kernel
     bool coarse_fm_valid = false;           // ... of the cached plane
     void* pw_rows = nullptr;    size_t pw_rows_bytes = 0;
     void* pw_fmeta = nullptr;   size_t pw_fmeta_bytes = 0;
@@ -310,7 +312,7 @@ const OptionSpec kOptions[] = {
     {"stream_pipeline", &mvs::Options::stream_pipeline, nullptr, 0, 1},
     {"stream_trace", &mvs::Options::stream_trace, nullptr, 0, 1},
     {"search_stream", &mvs::Options::search_stream, nullptr, 0, 1},
-    {"search_fm", &mvs::Options::search_fm, nullptr, 0, 1},
+    {"fragment_major", &mvs::Options::fragment_major, nullptr, 0, 1},
     {"pairwise_block_cells", nullptr, &mvs::Options::pairwise_block_cells, 1, (1LL << 62)},
 };
 
@@ -472,6 +474,7 @@ int mvs_ctx_destroy(mvs_ctx* c) {
     if (c->stage) (void)hipFree(c->stage);
     if (c->pw_coarse) (void)hipFree(c->pw_coarse);
     if (c->pw_coarse_fm) (void)hipFree(c->pw_coarse_fm);
+    if (c->pw_planes_fm) (void)hipFree(c->pw_planes_fm);
     if (c->pw_rows) (void)hipFree(c->pw_rows);
     if (c->pw_fmeta) (void)hipFree(c->pw_fmeta);
     if (c->pw_cand) (void)hipFree(c->pw_cand);
@@ -1190,6 +1193,25 @@ int prepare_coarse_fm(mvs_ctx* c, const mvs_sketch_set* s) {
     return MVS_OK;
 }
 
+// the fragment-major copy of the set's limb planes, cached in the context until the set (or its contents) changes:
+// a.planes_fm is set when the exact kernel that reads it will run for this block
+int attach_planes_fm(mvs_ctx* c, const mvs_sketch_set* s, mvs::PairwiseArgs& a, bool wanted) {
+    a.planes_fm = nullptr;
+    if (!wanted || !c->opt.fragment_major || s->limbs != 2) return MVS_OK;
+    if (!(c->planes_fm_id == s->id && c->planes_fm_gen == s->gen)) {
+        c->planes_fm_id = 0;
+        int rc = ensure_buf(c, &c->pw_planes_fm, &c->pw_planes_fm_bytes, (size_t)s->n_alloc * 2 * (size_t)s->d_pad);
+        if (rc) return rc;
+        mvs::launch_coarse_fm(c->stream, s->planes, s->n_alloc, s->d_pad, (int8_t*)c->pw_planes_fm, 2);
+        rc = check_kernel("k_coarse_fm(limb planes)");
+        if (rc) return rc;
+        c->planes_fm_id = s->id;
+        c->planes_fm_gen = s->gen;
+    }
+    a.planes_fm = (const int8_t*)c->pw_planes_fm;
+    return MVS_OK;
+}
+
 // One comparison of rows [rb,re) x columns [cb,ce) appending to `raw` (device) after the first `start`
 // cells; the running count is left in c->d_counter[0].  Two-stage (filter + exact re-check of the
 // candidates) when the set allows it, otherwise the exact MFMA / vector-ALU kernel on every cell.
@@ -1235,6 +1257,7 @@ struct TwoStage {
 void fill_args(mvs_ctx* c, const mvs_sketch_set* s, const double* d_n2, int keep_mode, int64_t rb, int64_t re, int64_t cb,
                int64_t ce, bool symmetric, bool mirror_all, double keep_coeff, mvs::PairwiseArgs& a) {
     a.planes = s->planes;
+    a.planes_fm = nullptr;
     a.n = s->n;
     a.n_alloc = s->n_alloc;
     a.d = s->d;
@@ -1283,6 +1306,8 @@ int two_stage_filter(mvs_ctx* c, const mvs_sketch_set* s, const double* d_n2, do
     if (rc) return rc;
     const bool forced = c->opt.pairwise_filter == 2;
     ts.tiles = mvs::filter_flags_tiles(a, c->opt);
+    rc = attach_planes_fm(c, s, a, ts.tiles);       // the flagged tiles go to the ping-pong exact kernel
+    if (rc) return rc;
     mvs::filter_tile_grid(a, &ts.n_tr, &ts.n_tc);
     // the symmetric schedule computes the tiles on and above the diagonal of the square only
     const bool sym = a.symmetric && (a.row_begin - a.col_begin) % 256 == 0 && !a.mirror_all;
@@ -1313,7 +1338,7 @@ int two_stage_filter(mvs_ctx* c, const mvs_sketch_set* s, const double* d_n2, do
     if (rc) return rc;
     a.coarse = (const int8_t*)c->pw_coarse;
     a.coarse_fm = nullptr;
-    if (c->opt.search_fm && mvs::filter_streams(a, c->opt)) {
+    if (c->opt.fragment_major && mvs::filter_streams(a, c->opt)) {
         rc = prepare_coarse_fm(c, s);
         if (rc) return rc;
         a.coarse_fm = (const int8_t*)c->pw_coarse_fm;
@@ -1579,6 +1604,8 @@ int pairwise_launch(mvs_ctx* c, const mvs_sketch_set* s, const double* d_n2, int
     if (rc) return rc;
     a.cand_thr = (const int32_t*)c->pw_thr;
     rc = set_cell_count(c, start);
+    if (rc) return rc;
+    rc = attach_planes_fm(c, s, a, mvs::exact_reads_fm(a, c->opt));
     if (rc) return rc;
     if (c->timing) HIP_TRY(hipEventRecord(c->ev[2], c->stream));
     rc = mvs::launch_pairwise(c->stream, a, 0, 0, c->opt);

@@ -70,8 +70,9 @@ struct Options {
                                     // rows are final -- and on the link -- a millisecond after the call started (10 % dense 100k:
                                     // encoded rows 37.4 against 38.4 ms, CSR pieces 94.5 against 102.9 ms = 1.02 x the link);
                                     // 0 = always one filter pass over the whole row range first
-    int search_fm = 1;              // the streaming search filter streams from the fragment-major copy of the coarse plane (0: from
-                                    // the row-major plane, as up to round 4's first version)
+    int fragment_major = 1;         // 1: the matrix-core kernels that copy 16 samples x 64 k values per instruction (ping-pong filter and
+                                    // exact kernel, streaming search filter) read fragment-major copies of the coarse plane / limb planes
+                                    // (PairwiseArgs::coarse_fm, planes_fm), built once per set; 0: the row-major planes (A/B, tests)
     int search_stream = 1;          // blocks of few rows x >= 4096 columns outside the symmetric schedule: 1 = the streaming
                                     // filter (rows resident in LDS, columns streamed into the matrix cores), 0 = the tile kernels
     int stream_trace = 0;           // 1: mvs_pairwise_stream prints the host-side time line of its row blocks to stderr
@@ -85,6 +86,8 @@ constexpr unsigned long long kStampSlots = 400000ULL;   // workgroups the time-s
 
 struct PairwiseArgs {
     const int8_t* planes;   // [(row*limbs + limb) * d_pad + k]
+    const int8_t* planes_fm;  // the same values fragment-major, or NULL: [((row / 16 * limbs + limb) * (d_pad / 64) + k / 64) * 1024 + lane * 16],
+                              // lane = (k / 16 % 4) * 16 + row % 16 (see coarse_fm); read by the ping-pong exact kernel (two limbs)
     int64_t n;              // samples
     int64_t n_alloc;        // allocated (zero padded) rows
     int d;
@@ -201,8 +204,10 @@ int launch_pairwise(hipStream_t stream, const PairwiseArgs& a, int mode, int alg
 // that appends candidate pairs, and the exact re-check of the candidates that appends kept cells
 int launch_coarse_build(hipStream_t stream, const int8_t* d_planes, int64_t n, int64_t n_alloc, int d_pad,
                         int8_t* d_coarse, CoarseRow* d_rows, int radix_mode);
-// fragment-major copy of the coarse plane (PairwiseArgs::coarse_fm)
-int launch_coarse_fm(hipStream_t stream, const int8_t* d_coarse, int64_t n_alloc, int d_pad, int8_t* d_fm);
+// fragment-major copy of the coarse plane (PairwiseArgs::coarse_fm) / of the limb planes (planes_fm): `limbs` planes per row
+int launch_coarse_fm(hipStream_t stream, const int8_t* d_coarse, int64_t n_alloc, int d_pad, int8_t* d_fm, int limbs = 1);
+// true when launch_pairwise / launch_exact_tiles run the kernel that reads planes_fm for this set
+bool exact_reads_fm(const PairwiseArgs& a, const Options& opt);
 int launch_filter_meta(hipStream_t stream, const CoarseRow* d_rows, const double* d_norms_sq, int64_t n,
                        int64_t n_alloc, int d, double coeff, float4* d_meta);
 int launch_filter(hipStream_t stream, const PairwiseArgs& a, const Options& opt);

@@ -1398,7 +1398,7 @@ __global__ __launch_bounds__(512, 2) void k_pairwise_pp(const PairwiseArgs a, in
     // the plane -- 16 samples x 64 k values in fragment order -- so a copy instruction touches 8 whole lines instead of 16
     // half lines, its LDS image is the fragment itself (lane l's 16 bytes at l * 16: no swizzle, no bank conflict) and the
     // next k-slice is 1 KiB further on
-    const bool fmode = MODE == 2 && a.coarse_fm != nullptr && (((a.row_begin | a.col_begin) & 15) == 0);
+    const bool fmode = (MODE == 2 ? a.coarse_fm != nullptr : a.planes_fm != nullptr) && (((a.row_begin | a.col_begin) & 15) == 0);
     const int kstep = fmode ? 1024 : kSK;
     const int8_t* src[kPPW];
 #pragma unroll
@@ -1410,9 +1410,10 @@ __global__ __launch_bounds__(512, 2) void k_pairwise_pp(const PairwiseArgs a, in
         const int c = (lane & 3) ^ swz16(s);
         const int64_t sample = (is_b ? j0 : i0) + s;
         src[p] = (MODE == 2 ? a.coarse : a.planes) + (sample * L + limb) * (int64_t)a.d_pad + c * 16;
-        if (fmode) {
-            const int64_t blk = ((is_b ? j0 : i0) + ((wave * kPPW + p) * 16 - (is_b ? L * TM : 0))) >> 4;
-            src[p] = a.coarse_fm + blk * (int64_t)(a.d_pad / kSK) * 1024 + lane * 16;
+        if (fmode) {                                             // the piece = 16 samples of one limb plane
+            const int rr0 = (wave * kPPW + p) * 16 - (is_b ? L * TM : 0);
+            const int64_t blk = ((is_b ? j0 : i0) + rr0 % TM) >> 4;
+            src[p] = (MODE == 2 ? a.coarse_fm : a.planes_fm) + (blk * L + rr0 / TM) * (int64_t)(a.d_pad / kSK) * 1024 + lane * 16;
         }
     }
     // waves 0-3 copy the A region (pieces 0..15), waves 4-7 the B region: the policy is wave-uniform
@@ -1433,11 +1434,13 @@ __global__ __launch_bounds__(512, 2) void k_pairwise_pp(const PairwiseArgs a, in
 #pragma unroll
     for (int i = 0; i < 8; ++i)
         a_off[i] = MODE == 2 ? (fmode ? (wm * 8 + i) * 1024 + lane * 16 : (wm * 128 + i * 16 + fr) * kSK + coff)
-                             : ((i & 1) * TM + wm * 64 + (i >> 1) * 16 + fr) * kSK + coff;
+                             : (fmode ? (((i & 1) * TM + wm * 64 + (i >> 1) * 16) >> 4) * 1024 + lane * 16
+                                      : ((i & 1) * TM + wm * 64 + (i >> 1) * 16 + fr) * kSK + coff);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
         b_off[i] = kRegion + (MODE == 2 ? (fmode ? (wn * 4 + i) * 1024 + lane * 16 : (wn * 64 + i * 16 + fr) * kSK + coff)
-                                        : ((i & 1) * TN + wn * 32 + (i >> 1) * 16 + fr) * kSK + coff);
+                                        : (fmode ? (((i & 1) * TN + wn * 32 + (i >> 1) * 16) >> 4) * 1024 + lane * 16
+                                                 : ((i & 1) * TN + wn * 32 + (i >> 1) * 16 + fr) * kSK + coff));
     float4 fm = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     if constexpr (MODE == 2) {   // the epilogue's row / column constants: one per thread, on their way during the k-loop
         const int64_t g = tid < TM ? i0 + tid : j0 + (tid - TM);
@@ -2524,25 +2527,28 @@ int launch_coarse_build(hipStream_t stream, const int8_t* d_planes, int64_t n, i
     return 0;
 }
 
-// row-major coarse plane -> fragment-major (PairwiseArgs::coarse_fm): one wave per KiB, written as whole lines
-__global__ __launch_bounds__(256) void k_coarse_fm(const int8_t* __restrict__ coarse, long long chunks, int nk, int d_pad,
+// row-major plane(s) -> fragment-major (PairwiseArgs::coarse_fm, planes_fm): one wave per KiB, written as whole lines.
+// Source row of (sample, limb) = (sample * limbs + limb) * d_pad; chunk ch = ((sample / 16) * limbs + limb) * nk + k / 64
+__global__ __launch_bounds__(256) void k_coarse_fm(const int8_t* __restrict__ coarse, long long chunks, int nk, int d_pad, int limbs,
                                                    int8_t* __restrict__ fm) {
     const int lane = threadIdx.x & 63;
     const int fr = lane & 15, fq = lane >> 4;
     for (long long ch = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); ch < chunks; ch += (long long)gridDim.x * 4) {
-        const long long blk = ch / nk;
-        const int ks = (int)(ch - blk * nk);
-        const v4i v = *reinterpret_cast<const v4i*>(coarse + (blk * 16 + fr) * (long long)d_pad + ks * 64 + fq * 16);
+        const long long bl = ch / nk;                              // (sample block, limb)
+        const int ks = (int)(ch - bl * nk);
+        const long long blk = bl / limbs;
+        const int limb = (int)(bl - blk * limbs);
+        const v4i v = *reinterpret_cast<const v4i*>(coarse + ((blk * 16 + fr) * limbs + limb) * (long long)d_pad + ks * 64 + fq * 16);
         *reinterpret_cast<v4i*>(fm + ch * 1024 + lane * 16) = v;
     }
 }
 
-int launch_coarse_fm(hipStream_t stream, const int8_t* d_coarse, int64_t n_alloc, int d_pad, int8_t* d_fm) {
+int launch_coarse_fm(hipStream_t stream, const int8_t* d_coarse, int64_t n_alloc, int d_pad, int8_t* d_fm, int limbs) {
     if (n_alloc <= 0) return 0;
     const int nk = d_pad / 64;
-    const long long chunks = (long long)(n_alloc / 16) * nk;
+    const long long chunks = (long long)(n_alloc / 16) * limbs * nk;
     const unsigned grid = (unsigned)std::min<long long>((chunks + 3) / 4, 65536);
-    hipLaunchKernelGGL(k_coarse_fm, dim3(grid), dim3(256), 0, stream, d_coarse, chunks, nk, d_pad, d_fm);
+    hipLaunchKernelGGL(k_coarse_fm, dim3(grid), dim3(256), 0, stream, d_coarse, chunks, nk, d_pad, limbs, d_fm);
     return 0;
 }
 
@@ -2675,6 +2681,14 @@ bool filter_streams(const PairwiseArgs& a, const Options& opt) {
     if (a.limbs != 2 || a.d_pad > 32768) return false;
     const int v = filter_variant_for(a, opt);
     return v == 50 || (v >= 7 && v <= 10) || (v >= 40 && v <= 42);      // the streaming search filter, the ping-pong tile filter
+}
+
+// the ping-pong exact kernel (two base-256 limbs) copies its LDS pieces from the fragment-major limb planes; the copy of
+// the planes is worth building for blocks that run long enough (the kernel is picked by number 7 / 8 / 9, 8 by default)
+bool exact_reads_fm(const PairwiseArgs& a, const Options& opt) {
+    const int v = pairwise_variant(opt);
+    return a.limbs == 2 && a.d_pad <= 32768 && v >= 7 && v <= 9 &&
+           (double)(a.row_end - a.row_begin) * (double)(a.col_end - a.col_begin) >= 4194304.0;
 }
 
 bool filter_flags_tiles(const PairwiseArgs& a, const Options& opt) {

@@ -228,6 +228,42 @@ def test_full_width_properties(ctx, pw_filter):
     ss.close()
 
 
+@pytest.mark.parametrize("n,d,clu", [(2321, 2048, 16), (2600, 100, 600), (2305, 4096, 2305)])
+def test_fragment_major_planes_change_no_cell(ctx, n, d, clu):
+    """The ping-pong exact kernel and the ping-pong tile filter copy their LDS pieces from fragment-major copies of the limb
+    planes / the coarse plane (one contiguous KiB per copy instruction; option fragment_major, on by default) when the
+    block's origin is a multiple of 16 samples, otherwise from the row-major planes: every combination gives the cells of
+    the row-major path -- exact kernel on every cell, two-stage with the ping-pong filter (flagged tiles go to the exact
+    kernel on a tile list), sparse and dense results, blocks that start off the 16-sample grid, shards -- and an oracle
+    stripe pins them."""
+    sk = synth.make_sketches_numpy(n, d, 3000, seed=n + d, cluster=clu)
+    n2 = _n2_from_sketches(sk)
+    ss = ctx.sketch_set(sk)
+    assert ss.limbs == 2
+    cap = 1 << 23
+    results = {}
+    for fmaj in (1, 0):
+        ctx.set_option("fragment_major", fmaj)
+        for filt, variant in ((0, -1), (2, 8)):
+            ctx.set_option("pairwise_filter", filt)
+            ctx.set_option("filter_variant", variant)
+            cells, cnt = ctx.pairwise_rows(ss, n2, capacity=cap)
+            whole = _cells_tuple(cells)
+            parts = []
+            # (16, 2016): origin on the 16-sample grid but off the tile grid, large enough for the fragment-major copy;
+            # (2016, 2023) / (2023, n): small blocks, the last one starting off the 16-sample grid (row-major planes)
+            for b, e in ((0, 16), (16, 2016), (2016, 2023), (2023, n)):
+                c, _ = ctx.pairwise_rows(ss, n2, row_begin=b, row_end=e, capacity=cap)
+                parts += _cells_tuple(c)
+            assert parts == whole
+            results[(fmaj, filt)] = whole
+    ref = results[(0, 0)]
+    assert all(v == ref for v in results.values()) and len(ref) >= n
+    want = _oracle_sorted(sk, n2, row_begin=1030, row_end=1060, chunk=192)
+    assert [t for t in ref if 1030 <= t[0] < 1060] == want
+    ss.close()
+
+
 def test_sharded_comparison_single_rank(ctx, pw_filter):
     """metagenome_vector_sketches_amd.parallel with the real GPU back end, world = 1 (the multi-rank
     orchestration is covered on CPU with gloo in tests/test_distributed_cpu.py)"""

@@ -167,7 +167,7 @@ def test_streaming_search_filter_equals_exact_kernel(ctx, d, n_db):
         for filt, stream, variant, fm in ((2, 1, 50, 1), (0, 1, -1, 1), (2, 0, -1, 1), (2, 1, 50, 0), (2, 1, -1, 1)):
             ctx.set_option("pairwise_filter", filt)
             ctx.set_option("search_stream", stream)
-            ctx.set_option("search_fm", fm)
+            ctx.set_option("fragment_major", fm)
             ctx.set_option("filter_variant", variant)    # 50 by number: up to 1023 rows (by size: up to 512)
             cnt = fn()
             ctx.synchronize()
