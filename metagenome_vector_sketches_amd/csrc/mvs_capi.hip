@@ -46,6 +46,9 @@ struct mvs_ctx {
     // per-call filter constants, candidate list
     void* pw_coarse = nullptr;  size_t pw_coarse_bytes = 0;
     void* pw_coarse_fm = nullptr;  size_t pw_coarse_fm_bytes = 0;   // fragment-major copy (streaming search filters), built on demand
+    void* st_tlist = nullptr;  size_t st_tlist_bytes = 0;    // dense row passes: active tiles per tile row of the block, their counts,
+    void* st_tlist_n = nullptr;  size_t st_tlist_n_bytes = 0;  // and every row's first / last kept column
+    void* st_ends = nullptr;  size_t st_ends_bytes = 0;
     void* pw_planes_fm = nullptr;  size_t pw_planes_fm_bytes = 0;   // fragment-major copy of the limb planes of set planes_fm_id
     unsigned long long planes_fm_id = 0, planes_fm_gen = 0;         // (generation planes_fm_gen), for the ping-pong exact kernel
     bool coarse_fm_valid = false;           // ... of the cached plane
@@ -475,6 +478,9 @@ int mvs_ctx_destroy(mvs_ctx* c) {
     if (c->pw_coarse) (void)hipFree(c->pw_coarse);
     if (c->pw_coarse_fm) (void)hipFree(c->pw_coarse_fm);
     if (c->pw_planes_fm) (void)hipFree(c->pw_planes_fm);
+    if (c->st_tlist) (void)hipFree(c->st_tlist);
+    if (c->st_tlist_n) (void)hipFree(c->st_tlist_n);
+    if (c->st_ends) (void)hipFree(c->st_ends);
     if (c->pw_rows) (void)hipFree(c->pw_rows);
     if (c->pw_fmeta) (void)hipFree(c->pw_fmeta);
     if (c->pw_cand) (void)hipFree(c->pw_cand);
@@ -1925,6 +1931,7 @@ struct BlockCsr {
     bool wide = false;                 // q is 16 bits wide in this block
     int set = 0;
     // rows encoded on the device: byte offset of every row's record (rows + 1 entries), directory values per row
+    bool sizes_ready = false;          // the encoder's per-row sizes (en_size / en_jac / en_first / en_par) are on the device already
     bool encoded = false;
     std::vector<uint64_t> enc_off;
     std::vector<uint32_t> enc_jac, enc_first;
@@ -1950,11 +1957,13 @@ int encode_block(mvs_ctx* c, BlockCsr& b, hipStream_t ps) {
     if (rc) return rc;
     const int qb = b.wide ? 2 : 1;
     HIP_TRY(hipMemsetAsync((char*)c->en_size + (size_t)rows * 8, 0, 8, ps));
-    mvs::launch_encode_sizes(ps, (const long long*)c->st_rowptr, (const int32_t*)c->st_col[b.set], c->st_q[b.set], qb, rows,
-                             (unsigned long long*)c->en_size, (unsigned int*)c->en_jac, (unsigned int*)c->en_first,
-                             (mvs::EncRow*)c->en_par);
-    rc = check_kernel("k_enc_size");
-    if (rc) return rc;
+    if (!b.sizes_ready) {                  // (a dense block's fill pass has computed them already)
+        mvs::launch_encode_sizes(ps, (const long long*)c->st_rowptr, (const int32_t*)c->st_col[b.set], c->st_q[b.set], qb, rows,
+                                 (unsigned long long*)c->en_size, (unsigned int*)c->en_jac, (unsigned int*)c->en_first,
+                                 (mvs::EncRow*)c->en_par);
+        rc = check_kernel("k_enc_size");
+        if (rc) return rc;
+    }
     size_t need = 0;
     rc = mvs::encode_offsets(ps, (unsigned long long*)c->en_size, (unsigned long long*)c->en_off, rows, nullptr, 0, &need);
     if (rc) return fail(rc, "scan sizing failed");
@@ -2045,7 +2054,7 @@ int csr_from_packed(mvs_ctx* c, int64_t rb, int64_t re, int64_t n, int shift, in
 // rows [rb, re) of the dense byte matrix (first row dense_row0, leading dimension ld) are final: count, scan, fill.
 // *odd: some kept cell of the launches so far has a q the byte cannot hold -- the caller redoes the block as a list.
 int csr_from_dense(mvs_ctx* c, int64_t rb, int64_t re, int64_t n_cols, int64_t dense_row0, int64_t ld, int64_t block_index,
-                   BlockCsr& out, bool* odd, hipStream_t ps, mvs::DenseActive active) {
+                   BlockCsr& out, bool* odd, hipStream_t ps, mvs::DenseActive active, bool want_sizes) {
     active.row_rel0 = rb - dense_row0;
     const int64_t rows = re - rb;
     out.rb = rb;
@@ -2057,9 +2066,17 @@ int csr_from_dense(mvs_ctx* c, int64_t rb, int64_t re, int64_t n_cols, int64_t d
     if (rc) return rc;
     rc = ensure_buf(c, &c->st_counts, &c->st_counts_bytes, (size_t)(rows + 1) * 8);
     if (rc) return rc;
+    // the active tiles of the block's tile rows, every row's first / last kept column
+    int tr0 = 0, n_trows = 0, n_tc = 0;
+    mvs::dense_tile_rows(active, rows, n_cols, &tr0, &n_trows, &n_tc);
+    rc = ensure_buf(c, &c->st_tlist, &c->st_tlist_bytes, std::max<size_t>((size_t)n_trows * (size_t)n_tc * 4, 4));
+    if (rc == MVS_OK) rc = ensure_buf(c, &c->st_tlist_n, &c->st_tlist_n_bytes, std::max<size_t>((size_t)n_trows * 4, 4));
+    if (rc == MVS_OK) rc = ensure_buf(c, &c->st_ends, &c->st_ends_bytes, std::max<size_t>((size_t)rows * sizeof(int2), 8));
+    if (rc) return rc;
     const uint8_t* first = (const uint8_t*)c->st_dense + (size_t)(rb - dense_row0) * (size_t)ld;
     HIP_TRY(hipMemsetAsync((char*)c->st_counts + (size_t)rows * 8, 0, 8, ps));
-    mvs::launch_dense_count(ps, first, ld, n_cols, rows, (long long*)c->st_counts, active);
+    mvs::launch_dense_count(ps, first, ld, n_cols, rows, (long long*)c->st_counts, (int2*)c->st_ends, active, (int*)c->st_tlist,
+                            (int*)c->st_tlist_n);
     rc = check_kernel("k_dense_count");
     if (rc) return rc;
     size_t need = 0;
@@ -2077,10 +2094,23 @@ int csr_from_dense(mvs_ctx* c, int64_t rb, int64_t re, int64_t n_cols, int64_t d
     out.n = out.row_ptr[(size_t)rows];
     rc = claim_csr_set(c, out.set, block_index, out.n, false, ps);
     if (rc) return rc;
+    // rows that will be encoded on the device: the record sizes come out of the fill pass (k_enc_size would read the CSR
+    // arrays this pass is writing once more)
+    if (want_sizes && rows > 0) {
+        rc = ensure_buf(c, &c->en_size, &c->en_size_bytes, (size_t)(rows + 1) * 8);
+        if (rc == MVS_OK) rc = ensure_buf(c, &c->en_jac, &c->en_jac_bytes, (size_t)rows * 4);
+        if (rc == MVS_OK) rc = ensure_buf(c, &c->en_first, &c->en_first_bytes, (size_t)rows * 4);
+        if (rc == MVS_OK) rc = ensure_buf(c, &c->en_par, &c->en_par_bytes, (size_t)rows * sizeof(mvs::EncRow));
+        if (rc) return rc;
+    }
+    const bool sizes = want_sizes && rows > 0 && out.n > 0;
     mvs::launch_dense_fill(ps, first, ld, n_cols, rows, (const long long*)c->st_rowptr, (int32_t*)c->st_col[out.set],
-                           (uint8_t*)c->st_q[out.set], active);
+                           (uint8_t*)c->st_q[out.set], active, (const int*)c->st_tlist, (const int*)c->st_tlist_n,
+                           (const int2*)c->st_ends, sizes ? (unsigned long long*)c->en_size : nullptr, (unsigned int*)c->en_jac,
+                           (unsigned int*)c->en_first, (mvs::EncRow*)c->en_par);
     rc = check_kernel("k_dense_fill");
     if (rc) return rc;
+    out.sizes_ready = sizes;
     HIP_TRY(hipEventRecord(c->dl_ready[out.set], ps));
     return MVS_OK;
 }
@@ -2722,7 +2752,7 @@ int pairwise_stream_impl(mvs_ctx* c, const mvs_sketch_set* s, const double* norm
         wait_for_set((int64_t)k);
         if (dense) {
             bool odd = false;
-            rc = csr_from_dense(c, rb, re, s->n, whole ? row_begin : rb, ld, (int64_t)k, blk, &odd, ps, active);
+            rc = csr_from_dense(c, rb, re, s->n, whole ? row_begin : rb, ld, (int64_t)k, blk, &odd, ps, active, ecb != nullptr);
             if (rc) return finish(rc);
             mark("csr", (long)k);
             if (!side) add_kernel_ms();

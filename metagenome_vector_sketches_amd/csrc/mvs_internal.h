@@ -237,12 +237,17 @@ int sort_packed(hipStream_t stream, unsigned long long* d_in, unsigned long long
 int launch_packed_csr(hipStream_t stream, const unsigned long long* d_keys, int64_t n, int shift, int64_t rows,
                       unsigned long long col_mask, long long* d_row_ptr, int32_t* d_col, uint8_t* d_q8, uint16_t* d_q16,
                       unsigned int* d_wide);
+// the tile rows [tr0, tr0 + n_trows) the rows of a launch fall into and the tile columns of the matrix: sizes of the
+// active-tile lists (d_list: n_trows x n_tc ints, d_list_n: n_trows ints) the row passes walk
+void dense_tile_rows(const DenseActive& active, int64_t rows, int64_t n_cols, int* tr0, int* n_trows, int* n_tc);
 int launch_dense_count(hipStream_t stream, const uint8_t* d_dense, int64_t ld, int64_t n_cols, int64_t rows, long long* d_counts,
-                       const DenseActive& active);
+                       int2* d_ends, const DenseActive& active, int* d_list, int* d_list_n);
 int dense_row_ptr(hipStream_t stream, long long* d_counts, long long* d_row_ptr, int64_t rows, void* d_scratch, size_t scratch_bytes,
                   size_t* scratch_needed);
+struct EncRow;
 int launch_dense_fill(hipStream_t stream, const uint8_t* d_dense, int64_t ld, int64_t n_cols, int64_t rows, const long long* d_row_ptr,
-                      int32_t* d_col, uint8_t* d_q, const DenseActive& active);
+                      int32_t* d_col, uint8_t* d_q, const DenseActive& active, const int* d_list, const int* d_list_n,
+                      const int2* d_ends, unsigned long long* d_size, unsigned int* d_jac, unsigned int* d_first_col, EncRow* d_par);
 // the re-check's kept cells (packed words, *d_n of them, rows relative to pack_row0 = the matrix's first row) into the dense
 // byte matrix: mark the tiles they fall into (newly touched ones are listed in d_new, count in d_new[-1] .. i.e. d_new_count),
 // clear those tiles, then write the bytes; *d_odd is set when a q is not in 1..255

@@ -27,6 +27,7 @@
 //   * workgroup -> tile mapping walks 16 x 16-tile super-patches, each of the 8 XCDs (blockIdx % 8)
 //     taking a 4 x 8 sub-patch, so that one XCD's L2 serves 12 operand panels to 32 tiles.
 #include "mvs_internal.h"
+#include "mvs_encode.h"
 
 #include <algorithm>
 #include <cstring>
@@ -2242,52 +2243,153 @@ __device__ __forceinline__ bool tile_active(const DenseActive& A, int tr, int tc
     return A.sym && mr >= 0 && mr < A.n_tr && mc < A.n_tc && A.flags[(size_t)mr * A.n_tc + mc] != 0u;
 }
 
-// counts[r] = kept cells of row r: one workgroup per row
-__global__ __launch_bounds__(256) void k_dense_count(const uint8_t* __restrict__ dense, long long ld, long long n_cols,
-                                                     long long* __restrict__ counts, const DenseActive A) {
-    __shared__ unsigned part[4];
-    const uint8_t* row = dense + (long long)blockIdx.x * ld;
-    const int tr = (int)((A.row_rel0 + blockIdx.x) >> 8);
-    unsigned c = 0;
-    for (long long k = (long long)threadIdx.x * 16; k < n_cols; k += 256 * 16) {
-        if (!tile_active(A, tr, (int)(k >> 8))) continue;
-        unsigned m = nz_mask16(*reinterpret_cast<const v4i*>(row + k));
-        if (k + 16 > n_cols) m &= (1u << (n_cols - k)) - 1u;                  // columns beyond the last sample
-        c += (unsigned)__popc(m);
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = c;
+// The tile columns of one tile row that can hold a kept cell, in ascending order: list[t * ld_list + 0 ..) and count[t]
+// for tile row tr0 + t.  The row passes below walk these lists -- at 10 % density a row of 391 tiles has 43 active ones,
+// and looking the flags up tile by tile (three dependent loads in front of every 16 bytes of the row, 25 steps per row)
+// was what the passes' time went into, not the bytes.
+__global__ __launch_bounds__(256) void k_active_tiles(const DenseActive A, int tr0, int n_tc, int* __restrict__ list,
+                                                      int* __restrict__ count) {
+    __shared__ int part[4];
+    __shared__ int run;
+    const int tr = tr0 + (int)blockIdx.x;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (threadIdx.x == 0) run = 0;
     __syncthreads();
-    if (threadIdx.x == 0) counts[blockIdx.x] = (long long)(part[0] + part[1] + part[2] + part[3]);
+    int* out = list + (size_t)blockIdx.x * (size_t)n_tc;
+    for (int t0 = 0; t0 < n_tc; t0 += 256) {
+        const int t = t0 + (int)threadIdx.x;
+        const bool f = t < n_tc && tile_active(A, tr, t);
+        const unsigned long long m = __ballot(f);
+        if (lane == 0) part[w] = __popcll(m);
+        __syncthreads();
+        int pos = run + __popcll(m & ((1ULL << lane) - 1ULL));
+        for (int i = 0; i < w; ++i) pos += part[i];
+        if (f) out[pos] = t;
+        __syncthreads();
+        if (threadIdx.x == 0) run += part[0] + part[1] + part[2] + part[3];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) count[blockIdx.x] = run;
 }
 
-// col / q of row r at row_ptr[r]: one workgroup per row, 4 KiB of the row per step, positions by a block-wide prefix sum.
-// The step's kept cells are gathered in LDS and leave as contiguous runs (thread t writes entries t, t + 256, ...): written
-// straight from the lanes -- every lane a short run of its own, a store instruction touching 64 scattered words -- the
-// kernel wrote 3.3 x its bytes to memory (WRITE_SIZE 1.03 GB per 6250-row block for 0.31 GB of col + q,
+// counts[r] = kept cells of row r, ends[r] = {first, last} kept column (when counts[r] > 0): one workgroup per row, 16 bytes
+// of an active tile per thread and step
+__global__ __launch_bounds__(256) void k_dense_count(const uint8_t* __restrict__ dense, long long ld, long long n_cols,
+                                                     long long* __restrict__ counts, int2* __restrict__ ends, long long row_rel0,
+                                                     int tr0, int n_tc, const int* __restrict__ list, const int* __restrict__ list_n) {
+    __shared__ unsigned part[4];
+    __shared__ int part_lo[4], part_hi[4];
+    const uint8_t* row = dense + (long long)blockIdx.x * ld;
+    const int t = (int)((row_rel0 + blockIdx.x) >> 8) - tr0;
+    const int* tl = list + (size_t)t * (size_t)n_tc;
+    const int pieces = list_n[t] * 16;
+    unsigned c = 0;
+    int lo = 0x7fffffff, hi = -1;
+    for (int p = (int)threadIdx.x; p < pieces; p += 256) {
+        const long long k = (long long)tl[p >> 4] * 256 + (p & 15) * 16;
+        if (k >= n_cols) continue;
+        unsigned m = nz_mask16(*reinterpret_cast<const v4i*>(row + k));
+        if (k + 16 > n_cols) m &= (1u << (n_cols - k)) - 1u;                  // columns beyond the last sample
+        if (m) {
+            c += (unsigned)__popc(m);
+            const int a = (int)k + (__ffs((int)m) - 1), b = (int)k + (31 - __clz((int)m));
+            lo = a < lo ? a : lo;
+            hi = b > hi ? b : hi;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        c += __shfl_xor(c, o, 64);
+        const int l2 = __shfl_xor(lo, o, 64), h2 = __shfl_xor(hi, o, 64);
+        lo = l2 < lo ? l2 : lo;
+        hi = h2 > hi ? h2 : hi;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        part[threadIdx.x >> 6] = c;
+        part_lo[threadIdx.x >> 6] = lo;
+        part_hi[threadIdx.x >> 6] = hi;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        counts[blockIdx.x] = (long long)(part[0] + part[1] + part[2] + part[3]);
+        int l = part_lo[0], h = part_hi[0];
+        for (int i = 1; i < 4; ++i) {
+            l = part_lo[i] < l ? part_lo[i] : l;
+            h = part_hi[i] > h ? part_hi[i] : h;
+        }
+        ends[blockIdx.x] = make_int2(l, h);
+    }
+}
+
+// what the shard encoder's size pass (k_enc_size, mvs_encode.hip) leaves per row; filled here when SIZES
+struct DenseSizes {
+    unsigned long long* size;
+    unsigned int* jac;
+    unsigned int* first_col;
+    EncRow* par;
+};
+
+// col / q of row r at row_ptr[r]: one workgroup per row, 4 KiB of the row's ACTIVE tiles per step, positions by a block-wide
+// prefix sum.  The step's kept cells are gathered in LDS and leave as contiguous runs (thread t writes entries t, t + 256,
+// ...): written straight from the lanes -- every lane a short run of its own, a store instruction touching 64 scattered
+// words -- the kernel wrote 3.3 x its bytes to memory (WRITE_SIZE 1.03 GB per 6250-row block for 0.31 GB of col + q,
 // profiles/r03_c2d_pmc_summary.txt before this change).
+// SIZES: the row's record size for the shard codec comes out of the same pass (what k_enc_size computes from the CSR arrays
+// this kernel has just written: width of the largest q; Rice parameter from the mean column delta, which is known before the
+// pass -- first and last kept column from k_dense_count --; sum of the deltas' quotients).
+template <bool SIZES>
 __global__ __launch_bounds__(256) void k_dense_fill(const uint8_t* __restrict__ dense, long long ld, long long n_cols,
                                                     const long long* __restrict__ row_ptr, int32_t* __restrict__ col,
-                                                    uint8_t* __restrict__ q, const DenseActive A) {
+                                                    uint8_t* __restrict__ q, long long row_rel0, int tr0, int n_tc,
+                                                    const int* __restrict__ list, const int* __restrict__ list_n,
+                                                    const int2* __restrict__ ends, const DenseSizes out) {
     __shared__ unsigned wsum[2][4];
     __shared__ int32_t s_col[256 * 16];
     __shared__ uint8_t s_q[256 * 16];
+    __shared__ unsigned long long red_s[4];
+    __shared__ unsigned red_q[4];
     const uint8_t* row = dense + (long long)blockIdx.x * ld;
     long long base = row_ptr[blockIdx.x];
     const long long row_total = row_ptr[blockIdx.x + 1] - base;
-    if (row_total == 0) return;                                   // block-uniform
+    if (row_total == 0) {                                         // block-uniform
+        if (SIZES && threadIdx.x == 0) {
+            out.size[blockIdx.x] = 0;
+            out.jac[blockIdx.x] = 0;
+            out.first_col[blockIdx.x] = 0;
+            out.par[blockIdx.x] = EncRow{0, 0, 0};
+        }
+        return;
+    }
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int tr = (int)((A.row_rel0 + blockIdx.x) >> 8);
+    const int t = (int)((row_rel0 + blockIdx.x) >> 8) - tr0;
+    const int* tl = list + (size_t)t * (size_t)n_tc;
+    const int pieces = list_n[t] * 16;
+    unsigned rice_k = 0;
+    int2 fl = make_int2(0, 0);
+    if (SIZES) {
+        fl = ends[blockIdx.x];
+        if (row_total > 1) {
+            const unsigned long long mean = (unsigned long long)(fl.y - fl.x) / (unsigned long long)(row_total - 1);   // the deltas telescope
+            rice_k = mean > 1 ? 63u - (unsigned)__builtin_clzll(mean) : 0u;
+        }
+    }
+    unsigned long long quot = 0;                                  // this thread's share of the sum of (delta >> k)
+    unsigned qmax = 0;
+    int prev_last = 0;                                            // last kept column of the steps so far
+    bool have_prev = false;
     unsigned step = 0;
-    for (long long k0 = 0; k0 < n_cols; k0 += 256 * 16, ++step) {
-        const long long k = k0 + (long long)threadIdx.x * 16;
+    for (int p0 = 0; p0 < pieces; p0 += 256, ++step) {
+        const int p = p0 + (int)threadIdx.x;
         v4i wv = v4i{0, 0, 0, 0};
         unsigned m = 0;
-        if (k < n_cols && tile_active(A, tr, (int)(k >> 8))) {
-            wv = *reinterpret_cast<const v4i*>(row + k);
-            m = nz_mask16(wv);
-            if (k + 16 > n_cols) m &= (1u << (n_cols - k)) - 1u;   // columns beyond the last sample
+        long long k = 0;
+        if (p < pieces) {
+            k = (long long)tl[p >> 4] * 256 + (p & 15) * 16;
+            if (k < n_cols) {
+                wv = *reinterpret_cast<const v4i*>(row + k);
+                m = nz_mask16(wv);
+                if (k + 16 > n_cols) m &= (1u << (n_cols - k)) - 1u;   // columns beyond the last sample
+            }
         }
         const unsigned mine = (unsigned)__popc(m);
         unsigned incl = mine;
@@ -2315,10 +2417,53 @@ __global__ __launch_bounds__(256) void k_dense_fill(const uint8_t* __restrict__ 
         }
         __syncthreads();
         for (unsigned i = threadIdx.x; i < total; i += 256) {
-            col[base + i] = s_col[i];
-            q[base + i] = s_q[i];
+            const int32_t cv = s_col[i];
+            const unsigned qv = s_q[i];
+            col[base + i] = cv;
+            q[base + i] = (uint8_t)qv;
+            if (SIZES) {
+                qmax = qv > qmax ? qv : qmax;
+                if (i > 0) quot += (unsigned long long)(unsigned)(cv - s_col[i - 1]) >> rice_k;
+                else if (have_prev) quot += (unsigned long long)(unsigned)(cv - prev_last) >> rice_k;
+            }
+        }
+        if (SIZES && total) {
+            prev_last = s_col[total - 1];
+            have_prev = true;
         }
         base += total;
+    }
+    if (SIZES) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            quot += (unsigned long long)__shfl_xor((long long)quot, o, 64);
+            const unsigned other = (unsigned)__shfl_xor((int)qmax, o, 64);
+            qmax = other > qmax ? other : qmax;
+        }
+        __syncthreads();
+        if (lane == 0) {
+            red_s[w] = quot;
+            red_q[w] = qmax;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned long long s = red_s[0] + red_s[1] + red_s[2] + red_s[3];
+            unsigned mx = red_q[0];
+            for (int i = 1; i < 4; ++i) mx = red_q[i] > mx ? red_q[i] : mx;
+            const unsigned long long n = (unsigned long long)row_total;
+            const unsigned wq = mx ? 32u - (unsigned)__clz((int)mx) : 1u;         // compact_vector::build: width of the largest, at least 1
+            const unsigned long long jac_bytes = 8 * (3 + (n * wq + 63) / 64);
+            unsigned long long total_bytes = jac_bytes, high = 0;
+            if (n > 1) {
+                const unsigned long long nr = n - 1;
+                high = nr + s;
+                total_bytes += 8 * (5 + (high + 63) / 64 + (nr + 63) / 64) + (rice_k ? 8 * (3 + (nr * rice_k + 63) / 64) : 0);
+            }
+            out.size[blockIdx.x] = total_bytes;
+            out.jac[blockIdx.x] = (unsigned)jac_bytes;
+            out.first_col[blockIdx.x] = (unsigned)fl.x;
+            out.par[blockIdx.x] = EncRow{high, wq, n > 1 ? rice_k : 0u};
+        }
     }
 }
 
@@ -2863,12 +3008,22 @@ int launch_packed_csr(hipStream_t stream, const unsigned long long* d_keys, int6
     return 0;
 }
 
-// rows [0, rows) of a dense byte matrix -> counts, row_ptr (exclusive scan, row_ptr[rows] = total), then col / q
+// rows [0, rows) of a dense byte matrix -> the active tiles of their tile rows (d_list: n_trows x n_tc ints, d_list_n:
+// n_trows), counts + first / last kept column, row_ptr (exclusive scan, row_ptr[rows] = total), then col / q
+void dense_tile_rows(const DenseActive& active, int64_t rows, int64_t n_cols, int* tr0, int* n_trows, int* n_tc) {
+    *tr0 = (int)(active.row_rel0 >> 8);
+    *n_trows = rows > 0 ? (int)((active.row_rel0 + rows - 1) >> 8) - *tr0 + 1 : 0;
+    *n_tc = (int)((n_cols + 255) / 256);
+}
+
 int launch_dense_count(hipStream_t stream, const uint8_t* d_dense, int64_t ld, int64_t n_cols, int64_t rows, long long* d_counts,
-                       const DenseActive& active) {
+                       int2* d_ends, const DenseActive& active, int* d_list, int* d_list_n) {
     if (rows <= 0) return 0;
+    int tr0, n_trows, n_tc;
+    dense_tile_rows(active, rows, n_cols, &tr0, &n_trows, &n_tc);
+    hipLaunchKernelGGL(k_active_tiles, dim3((unsigned)n_trows), dim3(256), 0, stream, active, tr0, n_tc, d_list, d_list_n);
     hipLaunchKernelGGL(k_dense_count, dim3((unsigned)rows), dim3(256), 0, stream, d_dense, (long long)ld, (long long)n_cols, d_counts,
-                       active);
+                       d_ends, (long long)active.row_rel0, tr0, n_tc, (const int*)d_list, (const int*)d_list_n);
     return 0;
 }
 
@@ -2895,11 +3050,20 @@ int dense_row_ptr(hipStream_t stream, long long* d_counts, long long* d_row_ptr,
     return e == hipSuccess ? 0 : MVS_E_HIP;
 }
 
+// d_size non-NULL: the shard encoder's per-row sizes as well (size / jac / first_col / par of launch_encode_sizes)
 int launch_dense_fill(hipStream_t stream, const uint8_t* d_dense, int64_t ld, int64_t n_cols, int64_t rows, const long long* d_row_ptr,
-                      int32_t* d_col, uint8_t* d_q, const DenseActive& active) {
+                      int32_t* d_col, uint8_t* d_q, const DenseActive& active, const int* d_list, const int* d_list_n,
+                      const int2* d_ends, unsigned long long* d_size, unsigned int* d_jac, unsigned int* d_first_col, EncRow* d_par) {
     if (rows <= 0) return 0;
-    hipLaunchKernelGGL(k_dense_fill, dim3((unsigned)rows), dim3(256), 0, stream, d_dense, (long long)ld, (long long)n_cols, d_row_ptr,
-                       d_col, d_q, active);
+    int tr0, n_trows, n_tc;
+    dense_tile_rows(active, rows, n_cols, &tr0, &n_trows, &n_tc);
+    const DenseSizes out{d_size, d_jac, d_first_col, d_par};
+    if (d_size)
+        hipLaunchKernelGGL(k_dense_fill<true>, dim3((unsigned)rows), dim3(256), 0, stream, d_dense, (long long)ld, (long long)n_cols,
+                           d_row_ptr, d_col, d_q, (long long)active.row_rel0, tr0, n_tc, d_list, d_list_n, d_ends, out);
+    else
+        hipLaunchKernelGGL(k_dense_fill<false>, dim3((unsigned)rows), dim3(256), 0, stream, d_dense, (long long)ld, (long long)n_cols,
+                           d_row_ptr, d_col, d_q, (long long)active.row_rel0, tr0, n_tc, d_list, d_list_n, d_ends, out);
     return 0;
 }
 
