@@ -109,6 +109,182 @@ __device__ __forceinline__ void stage_put(u64* stage, int lane, unsigned width, 
     }
 }
 
+// ---- the common row: 8-bit q values, Rice parameter at most 16, at least two cells ----
+// 256 cells per iteration, FOUR consecutive cells per lane: a quarter of the prefix sums, shuffles, stage hand-overs and
+// write-outs per cell of the general loop below (which spends ~390 instructions per chunk of 64 cells, whatever its LDS
+// atomics cost), the q values leave as one dword per lane without touching LDS, a lane's four low-bit fields (4 k bits) and
+// its four unary codes (a window of at most 64 bits when the lane's codes are that short) go into the stage words with one
+// or two ORs each.  The record layout is the one described at the top; the general loop handles everything else.
+struct FastRowIn {
+    int c[5];             // columns of cells i0 .. i0 + 3 and of cell i0 + 4 (indices clamped to the row)
+    unsigned q;           // the four q bytes (cells beyond the row: the last cell's byte, masked out when used)
+};
+
+template <typename Q>
+__device__ __forceinline__ void enc_row_fast(const int32_t* __restrict__ col, const Q* __restrict__ q, long long b, unsigned n,
+                                             const EncRow pr, u64* __restrict__ w, int lane, u64 (&st_l)[2][64], u64 (&st_h)[2][64]) {
+    const unsigned k = pr.k, nr = n - 1;
+    const u64 wq_words = ((u64)n * 8 + 63) / 64;
+    u64* qdst = w + 3;
+    u64* z = qdst + wq_words;
+    const u64 low_words = k ? ((u64)nr * k + 63) / 64 : 0;
+    const u64 idx = k ? 5 + low_words : 2;
+    u64* ldst = z + 5;
+    const u64 hw = (pr.high_bits + 63) / 64, ns = ((u64)nr + 63) / 64;
+    u64* high = z + idx + 2;
+    u64* samples = high + hw + 1;
+    if (lane == 0) {
+        w[0] = n;
+        w[1] = 8;
+        w[2] = wq_words;
+        z[0] = nr;
+        z[1] = k;
+        if (k) {
+            z[2] = nr;
+            z[3] = k;
+            z[4] = low_words;
+        }
+        z[idx] = pr.high_bits;
+        z[idx + 1] = hw;
+        high[hw] = ns;
+    }
+    const unsigned lmask = (1u << k) - 1u;
+    const int32_t* cb = col + b;
+    const Q* qb = q + b;
+    auto load = [&](unsigned c0, FastRowIn& in) {
+        const unsigned i0 = c0 + 4u * (unsigned)lane;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const unsigned i = i0 + (unsigned)j;
+            in.c[j] = cb[i < n ? i : nr];
+        }
+        unsigned qq = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned i = i0 + (unsigned)j;
+            qq |= (unsigned)qb[i < n ? i : nr] << (8 * j);
+        }
+        in.q = qq;
+    };
+    u64 base = 0, carry = 0;
+    bool direct = false;
+    unsigned it = 0;
+    auto iteration = [&](unsigned c0, const FastRowIn& in, FastRowIn& nxt) __attribute__((always_inline)) {
+        load(c0 + 256, nxt);                                   // in flight while this iteration is packed (clamped: harmless past the row)
+        u64* sl = st_l[it & 1];
+        u64* sh = st_h[it & 1];
+        const unsigned i0 = c0 + 4u * (unsigned)lane;
+        // deltas, quotients, code lengths of the lane's four cells
+        unsigned quot[4], low[4], len[4];
+        unsigned L = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool has = i0 + (unsigned)j < nr;
+            const unsigned d = has ? (unsigned)(in.c[j + 1] - in.c[j]) : 0u;
+            quot[j] = d >> k;
+            low[j] = d & lmask;
+            len[j] = has ? quot[j] + 1u : 0u;
+            L += len[j];
+        }
+        unsigned incl = L;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned up = (unsigned)__shfl_up((int)incl, o, 64);
+            if (lane >= o) incl += up;
+        }
+        const unsigned T = (unsigned)__shfl((int)incl, 63, 64);
+        const unsigned excl = incl - L;
+        const unsigned b63 = (unsigned)(base & 63);
+        const u64 w0 = base >> 6;
+        const unsigned nw = (b63 + T + 63u) >> 6;               // words this iteration's unary codes touch
+        const bool has_d = c0 < nr;                            // (the last iteration of a row may hold its last cell only)
+        const bool staged = has_d && !direct && nw <= 64u;
+        const unsigned lw = 4u * k;                            // low words of a full iteration (256 k bits)
+        if ((unsigned)lane < lw) sl[lane] = 0;
+        if (staged && (unsigned)lane < nw) sh[lane] = lane == 0 ? carry : 0;
+        wave_sync();
+        // q values: one dword per lane, straight to the record (the caller has zeroed it: the half word past the row stays 0)
+        if (i0 < n) {
+            const unsigned valid = n - i0 >= 4u ? 0xffffffffu : (1u << (8u * (n - i0))) - 1u;
+            reinterpret_cast<unsigned*>(qdst)[i0 >> 2] = in.q & valid;
+        }
+        if (has_d) {
+            if (k && i0 < nr) {                                // the lane's four low-bit fields: 4 k <= 64 bits at bit 4 k lane
+                u64 f = 0;
+#pragma unroll
+                for (int j = 3; j >= 0; --j) f = (f << k) | (u64)low[j];
+                const unsigned p = (unsigned)lane * lw, sw = p >> 6, so = p & 63u;
+                atomicOr(&sl[sw], f << so);
+                if (so + lw > 64u) atomicOr(&sl[sw + 1], f >> (64u - so));
+            }
+            if ((i0 & 63u) == 0u && i0 < nr) samples[i0 >> 6] = base + excl;     // bit position before every 64th element
+            if (staged) {
+                if (L) {
+                    const unsigned s0 = b63 + excl;             // the lane's first code starts here (relative to word w0)
+                    if (L <= 64u) {
+                        u64 win = 0;
+                        unsigned at = 0;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            if (len[j]) win |= 1ULL << (at + quot[j]);
+                            at += len[j];
+                        }
+                        const unsigned sw = s0 >> 6, so = s0 & 63u;
+                        atomicOr(&sh[sw], win << so);
+                        if (so && (win >> (64u - so))) atomicOr(&sh[sw + 1], win >> (64u - so));
+                    } else {
+                        unsigned at = s0;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            if (len[j]) {
+                                const unsigned pos = at + quot[j];
+                                atomicOr(&sh[pos >> 6], 1ULL << (pos & 63u));
+                            }
+                            at += len[j];
+                        }
+                    }
+                }
+            } else {
+                if (!direct) {
+                    if (lane == 0 && carry) atomicOr(&high[w0], carry);
+                    carry = 0;
+                    direct = true;
+                }
+                u64 at = base + excl;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (len[j]) {
+                        const u64 pos = at + quot[j];
+                        atomicOr(&high[pos >> 6], 1ULL << (pos & 63));
+                    }
+                    at += len[j];
+                }
+            }
+        }
+        wave_sync();
+        if (k && has_d) {
+            const unsigned remd = nr - c0 < 256u ? nr - c0 : 256u;
+            if ((unsigned)lane < (remd * k + 63u) / 64u) ldst[(u64)(c0 >> 6) * k + (u64)lane] = sl[lane];
+        }
+        if (staged) {
+            const bool ends_on_border = ((b63 + T) & 63u) == 0u;
+            const unsigned full = ends_on_border ? nw : nw - 1u;  // words that no later iteration adds to
+            if ((unsigned)lane < full) high[w0 + (u64)lane] = sh[lane];
+            carry = ends_on_border ? 0 : sh[nw - 1u];
+        }
+        base += T;
+        ++it;
+    };
+    FastRowIn A, B;
+    load(0, A);
+    for (unsigned c0 = 0; c0 < n; c0 += 512) {
+        iteration(c0, A, B);
+        if (c0 + 256 >= n) break;
+        iteration(c0 + 256, B, A);
+    }
+    if (lane == 0 && carry) high[base >> 6] = carry;
+}
+
 // Pass 2.  ONE loop over the row's chunks of 64 cells does all three containers of the record -- the q values, the low
 // bits of the column deltas, their unary quotients -- so the columns are read once, and the loads run ahead of their use
 // (columns two chunks, q one chunk): a wave's chunks depend on each other only through the bit position of the unary part,
@@ -117,7 +293,8 @@ __device__ __forceinline__ void stage_put(u64* stage, int lane, unsigned width, 
 template <typename Q>
 __global__ __launch_bounds__(64) void k_enc_fill(const long long* __restrict__ row_ptr, const int32_t* __restrict__ col,
                                                  const Q* __restrict__ q, const u64* __restrict__ offset,
-                                                 const EncRow* __restrict__ par, unsigned char* __restrict__ out, unsigned stage_words) {
+                                                 const EncRow* __restrict__ par, unsigned char* __restrict__ out, unsigned stage_words,
+                                                 int fast_rows) {
     __shared__ u64 st_q[2][64], st_l[2][64], st_h[2][64];
     const long long r = blockIdx.x;
     const int lane = threadIdx.x;
@@ -127,6 +304,10 @@ __global__ __launch_bounds__(64) void k_enc_fill(const long long* __restrict__ r
     const EncRow pr = par[r];
     const unsigned wq = pr.wq, k = pr.k;
     u64* w = reinterpret_cast<u64*>(out + offset[r]);
+    if (sizeof(Q) == 1 && fast_rows && wq == 8 && k <= 16 && n >= 2 && n < (1ULL << 31)) {       // row-uniform
+        enc_row_fast<Q>(col, q, b, (unsigned)n, pr, w, lane, st_l, st_h);
+        return;
+    }
     const u64 wq_words = (n * wq + 63) / 64;
     const u64 nr = n - 1;                                                // deltas; :732 a single-entry row has no delta sequence
     u64* qdst = w + 3;
@@ -280,12 +461,15 @@ int launch_encode_fill(hipStream_t stream, const long long* d_row_ptr, const int
                        int64_t rows, const unsigned long long* d_offset, const EncRow* d_par, unsigned char* d_out, int stage_words) {
     if (rows <= 0) return 0;
     const unsigned sw = stage_words < 1 ? 1u : (stage_words > 64 ? 64u : (unsigned)stage_words);
+    // stage_words = 64 (the default): common rows (8-bit q, Rice parameter <= 16) take the four-cells-per-lane loop; a lower
+    // value (tests) keeps every row on the general loop, whose fallbacks the value exists to exercise; 65+ = general loop, full stage
+    const int fast = stage_words == 64 ? 1 : 0;
     if (q_bytes == 2)
         hipLaunchKernelGGL(k_enc_fill<uint16_t>, dim3((unsigned)rows), dim3(64), 0, stream, d_row_ptr, d_col, (const uint16_t*)d_q,
-                           d_offset, d_par, d_out, sw);
+                           d_offset, d_par, d_out, sw, fast);
     else
         hipLaunchKernelGGL(k_enc_fill<uint8_t>, dim3((unsigned)rows), dim3(64), 0, stream, d_row_ptr, d_col, (const uint8_t*)d_q,
-                           d_offset, d_par, d_out, sw);
+                           d_offset, d_par, d_out, sw, fast);
     return 0;
 }
 
