@@ -117,8 +117,14 @@ int mvs_ctx_kernel_ms(mvs_ctx* ctx, int which, float* ms);
  *                         mvs_pairwise_stream with the two-stage comparison: up to stream_list_cells kept cells (bound from
  *                         the filter pass) leave as one sorted list, more through the dense byte matrix; stream_pipeline = 0
  *                         always filters the whole row range in one pass first (tests)
+ *   fragment_major        1 (default): the matrix-core kernels that move 16 samples x 64 k values per instruction (ping-pong
+ *                         filter and exact kernel, streaming search filter) read fragment-major copies of the coarse plane /
+ *                         limb planes, built once per resident set (+1 x the planes' bytes); 0: the row-major planes
+ *   search_stream         1 (default): blocks of up to 512 rows x at least 4096 columns outside the symmetric schedule (a
+ *                         search) take the streaming filter (rows resident in LDS, columns streamed); 0: the tile kernels
  *   stream_block_rows, encode_stage_words, pairwise_map, coarse_radix, cand_regions, recheck_mode, recheck_blocks
- *                         test / experiment switches (DESIGN.md, appendix "switches")
+ *                         test / experiment switches (DESIGN.md, appendix "switches"; encode_stage_words below 64 also keeps
+ *                         every row on the device encoder's general loop)
  *   comm_timeout_s        file transport (mvs_comm_create_files / _rendezvous): seconds a rank waits for its peers
  *   markers               1: roctx ranges named after the entry points around mvs_project_csr / mvs_pairwise_rows /
  *                         mvs_pairwise_block (rocprofv3 --marker-trace); libroctx64 is bound at run time
