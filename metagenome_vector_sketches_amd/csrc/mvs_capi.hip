@@ -316,6 +316,7 @@ const OptionSpec kOptions[] = {
     {"stream_trace", &mvs::Options::stream_trace, nullptr, 0, 1},
     {"search_stream", &mvs::Options::search_stream, nullptr, 0, 1},
     {"fragment_major", &mvs::Options::fragment_major, nullptr, 0, 1},
+    {"pairwise_bdirect", &mvs::Options::pairwise_bdirect, nullptr, 0, 1},
     {"pairwise_block_cells", nullptr, &mvs::Options::pairwise_block_cells, 1, (1LL << 62)},
 };
 

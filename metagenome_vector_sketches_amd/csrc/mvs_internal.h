@@ -70,6 +70,8 @@ struct Options {
                                     // rows are final -- and on the link -- a millisecond after the call started (10 % dense 100k:
                                     // encoded rows 37.4 against 38.4 ms, CSR pieces 94.5 against 102.9 ms = 1.02 x the link);
                                     // 0 = always one filter pass over the whole row range first
+    int pairwise_bdirect = 1;       // ping-pong kernels: 1 = the B operand's fragments come straight from the fragment-major plane into
+                                    // registers (LDS carries the A operand only), 0 = both operands through LDS
     int fragment_major = 1;         // 1: the matrix-core kernels that copy 16 samples x 64 k values per instruction (ping-pong filter and
                                     // exact kernel, streaming search filter) read fragment-major copies of the coarse plane / limb planes
                                     // (PairwiseArgs::coarse_fm, planes_fm), built once per set; 0: the row-major planes (A/B, tests)

@@ -1340,7 +1340,12 @@ __global__ __launch_bounds__(256) void k_cand_prune(const PairwiseArgs a, unsign
 // NT: cache policy of the HBM/L2 -> LDS copies: 0 default, 1 column panels (B region) non-temporal, 2 row panels (A region),
 // 3 both.  An XCD walks its sub-patch along a patch ROW, so consecutive groups of 32 tiles share their 4 row panels and
 // stream 8 new column panels through the L2; `nt` marks the stream as evict-first.
-template <int MODE, int NST, int ORDER = 0, int ABL = 0, int PH = 1, int NT = 0>
+// BD (needs the fragment-major planes and a tile origin on the 16-sample grid: the launcher checks): the B operand does not
+// go through LDS at all -- a wave loads its four B fragments of the NEXT slice straight from the fragment-major plane into
+// registers (one coalesced KiB per instruction, as k_search_filter does) while the matrix cores work on the current one,
+// and all eight waves copy the A region (two pieces each).  LDS then carries 8 instead of 12 fragment reads per wave and
+// slice and half the copy bytes: 80 instead of 128 bytes per clock at full matrix rate, which is its peak.
+template <int MODE, int NST, int ORDER = 0, int ABL = 0, int PH = 1, int NT = 0, int BD = 0>
 __global__ __launch_bounds__(512, 2) void k_pairwise_pp(const PairwiseArgs a, int n_tr, int n_tc) {
 #ifndef MVS_ABLATIONS
     static_assert(ABL == 0, "ablations need a -DMVS_ABLATIONS build");
@@ -1350,6 +1355,8 @@ __global__ __launch_bounds__(512, 2) void k_pairwise_pp(const PairwiseArgs a, in
     constexpr int L = G::L, TM = G::TM, TN = G::TN, kRegion = G::kRegion, kStage = G::kStage, kPPW = G::kPPW;
     constexpr int D = NST - 2;                                   // slices the copies run ahead
     static_assert(NST >= 3 && NST <= 5 && kPPW == 4, "ring geometry");
+    static_assert(BD == 0 || (NST == 4 && PH == 1 && ABL == 0 && NT == 0 && ORDER == 0), "the direct-B loop is written for the default ring");
+    constexpr int PA = BD ? 2 : kPPW;                            // pieces a wave copies per slice
 #ifdef MVS_ABLATIONS
     unsigned long long* stamp = nullptr;
     if (a.stamps && (unsigned long long)blockIdx.y * gridDim.x + blockIdx.x < kStampSlots) {
@@ -1399,12 +1406,12 @@ __global__ __launch_bounds__(512, 2) void k_pairwise_pp(const PairwiseArgs a, in
     // the plane -- 16 samples x 64 k values in fragment order -- so a copy instruction touches 8 whole lines instead of 16
     // half lines, its LDS image is the fragment itself (lane l's 16 bytes at l * 16: no swizzle, no bank conflict) and the
     // next k-slice is 1 KiB further on
-    const bool fmode = (MODE == 2 ? a.coarse_fm != nullptr : a.planes_fm != nullptr) && (((a.row_begin | a.col_begin) & 15) == 0);
+    const bool fmode = BD != 0 || ((MODE == 2 ? a.coarse_fm != nullptr : a.planes_fm != nullptr) && (((a.row_begin | a.col_begin) & 15) == 0));
     const int kstep = fmode ? 1024 : kSK;
-    const int8_t* src[kPPW];
+    const int8_t* src[PA];
 #pragma unroll
-    for (int p = 0; p < kPPW; ++p) {
-        const int row = (wave * kPPW + p) * 16 + (lane >> 2);    // [0, 2 * L * TM): A region then B region
+    for (int p = 0; p < PA; ++p) {
+        const int row = (wave * PA + p) * 16 + (lane >> 2);      // [0, 2 * L * TM): A region then B region (BD: A region only)
         const bool is_b = row >= L * TM;
         const int rr = is_b ? row - L * TM : row;
         const int limb = rr / TM, s = rr % TM;
@@ -1412,7 +1419,7 @@ __global__ __launch_bounds__(512, 2) void k_pairwise_pp(const PairwiseArgs a, in
         const int64_t sample = (is_b ? j0 : i0) + s;
         src[p] = (MODE == 2 ? a.coarse : a.planes) + (sample * L + limb) * (int64_t)a.d_pad + c * 16;
         if (fmode) {                                             // the piece = 16 samples of one limb plane
-            const int rr0 = (wave * kPPW + p) * 16 - (is_b ? L * TM : 0);
+            const int rr0 = (wave * PA + p) * 16 - (is_b ? L * TM : 0);
             const int64_t blk = ((is_b ? j0 : i0) + rr0 % TM) >> 4;
             src[p] = (MODE == 2 ? a.coarse_fm : a.planes_fm) + (blk * L + rr0 / TM) * (int64_t)(a.d_pad / kSK) * 1024 + lane * 16;
         }
@@ -1425,8 +1432,18 @@ __global__ __launch_bounds__(512, 2) void k_pairwise_pp(const PairwiseArgs a, in
     };
     auto stage_copy = [&](int slot, int k0) {
 #pragma unroll
-        for (int p = 0; p < kPPW; ++p) copy_piece(src[p] + k0, smem + slot * kStage + (wave * kPPW + p) * 1024);
+        for (int p = 0; p < PA; ++p) copy_piece(src[p] + k0, smem + slot * kStage + (wave * PA + p) * 1024);
     };
+    // BD: where the wave's four B fragments of slice 0 sit in the fragment-major plane (fragment i as in b_off below)
+    const int8_t* bsrc[4] = {nullptr, nullptr, nullptr, nullptr};
+    if constexpr (BD != 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int64_t colb = (j0 + (MODE == 2 ? wn * 64 + i * 16 : wn * 32 + (i >> 1) * 16)) >> 4;
+            const int limb = MODE == 2 ? 0 : (i & 1);
+            bsrc[i] = (MODE == 2 ? a.coarse_fm : a.planes_fm) + (colb * L + limb) * (int64_t)(a.d_pad / kSK) * 1024 + lane * 16;
+        }
+    }
     // ---- fragments: 8 of the A operand, 4 of the B operand per slice ----
     const int fr = lane & 15, fq = lane >> 4;
     const int coff = (fq ^ swz16(fr)) << 4;                      // tile bases are multiples of 16 samples
@@ -1459,84 +1476,158 @@ __global__ __launch_bounds__(512, 2) void k_pairwise_pp(const PairwiseArgs a, in
 #else
     const int nk = a.d_pad / kSK;
 #endif
+    if constexpr (BD != 0) {
+        // ---- direct-B loop: per phase 2 copies (slice s + 2) and 4 register loads (B of slice s + 1) are issued; at the end
+        // of the phase everything issued in EARLIER phases has to be through (slice s + 1 of A has landed, B of slice s is in
+        // its registers), what this phase issued may stay in flight ----
+        v4i fbA[4], fbB[4];
 #pragma unroll
-    for (int st = 0; st < D; ++st)
-        if (st < nk) stage_copy(st, st * kstep);
-    {   // slice 0 has landed <=> only the copies of the slices issued after it are outstanding
-        const int younger = (nk < D ? nk : D) - 1;
-        if (younger >= 2) wait_vmcnt<2 * kPPW>();
-        else if (younger == 1) wait_vmcnt<kPPW>();
-        else wait_vmcnt<0>();
-    }
-    __builtin_amdgcn_s_barrier();
-    if (wm == 1) __builtin_amdgcn_s_barrier();                   // group 1 runs one interval behind group 0
-    int slot = 0, fill = D % NST;
-    for (int s = 0; s < nk; ++s) {
-        const char* sb = smem + slot * kStage;
+        for (int st = 0; st < D; ++st)
+            if (st < nk) stage_copy(st, st * 1024);
+        // (inline asm: a load the compiler tracks makes it wait for vmcnt(0) in front of the MFMAs that use the registers a
+        // phase later -- which would drain this phase's copies and loads as well; the explicit waits below do the counting)
+        auto load_b = [&](v4i& dst, const int8_t* ptr) __attribute__((always_inline)) {
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory");
+        };
+        if (nk > 0) {
 #pragma unroll
-        for (int ph = 0; ph < PH; ++ph) {
-            constexpr int AF = 8 / PH, CP = kPPW / PH;               // A fragments / copy pieces per phase
-            // ---- LOAD: this phase's fragments (all B fragments belong to phase 0), its share of the copies ----
-            const bool copies_first = ORDER == 1 || (ORDER == 2 && (wn & 1));
-            auto copies = [&]() {
-                if (s + D < nk && ABL != 2) {
+            for (int i = 0; i < 4; ++i) load_b(fbA[i], bsrc[i]);
+        }
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (wm == 1) __builtin_amdgcn_s_barrier();               // group 1 runs one interval behind group 0
+        int slot = 0, fill = D % NST;
+        auto phase = [&](int s, v4i (&cur)[4], v4i (&nxt)[4]) __attribute__((always_inline)) {
+            const char* sb = smem + slot * kStage;
+            const bool more_a = s + D < nk, more_b = s + 1 < nk;
+            if (more_a) {
 #pragma unroll
-                    for (int p = ph * CP; p < (ph + 1) * CP; ++p)
-                        copy_piece(src[p] + (s + D) * kstep, smem + fill * kStage + (wave * kPPW + p) * 1024);
-                }
-            };
-            if (copies_first) copies();
-            if (ABL != 3 || s == 0) {
-                if (ph == 0) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) fb[i] = *reinterpret_cast<const v4i*>(sb + b_off[i]);
-                }
-#pragma unroll
-                for (int i = ph * AF; i < (ph + 1) * AF; ++i) fa[i] = *reinterpret_cast<const v4i*>(sb + a_off[i]);
+                for (int p = 0; p < PA; ++p) copy_piece(src[p] + (s + D) * 1024, smem + fill * kStage + (wave * PA + p) * 1024);
             }
+            if (more_b) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) load_b(nxt[i], bsrc[i] + (size_t)(s + 1) * 1024);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) fa[i] = *reinterpret_cast<const v4i*>(sb + a_off[i]);
             __builtin_amdgcn_sched_barrier(0);
-            if (!copies_first) copies();
-            if (ph == PH - 1) {
-                // slice s+1 must have landed before the barriers that open its readers' intervals: only slices
-                // s+2 .. min(s+D, nk-1) may still be in flight
-                const int last = s + D < nk - 1 ? s + D : nk - 1;
-                const int younger = last - (s + 1);
-                if (younger >= 2) wait_vmcnt<2 * kPPW>();
-                else if (younger == 1) wait_vmcnt<kPPW>();
-                else wait_vmcnt<0>();
-            }
-            // fragments in registers before the barrier: the MFMA interval then starts on the matrix pipe at once
+            if (more_a) wait_vmcnt<PA + 4>();
+            else if (more_b) wait_vmcnt<4>();
+            else wait_vmcnt<0>();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            // ---- MFMA ----
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_setprio(1);
-            if constexpr (ABL == 1) {
-                // no matrix-core work
-            } else if constexpr (MODE == 2) {
+            if constexpr (MODE == 2) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
 #pragma unroll
-                    for (int t = ph * AF; t < (ph + 1) * AF; ++t)
-                        accv[t * 4 + u] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[t], fb[u], accv[t * 4 + u], 0, 0, 0);
+                    for (int t = 0; t < 8; ++t)
+                        accv[t * 4 + u] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[t], cur[u], accv[t * 4 + u], 0, 0, 0);
             } else {
 #pragma unroll
                 for (int u = 0; u < 2; ++u)
 #pragma unroll
-                    for (int t = ph * AF / 2; t < (ph + 1) * AF / 2; ++t)
+                    for (int t = 0; t < 4; ++t)
 #pragma unroll
                         for (int la = 0; la < 2; ++la)
 #pragma unroll
                             for (int lb = 0; lb < 2; ++lb)
                                 accv[(t * 2 + u) * 3 + la + lb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(
-                                    fa[t * 2 + la], fb[u * 2 + lb], accv[(t * 2 + u) * 3 + la + lb], 0, 0, 0);
+                                    fa[t * 2 + la], cur[u * 2 + lb], accv[(t * 2 + u) * 3 + la + lb], 0, 0, 0);
             }
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
+            slot = slot == NST - 1 ? 0 : slot + 1;
+            fill = fill == NST - 1 ? 0 : fill + 1;
+        };
+        int s = 0;
+        for (; s + 2 <= nk; s += 2) {
+            phase(s, fbA, fbB);
+            phase(s + 1, fbB, fbA);
         }
-        slot = slot == NST - 1 ? 0 : slot + 1;
-        fill = fill == NST - 1 ? 0 : fill + 1;
+        if (s < nk) phase(s, fbA, fbB);
+    } else {
+    #pragma unroll
+        for (int st = 0; st < D; ++st)
+            if (st < nk) stage_copy(st, st * kstep);
+        {   // slice 0 has landed <=> only the copies of the slices issued after it are outstanding
+            const int younger = (nk < D ? nk : D) - 1;
+            if (younger >= 2) wait_vmcnt<2 * kPPW>();
+            else if (younger == 1) wait_vmcnt<kPPW>();
+            else wait_vmcnt<0>();
+        }
+        __builtin_amdgcn_s_barrier();
+        if (wm == 1) __builtin_amdgcn_s_barrier();                   // group 1 runs one interval behind group 0
+        int slot = 0, fill = D % NST;
+        for (int s = 0; s < nk; ++s) {
+            const char* sb = smem + slot * kStage;
+    #pragma unroll
+            for (int ph = 0; ph < PH; ++ph) {
+                constexpr int AF = 8 / PH, CP = kPPW / PH;               // A fragments / copy pieces per phase
+                // ---- LOAD: this phase's fragments (all B fragments belong to phase 0), its share of the copies ----
+                const bool copies_first = ORDER == 1 || (ORDER == 2 && (wn & 1));
+                auto copies = [&]() {
+                    if (s + D < nk && ABL != 2) {
+    #pragma unroll
+                        for (int p = ph * CP; p < (ph + 1) * CP; ++p)
+                            copy_piece(src[p] + (s + D) * kstep, smem + fill * kStage + (wave * kPPW + p) * 1024);
+                    }
+                };
+                if (copies_first) copies();
+                if (ABL != 3 || s == 0) {
+                    if (ph == 0) {
+    #pragma unroll
+                        for (int i = 0; i < 4; ++i) fb[i] = *reinterpret_cast<const v4i*>(sb + b_off[i]);
+                    }
+    #pragma unroll
+                    for (int i = ph * AF; i < (ph + 1) * AF; ++i) fa[i] = *reinterpret_cast<const v4i*>(sb + a_off[i]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (!copies_first) copies();
+                if (ph == PH - 1) {
+                    // slice s+1 must have landed before the barriers that open its readers' intervals: only slices
+                    // s+2 .. min(s+D, nk-1) may still be in flight
+                    const int last = s + D < nk - 1 ? s + D : nk - 1;
+                    const int younger = last - (s + 1);
+                    if (younger >= 2) wait_vmcnt<2 * kPPW>();
+                    else if (younger == 1) wait_vmcnt<kPPW>();
+                    else wait_vmcnt<0>();
+                }
+                // fragments in registers before the barrier: the MFMA interval then starts on the matrix pipe at once
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                // ---- MFMA ----
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(1);
+                if constexpr (ABL == 1) {
+                    // no matrix-core work
+                } else if constexpr (MODE == 2) {
+    #pragma unroll
+                    for (int u = 0; u < 4; ++u)
+    #pragma unroll
+                        for (int t = ph * AF; t < (ph + 1) * AF; ++t)
+                            accv[t * 4 + u] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[t], fb[u], accv[t * 4 + u], 0, 0, 0);
+                } else {
+    #pragma unroll
+                    for (int u = 0; u < 2; ++u)
+    #pragma unroll
+                        for (int t = ph * AF / 2; t < (ph + 1) * AF / 2; ++t)
+    #pragma unroll
+                            for (int la = 0; la < 2; ++la)
+    #pragma unroll
+                                for (int lb = 0; lb < 2; ++lb)
+                                    accv[(t * 2 + u) * 3 + la + lb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(
+                                        fa[t * 2 + la], fb[u * 2 + lb], accv[(t * 2 + u) * 3 + la + lb], 0, 0, 0);
+                }
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+            }
+            slot = slot == NST - 1 ? 0 : slot + 1;
+            fill = fill == NST - 1 ? 0 : fill + 1;
+        }
     }
     if (wm == 0) __builtin_amdgcn_s_barrier();                   // group 0 waits for group 1's last interval
 #ifdef MVS_ABLATIONS
@@ -2579,7 +2670,13 @@ int launch_mfma16(hipStream_t stream, const PairwiseArgs& a) {
     return 0;
 }
 
-template <int MODE, int NST, int ORDER = 0, int ABL = 0, int PH = 1, int NT = 0>
+// may the ping-pong kernel take its B operand straight from the fragment-major plane (k_pairwise_pp<.., BD = 1>)?
+static bool pp_direct_b(const PairwiseArgs& a, int mode, const Options& opt) {
+    return opt.pairwise_bdirect != 0 && (mode == 2 ? a.coarse_fm != nullptr : a.planes_fm != nullptr) &&
+           ((a.row_begin | a.col_begin) & 15) == 0;
+}
+
+template <int MODE, int NST, int ORDER = 0, int ABL = 0, int PH = 1, int NT = 0, int BD = 0>
 int launch_pp(hipStream_t stream, const PairwiseArgs& a) {
     using G = PpGeom<MODE>;
     const int64_t rows = a.row_end - a.row_begin, cols = a.col_end - a.col_begin;
@@ -2591,19 +2688,26 @@ int launch_pp(hipStream_t stream, const PairwiseArgs& a) {
     PairwiseArgs b = a;
     if (b.symmetric && ((a.row_begin - a.col_begin) % G::TM != 0 || a.mirror_all)) b.symmetric = 0;
     skinny_map(b, n_tr);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pairwise_pp<MODE, NST, ORDER, ABL, PH, NT>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pairwise_pp<MODE, NST, ORDER, ABL, PH, NT, BD>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return MVS_E_HIP;
-    hipLaunchKernelGGL((k_pairwise_pp<MODE, NST, ORDER, ABL, PH, NT>), dim3((unsigned)n_spc * 256u, (unsigned)n_spr), dim3(512), lds, stream,
+    hipLaunchKernelGGL((k_pairwise_pp<MODE, NST, ORDER, ABL, PH, NT, BD>), dim3((unsigned)n_spc * 256u, (unsigned)n_spr), dim3(512), lds, stream,
                        b, n_tr, n_tc);
     return 0;
+}
+
+// the default ping-pong kernel (4-stage ring), with the B operand straight from the fragment-major plane when that exists
+template <int MODE>
+int launch_pp_default(hipStream_t stream, const PairwiseArgs& a, const Options& opt) {
+    if (pp_direct_b(a, MODE, opt)) return launch_pp<MODE, 4, 0, 0, 1, 0, 1>(stream, a);
+    return launch_pp<MODE, 4>(stream, a);
 }
 
 template <int L, bool KARA, int MODE>
 int launch_mfma(hipStream_t stream, const PairwiseArgs& a, const Options& opt) {
     if constexpr (L == 2 && !KARA) {
         if (pairwise_variant(opt) == 7) return launch_pp<MODE, 5>(stream, a);
-        if (pairwise_variant(opt) == 8) return launch_pp<MODE, 4>(stream, a);
+        if (pairwise_variant(opt) == 8) return launch_pp_default<MODE>(stream, a, opt);
         if (pairwise_variant(opt) == 9) return launch_pp<MODE, 4, 0, 0, 2>(stream, a);
         if (pairwise_variant(opt) == 6) return launch_mfma16<MODE>(stream, a);
     }
@@ -2717,7 +2821,7 @@ int launch_filter(hipStream_t stream, const PairwiseArgs& a, const Options& opt)
     switch (v) {
         case 50: return launch_search_filter(stream, a);
         case 7: return launch_pp<2, 5>(stream, a);   // ping-pong wave groups, 256 x 256, 5-stage ring (all 160 KiB of LDS)
-        case 8: return launch_pp<2, 4>(stream, a);   // the same on a 4-stage ring
+        case 8: return launch_pp_default<2>(stream, a, opt);   // the same on a 4-stage ring (B operand direct when the fragment-major plane exists)
         case 9: return launch_pp<2, 4, 0, 0, 2>(stream, a);    // two phases per slice
         case 10: return launch_pp<2, 4, 2, 0, 2>(stream, a);   // two phases, copy / read order by wave parity
         case 40: return launch_pp<2, 4, 0, 0, 1, 1>(stream, a);   // variant 8 with non-temporal column-panel copies
@@ -2882,10 +2986,17 @@ int launch_exact_tiles(hipStream_t stream, const PairwiseArgs& a, const int* d_l
     b.tile_list = d_list;
     b.tile_list_n = n_list;
     const size_t lds = (size_t)4 * G::kStage;
+    const unsigned per = (4u * (unsigned)n_list + 7u) / 8u;
+    if (pp_direct_b(b, 0, opt)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pairwise_pp<0, 4, 0, 0, 1, 0, 1>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return MVS_E_HIP;
+        hipLaunchKernelGGL((k_pairwise_pp<0, 4, 0, 0, 1, 0, 1>), dim3(per * 8u), dim3(512), lds, stream, b, n_tr, n_tc);
+        return 0;
+    }
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pairwise_pp<0, 4>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return MVS_E_HIP;
-    const unsigned per = (4u * (unsigned)n_list + 7u) / 8u;
     hipLaunchKernelGGL((k_pairwise_pp<0, 4>), dim3(per * 8u), dim3(512), lds, stream, b, n_tr, n_tc);
     return 0;
 }

@@ -153,7 +153,7 @@ def ctx():
 def restore_options(ctx):
     """the context is shared by the whole session: whatever a test switches is switched back"""
     names = ("pairwise_filter", "pairwise_block_cells", "filter_variant", "exact_variant", "pairwise_variant",
-             "pairwise_symmetric", "sort", "tile_dense_thr", "stream_list_cells", "stream_block_rows", "stream_dense", "stream_pipeline", "search_stream", "fragment_major")
+             "pairwise_symmetric", "sort", "tile_dense_thr", "stream_list_cells", "stream_block_rows", "stream_dense", "stream_pipeline", "search_stream", "fragment_major", "pairwise_bdirect")
     old = {k: ctx.get_option(k) for k in names}
     yield
     for k, v in old.items():

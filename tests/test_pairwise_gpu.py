@@ -232,7 +232,8 @@ def test_full_width_properties(ctx, pw_filter):
 def test_fragment_major_planes_change_no_cell(ctx, n, d, clu):
     """The ping-pong exact kernel and the ping-pong tile filter copy their LDS pieces from fragment-major copies of the limb
     planes / the coarse plane (one contiguous KiB per copy instruction; option fragment_major, on by default) when the
-    block's origin is a multiple of 16 samples, otherwise from the row-major planes: every combination gives the cells of
+    block's origin is a multiple of 16 samples, otherwise from the row-major planes, and load the B operand's fragments
+    straight from those copies into registers (option pairwise_bdirect, on by default): every combination gives the cells of
     the row-major path -- exact kernel on every cell, two-stage with the ping-pong filter (flagged tiles go to the exact
     kernel on a tile list), sparse and dense results, blocks that start off the 16-sample grid, shards -- and an oracle
     stripe pins them."""
@@ -242,8 +243,11 @@ def test_fragment_major_planes_change_no_cell(ctx, n, d, clu):
     assert ss.limbs == 2
     cap = 1 << 23
     results = {}
-    for fmaj in (1, 0):
+    # (fragment_major, pairwise_bdirect): B operand straight from the fragment-major plane into registers / both operands
+    # through LDS copied from the fragment-major planes / the row-major planes
+    for fmaj, bdir in ((1, 1), (1, 0), (0, 0)):
         ctx.set_option("fragment_major", fmaj)
+        ctx.set_option("pairwise_bdirect", bdir)
         for filt, variant in ((0, -1), (2, 8)):
             ctx.set_option("pairwise_filter", filt)
             ctx.set_option("filter_variant", variant)
@@ -256,8 +260,8 @@ def test_fragment_major_planes_change_no_cell(ctx, n, d, clu):
                 c, _ = ctx.pairwise_rows(ss, n2, row_begin=b, row_end=e, capacity=cap)
                 parts += _cells_tuple(c)
             assert parts == whole
-            results[(fmaj, filt)] = whole
-    ref = results[(0, 0)]
+            results[(fmaj, bdir, filt)] = whole
+    ref = results[(0, 0, 0)]
     assert all(v == ref for v in results.values()) and len(ref) >= n
     want = _oracle_sorted(sk, n2, row_begin=1030, row_end=1060, chunk=192)
     assert [t for t in ref if 1030 <= t[0] < 1060] == want
