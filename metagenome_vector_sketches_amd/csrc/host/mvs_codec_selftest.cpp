@@ -408,7 +408,7 @@ int main(int argc, char* argv[]) {
             CHECK(writer.joinable());
             writer.join();
         }
-        CHECK(!std::filesystem::exists(mvs_host::csr_cache_path(p) + ".part"));
+        CHECK(!std::filesystem::exists(mvs_host::csr_cache_part_path(p)));
         CHECK(mvs_host::load_csr_cache(p, loaded));
         CHECK(plain.names.size() == 41 && plain.names[40] == "last" && plain.offsets[41] - plain.offsets[40] == 3);
         for (const mvs_host::HashSets* o : {&direct, &loaded}) {

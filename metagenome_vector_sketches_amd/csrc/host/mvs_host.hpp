@@ -109,6 +109,11 @@ struct CsrHeader {
 static_assert(sizeof(CsrHeader) == 64, "header layout");
 
 inline std::string csr_cache_path(const std::string& hash_file) { return hash_file + ".csr"; }
+// the file a cache is written to before it is renamed into place: one per writing process (two runs on the same hash file
+// must not write into each other's file)
+inline std::string csr_cache_part_path(const std::string& hash_file) {
+    return csr_cache_path(hash_file) + ".part." + std::to_string((long)::getpid());
+}
 
 inline bool text_identity(const std::string& path, uint64_t& size, int64_t& mtime_ns) {
     struct stat st;
@@ -551,7 +556,7 @@ inline bool read_hash_file(const std::string& path, bool with_names, HashSets& o
     if (!cache_for.empty() && with_names && total_room) {
         job = std::make_shared<CacheJob>();
         job->text = cache_for;
-        job->part = csr_cache_path(cache_for) + ".part";
+        job->part = csr_cache_part_path(cache_for);
         if (text_identity(cache_for, job->head.text_size, job->head.text_mtime_ns))
             job->fd = ::open(job->part.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
         if (job->fd < 0) {
@@ -700,7 +705,7 @@ inline bool write_csr_cache(const std::string& hash_file, const HashSets& sets, 
     uint64_t at = 0;
     for (size_t i = 0; i < sets.names.size(); ++i) ends[i] = at += sets.names[i].size();
     h.name_bytes = at;
-    const std::string path = csr_cache_path(hash_file), tmp = path + ".part";
+    const std::string path = csr_cache_path(hash_file), tmp = csr_cache_part_path(hash_file);
     // head: header, offsets, name ends, names, padding to 8
     std::string head;
     head.reserve(sizeof h + sets.offsets.size() * 8 + ends.size() * 8 + (size_t)at + 8);
