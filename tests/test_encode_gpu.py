@@ -136,10 +136,10 @@ def test_encoded_rows_decode_to_the_cell_list(ctx, gold, case):
         ctx.set_option("encode_stage_words", 64)
 
 
-@pytest.mark.parametrize("cluster", [2, 63, 64, 65, 128, 129, 193])
+@pytest.mark.parametrize("cluster", [2, 3, 4, 5, 63, 64, 65, 128, 129, 193, 255, 256, 257, 511, 513])
 def test_encoded_rows_at_chunk_borders(ctx, cluster):
-    """rows of exactly `cluster` cells (the encoder packs a row in chunks of 64 values: full chunks, one value more, one less,
-    several chunks), columns consecutive (Rice parameter 0) in one run, and with a second cluster far away in the same row
+    """rows of exactly `cluster` cells (the encoder packs a row in chunks of 64 values -- four cells per lane, 256 per
+    iteration, for the common rows --: full chunks / lanes / iterations, one value more, one less, several), columns consecutive (Rice parameter 0) in one run, and with a second cluster far away in the same row
     set (larger deltas, parameter > 0)"""
     n = cluster * 3
     sk = synth.make_sketches_numpy(n, 256, 3000, seed=cluster, cluster=cluster, shared=0.7)
@@ -156,6 +156,27 @@ def test_encoded_rows_at_chunk_borders(ctx, cluster):
     cells, cnt = ctx.pairwise_rows(ss, n2[idx])
     enc = ctx.pairwise_stream_encoded(ss, n2[idx])
     assert enc["n_cells"] == cnt and _decode(enc) == _cells(cells)
+    ss.close()
+
+
+def test_encoded_rows_with_distant_columns(ctx):
+    """rows whose few kept cells lie thousands of columns apart: Rice parameters around 10 (low-bit fields that straddle
+    stage words, unary codes of a lane that do not fit one window), rows of one and of two cells among them"""
+    rng = np.random.default_rng(9)
+    base = synth.make_sketches_numpy(2100, 2048, 3000, seed=21, cluster=1)
+    sk = np.concatenate([base, base + rng.integers(-2, 3, size=base.shape), base[:700] + rng.integers(-2, 3, size=(700, 2048))]).astype(np.int32)
+    n2 = _n2(sk)
+    ss = ctx.sketch_set(sk)
+    cells, cnt = ctx.pairwise_rows(ss, n2)
+    per_row = np.bincount(np.array([c["row"] for c in cells]), minlength=len(sk))
+    assert set(per_row.tolist()) >= {2, 3} and cnt >= 2 * len(sk)
+    for words in (64, 2):                                   # the four-cells-per-lane loop / the general loop with a small stage
+        ctx.set_option("encode_stage_words", words)
+        try:
+            enc = ctx.pairwise_stream_encoded(ss, n2)
+        finally:
+            ctx.set_option("encode_stage_words", 64)
+        assert enc["n_cells"] == cnt and _decode(enc) == _cells(cells)
     ss.close()
 
 
