@@ -420,6 +420,70 @@ int main(int argc, char* argv[]) {
         std::remove(mvs_host::csr_cache_path(p).c_str());
         std::remove(p.c_str());
     }
+    // whole files: random records (names with and without ':', empty lines, "\r\n", trailing blanks, bad tokens, duplicates,
+    // unordered and ordered values, long lines, a last line without newline) through read_hash_file with and without the
+    // cache written behind the parsers, against the scalar line parser applied line by line
+    {
+        std::mt19937_64 rng(123);
+        const std::string p = "/tmp/mvs_codec_selftest_hashes3.txt";
+        for (int round = 0; round < 60; ++round) {
+            std::string text;
+            std::vector<std::string> want_names;
+            std::vector<std::vector<uint64_t>> want_sets;
+            const int lines = 1 + (int)(rng() % 40);
+            for (int l = 0; l < lines; ++l) {
+                const int kind = (int)(rng() % 10);
+                std::string line;
+                if (kind == 0) {
+                    line = rng() % 2 ? "" : "a line without a colon 1 2 3";
+                } else {
+                    const std::string name = "s" + std::to_string(l) + (rng() % 5 == 0 ? " with blanks" : "");
+                    line = name + ":";
+                    const size_t n = kind == 1 ? 0 : kind == 2 ? 3000 + rng() % 3000 : rng() % 200;
+                    uint64_t run = rng() % 1000;
+                    for (size_t i = 0; i < n; ++i) {
+                        uint64_t v = rng() % 3 == 0 ? (run += 1 + rng() % 100000) : rng() >> (rng() % 40);
+                        if (round % 4 == 0) v = run += 1 + rng() % 1000;                     // an increasing file: the no-sort route
+                        line += std::string(1 + (rng() % 20 == 0), ' ') + std::to_string(v);
+                        if (rng() % 400 == 0) line += " " + std::to_string(v);                // a duplicate
+                    }
+                    if (rng() % 15 == 0) line += " 12x 5";
+                    if (rng() % 15 == 0) line += " -7 8";
+                    if (rng() % 10 == 0) line += "  ";
+                    std::vector<uint64_t> vals(mvs_host::count_token_starts_scalar(line.data() + name.size() + 1, line.data() + line.size()) + 1);
+                    bool inc = true;
+                    const size_t k = mvs_host::parse_u64_raw_scalar(line.data() + name.size() + 1, line.data() + line.size(), vals.data(), inc);
+                    vals.resize(k);
+                    std::sort(vals.begin(), vals.end());
+                    vals.erase(std::unique(vals.begin(), vals.end()), vals.end());
+                    want_names.push_back(name);
+                    want_sets.push_back(vals);
+                }
+                text += line;
+                if (l + 1 < lines || rng() % 2) text += round % 7 == 3 ? "\r\n" : "\n";
+            }
+            {
+                std::ofstream f(p, std::ios::binary);
+                f << text;
+            }
+            for (int cached = 0; cached < 2; ++cached) {
+                mvs_host::HashSets got;
+                CHECK(mvs_host::read_hash_file(p, true, got, 1 + (unsigned)(rng() % 5), cached ? p : std::string()));
+                mvs_host::HashSets from_cache;
+                if (cached && !want_names.empty() && got.hashes.size()) CHECK(mvs_host::load_csr_cache(p, from_cache));
+                for (const mvs_host::HashSets* o : {&got, &from_cache}) {
+                    if (o == &from_cache && from_cache.names.empty()) continue;
+                    CHECK(o->names == want_names && o->offsets.size() == want_names.size() + 1);
+                    for (size_t i = 0; i < want_sets.size(); ++i) {
+                        CHECK((size_t)(o->offsets[i + 1] - o->offsets[i]) == want_sets[i].size());
+                        for (size_t j = 0; j < want_sets[i].size(); ++j) CHECK(o->hashes[(size_t)o->offsets[i] + j] == want_sets[i][j]);
+                    }
+                }
+                std::remove(mvs_host::csr_cache_path(p).c_str());
+            }
+        }
+        std::remove(p.c_str());
+    }
     CHECK(mvs_host::format_g(56.46254) == "56.4625" && mvs_host::format_g(1234567.0) == "1.23457e+06");
     CHECK(mvs_host::format_g_float(-3.0f) == "-3" && mvs_host::format_g(0.0) == "0");
     std::cout << "mvs_codec_selftest ok" << std::endl;
