@@ -122,7 +122,7 @@ int mvs_ctx_kernel_ms(mvs_ctx* ctx, int which, float* ms);
  *                         limb planes, built once per resident set (+1 x the planes' bytes); 0: the row-major planes
  *   pairwise_bdirect      1 (default): with those copies, the ping-pong kernels load the B operand's fragments straight into
  *                         registers and LDS carries the A operand only; 0: both operands through LDS
- *   search_stream         1 (default): blocks of up to 512 rows x at least 4096 columns outside the symmetric schedule (a
+ *   search_stream         1 (default): blocks of up to 640 rows x at least 4096 columns outside the symmetric schedule (a
  *                         search) take the streaming filter (rows resident in LDS, columns streamed); 0: the tile kernels
  *   stream_block_rows, encode_stage_words, pairwise_map, coarse_radix, cand_regions, recheck_mode, recheck_blocks
  *                         test / experiment switches (DESIGN.md, appendix "switches"; encode_stage_words below 64 also keeps

@@ -1485,7 +1485,10 @@ __global__ __launch_bounds__(512, 2) void k_pairwise_pp(const PairwiseArgs a, in
         for (int st = 0; st < D; ++st)
             if (st < nk) stage_copy(st, st * 1024);
         // (inline asm: a load the compiler tracks makes it wait for vmcnt(0) in front of the MFMAs that use the registers a
-        // phase later -- which would drain this phase's copies and loads as well; the explicit waits below do the counting)
+        // phase later -- which would drain this phase's copies and loads as well; the explicit waits below do the counting.
+        // The compiler believes the asm's result is there at once, so the scheme relies on it leaving fbA / fbB where they
+        // are between issue and use: in the generated code the loads' destinations are the MFMAs' operands, and
+        // test_fragment_major_planes_change_no_cell / the pw_filter fixture compare this kernel with the LDS-only one)
         auto load_b = [&](v4i& dst, const int8_t* ptr) __attribute__((always_inline)) {
             asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory");
         };
@@ -2861,7 +2864,9 @@ static int launch_search_filter_rb(hipStream_t stream, const PairwiseArgs& a) {
     const int groups = (int)((rows + 16 * RB - 1) / (16 * RB));
     const long long chunks = (a.col_end - (a.col_begin & ~(int64_t)15) + 511) / 512;   // the chunk grid starts on a multiple of 16
     // one workgroup per CU (its LDS holds the group's rows); per XCD `slots` column walkers x `groups` row groups
-    const int slots = std::max(1, std::min<int>(32 / std::max(1, groups) + (32 % std::max(1, groups) ? 1 : 0), (int)((chunks + 7) / 8)));
+    // (rounded DOWN: the workgroups hold one CU each, 8 x slots x groups of them must fit the 256 CUs in ONE round -- rounded up,
+    // three groups made 264 workgroups and the last eight ran after all the others)
+    const int slots = std::max(1, std::min<int>(32 / std::max(1, groups), (int)((chunks + 7) / 8)));
     const size_t lds = (size_t)16 * RB * ((size_t)a.d_pad + 16) + (size_t)16 * RB * sizeof(float4);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_search_filter<RB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return MVS_E_HIP;
@@ -2882,13 +2887,13 @@ static int launch_search_filter(hipStream_t stream, const PairwiseArgs& a) {
 static int filter_variant_for(const PairwiseArgs& a, const Options& opt) {
     int v = opt.filter_variant;
     // 50: the streaming search filter -- a block of few rows that is not under the symmetric schedule, against at least
-    // 4096 columns (option search_stream = 0 leaves such blocks to the tile kernels).  Few = up to 512 when the kernel is
+    // 4096 columns (option search_stream = 0 leaves such blocks to the tile kernels).  Few = up to 640 when the kernel is
     // picked by size: 64 resident rows read the coarse plane once (10^6 columns: 0.35 ms), every further group of 64 reads
-    // it again, mostly from the XCD's L2 -- streamed from the fragment-major plane 256 rows take 0.65 ms and 512 rows 1.18 ms
-    // (1.0 and 1.83 ms from the row-major plane; the 256 x 256 tile filter 1.3 and ~1.5 ms); beyond eight groups the grid no
-    // longer fits the 256 CUs in one round (640 rows: 2.2 ms against 1.6 ms on tiles, 1023 rows 2.2 against 1.9); asked for
+    // it again, mostly from the XCD's L2 -- streamed from the fragment-major plane 256 rows take 0.65 ms, 512 rows 1.15 ms
+    // and 640 rows 1.48 ms (1.0 / 1.83 / 3.7 ms from the row-major plane; the 256 x 256 tile filter 1.3 / ~1.5 / 1.6 ms);
+    // beyond ten groups fewer than 240 of the 256 CUs get a workgroup (1023 rows: 2.2 ms against 1.9 on tiles); asked for
     // by number (filter_variant 50) it takes up to 1023 rows.
-    const int64_t few = v == 50 ? 1023 : 512;
+    const int64_t few = v == 50 ? 1023 : 640;
     if ((v < 0 || v == 50) && opt.search_stream != 0 && !a.symmetric && a.row_end - a.row_begin <= few &&
         a.col_end - a.col_begin >= 4096 && search_filter_rb(a) > 0)
         return 50;

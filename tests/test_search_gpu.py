@@ -168,7 +168,7 @@ def test_streaming_search_filter_equals_exact_kernel(ctx, d, n_db):
             ctx.set_option("pairwise_filter", filt)
             ctx.set_option("search_stream", stream)
             ctx.set_option("fragment_major", fm)
-            ctx.set_option("filter_variant", variant)    # 50 by number: up to 1023 rows (by size: up to 512)
+            ctx.set_option("filter_variant", variant)    # 50 by number: up to 1023 rows (by size: up to 640)
             cnt = fn()
             ctx.synchronize()
             out.append((sorted(map(tuple, cells[:cnt].cpu().numpy().tolist())), ctx.pairwise_candidates()))

@@ -1,8 +1,6 @@
 #!/bin/bash
-# search_bench for several query counts: streaming filter from the fragment-major plane (default) / the row-major plane
-for nq in 1 16 64 256 512 640 700 1023; do
-  for fm in 1 0; do
-    echo "== nq $nq MVS_FRAGMENT_MAJOR $fm"
-    MVS_FRAGMENT_MAJOR=$fm python tools/search_bench.py 1000000 2048 $nq 8 2>&1 | tail -2 | cut -c1-60,140-260
-  done
+# search_bench for several query counts (streaming filter by size up to 512 rows, by number beyond)
+for nq in 96 160 192 320 384 448 512 576 640; do
+    echo "== nq $nq"
+    MVS_FILTER_VARIANT=50 python tools/search_bench.py 1000000 2048 $nq 8 2>&1 | tail -2 | head -1 | cut -c1-60,140-260
 done
