@@ -478,12 +478,7 @@ def main():
                                 # NOT a roofline fraction: bit-slicing does 64 sign-accumulations in ~4.4 instructions
                                 "sign_accumulations_per_s_T": k1_intops / (k1 * 1e-3) / 1e12,
                                 "int32_lane_op_peak_T": VALU_INT_PEAK_TOPS},
-        "roofline_pairwise_step": {"kernel": "k_pairwise_mfma<filter> (128 x 128 ring tiles) + k_exact_pairs", "bound": "mfma",
-                                   "workload": "the %d x %d comparison inside the step" % (S, N_total),
-                                   "achieved": k2_flops / (k2 * 1e-3) / 1e12, "peak": INT8_MFMA_PEAK_TOPS,
-                                   "unit": "TFLOP/s", "frac": k2_flops / (k2 * 1e-3) / 1e12 / INT8_MFMA_PEAK_TOPS,
-                                   "two_stage": state["candidates"] > 0, "candidates": state["candidates"],
-                                   "traffic": traffic.get("k_pairwise_mfma_filter")},
+        "roofline_pairwise_step": step_pairwise_roofline(state, S, N_total, D, k2, k2_flops, traffic),
     }
 
     if args.pairwise_samples and world == 1:
@@ -533,6 +528,32 @@ def main():
 
     print(json.dumps(res))
     shutdown()
+
+
+def step_pairwise_roofline(state, S, N_total, D, k2_ms, k2_flops, traffic):
+    """MFMA utilisation of the filter kernel inside the configs[1] step: int8 operations issued (the tiles the launch
+    computed, in the kernel's own tile size, x one pass of 2 * edge^2 * d_pad) / the filter kernel's time / 5 POP/s.
+    The 2 d flop per cell of the rank's rows x all columns over ALL comparison kernels stays beside it as
+    `algorithmic_credit` (not a utilisation)."""
+    fi = state.get("filter_info")          # (variant, tile edge, tiles, d_pad) of the step's last filter launch, or None
+    credit = {"flops": k2_flops, "kernels_ms": k2_ms, "tflops": k2_flops / (k2_ms * 1e-3) / 1e12,
+              "ratio_to_peak": k2_flops / (k2_ms * 1e-3) / 1e12 / INT8_MFMA_PEAK_TOPS,
+              "note": "2 d flop per cell of this rank's rows x all columns over filter + re-check; not a utilisation"}
+    rec = {"bound": "mfma", "workload": "the %d x %d comparison inside the step" % (S, N_total),
+           "peak": INT8_MFMA_PEAK_TOPS, "unit": "TOP/s (int8 operations issued to the matrix cores)",
+           "two_stage": state["candidates"] > 0, "candidates": state["candidates"], "algorithmic_credit": credit,
+           "traffic": traffic.get("k_pairwise_pp_filter", traffic.get("k_pairwise_mfma_filter"))}
+    f_ms = state.get("filter_ms")
+    if not fi or not f_ms:
+        rec.update(kernel="exact kernel on every cell (no filter pass in this step)", achieved=None, frac=None)
+        return rec
+    variant, edge, tiles, d_pad = fi
+    issued = tiles * 2.0 * edge * edge * d_pad
+    rec.update(kernel="%s, %d x %d tiles" % ("k_pairwise_pp<filter>" if variant in (7, 8, 9, 10, 40, 41, 42) else
+                                             "k_search_filter" if variant == 50 else "k_pairwise_mfma<filter> (ring)", edge, edge),
+               achieved=issued / (f_ms * 1e-3) / 1e12, frac=issued / (f_ms * 1e-3) / 1e12 / INT8_MFMA_PEAK_TOPS,
+               issued_ops=issued, tiles=tiles, kernel_ms=f_ms)
+    return rec
 
 
 def comm_facts(coll, world):
@@ -678,23 +699,37 @@ def pairwise_leg(ctx, dev, n, d, nh, reps):
     cells_total = float(n) * n
     flops = 2.0 * d * cells_total
     two, ex = out["two_stage"], out["exact"]
-    tiles_share = 0.5 + 0.5 * 256.0 / n            # symmetric schedule: upper triangle + the diagonal tiles
     traffic, src = pmc_traffic("configs[2]") if (n, d) == (100_000, 2048) else ({}, {"file": None, "dropped": "non-default size"})
     t_f = two.get("filter_kernel_ms", two["kernels_ms"])
-    roof = {"kernel": "k_pairwise_pp<filter> + k_exact_pairs (two-stage comparison)", "bound": "mfma",
-            "workload": "configs[2]", "achieved": flops / (two["kernels_ms"] * 1e-3) / 1e12,
-            "peak": INT8_MFMA_PEAK_TOPS, "unit": "TFLOP/s",
-            "frac": flops / (two["kernels_ms"] * 1e-3) / 1e12 / INT8_MFMA_PEAK_TOPS,
-            "algorithmic_flops": flops, "kernel_ms": two["kernels_ms"],
-            # matrix-core work actually issued by the filter: ONE int8 pass over the tiles the symmetric schedule
-            # computes; the re-check of the candidates runs on the vector ALU
-            "issued": {"kernel": "k_pairwise_pp<filter> (ping-pong wave groups, 256 x 256 tiles)", "kernel_ms": t_f,
-                       "tflops": flops * tiles_share / (t_f * 1e-3) / 1e12,
-                       "frac": flops * tiles_share / (t_f * 1e-3) / 1e12 / INT8_MFMA_PEAK_TOPS},
+    # MFMA UTILISATION: int8 operations the matrix cores were actually given / kernel time / 5 POP/s.
+    # Filter: the 256 x 256 tiles the launch computed (the library's count: tiles on and above the diagonal of the
+    # symmetric square) x ONE pass of 2 * 256^2 * d_pad operations.  Exact kernel: the 128 x 128 tiles on and above the
+    # diagonal x the four limb-pair passes.  Neither can exceed 1.  What the result is WORTH -- 2 d operations per cell
+    # of the N x N matrix the reference computes, over the same time -- is `algorithmic_credit`: it counts both
+    # triangles although one is computed and four passes although the filter runs one, so it may exceed 1.
+    d_pad = (d + 127) // 128 * 128
+    n256, n128 = (n + 255) // 256, (n + 127) // 128
+    filter_tiles = two.get("filter_tiles") or n256 * (n256 + 1) // 2
+    issued_filter = filter_tiles * 2.0 * 256 * 256 * d_pad
+    issued_exact = n128 * (n128 + 1) // 2 * 4 * 2.0 * 128 * 128 * d_pad
+    roof = {"kernel": "k_pairwise_pp<filter> (ping-pong wave groups, 256 x 256 tiles, one int8 pass)", "bound": "mfma",
+            "workload": "configs[2]", "achieved": issued_filter / (t_f * 1e-3) / 1e12,
+            "peak": INT8_MFMA_PEAK_TOPS, "unit": "TOP/s (int8 operations issued to the matrix cores)",
+            "frac": issued_filter / (t_f * 1e-3) / 1e12 / INT8_MFMA_PEAK_TOPS,
+            "issued_ops": issued_filter, "tiles": filter_tiles, "kernel_ms": t_f,
+            "cross_check": "tiles x 2 x 256^2 x d_pad / 32768 = v_mfma_i32_16x16x64_i8 instructions per launch "
+                           "(SQ_INSTS_VALU_MFMA_I8 in profiles/*_c2_pmc_summary.txt)",
+            "mfma_instructions": issued_filter / 32768.0,
+            "algorithmic_credit": {"flops": flops, "kernels_ms": two["kernels_ms"],
+                                   "tflops": flops / (two["kernels_ms"] * 1e-3) / 1e12,
+                                   "ratio_to_peak": flops / (two["kernels_ms"] * 1e-3) / 1e12 / INT8_MFMA_PEAK_TOPS,
+                                   "note": "2 d flop per cell of the full N x N matrix over filter + re-check + flagged "
+                                           "tiles; NOT a utilisation: the symmetric schedule computes one triangle and "
+                                           "the filter one of the four limb passes, so this ratio can exceed 1"},
             "exact_kernel": {"kernel": "k_pairwise_pp<exact> (4 limb-pair passes per cell)", "kernel_ms": ex["kernels_ms"],
-                             "algorithmic_frac": flops / (ex["kernels_ms"] * 1e-3) / 1e12 / INT8_MFMA_PEAK_TOPS,
-                             "issued_frac": 4.0 * flops * (0.5 + 0.5 * 128.0 / n) / (ex["kernels_ms"] * 1e-3) / 1e12 /
-                             INT8_MFMA_PEAK_TOPS},
+                             "frac": issued_exact / (ex["kernels_ms"] * 1e-3) / 1e12 / INT8_MFMA_PEAK_TOPS,
+                             "issued_ops": issued_exact,
+                             "algorithmic_credit_ratio": flops / (ex["kernels_ms"] * 1e-3) / 1e12 / INT8_MFMA_PEAK_TOPS},
             # the only single-pass exact matrix type would be fp64 (78.6 TFLOP/s dense on MI355X)
             "vs_fp64_matrix_peak": flops / (two["kernels_ms"] * 1e-3) / 1e12 / FP64_MATRIX_PEAK_TFLOPS,
             "traffic": traffic.get("k_pairwise_pp_filter"),

@@ -14,7 +14,37 @@
         }                                                                            \
     } while (0)
 
+// `mvs_codec_selftest --parse <file> names|lines`: what read_hash_file() makes of a hash text file, one record per line as
+// "<hex of the name>\t<count>\t<values>" -- the CPU suite compares it with what the reference binaries did with the same
+// bytes (tests/golden/ref_parser.json).  MVS_HOST_NO_SIMD=1 takes the scalar parser.
+static int dump_parse(const char* path, bool with_names) {
+    mvs_host::HashSets sets;
+    if (!mvs_host::read_hash_file(path, with_names, sets, 2)) {
+        std::cerr << "cannot read " << path << std::endl;
+        return 2;
+    }
+    static const char* hex = "0123456789abcdef";
+    for (size_t i = 0; i + 1 < sets.offsets.size(); ++i) {
+        std::string line;
+        if (with_names)
+            for (unsigned char ch : sets.names[i]) {
+                line += hex[ch >> 4];
+                line += hex[ch & 15];
+            }
+        line += '\t';
+        line += std::to_string(sets.offsets[i + 1] - sets.offsets[i]);
+        line += '\t';
+        for (int64_t k = sets.offsets[i]; k < sets.offsets[i + 1]; ++k) {
+            if (k > sets.offsets[i]) line += ' ';
+            line += std::to_string(sets.hashes[(size_t)k]);
+        }
+        std::cout << line << "\n";
+    }
+    return 0;
+}
+
 int main(int argc, char* argv[]) {
+    if (argc == 4 && std::string(argv[1]) == "--parse") return dump_parse(argv[2], std::string(argv[3]) == "names");
     std::mt19937_64 rng(12345);
     // compact_vector: widths 1..64, sizes incl. 0 and 1
     for (int width = 1; width <= 64; ++width) {

@@ -196,16 +196,16 @@ inline size_t sort_unique_u64(uint64_t* v, size_t n) {
     return (size_t)(std::unique(v, v + n) - v);
 }
 
-// An upper bound of the number of values parse_u64_raw() extracts from [p, end): every extracted value starts at a
-// character above ' ' that follows one at or below ' ' (or the start).  All the parser's whitespace is at or below ' ';
-// treating more characters as blanks can only count more starts.
+// An upper bound of the number of values parse_u64_raw() extracts from [p, end): every extracted value consumes one whole
+// run of decimal digits (an optional sign in front of it), so there are at most as many values as digit runs -- "12-3" is
+// two values to `iss >> hash` (12, then -3 modulo 2^64), "1+2+3" three.  Exact for well-formed lines without duplicates.
 inline size_t count_token_starts_scalar(const char* p, const char* end) {
     size_t count = 0;
-    bool prev_blank = true;
+    bool prev_digit = false;
     for (; p < end; ++p) {
-        const bool blank = (signed char)*p < 0x21;
-        count += (size_t)(!blank && prev_blank);
-        prev_blank = blank;
+        const bool digit = (unsigned)(*p - '0') <= 9u;
+        count += (size_t)(digit && !prev_digit);
+        prev_digit = digit;
     }
     return count;
 }
@@ -244,10 +244,9 @@ inline size_t parse_u64_raw_scalar(const char* p, const char* end, uint64_t* dst
         p = q;
         if (overflow) break;                                   // failbit in the reference
         if (negate) v = 0 - v;
-        if (p < end && !(*p == ' ' || *p == '\t' || *p == '\r' || *p == '\v' || *p == '\f')) {
-            push(v);                                           // "12abc": 12 is extracted, then the stream fails
-            break;
-        }
+        // the extraction stops at the first character that is not a digit and the NEXT one starts right there: "12abc"
+        // gives 12 and then fails at 'a', "12-3" gives 12 and then -3 (modulo 2^64), "1+2" gives 1 and 2
+        // (tests/golden/ref_parser.json: the reference binaries on such lines)
         push(v);
     }
     return n;
@@ -257,19 +256,19 @@ inline size_t parse_u64_raw_scalar(const char* p, const char* end, uint64_t* dst
 #define MVS_HOST_AVX2 __attribute__((target("avx2,bmi,popcnt")))
 MVS_HOST_AVX2 inline size_t count_token_starts_avx2(const char* p, const char* end) {
     size_t count = 0;
-    uint32_t carry = 1;                                       // the start counts as "after a blank"
-    const __m256i lim = _mm256_set1_epi8(0x21);
+    uint32_t carry = 0;                                       // was the byte in front a digit?
+    const __m256i below0 = _mm256_set1_epi8('0' - 1), above9 = _mm256_set1_epi8('9' + 1);
     for (; end - p >= 32; p += 32) {
         const __m256i c = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(p));
-        const uint32_t w = (uint32_t)_mm256_movemask_epi8(_mm256_cmpgt_epi8(lim, c));    // (signed char) c < 0x21
-        count += (size_t)__builtin_popcount(~w & ((w << 1) | carry));
+        const uint32_t w = (uint32_t)_mm256_movemask_epi8(_mm256_and_si256(_mm256_cmpgt_epi8(c, below0), _mm256_cmpgt_epi8(above9, c)));
+        count += (size_t)__builtin_popcount(w & ~((w << 1) | carry));
         carry = w >> 31;
     }
-    bool prev_blank = carry != 0;
+    bool prev_digit = carry != 0;
     for (; p < end; ++p) {
-        const bool blank = (signed char)*p < 0x21;
-        count += (size_t)(!blank && prev_blank);
-        prev_blank = blank;
+        const bool digit = (unsigned)(*p - '0') <= 9u;
+        count += (size_t)(digit && !prev_digit);
+        prev_digit = digit;
     }
     return count;
 }

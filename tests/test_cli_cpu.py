@@ -100,3 +100,71 @@ def test_convert_error_paths(tmp_path):
     r = run(exe, "convert", str(tmp_path / "sigs"), str(tmp_path / "out.txt"))
     assert r.returncode == 0 and "Failed to unzip" in r.stderr
     assert (tmp_path / "out.txt").read_text() == "broken:\n"       # sample kept with an empty set, like the reference
+
+
+# ---- the text parser against what the REFERENCE binaries did with the same bytes (tests/golden/ref_parser.json,
+# ---- written by tests/golden/make_golden_parser.py from oracle/_ref/project_everything and standalone_projection) ----
+def _ref_parser_fixture():
+    import json
+    with open(os.path.join(ROOT, "tests", "golden", "ref_parser.json")) as f:
+        return json.load(f)
+
+
+def _parse_with_tool(path, mode, simd):
+    """mvs_codec_selftest --parse: (names, [sorted unique values]) as read_hash_file() returns them"""
+    import numpy as np
+    env = dict(os.environ)
+    if not simd:
+        env["MVS_HOST_NO_SIMD"] = "1"
+    r = subprocess.run([os.path.join(BIN, "mvs_codec_selftest"), "--parse", str(path), mode], capture_output=True, env=env)
+    assert r.returncode == 0, r.stderr
+    names, sets = [], []
+    for line in r.stdout.decode("ascii").split("\n")[:-1]:
+        hexname, count, vals = line.split("\t")
+        v = np.array([int(t) for t in vals.split()], dtype=np.uint64)
+        assert len(v) == int(count) and (len(v) < 2 or bool(np.all(v[1:] > v[:-1])))
+        names.append(bytes.fromhex(hexname).decode("latin-1"))
+        sets.append(v)
+    return names, sets
+
+
+def test_text_parser_against_reference_binary_on_malformed_lines(tmp_path):
+    """src/project_everything.cpp:264-281 (`while (iss >> hash)` per "name: ..." record): signs, 2^64 and beyond, digits
+    glued to letters or to signs, every kind of blank, lines without / with several ':', empty names, CR LF, no final newline,
+    an empty file.  Both parsers (AVX2 fast path with its scalar fallback; scalar only) must give the sets whose d = 128
+    projection (oracle, itself pinned against the reference) equals the vectors.bin the reference binary wrote, under the
+    names it wrote."""
+    import numpy as np
+    from oracle import pyoracle as orc
+    fx = _ref_parser_fixture()
+    d = fx["d"]
+    for key, case in sorted(fx["sketch"].items()):
+        p = tmp_path / ("sk_%s.txt" % key)
+        p.write_bytes(case["input"].encode("latin-1"))
+        want = np.array(case["vectors"], dtype=np.int32).reshape(len(case["names"]), d)
+        for simd in (True, False):
+            names, sets = _parse_with_tool(p, "names", simd)
+            assert names == case["names"], (key, simd)
+            assert case["stdout_first"].startswith("Loaded %d hash sets from " % len(names)), key
+            for i, v in enumerate(sets):
+                got = orc.project(v, d)
+                assert np.array_equal(got, want[i]), (key, simd, names[i], v[:8])
+
+
+def test_text_parser_against_reference_standalone_projection(tmp_path):
+    """src/standalone_projection.cpp:28-36: every line is a set (no names, no ':' rule); the reference's stdout is the
+    float rendering of the d = 128 sketch of what it parsed"""
+    import numpy as np
+    from oracle import pyoracle as orc
+    fx = _ref_parser_fixture()
+    d = fx["d"]
+    for key, case in sorted(fx["standalone_projection"].items()):
+        p = tmp_path / ("sp_%s.txt" % key)
+        p.write_bytes(case["input"].encode("latin-1"))
+        want_lines = case["stdout"].split("\n")[:-1]
+        for simd in (True, False):
+            _, sets = _parse_with_tool(p, "lines", simd)
+            assert len(sets) == len(want_lines), (key, simd)
+            for v, line in zip(sets, want_lines):
+                got = " ".join("%g" % float(np.float32(x)) for x in orc.project(v, d))
+                assert got == line, (key, simd)

@@ -413,6 +413,40 @@ def test_degenerate_inputs(tmp_path):
     assert (0, 0, 255) in got and (1, 1, 255) in got
 
 
+def test_executables_on_the_references_malformed_input_fixtures(tmp_path):
+    """tests/golden/ref_parser.json: what oracle/_ref/project_everything sketch and oracle/_ref/standalone_projection did with
+    signs, 2^64, digits glued to letters / signs, tabs / CR / VT / FF, lines without or with several ':', empty names, an
+    empty file (src/project_everything.cpp:264-281, src/standalone_projection.cpp:28-36).  Ours: the same "Loaded" count, the
+    same names, the same vectors.bin, the same stdout."""
+    import hashlib
+    import json
+    with open(os.path.join(ROOT, "tests", "golden", "ref_parser.json")) as f:
+        fx = json.load(f)
+    d = fx["d"]
+    for key, case in sorted(fx["sketch"].items()):
+        p = tmp_path / ("sk_%s.txt" % key)
+        p.write_bytes(case["input"].encode("latin-1"))
+        db = tmp_path / ("db_%s" % key)
+        r = subprocess.run([os.path.join(BIN, "project_everything"), "sketch", str(p), str(db), "-d", str(d)],
+                           capture_output=True, env=dict(os.environ, MVS_NO_CSR_CACHE="1"))
+        assert r.returncode == 0, (key, r.stderr)
+        first = r.stdout.decode("latin-1").split("\n")[0]
+        assert first.split(" from ")[0] == case["stdout_first"].split(" from ")[0], key
+        want = np.array(case["vectors"], dtype="<i4").reshape(len(case["names"]), d)
+        got = np.fromfile(str(db / "vectors.bin"), dtype="<i4")
+        assert hashlib.sha256(got.tobytes()).hexdigest() == hashlib.sha256(want.tobytes()).hexdigest(), key
+        lines = (db / "vector_norms.txt").read_bytes().decode("latin-1").split("\n")[:-1]
+        assert [l.rsplit(" ", 1)[0] for l in lines] == case["names"], key
+        for l, ref in zip(lines, case["norms"]):
+            assert abs(float(l.rsplit(" ", 1)[1]) - float(ref)) <= 1e-5 * abs(float(ref)) + 1e-12, key
+    for key, case in sorted(fx["standalone_projection"].items()):
+        p = tmp_path / ("sp_%s.txt" % key)
+        p.write_bytes(case["input"].encode("latin-1"))
+        r = subprocess.run([os.path.join(BIN, "standalone_projection"), str(p), str(d)], capture_output=True)
+        assert r.returncode == 0, (key, r.stderr)
+        assert r.stdout.decode("latin-1") == case["stdout"], key
+
+
 REF = os.path.join(ROOT, "oracle", "_ref")
 
 
