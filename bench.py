@@ -223,6 +223,9 @@ def main():
     ap.add_argument("--search-samples", type=int, default=500_000,
                     help="N=1: database size of the search leg (1 / 16 / 64 / 256 / 1024 query sketches against that many resident "
                          "sketches, mvs_search_block); 0 skips it")
+    ap.add_argument("--strong-steps", type=int, default=10,
+                    help="default mode: timed steps of the strong-scaled pairwise legs (configs[2] 100k x 2048 and configs[3] "
+                         "100k x 4096 split over the N ranks, reported as `strong`); 0 skips them")
     ap.add_argument("--overlap-parts", type=int, default=2,
                     help="N > 1: pieces the rank's samples are projected in; the all-gather of a finished piece's limb "
                          "planes runs beside the projection of the next (1: no overlap)")
@@ -319,7 +322,8 @@ def main():
             coll = parallel.TorchCollectives(dist, rank, world, stream=side)
 
     if args.config != 2:
-        res = strong_scaling(args, ctx, dev, rank, world, dist if world > 1 else None, coll, coll_note)
+        res = strong_run(args, ctx, dev, rank, world, dist if world > 1 else None, coll, args.config, args.steps, args.warmup)
+        res["config"]["collectives_note"] = coll_note
         if rank == 0:
             print(json.dumps(res))
         shutdown()
@@ -367,7 +371,6 @@ def main():
         _, cnt, info = sc.finish(cells_out=cells)
         state["k1_ms"] = k1
         state["cnt"] = cnt
-        state["candidates"] = ctx.pairwise_candidates()
         state["limbs"] = info["limbs"]
         state["schedule"] = info.get("schedule", "rows x all columns")
         state["allgather_bytes_per_rank"] = info["allgather_bytes_per_rank"]
@@ -384,14 +387,19 @@ def main():
     k1_ms, k2_ms, gather_ms = [], [], []
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        sc.ops.k2_ms = 0.0
         step()
         k1_ms.append(state["k1_ms"])
-        gather_ms.append(sc.last_gather_ms())    # events recorded before the comparison: already complete
-        # symmetric multi-rank schedule: several comparison launches per step (summed by GpuOps)
-        k2_ms.append(sc.ops.k2_ms if sc.ops.k2_ms > 0 else ctx.kernel_ms(1))
+        gather_ms.append(sc.last_gather_ms())    # events recorded before the comparison's end: already complete
+        # the comparison kernels of the rank's block plan: filter launches + re-check + exact kernel on flagged tiles
+        ps = ctx.plan_stats()
+        k2_ms.append(ps["filter_ms"] + ps["recheck_ms"] + ps["tiles_ms"])
+        state["plan"] = ps
     sync_all()
     elapsed = time.perf_counter() - t0
+    ps = state["plan"]
+    state["candidates"] = ps["candidates"]
+    state["filter_ms"] = ps["filter_ms"] if not ps["exact_mode"] else None
+    state["filter_info"] = None if ps["exact_mode"] else (8, 256, ps["filter_tiles"], ps["d_pad"])
     # outside the timed region: the device's text round trip against the host's (printf / strtod semantics)
     if not np.array_equal(n2_local.cpu().numpy(), fast_norm_sq(sumsq.cpu().numpy(), D)):
         raise SystemExit("device norm text round trip differs from the host's")
@@ -405,6 +413,26 @@ def main():
     else:
         kept_total = state["cnt"]
 
+    # ---- the strong-scaled pairwise step on every rank count: configs[2] and configs[3] split over the N ranks ----
+    total_hashes = float(offsets[S])                       # == S * NH unless --lognormal-sigma
+
+    def run_strong():
+        strong = {}
+        for cfg in (3, 4):
+            torch.cuda.empty_cache()
+            rec = strong_run(args, ctx, dev, rank, world, dist if world > 1 else None, coll, cfg, args.strong_steps, 3)
+            strong["configs[%d]" % (cfg - 1)] = {"workload": rec["config"]["workload"], "cells_per_s": rec["value"],
+                                                 "ms_per_step": rec["ms_per_step"], "kept_cells": rec["config"]["kept_cells"],
+                                                 "schedule": rec["config"]["schedule"], "overlap": rec["config"]["overlap"],
+                                                 "rccl_ranks": rec["config"].get("rccl_ranks", 0), "stages": rec["stages"],
+                                                 "roofline": rec["roofline"]}
+        return strong
+
+    strong = {}
+    if args.strong_steps > 0 and world > 1:                # every rank takes part; with one rank the legs run last (below)
+        del hashes, sketches, cells, sc
+        strong = run_strong()
+
     if rank != 0:
         shutdown()
         return
@@ -417,7 +445,6 @@ def main():
     limbs = state["limbs"]
 
     # roofline of the dominant kernel (K1, projection): algorithmic bytes = 8*n_i + 4*d per sample
-    total_hashes = float(offsets[S])                       # == S * NH unless --lognormal-sigma
     k1_bytes = 8.0 * total_hashes + 4.0 * D * S
     k1_gbs = k1_bytes / (k1 * 1e-3) / 1e9
     k1_intops = total_hashes * D             # sign accumulations
@@ -526,6 +553,11 @@ def main():
         if "pairwise" in res:
             res["pairwise"]["vs_cpu_port_all_cores"] = res["pairwise"]["cells_per_s"] / res["cpu_baseline"]["pairwise_cells_per_s"]
 
+    if args.strong_steps > 0 and world == 1:
+        del hashes, sketches, cells, sc
+        strong = run_strong()
+    if strong:
+        res["strong"] = strong
     print(json.dumps(res))
     shutdown()
 
@@ -573,81 +605,121 @@ def comm_facts(coll, world):
     return facts
 
 
-def strong_scaling(args, ctx, dev, rank, world, dist, coll, coll_note):
-    """--config 3 / 4 / 5: BASELINE.json configs[2] / [3] / [4] -- pairwise only, a FIXED number of synthesised sketches
-    split over the ranks by the reference's shard formula.  One step = re-code this rank's rows into its block of the
-    plane buffer -> all-gather of the int8 plane blocks and the norms -> this rank's share of the symmetric block plan
-    (two-stage comparison) -> exchange of the mirrored cells -> this rank's shard, sorted.  Sketches and norms are
-    resident in HBM when the clock starts."""
+STRONG = {3: (100_000, 2048, 2345), 4: (100_000, 4096, 3456), 5: (1_000_000, 2048, 4567)}   # --config -> (N, d, seed)
+
+
+def strong_run(args, ctx, dev, rank, world, dist, coll, config, steps, warmup):
+    """BASELINE.json configs[2] / [3] / [4] -- pairwise only, a FIXED number of synthesised sketches split over the ranks by
+    the reference's shard formula (src/pairwise_comp_optimized.cpp:937-940).  One step = parallel.ShardedComparison.run():
+    re-code this rank's rows (limb planes + the filter's coarse plane and row statistics, OWN rows only) -> all-gather of
+    statistics + norms, coarse plane in chunks, limb planes (on the communicator's stream) -> this rank's block plan of the
+    symmetric schedule (the diagonal block's filter starts at once, the peers' blocks as their chunks land) -> re-check,
+    flagged tiles -> kept cells routed, the mirror images exchanged, collected, sorted.  Sketches and norms are resident in HBM
+    when the clock starts.  Returns the rank-0 record (every rank takes part in its reductions)."""
     import torch
     from metagenome_vector_sketches_amd import parallel, synth
-    n_total, d = {3: (100_000, 2048), 4: (100_000, 4096), 5: (1_000_000, 2048)}[args.config]
+    n_total, d, seed = STRONG[config]
     rb, re = parallel.shard_rows(n_total, world, rank)
-    sk = synth.make_sketches_torch_rows(n_total, d, args.hashes, seed={3: 2345, 4: 3456, 5: 4567}[args.config], device=dev,
-                                        row_begin=rb, row_end=re)
+    sk = synth.make_sketches_torch_rows(n_total, d, args.hashes, seed=seed, device=dev, row_begin=rb, row_end=re)
     ss = torch.empty(re - rb, dtype=torch.int64, device=dev)
     _, max_abs = ctx.stats(sk, out=ss)
-    n2_local = fast_norm_sq(ss.cpu().numpy(), d)
+    n2_local = torch.from_numpy(fast_norm_sq(ss.cpu().numpy(), d)).to(dev)
     sc = parallel.ShardedComparison(parallel.GpuOps(ctx, dev), rank, world, collectives=coll)
     sc.time_gather = True
-    cap = max(1 << 22, 40 * (re - rb) + (1 << 20))
+    sc.trace = []
+    cap = max(1 << 21, 40 * (re - rb) + (1 << 20))
     cells = torch.empty((cap, 4), dtype=torch.int32, device=dev)
     state = {}
 
     def step():
-        sc.ops.k2_ms = 0.0
         _, cnt, info = sc.run(sk, n2_local, n_total, cells_out=cells, max_abs_local=max_abs)
-        state.update(cnt=cnt, info=info, k2=sc.ops.k2_ms if sc.ops.k2_ms > 0 else ctx.kernel_ms(1))
+        state.update(cnt=cnt, info=info)
 
     def sync_all():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     sync_all()
-    k2, gather = [], []
+    acc = {k: [] for k in ("filter", "recheck", "tiles", "prepare", "plan_span", "cells", "gather")}
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
-        k2.append(state["k2"])
-        gather.append(sc.last_gather_ms())
+        ps = ctx.plan_stats()                          # waits for the plan's last kernel, not for the sort behind it
+        acc["filter"].append(ps["filter_ms"])
+        acc["recheck"].append(ps["recheck_ms"])
+        acc["tiles"].append(ps["tiles_ms"])
+        acc["gather"].append(sc.last_gather_ms())
+        state["plan"] = ps
     sync_all()
     elapsed = time.perf_counter() - t0
+    # stage spans of the LAST step from the events the step left on its streams
+    tr = dict(sc.trace)
+    def span(a, b):
+        return tr[a].elapsed_time(tr[b]) if a in tr and b in tr else 0.0
+    ready = [k for k in tr if k.startswith("own rows")][-1]
+    prepare_ms = span("step begin", ready)
+    plan_span_ms = span("plan begin", "plan finished")
+    cells_ms = span("plan finished", "cells sorted")
     kept = state["cnt"]
+    k2 = float(np.mean(acc["filter"]) + np.mean(acc["recheck"]) + np.mean(acc["tiles"]))
+    vals = [elapsed, k2, float(np.mean(acc["gather"])), prepare_ms, plan_span_ms, cells_ms, float(np.mean(acc["filter"]))]
     if world > 1:
-        t = torch.tensor([elapsed, float(np.mean(k2)), float(np.mean(gather))], dtype=torch.float64, device=dev)
+        t = torch.tensor(vals, dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, k2_max, gather_max = (float(x) for x in t.tolist())
+        vals = [float(x) for x in t.tolist()]
         c = torch.tensor([kept], dtype=torch.int64, device=dev)
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
         kept = int(c.item())
-    else:
-        k2_max, gather_max = float(np.mean(k2)), float(np.mean(gather))
-    info = state["info"]
+    elapsed, k2_max, gather_max, prepare_ms, plan_span_ms, cells_ms, filter_ms = vals
+    info, ps = state["info"], state["plan"]
     cells_total = float(n_total) * n_total
-    per_step = elapsed / args.steps
+    per_step = elapsed / steps
+    ms = per_step * 1e3
+    # MFMA utilisation of this rank's filter launches: tiles computed x one int8 pass / their time / 5 POP/s (never > 1);
+    # 2 d flop per cell of the rank's share of the N x N matrix stays beside it as algorithmic credit
+    issued = ps["filter_tiles"] * 2.0 * 256 * 256 * ps["d_pad"] if not ps["exact_mode"] else 0.0
+    roof = {"kernel": "k_pairwise_pp<filter> over the rank's block plan (%d launches)" % ps["filter_launches"], "bound": "mfma",
+            "achieved": issued / (filter_ms * 1e-3) / 1e12 if filter_ms > 0 else None, "peak": INT8_MFMA_PEAK_TOPS,
+            "unit": "TOP/s per GPU (int8 operations issued to the matrix cores, rank 0's tile count over the slowest rank's time)",
+            "frac": issued / (filter_ms * 1e-3) / 1e12 / INT8_MFMA_PEAK_TOPS if filter_ms > 0 else None,
+            "issued_ops": issued, "tiles": ps["filter_tiles"], "kernel_ms": filter_ms,
+            "algorithmic_credit": {"flops_per_gpu": 2.0 * d * cells_total / world, "kernels_ms": k2_max,
+                                   "ratio_to_peak": 2.0 * d * cells_total / world / (k2_max * 1e-3) / 1e12 / INT8_MFMA_PEAK_TOPS
+                                   if k2_max > 0 else None,
+                                   "note": "2 d flop per cell of the rank's share of the full matrix; not a utilisation (one "
+                                           "triangle computed, one of four limb passes in the filter): may exceed 1"},
+            "traffic": None}
     return {"metric": "samples projected/sec + pairwise Jaccard cells/sec, d=2048, 1/2/4/8 GPUs",
             "value": cells_total / per_step, "unit": "pairwise cells/s (ordered pairs of the full N x N matrix, whole job)",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": per_step * 1e3,
+            "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": ms,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "int8 limbs x int32 MFMA accumulate; fp64 keep test", "data": "synthetic",
             "config": {"workload": "configs[%d]: %d synthetic samples, d=%d, pairwise, row shards over %d GPU(s)" %
-                                   (args.config - 1, n_total, d, world),
+                                   (config - 1, n_total, d, world),
                        "total_samples": n_total, "d": d, "limbs": info["limbs"], "kept_cells": kept,
-                       "schedule": info.get("schedule", "rows x all columns"),
-                       "collectives": info.get("collectives"), "collectives_note": coll_note, **comm_facts(coll, world)},
-            "stages": {"comparison_kernels_ms_max_over_ranks": k2_max, "allgather_ms_max_over_ranks": gather_max,
+                       "schedule": info.get("schedule"), "overlap": info.get("overlap"), "gather_chunks": sc.gather_chunks,
+                       "collectives": info.get("collectives"), **comm_facts(coll, world)},
+            "stages": {"prepare_own_rows_ms": prepare_ms,
+                       "comparison_kernels_ms_max_over_ranks": k2_max,
+                       "filter_ms": filter_ms, "recheck_ms": float(np.mean(acc["recheck"])), "flagged_tiles_ms": float(np.mean(acc["tiles"])),
+                       "filter_launches": ps["filter_launches"], "filter_tiles": ps["filter_tiles"], "candidates": ps["candidates"],
+                       "flagged_tiles": ps["flagged_tiles"],
+                       "plan_span_ms": plan_span_ms,
+                       # what the comparison waited for on top of its own kernels between plan begin and plan end: the
+                       # exchange that the diagonal block did not cover, the mid-plan host synchronisation, launch gaps
+                       "exposed_in_plan_ms": max(0.0, plan_span_ms - k2_max),
+                       "allgather_ms_max_over_ranks": gather_max,
                        "allgather_bytes_per_rank": info["allgather_bytes_per_rank"],
                        "allgather_bytes_received_per_rank": info["allgather_bytes_per_rank"] * (world - 1),
+                       "cells_route_exchange_sort_ms": cells_ms,
                        "exchanged_cells": info.get("exchanged_cells", 0),
-                       "other_ms": per_step * 1e3 - k2_max - gather_max},
-            "roofline": {"kernel": "k_pairwise_pp<filter> + k_exact_pairs (per rank)", "bound": "mfma",
-                         "achieved": 2.0 * d * cells_total / world / (k2_max * 1e-3) / 1e12, "peak": INT8_MFMA_PEAK_TOPS,
-                         "unit": "TFLOP/s per GPU (algorithmic: 2 d flop per cell of the rank's share)",
-                         "frac": 2.0 * d * cells_total / world / (k2_max * 1e-3) / 1e12 / INT8_MFMA_PEAK_TOPS,
-                         "traffic": None}}
+                       "other_ms": ms - prepare_ms - plan_span_ms - cells_ms,
+                       "note": "prepare + plan span + cells + other = ms_per_step; spans are the last step's, from events on the "
+                               "step's streams (max over ranks); host synchronisations per step: 2"},
+            "roofline": roof}
 
 
 def pairwise_leg(ctx, dev, n, d, nh, reps):

@@ -362,6 +362,75 @@ int mvs_search_block(mvs_ctx* ctx, const mvs_sketch_set* set, const double* norm
                      int64_t row_begin, int64_t row_end, int64_t col_begin, int64_t col_end, mvs_cell* cells,
                      int64_t capacity, int64_t* n_cells);
 
+/* ---- block plans: one rank's share of the symmetric multi-rank schedule, compared in few launches ----------------
+ * The reference shards by rows and lets every shard process compute its rows against ALL columns
+ * (src/pairwise_comp_optimized.cpp:937-982); dot, keep test and quantised Jaccard are symmetric in (row, col), so with G
+ * ranks every unordered pair of row blocks needs comparing only once (metagenome_vector_sketches_amd/parallel.py:
+ * block_plan).  A rank's share -- its diagonal block under the symmetric schedule plus G/2 off-diagonal blocks whose kept
+ * cells are mirrored -- is handed over as rectangles and runs as ONE two-stage comparison: the filter in as few launches
+ * as the caller wants (one per group of rectangles whose columns have arrived: the blocks of a peer can be launched as soon
+ * as that peer's rows have landed, while the rest of the exchange is still on the wire), then one re-check, one launch of
+ * the exact kernel on the flagged tiles.  One host synchronisation, in mvs_plan_finish.
+ *
+ * STORAGE coordinates.  Plans work on a set whose rows are laid out in per-rank blocks of `block_rows_padded` rows
+ * (mvs_shard_layout: the shard size ceil(N / G) of :938-940 rounded up to a multiple of 256, so that every block starts on
+ * the tile grid and on the 16-row grid of the fragment-major planes; the rows behind a shard's last sample are zero
+ * sketches with zero norms).  Kept cells come out in storage coordinates; mvs_cells_route turns them into sample indices
+ * and drops anything that touches a padding row.
+ *
+ * mvs_sketch_set_attach_derived : the filter's inputs for this set -- the fragment-major coarse plane (n_alloc * d_pad
+ *     bytes) and 16 bytes of statistics per row -- live in CALLER buffers from now on: the caller fills them for its own
+ *     rows with mvs_sketch_set_prepare_rows and for the other ranks' rows by gathering those ranks' (mvs_allgather_rows on
+ *     the coarse plane in units of 16 rows, mvs_allgather_bytes on the statistics), instead of every rank rebuilding them
+ *     for all N rows from the gathered limb planes.  Two-limb sets only (others: the calls succeed and plans run the exact
+ *     kernel block by block).
+ * mvs_sketch_set_prepare_rows   : coarse plane + statistics of rows [row_first, row_first + row_count) from the limb planes
+ *     (row_first and row_count multiples of 16).  Asynchronous.
+ * mvs_plan_begin  : frame = the rank's own row block [frame_row_begin, frame_row_end) (multiples of 256) x all columns;
+ *     the symmetric schedule applies inside the frame's square; MVS_PLAN_MIRROR_OUTSIDE mirrors every kept cell outside it.
+ *     norms_sq and cells are DEVICE buffers (norms indexed by storage row); cells are appended from index 0, unsorted.
+ * mvs_plan_filter : the filter over these rectangles (rows inside the frame; bounds on multiples of 256 or at the set's
+ *     end) as one launch.  Asynchronous: the caller orders it behind the arrival of the columns it reads.
+ * mvs_plan_finish : re-check + flagged tiles.  *d_count = DEVICE address of the running cell count (it may exceed the
+ *     capacity: cells beyond it were dropped, compare after reading it back).  Synchronises once in the middle. */
+#define MVS_PLAN_MIRROR_OUTSIDE 1
+typedef struct {
+    int64_t row_begin, row_end, col_begin, col_end;
+} mvs_plan_block;
+int mvs_shard_layout(int64_t n_total, int world, int64_t* block_rows, int64_t* block_rows_padded);
+int mvs_sketch_set_attach_derived(mvs_sketch_set* set, int8_t* coarse_fm, void* row_stats);
+int mvs_sketch_set_prepare_rows(mvs_ctx* ctx, mvs_sketch_set* set, int64_t row_first, int64_t row_count);
+int mvs_plan_begin(mvs_ctx* ctx, const mvs_sketch_set* set, const double* norms_sq, int keep_mode, int64_t frame_row_begin,
+                   int64_t frame_row_end, int flags, mvs_cell* cells, int64_t capacity);
+int mvs_plan_filter(mvs_ctx* ctx, const mvs_plan_block* blocks, int n_blocks);
+int mvs_plan_finish(mvs_ctx* ctx, const uint64_t** d_count);
+/* What the last plan did.  ms (timing enabled, else zeros): [0] filter launches summed, [1] re-check (candidate gather,
+ * pruning, k_exact_pairs), [2] exact kernel on the flagged tiles, [3] first filter launch .. end of the plan on the stream.
+ * counts: [0] candidates, [1] flagged tiles, [2] 256 x 256 filter tiles computed, [3] filter launches, [4] 1 if the plan ran
+ * the exact kernel block by block (no filter), [5] d_pad.  Call after the stream has drained. */
+int mvs_plan_stats(mvs_ctx* ctx, double ms[4], int64_t counts[6]);
+
+/* Kept cells of a plan -> this rank's shard.  A cell of the plan is in storage coordinates and, under the symmetric
+ * multi-rank schedule, about half of them are mirror images that belong to OTHER ranks' rows.
+ * mvs_cells_route   : cells [0, min(*d_n_raw, raw_capacity)) -> sample indices (row = block * block_rows + offset for offset <
+ *     block_rows; cells touching a padding row or a row >= n_total are dropped); those of rows [own_begin, own_end) are
+ *     appended to own_out (count in *d_own_count, DEVICE, zeroed by this call), the others to `send` = a 64-byte header
+ *     {foreign cells (may exceed the capacity), status, max_abs, *d_n_raw, raw_capacity, ...} followed by foreign_capacity
+ *     cells.  status / max_abs travel in the header so that one exchange tells every rank how every other rank fared.
+ * mvs_cells_collect : `recv` = world such buffers (after an all-gather of the send buffers): the cells of rows
+ *     [own_begin, own_end) in the other ranks' buffers are appended to own_out.
+ * mvs_cells_report  : read back -- out[0] = *d_own_count, then per rank {foreign cells, status, max_abs, raw cells,
+ *     raw capacity} (5 * world values).  Synchronous; the other two are asynchronous. */
+int mvs_cells_route(mvs_ctx* ctx, const mvs_cell* raw, const uint64_t* d_n_raw, int64_t raw_capacity, int64_t block_rows_padded,
+                    int64_t block_rows, int64_t n_total, int64_t own_begin, int64_t own_end, mvs_cell* own_out,
+                    int64_t own_capacity, uint64_t* d_own_count, void* send, int64_t foreign_capacity, int64_t status,
+                    int64_t max_abs);
+int mvs_cells_collect(mvs_ctx* ctx, const void* recv, int world, int rank, int64_t foreign_capacity, int64_t own_begin,
+                      int64_t own_end, mvs_cell* own_out, int64_t own_capacity, uint64_t* d_own_count);
+int mvs_cells_report(mvs_ctx* ctx, const void* recv, int world, int64_t foreign_capacity, const uint64_t* d_own_count,
+                     int64_t* out);
+#define MVS_CELLS_HEADER_BYTES 64
+
 /* Sort n cells by (row, col) from one DEVICE buffer into another (asynchronous on the context's stream). */
 int mvs_cells_sort(mvs_ctx* ctx, const mvs_cell* cells_in, int64_t n, mvs_cell* cells_out);
 

@@ -112,6 +112,17 @@ SYMBOLS = [
     ("mvs_allgather_f64", _c.c_int, [_P, _P, _P, _c.c_int64]),
     ("mvs_allgather_bytes", _c.c_int, [_P, _P, _P, _c.c_int64]),
     ("mvs_allreduce_max_i64", _c.c_int, [_P, _P, _c.POINTER(_c.c_int64)]),
+    ("mvs_shard_layout", _c.c_int, [_c.c_int64, _c.c_int, _c.POINTER(_c.c_int64), _c.POINTER(_c.c_int64)]),
+    ("mvs_sketch_set_attach_derived", _c.c_int, [_P, _P, _P]),
+    ("mvs_sketch_set_prepare_rows", _c.c_int, [_P, _P, _c.c_int64, _c.c_int64]),
+    ("mvs_plan_begin", _c.c_int, [_P, _P, _P, _c.c_int, _c.c_int64, _c.c_int64, _c.c_int, _P, _c.c_int64]),
+    ("mvs_plan_filter", _c.c_int, [_P, _P, _c.c_int]),
+    ("mvs_plan_finish", _c.c_int, [_P, _c.POINTER(_P)]),
+    ("mvs_plan_stats", _c.c_int, [_P, _c.POINTER(_c.c_double), _c.POINTER(_c.c_int64)]),
+    ("mvs_cells_route", _c.c_int, [_P, _P, _P, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _P,
+                                    _c.c_int64, _P, _P, _c.c_int64, _c.c_int64, _c.c_int64]),
+    ("mvs_cells_collect", _c.c_int, [_P, _P, _c.c_int, _c.c_int, _c.c_int64, _c.c_int64, _c.c_int64, _P, _c.c_int64, _P]),
+    ("mvs_cells_report", _c.c_int, [_P, _P, _c.c_int, _c.c_int64, _P, _c.POINTER(_c.c_int64)]),
     ("mvs_chunk_size", _c.c_int64, [_c.c_double, _c.c_int]),
     ("mvs_shard_rows", None, [_c.c_int64, _c.c_int, _c.c_int, _c.POINTER(_c.c_int64), _c.POINTER(_c.c_int64)]),
 ]
@@ -199,6 +210,10 @@ class SketchSet:
         _check(self.ctx.lib.mvs_sketch_set_fill_stats(self._h, p, eb, m, int(row_offset), n, ctypes.byref(mx)))
         return mx.value
 
+    def touch(self):
+        """the caller has rewritten the planes: data the library derived from them is rebuilt on the next comparison"""
+        _check(self.ctx.lib.mvs_sketch_set_touch(self._h))
+
     def close(self):
         if self._h:
             self.ctx.lib.mvs_sketch_set_destroy(self._h)
@@ -212,6 +227,8 @@ class SketchSet:
 
 
 COMM_ID_BYTES = 128
+PLAN_MIRROR_OUTSIDE = 1
+CELLS_HEADER_BYTES = 64
 
 
 class Comm:
@@ -682,6 +699,74 @@ class Context:
         _check(rc)
         return count.value
 
+    # ---- block plans (include/mvs_hip.h "block plans"): a rank's share of the symmetric multi-rank schedule ----
+    def attach_derived(self, sset, coarse_fm, row_stats):
+        """the filter's inputs of `sset` live in these device buffers from now on (n_alloc * d_pad bytes, n_alloc * 16 bytes)"""
+        cp, cm, ck = _buf(coarse_fm)
+        rp, rm, rk = _buf(row_stats)
+        if cm != MEM_DEVICE or rm != MEM_DEVICE:
+            raise ValueError("device buffers required")
+        _check(self.lib.mvs_sketch_set_attach_derived(sset._h, cp, rp))
+        sset._derived = (coarse_fm, row_stats)
+
+    def prepare_rows(self, sset, row_first, row_count):
+        _check(self.lib.mvs_sketch_set_prepare_rows(self._h, sset._h, int(row_first), int(row_count)))
+
+    def plan_begin(self, sset, norms_sq, frame_begin, frame_end, mirror_outside, cells, keep_mode=KEEP_INT32):
+        np_, nm, nk = _buf(norms_sq)
+        cp, cm, ck = _buf(cells)
+        if nm != MEM_DEVICE or cm != MEM_DEVICE:
+            raise ValueError("norms_sq and cells must be device buffers")
+        _check(self.lib.mvs_plan_begin(self._h, sset._h, np_, keep_mode, int(frame_begin), int(frame_end),
+                                       PLAN_MIRROR_OUTSIDE if mirror_outside else 0, cp, cells.shape[0]))
+
+    def plan_filter(self, blocks):
+        """blocks: [(row_begin, row_end, col_begin, col_end)] -> ONE filter launch (asynchronous)"""
+        arr = (_c.c_int64 * (4 * len(blocks)))(*[int(x) for b in blocks for x in b[:4]])
+        _check(self.lib.mvs_plan_filter(self._h, arr, len(blocks)))
+
+    def plan_finish(self):
+        """re-check + flagged tiles; -> device address of the running cell count"""
+        p = _P()
+        _check(self.lib.mvs_plan_finish(self._h, ctypes.byref(p)))
+        return p.value
+
+    def plan_stats(self):
+        ms = (_c.c_double * 4)()
+        cnt = (_c.c_int64 * 6)()
+        _check(self.lib.mvs_plan_stats(self._h, ms, cnt))
+        return {"filter_ms": ms[0], "recheck_ms": ms[1], "tiles_ms": ms[2], "span_ms": ms[3], "candidates": cnt[0],
+                "flagged_tiles": cnt[1], "filter_tiles": cnt[2], "filter_launches": cnt[3], "exact_mode": bool(cnt[4]),
+                "d_pad": cnt[5]}
+
+    def cells_route(self, raw, d_n_raw, block_pad, block_rows, n_total, own_begin, own_end, own_out, d_own_count, send,
+                    foreign_capacity, status=0, max_abs=0):
+        """d_n_raw: device ADDRESS (int) of the cell count (plan_finish); d_own_count: device tensor of one int64 / uint64"""
+        rp, rm, rk = _buf(raw)
+        op, om, ok = _buf(own_out)
+        cp, cm, ck = _buf(d_own_count)
+        sp, sm, sk = _buf(send)
+        if rm != MEM_DEVICE or om != MEM_DEVICE or cm != MEM_DEVICE or (send is not None and sm != MEM_DEVICE):
+            raise ValueError("device buffers required")
+        _check(self.lib.mvs_cells_route(self._h, rp, _P(int(d_n_raw)), raw.shape[0], int(block_pad), int(block_rows), int(n_total),
+                                        int(own_begin), int(own_end), op, own_out.shape[0], cp, sp, int(foreign_capacity),
+                                        int(status), int(max_abs)))
+
+    def cells_collect(self, recv, world, rank, foreign_capacity, own_begin, own_end, own_out, d_own_count):
+        rp, rm, rk = _buf(recv)
+        op, om, ok = _buf(own_out)
+        cp, cm, ck = _buf(d_own_count)
+        _check(self.lib.mvs_cells_collect(self._h, rp, int(world), int(rank), int(foreign_capacity), int(own_begin), int(own_end),
+                                          op, own_out.shape[0], cp))
+
+    def cells_report(self, recv, world, foreign_capacity, d_own_count):
+        """-> (cells of this shard, [(foreign cells, status, max_abs, raw cells, raw capacity)] per rank); synchronises"""
+        rp, rm, rk = _buf(recv)
+        cp, cm, ck = _buf(d_own_count)
+        out = (_c.c_int64 * (1 + 5 * world))()
+        _check(self.lib.mvs_cells_report(self._h, rp, int(world), int(foreign_capacity), cp, out))
+        return out[0], [tuple(out[1 + 5 * r:6 + 5 * r]) for r in range(world)]
+
     def cells_sort(self, cells_in, n, cells_out):
         ip, im, ik = _buf(cells_in)
         op, om, ok = _buf(cells_out)
@@ -699,6 +784,13 @@ class Context:
 
 def chunk_size(max_memory_gb, d):
     return load_library().mvs_chunk_size(float(max_memory_gb), int(d))
+
+
+def shard_layout(n_total, world):
+    """(rows per shard = ceil(n / world), the same rounded up to a multiple of 256: the block size in storage coordinates)"""
+    a, b = _c.c_int64(), _c.c_int64()
+    _check(load_library().mvs_shard_layout(int(n_total), int(world), ctypes.byref(a), ctypes.byref(b)))
+    return a.value, b.value
 
 
 def shard_rows(n, num_shards, shard_idx):

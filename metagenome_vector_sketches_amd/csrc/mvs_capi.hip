@@ -18,6 +18,8 @@
 #include <thread>
 #include <vector>
 
+#include <array>
+
 #include "mvs_encode.h"
 #include "mvs_internal.h"
 
@@ -117,6 +119,9 @@ struct mvs_ctx {
     size_t pinned_bytes = 0;
     hipEvent_t pinned_ev = nullptr;
     bool pinned_busy = false;
+    // block plans (mvs_plan_*): state between begin / filter / finish, scratch of mvs_sketch_set_prepare_rows, events
+    struct PlanState* plan = nullptr;
+    void* plan_tmp = nullptr;   size_t plan_tmp_bytes = 0;
 };
 
 struct mvs_sketch_set {
@@ -126,7 +131,12 @@ struct mvs_sketch_set {
     int64_t n = 0, n_alloc = 0;
     int d = 0, d_pad = 0, limbs = 0;
     unsigned long long id = 0, gen = 0;   // identity of the plane contents (cache key of derived data)
+    // mvs_sketch_set_attach_derived: the filter's inputs in caller buffers (block plans), NULL otherwise
+    int8_t* ext_coarse_fm = nullptr;
+    mvs::CoarseRow* ext_rows = nullptr;
 };
+
+static void plan_state_free(mvs_ctx* c);   // defined with PlanState (block plans, near the end of this file)
 
 namespace mvs {
 int capi_fail(int code, const char* fmt, ...);
@@ -511,6 +521,8 @@ int mvs_ctx_destroy(mvs_ctx* c) {
     if (c->pinned_ev) (void)hipEventDestroy(c->pinned_ev);
     for (auto& ev : c->ev)
         if (ev) (void)hipEventDestroy(ev);
+    plan_state_free(c);
+    if (c->plan_tmp) (void)hipFree(c->plan_tmp);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return MVS_OK;
@@ -1288,8 +1300,11 @@ void fill_args(mvs_ctx* c, const mvs_sketch_set* s, const double* d_n2, int keep
     a.symmetric = (symmetric && c->opt.pairwise_symmetric) ? 1 : 0;   // the launcher checks the alignment
 }
 
-// the running cell count starts at `start` (appending calls)
+// the running cell count starts at `start` (appending calls); kKeepCount: it stays what the device counter holds (a block
+// plan appends block after block without the host ever learning the count in between)
+constexpr unsigned long long kKeepCount = ~0ULL;
 int set_cell_count(mvs_ctx* c, unsigned long long start) {
+    if (start == kKeepCount) return MVS_OK;
     c->h_start = start;   // outlives the asynchronous copy
     if (start == 0) HIP_TRY(hipMemsetAsync(c->d_counter, 0, 8, c->stream));
     else HIP_TRY(hipMemcpyAsync(c->d_counter, &c->h_start, 8, hipMemcpyHostToDevice, c->stream));
@@ -2853,6 +2868,488 @@ int mvs_pairwise_block(mvs_ctx* c, const mvs_sketch_set* s, const double* norms_
     *n_cells = (int64_t)count;
     if ((int64_t)count > capacity)
         return fail(MVS_E_CAPACITY, "%llu cells appended but capacity is %lld", count, (long long)capacity);
+    return MVS_OK;
+}
+
+// -------------------------------------------------------------------------------------------------
+// block plans (include/mvs_hip.h "block plans"): a rank's share of the symmetric multi-rank schedule
+// -------------------------------------------------------------------------------------------------
+struct PlanState {
+    bool active = false;
+    bool two_stage = false;               // false: the exact kernel block by block (other limb codes, filter off, no derived data)
+    const mvs_sketch_set* set = nullptr;
+    const double* d_n2 = nullptr;
+    int keep_mode = MVS_KEEP_INT32;
+    int flags = 0;
+    int64_t f0 = 0, f1 = 0;               // the frame's rows
+    mvs::PairwiseArgs a{};                // frame, outputs, filter buffers
+    int n_tr = 0, n_tc = 0;               // the frame's grid of 256 x 256 tiles
+    unsigned long long regions_cap = 0, regions_next = 0;
+    std::vector<std::array<int64_t, 4>> blocks;   // every rectangle handed in, in order
+    std::vector<int> groups;              // blocks per filter launch
+    mvs_cell* cells = nullptr;
+    int64_t capacity = 0;
+    // what it did (mvs_plan_stats)
+    long long tiles = 0, launches = 0, candidates = 0, flagged = 0;
+    std::vector<hipEvent_t> ev;           // start / stop per filter launch, created once and reused
+    size_t ev_used = 0;
+    hipEvent_t e_chk0 = nullptr, e_chk1 = nullptr, e_tiles1 = nullptr;
+    bool timed = false, finished = false;
+};
+
+static void plan_state_free(mvs_ctx* c) {
+    PlanState* st = c->plan;
+    if (!st) return;
+    for (hipEvent_t e : st->ev)
+        if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : {st->e_chk0, st->e_chk1, st->e_tiles1})
+        if (e) (void)hipEventDestroy(e);
+    delete st;
+    c->plan = nullptr;
+}
+
+namespace {
+
+// tiles of a rectangle the symmetric schedule computes: everything except the tiles strictly below the diagonal of the square
+long long plan_block_tiles(const PlanState& st, const std::array<int64_t, 4>& b) {
+    const int64_t n_tr = (b[1] - b[0] + 255) / 256, n_tc = (b[3] - b[2] + 255) / 256;
+    long long t = 0;
+    for (int64_t r = 0; r < n_tr; ++r) {
+        const int64_t i0 = b[0] + r * 256;
+        for (int64_t k = 0; k < n_tc; ++k) {
+            const int64_t j0 = b[2] + k * 256;
+            if (j0 >= st.f0 && j0 + 256 <= i0) continue;
+            ++t;
+        }
+    }
+    return t;
+}
+
+int plan_reset_counters(mvs_ctx* c, PlanState& st, bool cells_too) {
+    if (cells_too) HIP_TRY(hipMemsetAsync(c->d_counter, 0, 8, c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_counter + 1, 0, 16, c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_counter + 5, 0, 224, c->stream));
+    HIP_TRY(hipMemsetAsync(st.a.recheck_queue, 0, 512, c->stream));
+    if (st.regions_cap) HIP_TRY(hipMemsetAsync(c->pw_chdr, 0, (size_t)st.regions_cap * 4, c->stream));
+    HIP_TRY(hipMemsetAsync(st.a.tile_flag, 0, (size_t)st.n_tr * (size_t)st.n_tc * 4, c->stream));
+    st.regions_next = 0;
+    return MVS_OK;
+}
+
+// filter constants of rows [r0, r1) (their statistics and norms must be in place on the stream)
+int plan_meta(mvs_ctx* c, PlanState& st, int64_t r0, int64_t r1) {
+    if (r1 <= r0) return MVS_OK;
+    const mvs_sketch_set* s = st.set;
+    mvs::launch_filter_meta(c->stream, s->ext_rows + r0, st.d_n2 + r0, r1 - r0, r1 - r0, s->d, st.a.keep_coeff,
+                            (float4*)c->pw_fmeta + r0);
+    return check_kernel("k_filter_meta");
+}
+
+// blocks [first, first + count) of the plan as ONE filter launch
+int plan_launch(mvs_ctx* c, PlanState& st, size_t first, int count) {
+    int64_t rect[mvs::kPlanSegs][4];
+    for (int k = 0; k < count; ++k)
+        for (int x = 0; x < 4; ++x) rect[k][x] = st.blocks[first + (size_t)k][(size_t)x];
+    mvs::PlanSegs segs;
+    const long long wg = mvs::plan_segments(rect, count, &segs);
+    if (wg < 0) return fail(MVS_E_INVALID, "plan launch too large");
+    if (wg == 0) return MVS_OK;
+    mvs::PairwiseArgs a = st.a;
+    const unsigned long long regions = (unsigned long long)wg * 8ull;
+    if (st.regions_cap && st.regions_next + regions <= st.regions_cap) {
+        a.cand_region_base = st.regions_next;
+        st.regions_next += regions;
+    } else {
+        a.cand_hdr = nullptr;            // this launch's waves append with the atomic
+        a.cand_ent = nullptr;
+    }
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (c->timing) {
+        while (st.ev.size() < st.ev_used + 2) {
+            hipEvent_t e = nullptr;
+            HIP_TRY(hipEventCreate(&e));
+            st.ev.push_back(e);
+        }
+        e0 = st.ev[st.ev_used];
+        e1 = st.ev[st.ev_used + 1];
+        st.ev_used += 2;
+        HIP_TRY(hipEventRecord(e0, c->stream));
+    }
+    const int rc = mvs::launch_filter_plan(c->stream, a, segs, wg);
+    if (rc) return fail(rc, "plan filter launch rejected");
+    const int rk = check_kernel("k_pairwise_pp(plan filter)");
+    if (rk) return rk;
+    if (e1) HIP_TRY(hipEventRecord(e1, c->stream));
+    ++st.launches;
+    return MVS_OK;
+}
+
+}  // namespace
+
+int mvs_shard_layout(int64_t n_total, int world, int64_t* block_rows, int64_t* block_rows_padded) {
+    if (n_total < 0 || world < 1) return fail(MVS_E_INVALID, "bad argument");
+    const int64_t rps = (n_total + world - 1) / world;                 // src/pairwise_comp_optimized.cpp:938
+    if (block_rows) *block_rows = rps;
+    if (block_rows_padded) *block_rows_padded = std::max<int64_t>(256, (rps + 255) / 256 * 256);
+    return MVS_OK;
+}
+
+int mvs_sketch_set_attach_derived(mvs_sketch_set* s, int8_t* coarse_fm, void* row_stats) {
+    if (!s) return fail(MVS_E_INVALID, "set is NULL");
+    if ((coarse_fm == nullptr) != (row_stats == nullptr)) return fail(MVS_E_INVALID, "both buffers or neither");
+    s->ext_coarse_fm = coarse_fm;
+    s->ext_rows = static_cast<mvs::CoarseRow*>(row_stats);
+    return MVS_OK;
+}
+
+int mvs_sketch_set_prepare_rows(mvs_ctx* c, mvs_sketch_set* s, int64_t row_first, int64_t row_count) {
+    if (!c || !s) return fail(MVS_E_INVALID, "NULL argument");
+    if (row_first < 0 || row_count < 0 || row_first + row_count > s->n_alloc || (row_first & 15) || (row_count & 15))
+        return fail(MVS_E_INVALID, "rows [%lld, +%lld): multiples of 16 inside the %lld allocated rows", (long long)row_first,
+                    (long long)row_count, (long long)s->n_alloc);
+    if (row_count == 0 || s->limbs != 2 || s->d_pad > 32768 || !s->ext_coarse_fm) return MVS_OK;   // nothing the filter could use
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = ensure_buf(c, &c->plan_tmp, &c->plan_tmp_bytes, (size_t)row_count * (size_t)s->d_pad);
+    if (rc) return rc;
+    mvs::launch_coarse_build(c->stream, s->planes + row_first * 2 * (int64_t)s->d_pad, row_count, row_count, s->d_pad,
+                             (int8_t*)c->plan_tmp, s->ext_rows + row_first, c->opt.coarse_radix);
+    rc = check_kernel("k_coarse_build(rows)");
+    if (rc) return rc;
+    mvs::launch_coarse_fm(c->stream, (const int8_t*)c->plan_tmp, row_count, s->d_pad, s->ext_coarse_fm + row_first * (int64_t)s->d_pad);
+    return check_kernel("k_coarse_fm(rows)");
+}
+
+int mvs_plan_begin(mvs_ctx* c, const mvs_sketch_set* s, const double* norms_sq, int keep_mode, int64_t f0, int64_t f1, int flags,
+                   mvs_cell* cells, int64_t capacity) {
+    if (!c || !s) return fail(MVS_E_INVALID, "NULL argument");
+    if (capacity < 0 || (keep_mode != MVS_KEEP_INT32 && keep_mode != MVS_KEEP_INT16) || (flags & ~MVS_PLAN_MIRROR_OUTSIDE) != 0 ||
+        f0 < 0 || f1 < f0 || f1 > s->n)
+        return fail(MVS_E_INVALID, "bad argument");
+    if (!norms_sq || (capacity > 0 && !cells)) return fail(MVS_E_INVALID, "NULL buffer");
+    HIP_TRY(hipSetDevice(c->device));
+    if (!c->plan) {
+        c->plan = new (std::nothrow) PlanState();
+        if (!c->plan) return fail(MVS_E_NOMEM, "out of host memory");
+    }
+    PlanState& st = *c->plan;
+    st.active = false;
+    st.finished = false;
+    st.set = s;
+    st.d_n2 = norms_sq;
+    st.keep_mode = keep_mode;
+    st.flags = flags;
+    st.f0 = f0;
+    st.f1 = f1;
+    st.cells = cells;
+    st.capacity = capacity;
+    st.blocks.clear();
+    st.groups.clear();
+    st.tiles = st.launches = st.candidates = st.flagged = 0;
+    st.ev_used = 0;
+    st.timed = c->timing;
+    st.two_stage = s->limbs == 2 && s->d_pad <= 32768 && c->opt.pairwise_filter != 0 && c->opt.pairwise_variant == 8 &&
+                   s->ext_coarse_fm != nullptr && (f0 & 255) == 0 && ((f1 & 255) == 0 || f1 == s->n) && f1 > f0;
+    mvs::PairwiseArgs& a = st.a;
+    a = mvs::PairwiseArgs{};
+    fill_args(c, s, norms_sq, keep_mode, f0, f1, 0, s->n, true, (flags & MVS_PLAN_MIRROR_OUTSIDE) != 0, 0.05, a);
+    a.symmetric = 1;                      // the plan's mirror rule needs the square (option pairwise_symmetric does not apply)
+    a.plan = 1;
+    a.cells = cells;
+    a.capacity = (unsigned long long)capacity;
+    c->last_candidates = 0;
+    c->last_flagged_tiles = 0;
+    c->last_filter_tiles = 0;
+    if (!st.two_stage) {
+        HIP_TRY(hipMemsetAsync(c->d_counter, 0, 8, c->stream));
+        st.active = true;
+        return MVS_OK;
+    }
+    mvs::filter_tile_grid(a, &st.n_tr, &st.n_tc);
+    int rc = ensure_buf(c, &c->pw_fmeta, &c->pw_fmeta_bytes, (size_t)s->n_alloc * sizeof(float4));
+    if (rc) return rc;
+    const double frame_cells = (double)(f1 - f0) * (double)s->n;
+    const int64_t cand_want = std::max<int64_t>(1 << 20, (int64_t)(frame_cells / 4096.0));
+    rc = ensure_buf(c, &c->pw_cand, &c->pw_cand_bytes, (size_t)cand_want * sizeof(int2));
+    if (rc) return rc;
+    // candidate regions: 8 per workgroup of every launch; a launch pads each rectangle to whole super-patches, so the sum
+    // over a plan is a little more than the frame's own padded grid -- a launch that no longer fits appends with atomics
+    const unsigned long long n_spr = (unsigned long long)(st.n_tr + 15) / 16, n_spc = (unsigned long long)(st.n_tc + 15) / 16;
+    st.regions_cap = c->opt.cand_regions ? n_spr * (n_spc + 8) * 2048ull : 0;
+    if (st.regions_cap > (8ull << 20)) st.regions_cap = 0;
+    if (st.regions_cap) {
+        rc = ensure_buf(c, &c->pw_chdr, &c->pw_chdr_bytes, (size_t)st.regions_cap * 4);
+        if (rc) return rc;
+        rc = ensure_buf(c, &c->pw_cent, &c->pw_cent_bytes, (size_t)st.regions_cap * mvs::kCandRegion * sizeof(int2));
+        if (rc) return rc;
+    }
+    rc = ensure_buf(c, &c->pw_tflag, &c->pw_tflag_bytes, (size_t)st.n_tr * (size_t)st.n_tc * 4);
+    if (rc) return rc;
+    rc = ensure_buf(c, &c->pw_trow, &c->pw_trow_bytes, (size_t)st.n_tr * 4);
+    if (rc) return rc;
+    a.coarse = nullptr;                   // plans read the fragment-major plane only
+    a.coarse_fm = s->ext_coarse_fm;
+    a.planes_fm = nullptr;                // flagged tiles: the exact kernel copies from the row-major limb planes
+    a.fmeta = (const float4*)c->pw_fmeta;
+    a.cand = (int2*)c->pw_cand;
+    a.cand_capacity = c->pw_cand_bytes / sizeof(int2);
+    a.cand_counter = c->d_counter + 2;
+    a.cand_limit = ~0ULL;
+    a.cand_stop = reinterpret_cast<unsigned int*>(c->d_counter + 32);
+    a.recheck_queue = c->d_counter + 128;
+    a.recheck_mode = c->opt.recheck_mode;
+    a.cand_hdr = st.regions_cap ? (unsigned int*)c->pw_chdr : nullptr;
+    a.cand_ent = st.regions_cap ? (int2*)c->pw_cent : nullptr;
+    a.tile_flag = (unsigned int*)c->pw_tflag;
+    a.tile_flag_ld = st.n_tc;
+    a.tile_dense_thr = c->opt.tile_dense_thr > 0 ? (unsigned)c->opt.tile_dense_thr : 0xffffffffu;
+    a.tile_flag_count = reinterpret_cast<unsigned int*>(c->d_counter + 8);
+    a.tile_flag_limit = 0xffffffffu;      // a plan never gives up on its filter: dense tiles go to the exact kernel one by one
+    rc = plan_reset_counters(c, st, true);
+    if (rc) return rc;
+    rc = plan_meta(c, st, f0, std::min<int64_t>(f1, s->n));
+    if (rc) return rc;
+    st.active = true;
+    return MVS_OK;
+}
+
+int mvs_plan_filter(mvs_ctx* c, const mvs_plan_block* blocks, int n_blocks) {
+    if (!c || !c->plan || !c->plan->active || c->plan->finished) return fail(MVS_E_INVALID, "no plan in progress (mvs_plan_begin)");
+    if (n_blocks < 0 || (n_blocks > 0 && !blocks)) return fail(MVS_E_INVALID, "bad argument");
+    PlanState& st = *c->plan;
+    const mvs_sketch_set* s = st.set;
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t first = st.blocks.size();
+    for (int k = 0; k < n_blocks; ++k) {
+        const mvs_plan_block& b = blocks[k];
+        const bool rows_ok = b.row_begin >= st.f0 && b.row_end <= st.f1 && b.row_begin <= b.row_end;
+        const bool cols_ok = b.col_begin >= 0 && b.col_end <= s->n && b.col_begin <= b.col_end;
+        const bool inside = b.col_begin >= st.f0 && b.col_end <= st.f1, outside = b.col_end <= st.f0 || b.col_begin >= st.f1;
+        if (!rows_ok || !cols_ok || !(inside || outside || b.col_begin == b.col_end))
+            return fail(MVS_E_INVALID, "plan block [%lld,%lld) x [%lld,%lld): rows inside the frame [%lld,%lld), columns inside or outside its square",
+                        (long long)b.row_begin, (long long)b.row_end, (long long)b.col_begin, (long long)b.col_end, (long long)st.f0, (long long)st.f1);
+        if (st.two_stage && (((b.row_begin | b.col_begin) & 255) != 0 || ((b.row_end & 255) != 0 && b.row_end != st.f1) ||
+                             ((b.col_end & 255) != 0 && b.col_end != s->n)))
+            return fail(MVS_E_INVALID, "plan block bounds must sit on multiples of 256 rows / columns");
+        if (b.row_begin == b.row_end || b.col_begin == b.col_end) continue;
+        st.blocks.push_back({b.row_begin, b.row_end, b.col_begin, b.col_end});
+    }
+    const size_t added = st.blocks.size() - first;
+    if (added == 0) return MVS_OK;
+    if (!st.two_stage) {
+        for (size_t k = first; k < st.blocks.size(); ++k) {
+            const auto& b = st.blocks[k];
+            const bool inside = b[2] >= st.f0 && b[3] <= st.f1;
+            unsigned long long count = 0;
+            const int rc = pairwise_launch(c, s, st.d_n2, st.keep_mode, b[0], b[1], b[2], b[3], inside,
+                                           !inside && (st.flags & MVS_PLAN_MIRROR_OUTSIDE) != 0, st.cells, st.capacity, kKeepCount, &count);
+            if (rc) return rc;
+            ++st.launches;
+        }
+        return MVS_OK;
+    }
+    for (size_t k = first; k < st.blocks.size(); ++k) {
+        const auto& b = st.blocks[k];
+        if (!(b[2] >= st.f0 && b[3] <= st.f1)) {          // columns outside the frame's rows: their constants are not there yet
+            const int rc = plan_meta(c, st, b[2], b[3]);
+            if (rc) return rc;
+        }
+        st.tiles += plan_block_tiles(st, b);
+    }
+    for (size_t k = first; k < st.blocks.size(); k += mvs::kPlanSegs) {
+        const int count = (int)std::min<size_t>(mvs::kPlanSegs, st.blocks.size() - k);
+        const int rc = plan_launch(c, st, k, count);
+        if (rc) return rc;
+        st.groups.push_back(count);
+    }
+    return MVS_OK;
+}
+
+int mvs_plan_finish(mvs_ctx* c, const uint64_t** d_count) {
+    if (!c || !c->plan || !c->plan->active || c->plan->finished) return fail(MVS_E_INVALID, "no plan in progress (mvs_plan_begin)");
+    PlanState& st = *c->plan;
+    const mvs_sketch_set* s = st.set;
+    HIP_TRY(hipSetDevice(c->device));
+    if (d_count) *d_count = reinterpret_cast<const uint64_t*>(c->d_counter);
+    st.finished = true;
+    st.active = false;
+    if (!st.two_stage || st.blocks.empty()) return MVS_OK;
+    auto lazy_event = [&](hipEvent_t& e) -> int {
+        if (!e) HIP_TRY(hipEventCreate(&e));
+        return MVS_OK;
+    };
+    if (st.timed) {
+        int rc = lazy_event(st.e_chk0);
+        if (rc) return rc;
+        rc = lazy_event(st.e_chk1);
+        if (rc) return rc;
+        rc = lazy_event(st.e_tiles1);
+        if (rc) return rc;
+        HIP_TRY(hipEventRecord(st.e_chk0, c->stream));
+    }
+    std::vector<int> row_count((size_t)st.n_tr);
+    unsigned long long back[33];
+    for (int attempt = 0;; ++attempt) {
+        if (st.regions_next > 0) {
+            mvs::launch_cand_gather(c->stream, st.a, (int64_t)st.regions_next);
+            const int rc = check_kernel("k_cand_gather");
+            if (rc) return rc;
+        }
+        mvs::launch_tile_count(c->stream, st.a.tile_flag, st.n_tr, st.n_tc, (int*)c->pw_trow);
+        int rc = check_kernel("k_tile_count");
+        if (rc) return rc;
+        // the plan's ONE host synchronisation: the later launches are sized from these counts
+        rc = read_back(c, c->stream, {{back, c->d_counter, sizeof(back)}, {row_count.data(), c->pw_trow, (size_t)st.n_tr * 4}});
+        if (rc) return rc;
+        st.candidates = (long long)back[2];
+        if (back[2] <= st.a.cand_capacity) break;
+        if (attempt >= 2) return fail(MVS_E_HIP, "internal: the candidate list keeps outgrowing its buffer");
+        // the list did not hold the candidates: grow it and run the plan's filter launches again (their inputs are resident)
+        rc = ensure_buf(c, &c->pw_cand, &c->pw_cand_bytes, (size_t)(back[2] + back[2] / 4) * sizeof(int2));
+        if (rc) return rc;
+        st.a.cand = (int2*)c->pw_cand;
+        st.a.cand_capacity = c->pw_cand_bytes / sizeof(int2);
+        rc = plan_reset_counters(c, st, true);
+        if (rc) return rc;
+        st.launches = 0;
+        st.ev_used = 0;
+        size_t k = 0;
+        for (int count : st.groups) {
+            rc = plan_launch(c, st, k, count);
+            if (rc) return rc;
+            k += (size_t)count;
+        }
+    }
+    c->last_candidates = (unsigned long long)st.candidates;
+    c->last_filter_tiles = st.tiles;
+    int n_flagged = 0;
+    std::vector<int> row_first((size_t)st.n_tr + 1, 0);
+    for (int t = 0; t < st.n_tr; ++t) row_first[(size_t)t + 1] = row_first[(size_t)t] + row_count[(size_t)t];
+    n_flagged = row_first[(size_t)st.n_tr];
+    st.flagged = n_flagged;
+    c->last_flagged_tiles = n_flagged;
+    mvs::PairwiseArgs a = st.a;
+    const int* d_list = nullptr;
+    if (n_flagged > 0) {
+        int rc = ensure_buf(c, &c->pw_tlist, &c->pw_tlist_bytes, ((size_t)n_flagged + 1) * 4);
+        if (rc) return rc;
+        mvs::launch_tile_list(c->stream, a.tile_flag, st.n_tr, st.n_tc, (const int*)c->pw_trow, (int*)c->pw_tlist);
+        rc = check_kernel("k_tile_list");
+        if (rc) return rc;
+        d_list = (const int*)c->pw_tlist + 1;
+        if (st.candidates > 0) {
+            rc = ensure_buf(c, &c->pw_cand2, &c->pw_cand2_bytes, (size_t)st.candidates * sizeof(int2));
+            if (rc) return rc;
+            mvs::launch_cand_prune(c->stream, a, (unsigned long long)st.candidates, (int2*)c->pw_cand2, c->d_counter + 6);
+            rc = check_kernel("k_cand_prune");
+            if (rc) return rc;
+            a.cand = (int2*)c->pw_cand2;
+            a.cand_capacity = c->pw_cand2_bytes / sizeof(int2);
+            a.cand_counter = c->d_counter + 6;
+        }
+        rc = ensure_buf(c, &c->pw_thr, &c->pw_thr_bytes, (size_t)s->n_alloc * 4);
+        if (rc) return rc;
+        mvs::launch_cand_thr(c->stream, st.d_n2, s->n, s->n_alloc, s->d, a.keep_coeff, (int32_t*)c->pw_thr);
+        rc = check_kernel("k_cand_thr");
+        if (rc) return rc;
+        a.cand_thr = (const int32_t*)c->pw_thr;
+    }
+    if (st.candidates > 0) {
+        int rc = mvs::launch_exact_pairs(c->stream, a, c->opt);
+        if (rc) return fail(rc, "exact re-check launch rejected");
+        rc = check_kernel("k_exact_pairs");
+        if (rc) return rc;
+    }
+    if (st.timed) HIP_TRY(hipEventRecord(st.e_chk1, c->stream));
+    if (n_flagged > 0) {
+        int rc = mvs::launch_exact_tiles(c->stream, a, d_list, n_flagged, c->opt);
+        if (rc) return fail(rc, "exact tile launch rejected");
+        rc = check_kernel("k_pairwise_pp(tiles)");
+        if (rc) return rc;
+    }
+    if (st.timed) HIP_TRY(hipEventRecord(st.e_tiles1, c->stream));
+    return MVS_OK;
+}
+
+int mvs_plan_stats(mvs_ctx* c, double ms[4], int64_t counts[6]) {
+    if (!c || !c->plan) return fail(MVS_E_INVALID, "no plan has run on this context");
+    PlanState& st = *c->plan;
+    if (ms) {
+        ms[0] = ms[1] = ms[2] = ms[3] = 0.0;
+        if (st.timed && st.two_stage && st.finished && st.ev_used >= 2 && st.e_tiles1) {
+            HIP_TRY(hipEventSynchronize(st.e_tiles1));
+            for (size_t k = 0; k + 1 < st.ev_used; k += 2) {
+                float t = 0.0f;
+                HIP_TRY(hipEventElapsedTime(&t, st.ev[k], st.ev[k + 1]));
+                ms[0] += t;
+            }
+            float t = 0.0f;
+            HIP_TRY(hipEventElapsedTime(&t, st.e_chk0, st.e_chk1));
+            ms[1] = t;
+            HIP_TRY(hipEventElapsedTime(&t, st.e_chk1, st.e_tiles1));
+            ms[2] = t;
+            HIP_TRY(hipEventElapsedTime(&t, st.ev[0], st.e_tiles1));
+            ms[3] = t;
+        }
+    }
+    if (counts) {
+        counts[0] = st.candidates;
+        counts[1] = st.flagged;
+        counts[2] = st.tiles;
+        counts[3] = st.launches;
+        counts[4] = st.two_stage ? 0 : 1;
+        counts[5] = st.set ? st.set->d_pad : 0;
+    }
+    return MVS_OK;
+}
+
+int mvs_cells_route(mvs_ctx* c, const mvs_cell* raw, const uint64_t* d_n_raw, int64_t raw_capacity, int64_t block_rows_padded,
+                    int64_t block_rows, int64_t n_total, int64_t own_begin, int64_t own_end, mvs_cell* own_out, int64_t own_capacity,
+                    uint64_t* d_own_count, void* send, int64_t foreign_capacity, int64_t status, int64_t max_abs) {
+    if (!c || !d_n_raw || !d_own_count) return fail(MVS_E_INVALID, "NULL argument");
+    if (raw_capacity < 0 || block_rows_padded < 1 || block_rows < 0 || block_rows > block_rows_padded || n_total < 0 ||
+        own_begin < 0 || own_end < own_begin || own_end > n_total || own_capacity < 0 || foreign_capacity < 0 ||
+        n_total >= (1LL << 31) - 256 || (raw_capacity > 0 && !raw) || (own_capacity > 0 && !own_out))
+        return fail(MVS_E_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemsetAsync(d_own_count, 0, 8, c->stream));
+    if (send) HIP_TRY(hipMemsetAsync(send, 0, MVS_CELLS_HEADER_BYTES, c->stream));
+    mvs::launch_cells_route(c->stream, raw, reinterpret_cast<const unsigned long long*>(d_n_raw), (unsigned long long)raw_capacity,
+                            block_rows_padded, block_rows, n_total, (int)own_begin, (int)own_end, own_out,
+                            (unsigned long long)own_capacity, reinterpret_cast<unsigned long long*>(d_own_count),
+                            static_cast<unsigned long long*>(send), (unsigned long long)foreign_capacity, status, max_abs);
+    return check_kernel("k_cells_route");
+}
+
+int mvs_cells_collect(mvs_ctx* c, const void* recv, int world, int rank, int64_t foreign_capacity, int64_t own_begin, int64_t own_end,
+                      mvs_cell* own_out, int64_t own_capacity, uint64_t* d_own_count) {
+    if (!c || !d_own_count) return fail(MVS_E_INVALID, "NULL argument");
+    if (world < 1 || rank < 0 || rank >= world || foreign_capacity < 0 || own_capacity < 0 || own_begin < 0 || own_end < own_begin ||
+        (world > 1 && !recv) || (own_capacity > 0 && !own_out))
+        return fail(MVS_E_INVALID, "bad argument");
+    if (world == 1) return MVS_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    mvs::launch_cells_collect(c->stream, static_cast<const unsigned long long*>(recv), world, rank, (unsigned long long)foreign_capacity,
+                              (int)own_begin, (int)own_end, own_out, (unsigned long long)own_capacity,
+                              reinterpret_cast<unsigned long long*>(d_own_count));
+    return check_kernel("k_cells_collect");
+}
+
+int mvs_cells_report(mvs_ctx* c, const void* recv, int world, int64_t foreign_capacity, const uint64_t* d_own_count, int64_t* out) {
+    if (!c || !d_own_count || !out || world < 1 || foreign_capacity < 0 || (world > 1 && !recv))
+        return fail(MVS_E_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    std::vector<unsigned long long> hdr((size_t)world * 8, 0);
+    unsigned long long own = 0;
+    HIP_TRY(hipMemcpyAsync(&own, d_own_count, 8, hipMemcpyDeviceToHost, c->stream));
+    if (recv) {
+        const size_t stride = MVS_CELLS_HEADER_BYTES + (size_t)foreign_capacity * sizeof(mvs_cell);
+        HIP_TRY(hipMemcpy2DAsync(hdr.data(), MVS_CELLS_HEADER_BYTES, recv, stride, MVS_CELLS_HEADER_BYTES, (size_t)world,
+                                 hipMemcpyDeviceToHost, c->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    out[0] = (int64_t)own;
+    for (int r = 0; r < world; ++r)
+        for (int k = 0; k < 5; ++k) out[1 + r * 5 + k] = (int64_t)hdr[(size_t)r * 8 + (size_t)k];
     return MVS_OK;
 }
 

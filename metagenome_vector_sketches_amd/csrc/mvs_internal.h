@@ -162,6 +162,24 @@ struct PairwiseArgs {
     unsigned int tile_flag_limit;    //    is dense nearly everywhere: the exact kernel alone is faster)
     const int* tile_list;            // k_pairwise_pp<0>: flagged filter tiles (row-major ids), NULL = the whole grid
     int tile_list_n;
+    // Block plans (mvs_plan_*: a rank's share of the symmetric multi-rank schedule in ONE launch, PlanSegs below).
+    // [row_begin, row_end) x [col_begin, col_end) is then the FRAME the tile flags, the flagged-tile list and the candidate
+    // pruning index into; the tiles themselves come from the launch's segments.  plan = 1 also keeps `symmetric` together
+    // with `mirror_all`: inside the square [sym_begin, sym_end)^2 the symmetric schedule rules (tiles below the diagonal
+    // skipped, cells above it mirrored), every kept cell outside it is mirrored (its transposed block is nobody else's).
+    int plan;
+    unsigned long long cand_region_base;   // first candidate region of this launch (several filter launches share the arrays)
+};
+
+// The rectangles of one plan launch of k_pairwise_pp: a 1-D grid, segment s owning workgroups [wg_begin[s], wg_begin[s + 1])
+// = n_spr x n_spc super-patches of 256 workgroups (map_tile inside each, so the XCD-aware placement of the single-block
+// launch carries over: every segment starts on a multiple of 256 workgroups).  n = 0: the launch is one block on the 2-D grid.
+constexpr int kPlanSegs = 16;
+struct PlanSegs {
+    int n;
+    unsigned wg_begin[kPlanSegs + 1];
+    int n_tr[kPlanSegs], n_tc[kPlanSegs], n_spc[kPlanSegs];
+    long long i_begin[kPlanSegs], j_begin[kPlanSegs];
 };
 
 // Which 256 x 256 tiles of the dense byte matrix can hold a kept cell (tile-granular comparison feeding the matrix): the
@@ -213,6 +231,10 @@ bool exact_reads_fm(const PairwiseArgs& a, const Options& opt);
 int launch_filter_meta(hipStream_t stream, const CoarseRow* d_rows, const double* d_norms_sq, int64_t n,
                        int64_t n_alloc, int d, double coeff, float4* d_meta);
 int launch_filter(hipStream_t stream, const PairwiseArgs& a, const Options& opt);
+// block plans (mvs_plan_*): rectangles {row_begin, row_end, col_begin, col_end} -> the segments of one launch (returns its
+// 1-D grid in workgroups, 0: empty, -1: too many rectangles / too large for one launch), and that launch of the ping-pong filter
+long long plan_segments(const int64_t (*blocks)[4], int n, PlanSegs* segs);
+int launch_filter_plan(hipStream_t stream, const PairwiseArgs& a, const PlanSegs& segs, long long workgroups);
 int launch_exact_pairs(hipStream_t stream, const PairwiseArgs& a, const Options& opt);
 // candidate regions of the ping-pong filter: how many (workgroups x 8 waves) launch_filter's grid has for this block, 0 if
 // the variant it would pick appends with atomics only; k_cand_gather moves the regions' contents into the candidate list
@@ -259,6 +281,14 @@ int launch_packed_to_dense(hipStream_t stream, const unsigned long long* d_keys,
 // true when launch_pairwise would run the kernel whose epilogue can write the dense byte matrix (two base-256 limbs on the
 // ping-pong kernel)
 bool exact_kernel_writes_dense(const PairwiseArgs& a, const Options& opt);
+// kept cells of a block plan (storage coordinates) -> sample indices, own rows / other ranks' rows (mvs_cells_route);
+// the cells of own rows out of the other ranks' send buffers (mvs_cells_collect)
+int launch_cells_route(hipStream_t stream, const mvs_cell* d_raw, const unsigned long long* d_n_raw, unsigned long long raw_capacity,
+                       long long block_pad, long long block_rows, long long n_total, int own_begin, int own_end, mvs_cell* d_own,
+                       unsigned long long own_capacity, unsigned long long* d_own_count, unsigned long long* d_send,
+                       unsigned long long foreign_capacity, long long status, long long max_abs);
+int launch_cells_collect(hipStream_t stream, const unsigned long long* d_recv, int world, int rank, unsigned long long capacity,
+                         int own_begin, int own_end, mvs_cell* d_own, unsigned long long own_capacity, unsigned long long* d_own_count);
 // sort cells by (row, col); tmp buffers owned by the caller
 int sort_cells(hipStream_t stream, mvs_cell* d_cells, mvs_cell* d_tmp, int64_t n, void* d_scratch,
                size_t scratch_bytes, size_t* scratch_needed, const Options& opt);

@@ -712,7 +712,8 @@ __device__ __forceinline__ void epilogue_exact16(const PairwiseArgs& a, v4i (&ac
     for (int u = 0; u < 2; ++u) {
         const int col_l = wn * 32 + u * 16 + fr;
         const int64_t col = j0 + col_l;
-        const bool mirror = a.mirror_all || (mirror_tile && col < a.sym_end);
+        const bool in_sq = a.symmetric && col >= a.sym_begin && col < a.sym_end;
+        const bool mirror = in_sq ? mirror_tile : a.mirror_all != 0;
         unsigned m16 = 0;
 #pragma unroll
         for (int t = 0; t < 4; ++t)
@@ -737,7 +738,8 @@ __device__ __forceinline__ void epilogue_exact16(const PairwiseArgs& a, v4i (&ac
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         const int64_t col = j0 + wn * 32 + u * 16 + fr;
-        const bool mirror = a.mirror_all || (mirror_tile && col < a.sym_end);
+        const bool in_sq = a.symmetric && col >= a.sym_begin && col < a.sym_end;
+        const bool mirror = in_sq ? mirror_tile : a.mirror_all != 0;
         const unsigned m = masks[u * 64];   // this lane's own word
         if (__ballot(m != 0) == 0ULL) continue;
 #pragma unroll
@@ -1033,7 +1035,7 @@ __device__ __forceinline__ void epilogue_filter16(const PairwiseArgs& a, v4i (&a
     int2* list;
     unsigned long long list_cap;
     if (to_region) {
-        const unsigned long long reg = ((unsigned long long)blockIdx.y * gridDim.x + blockIdx.x) * 8ull + (unsigned)wave;
+        const unsigned long long reg = a.cand_region_base + ((unsigned long long)blockIdx.y * gridDim.x + blockIdx.x) * 8ull + (unsigned)wave;
         if (lane == 63) a.cand_hdr[reg] = total;
         slot = reg * kCandRegion + (incl - mine);
         list = a.cand_ent;
@@ -1060,7 +1062,9 @@ __device__ __forceinline__ void epilogue_filter16(const PairwiseArgs& a, v4i (&a
             const int b = __ffs((int)m) - 1;
             m &= m - 1;
             const int row_l = wm * 128 + (b >> 2) * 16 + fq * 4 + (b & 3);
-            const bool mirror = a.mirror_all || (in_square && cd > row_l);
+            // inside the symmetric square the diagonal decides; outside it (a block whose transpose no other launch computes)
+            // mirror_all does -- the two meet in one launch only for a block plan
+            const bool mirror = in_square ? cd > row_l : a.mirror_all != 0;
             if (slot < list_cap)
                 list[slot] = make_int2((int32_t)(i0 + row_l), mirror ? (int)((unsigned)col | 0x80000000u) : (int)col);
             ++slot;
@@ -1346,7 +1350,7 @@ __global__ __launch_bounds__(256) void k_cand_prune(const PairwiseArgs a, unsign
 // and all eight waves copy the A region (two pieces each).  LDS then carries 8 instead of 12 fragment reads per wave and
 // slice and half the copy bytes: 80 instead of 128 bytes per clock at full matrix rate, which is its peak.
 template <int MODE, int NST, int ORDER = 0, int ABL = 0, int PH = 1, int NT = 0, int BD = 0>
-__global__ __launch_bounds__(512, 2) void k_pairwise_pp(const PairwiseArgs a, int n_tr, int n_tc) {
+__global__ __launch_bounds__(512, 2) void k_pairwise_pp(const PairwiseArgs a, int n_tr, int n_tc, const PlanSegs segs) {
 #ifndef MVS_ABLATIONS
     static_assert(ABL == 0, "ablations need a -DMVS_ABLATIONS build");
 #endif
@@ -1374,6 +1378,7 @@ __global__ __launch_bounds__(512, 2) void k_pairwise_pp(const PairwiseArgs a, in
     }
 #endif
     TileCoord tc;
+    int64_t org_i = a.row_begin, org_j = a.col_begin;            // where tile (0, 0) of this workgroup's grid sits
     if (MODE == 0 && a.tile_list != nullptr) {
         // the flagged tiles of the tile-granular comparison: entry = a 256 x 256 filter tile = four tiles of this kernel,
         // consecutive indices; XCD label x (blockIdx.x % 8) takes the x-th contiguous eighth of the row-major list, so the
@@ -1385,6 +1390,16 @@ __global__ __launch_bounds__(512, 2) void k_pairwise_pp(const PairwiseArgs a, in
         tc.tr = (entry / a.tile_flag_ld) * 2 + (int)((idx >> 1) & 1u);
         tc.tc = (entry % a.tile_flag_ld) * 2 + (int)(idx & 1u);
         tc.valid = tc.tr < n_tr && tc.tc < n_tc;
+    } else if (segs.n > 0) {
+        // a block plan: the workgroup's segment (uniform: scalar compares on the kernel arguments), then the single-block
+        // map inside it -- a segment starts on a multiple of 256 workgroups, so blockIdx.x % 8 is the XCD label there too
+        int sg = 0;
+        for (int k = 1; k < segs.n; ++k) sg += blockIdx.x >= segs.wg_begin[k] ? 1 : 0;
+        const unsigned local = blockIdx.x - segs.wg_begin[sg];
+        const unsigned per_row = (unsigned)segs.n_spc[sg] * 256u;
+        tc = map_tile(local % per_row, local / per_row, segs.n_tr[sg], segs.n_tc[sg], a.map_mode);
+        org_i = segs.i_begin[sg];
+        org_j = segs.j_begin[sg];
     } else {
         tc = map_tile(blockIdx.x, blockIdx.y, n_tr, n_tc, a.map_mode);
     }
@@ -1392,7 +1407,7 @@ __global__ __launch_bounds__(512, 2) void k_pairwise_pp(const PairwiseArgs a, in
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;                     // wm is also the wave group: waves w and w+4 share a SIMD
-    const int64_t i0 = a.row_begin + (int64_t)tc.tr * TM, j0 = a.col_begin + (int64_t)tc.tc * TN;
+    const int64_t i0 = org_i + (int64_t)tc.tr * TM, j0 = org_j + (int64_t)tc.tc * TN;
     bool mirror_tile = false;
     if (MODE != 1 && a.symmetric) {
         if (j0 >= a.sym_begin && j0 + TN <= i0) return;
@@ -2604,6 +2619,93 @@ __global__ __launch_bounds__(256) void k_packed_scatter(const unsigned long long
     }
 }
 
+// ---- kept cells of a block plan -> the rank's shard (mvs_cells_route / mvs_cells_collect) ----
+// header of a send buffer: [0] foreign cells appended (may exceed the capacity), [1] status, [2] max |v|, [3] raw cells,
+// [4] raw capacity; 64 bytes, then the cells
+struct RouteArgs {
+    const mvs_cell* raw;
+    const unsigned long long* n_raw;
+    unsigned long long raw_capacity;
+    long long block_pad, block_rows, n_total;   // storage row s -> sample (s / block_pad) * block_rows + s % block_pad
+    int own_begin, own_end;
+    mvs_cell* own;
+    unsigned long long own_capacity;
+    unsigned long long* own_count;
+    unsigned long long* send;                    // header (8 words) + cells, or NULL
+    unsigned long long foreign_capacity;
+    long long status, max_abs;
+};
+
+__device__ __forceinline__ void append_cell(mvs_cell* out, unsigned long long cap, unsigned long long* counter, bool want,
+                                            const mvs_cell& c, int lane) {
+    const unsigned long long m = __ballot(want);
+    if (m == 0ULL) return;
+    unsigned long long base = 0;
+    const int leader = __ffsll((long long)m) - 1;
+    if (lane == leader) base = atomicAdd(counter, (unsigned long long)__popcll(m));
+    base = (unsigned long long)__shfl((long long)base, leader, 64);
+    if (want) {
+        const unsigned long long slot = base + (unsigned long long)__popcll(m & ((1ULL << lane) - 1ULL));
+        if (slot < cap) out[slot] = c;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_cells_route(const RouteArgs r) {
+    const int lane = threadIdx.x & 63;
+    const unsigned long long total = *r.n_raw;
+    const unsigned long long n = total < r.raw_capacity ? total : r.raw_capacity;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && r.send) {
+        r.send[1] = (unsigned long long)r.status;
+        r.send[2] = (unsigned long long)r.max_abs;
+        r.send[3] = total;
+        r.send[4] = r.raw_capacity;
+    }
+    mvs_cell* foreign = r.send ? reinterpret_cast<mvs_cell*>(r.send + 8) : nullptr;
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    // whole waves stay in the loop together (the appends are wave-wide)
+    for (unsigned long long base = (unsigned long long)blockIdx.x * blockDim.x + (threadIdx.x & ~63u); base < n; base += stride) {
+        const unsigned long long i = base + lane;
+        mvs_cell c{0, 0, 0, 0};
+        bool valid = false;
+        if (i < n) {
+            c = r.raw[i];
+            const long long br = c.row / r.block_pad, orow = c.row - br * r.block_pad;
+            const long long bc = c.col / r.block_pad, ocol = c.col - bc * r.block_pad;
+            const long long row = br * r.block_rows + orow, col = bc * r.block_rows + ocol;
+            valid = orow < r.block_rows && ocol < r.block_rows && row < r.n_total && col < r.n_total;
+            c.row = (int32_t)row;
+            c.col = (int32_t)col;
+        }
+        const bool mine = valid && c.row >= r.own_begin && c.row < r.own_end;
+        append_cell(r.own, r.own_capacity, r.own_count, mine, c, lane);
+        if (r.send) append_cell(foreign, r.foreign_capacity, r.send, valid && !mine, c, lane);
+    }
+}
+
+// recv: `world` send buffers of hdr + capacity cells each; blockIdx.y = peer
+__global__ __launch_bounds__(256) void k_cells_collect(const unsigned long long* __restrict__ recv, int rank, unsigned long long capacity,
+                                                       int own_begin, int own_end, mvs_cell* __restrict__ own, unsigned long long own_capacity,
+                                                       unsigned long long* __restrict__ own_count) {
+    const int peer = blockIdx.y;
+    if (peer == rank) return;
+    const int lane = threadIdx.x & 63;
+    const unsigned long long* buf = recv + (size_t)peer * (8 + capacity * 2);
+    const unsigned long long total = buf[0];
+    const unsigned long long n = total < capacity ? total : capacity;
+    const mvs_cell* cells = reinterpret_cast<const mvs_cell*>(buf + 8);
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    for (unsigned long long base = (unsigned long long)blockIdx.x * blockDim.x + (threadIdx.x & ~63u); base < n; base += stride) {
+        const unsigned long long i = base + lane;
+        mvs_cell c{0, 0, 0, 0};
+        bool mine = false;
+        if (i < n) {
+            c = cells[i];
+            mine = c.row >= own_begin && c.row < own_end;
+        }
+        append_cell(own, own_capacity, own_count, mine, c, lane);
+    }
+}
+
 struct CellLess {
     __host__ __device__ bool operator()(const mvs_cell& x, const mvs_cell& y) const {
         return x.row < y.row || (x.row == y.row && x.col < y.col);
@@ -2695,7 +2797,7 @@ int launch_pp(hipStream_t stream, const PairwiseArgs& a) {
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return MVS_E_HIP;
     hipLaunchKernelGGL((k_pairwise_pp<MODE, NST, ORDER, ABL, PH, NT, BD>), dim3((unsigned)n_spc * 256u, (unsigned)n_spr), dim3(512), lds, stream,
-                       b, n_tr, n_tc);
+                       b, n_tr, n_tc, PlanSegs{});
     return 0;
 }
 
@@ -2851,6 +2953,47 @@ int launch_filter(hipStream_t stream, const PairwiseArgs& a, const Options& opt)
     }
 }
 
+// ---- block plans: several rectangles of 256 x 256 filter tiles in ONE launch of the ping-pong filter ----
+// blocks[k] = {row_begin, row_end, col_begin, col_end}, origins on multiples of 256 rows / columns (the caller checks);
+// fills segs and returns the 1-D grid size in workgroups, 0 if the plan is empty, -1 if it does not fit one launch
+long long plan_segments(const int64_t (*blocks)[4], int n, PlanSegs* segs) {
+    *segs = PlanSegs{};
+    if (n > kPlanSegs) return -1;
+    unsigned long long wg = 0;
+    int m = 0;
+    for (int k = 0; k < n; ++k) {
+        const int64_t rows = blocks[k][1] - blocks[k][0], cols = blocks[k][3] - blocks[k][2];
+        if (rows <= 0 || cols <= 0) continue;
+        const int n_tr = (int)((rows + 255) / 256), n_tc = (int)((cols + 255) / 256);
+        const int n_spr = (n_tr + 15) / 16, n_spc = (n_tc + 15) / 16;
+        segs->wg_begin[m] = (unsigned)wg;
+        segs->n_tr[m] = n_tr;
+        segs->n_tc[m] = n_tc;
+        segs->n_spc[m] = n_spc;
+        segs->i_begin[m] = blocks[k][0];
+        segs->j_begin[m] = blocks[k][2];
+        wg += (unsigned long long)n_spr * (unsigned long long)n_spc * 256ull;
+        if (wg * 512ull > 0xffffffffull) return -1;             // a dispatch holds at most 2^32 work-items per dimension
+        ++m;
+    }
+    segs->n = m;
+    for (int k = m; k <= kPlanSegs; ++k) segs->wg_begin[k] = (unsigned)wg;
+    return (long long)wg;
+}
+
+// the ping-pong filter (4-stage ring, B operand direct) over the segments of a plan; `a` carries the frame (PairwiseArgs::plan)
+int launch_filter_plan(hipStream_t stream, const PairwiseArgs& a, const PlanSegs& segs, long long workgroups) {
+    if (a.limbs != 2 || a.d_pad > 32768 || !a.plan || a.coarse_fm == nullptr || ((a.row_begin | a.col_begin) & 255) != 0) return MVS_E_INVALID;
+    if (workgroups <= 0 || segs.n <= 0) return 0;
+    using G = PpGeom<2>;
+    const size_t lds = (size_t)4 * G::kStage;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pairwise_pp<2, 4, 0, 0, 1, 0, 1>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return MVS_E_HIP;
+    hipLaunchKernelGGL((k_pairwise_pp<2, 4, 0, 0, 1, 0, 1>), dim3((unsigned)workgroups), dim3(512), lds, stream, a, 0, 0, segs);
+    return 0;
+}
+
 // row blocks of 16 the streaming search filter keeps resident for this sketch length (0: the rows do not fit the LDS)
 static int search_filter_rb(const PairwiseArgs& a) {
     for (int rb : {4, 2, 1})
@@ -2987,7 +3130,7 @@ int launch_exact_tiles(hipStream_t stream, const PairwiseArgs& a, const int* d_l
     const int64_t rows = a.row_end - a.row_begin, cols = a.col_end - a.col_begin;
     const int n_tr = (int)((rows + G::TM - 1) / G::TM), n_tc = (int)((cols + G::TN - 1) / G::TN);
     PairwiseArgs b = a;
-    if (b.symmetric && ((a.row_begin - a.col_begin) % 256 != 0 || a.mirror_all)) b.symmetric = 0;   // as launch_pp<2> decided
+    if (b.symmetric && !a.plan && ((a.row_begin - a.col_begin) % 256 != 0 || a.mirror_all)) b.symmetric = 0;   // as launch_pp<2> decided
     b.tile_list = d_list;
     b.tile_list_n = n_list;
     const size_t lds = (size_t)4 * G::kStage;
@@ -2996,13 +3139,13 @@ int launch_exact_tiles(hipStream_t stream, const PairwiseArgs& a, const int* d_l
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pairwise_pp<0, 4, 0, 0, 1, 0, 1>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return MVS_E_HIP;
-        hipLaunchKernelGGL((k_pairwise_pp<0, 4, 0, 0, 1, 0, 1>), dim3(per * 8u), dim3(512), lds, stream, b, n_tr, n_tc);
+        hipLaunchKernelGGL((k_pairwise_pp<0, 4, 0, 0, 1, 0, 1>), dim3(per * 8u), dim3(512), lds, stream, b, n_tr, n_tc, PlanSegs{});
         return 0;
     }
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pairwise_pp<0, 4>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return MVS_E_HIP;
-    hipLaunchKernelGGL((k_pairwise_pp<0, 4>), dim3(per * 8u), dim3(512), lds, stream, b, n_tr, n_tc);
+    hipLaunchKernelGGL((k_pairwise_pp<0, 4>), dim3(per * 8u), dim3(512), lds, stream, b, n_tr, n_tc, PlanSegs{});
     return 0;
 }
 
@@ -3097,6 +3240,26 @@ int launch_pairwise(hipStream_t stream, const PairwiseArgs& a, int mode, int alg
         else
             hipLaunchKernelGGL(k_pairwise_valu<1>, grid, dim3(256), 0, stream, s);
     }
+    return 0;
+}
+
+int launch_cells_route(hipStream_t stream, const mvs_cell* d_raw, const unsigned long long* d_n_raw, unsigned long long raw_capacity,
+                       long long block_pad, long long block_rows, long long n_total, int own_begin, int own_end, mvs_cell* d_own,
+                       unsigned long long own_capacity, unsigned long long* d_own_count, unsigned long long* d_send,
+                       unsigned long long foreign_capacity, long long status, long long max_abs) {
+    RouteArgs r{d_raw, d_n_raw, raw_capacity, block_pad, block_rows, n_total, own_begin, own_end, d_own, own_capacity, d_own_count,
+                d_send, foreign_capacity, status, max_abs};
+    const unsigned long long blocks = std::min<unsigned long long>(1024ULL, std::max<unsigned long long>(1ULL, (raw_capacity + 255) / 256));
+    hipLaunchKernelGGL(k_cells_route, dim3((unsigned)blocks), dim3(256), 0, stream, r);
+    return 0;
+}
+
+int launch_cells_collect(hipStream_t stream, const unsigned long long* d_recv, int world, int rank, unsigned long long capacity,
+                         int own_begin, int own_end, mvs_cell* d_own, unsigned long long own_capacity, unsigned long long* d_own_count) {
+    if (world <= 1) return 0;
+    const unsigned long long blocks = std::min<unsigned long long>(256ULL, std::max<unsigned long long>(1ULL, (capacity + 255) / 256));
+    hipLaunchKernelGGL(k_cells_collect, dim3((unsigned)blocks, (unsigned)world), dim3(256), 0, stream, d_recv, rank, capacity, own_begin,
+                       own_end, d_own, own_capacity, d_own_count);
     return 0;
 }
 

@@ -1,27 +1,36 @@
 """Row-sharded all-vs-all comparison across the GPUs of one node (one process per GPU).
 
 Partitioning is the reference's own (src/pairwise_comp_optimized.cpp:938-940): rank r owns rows
-[r*ceil(N/G), min((r+1)*ceil(N/G), N)) and compares them against ALL N columns, producing exactly the
-`shard_r/` of a `--num_shards G --shard_idx r` run.  The reference's "exchange" is every process
-re-reading the shared vectors.bin; here every rank sketches (or loads) only its own rows and ONE
-all-gather (RCCL over xGMI when the process group is `nccl`) of the int8 limb-plane row blocks gives
-every GPU all N columns.  Norms (N doubles) are all-gathered the same way.  Results are not exchanged.
+[r*ceil(N/G), min((r+1)*ceil(N/G), N)) and ends up with exactly the `shard_r/` of a `--num_shards G --shard_idx r`
+run.  The reference's "exchange" is every shard process re-reading the shared vectors.bin and comparing its rows
+against ALL columns (:949-982); here a rank sketches (or loads) only its own rows and the step is
 
-The collective calls are torch.distributed's; the numeric work goes through an `ops` object:
-`GpuOps` (libmvs_hip.so through the C ABI) in production.  tests/ substitutes a CPU stand-in built on
-the oracle to exercise this module with the gloo backend.
+  own rows  -> limb planes + the filter's inputs (coarse plane, row statistics) for OWN rows only
+  exchange  -> all-gather of the row statistics and norms (bytes per row), of the coarse plane in row CHUNKS, then of
+               the limb planes -- on the communicator's stream (RCCL over xGMI), in that order: the filter needs only the
+               first two, the limb planes are read by the exact re-check at the very end
+  compare   -> the rank's share of the symmetric schedule as ONE block plan (libmvs_hip: mvs_plan_*): every unordered
+               pair of row blocks is compared by exactly one rank (block (r, r+k) by rank r for 0 < k < G/2, the opposite
+               block of an even G split in halves), kept cells outside the rank's own square are mirrored.  The filter
+               runs as one launch for the diagonal block -- it needs nothing from anybody, so it starts before the
+               exchange has delivered a byte -- and one launch per arrived chunk of the peers' rows
+  cells     -> split on the device into this shard's cells and mirror images that belong to other ranks' rows; ONE
+               fixed-size all-gather of the latter (its header carries every rank's status and largest |v|: no separate
+               agreement collectives), collect, sort.
 
-With more than one rank the default schedule is SYMMETRIC across ranks as well: every unordered pair of row
-blocks is compared by exactly one rank (block (r, r+d) by rank r for 0 < d < G/2; the opposite block of an
-even G is split in halves between the two ranks), which appends each kept cell AND its mirror image; the
-mirrored cells that belong to other ranks' rows are then exchanged (one more all-gather, of kept cells --
-a few MB) and merged.  Per-rank comparison work drops from G - 1/2 blocks to G/2.  Set
-MVS_SHARDED_SYMMETRIC=0 for the plain rows x all-columns schedule.
+Host synchronisations per step: one inside mvs_plan_finish (candidate and flagged-tile counts size the later launches)
+and one for the final cell counts.
 
-The exchange itself goes through a small `collectives` object: `NativeCollectives` wraps the communicator of the
-C ABI (mvs_comm: RCCL bound at run time, or the file transport for ranks sharing a device) -- the same entry
-points the C++ `pairwise_comp_optimized` uses with MVS_COLLECTIVE=rccl; `TorchCollectives` wraps a
-torch.distributed process group (gloo in the CPU tests, nccl = RCCL otherwise).
+Storage coordinates: every rank's block of the gathered buffers is padded to a multiple of 256 rows
+(_capi.shard_layout), so that all blocks start on the tile grid and on the 16-row grid of the fragment-major planes
+whatever N and G are; kept cells are translated back to sample indices when they are routed.
+
+The numeric work goes through an `ops` object (`GpuOps`: libmvs_hip.so through the C ABI; tests/ substitutes a CPU
+stand-in built on the oracle to exercise this module with the gloo backend), the exchange through a `collectives`
+object: `NativeCollectives` wraps the communicator of the C ABI (mvs_comm: RCCL bound at run time, or the file transport
+for ranks sharing a device) -- the same entry points the C++ `pairwise_comp_optimized` uses with MVS_COLLECTIVE=rccl;
+`TorchCollectives` wraps a torch.distributed process group (gloo in the CPU tests, nccl = RCCL otherwise).
+MVS_SHARDED_SYMMETRIC=0 selects the plain rows x all-columns schedule (no mirroring, no cell exchange).
 """
 import os
 
@@ -30,73 +39,143 @@ import numpy as np
 from . import _capi
 
 
-class TorchCollectives:
+# ---------------------------------------------------------------------------------------------------------------
+# collectives
+# ---------------------------------------------------------------------------------------------------------------
+class _Done:
+    """handle of an exchange that has already happened"""
+
+    def wait(self):
+        return None
+
+
+class _StreamHandle:
+    """an exchange queued on a side stream: wait() makes the CURRENT stream wait for it (no host wait)"""
+
+    def __init__(self, event):
+        self.event = event
+
+    def wait(self):
+        import torch
+        torch.cuda.current_stream().wait_event(self.event)
+
+
+class _ThreadHandle:
+    """an exchange that runs on a worker thread (the file transport blocks its caller): wait() joins it, then orders the
+    current stream behind what it queued"""
+
+    def __init__(self, future):
+        self.future = future
+
+    def wait(self):
+        import torch
+        ev = self.future.result()
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+
+
+class _Collectives:
+    """submit(fn): run the collective calls in fn() so that they see everything the compute stream has queued so far;
+    returns a handle whose wait() orders the compute stream behind them.  Base: synchronous."""
+    stream = None
+
+    def submit(self, fn):
+        fn()
+        return _Done()
+
+    def _submit_on_stream(self, fn):
+        import torch
+        main = torch.cuda.current_stream()
+        self.stream.wait_stream(main)
+        with torch.cuda.stream(self.stream):
+            fn()
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        return _StreamHandle(ev)
+
+
+class TorchCollectives(_Collectives):
     """the collectives of the exchange over torch.distributed.  stream: a torch.cuda.Stream the collectives are issued
-    on (None: the caller's current stream) -- a side stream lets an exchange run beside the compute stream's kernels"""
+    on (None: the caller's current stream, synchronous semantics)"""
     kind = "torch.distributed"
 
     def __init__(self, dist, rank, world, stream=None):
         self.dist, self.rank, self.world, self.stream = dist, rank, world, stream
+        self._send = None
 
-    def _on_stream(self):
-        import contextlib
+    def submit(self, fn):
         if self.stream is None:
-            return contextlib.nullcontext()
-        import torch
-        return torch.cuda.stream(self.stream)
-
-    def allreduce_max(self, value, like):
-        import torch
-        with self._on_stream():
-            t = torch.tensor([int(value)], dtype=torch.int64, device=getattr(like, "device", "cpu"))
-            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
-            return int(t.cpu()[0])
+            return super().submit(fn)
+        return self._submit_on_stream(fn)
 
     def allgather_blocks(self, buf, block_elems):
         """buf: 1-D tensor of world * block_elems elements whose block `rank` is filled in"""
-        with self._on_stream():
-            send = buf[self.rank * block_elems:(self.rank + 1) * block_elems]
-            if self._send is None or self._send.shape != send.shape or self._send.dtype != send.dtype:
-                self._send = send.new_empty(send.shape)
-            self._send.copy_(send)     # a separate send block: NCCL / gloo need not support aliased in-place gathers
-            self.dist.all_gather_into_tensor(buf[:self.world * block_elems], self._send)
+        send = buf[self.rank * block_elems:(self.rank + 1) * block_elems]
+        if self._send is None or self._send.shape != send.shape or self._send.dtype != send.dtype:
+            self._send = send.new_empty(send.shape)
+        self._send.copy_(send)     # a separate send block: NCCL / gloo need not support aliased in-place gathers
+        self.dist.all_gather_into_tensor(buf[:self.world * block_elems], self._send)
 
-    def allgather_rows(self, planes, rows_per_rank, row_first, row_count, limbs, d_pad):
-        """rows [row_first, row_first + row_count) of every rank's block of the plane buffer (mvs_allgather_rows)"""
+    def allgather_rows(self, buf, rows_per_rank, row_first, row_count, row_bytes):
+        """rows [row_first, row_first + row_count) of every rank's block of a byte buffer (mvs_allgather_rows)"""
         if row_count == rows_per_rank:
-            return self.allgather_blocks(planes, rows_per_rank * (limbs & 0xff) * d_pad)
+            return self.allgather_blocks(buf, rows_per_rank * row_bytes)
         if row_count == 0:
             return
-        with self._on_stream():
-            rb = (limbs & 0xff) * d_pad
-            view = planes[:self.world * rows_per_rank * rb].view(self.world, rows_per_rank * rb)[:, row_first * rb:(row_first + row_count) * rb]
-            tmp = planes.new_empty(self.world * row_count * rb)
-            self.dist.all_gather_into_tensor(tmp, view[self.rank].contiguous())
-            view.copy_(tmp.view(self.world, row_count * rb))
-
-    _send = None
+        view = buf[:self.world * rows_per_rank * row_bytes].view(self.world, rows_per_rank * row_bytes)[
+            :, row_first * row_bytes:(row_first + row_count) * row_bytes]
+        tmp = buf.new_empty(self.world * row_count * row_bytes)
+        self.dist.all_gather_into_tensor(tmp, view[self.rank].contiguous())
+        view.copy_(tmp.view(self.world, row_count * row_bytes))
 
 
-class NativeCollectives:
+class NativeCollectives(_Collectives):
     """the same over the communicator of the C ABI (in place on the device, on the stream of the communicator's
     context).  stream: that stream as a torch.cuda.Stream when it is NOT the compute stream (bench.py gives the
-    communicator a context of its own on a side stream, so that an exchange can run beside the projection kernel);
-    ShardedComparison then orders the two streams around every exchange."""
+    communicator a context of its own on a side stream, so that an exchange runs beside the compute stream's kernels).
+    RCCL calls are asynchronous: submit() queues them on the side stream and returns.  The file transport (ranks sharing
+    one card: rehearsals and tests) blocks inside every call, so its calls run on a worker thread."""
 
     def __init__(self, comm, stream=None):
         self.comm, self.rank, self.world, self.stream = comm, comm.rank, comm.world, stream
         self.kind = "libmvs_hip mvs_comm (%s)" % ("RCCL" if comm.is_rccl else "file transport")
+        self._pool = None
 
-    def allreduce_max(self, value, like):
-        return self.comm.allreduce_max(value)
+    def submit(self, fn):
+        if self.stream is None:
+            return super().submit(fn)
+        if self.comm.is_rccl:
+            return self._submit_on_stream(fn)
+        import torch
+        from concurrent.futures import ThreadPoolExecutor
+        if self._pool is None:
+            self._pool = ThreadPoolExecutor(max_workers=1)      # ONE thread: the collectives keep their order
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream())
+        device = torch.cuda.current_device()
+
+        def job():
+            torch.cuda.set_device(device)
+            self.stream.wait_event(ready)
+            fn()
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+            return ev
+        return _ThreadHandle(self._pool.submit(job))
 
     def allgather_blocks(self, buf, block_elems):
         self.comm.allgather_bytes(buf, block_elems * buf.element_size())
 
-    def allgather_rows(self, planes, rows_per_rank, row_first, row_count, limbs, d_pad):
-        self.comm.allgather_rows(planes, rows_per_rank, row_first, row_count, limbs, d_pad)
+    def allgather_rows(self, buf, rows_per_rank, row_first, row_count, row_bytes):
+        # mvs_allgather_rows speaks of rows of limbs * d_pad bytes with d_pad a multiple of 128
+        if row_bytes % 128 != 0:
+            raise ValueError("row size must be a multiple of 128 bytes")
+        self.comm.allgather_rows(buf, rows_per_rank, row_first, row_count, 1, row_bytes)
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# partitioning
+# ---------------------------------------------------------------------------------------------------------------
 def shard_rows(n_total, world, rank):
     """src/pairwise_comp_optimized.cpp:938-940"""
     rps = (n_total + world - 1) // world
@@ -104,62 +183,102 @@ def shard_rows(n_total, world, rank):
     return b, min(b + rps, n_total)
 
 
-def block_plan(n_total, world, rank):
-    """Blocks (row_begin, row_end, col_begin, col_end, flags) rank `rank` compares in the symmetric schedule.
-    Over all ranks every unordered pair of samples is covered exactly once (diagonal blocks: both orders)."""
-    rb, re = shard_rows(n_total, world, rank)
-    plan = []
-    if re > rb:
-        plan.append((rb, re, rb, re, _capi.BLOCK_SYMMETRIC))
-    for d in range(1, (world - 1) // 2 + 1):
-        cb, ce = shard_rows(n_total, world, (rank + d) % world)
-        if re > rb and ce > cb:
-            plan.append((rb, re, cb, ce, _capi.BLOCK_MIRROR_ALL))
+def half_split(block_pad):
+    """where the opposite block of an even world is cut: a multiple of 256 rows near the middle"""
+    return ((block_pad // 256 + 1) // 2) * 256
+
+
+def block_plan(world, rank, block_pad, symmetric=True):
+    """Rectangles (row_begin, row_end, col_begin, col_end) in STORAGE coordinates (rank p's rows at [p * block_pad,
+    (p + 1) * block_pad)) that rank `rank` compares.  Symmetric schedule: its diagonal block first (tiles below the
+    diagonal are skipped by the kernel and produced by mirroring), then the blocks whose kept cells are mirrored into other
+    ranks' rows -- over all ranks every unordered pair of rows is covered exactly once.  Otherwise: its rows against every
+    block (the reference's schedule)."""
+    P = block_pad
+    rb, re = rank * P, (rank + 1) * P
+    plan = [(rb, re, rb, re)]
+    if not symmetric:
+        return plan + [(rb, re, p * P, (p + 1) * P) for p in range(world) if p != rank]
+    for k in range(1, (world - 1) // 2 + 1):
+        p = (rank + k) % world
+        plan.append((rb, re, p * P, (p + 1) * P))
     if world > 1 and world % 2 == 0:
         p = (rank + world // 2) % world
-        pb, pe = shard_rows(n_total, world, p)
+        h = half_split(P)
         if rank < p:                      # the lower rank takes the first half of ITS rows against all of p's
-            mid = rb + (re - rb + 1) // 2
-            if mid > rb and pe > pb:
-                plan.append((rb, mid, pb, pe, _capi.BLOCK_MIRROR_ALL))
-        else:                             # the higher rank takes all of its rows against the second half of p's
-            mid = pb + (pe - pb + 1) // 2
-            if re > rb and pe > mid:
-                plan.append((rb, re, mid, pe, _capi.BLOCK_MIRROR_ALL))
+            if h > 0:
+                plan.append((rb, rb + h, p * P, (p + 1) * P))
+        elif h < P:                       # the higher rank takes all of its rows against the second half of p's
+            plan.append((rb, re, p * P + h, (p + 1) * P))
     return plan
 
 
+def chunk_bounds(block_pad, chunks):
+    """[(c0, c1)] cutting a block of block_pad rows into at most `chunks` pieces on multiples of 256 rows"""
+    tiles = block_pad // 256
+    chunks = max(1, min(chunks, tiles))
+    cuts = [(tiles * k // chunks) * 256 for k in range(chunks + 1)]
+    return [(cuts[k], cuts[k + 1]) for k in range(chunks) if cuts[k + 1] > cuts[k]]
+
+
+def clip_blocks(blocks, block_pad, c0, c1):
+    """the parts of the rectangles whose columns lie at offsets [c0, c1) of their rank block"""
+    out = []
+    for (rb, re, cb, ce) in blocks:
+        base = (cb // block_pad) * block_pad
+        lo, hi = max(cb, base + c0), min(ce, base + c1)
+        if hi > lo:
+            out.append((rb, re, lo, hi))
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# numeric back end
+# ---------------------------------------------------------------------------------------------------------------
 class GpuOps:
     """numeric back end on one MI355X: everything is a call into libmvs_hip.so"""
 
     def __init__(self, ctx, device):
         import torch
         self.ctx, self.device = ctx, device
-        self.k2_ms = 0.0
         # buffers here are torch tensors (zero fills, copies and slices run on torch's stream): the library
         # must issue its kernels on that same stream or nothing orders them against each other
         ctx.set_stream(torch.cuda.current_stream(torch.device(device)))
+
+    def layout(self, n_total, world):
+        return _capi.shard_layout(n_total, world)
 
     def new_cells(self, capacity):
         import torch
         return torch.empty((capacity, 4), dtype=torch.int32, device=self.device)
 
-    def open_set(self, planes, n, n_alloc, d, d_pad, limbs):
-        return self.ctx.sketch_set_from_planes(planes, n, n_alloc, d, d_pad, limbs)
+    def new_bytes(self, nbytes):
+        import torch
+        return torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
 
-    def close_set(self, sset):
-        sset.close()
+    def new_planes(self, nbytes):
+        import torch
+        return torch.zeros(nbytes, dtype=torch.int8, device=self.device)
 
-    def compare_block(self, sset, norms_sq, rb, re, cb, ce, flags, keep_mode, raw, n_raw):
-        n = self.ctx.pairwise_block(sset, norms_sq, rb, re, cb, ce, flags, raw, n_raw, keep_mode=keep_mode)
-        try:
-            self.k2_ms += self.ctx.kernel_ms(1)
-        except _capi.MvsError:
-            pass
-        return n
+    def new_counter(self):
+        import torch
+        return torch.zeros(1, dtype=torch.int64, device=self.device)
 
-    def sort_cells(self, cells_in, n, cells_out):
-        self.ctx.cells_sort(cells_in, n, cells_out)
+    def zero_count(self):
+        """a count reference (what plan_finish returns) that reads zero: a rank whose comparison failed routes nothing"""
+        if getattr(self, "_zero", None) is None:
+            self._zero = self.new_counter()
+        return self._zero.data_ptr()
+
+    def zero_(self, t):
+        t.zero_()
+
+    def to_device(self, host_array):
+        import torch
+        return torch.from_numpy(np.ascontiguousarray(host_array)).to(self.device)
+
+    def to_host_cells(self, cells, n):
+        return cells[:n].cpu().numpy().view(_capi.CELL_DTYPE).reshape(-1)
 
     def max_abs(self, sketches):
         return self.ctx.max_abs(sketches)
@@ -170,153 +289,157 @@ class GpuOps:
     def limb_geometry(self, n, d, limbs):
         return self.ctx.limb_geometry(n, d, limbs)
 
-    def new_planes(self, nbytes):
-        import torch
-        return torch.zeros(nbytes, dtype=torch.int8, device=self.device)
-
     def limb_split(self, sketches, limbs, planes, d_pad, row_offset):
         self.ctx.limb_split(sketches, limbs, planes, d_pad, row_offset)
 
-    def to_device(self, host_array):
-        import torch
-        return torch.from_numpy(np.ascontiguousarray(host_array)).to(self.device)
-
-    def compare(self, planes, n, n_alloc, d, d_pad, limbs, norms_sq, row_begin, row_end, keep_mode, cells_out):
+    def open_set(self, planes, n, n_alloc, d, d_pad, limbs, coarse_fm, stats):
         sset = self.ctx.sketch_set_from_planes(planes, n, n_alloc, d, d_pad, limbs)
-        try:
-            return self.ctx.pairwise_rows(sset, norms_sq, row_begin=row_begin, row_end=row_end,
-                                          keep_mode=keep_mode, cells_out=cells_out)
-        finally:
-            sset.close()
+        self.ctx.attach_derived(sset, coarse_fm, stats)
+        return sset
+
+    def close_set(self, sset):
+        sset.close()
+
+    def touch_set(self, sset):
+        sset.touch()
+
+    def prepare_rows(self, sset, first, count):
+        self.ctx.prepare_rows(sset, first, count)
+
+    def plan_begin(self, sset, norms_sq, f0, f1, mirror_outside, raw, keep_mode):
+        self.ctx.plan_begin(sset, norms_sq, f0, f1, mirror_outside, raw, keep_mode=keep_mode)
+
+    def plan_filter(self, blocks):
+        self.ctx.plan_filter(blocks)
+
+    def plan_finish(self):
+        return self.ctx.plan_finish()
+
+    def plan_stats(self):
+        return self.ctx.plan_stats()
+
+    def cells_route(self, raw, d_n_raw, block_pad, block_rows, n_total, own, own_out, d_own, send, cap_f, status, max_abs):
+        self.ctx.cells_route(raw, d_n_raw, block_pad, block_rows, n_total, own[0], own[1], own_out, d_own, send, cap_f,
+                             status, max_abs)
+
+    def cells_collect(self, recv, world, rank, cap_f, own, own_out, d_own):
+        self.ctx.cells_collect(recv, world, rank, cap_f, own[0], own[1], own_out, d_own)
+
+    def cells_report(self, recv, world, cap_f, d_own):
+        return self.ctx.cells_report(recv, world, cap_f, d_own)
+
+    def sort_cells(self, cells_in, n, cells_out):
+        self.ctx.cells_sort(cells_in, n, cells_out)
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# the step
+# ---------------------------------------------------------------------------------------------------------------
 class ShardedComparison:
-    """State that survives between steps (the gathered plane buffer is reused while its geometry holds).
+    """State that survives between steps (the gathered buffers are reused while their geometry holds).
 
     run() is the whole exchange + comparison for local rows that are complete.  begin() / feed() / finish() do the same
-    for local rows that become final in PARTS: the limb planes of a finished part are handed to the all-gather at once
-    (mvs_allgather_rows, on the collectives' stream), so the exchange of part k runs beside the projection of part
-    k + 1.  The limb code has to be fixed before the first part is known in full, so the parts are coded with
-    `limbs_guess` (two base-256 limbs: |v| <= 32639, what sketches of up to tens of millions of hashes need) and the
-    all-reduce of max|v| at the end verifies the guess on all ranks; if it does not hold, finish() falls back to run()
-    -- same result, no overlap."""
+    for local rows that become final in PARTS (bench.py projects a rank's samples in pieces): the planes and filter
+    inputs of a finished part are handed to the all-gather at once, so the exchange of part k runs beside the projection
+    of part k + 1.  The limb code has to be fixed before the first row is known, so rows are coded with `limbs_guess` (two
+    base-256 limbs: |v| <= 32639, what sketches of up to tens of millions of hashes need; fewer limbs than the guess is
+    exact too) and every rank's largest |v| travels in the header of the cell exchange: if the guess does not hold on some
+    rank, every rank sees that and redoes the step with the limb code the data needs."""
 
     def __init__(self, ops, rank=0, world=1, dist=None, collectives=None):
         """dist: a torch.distributed module with an initialised default group, or collectives: a
         TorchCollectives / NativeCollectives object (takes precedence)."""
         self.ops, self.rank, self.world = ops, rank, world
         self.coll = collectives if collectives is not None else (TorchCollectives(dist, rank, world) if dist is not None else None)
-        self._planes = None
-        self._key = None
-        self._raw = self._tmp = self._xraw = None
-        self._n2 = None
-        self.time_gather = False         # bench: torch events around the all-gathers (read with last_gather_ms())
-        self._ev = None
-        self._step = None
-        self.symmetric = os.environ.get("MVS_SHARDED_SYMMETRIC", "1") != "0"
         if world > 1 and self.coll is None:
             raise ValueError("world > 1 needs torch.distributed or a communicator")
+        self.symmetric = os.environ.get("MVS_SHARDED_SYMMETRIC", "1") != "0"
+        self.gather_chunks = max(1, int(os.environ.get("MVS_GATHER_CHUNKS", "2")))   # pieces the peers' coarse rows arrive in
+        self.time_gather = False         # bench: events around the exchange (read with last_gather_ms())
+        self.trace = None                # a list: (label, torch event) pairs of the last step (tools/exp/r05_overlap_trace.py)
+        self._key = None
+        self._planes = self._coarse = self._stats = self._n2 = self._sset = None
+        self._raw = self._own = self._xbuf = self._d_own = None
+        self._cap_f = 1 << 14
+        self._step = None
+        self._ev = None
 
+    # ---- timing aids ----
     def last_gather_ms(self):
-        """span from the first to the last all-gather of the last step on the exchange stream (0 with one rank);
+        """span from the first to the last collective of the last step on the exchange stream (0 with one rank);
         synchronises on the end event"""
-        if self._ev is None:
+        if self._ev is None or self._ev[0] is None or self._ev[1] is None:
             return 0.0
         self._ev[1].synchronize()
         return self._ev[0].elapsed_time(self._ev[1])
 
-    # ---- stream order: compute stream <-> the collectives' stream (when they differ) ----
-    def _side(self):
-        return getattr(self.coll, "stream", None) if self.coll is not None else None
-
-    def _exchange(self, fn):
-        """fn() issues collectives: they see everything the compute stream has queued so far, and the compute stream
-        sees their result"""
-        side = self._side()
-        if side is None:
-            return fn()
-        import torch
-        main = torch.cuda.current_stream()
-        side.wait_stream(main)
-        out = fn()
-        main.wait_stream(side)
-        return out
-
     def _mark(self, which):
-        if not self.time_gather or self.world == 1:
+        """inside a submitted exchange: an event on the stream the collectives run on"""
+        if not self.time_gather or self.world == 1 or getattr(self.coll, "stream", None) is None:
             return
         import torch
-        if which == 0:
-            self._ev = [torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)]
-        side = self._side()
-        self._ev[which].record(side if side is not None else torch.cuda.current_stream())
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(self.coll.stream)
+        if self._ev is None:
+            self._ev = [None, None]
+        if which == 0 and self._ev[0] is None:
+            self._ev[0] = ev
+        if which == 1:
+            self._ev[1] = ev
 
-    def _agree(self, status):
-        """every rank learns whether any rank failed (a rank that raises alone would leave the others inside the
-        next collective until the launcher's timeout): returns the largest status"""
-        if self.world == 1:
-            return status
-        return self.coll.allreduce_max(status, self._planes)
+    def _trace(self, label, stream=None):
+        if self.trace is None:
+            return
+        import torch
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(stream if stream is not None else torch.cuda.current_stream())
+        self.trace.append((label, ev))
 
+    # ---- buffers ----
     def _prepare(self, n_total, d, limbs):
-        """plane buffer + norm buffer of the global geometry -> (rps, n_alloc, d_pad)"""
         ops, world = self.ops, self.world
-        rps = (n_total + world - 1) // world            # rows per shard = block size of the all-gather
-        n_rows_global = rps * world                      # >= n_total; the tail rows stay zero
-        n_alloc, d_pad, nbytes = ops.limb_geometry(n_rows_global, d, limbs)
-        key = (limbs, n_alloc, d_pad, n_rows_global)
+        rps, P = ops.layout(n_total, world)
+        n_st = P * world                                 # storage rows; the rows behind a shard's samples stay zero
+        n_alloc, d_pad, nbytes = ops.limb_geometry(n_st, d, limbs)
+        key = (limbs, n_alloc, d_pad, n_st, n_total, d)
         if self._key != key:
+            if self._sset is not None:
+                ops.close_set(self._sset)
+                self._sset = None
             self._planes = ops.new_planes(nbytes)
-            self._n2 = ops.to_device(np.zeros(n_rows_global, dtype=np.float64))
+            self._coarse = ops.new_bytes(n_alloc * d_pad)          # fragment-major coarse plane (two-limb sets)
+            self._stats = ops.new_bytes(n_alloc * 16)              # 16 bytes of row statistics
+            self._n2 = ops.to_device(np.zeros(n_alloc, dtype=np.float64))
+            self._sset = ops.open_set(self._planes, n_st, n_alloc, d, d_pad, limbs, self._coarse, self._stats)
             self._key = key
-        return rps, n_alloc, d_pad
+        return rps, P, n_alloc, d_pad
 
-    def _put_norms(self, norms_sq_part, first, count, rps):
+    def _put_norms(self, norms_sq_part, first, count, P):
         """norms of local rows [first, first + count) into this rank's block of the gathered norm buffer"""
-        n2_all, base = self._n2, self.rank * rps + first
+        n2_all, base = self._n2, self.rank * P + first
         if _capi._is_torch(norms_sq_part) and not _capi._is_torch(n2_all):
             norms_sq_part = norms_sq_part.cpu().numpy()      # host back end (tests): plain arrays
-        if _capi._is_torch(norms_sq_part):
+        if _capi._is_torch(norms_sq_part) and getattr(norms_sq_part, "device", None) == getattr(n2_all, "device", None):
             n2_all[base:base + count].copy_(norms_sq_part)   # already on the device: no host round trip
         else:
-            n2_all[base:base + count] = self.ops.to_device(np.ascontiguousarray(norms_sq_part, dtype=np.float64))
+            host = norms_sq_part.cpu().numpy() if _capi._is_torch(norms_sq_part) else norms_sq_part
+            n2_all[base:base + count] = self.ops.to_device(np.ascontiguousarray(host, dtype=np.float64))
 
+    # ---- whole steps ----
     def run(self, sketches_local, norms_sq_local, n_total, keep_mode=_capi.KEEP_INT32, cells_out=None,
-            max_abs_local=None):
+            max_abs_local=None, limbs_guess=2):
         """sketches_local: this rank's rows (int32/int16 [n_local, d]); norms_sq_local: float64 [n_local], a host
         array or a device tensor; max_abs_local: largest |v| of sketches_local if the caller already has it
-        (Context.stats).  Returns (cells, n_cells, info) for this rank's shard.
-        cells_out (device [capacity, 4] int32): capacity only has to hold this shard's cells; what the symmetric
-        schedule has in flight on top of them (mirrored cells on their way to other ranks) lives in internal buffers."""
-        ops, rank, world = self.ops, self.rank, self.world
-        n_local, d = sketches_local.shape
-        rb, re = shard_rows(n_total, world, rank)
-        if re - rb != n_local:
-            raise ValueError("rank %d holds %d rows but its shard is [%d,%d)" % (rank, n_local, rb, re))
-        if max_abs_local is not None:
-            max_abs = int(max_abs_local)
-        else:
-            max_abs = ops.max_abs(sketches_local) if n_local else 0
-        if world > 1:
-            max_abs = self.coll.allreduce_max(max_abs, sketches_local)
-        limbs = ops.limbs_for(max_abs)
-        rps, n_alloc, d_pad = self._prepare(n_total, d, limbs)
-        planes = self._planes
-        if n_local:
-            ops.limb_split(sketches_local, limbs, planes, d_pad, rank * rps)
-            self._put_norms(norms_sq_local, 0, n_local, rps)
-        if n_local < rps:
-            self._n2[rank * rps + n_local:(rank + 1) * rps] = 0      # the block's tail rows: zero sketches, zero norms
-        if world > 1:
-            def gather():
-                self._mark(0)
-                self.coll.allgather_rows(planes, rps, 0, rps, limbs, d_pad)   # int8 row blocks: 2 B per entry at two limbs instead of 4
-                self.coll.allgather_blocks(self._n2, rps)
-                self._mark(1)
-            self._exchange(gather)
-        return self._compare(n_total, d, limbs, rps, n_alloc, d_pad, rb, re, keep_mode, cells_out, overlapped=False)
+        (Context.stats).  Returns (cells, n_cells, info) for this rank's shard, sorted by (row, col).
+        cells_out (device [capacity, 4] int32): capacity only has to hold this shard's cells; without it the cells come
+        back as a host array."""
+        n_local = sketches_local.shape[0]
+        if max_abs_local is None:
+            max_abs_local = self.ops.max_abs(sketches_local) if n_local else 0
+        self.begin(sketches_local, norms_sq_local, n_total, limbs_guess=limbs_guess)
+        self.feed(0, self._step["P"], int(max_abs_local))
+        return self.finish(keep_mode=keep_mode, cells_out=cells_out)
 
-    # ---- local rows arriving in parts ----
     def begin(self, sketches_local, norms_sq_local, n_total, limbs_guess=2):
         """sketches_local / norms_sq_local: the rank's FULL buffers ([n_local, d] / [n_local]); their rows become valid
         part by part (feed).  Nothing is read here."""
@@ -324,157 +447,190 @@ class ShardedComparison:
         rb, re = shard_rows(n_total, self.world, self.rank)
         if re - rb != n_local:
             raise ValueError("rank %d holds %d rows but its shard is [%d,%d)" % (self.rank, n_local, rb, re))
-        rps, n_alloc, d_pad = self._prepare(n_total, d, limbs_guess)
-        if n_local < rps:
-            self._n2[self.rank * rps + n_local:(self.rank + 1) * rps] = 0
-        self._step = {"sk": sketches_local, "n2": norms_sq_local, "n_total": n_total, "limbs": limbs_guess, "rps": rps,
-                      "n_alloc": n_alloc, "d_pad": d_pad, "max_abs": 0, "fed": 0, "parts": 0}
+        rps, P, n_alloc, d_pad = self._prepare(n_total, d, limbs_guess)
+        self.ops.touch_set(self._sset)                    # the buffers are about to be rewritten
+        self._ev = None
+        if self.trace is not None:
+            del self.trace[:]
+            self._trace("step begin")
+        self._step = {"sk": sketches_local, "n2": norms_sq_local, "n_total": n_total, "limbs": limbs_guess, "rps": rps, "P": P,
+                      "n_alloc": n_alloc, "d_pad": d_pad, "max_abs": 0, "fed": 0, "parts": 0, "coarse": [], "last": [],
+                      "rows": (rb, re)}
 
     def part_bounds(self, n_total, parts):
-        """[(row_begin, row_end)] cutting a rank's block of ceil(n_total / world) rows into `parts` pieces: the SAME
-        bounds on every rank (a collective's sizes must agree); a rank whose shard is shorter than the block simply has
-        fewer -- or no -- rows of its own inside the later pieces"""
-        rps = (n_total + self.world - 1) // self.world
-        step = max(1, (rps + parts - 1) // parts)
-        return [(b, min(b + step, rps)) for b in range(0, max(rps, 1), step)]
+        """[(row_begin, row_end)] cutting a rank's block (STORAGE rows 0 .. block_pad, the same bounds on every rank: a
+        collective's sizes must agree) into `parts` pieces on multiples of 256 rows; a rank whose shard is shorter than the
+        block simply has fewer -- or no -- rows of its own inside the later pieces"""
+        _, P = self.ops.layout(n_total, self.world)
+        return chunk_bounds(P, parts)
 
     def feed(self, row_begin, row_end, max_abs_part):
-        """rows [row_begin, row_end) of this rank's BLOCK (block coordinates: 0 .. ceil(n_total / world), the same
-        bounds on every rank, in order -- part_bounds()) are final: those of them the rank owns (below its n_local) have
-        been written to the buffers given to begin(); max_abs_part: their largest |v|.  Their planes are coded and, with
-        more than one rank, the exchange of exactly this row range of every rank's block starts now."""
+        """rows [row_begin, row_end) of this rank's BLOCK (storage rows, multiples of 256, in order -- part_bounds()) are
+        final: those of them the rank owns (below its n_local) have been written to the buffers given to begin();
+        max_abs_part: their largest |v|.  Their planes and filter inputs are built and, with more than one rank, the
+        exchange of exactly this row range of every rank's block starts now."""
         st = self._step
-        if st is None or row_begin != st["fed"] or row_end < row_begin or row_end > st["rps"]:
+        if st is None or row_begin != st["fed"] or row_end < row_begin or row_end > st["P"] or (row_begin % 256) or \
+                (row_end % 256 and row_end != st["P"]):
             raise ValueError("feed(%d, %d) out of order" % (row_begin, row_end))
+        ops, P, limbs, d_pad = self.ops, st["P"], st["limbs"], st["d_pad"]
         st["fed"], st["parts"] = row_end, st["parts"] + 1
         st["max_abs"] = max(st["max_abs"], int(max_abs_part))
-        rps, limbs, d_pad = st["rps"], st["limbs"], st["d_pad"]
         n_local = st["sk"].shape[0]
         own_b, own_e = min(row_begin, n_local), min(row_end, n_local)
+        base = self.rank * P
         if own_e > own_b:
-            self.ops.limb_split(st["sk"][own_b:own_e], limbs, self._planes, d_pad, self.rank * rps + own_b)
-            self._put_norms(st["n2"][own_b:own_e], own_b, own_e - own_b, rps)
-        if self.world > 1 and row_end > row_begin:
-            def gather():
-                if st["parts"] == 1:
-                    self._mark(0)
-                self.coll.allgather_rows(self._planes, rps, row_begin, row_end - row_begin, limbs, d_pad)
-            self._exchange_begin(gather)
+            ops.limb_split(st["sk"][own_b:own_e], limbs, self._planes, d_pad, base + own_b)
+            self._put_norms(st["n2"][own_b:own_e], own_b, own_e - own_b, P)
+        if row_end > row_begin:
+            ops.prepare_rows(self._sset, base + row_begin, row_end - row_begin)     # rows behind n_local: zero sketches
+        self._trace("own rows [%d,%d) ready" % (row_begin, row_end))
+        if self.world == 1 or row_end == row_begin:
+            return
+        coll, last = self.coll, row_end == P
+        nl = limbs & 0xff
 
-    def _exchange_begin(self, fn):
-        """like _exchange, but the compute stream does NOT wait: what it queues next (the next part's projection) runs
-        beside the exchange; finish() joins the streams"""
-        side = self._side()
-        if side is None:
-            return fn()
-        import torch
-        side.wait_stream(torch.cuda.current_stream())
-        return fn()
+        def small():                      # bytes per row: what every peer filter launch needs first
+            self._mark(0)
+            coll.allgather_blocks(self._stats, P * 16)
+            coll.allgather_blocks(self._n2, P)
+        if last:
+            st["last"].append(coll.submit(small))
+        # the coarse plane of the part in row chunks (units of 16 rows = d_pad * 16 contiguous bytes), then its limb planes
+        for (c0, c1) in chunk_bounds(row_end - row_begin, self.gather_chunks):
+            a, b = row_begin + c0, row_begin + c1
+
+            def coarse(a=a, b=b):
+                self._mark(0)
+                coll.allgather_rows(self._coarse, P // 16, a // 16, (b - a) // 16, 16 * d_pad)
+                self._trace("coarse rows [%d,%d) gathered" % (a, b), getattr(coll, "stream", None))
+            st["coarse"].append((a, b, coll.submit(coarse)))
+
+        def planes():
+            coll.allgather_rows(self._planes, P, row_begin, row_end - row_begin, nl * d_pad)
+            self._mark(1)
+            self._trace("limb planes [%d,%d) gathered" % (row_begin, row_end), getattr(coll, "stream", None))
+        st["last"].append(coll.submit(planes))
 
     def finish(self, keep_mode=_capi.KEEP_INT32, cells_out=None):
         st, self._step = self._step, None
-        if st is None or st["fed"] != st["rps"]:
+        if st is None or st["fed"] != st["P"]:
             raise ValueError("finish() before the whole block was fed")
-        world, rps, limbs = self.world, st["rps"], st["limbs"]
-        max_abs = st["max_abs"]
-        if world > 1:
-            max_abs = self.coll.allreduce_max(max_abs, st["sk"])
-        need = self.ops.limbs_for(max_abs)
-        # planes coded with MORE base-256 limbs than the data needs are still exact (the high limbs are zero); only a guess
-        # that is too small -- or a guess / need in the three-plane Karatsuba code, which is a different encoding -- forces
-        # the step to be redone (ADVICE r3: max|v| <= 127 against the guess of two limbs used to redo split and exchange)
-        plain = need <= 4 and limbs <= 4
-        if (need > limbs) if plain else (need != limbs):
-            # the guess does not hold (on some rank): every rank takes this branch and redoes the step the plain way
-            if self._side() is not None:
-                import torch
-                torch.cuda.current_stream().wait_stream(self._side())
-            cells, cnt, info = self.run(st["sk"], st["n2"], st["n_total"], keep_mode=keep_mode, cells_out=cells_out,
-                                        max_abs_local=st["max_abs"])
-            info["overlap"] = "limb guess %d did not hold: plain exchange" % limbs
-            return cells, cnt, info
-        if world > 1:
-            def gather():
-                self.coll.allgather_blocks(self._n2, rps)
-                self._mark(1)
-            self._exchange(gather)           # joins the exchange stream: every part's rows are in place after this
-        rb, re = shard_rows(st["n_total"], world, self.rank)
-        return self._compare(st["n_total"], st["sk"].shape[1], limbs, rps, st["n_alloc"], st["d_pad"], rb, re, keep_mode,
-                             cells_out, overlapped=world > 1 and st["parts"] > 1)
-
-    def _compare(self, n_total, d, limbs, rps, n_alloc, d_pad, rb, re, keep_mode, cells_out, overlapped):
-        ops, world, planes = self.ops, self.world, self._planes
-        # rows beyond n_total are zero sketches with zero norms: they can never be kept
-        n2_dev = self._n2[:n_total]
-        info = {"limbs": limbs, "rows": (rb, re), "allgather_bytes_per_rank": rps * (limbs & 0xff) * d_pad if world > 1 else 0,
-                "collectives": self.coll.kind if world > 1 else "none",
-                "overlap": "exchange of a part beside the projection of the next" if overlapped else "none"}
-        if world > 1 and self.symmetric and cells_out is not None:
-            cells, cnt = self._run_symmetric(planes, n_total, n_alloc, d, d_pad, limbs, n2_dev, rb, re, keep_mode,
-                                             cells_out, info)
+        ops, world, rank = self.ops, self.world, self.rank
+        P, rps, limbs, n_total = st["P"], st["rps"], st["limbs"], st["n_total"]
+        rb, re = st["rows"]
+        info = {"limbs": limbs, "rows": (rb, re), "collectives": self.coll.kind if world > 1 else "none",
+                "allgather_bytes_per_rank": P * ((limbs & 0xff) + 1) * st["d_pad"] + P * 24 if world > 1 else 0,
+                "schedule": "symmetric" if (self.symmetric and world > 1) else "rows x all columns",
+                "overlap": "none" if world == 1 else
+                           "diagonal block beside the exchange; peers' blocks per arrived chunk of coarse rows" +
+                           ("; exchange of a part beside the projection of the next" if st["parts"] > 1 else "")}
+        cap = cells_out.shape[0] if cells_out is not None else max(1 << 16, 64 * max(re - rb, 1))
+        plan = block_plan(world, rank, P, symmetric=self.symmetric)
+        mirror = self.symmetric and world > 1
+        status, err, d_cnt = 0, None, None
+        need_compute = True
+        for attempt in range(5):
+            # raw: what this rank's blocks produce -- its own cells AND the mirror images on their way to other ranks
+            want_raw = (2 if mirror else 1) * cap + 1024
+            if self._raw is None or self._raw.shape[0] < want_raw:
+                self._raw = ops.new_cells(want_raw)
+            if self._own is None or self._own.shape[0] < cap:
+                self._own = ops.new_cells(cap)
+            if self._d_own is None:
+                self._d_own = ops.new_counter()
+            if need_compute and status == 0:
+                try:
+                    d_cnt = self._compare(st, plan, mirror, keep_mode, first=(attempt == 0))
+                except _capi.MvsError as e:       # the others learn about it from the header of the cell exchange
+                    status, err, d_cnt = e.code, e, None
+            # every rank's send buffer = a 64-byte header {foreign cells, status, max |v|, raw cells, raw capacity} + room for
+            # cap_f mirror images; ONE all-gather of them tells every rank how every other rank fared
+            cap_f = self._cap_f if mirror else 0
+            stride = _capi.CELLS_HEADER_BYTES + 16 * cap_f
+            if self._xbuf is None or self._xbuf.shape[0] < world * stride:
+                self._xbuf = ops.new_bytes(world * stride)
+            xb = self._xbuf[:world * stride]
+            send = xb[rank * stride:(rank + 1) * stride]
+            ops.cells_route(self._raw, d_cnt if d_cnt is not None else ops.zero_count(), P, rps, n_total, (rb, re), self._own,
+                            self._d_own, send, cap_f, status, st["max_abs"])
+            self._trace("cells routed")
+            if world > 1:
+                self.coll.submit(lambda: self.coll.allgather_blocks(xb, stride)).wait()
+                if mirror:
+                    ops.cells_collect(xb, world, rank, cap_f, (rb, re), self._own, self._d_own)
+            n_out, heads = ops.cells_report(xb, world, cap_f, self._d_own)            # the step's second (last) host sync
+            worst = max(int(h[1]) for h in heads)
+            if worst:
+                raise err if err is not None else _capi.MvsError(worst, "another rank failed in its block comparisons")
+            need = ops.limbs_for(max(int(h[2]) for h in heads))
+            plain = need <= 4 and limbs <= 4
+            if (need > limbs) if plain else (need != limbs):
+                # the guess does not hold (on some rank): every rank sees the same headers and redoes the step
+                self.begin(st["sk"], st["n2"], n_total, limbs_guess=need)
+                self.feed(0, P, st["max_abs"])
+                cells, cnt, info2 = self.finish(keep_mode=keep_mode, cells_out=cells_out)
+                info2["overlap"] = "limb guess %d did not hold: step redone with %d" % (limbs, need)
+                return cells, cnt, info2
+            redo = False
+            mine = heads[rank]
+            need_compute = int(mine[3]) > int(mine[4])      # this rank's raw list overflowed: its blocks again, with room
+            if any(int(h[3]) > int(h[4]) for h in heads):   # ... and the others exchange again with it
+                redo = True
+                if need_compute:
+                    cap = max(cap, int(mine[3]) // (2 if mirror else 1) + 1)
+            if mirror and max(int(h[0]) for h in heads) > cap_f:
+                self._cap_f = max(int(h[0]) for h in heads) * 5 // 4 + 1024
+                redo = True
+            if n_out > self._own.shape[0]:
+                if cells_out is not None:
+                    raise _capi.MvsError(_capi.MVS_E_CAPACITY, "%d cells for this shard but capacity is %d" %
+                                         (n_out, cells_out.shape[0]), needed=n_out)
+                cap = n_out + n_out // 4
+                redo = True
+            if not redo:
+                break
         else:
-            status, err = 0, None
-            cells, cnt = None, 0
-            try:
-                cells, cnt = ops.compare(planes, n_total, n_alloc, d, d_pad, limbs, n2_dev, rb, re, keep_mode, cells_out)
-            except _capi.MvsError as e:
-                status, err = e.code, e
-            if self._agree(status):
-                raise err if err is not None else _capi.MvsError(_capi.MVS_E_HIP, "another rank failed in the comparison")
-        return cells, cnt, info
+            raise _capi.MvsError(_capi.MVS_E_CAPACITY, "the step's buffers kept overflowing")
+        if cells_out is not None and n_out > cells_out.shape[0]:
+            raise _capi.MvsError(_capi.MVS_E_CAPACITY, "%d cells for this shard but capacity is %d" % (n_out, cells_out.shape[0]),
+                                 needed=n_out)
+        out = cells_out if cells_out is not None else ops.new_cells(max(n_out, 1))
+        if n_out:
+            ops.sort_cells(self._own, n_out, out)
+        self._trace("cells sorted")
+        info["exchanged_cells"] = int(heads[rank][0]) if mirror else 0
+        info["blocks"] = len(plan)
+        if cells_out is None:
+            return ops.to_host_cells(out, n_out), n_out, info
+        return out, n_out, info
 
-    def _run_symmetric(self, planes, n_total, n_alloc, d, d_pad, limbs, n2_dev, rb, re, keep_mode, cells_out, info):
-        """every unordered pair of row blocks once + exchange of the mirrored cells (module docstring)"""
-        import torch
-        ops, rank, world = self.ops, self.rank, self.world
-        cap = cells_out.shape[0]
-        # raw / tmp hold what this rank's blocks produce: its own cells AND the mirrored ones on their way to other
-        # ranks (about as many again), so they are sized from the caller's capacity with that in mind and regrown on
-        # demand -- only the final shard has to fit cells_out
-        want = 2 * cap + 1024
-        status, err, n_raw = 0, None, 0
-        plan = block_plan(n_total, world, rank)
-        for attempt in range(3):
-            if self._raw is None or self._raw.shape[0] < want:
-                self._raw, self._tmp = ops.new_cells(want), ops.new_cells(want)
-            raw, tmp = self._raw, self._tmp
-            status, err, n_raw = 0, None, 0
-            sset = ops.open_set(planes, n_total, n_alloc, d, d_pad, limbs)
-            try:
-                for (b0, b1, c0, c1, flags) in plan:
-                    n_raw = ops.compare_block(sset, n2_dev, b0, b1, c0, c1, flags, keep_mode, raw, n_raw)
-            except _capi.MvsError as e:          # tell the others before anybody enters the exchange
-                status, err = e.code, e
-            finally:
-                ops.close_set(sset)
-            needed = getattr(err, "needed", None)
-            if status == _capi.MVS_E_CAPACITY and needed and attempt < 2:
-                want = int(needed) + int(needed) // 4 + 1024      # the library reported the count so far: retry, local to this rank
-                continue
-            break
-        if self._agree(status):
-            raise err if err is not None else _capi.MvsError(_capi.MVS_E_HIP, "another rank failed in its block comparisons")
-        ops.sort_cells(raw, n_raw, tmp)                     # (row, col) order: own rows form one contiguous run
-        rows = tmp[:n_raw, 0].contiguous()
-        lo, hi = torch.searchsorted(rows, torch.tensor([rb, re], dtype=rows.dtype, device=rows.device)).tolist()   # sync 1
-        n_local, n_foreign = hi - lo, n_raw - (hi - lo)     # mirrored cells of rows other ranks own: before lo / after hi
-        max_f = max(self.coll.allreduce_max(n_foreign, rows), 1)
-        # exchange: all-gather of the padded foreign lists; every rank keeps the cells of its own rows
-        recv = torch.full((world * max_f, 4), 2147483647, dtype=tmp.dtype, device=tmp.device)
-        mine = recv[rank * max_f:(rank + 1) * max_f]
-        mine[:lo] = tmp[:lo]
-        mine[lo:n_foreign] = tmp[hi:n_raw]
-        self._exchange(lambda: self.coll.allgather_blocks(recv.view(-1), max_f * 4))
-        wanted = (recv[:, 0] >= rb) & (recv[:, 0] < re)
-        got = recv[wanted]                                  # sync 2: compacted, only the cells of this shard's rows
-        n_out = n_local + got.shape[0]
-        status = _capi.MVS_E_CAPACITY if n_out > cap else 0
-        if self._agree(status):
-            raise _capi.MvsError(_capi.MVS_E_CAPACITY, "%d cells for this shard but capacity is %d" % (n_out, cap))
-        if self._xraw is None or self._xraw.shape[0] < n_out:
-            self._xraw = ops.new_cells(n_out + n_out // 4 + 1024)
-        self._xraw[:n_local] = tmp[lo:hi]
-        self._xraw[n_local:n_out] = got
-        ops.sort_cells(self._xraw, n_out, cells_out)
-        info.update({"blocks": len(plan), "exchanged_cells": int(n_foreign), "schedule": "symmetric"})
-        return cells_out, n_out
+    def _compare(self, st, plan, mirror, keep_mode, first):
+        """the rank's block plan: diagonal block at once, the other blocks per arrived chunk -> device address of the count"""
+        ops, P = self.ops, st["P"]
+        rank = self.rank
+        ops.plan_begin(self._sset, self._n2, rank * P, (rank + 1) * P, mirror, self._raw, keep_mode)
+        self._trace("plan begin")
+        ops.plan_filter(plan[:1])                          # nothing of it comes from another rank
+        self._trace("filter launched: diagonal block")
+        others = plan[1:]
+        if others:
+            pending = st["coarse"] if first else []
+            if first:
+                for h in st["last"][:1]:
+                    h.wait()                               # row statistics + norms of every rank
+            if pending:
+                for (a, b, h) in pending:
+                    h.wait()
+                    blocks = clip_blocks(others, P, a, b)
+                    if blocks:
+                        ops.plan_filter(blocks)
+                        self._trace("filter launched: peers' rows [%d,%d)" % (a, b))
+            else:
+                ops.plan_filter(others)
+            if first:
+                for h in st["last"][1:]:
+                    h.wait()                               # the limb planes: the re-check reads them
+        d_cnt = ops.plan_finish()
+        self._trace("plan finished")
+        return d_cnt

@@ -1,9 +1,11 @@
-"""CPU, world_size 2, gloo: the row-sharded comparison (metagenome_vector_sketches_amd/parallel.py).
+"""CPU, world_size 2-4, gloo: the row-sharded comparison (metagenome_vector_sketches_amd/parallel.py).
 
 The orchestration code is the product's; the numeric back end is replaced by a stand-in built on the
-oracle (tests may use the oracle; the product may not), so what is verified here is the sharding, the
-plane-buffer layout that the all-gather assembles, the padding of an uneven last shard and the norms
-exchange: the union of the ranks' shards must equal the single-process result cell for cell."""
+oracle (tests may use the oracle; the product may not), so what is verified here is the sharding, the storage layout
+the all-gathers assemble (per-rank blocks padded to 256 rows), the block plan of the symmetric schedule, the ORDER of the
+step (a filter launch may only read columns whose coarse rows and statistics have landed; the re-check needs the limb
+planes), the routing / exchange of the mirrored cells with its header protocol (status, largest |v|, overflow), and the
+padding of an uneven last shard: the union of the ranks' shards must equal the single-process result cell for cell."""
 import os
 import sys
 
@@ -18,12 +20,20 @@ sys.path.insert(0, ROOT)
 
 
 class OracleOps:
-    """CPU stand-in for parallel.GpuOps with the same plane layout as the HIP limb-split kernel:
-    planes[(row*limbs + limb)*d_pad + k], signed base-256 digits."""
+    """CPU stand-in for parallel.GpuOps with the same plane layout as the HIP limb-split kernel
+    (planes[(row*limbs + limb)*d_pad + k], signed base-256 digits) and the same call protocol as the block-plan entry
+    points of the C ABI.  prepare_rows() leaves a marker in the coarse / statistics buffers instead of real filter
+    inputs; plan_filter() insists on finding it for every row and column it is asked to compare."""
 
     def __init__(self):
         from oracle import pyoracle
         self.orc = pyoracle
+        self.log = []
+
+    # ---- geometry / buffers ----
+    def layout(self, n_total, world):
+        rps = (n_total + world - 1) // world
+        return rps, max(256, (rps + 255) // 256 * 256)
 
     def max_abs(self, sk):
         return int(np.abs(np.asarray(sk, dtype=np.int64)).max()) if sk.size else 0
@@ -32,12 +42,37 @@ class OracleOps:
         return 1 if m <= 127 else 2 if m <= 32639 else 3 if m <= 8355711 else 4
 
     def limb_geometry(self, n, d, limbs):
-        n_alloc = (n + 127) // 128 * 128 + 128
+        n_alloc = (n + 255) // 256 * 256 + 256
         d_pad = (d + 127) // 128 * 128
         return n_alloc, d_pad, n_alloc * limbs * d_pad
 
     def new_planes(self, nbytes):
         return torch.zeros(nbytes, dtype=torch.int8)
+
+    def new_bytes(self, nbytes):
+        return torch.zeros(nbytes, dtype=torch.uint8)
+
+    def new_cells(self, capacity):
+        return torch.zeros((capacity, 4), dtype=torch.int32)
+
+    def new_counter(self):
+        return torch.zeros(1, dtype=torch.int64)
+
+    def zero_count(self):
+        return [0]
+
+    def zero_(self, t):
+        t.zero_()
+
+    def to_device(self, a):
+        return torch.from_numpy(np.ascontiguousarray(a))
+
+    def to_host_cells(self, cells, n):
+        a = cells[:n].numpy()
+        out = np.zeros(n, dtype=[("row", "<i4"), ("col", "<i4"), ("dot", "<i4"), ("q", "<i4")])
+        for k, name in enumerate(("row", "col", "dot", "q")):
+            out[name] = a[:, k]
+        return out
 
     def limb_split(self, sk, limbs, planes, d_pad, row_offset):
         v = np.asarray(sk, dtype=np.int64).copy()
@@ -48,43 +83,122 @@ class OracleOps:
             view[row_offset:row_offset + n, l, :d] = digit.astype(np.int8)
             v = (v - digit) // 256
 
-    def to_device(self, a):
-        return torch.from_numpy(np.ascontiguousarray(a))
-
-    def _sketches(self, planes, n, d, d_pad, limbs):
-        view = planes.numpy().reshape(-1, limbs, d_pad).astype(np.int64)
-        return sum(view[:n, l, :d] * (256 ** l) for l in range(limbs)).astype(np.int32)
-
-    def compare(self, planes, n, n_alloc, d, d_pad, limbs, norms_sq, rb, re, keep_mode, cells_out):
-        sk = self._sketches(planes, n, d, d_pad, limbs)
-        cells = self.orc.pairwise_rows(sk, norms_sq.numpy(), row_begin=rb, row_end=re, chunk=192, threads=2)
-        order = np.lexsort((cells["col"], cells["row"]))
-        if cells_out is None:
-            return cells[order], len(cells)
-        arr = np.stack([cells[order][k] for k in ("row", "col", "dot", "q")], axis=1).astype(np.int32)
-        cells_out[:len(arr)] = torch.from_numpy(arr)
-        return cells_out, len(arr)
-
-    # ---- block interface of the symmetric schedule ----
-    def new_cells(self, capacity):
-        return torch.empty((capacity, 4), dtype=torch.int32)
-
-    def open_set(self, planes, n, n_alloc, d, d_pad, limbs):
-        return (self._sketches(planes, n, d, d_pad, limbs), n)
+    # ---- sets and their derived data ----
+    def open_set(self, planes, n, n_alloc, d, d_pad, limbs, coarse_fm, stats):
+        return {"planes": planes, "n": n, "n_alloc": n_alloc, "d": d, "d_pad": d_pad, "limbs": limbs, "coarse": coarse_fm,
+                "stats": stats}
 
     def close_set(self, sset):
         pass
 
-    def compare_block(self, sset, norms_sq, rb, re, cb, ce, flags, keep_mode, raw, n_raw):
-        sk, n = sset
-        cells = self.orc.pairwise_rows(sk, norms_sq.numpy(), row_begin=rb, row_end=re, chunk=192, threads=2)
-        cells = cells[(cells["col"] >= cb) & (cells["col"] < ce)]
-        arr = np.stack([cells[k] for k in ("row", "col", "dot", "q")], axis=1).astype(np.int32)
-        if flags & 2:      # MVS_BLOCK_MIRROR_ALL
-            arr = np.concatenate([arr, arr[:, [1, 0, 2, 3]]])
-        arr = arr[np.random.default_rng(n_raw).permutation(len(arr))]      # the device appends in no particular order
-        raw[n_raw:n_raw + len(arr)] = torch.from_numpy(arr)
-        return n_raw + len(arr)
+    def touch_set(self, sset):
+        sset["coarse"].zero_()           # a new step: nothing has landed yet
+        sset["stats"].zero_()
+
+    def prepare_rows(self, sset, first, count):
+        assert first % 16 == 0 and count % 16 == 0
+        d_pad = sset["d_pad"]
+        sset["coarse"][first * d_pad:(first + count) * d_pad] = 1
+        sset["stats"][first * 16:(first + count) * 16] = 7
+
+    def _landed(self, sset, r0, r1):
+        d_pad = sset["d_pad"]
+        c = sset["coarse"].numpy()[r0 * d_pad:r1 * d_pad].reshape(r1 - r0, d_pad)
+        s = sset["stats"].numpy()[r0 * 16:r1 * 16]
+        return bool(np.all(c[:, 0] == 1) and np.all(c[:, -1] == 1) and np.all(s == 7))
+
+    def _sketches(self, sset):
+        planes, n, d, d_pad, limbs = sset["planes"], sset["n"], sset["d"], sset["d_pad"], sset["limbs"]
+        view = planes.numpy().reshape(-1, limbs, d_pad).astype(np.int64)
+        return sum(view[:n, l, :d] * (256 ** l) for l in range(limbs)).astype(np.int32)
+
+    # ---- block plans ----
+    def plan_begin(self, sset, norms_sq, f0, f1, mirror_outside, raw, keep_mode):
+        assert f0 % 256 == 0 and f1 % 256 == 0
+        assert self._landed(sset, f0, f1), "the frame's own rows were not prepared"
+        self.plan = {"sset": sset, "n2": norms_sq, "f0": f0, "f1": f1, "mirror": mirror_outside, "raw": raw, "blocks": []}
+        self.log.append("begin")
+
+    def plan_filter(self, blocks):
+        p = self.plan
+        for (rb, re, cb, ce) in blocks:
+            assert p["f0"] <= rb <= re <= p["f1"] and rb % 256 == 0 and cb % 256 == 0
+            inside = cb >= p["f0"] and ce <= p["f1"]
+            assert inside or ce <= p["f0"] or cb >= p["f1"]
+            assert self._landed(p["sset"], cb, ce), "filter launched on columns [%d,%d) that have not arrived" % (cb, ce)
+            p["blocks"].append((rb, re, cb, ce))
+        self.log.append("filter %d" % len(blocks))
+
+    def plan_finish(self):
+        p = self.plan
+        sset = p["sset"]
+        sk = self._sketches(sset)                       # storage rows (padding rows: zeros)
+        n2 = p["n2"].numpy()[:sset["n"]]
+        out = []
+        for (rb, re, cb, ce) in p["blocks"]:
+            cells = self.orc.pairwise_rows(sk, n2, row_begin=rb, row_end=re, chunk=192, threads=2)
+            cells = cells[(cells["col"] >= cb) & (cells["col"] < ce)]
+            arr = np.stack([cells[k] for k in ("row", "col", "dot", "q")], axis=1).astype(np.int32)
+            inside = cb >= p["f0"] and ce <= p["f1"]
+            if inside:                                  # symmetric schedule: one triangle computed, the other mirrored
+                upper = arr[arr[:, 1] > arr[:, 0]]
+                arr = np.concatenate([arr[arr[:, 1] == arr[:, 0]], upper, upper[:, [1, 0, 2, 3]]])
+            elif p["mirror"]:
+                arr = np.concatenate([arr, arr[:, [1, 0, 2, 3]]])
+            out.append(arr)
+        arr = np.concatenate(out) if out else np.zeros((0, 4), dtype=np.int32)
+        arr = arr[np.random.default_rng(len(arr)).permutation(len(arr))]      # the device appends in no particular order
+        raw = p["raw"]
+        keep = min(len(arr), raw.shape[0])
+        raw[:keep] = torch.from_numpy(arr[:keep])
+        self.log.append("finish")
+        return [len(arr)]                               # the count may exceed the capacity, as on the device
+
+    # ---- kept cells -> shard ----
+    def cells_route(self, raw, d_n_raw, P, rps, n_total, own, own_out, d_own, send, cap_f, status, max_abs):
+        total = int(d_n_raw[0])
+        n = min(total, raw.shape[0])
+        a = raw[:n].numpy().astype(np.int64)
+        br, orow, bc, ocol = a[:, 0] // P, a[:, 0] % P, a[:, 1] // P, a[:, 1] % P
+        row, col = br * rps + orow, bc * rps + ocol
+        valid = (orow < rps) & (ocol < rps) & (row < n_total) & (col < n_total)
+        g = np.stack([row, col, a[:, 2], a[:, 3]], axis=1).astype(np.int32)
+        mine = valid & (row >= own[0]) & (row < own[1])
+        mc = g[mine]
+        keep = min(len(mc), own_out.shape[0])
+        own_out[:keep] = torch.from_numpy(mc[:keep])
+        d_own[0] = len(mc)
+        fc = g[valid & ~mine]
+        hdr = np.zeros(8, dtype=np.int64)
+        hdr[:5] = [len(fc), status, max_abs, total, raw.shape[0]]
+        send[:64] = torch.from_numpy(hdr.view(np.uint8).copy())
+        k = min(len(fc), cap_f)
+        if k:
+            send[64:64 + 16 * k] = torch.from_numpy(np.ascontiguousarray(fc[:k]).view(np.uint8).reshape(-1).copy())
+
+    def cells_collect(self, recv, world, rank, cap_f, own, own_out, d_own):
+        stride = 64 + 16 * cap_f
+        n_own = int(d_own[0])
+        for p in range(world):
+            if p == rank:
+                continue
+            buf = recv[p * stride:(p + 1) * stride].numpy()
+            n = min(int(buf[:8].view(np.int64)[0]), cap_f)
+            cells = buf[64:64 + 16 * n].view(np.int32).reshape(n, 4)
+            got = cells[(cells[:, 0] >= own[0]) & (cells[:, 0] < own[1])]
+            room = max(0, min(len(got), own_out.shape[0] - n_own))
+            if room:
+                own_out[n_own:n_own + room] = torch.from_numpy(got[:room].copy())
+            n_own += len(got)
+        d_own[0] = n_own
+
+    def cells_report(self, recv, world, cap_f, d_own):
+        stride = 64 + 16 * cap_f
+        heads = []
+        for p in range(world):
+            h = recv[p * stride:p * stride + 64].numpy().view(np.int64)
+            heads.append(tuple(int(x) for x in h[:5]))
+        return int(d_own[0]), heads
 
     def sort_cells(self, cells_in, n, cells_out):
         a = cells_in[:n].numpy()
@@ -99,60 +213,79 @@ def _make(n, d, seed):
     return sk, n2
 
 
+def _plain(cells):
+    return np.stack([cells[k] for k in ("row", "col", "dot", "q")], axis=1).astype(np.int32)
+
+
 def _worker(rank, world, port, n, d, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from metagenome_vector_sketches_amd import parallel
+    from metagenome_vector_sketches_amd import parallel, _capi
     from oracle import pyoracle as orc_mod
     sk, n2 = _make(n, d, seed=99)
     b, e = parallel.shard_rows(n, world, rank)
-    sc = parallel.ShardedComparison(OracleOps(), rank, world, dist)
-    cells, cnt, info = sc.run(sk[b:e], n2[b:e], n)          # no output buffer -> plain rows x all-columns schedule
-    cells2, cnt2, _ = sc.run(sk[b:e], n2[b:e], n)          # second step reuses the plane buffer
+    ops = OracleOps()
+    sc = parallel.ShardedComparison(ops, rank, world, dist)
+    assert sc.symmetric
+    cells, cnt, info = sc.run(sk[b:e], n2[b:e], n)          # no output buffer -> the shard comes back as a host array
+    assert info["schedule"] == ("symmetric" if world > 1 else "rows x all columns")
+    # the order of the step: the diagonal block's filter first, then one launch per arrived chunk, then the rest
+    assert ops.log[0] == "begin" and ops.log[1] == "filter 1" and ops.log[-1] == "finish"
+    if len(parallel.block_plan(world, rank, ops.layout(n, world)[1])) > 1:
+        assert len([x for x in ops.log if x.startswith("filter")]) >= 2
+    cells2, cnt2, _ = sc.run(sk[b:e], n2[b:e], n)           # second step reuses the gathered buffers
     assert cnt == cnt2 and np.array_equal(cells, cells2)
     np.save(os.path.join(out_dir, "cells_%d.npy" % rank), cells)
-    # symmetric schedule: every unordered block pair once + exchange of the mirrored cells
+    plain = _plain(cells)
+    # into a caller's buffer; the plain rows x all-columns schedule (no mirroring, no cell exchange) gives the same shard
     out = torch.empty((n * n, 4), dtype=torch.int32)
     _, cnt3, info3 = sc.run(sk[b:e], n2[b:e], n, cells_out=out)
-    assert info3.get("schedule") == "symmetric"
-    plain = np.stack([cells[k] for k in ("row", "col", "dot", "q")], axis=1).astype(np.int32)
     assert cnt3 == cnt and np.array_equal(out[:cnt3].numpy(), plain), (rank, cnt3, cnt)
+    sc_rows = parallel.ShardedComparison(OracleOps(), rank, world, dist)
+    sc_rows.symmetric = False
+    _, cnt3b, info3b = sc_rows.run(sk[b:e], n2[b:e], n, cells_out=out)
+    assert info3b["schedule"] == "rows x all columns" and info3b["exchanged_cells"] == 0
+    assert cnt3b == cnt and np.array_equal(out[:cnt3b].numpy(), plain)
     # local rows arriving in parts (begin / feed / finish): the exchange of a part starts when it is fed; same cells
     local, n2l = torch.from_numpy(sk[b:e].copy()), n2[b:e]
     sc.begin(local, n2l, n)
     bounds = sc.part_bounds(n, 3)
-    assert bounds[0][0] == 0 and bounds[-1][1] == (n + world - 1) // world and len(bounds) in (2, 3)
-    for (p0, p1) in bounds:                                  # block coordinates: the same on every rank
+    assert bounds[0][0] == 0 and bounds[-1][1] == ops.layout(n, world)[1]
+    for (p0, p1) in bounds:                                  # storage rows of the block: the same on every rank
         q0, q1 = min(p0, e - b), min(p1, e - b)
         sc.feed(p0, p1, int(np.abs(sk[b + q0:b + q1]).max()) if q1 > q0 else 0)
     _, cnt4, info4 = sc.finish(cells_out=out)
-    assert cnt4 == cnt and np.array_equal(out[:cnt4].numpy(), plain) and info4["overlap"].startswith("exchange of a part")
-    # a limb guess that does not hold on ONE rank only: every rank falls back to the plain exchange, same cells
+    assert cnt4 == cnt and np.array_equal(out[:cnt4].numpy(), plain)
+    # a limb guess that does not hold on ONE rank only: every rank learns it from the exchange's headers and redoes the step
     sc.begin(local, n2l, n, limbs_guess=1)
-    sc.feed(0, (n + world - 1) // world, int(np.abs(sk[b:e]).max()) if rank == world - 1 else 1)
+    sc.feed(0, ops.layout(n, world)[1], int(np.abs(sk[b:e]).max()) if rank == world - 1 else 1)
     _, cnt5, info5 = sc.finish(cells_out=out)
-    assert cnt5 == cnt and np.array_equal(out[:cnt5].numpy(), plain) and "did not hold" in info5["overlap"]
-    # a guess that is too LARGE is no reason to redo anything: one-limb data (max |v| <= 127) coded with the default guess
-    # of two limbs keeps the overlapped exchange -- same cells as the plain run, which picks one limb
+    assert cnt5 == cnt and np.array_equal(out[:cnt5].numpy(), plain)
+    assert "did not hold" in info5["overlap"] or world == 1 and rank != world - 1, info5
+    # a guess that is too LARGE is no reason to redo anything: one-limb data (max |v| <= 127) coded with two limbs is exact
     small = np.clip(sk, -100, 100).astype(np.int32)
     n2s = np.array([orc_mod.norm_sq_from_text(orc_mod.format_norm(orc_mod.norm(r))) for r in small])
     out_s = torch.empty((n * n, 4), dtype=torch.int32)
-    _, cnt_s, info_s = sc.run(small[b:e], n2s[b:e], n, cells_out=out_s)
+    _, cnt_s, info_s = sc.run(small[b:e], n2s[b:e], n, cells_out=out_s, limbs_guess=1)
     want_s = out_s[:cnt_s].numpy().copy()
     assert info_s["limbs"] == 1
-    sc.begin(torch.from_numpy(small[b:e].copy()), n2s[b:e], n)
-    for (p0, p1) in bounds:
-        q0, q1 = min(p0, e - b), min(p1, e - b)
-        sc.feed(p0, p1, int(np.abs(small[b + q0:b + q1]).max()) if q1 > q0 else 0)
-    _, cnt_s2, info_s2 = sc.finish(cells_out=out_s)
-    assert info_s2["limbs"] == 2 and info_s2["overlap"].startswith("exchange of a part"), info_s2
+    _, cnt_s2, info_s2 = sc.run(small[b:e], n2s[b:e], n, cells_out=out_s)
+    assert info_s2["limbs"] == 2 and "did not hold" not in info_s2["overlap"], info_s2
     assert cnt_s2 == cnt_s and np.array_equal(out_s[:cnt_s2].numpy(), want_s)
-    # an output buffer that holds exactly this shard (the mirrored cells in flight live in internal buffers)
-    tight = torch.empty((cnt, 4), dtype=torch.int32)
-    _, cnt6, _ = sc.run(sk[b:e], n2[b:e], n, cells_out=tight)
-    assert cnt6 == cnt and np.array_equal(tight.numpy(), plain)
-    # a second, larger problem that pads to the same plane geometry: the gathered-norm buffer follows the row count
+    # an output buffer that holds exactly this shard: the raw list and the exchange buffers start too small for the mirrored
+    # cells in flight and are regrown from what the headers report (every rank goes through the same retries)
+    sc_tight = parallel.ShardedComparison(OracleOps(), rank, world, dist)
+    sc_tight._cap_f = 4
+    tight = torch.empty((max(cnt, 1), 4), dtype=torch.int32)
+    _, cnt6, _ = sc_tight.run(sk[b:e], n2[b:e], n, cells_out=tight)
+    assert cnt6 == cnt and np.array_equal(tight[:cnt].numpy(), plain)
+    # a buffer that cannot hold the shard: MVS_E_CAPACITY with the number of cells there are
+    if cnt > 1:
+        with pytest.raises(_capi.MvsError) as ei:
+            sc_tight.run(sk[b:e], n2[b:e], n, cells_out=torch.empty((cnt - 1, 4), dtype=torch.int32))
+        assert ei.value.code == _capi.MVS_E_CAPACITY and ei.value.needed == cnt
+    # a second, larger problem: other geometry, other buffers
     n_big = n + 3
     sk2, n22 = _make(n_big, d, seed=99)
     b2, e2 = parallel.shard_rows(n_big, world, rank)
@@ -165,22 +298,36 @@ def _worker(rank, world, port, n, d, out_dir):
 def test_block_plan_covers_every_pair_once():
     from metagenome_vector_sketches_amd import parallel
     for world in (1, 2, 3, 4, 5, 8):
-        for n in (1, 7, 64, 101):
-            seen = np.zeros((n, n), dtype=np.int32)
+        for P in (256, 512, 768, 1280):
+            t = P // 256                                     # in units of tiles
+            seen = np.zeros((world * t, world * t), dtype=np.int32)
             for rank in range(world):
-                for (rb, re, cb, ce, flags) in parallel.block_plan(n, world, rank):
-                    seen[rb:re, cb:ce] += 1
-                    if flags & 2:                      # mirrored into the transposed block
-                        seen[cb:ce, rb:re] += 1
-                    assert parallel.shard_rows(n, world, rank)[0] <= rb and re <= parallel.shard_rows(n, world, rank)[1]
-            assert np.all(seen == 1), (world, n)
-    # per-rank work is balanced: G/2 blocks each (even G)
-    work = [sum((re - rb) * (ce - cb) * (0.5 if f & 1 else 1.0) for rb, re, cb, ce, f in parallel.block_plan(8000, 8, r))
+                plan = parallel.block_plan(world, rank, P)
+                assert plan[0] == (rank * P, (rank + 1) * P, rank * P, (rank + 1) * P)     # the diagonal block comes first
+                for k, (rb, re, cb, ce) in enumerate(plan):
+                    assert rank * P <= rb <= re <= (rank + 1) * P and all(x % 256 == 0 for x in (rb, re, cb, ce))
+                    seen[rb // 256:re // 256, cb // 256:ce // 256] += 1
+                    if k > 0:                                # mirrored into the transposed block
+                        seen[cb // 256:ce // 256, rb // 256:re // 256] += 1
+            assert np.all(seen == 1), (world, P)
+            # the plain schedule: every rank its rows against everything, nothing mirrored
+            seen[:] = 0
+            for rank in range(world):
+                for (rb, re, cb, ce) in parallel.block_plan(world, rank, P, symmetric=False):
+                    seen[rb // 256:re // 256, cb // 256:ce // 256] += 1
+            assert np.all(seen == 1)
+    # per-rank work is balanced: G/2 blocks each (even G, an even number of tile rows)
+    work = [sum((re - rb) * (ce - cb) * (0.5 if k == 0 else 1.0) for k, (rb, re, cb, ce) in enumerate(parallel.block_plan(8, r, 1024)))
             for r in range(8)]
-    assert max(work) == min(work) == 4 * 1000 * 1000
+    assert max(work) == min(work) == 4 * 1024 * 1024
+    # chunks: multiples of 256, in order, covering the block; clipping keeps the rows and cuts the columns per rank block
+    assert parallel.chunk_bounds(1280, 2) == [(0, 512), (512, 1280)] and parallel.chunk_bounds(256, 4) == [(0, 256)]
+    plan = parallel.block_plan(4, 3, 512)
+    got = parallel.clip_blocks(plan[1:], 512, 256, 512)
+    assert got == [(1536, 2048, 256, 512), (1536, 2048, 768, 1024)]      # rank 0's block, second half of rank 1's
 
 
-@pytest.mark.parametrize("n,world", [(96, 2), (101, 2), (101, 3), (130, 4)])   # uneven last shards -> padded blocks
+@pytest.mark.parametrize("n,world", [(96, 2), (101, 2), (101, 3), (130, 4), (700, 2)])   # uneven last shards -> padded blocks
 def test_multi_rank_shards_equal_single_process(tmp_path, n, world):
     d, port = 256, 29500 + (os.getpid() + n + world) % 2000
     mp.spawn(_worker, args=(world, port, n, d, str(tmp_path)), nprocs=world, join=True)
@@ -201,6 +348,19 @@ def test_multi_rank_shards_equal_single_process(tmp_path, n, world):
     want2 = want2[np.lexsort((want2["col"], want2["row"]))]
     got2 = np.concatenate([np.load(os.path.join(str(tmp_path), "cells_big_%d.npy" % r)) for r in range(world)])
     assert np.array_equal(got2, want2)
+
+
+def test_single_rank_goes_through_the_same_step():
+    """world 1: no collectives, the same plan / route / report path"""
+    from metagenome_vector_sketches_amd import parallel
+    from oracle import pyoracle as orc
+    n, d = 300, 128
+    sk, n2 = _make(n, d, seed=5)
+    sc = parallel.ShardedComparison(OracleOps(), 0, 1)
+    cells, cnt, info = sc.run(sk, n2, n)
+    want = orc.pairwise_rows(sk, n2, chunk=192)
+    want = want[np.lexsort((want["col"], want["row"]))]
+    assert cnt == len(want) and np.array_equal(cells, want) and info["collectives"] == "none"
 
 
 def test_shard_rows_matches_reference_formula():

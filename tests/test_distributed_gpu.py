@@ -107,7 +107,7 @@ def _native_worker(rank, world, n, d, out_dir):
             sc.feed(p0, p1, int(local[q0:q1].abs().max()) if q1 > q0 else 0)
         _, cnt, info = sc.finish(cells_out=out)
         torch.cuda.synchronize()
-        assert info["overlap"].startswith("exchange of a part")
+        assert "exchange of a part" in info["overlap"]
         np.save(os.path.join(out_dir, "ncells_p%d_%d.npy" % (parts, rank)), out[:cnt].cpu().numpy())
     comm2.close()
     ctx2.close()
@@ -229,7 +229,9 @@ def test_bare_bench_gpus2_launches_itself():
     assert d["config"]["total_samples"] == 4000 and d["config"]["schedule"] == "symmetric"
     assert d["config"]["comm_world"] == 2 and d["config"]["rccl_ranks"] == 0      # rehearsal: file transport, not RCCL
     assert d["config"]["kept_cells"] >= 4000 * 10
-    assert d["stages"]["allgather_bytes_per_rank"] == 2000 * 2 * 2048 and d["stages"]["allgather_ms"] > 0
+    # per rank: a block of 2048 storage rows (2000 samples padded to the tile grid) x (two limb planes + the coarse plane)
+    # x 2048 bytes, + 24 bytes of statistics and norm per row
+    assert d["stages"]["allgather_bytes_per_rank"] == 2048 * 3 * 2048 + 2048 * 24 and d["stages"]["allgather_ms"] > 0
 
 
 def test_bare_bench_gpus2_config4_launches_itself():

@@ -1,0 +1,210 @@
+"""GPU: block plans (include/mvs_hip.h "block plans") -- a rank's share of the symmetric multi-rank schedule as one
+two-stage comparison in storage coordinates.  All G ranks of a split are played by ONE process on the one card: the
+storage buffers hold every rank's block (what the all-gathers would have assembled), each rank's plan runs in turn, its
+kept cells are routed, the mirrored ones are handed to their owners through the same send-buffer format the exchange uses.
+The union must equal mvs_pairwise_rows / the oracle cell for cell (src/pairwise_comp_optimized.cpp:135-147, :654-665)."""
+import numpy as np
+import pytest
+import torch
+
+from metagenome_vector_sketches_amd import _capi, parallel, synth
+from oracle import pyoracle as orc
+
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("restore_options")]
+DEV = "cuda:0"
+
+
+@pytest.fixture(autouse=True)
+def _on_torchs_stream(ctx):
+    """the buffers here are torch tensors: the library must issue its kernels on the stream torch fills and reads them on"""
+    ctx.set_stream(torch.cuda.current_stream())
+    yield
+    torch.cuda.synchronize()
+    ctx.set_stream(None)
+
+
+def _n2(sk):
+    return np.array([orc.norm_sq_from_text(orc.format_norm(orc.norm(row))) for row in sk.astype(np.int32)])
+
+
+def _want(sk, n2, keep_mode):
+    cells = orc.pairwise_rows(sk, n2, chunk=192, threads=8) if keep_mode == _capi.KEEP_INT32 else None
+    if cells is None:
+        pytest.skip("oracle keep mode")
+    cells = cells[np.lexsort((cells["col"], cells["row"]))]
+    return np.stack([cells[k] for k in ("row", "col", "dot", "q")], axis=1).astype(np.int32)
+
+
+class Split:
+    """storage buffers of a G-way split on one device, filled for ALL ranks"""
+
+    def __init__(self, ctx, sk, n2, world, limbs=2):
+        self.ctx, self.world = ctx, world
+        n, d = sk.shape
+        self.n, self.d = n, d
+        self.rps, self.P = _capi.shard_layout(n, world)
+        n_st = self.P * world
+        self.n_alloc, self.d_pad, nbytes = ctx.limb_geometry(n_st, d, limbs)
+        self.planes = torch.zeros(nbytes, dtype=torch.int8, device=DEV)
+        self.coarse = torch.zeros(self.n_alloc * self.d_pad, dtype=torch.uint8, device=DEV)
+        self.stats = torch.zeros(self.n_alloc * 16, dtype=torch.uint8, device=DEV)
+        self.n2 = torch.zeros(self.n_alloc, dtype=torch.float64, device=DEV)
+        self.sset = ctx.sketch_set_from_planes(self.planes, n_st, self.n_alloc, d, self.d_pad, limbs)
+        ctx.attach_derived(self.sset, self.coarse, self.stats)
+        for r in range(world):
+            b, e = parallel.shard_rows(n, world, r)
+            if e > b:
+                ctx.limb_split(torch.from_numpy(sk[b:e].copy()).to(DEV), limbs, self.planes, self.d_pad, r * self.P)
+                self.n2[r * self.P:r * self.P + (e - b)] = torch.from_numpy(n2[b:e].copy()).to(DEV)
+            ctx.prepare_rows(self.sset, r * self.P, self.P)
+
+    def rank_cells(self, rank, symmetric=True, chunks=1, keep_mode=_capi.KEEP_INT32, cap=None, cap_f=None):
+        """-> (own cells [k, 4] in sample indices, the send buffer as the exchange would carry it, plan statistics)"""
+        ctx, P, world = self.ctx, self.P, self.world
+        cap = cap or max(4096, 80 * self.n)
+        raw = torch.empty((2 * cap, 4), dtype=torch.int32, device=DEV)
+        own = torch.empty((cap, 4), dtype=torch.int32, device=DEV)
+        d_own = torch.zeros(1, dtype=torch.int64, device=DEV)
+        plan = parallel.block_plan(world, rank, P, symmetric=symmetric)
+        mirror = symmetric and world > 1
+        ctx.plan_begin(self.sset, self.n2, rank * P, (rank + 1) * P, mirror, raw, keep_mode=keep_mode)
+        ctx.plan_filter(plan[:1])
+        for (c0, c1) in parallel.chunk_bounds(P, chunks):
+            blocks = parallel.clip_blocks(plan[1:], P, c0, c1)
+            if blocks:
+                ctx.plan_filter(blocks)
+        d_cnt = ctx.plan_finish()
+        cap_f = cap if cap_f is None else cap_f
+        send = torch.zeros(_capi.CELLS_HEADER_BYTES + 16 * cap_f, dtype=torch.uint8, device=DEV)
+        b, e = parallel.shard_rows(self.n, world, rank)
+        ctx.cells_route(raw, d_cnt, P, self.rps, self.n, b, e, own, d_own, send, cap_f, status=0, max_abs=123 + rank)
+        n_own, heads = ctx.cells_report(send, 1, cap_f, d_own)
+        assert heads[0][1] == 0 and heads[0][2] == 123 + rank and heads[0][3] <= heads[0][4]
+        return own[:n_own].cpu().numpy(), send, ctx.plan_stats(), heads[0]
+
+
+def _union(split, symmetric=True, chunks=1, keep_mode=_capi.KEEP_INT32):
+    """every rank's shard = its own cells + what the other ranks' send buffers hold for its rows (mvs_cells_collect)"""
+    ctx, world = split.ctx, split.world
+    per_rank = [split.rank_cells(r, symmetric, chunks, keep_mode) for r in range(world)]
+    cap_f = (per_rank[0][1].numel() - _capi.CELLS_HEADER_BYTES) // 16
+    recv = torch.cat([x[1] for x in per_rank])
+    shards = []
+    for r in range(world):
+        b, e = parallel.shard_rows(split.n, world, r)
+        own_np = per_rank[r][0]
+        own = torch.empty((len(own_np) + int(sum(h[3][0] for h in per_rank)) + 1, 4), dtype=torch.int32, device=DEV)
+        own[:len(own_np)] = torch.from_numpy(own_np).to(DEV)
+        d_own = torch.tensor([len(own_np)], dtype=torch.int64, device=DEV)
+        ctx.cells_collect(recv, world, r, cap_f, b, e, own, d_own)
+        n_out, heads = ctx.cells_report(recv, world, cap_f, d_own)
+        assert [h[2] for h in heads] == [123 + k for k in range(world)]
+        got = own[:n_out].cpu().numpy()
+        assert np.all((got[:, 0] >= b) & (got[:, 0] < e))
+        out = torch.empty((max(n_out, 1), 4), dtype=torch.int32, device=DEV)
+        if n_out:
+            ctx.cells_sort(own, n_out, out)
+        shards.append(out[:n_out].cpu().numpy())
+    return np.concatenate(shards), per_rank
+
+
+@pytest.mark.parametrize("n,d,world", [(700, 512, 1), (700, 512, 2), (1300, 256, 3), (2100, 256, 4), (2100, 128, 8),
+                                       (5000, 256, 5), (3000, 2048, 4)])
+@pytest.mark.parametrize("mode", ["two_stage", "exact"])
+def test_plans_of_all_ranks_give_the_whole_matrix(ctx, n, d, world, mode):
+    ctx.set_option("pairwise_filter", 2 if mode == "two_stage" else 0)
+    sk = synth.make_sketches_numpy(n, d, 3000, seed=n + world, cluster=8)
+    n2 = _n2(sk)
+    want = _want(sk, n2, _capi.KEEP_INT32)
+    split = Split(ctx, sk, n2, world)
+    got, per_rank = _union(split, symmetric=True, chunks=1)
+    assert len(want) > 4 * n and np.array_equal(got, want)
+    st = per_rank[0][2]
+    assert st["exact_mode"] == (mode == "exact")
+    if mode == "two_stage":
+        assert st["filter_launches"] >= 1 and st["filter_tiles"] > 0 and st["candidates"] > 0
+    # the peers' columns arriving in chunks (one filter launch per chunk), and the plain rows x all-columns schedule
+    got2, _ = _union(split, symmetric=True, chunks=3)
+    assert np.array_equal(got2, want)
+    got3, per3 = _union(split, symmetric=False, chunks=2)
+    assert np.array_equal(got3, want)
+    assert all(x[3][0] == 0 for x in per3)                       # nothing to send anywhere
+
+
+def test_plan_on_dense_clusters_goes_through_flagged_tiles(ctx):
+    """clusters of 600 related samples: whole 256 x 256 tiles are dense, on the diagonal blocks AND in the peers' blocks --
+    those tiles go to the exact kernel (flagged), the rest through the re-check; mirror rules inside / outside the square"""
+    n, d, world = 2600, 256, 4
+    sk = synth.make_sketches_numpy(n, d, 3000, seed=77, cluster=600)
+    n2 = _n2(sk)
+    want = _want(sk, n2, _capi.KEEP_INT32)
+    assert len(want) > 100 * n
+    ctx.set_option("pairwise_filter", 2)
+    split = Split(ctx, sk, n2, world)
+    got, per_rank = _union(split)
+    assert sum(x[2]["flagged_tiles"] for x in per_rank) > world       # off-diagonal tiles too
+    assert np.array_equal(got, want)
+    ctx.set_option("tile_dense_thr", 0)                               # nothing is flagged: every candidate re-checked
+    got2, per2 = _union(split)
+    assert sum(x[2]["flagged_tiles"] for x in per2) == 0 and np.array_equal(got2, want)
+
+
+def test_plan_int16_keep_mode_and_overflow_reporting(ctx):
+    n, d, world = 900, 256, 2
+    sk = synth.make_sketches_numpy(n, d, 3000, seed=5, cluster=8)
+    n2 = _n2(sk)
+    ctx.set_option("pairwise_filter", 2)
+    split = Split(ctx, sk, n2, world)
+    # the floating keep test of the int16 path (src/pairwise_comp_optimized_16bits.cpp:218) against mvs_pairwise_rows
+    plain = ctx.sketch_set(sk)
+    ref, cnt = ctx.pairwise_rows(plain, n2, keep_mode=_capi.KEEP_INT16)
+    plain.close()
+    ref = ref[np.lexsort((ref["col"], ref["row"]))]
+    want = np.stack([ref[k] for k in ("row", "col", "dot", "q")], axis=1).astype(np.int32)
+    got, _ = _union(split, keep_mode=_capi.KEEP_INT16)
+    assert np.array_equal(got, want)
+    # a raw list and a send buffer that are too small: nothing is written out of bounds, the header says how much there was
+    own, send, st, head = split.rank_cells(0, cap=64, cap_f=16)
+    assert head[3] > head[4] == 128                                    # raw cells > raw capacity
+    own, send, st, head = split.rank_cells(0, cap_f=16)
+    assert head[0] > 16 and head[3] <= head[4]                         # more mirror images than the buffer holds
+
+
+def test_plan_rejects_what_it_cannot_run(ctx):
+    n, d = 600, 128
+    sk = synth.make_sketches_numpy(n, d, 3000, seed=1, cluster=8)
+    split = Split(ctx, sk, _n2(sk), 2)
+    ctx.set_option("pairwise_filter", 2)
+    raw = torch.empty((1024, 4), dtype=torch.int32, device=DEV)
+    with pytest.raises(_capi.MvsError):
+        ctx.plan_filter([(0, 256, 0, 256)])                            # no plan in progress
+    ctx.plan_begin(split.sset, split.n2, 0, split.P, True, raw)
+    with pytest.raises(_capi.MvsError):
+        ctx.plan_filter([(0, split.P, 128, split.P)])                  # not on the tile grid
+    with pytest.raises(_capi.MvsError):
+        ctx.plan_filter([(split.P, 2 * split.P, 0, split.P)])          # rows outside the frame
+    with pytest.raises(_capi.MvsError):
+        ctx.plan_filter([(0, split.P, 0, 2 * split.P)])                # columns straddle the frame's square
+    ctx.plan_filter([(0, split.P, 0, split.P)])
+    ctx.plan_finish()
+    with pytest.raises(_capi.MvsError):
+        ctx.plan_finish()
+
+
+def test_sharded_comparison_single_rank_equals_pairwise_rows(ctx):
+    """world 1 through parallel.ShardedComparison (what `bench.py --config 3 --gpus 1` times) against mvs_pairwise_rows"""
+    n, d = 6000, 512
+    sk = synth.make_sketches_numpy(n, d, 3000, seed=11, cluster=16)
+    n2 = _n2(sk)
+    plain = ctx.sketch_set(sk)
+    ref, cnt = ctx.pairwise_rows(plain, n2)
+    plain.close()
+    want = np.stack([ref[k] for k in ("row", "col", "dot", "q")], axis=1).astype(np.int32)
+    sc = parallel.ShardedComparison(parallel.GpuOps(ctx, torch.device(DEV)), 0, 1)
+    out = torch.empty((cnt + 10, 4), dtype=torch.int32, device=DEV)
+    for _ in range(2):
+        _, got_n, info = sc.run(torch.from_numpy(sk).to(DEV), n2, n, cells_out=out)
+        torch.cuda.synchronize()
+        assert got_n == cnt and np.array_equal(out[:cnt].cpu().numpy(), want)
+    host, got_n, _ = sc.run(torch.from_numpy(sk).to(DEV), n2, n)
+    assert got_n == cnt and np.array_equal(host, ref[np.lexsort((ref["col"], ref["row"]))])
