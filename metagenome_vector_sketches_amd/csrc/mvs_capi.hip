@@ -134,6 +134,9 @@ struct mvs_sketch_set {
     // mvs_sketch_set_attach_derived: the filter's inputs in caller buffers (block plans), NULL otherwise
     int8_t* ext_coarse_fm = nullptr;
     mvs::CoarseRow* ext_rows = nullptr;
+    // rows rewritten (mvs_sketch_set_fill) since the context's derived data of this set was built: refreshed row by row on
+    // the next comparison instead of rebuilding everything (a search appends a handful of query rows to a resident database)
+    int64_t dirty_lo = 0, dirty_hi = 0;
 };
 
 static void plan_state_free(mvs_ctx* c);   // defined with PlanState (block plans, near the end of this file)
@@ -1098,13 +1101,37 @@ int mvs_sketch_set_alloc(mvs_ctx* c, int64_t n, int d, int limbs, mvs_sketch_set
     return MVS_OK;
 }
 
+namespace {
+// Rows [lo, hi) of an owned set are about to be rewritten.  If the context holds data derived from the set's present
+// contents (coarse plane, fragment-major copies) and the range is a small part of it, the set keeps its generation and
+// remembers the range: refresh_derived() re-derives just those rows before the next comparison.  A search front end
+// that appends its queries behind a resident database (search.py: SearchIndex) thus keeps the database's coarse plane --
+// bumping the generation made every search rebuild it (6 ms per 10^6 sketches) or fall back to the exact kernels.
+void note_rows_rewritten(mvs_sketch_set* s, int64_t lo, int64_t hi) {
+    mvs_ctx* c = s->ctx;
+    // (the "a block of few rows went to the exact kernel for lack of a coarse plane" marker counts as well: it is what makes
+    // the SECOND such block build the plane, and it must survive the upload of that block's rows)
+    const bool cached = (c->coarse_id == s->id && c->coarse_gen == s->gen) || (c->planes_fm_id == s->id && c->planes_fm_gen == s->gen) ||
+                        (c->few_rows_id == s->id && c->few_rows_gen == s->gen);
+    const int64_t u_lo = s->dirty_hi > s->dirty_lo ? std::min(s->dirty_lo, lo) : lo;
+    const int64_t u_hi = s->dirty_hi > s->dirty_lo ? std::max(s->dirty_hi, hi) : hi;
+    if (cached && (u_hi - u_lo) * 8 <= s->n) {
+        s->dirty_lo = u_lo;
+        s->dirty_hi = u_hi;
+        return;
+    }
+    ++s->gen;   // derived data of the old contents is stale as a whole
+    s->dirty_lo = s->dirty_hi = 0;
+}
+}  // namespace
+
 int mvs_sketch_set_fill(mvs_sketch_set* s, const void* sketches, int elem_bytes, int mem, int64_t row_offset,
                         int64_t n_rows) {
     if (!s || !s->owned) return fail(MVS_E_INVALID, "set is NULL or not owned by the library");
     if (row_offset < 0 || n_rows < 0 || row_offset + n_rows > s->n)
         return fail(MVS_E_INVALID, "rows [%lld,%lld) outside the set", (long long)row_offset,
                     (long long)(row_offset + n_rows));
-    ++s->gen;   // derived data (coarse plane) of the old contents is stale
+    if (n_rows > 0) note_rows_rewritten(s, row_offset, row_offset + n_rows);
     return mvs_limb_split(s->ctx, sketches, elem_bytes, mem, n_rows, s->d, s->limbs, s->owned, s->d_pad, row_offset);
 }
 
@@ -1129,7 +1156,7 @@ int mvs_sketch_set_fill_stats(mvs_sketch_set* s, const void* sketches, int elem_
         HIP_TRY(hipMemcpyAsync(c->stage, sketches, bytes, hipMemcpyHostToDevice, c->stream));
         d_in = c->stage;
     }
-    ++s->gen;
+    note_rows_rewritten(s, row_offset, row_offset + n_rows);
     HIP_TRY(hipMemsetAsync(c->d_counter, 0, 8, c->stream));
     mvs::launch_max_abs(c->stream, d_in, elem_bytes, n_rows * s->d, c->d_counter);
     int rc = check_kernel("k_max_abs");
@@ -1164,6 +1191,7 @@ int mvs_sketch_set_planes(mvs_sketch_set* s, int8_t** planes) {
 int mvs_sketch_set_touch(mvs_sketch_set* s) {
     if (!s) return fail(MVS_E_INVALID, "set is NULL");
     ++s->gen;
+    s->dirty_lo = s->dirty_hi = 0;
     return MVS_OK;
 }
 
@@ -1180,8 +1208,43 @@ int mvs_sketch_set_destroy(mvs_sketch_set* s) {
 
 namespace {
 
+// the rows of `s` that were rewritten since the context's derived data was built (note_rows_rewritten): re-derive exactly
+// those rows in every cache that belongs to the set's present generation, coarse plane first (its fragment-major copy is
+// made from it).  The fragment-major layouts hold 16 rows per KiB, so the range is widened to whole groups of 16.
+int refresh_derived(mvs_ctx* c, const mvs_sketch_set* cs) {
+    mvs_sketch_set* s = const_cast<mvs_sketch_set*>(cs);
+    if (s->dirty_hi <= s->dirty_lo) return MVS_OK;
+    const int64_t lo = s->dirty_lo & ~(int64_t)15, hi = std::min<int64_t>(s->n_alloc, (s->dirty_hi + 15) & ~(int64_t)15);
+    const int64_t count = hi - lo, dp = s->d_pad;
+    s->dirty_lo = s->dirty_hi = 0;
+    if (s->limbs == 2 && c->coarse_id == s->id && c->coarse_gen == s->gen) {
+        if (c->coarse_mode != c->opt.coarse_radix) {
+            c->coarse_id = 0;                                  // another radix rule was asked for: rebuilt as a whole anyway
+        } else {
+            const int64_t valid = std::max<int64_t>(0, std::min<int64_t>(count, s->n - lo));
+            mvs::launch_coarse_build(c->stream, s->planes + lo * 2 * dp, valid, count, s->d_pad, (int8_t*)c->pw_coarse + lo * dp,
+                                     (mvs::CoarseRow*)c->pw_rows + lo, c->opt.coarse_radix);
+            int rc = check_kernel("k_coarse_build(rows)");
+            if (rc) return rc;
+            if (c->coarse_fm_valid) {
+                mvs::launch_coarse_fm(c->stream, (const int8_t*)c->pw_coarse + lo * dp, count, s->d_pad, (int8_t*)c->pw_coarse_fm + lo * dp);
+                rc = check_kernel("k_coarse_fm(rows)");
+                if (rc) return rc;
+            }
+        }
+    }
+    if (s->limbs == 2 && c->planes_fm_id == s->id && c->planes_fm_gen == s->gen) {
+        mvs::launch_coarse_fm(c->stream, s->planes + lo * 2 * dp, count, s->d_pad, (int8_t*)c->pw_planes_fm + lo * 2 * dp, 2);
+        const int rc = check_kernel("k_coarse_fm(limb planes, rows)");
+        if (rc) return rc;
+    }
+    return MVS_OK;
+}
+
 // coarse plane + row statistics of `s`, cached in the context until the set (or its contents) changes
 int prepare_coarse(mvs_ctx* c, const mvs_sketch_set* s) {
+    const int rr = refresh_derived(c, s);
+    if (rr) return rr;
     if (c->coarse_id == s->id && c->coarse_gen == s->gen && c->coarse_mode == c->opt.coarse_radix) return MVS_OK;
     c->coarse_id = 0;
     c->coarse_fm_valid = false;
@@ -1216,6 +1279,8 @@ int prepare_coarse_fm(mvs_ctx* c, const mvs_sketch_set* s) {
 // a.planes_fm is set when the exact kernel that reads it will run for this block
 int attach_planes_fm(mvs_ctx* c, const mvs_sketch_set* s, mvs::PairwiseArgs& a, bool wanted) {
     a.planes_fm = nullptr;
+    const int rr = refresh_derived(c, s);
+    if (rr) return rr;
     if (!wanted || !c->opt.fragment_major || s->limbs != 2) return MVS_OK;
     if (!(c->planes_fm_id == s->id && c->planes_fm_gen == s->gen)) {
         c->planes_fm_id = 0;

@@ -190,3 +190,47 @@ def test_streaming_search_filter_equals_exact_kernel(ctx, d, n_db):
         for keep in (_capi.KEEP_INT32, _capi.KEEP_INT16):
             run(lambda: ctx.pairwise_block(ss, n2_t, n_db, n_db + 300, 0, n_db, flags, cells, 0, keep_mode=keep))
     ss.close()
+
+
+def test_resident_index_keeps_its_coarse_plane_across_searches(tmp_path):
+    """every search uploads NEW query sketches into the scratch rows behind the database.  That must not throw
+    away what the context derived from the database rows: from the second search on the first stage is the streaming
+    filter on the cached coarse plane (pairwise_candidates() > 0), only the query rows are re-derived, and the answers
+    stay those of the exact kernel (a fresh index with the filter switched off)."""
+    from metagenome_vector_sketches_amd import Context, search, synth
+    n, d = 9000, 1024
+    rng = np.random.default_rng(42)
+    hashes, offsets = synth.make_csr_numpy(n, 400, seed=3, cluster=10, shared=0.5)
+    ctx = Context(0)
+    sk = ctx.project_csr(hashes, offsets, d)
+    db = str(tmp_path / "db") + "/"
+    os.makedirs(db)
+    sk.astype("<i4").tofile(db + "vectors.bin")
+    norms = np.sqrt((sk.astype(np.float64) ** 2).sum(axis=1) / d)
+    open(db + "vector_norms.txt", "w").write("".join("s%d %g\n" % (i, x) for i, x in enumerate(norms)))
+    open(db + "dimension.txt", "w").write("%d\n" % d)
+    open(db + "dtype.txt", "w").write("int32\n")
+
+    def query_file(k, count):
+        qf = tmp_path / ("q%d.txt" % k)
+        with open(qf, "w") as f:
+            for q in range(count):
+                i = int(rng.integers(0, n))
+                h = hashes[offsets[i]:offsets[i + 1]]
+                h = h[rng.random(len(h)) < 0.8] if q % 2 else h          # a subsample of a database sample, or the sample
+                f.write("q%d:" % q + "".join(" %d" % int(x) for x in h) + "\n")
+        return str(qf)
+    files = [query_file(k, c) for k, c in enumerate((3, 40, 7, 300, 1))]
+    with search.SearchIndex(db, ctx=ctx, max_queries=512) as exact:
+        ctx.set_option("pairwise_filter", 0)
+        want = [exact.search(f, 0.1, verbose=False) for f in files]
+        ctx.set_option("pairwise_filter", 1)
+    assert all(len(w) >= 1 for w in want)
+    with search.SearchIndex(db, ctx=ctx, max_queries=512) as idx:
+        cands = []
+        for f, w in zip(files, want):
+            assert idx.search(f, 0.1, verbose=False) == w
+            cands.append(ctx.pairwise_candidates())
+        # first search: the exact streaming kernel (no plane yet); second: builds the plane; from then on it is kept
+        assert cands[0] == 0 and all(c > 0 for c in cands[1:]), cands
+    ctx.close()
