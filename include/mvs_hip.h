@@ -400,6 +400,13 @@ typedef struct {
 int mvs_shard_layout(int64_t n_total, int world, int64_t* block_rows, int64_t* block_rows_padded);
 int mvs_sketch_set_attach_derived(mvs_sketch_set* set, int8_t* coarse_fm, void* row_stats);
 int mvs_sketch_set_prepare_rows(mvs_ctx* ctx, mvs_sketch_set* set, int64_t row_first, int64_t row_count);
+/* mvs_limb_split + mvs_sketch_set_prepare_rows in ONE pass over the sketches (k_recode_rows): rows [row_first, row_first +
+ * n_rows) of the set's planes and derived data from `sketches` (DEVICE, n_rows x d, elem_bytes 4 or 2), the remaining rows up to
+ * row_first + row_count as zero rows (their planes must be zero already).  WRITES the plane buffer the set was made from
+ * (mvs_sketch_set_from_planes).  Two-limb sets of d_pad <= 4096 with derived data attached; anything else takes the separate
+ * passes, same result.  Asynchronous. */
+int mvs_sketch_set_recode_rows(mvs_ctx* ctx, mvs_sketch_set* set, const void* sketches, int elem_bytes, int64_t n_rows,
+                               int64_t row_first, int64_t row_count);
 int mvs_plan_begin(mvs_ctx* ctx, const mvs_sketch_set* set, const double* norms_sq, int keep_mode, int64_t frame_row_begin,
                    int64_t frame_row_end, int flags, mvs_cell* cells, int64_t capacity);
 int mvs_plan_filter(mvs_ctx* ctx, const mvs_plan_block* blocks, int n_blocks);

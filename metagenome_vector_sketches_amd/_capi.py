@@ -115,6 +115,7 @@ SYMBOLS = [
     ("mvs_shard_layout", _c.c_int, [_c.c_int64, _c.c_int, _c.POINTER(_c.c_int64), _c.POINTER(_c.c_int64)]),
     ("mvs_sketch_set_attach_derived", _c.c_int, [_P, _P, _P]),
     ("mvs_sketch_set_prepare_rows", _c.c_int, [_P, _P, _c.c_int64, _c.c_int64]),
+    ("mvs_sketch_set_recode_rows", _c.c_int, [_P, _P, _P, _c.c_int, _c.c_int64, _c.c_int64, _c.c_int64]),
     ("mvs_plan_begin", _c.c_int, [_P, _P, _P, _c.c_int, _c.c_int64, _c.c_int64, _c.c_int, _P, _c.c_int64]),
     ("mvs_plan_filter", _c.c_int, [_P, _P, _c.c_int]),
     ("mvs_plan_finish", _c.c_int, [_P, _c.POINTER(_P)]),
@@ -711,6 +712,16 @@ class Context:
 
     def prepare_rows(self, sset, row_first, row_count):
         _check(self.lib.mvs_sketch_set_prepare_rows(self._h, sset._h, int(row_first), int(row_count)))
+
+    def recode_rows(self, sset, sketches, row_first, row_count):
+        """limb planes + filter inputs of rows [row_first, row_first + row_count) in one pass: the first len(sketches) of them
+        from `sketches` (device [n, d]; None: none), the rest zero rows"""
+        n = 0 if sketches is None else sketches.shape[0]
+        sp, sm, sk = _buf(sketches)
+        if n and sm != MEM_DEVICE:
+            raise ValueError("sketches must be a device buffer")
+        _check(self.lib.mvs_sketch_set_recode_rows(self._h, sset._h, sp, self._elem_bytes(sketches) if n else 4, n, int(row_first),
+                                                   int(row_count)))
 
     def plan_begin(self, sset, norms_sq, frame_begin, frame_end, mirror_outside, cells, keep_mode=KEEP_INT32):
         np_, nm, nk = _buf(norms_sq)

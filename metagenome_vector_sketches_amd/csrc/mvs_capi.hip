@@ -3084,6 +3084,29 @@ int mvs_sketch_set_prepare_rows(mvs_ctx* c, mvs_sketch_set* s, int64_t row_first
     return check_kernel("k_coarse_fm(rows)");
 }
 
+int mvs_sketch_set_recode_rows(mvs_ctx* c, mvs_sketch_set* s, const void* sketches, int elem_bytes, int64_t n_rows, int64_t row_first,
+                               int64_t row_count) {
+    if (!c || !s) return fail(MVS_E_INVALID, "NULL argument");
+    if ((elem_bytes != 4 && elem_bytes != 2) || n_rows < 0 || row_first < 0 || row_count < n_rows || row_first + row_count > s->n_alloc ||
+        (row_first & 15) || (row_count & 15) || (n_rows > 0 && !sketches))
+        return fail(MVS_E_INVALID, "rows [%lld, +%lld) (%lld of them given): multiples of 16 inside the %lld allocated rows",
+                    (long long)row_first, (long long)row_count, (long long)n_rows, (long long)s->n_alloc);
+    if (row_count == 0) return MVS_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    int8_t* planes = const_cast<int8_t*>(s->planes) + row_first * (int64_t)mvs::planes_of(s->limbs) * s->d_pad;
+    if (s->limbs == 2 && s->ext_coarse_fm &&
+        mvs::launch_recode_rows(c->stream, sketches, elem_bytes, n_rows, row_count, s->d, s->d_pad, planes,
+                                s->ext_coarse_fm + row_first * (int64_t)s->d_pad, s->ext_rows + row_first, c->opt.coarse_radix))
+        return check_kernel("k_recode_rows");
+    // other limb codes, longer sketches, no derived data attached: the separate passes
+    if (n_rows > 0) {
+        mvs::launch_limb_split(c->stream, sketches, elem_bytes, n_rows, s->d, s->limbs, const_cast<int8_t*>(s->planes), s->d_pad, row_first);
+        const int rc = check_kernel("k_limb_split");
+        if (rc) return rc;
+    }
+    return mvs_sketch_set_prepare_rows(c, s, row_first, row_count);
+}
+
 int mvs_plan_begin(mvs_ctx* c, const mvs_sketch_set* s, const double* norms_sq, int keep_mode, int64_t f0, int64_t f1, int flags,
                    mvs_cell* cells, int64_t capacity) {
     if (!c || !s) return fail(MVS_E_INVALID, "NULL argument");

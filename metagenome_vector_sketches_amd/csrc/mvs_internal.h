@@ -224,6 +224,10 @@ int launch_pairwise(hipStream_t stream, const PairwiseArgs& a, int mode, int alg
 // that appends candidate pairs, and the exact re-check of the candidates that appends kept cells
 int launch_coarse_build(hipStream_t stream, const int8_t* d_planes, int64_t n, int64_t n_alloc, int d_pad,
                         int8_t* d_coarse, CoarseRow* d_rows, int radix_mode);
+// limb split + coarse build + fragment-major copy of a row range in one pass (k_recode_rows); false: no fused kernel for
+// this geometry (the caller takes the three separate launches)
+bool launch_recode_rows(hipStream_t stream, const void* d_sk, int elem_bytes, int64_t n_rows, int64_t count, int d, int d_pad,
+                        int8_t* d_planes, int8_t* d_coarse_fm, CoarseRow* d_rows, int radix_mode);
 // fragment-major copy of the coarse plane (PairwiseArgs::coarse_fm) / of the limb planes (planes_fm): `limbs` planes per row
 int launch_coarse_fm(hipStream_t stream, const int8_t* d_coarse, int64_t n_alloc, int d_pad, int8_t* d_fm, int limbs = 1);
 // true when launch_pairwise / launch_exact_tiles run the kernel that reads planes_fm for this set

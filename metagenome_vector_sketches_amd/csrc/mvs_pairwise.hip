@@ -2044,6 +2044,156 @@ __global__ __launch_bounds__(256) void k_coarse_build(const int8_t* __restrict__
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// k_recode_rows<T, CH>: sketches -> two-limb planes + fragment-major coarse plane + row statistics in ONE pass (block plans:
+// a rank re-codes its own rows every step; the three kernels this replaces -- k_limb_split, k_coarse_build,
+// k_coarse_fm -- read or write every row five times).  One wave per row, a lane keeps CH chunks of 16 entries in registers
+// (d_pad <= CH * 1024): the radix trials of k_coarse_build run on registers, the limb digits and the coarse bytes leave as
+// 16-byte stores -- the coarse bytes straight into their place in the fragment-major plane (lane's 16 k values of row r at
+// [(r / 16 * nk + k / 64) * 1024 + ((k / 16 % 4) * 16 + r % 16) * 16]; a workgroup is one group of 16 rows, so the sixteen
+// 16-byte pieces of every 256-byte run arrive together).  Same digits, same coarse values, same statistics as the three
+// kernels produce (the statistics are taken from the value the two limbs hold, as k_coarse_build reads it back).
+// Rows [n_rows, count) of the range are written as zero rows (their planes are zero already: never written).
+// ---------------------------------------------------------------------------------------------------
+template <typename T, int CH>
+__global__ __launch_bounds__(CH == 4 ? 512 : 1024) void k_recode_rows(const T* __restrict__ sk, int64_t n_rows, int64_t count, int d, int d_pad,
+                                                      int8_t* __restrict__ planes, int8_t* __restrict__ coarse_fm,
+                                                      CoarseRow* __restrict__ rows, int radix_mode) {
+    const int lane = threadIdx.x & 63;
+    // relative to the range's first row (a multiple of 16); 16 rows per workgroup (8 where a lane holds 64 entries: the
+    // 128 registers a 1024-thread workgroup leaves per lane spill there)
+    const int64_t row = (int64_t)blockIdx.x * (CH == 4 ? 8 : 16) + (threadIdx.x >> 6);
+    if (row >= count) return;
+    const int nk = d_pad / 64;
+    int v[CH][16];
+    int mx = 0;
+    unsigned long long ss = 0;
+    const bool real = row < n_rows;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const int k0 = (lane + 64 * c) * 16;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[c][e] = 0;
+        if (real && k0 < d) {
+            const T* src = sk + row * (int64_t)d + k0;
+            if (k0 + 16 <= d && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)) {
+                if constexpr (sizeof(T) == 4) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const v4i x = *reinterpret_cast<const v4i*>(src + 4 * q);
+                        v[c][4 * q] = x[0]; v[c][4 * q + 1] = x[1]; v[c][4 * q + 2] = x[2]; v[c][4 * q + 3] = x[3];
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const v4i x = *reinterpret_cast<const v4i*>(src + 8 * q);
+#pragma unroll
+                        for (int w = 0; w < 4; ++w) {
+                            v[c][8 * q + 2 * w] = (int)(int16_t)((uint32_t)x[w] & 0xffffu);
+                            v[c][8 * q + 2 * w + 1] = (int)(int16_t)((uint32_t)x[w] >> 16);
+                        }
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    if (k0 + e < d) v[c][e] = (int)src[e];
+            }
+        }
+        // two signed base-256 digits, as k_limb_split takes them; from here on v is what those two digits hold
+        if (k0 < d_pad) {
+            v4i lo4, hi4;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                uint32_t pl = 0, ph = 0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int x = v[c][4 * w + e];
+                    const int l0 = (int)(int8_t)(x & 0xff);
+                    const int l1 = (int)(int8_t)(((int32_t)((uint32_t)x - (uint32_t)l0) >> 8) & 0xff);
+                    pl |= (uint32_t)(uint8_t)l0 << (8 * e);
+                    ph |= (uint32_t)(uint8_t)l1 << (8 * e);
+                    const int y = l0 + 256 * l1;
+                    v[c][4 * w + e] = y;
+                    const int ay = y < 0 ? -y : y;
+                    mx = ay > mx ? ay : mx;
+                    ss += (unsigned)(y * y);
+                }
+                lo4[w] = (int)pl;
+                hi4[w] = (int)ph;
+            }
+            if (real) {
+                *reinterpret_cast<v4i*>(planes + row * 2 * (int64_t)d_pad + k0) = lo4;
+                *reinterpret_cast<v4i*>(planes + (row * 2 + 1) * (int64_t)d_pad + k0) = hi4;
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const int other = __shfl_xor(mx, o, 64);
+        mx = other > mx ? other : mx;
+        ss += __shfl_xor(ss, o, 64);
+    }
+    int m = mx <= 127 ? 1 : (mx + 126) / 127;
+    if (radix_mode == 1 && m > 1) {          // k_coarse_build's search: the radix with the smallest residual among 16
+        const int step = m >= 64 ? m / 32 : 1;
+        unsigned long long best = ~0ULL;
+        int best_m = m;
+        for (int t = 0; t < 16; ++t) {
+            const int mc = m - t * step;
+            if (mc < 1) break;
+            const float ic = 1.0f / (float)mc;
+            unsigned long long r2c = 0;
+#pragma unroll
+            for (int c = 0; c < CH; ++c)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    int cc = (int)rintf((float)v[c][e] * ic);
+                    cc = cc > 127 ? 127 : (cc < -127 ? -127 : cc);
+                    const int r = v[c][e] - mc * cc;
+                    r2c += (unsigned long long)((long long)r * r);
+                }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) r2c += __shfl_xor(r2c, o, 64);
+            if (r2c < best) {
+                best = r2c;
+                best_m = mc;
+            }
+        }
+        m = best_m;
+    }
+    const float inv = 1.0f / (float)m;
+    unsigned c2 = 0, r2 = 0;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const int kc = lane + 64 * c;
+        if (kc * 16 >= d_pad) continue;
+        v4i o4;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            uint32_t packed = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int x = v[c][4 * w + e];
+                int cc = (int)rintf((float)x * inv);
+                cc = cc > 127 ? 127 : (cc < -127 ? -127 : cc);
+                const int r = x - m * cc;
+                c2 += (unsigned)(cc * cc);
+                r2 += (unsigned)(r * r);
+                packed |= (uint32_t)(uint8_t)(int8_t)cc << (8 * e);
+            }
+            o4[w] = (int)packed;
+        }
+        *reinterpret_cast<v4i*>(coarse_fm + ((row >> 4) * nk + (kc >> 2)) * 1024 + (((kc & 3) << 4) + (row & 15)) * 16) = o4;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        c2 += __shfl_xor(c2, o, 64);
+        r2 += __shfl_xor(r2, o, 64);
+    }
+    if (lane == 0) rows[row] = real ? CoarseRow{m, (int32_t)c2, (int32_t)r2, ss >= (1ULL << 31) ? 1 : 0} : CoarseRow{1, 0, 0, 0};
+}
+
 // per-call filter constants {s, w, a, p} (see above); padding rows never pass (s = +inf)
 __global__ __launch_bounds__(256) void k_filter_meta(const CoarseRow* __restrict__ rows, const double* __restrict__ n2,
                                                      int64_t n, int64_t n_alloc, int d, double coeff,
@@ -2904,6 +3054,23 @@ int launch_coarse_fm(hipStream_t stream, const int8_t* d_coarse, int64_t n_alloc
     const unsigned grid = (unsigned)std::min<long long>((chunks + 3) / 4, 65536);
     hipLaunchKernelGGL(k_coarse_fm, dim3(grid), dim3(256), 0, stream, d_coarse, chunks, nk, d_pad, limbs, d_fm);
     return 0;
+}
+
+// sketches (n_rows x d, device) -> limb planes, fragment-major coarse plane and statistics of `count` rows (a multiple of 16;
+// rows beyond n_rows: zero rows), all pointers at the range's first row.  false: this sketch length has no fused kernel
+bool launch_recode_rows(hipStream_t stream, const void* d_sk, int elem_bytes, int64_t n_rows, int64_t count, int d, int d_pad,
+                        int8_t* d_planes, int8_t* d_coarse_fm, CoarseRow* d_rows, int radix_mode) {
+    if (count <= 0) return true;
+    if (d_pad > 4096 || (count & 15)) return false;
+    const int ch = d_pad <= 1024 ? 1 : (d_pad <= 2048 ? 2 : 4);
+#define MVS_RECODE(T, CH) hipLaunchKernelGGL((k_recode_rows<T, CH>), dim3((unsigned)(count / (CH == 4 ? 8 : 16))), dim3(CH == 4 ? 512 : 1024), 0, stream, (const T*)d_sk, n_rows, count, d, d_pad, d_planes, d_coarse_fm, d_rows, radix_mode)
+    if (elem_bytes == 4) {
+        if (ch == 1) MVS_RECODE(int32_t, 1); else if (ch == 2) MVS_RECODE(int32_t, 2); else MVS_RECODE(int32_t, 4);
+    } else {
+        if (ch == 1) MVS_RECODE(int16_t, 1); else if (ch == 2) MVS_RECODE(int16_t, 2); else MVS_RECODE(int16_t, 4);
+    }
+#undef MVS_RECODE
+    return true;
 }
 
 int launch_filter_meta(hipStream_t stream, const CoarseRow* d_rows, const double* d_norms_sq, int64_t n,

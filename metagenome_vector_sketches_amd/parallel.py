@@ -306,6 +306,16 @@ class GpuOps:
     def prepare_rows(self, sset, first, count):
         self.ctx.prepare_rows(sset, first, count)
 
+    def recode_rows(self, sset, sketches, limbs, planes, d_pad, first, count):
+        """limb planes and filter inputs of storage rows [first, first + count) in one pass: the first len(sketches) of them
+        from `sketches`, the rest (behind a shard's last sample) as zero rows"""
+        if _capi._is_torch(sketches) and sketches.is_cuda:
+            self.ctx.recode_rows(sset, sketches if sketches.shape[0] else None, first, count)
+            return
+        if sketches.shape[0]:                      # host sketches: upload inside the limb split, then derive
+            self.ctx.limb_split(sketches, limbs, planes, d_pad, first)
+        self.ctx.prepare_rows(sset, first, count)
+
     def plan_begin(self, sset, norms_sq, f0, f1, mirror_outside, raw, keep_mode):
         self.ctx.plan_begin(sset, norms_sq, f0, f1, mirror_outside, raw, keep_mode=keep_mode)
 
@@ -454,7 +464,7 @@ class ShardedComparison:
             del self.trace[:]
             self._trace("step begin")
         self._step = {"sk": sketches_local, "n2": norms_sq_local, "n_total": n_total, "limbs": limbs_guess, "rps": rps, "P": P,
-                      "n_alloc": n_alloc, "d_pad": d_pad, "max_abs": 0, "fed": 0, "parts": 0, "coarse": [], "last": [],
+                      "n_alloc": n_alloc, "d_pad": d_pad, "max_abs": 0, "fed": 0, "parts": 0, "small": [], "coarse": [], "planes": [],
                       "rows": (rb, re)}
 
     def part_bounds(self, n_total, parts):
@@ -480,10 +490,9 @@ class ShardedComparison:
         own_b, own_e = min(row_begin, n_local), min(row_end, n_local)
         base = self.rank * P
         if own_e > own_b:
-            ops.limb_split(st["sk"][own_b:own_e], limbs, self._planes, d_pad, base + own_b)
             self._put_norms(st["n2"][own_b:own_e], own_b, own_e - own_b, P)
-        if row_end > row_begin:
-            ops.prepare_rows(self._sset, base + row_begin, row_end - row_begin)     # rows behind n_local: zero sketches
+        if row_end > row_begin:                   # the rows behind n_local are zero sketches
+            ops.recode_rows(self._sset, st["sk"][own_b:own_e], limbs, self._planes, d_pad, base + row_begin, row_end - row_begin)
         self._trace("own rows [%d,%d) ready" % (row_begin, row_end))
         if self.world == 1 or row_end == row_begin:
             return
@@ -495,7 +504,7 @@ class ShardedComparison:
             coll.allgather_blocks(self._stats, P * 16)
             coll.allgather_blocks(self._n2, P)
         if last:
-            st["last"].append(coll.submit(small))
+            st["small"].append(coll.submit(small))
         # the coarse plane of the part in row chunks (units of 16 rows = d_pad * 16 contiguous bytes), then its limb planes
         for (c0, c1) in chunk_bounds(row_end - row_begin, self.gather_chunks):
             a, b = row_begin + c0, row_begin + c1
@@ -510,7 +519,7 @@ class ShardedComparison:
             coll.allgather_rows(self._planes, P, row_begin, row_end - row_begin, nl * d_pad)
             self._mark(1)
             self._trace("limb planes [%d,%d) gathered" % (row_begin, row_end), getattr(coll, "stream", None))
-        st["last"].append(coll.submit(planes))
+        st["planes"].append(coll.submit(planes))
 
     def finish(self, keep_mode=_capi.KEEP_INT32, cells_out=None):
         st, self._step = self._step, None
@@ -614,23 +623,23 @@ class ShardedComparison:
         ops.plan_filter(plan[:1])                          # nothing of it comes from another rank
         self._trace("filter launched: diagonal block")
         others = plan[1:]
-        if others:
-            pending = st["coarse"] if first else []
-            if first:
-                for h in st["last"][:1]:
-                    h.wait()                               # row statistics + norms of every rank
-            if pending:
-                for (a, b, h) in pending:
-                    h.wait()
-                    blocks = clip_blocks(others, P, a, b)
-                    if blocks:
-                        ops.plan_filter(blocks)
-                        self._trace("filter launched: peers' rows [%d,%d)" % (a, b))
-            else:
-                ops.plan_filter(others)
-            if first:
-                for h in st["last"][1:]:
-                    h.wait()                               # the limb planes: the re-check reads them
+        if first:
+            for h in st["small"]:
+                h.wait()                                   # row statistics + norms of every rank
+        if first and st["coarse"]:
+            for (a, b, h) in st["coarse"]:
+                h.wait()
+                blocks = clip_blocks(others, P, a, b)
+                if blocks:
+                    ops.plan_filter(blocks)
+                    self._trace("filter launched: peers' rows [%d,%d)" % (a, b))
+        elif others:
+            ops.plan_filter(others)
+        if first:
+            # the limb planes: the re-check reads them.  Every exchange of the step is joined here even if this rank's plan
+            # needs nothing from anybody (rank 1 of 2): the next step rewrites the buffers the collectives read
+            for h in st["planes"]:
+                h.wait()
         d_cnt = ops.plan_finish()
         self._trace("plan finished")
         return d_cnt

@@ -25,10 +25,11 @@ class OracleOps:
     points of the C ABI.  prepare_rows() leaves a marker in the coarse / statistics buffers instead of real filter
     inputs; plan_filter() insists on finding it for every row and column it is asked to compare."""
 
-    def __init__(self):
+    def __init__(self, coll=None):
         from oracle import pyoracle
         self.orc = pyoracle
         self.log = []
+        self.coll = coll                  # lazy collectives: the re-check must not run while exchanges are outstanding
 
     # ---- geometry / buffers ----
     def layout(self, n_total, world):
@@ -101,6 +102,11 @@ class OracleOps:
         sset["coarse"][first * d_pad:(first + count) * d_pad] = 1
         sset["stats"][first * 16:(first + count) * 16] = 7
 
+    def recode_rows(self, sset, sketches, limbs, planes, d_pad, first, count):
+        if sketches.shape[0]:
+            self.limb_split(sketches, limbs, planes, d_pad, first)
+        self.prepare_rows(sset, first, count)
+
     def _landed(self, sset, r0, r1):
         d_pad = sset["d_pad"]
         c = sset["coarse"].numpy()[r0 * d_pad:r1 * d_pad].reshape(r1 - r0, d_pad)
@@ -132,6 +138,8 @@ class OracleOps:
     def plan_finish(self):
         p = self.plan
         sset = p["sset"]
+        if self.coll is not None:
+            assert self.coll.outstanding() == 0, "re-check while %d exchanges have not been waited for" % self.coll.outstanding()
         sk = self._sketches(sset)                       # storage rows (padding rows: zeros)
         n2 = p["n2"].numpy()[:sset["n"]]
         out = []
@@ -205,6 +213,34 @@ class OracleOps:
         cells_out[:n] = torch.from_numpy(a[np.lexsort((a[:, 1], a[:, 0]))])
 
 
+def lazy_collectives(dist_mod, rank, world):
+    """torch.distributed collectives whose exchanges happen as LATE as the step allows: submit() only queues the calls, a
+    handle's wait() runs everything queued up to it.  With them a step that reads a buffer before waiting for the exchange
+    that fills it finds the buffer empty (OracleOps checks the markers) -- on a GPU the same mistake is a race."""
+    from metagenome_vector_sketches_amd import parallel
+
+    class Lazy(parallel.TorchCollectives):
+        def __init__(self):
+            super().__init__(dist_mod, rank, world)
+            self.queue = []
+
+        def submit(self, fn):
+            self.queue.append(fn)
+            me, upto = self, len(self.queue)
+
+            class H:
+                def wait(self):
+                    while me.queue and upto > me.done:
+                        me.queue[me.done]()
+                        me.done += 1
+            return H()
+        done = 0
+
+        def outstanding(self):
+            return len(self.queue) - self.done
+    return Lazy()
+
+
 def _make(n, d, seed):
     from metagenome_vector_sketches_amd import synth
     from oracle import pyoracle as orc
@@ -247,6 +283,17 @@ def _worker(rank, world, port, n, d, out_dir):
     _, cnt3b, info3b = sc_rows.run(sk[b:e], n2[b:e], n, cells_out=out)
     assert info3b["schedule"] == "rows x all columns" and info3b["exchanged_cells"] == 0
     assert cnt3b == cnt and np.array_equal(out[:cnt3b].numpy(), plain)
+    # exchanges that complete as late as the step allows: nothing may be read before its handle has been waited for
+    lazy = lazy_collectives(dist, rank, world)
+    sc_lazy = parallel.ShardedComparison(OracleOps(lazy), rank, world, collectives=lazy)
+    _, cnt_l, _ = sc_lazy.run(sk[b:e], n2[b:e], n, cells_out=out)
+    assert cnt_l == cnt and np.array_equal(out[:cnt_l].numpy(), plain)
+    sc_lazy.begin(torch.from_numpy(sk[b:e].copy()), n2[b:e], n)
+    for (p0, p1) in sc_lazy.part_bounds(n, 2):
+        q0, q1 = min(p0, e - b), min(p1, e - b)
+        sc_lazy.feed(p0, p1, int(np.abs(sk[b + q0:b + q1]).max()) if q1 > q0 else 0)
+    _, cnt_l, _ = sc_lazy.finish(cells_out=out)
+    assert cnt_l == cnt and np.array_equal(out[:cnt_l].numpy(), plain)
     # local rows arriving in parts (begin / feed / finish): the exchange of a part starts when it is fed; same cells
     local, n2l = torch.from_numpy(sk[b:e].copy()), n2[b:e]
     sc.begin(local, n2l, n)

@@ -208,3 +208,41 @@ def test_sharded_comparison_single_rank_equals_pairwise_rows(ctx):
         assert got_n == cnt and np.array_equal(out[:cnt].cpu().numpy(), want)
     host, got_n, _ = sc.run(torch.from_numpy(sk).to(DEV), n2, n)
     assert got_n == cnt and np.array_equal(host, ref[np.lexsort((ref["col"], ref["row"]))])
+
+
+@pytest.mark.parametrize("d", [64, 100, 512, 1100, 2048, 2100, 4096, 5000])
+@pytest.mark.parametrize("dtype", [np.int32, np.int16])
+def test_recode_rows_equals_the_separate_passes(ctx, d, dtype):
+    """k_recode_rows (one pass over the sketches) against k_limb_split + k_coarse_build + k_coarse_fm: byte-identical limb
+    planes, fragment-major coarse plane and row statistics, including the zero rows behind the samples and sketch lengths that
+    are not multiples of 16 / that have no fused kernel (d_pad > 4096: the call takes the separate passes itself)"""
+    rng = np.random.default_rng(d)
+    n, rows = 37, 48                                            # 37 samples in a range of 48 rows starting at row 32
+    hi = 30000 if dtype == np.int16 else 32639
+    sk = rng.integers(-hi, hi + 1, size=(n, d)).astype(dtype)
+    sk[3] = 0
+    sk[5] = rng.integers(-100, 101, size=d).astype(dtype)      # a one-limb row
+    sk[7, :] = hi
+    n_st = 128
+    n_alloc, d_pad, nbytes = ctx.limb_geometry(n_st, d, 2)
+    out = []
+    for fused in (True, False):
+        planes = torch.zeros(nbytes, dtype=torch.int8, device=DEV)
+        coarse = torch.full((n_alloc * d_pad,), 0x55, dtype=torch.uint8, device=DEV)
+        stats = torch.full((n_alloc * 16,), 0x55, dtype=torch.uint8, device=DEV)
+        sset = ctx.sketch_set_from_planes(planes, n_st, n_alloc, d, d_pad, 2)
+        ctx.attach_derived(sset, coarse, stats)
+        dev_sk = torch.from_numpy(sk).to(DEV)
+        if fused:
+            ctx.recode_rows(sset, dev_sk, 32, rows)
+        else:
+            ctx.limb_split(dev_sk, 2, planes, d_pad, 32)
+            ctx.prepare_rows(sset, 32, rows)
+        torch.cuda.synchronize()
+        out.append((planes.cpu().numpy().copy(), coarse.cpu().numpy().copy(), stats.cpu().numpy().copy()))
+        sset.close()
+    for a, b in zip(out[0], out[1]):
+        assert np.array_equal(a, b)
+    assert np.all(out[0][1][:32 * d_pad] == 0x55) and np.all(out[0][1][80 * d_pad:] == 0x55)     # nothing outside the range
+    st = out[0][2][32 * 16:80 * 16].view(np.int32).reshape(rows, 4)
+    assert np.all(st[n:] == [1, 0, 0, 0]) and st[3].tolist() == [1, 0, 0, 0] and st[5, 0] == 1 and st[7, 0] > 1
