@@ -423,6 +423,7 @@ def main():
             rec = strong_run(args, ctx, dev, rank, world, dist if world > 1 else None, coll, cfg, args.strong_steps, 3)
             strong["configs[%d]" % (cfg - 1)] = {"workload": rec["config"]["workload"], "cells_per_s": rec["value"],
                                                  "ms_per_step": rec["ms_per_step"], "kept_cells": rec["config"]["kept_cells"],
+                                                 "cells_checksum": rec["config"]["cells_checksum"],
                                                  "schedule": rec["config"]["schedule"], "overlap": rec["config"]["overlap"],
                                                  "rccl_ranks": rec["config"].get("rccl_ranks", 0), "stages": rec["stages"],
                                                  "roofline": rec["roofline"]}
@@ -664,15 +665,23 @@ def strong_run(args, ctx, dev, rank, world, dist, coll, config, steps, warmup):
     plan_span_ms = span("plan begin", "plan finished")
     cells_ms = span("plan finished", "cells sorted")
     kept = state["cnt"]
+    # an order-independent checksum of the shard (sum over its cells of a 64-bit mix of row, col, dot, q; wraps mod 2^64), summed
+    # over the ranks: the same whatever the rank count, since the union of the shards is the same matrix
+    cc = cells[:kept].to(torch.int64)
+    mix = (cc[:, 0] * 1000003 + cc[:, 1]) * 2654435761 + cc[:, 2] * 40503 + cc[:, 3]
+    digest = torch.stack([mix.sum(), (mix * mix).sum()])
+    timeline = [[k, round(tr["step begin"].elapsed_time(ev), 4)] for k, ev in sc.trace] if "step begin" in tr else []
     k2 = float(np.mean(acc["filter"]) + np.mean(acc["recheck"]) + np.mean(acc["tiles"]))
     vals = [elapsed, k2, float(np.mean(acc["gather"])), prepare_ms, plan_span_ms, cells_ms, float(np.mean(acc["filter"]))]
     if world > 1:
         t = torch.tensor(vals, dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         vals = [float(x) for x in t.tolist()]
-        c = torch.tensor([kept], dtype=torch.int64, device=dev)
+        c = torch.cat([torch.tensor([kept], dtype=torch.int64, device=dev), digest])
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
-        kept = int(c.item())
+        kept = int(c[0].item())
+        digest = c[1:]
+    digest = "%016x%016x" % (int(digest[0].item()) & (2 ** 64 - 1), int(digest[1].item()) & (2 ** 64 - 1))
     elapsed, k2_max, gather_max, prepare_ms, plan_span_ms, cells_ms, filter_ms = vals
     info, ps = state["info"], state["plan"]
     cells_total = float(n_total) * n_total
@@ -699,7 +708,7 @@ def strong_run(args, ctx, dev, rank, world, dist, coll, config, steps, warmup):
             "dtype": "int8 limbs x int32 MFMA accumulate; fp64 keep test", "data": "synthetic",
             "config": {"workload": "configs[%d]: %d synthetic samples, d=%d, pairwise, row shards over %d GPU(s)" %
                                    (config - 1, n_total, d, world),
-                       "total_samples": n_total, "d": d, "limbs": info["limbs"], "kept_cells": kept,
+                       "total_samples": n_total, "d": d, "limbs": info["limbs"], "kept_cells": kept, "cells_checksum": digest,
                        "schedule": info.get("schedule"), "overlap": info.get("overlap"), "gather_chunks": sc.gather_chunks,
                        "collectives": info.get("collectives"), **comm_facts(coll, world)},
             "stages": {"prepare_own_rows_ms": prepare_ms,
@@ -719,6 +728,9 @@ def strong_run(args, ctx, dev, rank, world, dist, coll, config, steps, warmup):
                        "other_ms": ms - prepare_ms - plan_span_ms - cells_ms,
                        "note": "prepare + plan span + cells + other = ms_per_step; spans are the last step's, from events on the "
                                "step's streams (max over ranks); host synchronisations per step: 2"},
+            # rank 0's last step: (what, ms since the step began) from events on the compute stream and on the exchange's
+            # stream -- "filter launched" / "gathered" events complete when the work queued before them has
+            "timeline": timeline,
             "roofline": roof}
 
 

@@ -102,12 +102,13 @@ def _native_worker(rank, world, n, d, out_dir):
     n2_dev = torch.from_numpy(n2[b:e].copy()).to("cuda:0")
     for parts in (2, 3):
         sc.begin(local, n2_dev, n)
-        for (p0, p1) in sc.part_bounds(n, parts):
+        bounds = sc.part_bounds(n, parts)              # on multiples of 256 storage rows: a small block is one part
+        for (p0, p1) in bounds:
             q0, q1 = min(p0, e - b), min(p1, e - b)
             sc.feed(p0, p1, int(local[q0:q1].abs().max()) if q1 > q0 else 0)
         _, cnt, info = sc.finish(cells_out=out)
         torch.cuda.synchronize()
-        assert "exchange of a part" in info["overlap"]
+        assert ("exchange of a part" in info["overlap"]) == (len(bounds) > 1)
         np.save(os.path.join(out_dir, "ncells_p%d_%d.npy" % (parts, rank)), out[:cnt].cpu().numpy())
     comm2.close()
     ctx2.close()
@@ -239,3 +240,25 @@ def test_bare_bench_gpus2_config4_launches_itself():
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["total_samples"] == 100_000
     assert d["config"]["d"] == 4096 and d["config"]["comm_world"] == 2
     assert d["config"]["kept_cells"] >= 100_000 * 10
+    assert d["stages"]["filter_launches"] >= 2 and d["config"]["schedule"] == "symmetric"
+
+
+def test_strong_scaled_step_gives_the_same_cells_for_every_rank_count():
+    """configs[2] (100k x 2048) through bench.py with 1, 2 and 4 ranks (the ranks share the card: MVS_BENCH_REHEARSAL):
+    the same number of kept cells and the same order-independent checksum over all shards -- the union of the shards is
+    bit for bit the one-rank result -- and every rank count reports its stage times"""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "MVS_PAIRWISE_FILTER")}
+    env["MVS_BENCH_REHEARSAL"] = "1"
+    seen = {}
+    for g in (1, 2, 4):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(g), "--config", "3", "--steps", "2",
+                            "--warmup", "1"], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        seen[g] = (d["config"]["kept_cells"], d["config"]["cells_checksum"])
+        assert d["stages"]["filter_tiles"] > 0 and d["roofline"]["frac"] is not None and d["roofline"]["frac"] <= 1.0
+        assert [x for x in d["timeline"] if x[0].startswith("filter launched: diagonal block")]
+    assert seen[1] == seen[2] == seen[4] and seen[1][0] > 1_000_000, seen
