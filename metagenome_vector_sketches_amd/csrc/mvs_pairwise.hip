@@ -2786,20 +2786,23 @@ struct RouteArgs {
     long long status, max_abs;
 };
 
-__device__ __forceinline__ void append_cell(mvs_cell* out, unsigned long long cap, unsigned long long* counter, bool want,
-                                            const mvs_cell& c, int lane) {
-    const unsigned long long m = __ballot(want);
-    if (m == 0ULL) return;
-    unsigned long long base = 0;
-    const int leader = __ffsll((long long)m) - 1;
-    if (lane == leader) base = atomicAdd(counter, (unsigned long long)__popcll(m));
-    base = (unsigned long long)__shfl((long long)base, leader, 64);
-    if (want) {
-        const unsigned long long slot = base + (unsigned long long)__popcll(m & ((1ULL << lane) - 1ULL));
-        if (slot < cap) out[slot] = c;
-    }
+// room for `mine` cells per lane behind *counter with ONE atomic per wave (wave_reserve above), for the route / collect kernels
+__device__ __forceinline__ void append_cells(mvs_cell* out, unsigned long long cap, unsigned long long* counter, const mvs_cell* c,
+                                             unsigned want_mask, int lane) {
+    const unsigned mine = (unsigned)__popc(want_mask);
+    if (__ballot(mine != 0) == 0ULL) return;
+    unsigned long long slot = wave_reserve(counter, mine, lane);
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+        if (want_mask & (1u << k)) {
+            if (slot < cap) out[slot] = c[k];
+            ++slot;
+        }
 }
 
+// a wave takes 512 consecutive cells per round (8 per lane, each load instruction 1 KiB contiguous) and reserves room for all
+// it keeps with one atomic: 1.6 M cells are 3 200 atomics on the counter instead of 25 000 (one per 64 cells: 0.3 ms, the
+// counter's line going back and forth)
 __global__ __launch_bounds__(256) void k_cells_route(const RouteArgs r) {
     const int lane = threadIdx.x & 63;
     const unsigned long long total = *r.n_raw;
@@ -2811,24 +2814,29 @@ __global__ __launch_bounds__(256) void k_cells_route(const RouteArgs r) {
         r.send[4] = r.raw_capacity;
     }
     mvs_cell* foreign = r.send ? reinterpret_cast<mvs_cell*>(r.send + 8) : nullptr;
-    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
-    // whole waves stay in the loop together (the appends are wave-wide)
-    for (unsigned long long base = (unsigned long long)blockIdx.x * blockDim.x + (threadIdx.x & ~63u); base < n; base += stride) {
-        const unsigned long long i = base + lane;
-        mvs_cell c{0, 0, 0, 0};
-        bool valid = false;
-        if (i < n) {
-            c = r.raw[i];
-            const long long br = c.row / r.block_pad, orow = c.row - br * r.block_pad;
-            const long long bc = c.col / r.block_pad, ocol = c.col - bc * r.block_pad;
-            const long long row = br * r.block_rows + orow, col = bc * r.block_rows + ocol;
-            valid = orow < r.block_rows && ocol < r.block_rows && row < r.n_total && col < r.n_total;
-            c.row = (int32_t)row;
-            c.col = (int32_t)col;
+    const unsigned long long waves = (unsigned long long)gridDim.x * 4;
+    for (unsigned long long base = ((unsigned long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 512; base < n; base += waves * 512) {
+        mvs_cell c[8];
+        unsigned mine = 0, other = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const unsigned long long i = base + (unsigned long long)k * 64 + lane;
+            c[k] = mvs_cell{0, 0, 0, 0};
+            if (i < n) {
+                c[k] = r.raw[i];
+                const long long br = c[k].row / r.block_pad, orow = c[k].row - br * r.block_pad;
+                const long long bc = c[k].col / r.block_pad, ocol = c[k].col - bc * r.block_pad;
+                const long long row = br * r.block_rows + orow, col = bc * r.block_rows + ocol;
+                const bool valid = orow < r.block_rows && ocol < r.block_rows && row < r.n_total && col < r.n_total;
+                c[k].row = (int32_t)row;
+                c[k].col = (int32_t)col;
+                const bool own = valid && row >= r.own_begin && row < r.own_end;
+                mine |= own ? 1u << k : 0u;
+                other |= (valid && !own) ? 1u << k : 0u;
+            }
         }
-        const bool mine = valid && c.row >= r.own_begin && c.row < r.own_end;
-        append_cell(r.own, r.own_capacity, r.own_count, mine, c, lane);
-        if (r.send) append_cell(foreign, r.foreign_capacity, r.send, valid && !mine, c, lane);
+        append_cells(r.own, r.own_capacity, r.own_count, c, mine, lane);
+        if (r.send) append_cells(foreign, r.foreign_capacity, r.send, c, other, lane);
     }
 }
 
@@ -2843,16 +2851,20 @@ __global__ __launch_bounds__(256) void k_cells_collect(const unsigned long long*
     const unsigned long long total = buf[0];
     const unsigned long long n = total < capacity ? total : capacity;
     const mvs_cell* cells = reinterpret_cast<const mvs_cell*>(buf + 8);
-    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
-    for (unsigned long long base = (unsigned long long)blockIdx.x * blockDim.x + (threadIdx.x & ~63u); base < n; base += stride) {
-        const unsigned long long i = base + lane;
-        mvs_cell c{0, 0, 0, 0};
-        bool mine = false;
-        if (i < n) {
-            c = cells[i];
-            mine = c.row >= own_begin && c.row < own_end;
+    const unsigned long long waves = (unsigned long long)gridDim.x * 4;
+    for (unsigned long long base = ((unsigned long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 512; base < n; base += waves * 512) {
+        mvs_cell c[8];
+        unsigned mine = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const unsigned long long i = base + (unsigned long long)k * 64 + lane;
+            c[k] = mvs_cell{0, 0, 0, 0};
+            if (i < n) {
+                c[k] = cells[i];
+                mine |= (c[k].row >= own_begin && c[k].row < own_end) ? 1u << k : 0u;
+            }
         }
-        append_cell(own, own_capacity, own_count, mine, c, lane);
+        append_cells(own, own_capacity, own_count, c, mine, lane);
     }
 }
 
