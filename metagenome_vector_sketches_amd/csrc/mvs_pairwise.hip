@@ -1515,9 +1515,13 @@ __global__ __launch_bounds__(512, 2) void k_pairwise_pp(const PairwiseArgs a, in
         __builtin_amdgcn_s_barrier();
         if (wm == 1) __builtin_amdgcn_s_barrier();               // group 1 runs one interval behind group 0
         int slot = 0, fill = D % NST;
-        auto phase = [&](int s, v4i (&cur)[4], v4i (&nxt)[4]) __attribute__((always_inline)) {
+        // `last`: the phase of the very last slice (the odd tail below) has no B fragments to load -- said at compile time, so
+        // that no dead load is emitted there at all: hipcc gave the four unused results of such loads ONE register quadruple
+        // and re-used it for the A fragments, code that would race if the (never true) condition around it ever held;
+        // tools/check_isa.py walks the generated code for exactly this kind of thing
+        auto phase = [&](int s, v4i (&cur)[4], v4i (&nxt)[4], auto last) __attribute__((always_inline)) {
             const char* sb = smem + slot * kStage;
-            const bool more_a = s + D < nk, more_b = s + 1 < nk;
+            const bool more_a = s + D < nk, more_b = !decltype(last)::value && s + 1 < nk;
             if (more_a) {
 #pragma unroll
                 for (int p = 0; p < PA; ++p) copy_piece(src[p] + (s + D) * 1024, smem + fill * kStage + (wave * PA + p) * 1024);
@@ -1562,10 +1566,10 @@ __global__ __launch_bounds__(512, 2) void k_pairwise_pp(const PairwiseArgs a, in
         };
         int s = 0;
         for (; s + 2 <= nk; s += 2) {
-            phase(s, fbA, fbB);
-            phase(s + 1, fbB, fbA);
+            phase(s, fbA, fbB, std::false_type{});
+            phase(s + 1, fbB, fbA, std::false_type{});
         }
-        if (s < nk) phase(s, fbA, fbB);
+        if (s < nk) phase(s, fbA, fbB, std::true_type{});
     } else {
     #pragma unroll
         for (int st = 0; st < D; ++st)

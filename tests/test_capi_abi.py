@@ -79,3 +79,16 @@ def test_library_reads_the_environment_only_when_a_context_is_created():
     import subprocess
     syms = subprocess.run(["nm", "-D", "--defined-only", _capi.LIB_PATH], capture_output=True, text=True).stdout
     assert "mvs_ctx_set_option" in syms and "mvs_comm_create" in syms and "mvs_allgather_planes" in syms
+
+
+def test_generated_code_of_the_hand_counted_loads():
+    """`make check-isa`: the direct-B ping-pong kernels (k_pairwise_pp<..., BD = 1>) issue their B-fragment loads as inline asm
+    and count vmcnt by hand; the compiler believes the results are there at once.  tools/check_isa.py disassembles the gfx950
+    code object inside the library that ships and checks that nothing touches a loaded fragment register before the wait that
+    retires it and that every MFMA's B operand is such a register -- and that it would notice: three mutated variants of the
+    real code (a register copy right after the load, a foreign B operand, weakened waits) must be rejected."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_isa.py"), "--self-test"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "direct-B kernels pass" in r.stdout and "all 3 mutations" in r.stdout
