@@ -453,6 +453,14 @@ int mvs_ctx_create(int device, mvs_ctx** out) {
     mvs_ctx* c = new (std::nothrow) mvs_ctx();
     if (!c) return fail(MVS_E_NOMEM, "out of host memory");
     c->device = device;
+#ifdef MVS_ABLATIONS
+    // The profiling build compiles the ping-pong kernels with extra code (time stamps, injected candidates), and with it
+    // hipcc no longer keeps the fragment registers of the direct-B loop's hand-counted loads untouched: measured in round 5,
+    // the ablation build's direct-B filter lost candidates at random (499 k +- 300 listed against 413 702, a few dozen kept
+    // cells missing) while the shipped library -- which tools/check_isa.py gates -- is exact and deterministic.  So this build
+    // runs both operands through LDS unless asked otherwise, and what it measures is the LDS-only kernel.
+    c->opt.pairwise_bdirect = 0;
+#endif
     options_from_env(c->opt);
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
         delete c;
