@@ -419,23 +419,31 @@ int mvs_plan_stats(mvs_ctx* ctx, double ms[4], int64_t counts[6]);
 
 /* Kept cells of a plan -> this rank's shard.  A cell of the plan is in storage coordinates and, under the symmetric
  * multi-rank schedule, about half of them are mirror images that belong to OTHER ranks' rows.
+ * d_own_count (DEVICE) is the shard's state block of 16 + 4 * (own_end - own_begin + 1) bytes: u64 cells of own rows, u32 largest
+ *     number of cells in one row (valid after mvs_cells_report), u32 unused, then one u32 per own row: its cells.
  * mvs_cells_route   : cells [0, min(*d_n_raw, raw_capacity)) -> sample indices (row = block * block_rows + offset for offset <
  *     block_rows; cells touching a padding row or a row >= n_total are dropped); those of rows [own_begin, own_end) are
- *     appended to own_out (count in *d_own_count, DEVICE, zeroed by this call), the others to `send` = a 64-byte header
+ *     appended to own_out (state block zeroed by this call, then counted into), the others to `send` = a 64-byte header
  *     {foreign cells (may exceed the capacity), status, max_abs, *d_n_raw, raw_capacity, ...} followed by foreign_capacity
  *     cells.  status / max_abs travel in the header so that one exchange tells every rank how every other rank fared.
  * mvs_cells_collect : `recv` = world such buffers (after an all-gather of the send buffers): the cells of rows
  *     [own_begin, own_end) in the other ranks' buffers are appended to own_out.
- * mvs_cells_report  : read back -- out[0] = *d_own_count, then per rank {foreign cells, status, max_abs, raw cells,
- *     raw capacity} (5 * world values).  Synchronous; the other two are asynchronous. */
+ * mvs_cells_report  : read back -- out[0] = cells of own rows, then per rank {foreign cells, status, max_abs, raw cells,
+ *     raw capacity} (5 * world values), then out[1 + 5 * world] = the largest number of cells in one own row.  Synchronous; the
+ *     others are asynchronous.
+ * mvs_cells_sort_rows : own_out -> (row, col) order by row buckets -- the rows' counts are in the state block: scan, scatter
+ *     into the rows' segments, one wave per row orders its cells by column.  For shards whose rows hold at most 64 cells (what
+ *     the report says); anything else: mvs_cells_sort. */
 int mvs_cells_route(mvs_ctx* ctx, const mvs_cell* raw, const uint64_t* d_n_raw, int64_t raw_capacity, int64_t block_rows_padded,
                     int64_t block_rows, int64_t n_total, int64_t own_begin, int64_t own_end, mvs_cell* own_out,
                     int64_t own_capacity, uint64_t* d_own_count, void* send, int64_t foreign_capacity, int64_t status,
                     int64_t max_abs);
 int mvs_cells_collect(mvs_ctx* ctx, const void* recv, int world, int rank, int64_t foreign_capacity, int64_t own_begin,
                       int64_t own_end, mvs_cell* own_out, int64_t own_capacity, uint64_t* d_own_count);
-int mvs_cells_report(mvs_ctx* ctx, const void* recv, int world, int64_t foreign_capacity, const uint64_t* d_own_count,
+int mvs_cells_report(mvs_ctx* ctx, const void* recv, int world, int64_t foreign_capacity, int64_t own_rows, uint64_t* d_own_count,
                      int64_t* out);
+int mvs_cells_sort_rows(mvs_ctx* ctx, const mvs_cell* cells_in, int64_t n, int64_t own_begin, int64_t own_end,
+                        const uint64_t* d_own_count, mvs_cell* cells_out);
 #define MVS_CELLS_HEADER_BYTES 64
 
 /* Sort n cells by (row, col) from one DEVICE buffer into another (asynchronous on the context's stream). */

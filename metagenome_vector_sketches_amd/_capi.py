@@ -123,7 +123,8 @@ SYMBOLS = [
     ("mvs_cells_route", _c.c_int, [_P, _P, _P, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _P,
                                     _c.c_int64, _P, _P, _c.c_int64, _c.c_int64, _c.c_int64]),
     ("mvs_cells_collect", _c.c_int, [_P, _P, _c.c_int, _c.c_int, _c.c_int64, _c.c_int64, _c.c_int64, _P, _c.c_int64, _P]),
-    ("mvs_cells_report", _c.c_int, [_P, _P, _c.c_int, _c.c_int64, _P, _c.POINTER(_c.c_int64)]),
+    ("mvs_cells_report", _c.c_int, [_P, _P, _c.c_int, _c.c_int64, _c.c_int64, _P, _c.POINTER(_c.c_int64)]),
+    ("mvs_cells_sort_rows", _c.c_int, [_P, _P, _c.c_int64, _c.c_int64, _c.c_int64, _P, _P]),
     ("mvs_chunk_size", _c.c_int64, [_c.c_double, _c.c_int]),
     ("mvs_shard_rows", None, [_c.c_int64, _c.c_int, _c.c_int, _c.POINTER(_c.c_int64), _c.POINTER(_c.c_int64)]),
 ]
@@ -770,13 +771,20 @@ class Context:
         _check(self.lib.mvs_cells_collect(self._h, rp, int(world), int(rank), int(foreign_capacity), int(own_begin), int(own_end),
                                           op, own_out.shape[0], cp))
 
-    def cells_report(self, recv, world, foreign_capacity, d_own_count):
-        """-> (cells of this shard, [(foreign cells, status, max_abs, raw cells, raw capacity)] per rank); synchronises"""
+    def cells_report(self, recv, world, foreign_capacity, own_rows, d_own_count):
+        """-> (cells of this shard, [(foreign cells, status, max_abs, raw cells, raw capacity)] per rank, most cells in one
+        row); synchronises"""
         rp, rm, rk = _buf(recv)
         cp, cm, ck = _buf(d_own_count)
-        out = (_c.c_int64 * (1 + 5 * world))()
-        _check(self.lib.mvs_cells_report(self._h, rp, int(world), int(foreign_capacity), cp, out))
-        return out[0], [tuple(out[1 + 5 * r:6 + 5 * r]) for r in range(world)]
+        out = (_c.c_int64 * (2 + 5 * world))()
+        _check(self.lib.mvs_cells_report(self._h, rp, int(world), int(foreign_capacity), int(own_rows), cp, out))
+        return out[0], [tuple(out[1 + 5 * r:6 + 5 * r]) for r in range(world)], out[1 + 5 * world]
+
+    def cells_sort_rows(self, cells_in, n, own_begin, own_end, d_own_count, cells_out):
+        ip, im, ik = _buf(cells_in)
+        op, om, ok = _buf(cells_out)
+        cp, cm, ck = _buf(d_own_count)
+        _check(self.lib.mvs_cells_sort_rows(self._h, ip, int(n), int(own_begin), int(own_end), cp, op))
 
     def cells_sort(self, cells_in, n, cells_out):
         ip, im, ik = _buf(cells_in)

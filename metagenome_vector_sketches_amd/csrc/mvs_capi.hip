@@ -3350,7 +3350,7 @@ int mvs_plan_finish(mvs_ctx* c, const uint64_t** d_count) {
         a.cand_thr = (const int32_t*)c->pw_thr;
     }
     if (st.candidates > 0) {
-        int rc = mvs::launch_exact_pairs(c->stream, a, c->opt);
+        int rc = mvs::launch_exact_pairs(c->stream, a, c->opt, st.candidates);
         if (rc) return fail(rc, "exact re-check launch rejected");
         rc = check_kernel("k_exact_pairs");
         if (rc) return rc;
@@ -3407,7 +3407,7 @@ int mvs_cells_route(mvs_ctx* c, const mvs_cell* raw, const uint64_t* d_n_raw, in
         n_total >= (1LL << 31) - 256 || (raw_capacity > 0 && !raw) || (own_capacity > 0 && !own_out))
         return fail(MVS_E_INVALID, "bad argument");
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipMemsetAsync(d_own_count, 0, 8, c->stream));
+    HIP_TRY(hipMemsetAsync(d_own_count, 0, 16 + 4 * (size_t)(own_end - own_begin + 1), c->stream));   // count, max, per-row counts
     if (send) HIP_TRY(hipMemsetAsync(send, 0, MVS_CELLS_HEADER_BYTES, c->stream));
     mvs::launch_cells_route(c->stream, raw, reinterpret_cast<const unsigned long long*>(d_n_raw), (unsigned long long)raw_capacity,
                             block_rows_padded, block_rows, n_total, (int)own_begin, (int)own_end, own_out,
@@ -3430,22 +3430,44 @@ int mvs_cells_collect(mvs_ctx* c, const void* recv, int world, int rank, int64_t
     return check_kernel("k_cells_collect");
 }
 
-int mvs_cells_report(mvs_ctx* c, const void* recv, int world, int64_t foreign_capacity, const uint64_t* d_own_count, int64_t* out) {
-    if (!c || !d_own_count || !out || world < 1 || foreign_capacity < 0 || (world > 1 && !recv))
+int mvs_cells_sort_rows(mvs_ctx* c, const mvs_cell* cells_in, int64_t n, int64_t own_begin, int64_t own_end, const uint64_t* d_own_state,
+                        mvs_cell* cells_out) {
+    if (!c || !d_own_state) return fail(MVS_E_INVALID, "NULL argument");
+    if (n < 0 || own_begin < 0 || own_end < own_begin || own_end - own_begin >= (1LL << 30)) return fail(MVS_E_INVALID, "bad argument");
+    if (n == 0) return MVS_OK;
+    if (!cells_in || !cells_out || cells_in == cells_out) return fail(MVS_E_INVALID, "need two distinct device buffers");
+    HIP_TRY(hipSetDevice(c->device));
+    size_t need = 0;
+    int rc = mvs::sort_cells_rows(c->stream, cells_in, cells_out, n, (int)own_begin, (int)(own_end - own_begin),
+                                  reinterpret_cast<const unsigned long long*>(d_own_state), nullptr, 0, &need);
+    if (rc) return fail(rc, "row sort sizing failed");
+    rc = ensure_buf(c, &c->pw_sort, &c->pw_sort_bytes, need);
+    if (rc) return rc;
+    rc = mvs::sort_cells_rows(c->stream, cells_in, cells_out, n, (int)own_begin, (int)(own_end - own_begin),
+                              reinterpret_cast<const unsigned long long*>(d_own_state), c->pw_sort, c->pw_sort_bytes, nullptr);
+    if (rc) return fail(rc, "row sort failed");
+    return check_kernel("k_rows_sort");
+}
+
+int mvs_cells_report(mvs_ctx* c, const void* recv, int world, int64_t foreign_capacity, int64_t own_rows, uint64_t* d_own_count,
+                     int64_t* out) {
+    if (!c || !d_own_count || !out || world < 1 || foreign_capacity < 0 || own_rows < 0 || (world > 1 && !recv))
         return fail(MVS_E_INVALID, "bad argument");
     HIP_TRY(hipSetDevice(c->device));
     std::vector<unsigned long long> hdr((size_t)world * 8, 0);
-    unsigned long long own = 0;
-    HIP_TRY(hipMemcpyAsync(&own, d_own_count, 8, hipMemcpyDeviceToHost, c->stream));
+    unsigned long long own[2] = {0, 0};
+    mvs::launch_rows_max(c->stream, reinterpret_cast<unsigned long long*>(d_own_count), (int)own_rows);
+    HIP_TRY(hipMemcpyAsync(own, d_own_count, 16, hipMemcpyDeviceToHost, c->stream));
     if (recv) {
         const size_t stride = MVS_CELLS_HEADER_BYTES + (size_t)foreign_capacity * sizeof(mvs_cell);
         HIP_TRY(hipMemcpy2DAsync(hdr.data(), MVS_CELLS_HEADER_BYTES, recv, stride, MVS_CELLS_HEADER_BYTES, (size_t)world,
                                  hipMemcpyDeviceToHost, c->stream));
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
-    out[0] = (int64_t)own;
+    out[0] = (int64_t)own[0];
     for (int r = 0; r < world; ++r)
         for (int k = 0; k < 5; ++k) out[1 + r * 5 + k] = (int64_t)hdr[(size_t)r * 8 + (size_t)k];
+    out[1 + 5 * world] = (int64_t)(own[1] & 0xffffffffULL);
     return MVS_OK;
 }
 

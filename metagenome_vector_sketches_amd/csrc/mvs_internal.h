@@ -239,7 +239,7 @@ int launch_filter(hipStream_t stream, const PairwiseArgs& a, const Options& opt)
 // 1-D grid in workgroups, 0: empty, -1: too many rectangles / too large for one launch), and that launch of the ping-pong filter
 long long plan_segments(const int64_t (*blocks)[4], int n, PlanSegs* segs);
 int launch_filter_plan(hipStream_t stream, const PairwiseArgs& a, const PlanSegs& segs, long long workgroups);
-int launch_exact_pairs(hipStream_t stream, const PairwiseArgs& a, const Options& opt);
+int launch_exact_pairs(hipStream_t stream, const PairwiseArgs& a, const Options& opt, long long n_hint = -1);
 // candidate regions of the ping-pong filter: how many (workgroups x 8 waves) launch_filter's grid has for this block, 0 if
 // the variant it would pick appends with atomics only; k_cand_gather moves the regions' contents into the candidate list
 int64_t filter_region_count(const PairwiseArgs& a, const Options& opt);
@@ -293,6 +293,10 @@ int launch_cells_route(hipStream_t stream, const mvs_cell* d_raw, const unsigned
                        unsigned long long foreign_capacity, long long status, long long max_abs);
 int launch_cells_collect(hipStream_t stream, const unsigned long long* d_recv, int world, int rank, unsigned long long capacity,
                          int own_begin, int own_end, mvs_cell* d_own, unsigned long long own_capacity, unsigned long long* d_own_count);
+// the shard's cells by row buckets (rows of <= 64 cells): state block as the route / collect kernels fill it
+int launch_rows_max(hipStream_t stream, unsigned long long* d_state, int rows);
+int sort_cells_rows(hipStream_t stream, const mvs_cell* d_in, mvs_cell* d_out, int64_t n, int row0, int rows,
+                    const unsigned long long* d_state, void* d_scratch, size_t scratch_bytes, size_t* scratch_needed);
 // sort cells by (row, col); tmp buffers owned by the caller
 int sort_cells(hipStream_t stream, mvs_cell* d_cells, mvs_cell* d_tmp, int64_t n, void* d_scratch,
                size_t scratch_bytes, size_t* scratch_needed, const Options& opt);

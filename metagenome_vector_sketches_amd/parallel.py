@@ -260,9 +260,10 @@ class GpuOps:
         import torch
         return torch.zeros(nbytes, dtype=torch.int8, device=self.device)
 
-    def new_counter(self):
+    def new_counter(self, rows=0):
+        """the shard's state block (mvs_cells_route): count, largest row, one uint32 per own row (+ one)"""
         import torch
-        return torch.zeros(1, dtype=torch.int64, device=self.device)
+        return torch.zeros(2 + (rows + 2) // 2, dtype=torch.int64, device=self.device)
 
     def zero_count(self):
         """a count reference (what plan_finish returns) that reads zero: a rank whose comparison failed routes nothing"""
@@ -335,11 +336,15 @@ class GpuOps:
     def cells_collect(self, recv, world, rank, cap_f, own, own_out, d_own):
         self.ctx.cells_collect(recv, world, rank, cap_f, own[0], own[1], own_out, d_own)
 
-    def cells_report(self, recv, world, cap_f, d_own):
-        return self.ctx.cells_report(recv, world, cap_f, d_own)
+    def cells_report(self, recv, world, cap_f, own, d_own):
+        return self.ctx.cells_report(recv, world, cap_f, own[1] - own[0], d_own)
 
-    def sort_cells(self, cells_in, n, cells_out):
-        self.ctx.cells_sort(cells_in, n, cells_out)
+    def sort_cells(self, cells_in, n, cells_out, own=None, d_own=None, max_row=None):
+        """(row, col) order: by row buckets when no row holds more than 64 cells (the usual shard), else the general sort"""
+        if own is not None and max_row is not None and max_row <= 64:
+            self.ctx.cells_sort_rows(cells_in, n, own[0], own[1], d_own, cells_out)
+        else:
+            self.ctx.cells_sort(cells_in, n, cells_out)
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -370,6 +375,7 @@ class ShardedComparison:
         self._key = None
         self._planes = self._coarse = self._stats = self._n2 = self._sset = None
         self._raw = self._own = self._xbuf = self._d_own = None
+        self._d_own_rows = 0
         self._cap_f = 1 << 14
         self._step = None
         self._ev = None
@@ -546,8 +552,8 @@ class ShardedComparison:
                 self._raw = ops.new_cells(want_raw)
             if self._own is None or self._own.shape[0] < cap:
                 self._own = ops.new_cells(cap)
-            if self._d_own is None:
-                self._d_own = ops.new_counter()
+            if self._d_own is None or self._d_own_rows < re - rb:
+                self._d_own, self._d_own_rows = ops.new_counter(re - rb), re - rb
             if need_compute and status == 0:
                 try:
                     d_cnt = self._compare(st, plan, mirror, keep_mode, first=(attempt == 0))
@@ -568,7 +574,7 @@ class ShardedComparison:
                 self.coll.submit(lambda: self.coll.allgather_blocks(xb, stride)).wait()
                 if mirror:
                     ops.cells_collect(xb, world, rank, cap_f, (rb, re), self._own, self._d_own)
-            n_out, heads = ops.cells_report(xb, world, cap_f, self._d_own)            # the step's second (last) host sync
+            n_out, heads, max_row = ops.cells_report(xb, world, cap_f, (rb, re), self._d_own)   # the step's second (last) host sync
             worst = max(int(h[1]) for h in heads)
             if worst:
                 raise err if err is not None else _capi.MvsError(worst, "another rank failed in its block comparisons")
@@ -606,7 +612,7 @@ class ShardedComparison:
                                  needed=n_out)
         out = cells_out if cells_out is not None else ops.new_cells(max(n_out, 1))
         if n_out:
-            ops.sort_cells(self._own, n_out, out)
+            ops.sort_cells(self._own, n_out, out, (rb, re), self._d_own, max_row)
         self._trace("cells sorted")
         info["exchanged_cells"] = int(heads[rank][0]) if mirror else 0
         info["blocks"] = len(plan)

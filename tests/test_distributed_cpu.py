@@ -56,7 +56,7 @@ class OracleOps:
     def new_cells(self, capacity):
         return torch.zeros((capacity, 4), dtype=torch.int32)
 
-    def new_counter(self):
+    def new_counter(self, rows=0):
         return torch.zeros(1, dtype=torch.int64)
 
     def zero_count(self):
@@ -200,15 +200,15 @@ class OracleOps:
             n_own += len(got)
         d_own[0] = n_own
 
-    def cells_report(self, recv, world, cap_f, d_own):
+    def cells_report(self, recv, world, cap_f, own, d_own):
         stride = 64 + 16 * cap_f
         heads = []
         for p in range(world):
             h = recv[p * stride:p * stride + 64].numpy().view(np.int64)
             heads.append(tuple(int(x) for x in h[:5]))
-        return int(d_own[0]), heads
+        return int(d_own[0]), heads, 1 << 30
 
-    def sort_cells(self, cells_in, n, cells_out):
+    def sort_cells(self, cells_in, n, cells_out, own=None, d_own=None, max_row=None):
         a = cells_in[:n].numpy()
         cells_out[:n] = torch.from_numpy(a[np.lexsort((a[:, 1], a[:, 0]))])
 

@@ -64,7 +64,8 @@ class Split:
         cap = cap or max(4096, 400 * self.n)
         raw = torch.empty((2 * cap, 4), dtype=torch.int32, device=DEV)
         own = torch.empty((cap, 4), dtype=torch.int32, device=DEV)
-        d_own = torch.zeros(1, dtype=torch.int64, device=DEV)
+        b, e = parallel.shard_rows(self.n, world, rank)
+        d_own = torch.full((2 + (e - b + 2) // 2,), -1, dtype=torch.int64, device=DEV)    # the state block: route clears it
         plan = parallel.block_plan(world, rank, P, symmetric=symmetric)
         mirror = symmetric and world > 1
         ctx.plan_begin(self.sset, self.n2, rank * P, (rank + 1) * P, mirror, raw, keep_mode=keep_mode)
@@ -76,11 +77,10 @@ class Split:
         d_cnt = ctx.plan_finish()
         cap_f = cap if cap_f is None else cap_f
         send = torch.zeros(_capi.CELLS_HEADER_BYTES + 16 * cap_f, dtype=torch.uint8, device=DEV)
-        b, e = parallel.shard_rows(self.n, world, rank)
         ctx.cells_route(raw, d_cnt, P, self.rps, self.n, b, e, own, d_own, send, cap_f, status=0, max_abs=123 + rank)
-        n_own, heads = ctx.cells_report(send, 1, cap_f, d_own)
+        n_own, heads = ctx.cells_report(send, 1, cap_f, e - b, d_own)[:2]
         assert heads[0][1] == 0 and heads[0][2] == 123 + rank and (heads[0][3] <= heads[0][4] or cap < 4096)
-        return own[:n_own].cpu().numpy(), send, ctx.plan_stats(), heads[0]
+        return own[:n_own].cpu().numpy(), send, ctx.plan_stats(), heads[0], own, d_own
 
 
 def _union(split, symmetric=True, chunks=1, keep_mode=_capi.KEEP_INT32):
@@ -92,18 +92,20 @@ def _union(split, symmetric=True, chunks=1, keep_mode=_capi.KEEP_INT32):
     shards = []
     for r in range(world):
         b, e = parallel.shard_rows(split.n, world, r)
-        own_np = per_rank[r][0]
-        own = torch.empty((len(own_np) + int(sum(h[3][0] for h in per_rank)) + 1, 4), dtype=torch.int32, device=DEV)
-        own[:len(own_np)] = torch.from_numpy(own_np).to(DEV)
-        d_own = torch.tensor([len(own_np)], dtype=torch.int64, device=DEV)
+        own, d_own = per_rank[r][4], per_rank[r][5]                  # the rank's own cells and its state block, as routed
         ctx.cells_collect(recv, world, r, cap_f, b, e, own, d_own)
-        n_out, heads = ctx.cells_report(recv, world, cap_f, d_own)
-        assert [h[2] for h in heads] == [123 + k for k in range(world)]
+        n_out, heads, max_row = ctx.cells_report(recv, world, cap_f, e - b, d_own)
+        assert [h[2] for h in heads] == [123 + k for k in range(world)] and n_out <= own.shape[0]
         got = own[:n_out].cpu().numpy()
         assert np.all((got[:, 0] >= b) & (got[:, 0] < e))
+        assert max_row == (np.bincount(got[:, 0] - b).max() if n_out else 0)
         out = torch.empty((max(n_out, 1), 4), dtype=torch.int32, device=DEV)
         if n_out:
             ctx.cells_sort(own, n_out, out)
+            if max_row <= 64:                                            # the row-bucket sort: the same order
+                out2 = torch.zeros_like(out)
+                ctx.cells_sort_rows(own, n_out, b, e, d_own, out2)
+                assert torch.equal(out2[:n_out], out[:n_out])
         shards.append(out[:n_out].cpu().numpy())
     return np.concatenate(shards), per_rank
 
@@ -164,9 +166,9 @@ def test_plan_int16_keep_mode_and_overflow_reporting(ctx):
     got, _ = _union(split, keep_mode=_capi.KEEP_INT16)
     assert np.array_equal(got, want)
     # a raw list and a send buffer that are too small: nothing is written out of bounds, the header says how much there was
-    own, send, st, head = split.rank_cells(0, cap=64, cap_f=16)
+    own, send, st, head = split.rank_cells(0, cap=64, cap_f=16)[:4]
     assert head[3] > head[4] == 128                                    # raw cells > raw capacity
-    own, send, st, head = split.rank_cells(0, cap_f=16)
+    own, send, st, head = split.rank_cells(0, cap_f=16)[:4]
     assert head[0] > 16 and head[3] <= head[4]                         # more mirror images than the buffer holds
 
 

@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""Stage times of ONE rank of a G-way strong-scaled pairwise step, measured on one GPU, + a link model -> predicted scaling.
+
+    python tools/strong_model.py [N] [d] [--ranks 1,2,4,8] [--link-GBps 61,122] [--chunks 2]
+
+No multi-GPU node is needed: the storage buffers of all G ranks (per-rank blocks padded to 256 rows: _capi.shard_layout) are
+built on the one device, then rank 0's step runs exactly as parallel.ShardedComparison runs it -- re-code + derive its OWN
+rows (k_recode_rows), its block plan of the symmetric schedule (diagonal block, then the peers' blocks in `chunks` launches:
+mvs_plan_begin / _filter / _finish), kept cells routed and sorted -- with every byte the exchange would have delivered
+already in place.  What is measured: the device time of every stage for the per-rank problem size (events on the stream),
+and the host-visible step time without any exchange.  What is modelled: the exchange.  Per rank and peer the all-gathers move
+P * 24 bytes (statistics + norms), P * d_pad bytes (coarse plane, in `chunks` pieces) and P * 2 * d_pad bytes (limb planes),
+P = padded rows per rank; on the fully connected xGMI mesh every peer's block arrives over its own link, so a gather takes
+block bytes / link rate (+ a latency per collective).  The filter of the diagonal block starts at once; the peers' chunk c
+can start when chunk c of the coarse plane has landed; the re-check needs the limb planes.  The model walks that timeline.
+Link rates: MI355X xGMI is 153.6 GB/s per link bidirectional = 76.8 GB/s per direction (the task statement quotes ~153 GB/s
+per link); 61 GB/s = 80 % of one direction (conservative), 122 GB/s = 80 % of 153 (optimistic).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+import metagenome_vector_sketches_amd as pkg
+from metagenome_vector_sketches_amd import _capi, parallel, synth
+
+
+def fast_norm_sq(sumsq, d):
+    x = np.sqrt(sumsq.astype(np.float64) / d)
+    return np.array([float("%g" % v) for v in x]) ** 2
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("n", nargs="?", type=int, default=100_000)
+    ap.add_argument("d", nargs="?", type=int, default=2048)
+    ap.add_argument("--ranks", default="1,2,4,8")
+    ap.add_argument("--link-GBps", default="61,122")
+    ap.add_argument("--latency-us", type=float, default=20.0, help="per collective")
+    ap.add_argument("--chunks", type=int, default=2)
+    ap.add_argument("--reps", type=int, default=8)
+    ap.add_argument("--seed", type=int, default=2345)
+    ap.add_argument("--out", default="")
+    args = ap.parse_args()
+    dev = torch.device("cuda", 0)
+    ctx = pkg.Context(0)
+    ctx.set_stream(torch.cuda.current_stream())
+    ctx.set_timing(True)
+    n, d = args.n, args.d
+    sk = synth.make_sketches_torch(n, d, 50_000, seed=args.seed, device=dev)
+    ss = torch.empty(n, dtype=torch.int64, device=dev)
+    ctx.sumsq(sk, out=ss)
+    n2 = torch.from_numpy(fast_norm_sq(ss.cpu().numpy(), d)).to(dev)
+    out = {"n": n, "d": d, "chunks": args.chunks, "ranks": {}}
+    base_ms = None
+    for G in [int(x) for x in args.ranks.split(",")]:
+        rps, P = _capi.shard_layout(n, G)
+        n_st = P * G
+        n_alloc, d_pad, nbytes = ctx.limb_geometry(n_st, d, 2)
+        planes = torch.zeros(nbytes, dtype=torch.int8, device=dev)
+        coarse = torch.zeros(n_alloc * d_pad, dtype=torch.uint8, device=dev)
+        stats = torch.zeros(n_alloc * 16, dtype=torch.uint8, device=dev)
+        n2_st = torch.zeros(n_alloc, dtype=torch.float64, device=dev)
+        sset = ctx.sketch_set_from_planes(planes, n_st, n_alloc, d, d_pad, 2)
+        ctx.attach_derived(sset, coarse, stats)
+        for r in range(G):                                      # what the exchange would have delivered
+            b, e = parallel.shard_rows(n, G, r)
+            ctx.recode_rows(sset, sk[b:e] if e > b else None, r * P, P)
+            n2_st[r * P:r * P + (e - b)] = n2[b:e]
+        b0, e0 = parallel.shard_rows(n, G, 0)
+        cap = max(1 << 21, 40 * (e0 - b0) + (1 << 20))
+        raw = torch.empty((2 * cap, 4), dtype=torch.int32, device=dev)
+        own = torch.empty((cap, 4), dtype=torch.int32, device=dev)
+        outc = torch.empty((cap, 4), dtype=torch.int32, device=dev)
+        d_own = torch.zeros(2 + (e0 - b0 + 2) // 2, dtype=torch.int64, device=dev)      # the shard's state block
+        send = torch.zeros(_capi.CELLS_HEADER_BYTES + 16 * cap, dtype=torch.uint8, device=dev)
+        plan = parallel.block_plan(G, 0, P)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(8)]
+        acc = []
+        for rep in range(args.reps + 2):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ev[0].record()
+            ctx.recode_rows(sset, sk[b0:e0], 0, P)              # own rows only
+            ev[1].record()
+            ctx.plan_begin(sset, n2_st, 0, P, G > 1, raw)
+            ctx.plan_filter(plan[:1])
+            ev[2].record()
+            for (c0, c1) in parallel.chunk_bounds(P, args.chunks):
+                blocks = parallel.clip_blocks(plan[1:], P, c0, c1)
+                if blocks:
+                    ctx.plan_filter(blocks)
+            ev[3].record()
+            d_cnt = ctx.plan_finish()
+            ev[4].record()
+            ctx.cells_route(raw, d_cnt, P, rps, n, b0, e0, own, d_own, send, cap)
+            n_own, heads, max_row = ctx.cells_report(send, 1, cap, e0 - b0, d_own)
+            ev[5].record()
+            if n_own and max_row <= 64:
+                ctx.cells_sort_rows(own, n_own, b0, e0, d_own, outc)
+            elif n_own:
+                ctx.cells_sort(own, n_own, outc)
+            ev[6].record()
+            torch.cuda.synchronize()
+            wall = (time.perf_counter() - t0) * 1e3
+            if rep >= 2:
+                ps = ctx.plan_stats()
+                acc.append({"wall_ms": wall, "prepare_ms": ev[0].elapsed_time(ev[1]), "diag_filter_ms": ev[1].elapsed_time(ev[2]),
+                            "peer_filters_ms": ev[2].elapsed_time(ev[3]), "finish_ms": ev[3].elapsed_time(ev[4]),
+                            "route_report_ms": ev[4].elapsed_time(ev[5]), "sort_ms": ev[5].elapsed_time(ev[6]),
+                            "filter_kernels_ms": ps["filter_ms"], "recheck_ms": ps["recheck_ms"], "tiles_ms": ps["tiles_ms"],
+                            "filter_tiles": ps["filter_tiles"], "filter_launches": ps["filter_launches"], "candidates": ps["candidates"],
+                            "flagged_tiles": ps["flagged_tiles"], "own_cells": int(n_own), "foreign_cells": int(heads[0][0])})
+        m = {k: float(np.mean([a[k] for a in acc])) for k in acc[0]}
+        m["rows_per_rank_padded"] = P
+        m["plan_blocks"] = len(plan)
+        if base_ms is None:
+            base_ms = m["wall_ms"]
+        # ---- the exchange, modelled ----
+        models = {}
+        for rate in [float(x) for x in args.link_GBps.split(",")]:
+            lat = args.latency_us * 1e-3
+            small = lat + P * 24 / (rate * 1e6) if G > 1 else 0.0                       # ms
+            chunks = parallel.chunk_bounds(P, args.chunks)
+            t_comm, arrive = m["prepare_ms"] + small, []
+            for (c0, c1) in chunks:
+                t_comm += (lat + (c1 - c0) * d_pad / (rate * 1e6)) if G > 1 else 0.0
+                arrive.append(t_comm)
+            planes_at = t_comm + ((lat + P * 2 * d_pad / (rate * 1e6)) if G > 1 else 0.0)
+            # compute stream: prepare, diagonal filter, then the chunk launches (each waits for its chunk), finish waits for the planes
+            t = m["prepare_ms"] + m["diag_filter_ms"]
+            per_chunk = m["peer_filters_ms"] / max(1, len(chunks))
+            waited = 0.0
+            for a in arrive:
+                if G > 1 and a > t:
+                    waited += a - t
+                    t = a
+                t += per_chunk if len(plan) > 1 else 0.0
+            if G > 1 and planes_at > t:
+                waited += planes_at - t
+                t = planes_at
+            t += m["finish_ms"] + m["route_report_ms"]
+            exch = (lat + (64 + 16 * m["foreign_cells"] * 1.25) / (rate * 1e6)) if G > 1 else 0.0   # the mirrored cells
+            t += exch + m["sort_ms"]
+            host_gap = max(0.0, m["wall_ms"] - (m["prepare_ms"] + m["diag_filter_ms"] + m["peer_filters_ms"] + m["finish_ms"] +
+                                                m["route_report_ms"] + m["sort_ms"]))
+            t += host_gap
+            models["%g GB/s per link and direction" % rate] = {"step_ms": t, "exposed_exchange_ms": waited + exch,
+                                                               "speedup_vs_1gpu_measured": base_ms / t}
+        m["model"] = models
+        out["ranks"][str(G)] = m
+        print("G=%d  P=%d  wall %.3f ms (no exchange)  prepare %.3f  diag %.3f  peers %.3f  finish %.3f  route %.3f  sort %.3f | "
+              "filter kernels %.3f (%d tiles, %d launches)  re-check %.3f  tiles %.3f" %
+              (G, P, m["wall_ms"], m["prepare_ms"], m["diag_filter_ms"], m["peer_filters_ms"], m["finish_ms"], m["route_report_ms"],
+               m["sort_ms"], m["filter_kernels_ms"], m["filter_tiles"], m["filter_launches"], m["recheck_ms"], m["tiles_ms"]))
+        for k, v in models.items():
+            print("      %s: step %.3f ms (exchange exposed %.3f) -> %.2f x the measured 1-GPU step" %
+                  (k, v["step_ms"], v["exposed_exchange_ms"], v["speedup_vs_1gpu_measured"]))
+        sset.close()
+        del planes, coarse, stats, n2_st, raw, own, outc, send
+        torch.cuda.empty_cache()
+    if args.out:
+        with open(args.out, "w") as f:
+            json.dump(out, f, indent=1)
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()
