@@ -2606,9 +2606,16 @@ __global__ __launch_bounds__(256) void k_dense_fill(const uint8_t* __restrict__ 
                                                     uint8_t* __restrict__ q, long long row_rel0, int tr0, int n_tc,
                                                     const int* __restrict__ list, const int* __restrict__ list_n,
                                                     const int2* __restrict__ ends, const DenseSizes out) {
+    // A lane scatters a RUN of up to 16 entries starting at its prefix position; in a dense row those positions are 16 apart,
+    // i.e. 16 words (columns) or 4 words (q bytes) apart: a 16-way / 4-way bank conflict on every store of the loop
+    // (SQ_LDS_BANK_CONFLICT 2.8e7 cycles per launch, round 4).  One pad word per 16 entries (columns: index i lives at
+    // i + i / 16, a stride of 17 words; q: byte i at i + 4 * (i / 16), a stride of 5 words -- both odd) spreads the lanes of a
+    // store over all 64 banks; the contiguous read-out below stays conflict free.
     __shared__ unsigned wsum[2][4];
-    __shared__ int32_t s_col[256 * 16];
-    __shared__ uint8_t s_q[256 * 16];
+    __shared__ int32_t s_col[256 * 16 + 256];
+    __shared__ uint8_t s_q[256 * 16 + 4 * 256];
+    auto ci = [](unsigned i) { return i + (i >> 4); };
+    auto qi = [](unsigned i) { return i + ((i >> 4) << 2); };
     __shared__ unsigned long long red_s[4];
     __shared__ unsigned red_q[4];
     const uint8_t* row = dense + (long long)blockIdx.x * ld;
@@ -2674,24 +2681,24 @@ __global__ __launch_bounds__(256) void k_dense_fill(const uint8_t* __restrict__ 
         while (m) {
             const int b = __ffs((int)m) - 1;
             m &= m - 1;
-            s_col[at] = (int32_t)(k + b);
-            s_q[at] = (uint8_t)((unsigned)wv[b >> 2] >> (8 * (b & 3)));
+            s_col[ci(at)] = (int32_t)(k + b);
+            s_q[qi(at)] = (uint8_t)((unsigned)wv[b >> 2] >> (8 * (b & 3)));
             ++at;
         }
         __syncthreads();
         for (unsigned i = threadIdx.x; i < total; i += 256) {
-            const int32_t cv = s_col[i];
-            const unsigned qv = s_q[i];
+            const int32_t cv = s_col[ci(i)];
+            const unsigned qv = s_q[qi(i)];
             col[base + i] = cv;
             q[base + i] = (uint8_t)qv;
             if (SIZES) {
                 qmax = qv > qmax ? qv : qmax;
-                if (i > 0) quot += (unsigned long long)(unsigned)(cv - s_col[i - 1]) >> rice_k;
+                if (i > 0) quot += (unsigned long long)(unsigned)(cv - s_col[ci(i - 1)]) >> rice_k;
                 else if (have_prev) quot += (unsigned long long)(unsigned)(cv - prev_last) >> rice_k;
             }
         }
         if (SIZES && total) {
-            prev_last = s_col[total - 1];
+            prev_last = s_col[ci(total - 1)];
             have_prev = true;
         }
         base += total;
@@ -3167,7 +3174,7 @@ int launch_filter(hipStream_t stream, const PairwiseArgs& a, const Options& opt)
     // opt.filter_variant: tile shape / ring depth of the one-pass filter.
     // Default (-1): the ping-pong kernel on 256 x 256 tiles (half the L2 -> LDS bytes per cell of 128 x 128 tiles; its
     // two wave groups overlap copies and MFMAs: 11.4 -> 10.0 ms at 100k samples against the ring kernel on the same
-    // tiles) once the block holds enough tiles to keep 256 CUs busy through the tail, 128 x 128 ring tiles below that.
+    // tiles) from 128 tiles on (filter_variant_for), 128 x 128 ring tiles for the small blocks below that.
     const int v = filter_variant_for(a, opt);
     switch (v) {
         case 50: return launch_search_filter(stream, a);
@@ -3290,7 +3297,10 @@ static int filter_variant_for(const PairwiseArgs& a, const Options& opt) {
     if (v < 0) {
         const double tiles = (double)(a.row_end - a.row_begin) * (double)(a.col_end - a.col_begin) / 65536.0 *
                              (a.symmetric ? 0.5 : 1.0);
-        v = tiles >= 4096.0 ? 8 : 0;
+        // [r5] the ping-pong kernel on the fragment-major plane (B operand direct) wins from ~128 tiles on: symmetric
+        // 4096^2 0.032 against 0.041 ms, 10 000^2 0.126 / 0.147, 12 544 x 12 544 without symmetry 0.291 / 0.421, 26 000^2
+        // 0.594 / 0.870 (profiles/r05_exp_small_blocks.log); below that the 128 x 128 ring tiles keep more CUs busy
+        v = tiles >= 128.0 ? 8 : 0;
     }
     return v;
 }
