@@ -8,10 +8,12 @@
 #             c2d = 100k x 2048 with a 10 %-dense result streamed out (tools/stream_bench.py: two-stage comparison feeding the
 #                   dense byte matrix, rows encoded on the device)
 #             srch = 64 query sketches against 10^6 resident sketches (tools/search_bench.py: k_search_filter + re-check)
+#             c3s = the strong-scaled pairwise step on one rank (bench.py --config 3 --gpus 1: k_recode_rows, the block plan's
+#                   filter launch, re-check, flagged tiles, k_cells_route, the row-bucket sort)
 # The profiled program itself follows `--` (no env / sh wrapper); counters are collected in their own passes.
 set -u
-TAG=${1:-r04}
-WORKLOADS=${2:-"c1 c2 c2x c2d srch"}
+TAG=${1:-r05}
+WORKLOADS=${2:-"c1 c2 c2x c2d srch c3s"}
 want() { case " $WORKLOADS " in *" $1 "*) return 0;; *) return 1;; esac; }
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/$TAG
@@ -36,14 +38,15 @@ run_set() {   # name, command...
     echo "$*" > "$OUT/${name}_pmc/command.txt"
 }
 
-if want c1; then run_set c1 python3 "$REPO/bench.py" --steps 3 --warmup 2 --no-cpu-baseline --pairwise-samples 0 --stream-samples 0 --search-samples 0 --density-samples 0 || exit 1; fi
+if want c1; then run_set c1 python3 "$REPO/bench.py" --steps 3 --warmup 2 --no-cpu-baseline --pairwise-samples 0 --stream-samples 0 --search-samples 0 --density-samples 0 --strong-steps 0 || exit 1; fi
 if want c2; then export MVS_PAIRWISE_FILTER=1; run_set c2 python3 "$REPO/tools/run_pairwise.py" 100000 2048 4 || exit 1; unset MVS_PAIRWISE_FILTER; fi
 if want c2x; then export MVS_PAIRWISE_FILTER=0; run_set c2x python3 "$REPO/tools/run_pairwise.py" 100000 2048 3 || exit 1; unset MVS_PAIRWISE_FILTER; fi
 if want c2d; then run_set c2d python3 "$REPO/tools/stream_bench.py" 100000 2048 10000 2 encoded || exit 1; fi
 if want srch; then run_set srch python3 "$REPO/tools/search_bench.py" 1000000 2048 64 6 || exit 1; fi
+if want c3s; then run_set c3s python3 "$REPO/bench.py" --config 3 --gpus 1 --steps 3 --warmup 2 || exit 1; fi
 
 cd "$REPO"
-for w in c1 c2 c2x c2d srch; do
+for w in c1 c2 c2x c2d srch c3s; do
     [ -d "$OUT/${w}_stats" ] || continue
     python3 tools/pmc_summary.py --stats "$OUT/${w}_stats" > "$OUT/${w}_kernel_stats.txt"
     python3 tools/pmc_summary.py "$OUT/${w}_pmc" > "$OUT/${w}_pmc_summary.txt"
@@ -55,6 +58,7 @@ SPECS=""
 [ -d "$OUT/c2x_pmc" ] && SPECS="$SPECS configs[2]-exact=$OUT/c2x_pmc"
 [ -d "$OUT/c2d_pmc" ] && SPECS="$SPECS dense-100k=$OUT/c2d_pmc"
 [ -d "$OUT/srch_pmc" ] && SPECS="$SPECS search-64x1M=$OUT/srch_pmc"
+[ -d "$OUT/c3s_pmc" ] && SPECS="$SPECS strong-configs[2]-1rank=$OUT/c3s_pmc"
 python3 tools/pmc_summary.py --traffic "$OUT/pmc_traffic.json" $SPECS
 # keep the merged-back payload small: the raw per-dispatch CSVs of the PMC passes are summarised above
 find "$OUT" -name "*_counter_collection.csv" -size +4M -delete

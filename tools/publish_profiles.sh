@@ -2,9 +2,9 @@
 # Copy the summaries of gpurun_out/<tag>/ (made by tools/collect_profiles.sh) into profiles/<tag>_*:
 #   bash tools/publish_profiles.sh r03
 set -e
-TAG=${1:-r04}
+TAG=${1:-r05}
 SRC=gpurun_out/$TAG
-for w in c1 c2 c2x c2d srch; do
+for w in c1 c2 c2x c2d srch c3s; do
     [ -f $SRC/${w}_kernel_stats.txt ] || continue
     grep "^k_" $SRC/${w}_kernel_stats.txt > profiles/${TAG}_${w}_kernel_stats.txt
     cp $SRC/${w}_pmc_summary.txt profiles/${TAG}_${w}_pmc_summary.txt
