@@ -1312,28 +1312,33 @@ __global__ __launch_bounds__(256) void k_tile_list(const unsigned int* __restric
     }
 }
 
-// the candidate list without the pairs whose tile is flagged (those cells come from the exact kernel): order is kept
-// within a wave's 64 entries, one atomic per wave
+// the candidate list without the pairs whose tile is flagged (those cells come from the exact kernel)
 __global__ __launch_bounds__(256) void k_cand_prune(const PairwiseArgs a, unsigned long long n_cand, int2* __restrict__ out,
                                                     unsigned long long* __restrict__ out_count) {
+    // 512 entries per wave and round (8 per lane), ONE atomic for all of them: with one per 64 entries the 6 500 atomics of a
+    // 100k comparison's list queued on the counter's line for 0.08 ms (k_cand_prune "waiting 0.99 of wave cycles", round 5)
     const int lane = threadIdx.x & 63;
     const unsigned long long waves = (unsigned long long)gridDim.x * 4;
-    for (unsigned long long base = ((unsigned long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64; base < n_cand; base += waves * 64) {
-        const unsigned long long i = base + lane;
-        bool keep = false;
-        int2 pr = make_int2(0, 0);
-        if (i < n_cand) {
-            pr = a.cand[i];
-            const int64_t t = (((int64_t)pr.x - a.row_begin) >> 8) * (int64_t)a.tile_flag_ld +
-                              (((int64_t)(pr.y & 0x7fffffff) - a.col_begin) >> 8);
-            keep = a.tile_flag[t] == 0u;
+    for (unsigned long long base = ((unsigned long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 512; base < n_cand; base += waves * 512) {
+        int2 pr[8];
+        unsigned keep = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const unsigned long long i = base + (unsigned long long)k * 64 + lane;
+            pr[k] = make_int2(0, 0);
+            if (i < n_cand) {
+                pr[k] = a.cand[i];
+                const int64_t t = (((int64_t)pr[k].x - a.row_begin) >> 8) * (int64_t)a.tile_flag_ld +
+                                  (((int64_t)(pr[k].y & 0x7fffffff) - a.col_begin) >> 8);
+                keep |= a.tile_flag[t] == 0u ? 1u << k : 0u;
+            }
         }
-        const unsigned long long m = __ballot(keep);
-        if (m == 0ULL) continue;
-        unsigned long long slot = 0;
-        if (lane == 0) slot = atomicAdd(out_count, (unsigned long long)__popcll(m));
-        slot = (unsigned long long)__shfl((long long)slot, 0, 64) + (unsigned long long)__popcll(m & ((1ULL << lane) - 1ULL));
-        if (keep) out[slot] = pr;
+        const unsigned mine = (unsigned)__popc(keep);
+        if (__ballot(mine != 0) == 0ULL) continue;
+        unsigned long long slot = wave_reserve(out_count, mine, lane);
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (keep & (1u << k)) out[slot++] = pr[k];
     }
 }
 
@@ -2915,30 +2920,49 @@ __global__ __launch_bounds__(256) void k_rows_scatter(const mvs_cell* __restrict
     }
 }
 
+// bitonic network over W lanes (W = 16: four rows per wave, W = 64: one), ascending by column; lanes without a cell hold INT_MAX
+template <int W>
+__device__ __forceinline__ void bitonic_by_col(mvs_cell& c, int lane) {
+#pragma unroll
+    for (int k = 2; k <= W; k <<= 1)
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            mvs_cell o;
+            o.row = __shfl_xor(c.row, j, 64);
+            o.col = __shfl_xor(c.col, j, 64);
+            o.dot = __shfl_xor(c.dot, j, 64);
+            o.q = __shfl_xor(c.q, j, 64);
+            const bool up = (lane & k) == 0 || k == W;        // this k-block sorts ascending (the last merge always does)
+            const bool low = (lane & j) == 0;                 // the lower lane of a pair keeps the smaller key when ascending
+            const bool take_min = up == low;
+            if (take_min ? o.col < c.col : o.col > c.col) c = o;
+        }
+}
+
 __global__ __launch_bounds__(256) void k_rows_sort(mvs_cell* __restrict__ cells, const unsigned* __restrict__ row_ptr, int rows) {
     const int lane = threadIdx.x & 63;
     const int waves = gridDim.x * 4;
-    for (int r = blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += waves) {
-        const unsigned b = row_ptr[r], cnt = row_ptr[r + 1] - b;
-        if (cnt < 2) continue;
-        mvs_cell c{0, 0x7fffffff, 0, 0};
-        if ((unsigned)lane < cnt) c = cells[b + lane];
-#pragma unroll
-        for (int k = 2; k <= 64; k <<= 1)
-#pragma unroll
-            for (int j = k >> 1; j > 0; j >>= 1) {
-                mvs_cell o;
-                o.row = __shfl_xor(c.row, j, 64);
-                o.col = __shfl_xor(c.col, j, 64);
-                o.dot = __shfl_xor(c.dot, j, 64);
-                o.q = __shfl_xor(c.q, j, 64);
-                const bool up = (lane & k) == 0;              // this k-block sorts ascending
-                const bool low = (lane & j) == 0;             // the lower lane of the pair keeps the smaller key when ascending
-                const bool take_min = up == low;
-                const bool other_smaller = o.col < c.col;
-                if (take_min ? other_smaller : !other_smaller && o.col != c.col) c = o;
-            }
-        if ((unsigned)lane < cnt) cells[b + lane] = c;
+    // a wave takes four consecutive rows: when none of them holds more than 16 cells (the usual shard: clusters of 16) each
+    // quarter of the wave sorts one row, 10 exchange steps instead of 21 on a quarter of the lanes; otherwise row by row
+    for (int r0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4; r0 < rows; r0 += waves * 4) {
+        const int rq = r0 + (lane >> 4);
+        const unsigned bq = rq < rows ? row_ptr[rq] : 0u, cq = rq < rows ? row_ptr[rq + 1] - bq : 0u;
+        if (__ballot(cq > 16u) == 0ULL) {
+            mvs_cell c{0, 0x7fffffff, 0, 0};
+            const unsigned l16 = (unsigned)lane & 15u;
+            if (l16 < cq) c = cells[bq + l16];
+            if (__ballot(cq > 1u) != 0ULL) bitonic_by_col<16>(c, lane);
+            if (l16 < cq && cq > 1u) cells[bq + l16] = c;
+            continue;
+        }
+        for (int r = r0; r < r0 + 4 && r < rows; ++r) {
+            const unsigned b = row_ptr[r], cnt = row_ptr[r + 1] - b;
+            if (cnt < 2) continue;
+            mvs_cell c{0, 0x7fffffff, 0, 0};
+            if ((unsigned)lane < cnt) c = cells[b + lane];
+            bitonic_by_col<64>(c, lane);
+            if ((unsigned)lane < cnt) cells[b + lane] = c;
+        }
     }
 }
 
@@ -3372,7 +3396,7 @@ int launch_tile_list(hipStream_t stream, const unsigned int* d_flags, int n_tr, 
 int launch_cand_prune(hipStream_t stream, const PairwiseArgs& a, unsigned long long n_cand, int2* d_out,
                       unsigned long long* d_out_count) {
     if (n_cand == 0) return 0;
-    const unsigned long long blocks = std::min<unsigned long long>(4096ULL, (n_cand + 255) / 256);
+    const unsigned long long blocks = std::min<unsigned long long>(4096ULL, (n_cand + 2047) / 2048);
     hipLaunchKernelGGL(k_cand_prune, dim3((unsigned)blocks), dim3(256), 0, stream, a, n_cand, d_out, d_out_count);
     return 0;
 }
@@ -3552,7 +3576,7 @@ int sort_cells_rows(hipStream_t stream, const mvs_cell* d_in, mvs_cell* d_out, i
     if (hipMemcpyAsync(cursor, row_ptr, tab, hipMemcpyDeviceToDevice, stream) != hipSuccess) return MVS_E_HIP;
     const unsigned blocks = (unsigned)std::min<int64_t>(2048, std::max<int64_t>(1, (n + 255) / 256));
     hipLaunchKernelGGL(k_rows_scatter, dim3(blocks), dim3(256), 0, stream, d_in, (unsigned long long)n, row0, cursor, d_out);
-    hipLaunchKernelGGL(k_rows_sort, dim3((unsigned)std::min(4096, (rows + 3) / 4)), dim3(256), 0, stream, d_out, row_ptr, rows);
+    hipLaunchKernelGGL(k_rows_sort, dim3((unsigned)std::min(4096, (rows + 15) / 16)), dim3(256), 0, stream, d_out, row_ptr, rows);
     return 0;
 }
 
