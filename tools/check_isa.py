@@ -33,7 +33,7 @@ import tempfile
 LLVM = os.environ.get("MVS_LLVM_BIN", "/opt/rocm/lib/llvm/bin")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
-KERNEL_RE = re.compile(r"k_pairwise_ppILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi1EE")
+KERNEL_RE = re.compile(r"k_pairwise_ppILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi[12]EE")    # BD = 1 or 2
 
 
 def run(cmd):
