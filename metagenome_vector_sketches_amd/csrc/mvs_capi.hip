@@ -330,6 +330,7 @@ const OptionSpec kOptions[] = {
     {"search_stream", &mvs::Options::search_stream, nullptr, 0, 1},
     {"fragment_major", &mvs::Options::fragment_major, nullptr, 0, 1},
     {"pairwise_bdirect", &mvs::Options::pairwise_bdirect, nullptr, 0, 1},
+    {"plan_strip_wgs", &mvs::Options::plan_strip_wgs, nullptr, 256, 1 << 22},
     {"pairwise_block_cells", nullptr, &mvs::Options::pairwise_block_cells, 1, (1LL << 62)},
 };
 
@@ -2989,11 +2990,10 @@ long long plan_block_tiles(const PlanState& st, const std::array<int64_t, 4>& b)
     long long t = 0;
     for (int64_t r = 0; r < n_tr; ++r) {
         const int64_t i0 = b[0] + r * 256;
-        for (int64_t k = 0; k < n_tc; ++k) {
-            const int64_t j0 = b[2] + k * 256;
-            if (j0 >= st.f0 && j0 + 256 <= i0) continue;
-            ++t;
-        }
+        // skipped in this tile row: the tiles with j0 >= f0 and j0 + 256 <= i0 (tile origins share the 256 grid)
+        const int64_t lo = std::max(b[2], st.f0), hi = std::min(b[2] + n_tc * 256, i0);      // j0 in [lo, hi - 256]
+        const int64_t skipped = hi - lo >= 256 ? (hi - lo) / 256 : 0;
+        t += n_tc - skipped;
     }
     return t;
 }
@@ -3227,7 +3227,17 @@ int mvs_plan_filter(mvs_ctx* c, const mvs_plan_block* blocks, int n_blocks) {
                              ((b.col_end & 255) != 0 && b.col_end != s->n)))
             return fail(MVS_E_INVALID, "plan block bounds must sit on multiples of 256 rows / columns");
         if (b.row_begin == b.row_end || b.col_begin == b.col_end) continue;
-        st.blocks.push_back({b.row_begin, b.row_end, b.col_begin, b.col_end});
+        // a dispatch holds at most 2^32 work-items per dimension: a rectangle whose padded grid (super-patches of 16 x 16 tiles,
+        // 256 workgroups of 512 threads each) is beyond 2^22 workgroups -- a single 1M x 1M block -- is cut into column strips of
+        // whole patch columns (4096 columns), each a rectangle of its own
+        const int64_t n_spr = ((b.row_end - b.row_begin + 255) / 256 + 15) / 16, n_spc = ((b.col_end - b.col_begin + 255) / 256 + 15) / 16;
+        const int64_t per = std::max<int64_t>(1, (int64_t)c->opt.plan_strip_wgs / (n_spr * 256));
+        if (!st.two_stage || n_spc <= per) {
+            st.blocks.push_back({b.row_begin, b.row_end, b.col_begin, b.col_end});
+        } else {
+            for (int64_t c0 = b.col_begin; c0 < b.col_end; c0 += per * 4096)
+                st.blocks.push_back({b.row_begin, b.row_end, c0, std::min<int64_t>(b.col_end, c0 + per * 4096)});
+        }
     }
     const size_t added = st.blocks.size() - first;
     if (added == 0) return MVS_OK;
@@ -3251,11 +3261,22 @@ int mvs_plan_filter(mvs_ctx* c, const mvs_plan_block* blocks, int n_blocks) {
         }
         st.tiles += plan_block_tiles(st, b);
     }
-    for (size_t k = first; k < st.blocks.size(); k += mvs::kPlanSegs) {
-        const int count = (int)std::min<size_t>(mvs::kPlanSegs, st.blocks.size() - k);
+    // one launch per group of rectangles: at most kPlanSegs of them and 2^23 - 1 workgroups (2^32 work-items) together
+    auto padded = [](const std::array<int64_t, 4>& b) {
+        return (((b[1] - b[0] + 255) / 256 + 15) / 16) * (((b[3] - b[2] + 255) / 256 + 15) / 16) * 256;
+    };
+    for (size_t k = first; k < st.blocks.size();) {
+        int count = 0;
+        int64_t wg = 0;
+        while (k + (size_t)count < st.blocks.size() && count < mvs::kPlanSegs &&
+               (count == 0 || wg + padded(st.blocks[k + (size_t)count]) < 2 * (int64_t)c->opt.plan_strip_wgs)) {
+            wg += padded(st.blocks[k + (size_t)count]);
+            ++count;
+        }
         const int rc = plan_launch(c, st, k, count);
         if (rc) return rc;
         st.groups.push_back(count);
+        k += (size_t)count;
     }
     return MVS_OK;
 }

@@ -78,6 +78,8 @@ struct Options {
     int search_stream = 1;          // blocks of few rows x >= 4096 columns outside the symmetric schedule: 1 = the streaming
                                     // filter (rows resident in LDS, columns streamed into the matrix cores), 0 = the tile kernels
     int stream_trace = 0;           // 1: mvs_pairwise_stream prints the host-side time line of its row blocks to stderr
+    int plan_strip_wgs = 1 << 22;   // block plans: a rectangle whose padded grid holds more workgroups than this is cut into column
+                                    // strips (a dispatch holds 2^32 work-items per dimension = 2^23 workgroups; tests lower it)
     int comm_timeout_s = 600;       // file transport: how long a rank waits for a peer's block before it gives up
     double pairwise_block_cells = 1099511627776.0;   // row-chunk bound of mvs_pairwise_rows (2^40 cells)
 };

@@ -248,3 +248,25 @@ def test_recode_rows_equals_the_separate_passes(ctx, d, dtype):
     assert np.all(out[0][1][:32 * d_pad] == 0x55) and np.all(out[0][1][80 * d_pad:] == 0x55)     # nothing outside the range
     st = out[0][2][32 * 16:80 * 16].view(np.int32).reshape(rows, 4)
     assert np.all(st[n:] == [1, 0, 0, 0]) and st[3].tolist() == [1, 0, 0, 0] and st[5, 0] == 1 and st[7, 0] > 1
+
+
+def test_plan_rectangle_beyond_one_dispatch_is_cut_into_strips(ctx):
+    """A rectangle whose padded tile grid holds more workgroups than one dispatch takes (BASELINE configs[4] on one GPU: the
+    1M x 1M diagonal block is 15 M workgroups) is cut into column strips of whole super-patch columns, launched in groups that
+    fit.  With the limit lowered (option plan_strip_wgs) the same happens at test size: same cells, same tile count, more launches."""
+    n, d = 9000, 128
+    sk = synth.make_sketches_numpy(n, d, 1000, seed=9, cluster=6)
+    n2 = _n2(sk)
+    ctx.set_option("pairwise_filter", 2)
+    split = Split(ctx, sk, n2, 2)
+    want, per_rank = _union(split)
+    launches = [x[2]["filter_launches"] for x in per_rank]
+    tiles = [x[2]["filter_tiles"] for x in per_rank]
+    try:
+        ctx.set_option("plan_strip_wgs", 512)                  # 2 patch rows x 256 -> one patch column per strip
+        got, per2 = _union(split)
+    finally:
+        ctx.set_option("plan_strip_wgs", 1 << 22)
+    assert np.array_equal(got, want) and len(want) > 4 * n
+    assert [x[2]["filter_tiles"] for x in per2] == tiles
+    assert all(b > a for a, b in zip(launches, [x[2]["filter_launches"] for x in per2]))
