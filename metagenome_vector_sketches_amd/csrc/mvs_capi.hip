@@ -1603,7 +1603,7 @@ bool two_stage_applies(mvs_ctx* c, const mvs_sketch_set* s, int64_t rb, int64_t 
     const bool few_rows_again = c->few_rows_id == s->id && c->few_rows_gen == s->gen;
     // ... unless the coarse plane is there already: the streaming filter then reads half the bytes the streaming exact kernel
     // does (one coarse plane against two limb planes) and has the matrix cores for the products (16 rows x 10^6 columns:
-    // 1.44 ms exact)
+    // 1.44 ms exact, see LABNOTES.md section 7)
     mvs::PairwiseArgs probe{};
     probe.limbs = s->limbs;
     probe.d_pad = s->d_pad;

@@ -244,7 +244,7 @@ __global__ __launch_bounds__(WM * WN * 64, (AT * BT > 2 ? 1 : 2)) void k_pairwis
 
     // Symmetric schedule (row_begin % TM == 0, col_begin == 0, TN | TM): inside the square
     // [row_begin,row_end)^2 a tile strictly below the diagonal is skipped; its cells come from the tile
-    // strictly above the diagonal that holds their transposes (DESIGN.md K2 has the covering argument).
+    // strictly above the diagonal that holds their transposes (DESIGN.md section 4 has the covering argument).
     bool mirror_tile = false;
     if (MODE != 1 && a.symmetric) {
         if (j0 >= a.sym_begin && j0 + TN <= i0) return;
@@ -1107,7 +1107,7 @@ __global__ __launch_bounds__(256) void k_cand_gather(const PairwiseArgs a, unsig
 // Streaming filter for a few rows against very many columns (a search: 1 .. 1023 query sketches against a resident
 // database; one of very many shards).  The tile kernels above fetch 64-byte k-slices of 256 columns per workgroup
 // through LDS and live on L2 reuse between neighbouring tiles; a block a few rows high has none, and they ran at
-// 1.3-3 TB/s of the 8 TB/s HBM peak.  Here the ROWS are resident -- the coarse plane of 16 * RB
+// 1.3-3 TB/s of the 8 TB/s HBM peak (LABNOTES.md: section 7, round 3).  Here the ROWS are resident -- the coarse plane of 16 * RB
 // query rows in LDS (row stride d_pad + 16 bytes: the 16 rows a ds_read_b128 touches fall into 16 different bank groups) --
 // and the COLUMNS stream: a lane loads 16 consecutive k-bytes of one column's coarse row straight from global memory,
 // which is exactly the B fragment of v_mfma_i32_16x16x64_i8 (column = lane & 15, k quarter = lane >> 4), three k-slices
@@ -1751,7 +1751,7 @@ __device__ __forceinline__ void limbs_to_i16(uint32_t lo, uint32_t hi, int& w01,
 // c + a.lo * b.lo + a.hi * b.hi on int16 pairs, mod 2^32 (v_dot2_i32_i16).  The operands arrive as scalars on purpose:
 // __builtin_bit_cast applied directly to a vector ELEMENT (bit_cast<v2s>(vec[e])) is folded to element 0 by hipcc 7.2 -- the
 // unrolled loop below then multiplied the first dword of every 16-byte chunk four times (seen in the ISA; the same toolchain
-// fault as in the filter epilogue's maximum, DESIGN.md "toolchain note").
+// fault as in the filter epilogue's maximum, LABNOTES.md "Toolchain note").
 __device__ __forceinline__ int dot2_i16(int a, int b, int c) {
     using v2s = __attribute__((ext_vector_type(2))) short;
     return __builtin_amdgcn_sdot2(__builtin_bit_cast(v2s, a), __builtin_bit_cast(v2s, b), c, false);
