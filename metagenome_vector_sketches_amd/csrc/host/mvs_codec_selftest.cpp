@@ -300,7 +300,12 @@ int main(int argc, char* argv[]) {
         CHECK(hn.offsets[2] - hn.offsets[1] == 1 && hn.offsets[3] - hn.offsets[2] == 1 && hn.hashes[5] == 3);
         // binary CSR cache: round trip, then stale once the text changes
         CHECK(!mvs_host::load_csr_cache(p, hl));
+        // what a killed run left behind goes away with the next cache write; a live writer's file (pid 1 stands in) stays
+        const std::string dead = mvs_host::csr_cache_path(p) + ".part.2147483646", live = mvs_host::csr_cache_path(p) + ".part.1";
+        for (const std::string& f : {dead, live}) std::ofstream(f) << "x";
         CHECK(mvs_host::write_csr_cache(p, hn));
+        CHECK(!std::filesystem::exists(dead) && std::filesystem::exists(live));
+        std::remove(live.c_str());
         mvs_host::HashSets hc;
         CHECK(mvs_host::load_csr_cache(p, hc));
         CHECK(hc.names == hn.names && hc.offsets == hn.offsets && hc.hashes.size() == hn.hashes.size());

@@ -27,6 +27,8 @@
 #include <thread>
 #include <vector>
 
+#include <cerrno>
+#include <csignal>
 #include <dlfcn.h>
 #include <fcntl.h>
 #include <sys/mman.h>
@@ -113,6 +115,25 @@ inline std::string csr_cache_path(const std::string& hash_file) { return hash_fi
 // must not write into each other's file)
 inline std::string csr_cache_part_path(const std::string& hash_file) {
     return csr_cache_path(hash_file) + ".part." + std::to_string((long)::getpid());
+}
+
+// ".part.<pid>" files next to `hash_file` whose writer no longer exists (a killed run leaves up to the size of the cache
+// behind): removed before a new cache is written.  A pid that cannot be probed (another user's process) is left alone.
+inline void remove_stale_cache_parts(const std::string& hash_file) {
+    namespace fs = std::filesystem;
+    std::error_code ec;
+    const fs::path cache(csr_cache_path(hash_file));
+    const fs::path dir = cache.parent_path().empty() ? fs::path(".") : cache.parent_path();
+    const std::string prefix = cache.filename().string() + ".part.";
+    for (fs::directory_iterator it(dir, ec), end; !ec && it != end; it.increment(ec)) {
+        const std::string name = it->path().filename().string();
+        if (name.size() <= prefix.size() || name.compare(0, prefix.size(), prefix) != 0) continue;
+        const std::string tail = name.substr(prefix.size());
+        if (tail.find_first_not_of("0123456789") != std::string::npos || tail.size() > 10) continue;
+        const long pid = std::strtol(tail.c_str(), nullptr, 10);
+        if (pid <= 0 || pid == (long)::getpid()) continue;
+        if (::kill((pid_t)pid, 0) != 0 && errno == ESRCH) ::unlink(it->path().c_str());
+    }
 }
 
 inline bool text_identity(const std::string& path, uint64_t& size, int64_t& mtime_ns) {
@@ -556,6 +577,7 @@ inline bool read_hash_file(const std::string& path, bool with_names, HashSets& o
         job = std::make_shared<CacheJob>();
         job->text = cache_for;
         job->part = csr_cache_part_path(cache_for);
+        remove_stale_cache_parts(cache_for);
         if (text_identity(cache_for, job->head.text_size, job->head.text_mtime_ns))
             job->fd = ::open(job->part.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
         if (job->fd < 0) {
@@ -605,8 +627,19 @@ inline bool read_hash_file(const std::string& path, bool with_names, HashSets& o
                     }
                 }
             };
-            for (int t = 0; t < 3; ++t) job->helpers.emplace_back(writer, job);
             got = job->got.get();
+            try {
+                for (int t = 0; t < 3; ++t) job->helpers.emplace_back(writer, job);
+            } catch (const std::exception&) {
+                // no thread to be had: the parse goes on without the cache (a joinable thread must not be destroyed)
+                job->stop = true;
+                for (auto& th : job->helpers) th.join();
+                job->helpers.clear();
+                ::close(job->fd);
+                ::unlink(job->part.c_str());
+                got_owner = std::move(job->got);
+                job.reset();
+            }
         }
     }
     // ends the cache job on the way out of a failed parse
@@ -705,6 +738,7 @@ inline bool write_csr_cache(const std::string& hash_file, const HashSets& sets, 
     for (size_t i = 0; i < sets.names.size(); ++i) ends[i] = at += sets.names[i].size();
     h.name_bytes = at;
     const std::string path = csr_cache_path(hash_file), tmp = csr_cache_part_path(hash_file);
+    remove_stale_cache_parts(hash_file);
     // head: header, offsets, name ends, names, padding to 8
     std::string head;
     head.reserve(sizeof h + sets.offsets.size() * 8 + ends.size() * 8 + (size_t)at + 8);

@@ -1271,10 +1271,27 @@ int prepare_coarse(mvs_ctx* c, const mvs_sketch_set* s) {
     return MVS_OK;
 }
 
+// The fragment-major copies are a convenience of the matrix-core kernels (which also read the row-major planes, slower):
+// they are only made when they fit beside what the comparison itself still has to allocate -- candidate lists, kept
+// cells, the dense matrix of a streamed result -- i.e. when growing the buffer leaves the larger of 2 GiB and 1/16 of
+// the card free.  A copy that does not fit is skipped, never an error.
+bool fm_copy_fits(size_t have_bytes, size_t want_bytes) {
+    if (want_bytes <= have_bytes) return true;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return false;
+    const size_t reserve = std::max<size_t>((size_t)2 << 30, total_b / 16);
+    return free_b + have_bytes >= want_bytes + reserve;      // ensure_buf frees the old buffer before it allocates
+}
+
 // the fragment-major copy of the cached coarse plane (after prepare_coarse), built the first time a streaming search filter
-// runs on the set
-int prepare_coarse_fm(mvs_ctx* c, const mvs_sketch_set* s) {
+// runs on the set; *made = false when it was skipped for lack of room (fm_copy_fits)
+int prepare_coarse_fm(mvs_ctx* c, const mvs_sketch_set* s, bool* made) {
+    *made = true;
     if (c->coarse_fm_valid) return MVS_OK;
+    if (!fm_copy_fits(c->pw_coarse_fm_bytes, (size_t)s->n_alloc * (size_t)s->d_pad)) {
+        *made = false;
+        return MVS_OK;
+    }
     int rc = ensure_buf(c, &c->pw_coarse_fm, &c->pw_coarse_fm_bytes, (size_t)s->n_alloc * (size_t)s->d_pad);
     if (rc) return rc;
     mvs::launch_coarse_fm(c->stream, (const int8_t*)c->pw_coarse, s->n_alloc, s->d_pad, (int8_t*)c->pw_coarse_fm);
@@ -1293,6 +1310,7 @@ int attach_planes_fm(mvs_ctx* c, const mvs_sketch_set* s, mvs::PairwiseArgs& a, 
     if (!wanted || !c->opt.fragment_major || s->limbs != 2) return MVS_OK;
     if (!(c->planes_fm_id == s->id && c->planes_fm_gen == s->gen)) {
         c->planes_fm_id = 0;
+        if (!fm_copy_fits(c->pw_planes_fm_bytes, (size_t)s->n_alloc * 2 * (size_t)s->d_pad)) return MVS_OK;   // row-major kernels
         int rc = ensure_buf(c, &c->pw_planes_fm, &c->pw_planes_fm_bytes, (size_t)s->n_alloc * 2 * (size_t)s->d_pad);
         if (rc) return rc;
         mvs::launch_coarse_fm(c->stream, s->planes, s->n_alloc, s->d_pad, (int8_t*)c->pw_planes_fm, 2);
@@ -1435,9 +1453,10 @@ int two_stage_filter(mvs_ctx* c, const mvs_sketch_set* s, const double* d_n2, do
     a.coarse = (const int8_t*)c->pw_coarse;
     a.coarse_fm = nullptr;
     if (c->opt.fragment_major && mvs::filter_streams(a, c->opt)) {
-        rc = prepare_coarse_fm(c, s);
+        bool made = false;
+        rc = prepare_coarse_fm(c, s, &made);
         if (rc) return rc;
-        a.coarse_fm = (const int8_t*)c->pw_coarse_fm;
+        if (made) a.coarse_fm = (const int8_t*)c->pw_coarse_fm;
     }
     a.fmeta = (const float4*)c->pw_fmeta;
     a.cand_counter = c->d_counter + 2;
@@ -2512,7 +2531,6 @@ int pairwise_stream_impl(mvs_ctx* c, const mvs_sketch_set* s, const double* norm
     mvs::filter_tile_grid(wa, &n_tr_all, &n_tc_all);
     const int tile_o = (int)(row_begin / 256);
     enum { kNone, kM1, kM2 } matrix_mode = kNone;
-    bool probe_gave_up = false;                                      // M1: the first tile row's filter pass stopped (dense everywhere)
     TwoStage ts;                                                     // M2: the whole pass; M1: the current block's pass
     mvs::DenseActive active{};                                       // flags == NULL: every tile (plan B)
     const int saved_variant = c->opt.filter_variant;
@@ -2588,7 +2606,7 @@ int pairwise_stream_impl(mvs_ctx* c, const mvs_sketch_set* s, const double* norm
             if (rc != MVS_OK && rc != kNeedExact) return finish(rc);
             // share of flagged tiles in this row of tiles, extrapolated to the tiles of the whole pass, as list cells
             const double tiles_all = std::max(1.0, (double)n_tr_all * (double)n_tc_all - 0.5 * (double)n_tr_all * (double)(n_tr_all - 1));
-            probe_gave_up = rc == kNeedExact;
+            const bool probe_gave_up = rc == kNeedExact;                 // the pass stopped: dense everywhere (never M1 then)
             const double est = probe_gave_up ? 1e30
                                              : ((double)ts.n_flagged * 131072.0 + 2.0 * (double)ts.n_cand) / (double)n_tc_all * tiles_all;
             if (probe_gave_up) {
@@ -2694,11 +2712,9 @@ int pairwise_stream_impl(mvs_ctx* c, const mvs_sketch_set* s, const double* norm
             const size_t done = (size_t)n_tc_all;
             HIP_TRY(hipMemsetAsync((unsigned int*)c->pw_tflag + done, 0, ((size_t)n_tr_all * (size_t)n_tc_all - done) * 4, c->stream));
         }
-        if (!probe_gave_up) {
-            rc = recheck_into_matrix(ts);                            // M2: all candidates; M1: block 0's
-            if (rc) return finish(rc);
-            add_kernel_ms();                                         // filter + re-check
-        }
+        rc = recheck_into_matrix(ts);                                // M2: all candidates; M1: block 0's
+        if (rc) return finish(rc);
+        add_kernel_ms();                                             // filter + re-check
         c->st_two_stage = matrix_mode == kM1 ? 3 : 2;
     } else if (dense) {
         const size_t bytes = (size_t)(whole ? rows_all : std::min(block_rows + 256, rows_all)) * (size_t)ld;
@@ -2764,9 +2780,8 @@ int pairwise_stream_impl(mvs_ctx* c, const mvs_sketch_set* s, const double* norm
             int r = MVS_OK;
             const bool opens = k < seg_first.size() && seg_first[k];
             if (k == 0) {
-                r = probe_gave_up ? kNeedExact : MVS_OK;
-                seg_row0 = rb;
-                seg_exact = probe_gave_up;
+                seg_row0 = rb;                                       // the probe's tile row: filtered and re-checked already
+                seg_exact = false;
             } else if (opens) {
                 size_t last = k;
                 while (last + 1 < blocks.size() && !seg_first[last + 1]) ++last;
