@@ -1949,6 +1949,28 @@ __global__ __launch_bounds__(256) void k_cand_thr(const double* __restrict__ n2,
 // planes and applies the reference's keep test and quantisation.  On typical sketches (d = 2048) B is
 // about a fifth of the threshold and ~1e-4 of the unrelated pairs pass.
 // ---------------------------------------------------------------------------------------------------
+// One entry of a radix trial: the squared residual of v under radix mc (ic = 1.0f / mc).  Two-limb values only:
+// |v| <= 32896 = 128 * 256 + 128, so the radix that just avoids clamping is m <= 260, a trial radix is mc >= m - 15 * step
+// with step <= 8, and |r| is at most mc / 2 where the coarse value is not clamped and |v| - 127 mc <= 127 (m - mc) <= 15240
+// where it is: every factor fits the 24-bit multipliers (full rate; the 32-bit multiply and the 64-bit
+// multiply-add are quarter rate, and sixteen trials over every entry are what the kernels around this spend their time on),
+// and sixteen squares fit 32 bits (16 * 15240^2 = 3.72e9).
+constexpr int kTrialResidualMax = 15240;
+static_assert(16ull * kTrialResidualMax * kTrialResidualMax < (1ull << 32), "sixteen squared residuals per 32-bit partial sum");
+// (Written as instructions: left to itself the compiler turns the sum of squares into a chain of v_mad_u64_u32.)
+__device__ __forceinline__ int mad24(int a, int b, int c) {                // a * b + c, a and b within 24 bits
+    int o;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(o) : "v"(a), "v"(b), "v"(c));
+    return o;
+}
+// part += r^2 for r = v - mc * round(v / mc) clamped; neg_mc = -mc
+__device__ __forceinline__ unsigned trial_residual_acc(unsigned part, int v, float vf, int neg_mc, float ic) {
+    int c = (int)__builtin_rintf(vf * ic);
+    c = c > 127 ? 127 : (c < -127 ? -127 : c);
+    const int r = mad24(neg_mc, c, v);
+    return (unsigned)mad24(r, r, (int)part);
+}
+
 __global__ __launch_bounds__(256) void k_coarse_build(const int8_t* __restrict__ planes, int64_t n, int64_t n_alloc,
                                                       int d_pad, int8_t* __restrict__ coarse,
                                                       CoarseRow* __restrict__ rows, int radix_mode) {
@@ -1975,7 +1997,7 @@ __global__ __launch_bounds__(256) void k_coarse_build(const int8_t* __restrict__
                 const int v = (int)(int8_t)((uint32_t)l4[w] >> (8 * e)) + 256 * (int)(int8_t)((uint32_t)h4[w] >> (8 * e));
                 const int av = v < 0 ? -v : v;
                 mx = av > mx ? av : mx;
-                ss += (unsigned)(v * v);   // |v| <= 32895: the square fits 32 bits
+                ss += (unsigned)__mul24(v, v);   // |v| <= 32896: the square fits 32 bits
             }
         }
     }
@@ -2001,16 +2023,15 @@ __global__ __launch_bounds__(256) void k_coarse_build(const int8_t* __restrict__
             unsigned long long r2c = 0;
             for (int k = lane; k < chunks; k += 64) {
                 const v4i l4 = lo[k], h4 = hi[k];
+                unsigned part = 0;                             // 16 squares of |r| <= kTrialResidualMax: fits (see there)
 #pragma unroll
                 for (int w = 0; w < 4; ++w)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int v = (int)(int8_t)((uint32_t)l4[w] >> (8 * e)) + 256 * (int)(int8_t)((uint32_t)h4[w] >> (8 * e));
-                        int c = (int)rintf((float)v * ic);
-                        c = c > 127 ? 127 : (c < -127 ? -127 : c);
-                        const int r = v - mc * c;
-                        r2c += (unsigned long long)((long long)r * r);
+                        part = trial_residual_acc(part, v, (float)v, -mc, ic);
                     }
+                r2c += part;
             }
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) r2c += __shfl_xor(r2c, o, 64);
@@ -2034,9 +2055,9 @@ __global__ __launch_bounds__(256) void k_coarse_build(const int8_t* __restrict__
                 const int v = (int)(int8_t)((uint32_t)l4[w] >> (8 * e)) + 256 * (int)(int8_t)((uint32_t)h4[w] >> (8 * e));
                 int c = (int)rintf((float)v * inv);
                 c = c > 127 ? 127 : (c < -127 ? -127 : c);
-                const int r = v - m * c;   // exact, whatever the rounding above did
-                c2 += (unsigned)(c * c);
-                r2 += (unsigned)(r * r);
+                const int r = mad24(-m, c, v);   // exact, whatever the rounding above did (24-bit factors: see mad24)
+                c2 = (unsigned)mad24(c, c, (int)c2);
+                r2 = (unsigned)mad24(r, r, (int)r2);
                 packed |= (uint32_t)(uint8_t)(int8_t)c << (8 * e);
             }
             o4[w] = (int)packed;
@@ -2126,7 +2147,7 @@ __global__ __launch_bounds__(CH == 4 ? 512 : 1024) void k_recode_rows(const T* _
                     v[c][4 * w + e] = y;
                     const int ay = y < 0 ? -y : y;
                     mx = ay > mx ? ay : mx;
-                    ss += (unsigned)(y * y);
+                    ss += (unsigned)__mul24(y, y);
                 }
                 lo4[w] = (int)pl;
                 hi4[w] = (int)ph;
@@ -2154,14 +2175,12 @@ __global__ __launch_bounds__(CH == 4 ? 512 : 1024) void k_recode_rows(const T* _
             const float ic = 1.0f / (float)mc;
             unsigned long long r2c = 0;
 #pragma unroll
-            for (int c = 0; c < CH; ++c)
+            for (int c = 0; c < CH; ++c) {
+                unsigned part = 0;
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    int cc = (int)rintf((float)v[c][e] * ic);
-                    cc = cc > 127 ? 127 : (cc < -127 ? -127 : cc);
-                    const int r = v[c][e] - mc * cc;
-                    r2c += (unsigned long long)((long long)r * r);
-                }
+                for (int e = 0; e < 16; ++e) part = trial_residual_acc(part, v[c][e], (float)v[c][e], -mc, ic);
+                r2c += part;
+            }
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) r2c += __shfl_xor(r2c, o, 64);
             if (r2c < best) {
@@ -2186,9 +2205,9 @@ __global__ __launch_bounds__(CH == 4 ? 512 : 1024) void k_recode_rows(const T* _
                 const int x = v[c][4 * w + e];
                 int cc = (int)rintf((float)x * inv);
                 cc = cc > 127 ? 127 : (cc < -127 ? -127 : cc);
-                const int r = x - m * cc;
-                c2 += (unsigned)(cc * cc);
-                r2 += (unsigned)(r * r);
+                const int r = mad24(-m, cc, x);
+                c2 = (unsigned)mad24(cc, cc, (int)c2);
+                r2 = (unsigned)mad24(r, r, (int)r2);
                 packed |= (uint32_t)(uint8_t)(int8_t)cc << (8 * e);
             }
             o4[w] = (int)packed;

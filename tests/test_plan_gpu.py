@@ -254,8 +254,8 @@ def test_plan_rectangle_beyond_one_dispatch_is_cut_into_strips(ctx):
     """A rectangle whose padded tile grid holds more workgroups than one dispatch takes (BASELINE configs[4] on one GPU: the
     1M x 1M diagonal block is 15 M workgroups) is cut into column strips of whole super-patch columns, launched in groups that
     fit.  With the limit lowered (option plan_strip_wgs) the same happens at test size: same cells, same tile count, more launches."""
-    n, d = 9000, 128
-    sk = synth.make_sketches_numpy(n, d, 1000, seed=9, cluster=6)
+    n, d = 9000, 512                                           # (d = 128 keeps 5 M chance pairs: more than the test's buffers)
+    sk = synth.make_sketches_numpy(n, d, 3000, seed=9, cluster=6)
     n2 = _n2(sk)
     ctx.set_option("pairwise_filter", 2)
     split = Split(ctx, sk, n2, 2)
