@@ -392,8 +392,18 @@ int mvs_search_block(mvs_ctx* ctx, const mvs_sketch_set* set, const double* norm
  * mvs_plan_filter : the filter over these rectangles (rows inside the frame; bounds on multiples of 256 or at the set's
  *     end) as one launch.  Asynchronous: the caller orders it behind the arrival of the columns it reads.
  * mvs_plan_finish : re-check + flagged tiles.  *d_count = DEVICE address of the running cell count (it may exceed the
- *     capacity: cells beyond it were dropped, compare after reading it back).  Synchronises once in the middle. */
+ *     capacity: cells beyond it were dropped, compare after reading it back).  Synchronises once in the middle.
+ *
+ * Option plan_speculate = 1 (off by default; set it around mvs_plan_begin, where the decision is taken): a plan with the
+ *     same frame, set geometry, keep mode and capacity as the previous plan of this context sizes its second half --
+ *     candidate pruning, re-check, the launch on the flagged tiles -- from THAT plan's counts and mvs_plan_finish does not
+ *     synchronise at all: the kernels read the real counts on the device, and a last kernel checks that the sizes held.  If
+ *     they did not (more flagged tiles than twice the previous count + 64, a candidate list beyond its buffer), the cell
+ *     count reads MVS_PLAN_STALE or more: discard the cells and run the same plan again -- it will not speculate.  The
+ *     counts reach the host with the caller's next read-back (mvs_cells_report brings them along; mvs_plan_stats and the
+ *     next mvs_plan_begin wait for them if nobody has).  A steady multi-rank step thus has ONE host synchronisation. */
 #define MVS_PLAN_MIRROR_OUTSIDE 1
+#define MVS_PLAN_STALE (1ULL << 62)
 typedef struct {
     int64_t row_begin, row_end, col_begin, col_end;
 } mvs_plan_block;
@@ -413,8 +423,9 @@ int mvs_plan_filter(mvs_ctx* ctx, const mvs_plan_block* blocks, int n_blocks);
 int mvs_plan_finish(mvs_ctx* ctx, const uint64_t** d_count);
 /* What the last plan did.  ms (timing enabled, else zeros): [0] filter launches summed, [1] re-check (candidate gather,
  * pruning, k_exact_pairs), [2] exact kernel on the flagged tiles, [3] first filter launch .. end of the plan on the stream.
- * counts: [0] candidates, [1] flagged tiles, [2] 256 x 256 filter tiles computed, [3] filter launches, [4] 1 if the plan ran
- * the exact kernel block by block (no filter), [5] d_pad.  Call after the stream has drained. */
+ * counts: [0] candidates, [1] flagged tiles, [2] 256 x 256 filter tiles computed, [3] filter launches, [4] bit 0: the plan ran
+ * the exact kernel block by block (no filter), bit 1: it ran ahead of its read-backs (plan_speculate), bit 2: and its sizes
+ * did not hold (MVS_PLAN_STALE), [5] d_pad.  Call after the stream has drained. */
 int mvs_plan_stats(mvs_ctx* ctx, double ms[4], int64_t counts[6]);
 
 /* Kept cells of a plan -> this rank's shard.  A cell of the plan is in storage coordinates and, under the symmetric

@@ -231,6 +231,7 @@ class SketchSet:
 COMM_ID_BYTES = 128
 PLAN_MIRROR_OUTSIDE = 1
 CELLS_HEADER_BYTES = 64
+PLAN_STALE = 1 << 62          # mvs_plan_finish under option plan_speculate: the cell count of a plan that must run again
 
 
 class Comm:
@@ -748,8 +749,8 @@ class Context:
         cnt = (_c.c_int64 * 6)()
         _check(self.lib.mvs_plan_stats(self._h, ms, cnt))
         return {"filter_ms": ms[0], "recheck_ms": ms[1], "tiles_ms": ms[2], "span_ms": ms[3], "candidates": cnt[0],
-                "flagged_tiles": cnt[1], "filter_tiles": cnt[2], "filter_launches": cnt[3], "exact_mode": bool(cnt[4]),
-                "d_pad": cnt[5]}
+                "flagged_tiles": cnt[1], "filter_tiles": cnt[2], "filter_launches": cnt[3], "exact_mode": bool(cnt[4] & 1),
+                "speculated": bool(cnt[4] & 2), "stale": bool(cnt[4] & 4), "d_pad": cnt[5]}
 
     def cells_route(self, raw, d_n_raw, block_pad, block_rows, n_total, own_begin, own_end, own_out, d_own_count, send,
                     foreign_capacity, status=0, max_abs=0):

@@ -240,17 +240,21 @@ struct ReadBack {
     const void* src;
     size_t bytes;
 };
+int ensure_read_back(mvs_ctx* c, size_t total) {
+    if (c->rb_pinned && c->rb_bytes >= total) return MVS_OK;
+    if (c->rb_pinned) HIP_TRY(hipHostFree(c->rb_pinned));
+    c->rb_pinned = nullptr;
+    c->rb_bytes = 0;
+    const size_t want = std::max<size_t>(total * 2, (size_t)1 << 20);
+    HIP_TRY(hipHostMalloc(&c->rb_pinned, want, hipHostMallocDefault));
+    c->rb_bytes = want;
+    return MVS_OK;
+}
 int read_back(mvs_ctx* c, hipStream_t st, std::initializer_list<ReadBack> items) {
     size_t total = 0;
     for (const ReadBack& it : items) total += (it.bytes + 63) & ~(size_t)63;
-    if (c->rb_bytes < total) {
-        if (c->rb_pinned) HIP_TRY(hipHostFree(c->rb_pinned));
-        c->rb_pinned = nullptr;
-        c->rb_bytes = 0;
-        const size_t want = std::max<size_t>(total * 2, (size_t)1 << 20);
-        HIP_TRY(hipHostMalloc(&c->rb_pinned, want, hipHostMallocDefault));
-        c->rb_bytes = want;
-    }
+    const int rc_rb = ensure_read_back(c, total);
+    if (rc_rb) return rc_rb;
     size_t at = 0;
     for (const ReadBack& it : items) {
         if (it.bytes) HIP_TRY(hipMemcpyAsync((char*)c->rb_pinned + at, it.src, it.bytes, hipMemcpyDeviceToHost, st));
@@ -331,6 +335,8 @@ const OptionSpec kOptions[] = {
     {"fragment_major", &mvs::Options::fragment_major, nullptr, 0, 1},
     {"pairwise_bdirect", &mvs::Options::pairwise_bdirect, nullptr, 0, 1},
     {"plan_strip_wgs", &mvs::Options::plan_strip_wgs, nullptr, 256, 1 << 22},
+    {"recode_rows_wg", &mvs::Options::recode_rows_wg, nullptr, 8, 16},
+    {"plan_speculate", &mvs::Options::plan_speculate, nullptr, 0, 1},
     {"pairwise_block_cells", nullptr, &mvs::Options::pairwise_block_cells, 1, (1LL << 62)},
 };
 
@@ -753,8 +759,10 @@ int mvs_project_csr_stats(mvs_ctx* c, const uint64_t* hashes, int mem_hashes, co
     if (sumsq) {
         if (fused) {
             unsigned long long m = 0;
-            HIP_TRY(hipMemcpyAsync(&m, c->d_counter, 8, hipMemcpyDeviceToHost, c->stream));
-            HIP_TRY(hipStreamSynchronize(c->stream));
+            {
+                const int rb_rc = read_back(c, c->stream, {{&m, c->d_counter, 8}});
+                if (rb_rc) return rb_rc;
+            }
             *max_abs = (int64_t)m;
         } else {   // some sample spans several units: its entries are final only now
             rc = mvs_sketch_stats(c, d_out, MVS_MEM_DEVICE, n_samples, d, sumsq, MVS_MEM_DEVICE, max_abs);
@@ -889,8 +897,10 @@ int mvs_sketch_stats(mvs_ctx* c, const int32_t* sketches, int mem_in, int64_t n,
     if (mem_out == MVS_MEM_HOST)
         HIP_TRY(hipMemcpyAsync(sumsq, d_out, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
     unsigned long long m = 0;
-    HIP_TRY(hipMemcpyAsync(&m, c->d_counter, 8, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    {
+        const int rb_rc = read_back(c, c->stream, {{&m, c->d_counter, 8}});
+        if (rb_rc) return rb_rc;
+    }
     *max_abs = (int64_t)m;
     return MVS_OK;
 }
@@ -947,8 +957,10 @@ int mvs_sketch_max_abs(mvs_ctx* c, const void* sketches, int elem_bytes, int mem
     int rc = check_kernel("k_max_abs");
     if (rc) return rc;
     unsigned long long m = 0;
-    HIP_TRY(hipMemcpyAsync(&m, c->d_counter, 8, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    {
+        const int rb_rc = read_back(c, c->stream, {{&m, c->d_counter, 8}});
+        if (rb_rc) return rb_rc;
+    }
     *max_abs = (int64_t)m;
     return MVS_OK;
 }
@@ -1174,8 +1186,10 @@ int mvs_sketch_set_fill_stats(mvs_sketch_set* s, const void* sketches, int elem_
     rc = check_kernel("k_limb_split");
     if (rc) return rc;
     unsigned long long m = 0;
-    HIP_TRY(hipMemcpyAsync(&m, c->d_counter, 8, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    {
+        const int rb_rc = read_back(c, c->stream, {{&m, c->d_counter, 8}});
+        if (rb_rc) return rb_rc;
+    }
     *max_abs = (int64_t)m;
     return MVS_OK;
 }
@@ -1795,8 +1809,10 @@ int mvs_pairwise_rows(mvs_ctx* c, const mvs_sketch_set* s, const double* norms_s
                              &got);
         if (rc) return rc;
         if (got == ~0ULL) {
-            HIP_TRY(hipMemcpyAsync(&got, c->d_counter, 8, hipMemcpyDeviceToHost, c->stream));
-            HIP_TRY(hipStreamSynchronize(c->stream));
+            {
+                const int rb_rc = read_back(c, c->stream, {{&got, c->d_counter, 8}});
+                if (rb_rc) return rb_rc;
+            }
         }
         count = got;
         rb = re;
@@ -2951,8 +2967,10 @@ int mvs_pairwise_block(mvs_ctx* c, const mvs_sketch_set* s, const double* norms_
                              (unsigned long long)*n_cells, &count);
     if (rc) return rc;
     if (count == ~0ULL) {
-        HIP_TRY(hipMemcpyAsync(&count, c->d_counter, 8, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
+        {
+            const int rb_rc = read_back(c, c->stream, {{&count, c->d_counter, 8}});
+            if (rb_rc) return rb_rc;
+        }
     }
     *n_cells = (int64_t)count;
     if ((int64_t)count > capacity)
@@ -2984,6 +3002,18 @@ struct PlanState {
     size_t ev_used = 0;
     hipEvent_t e_chk0 = nullptr, e_chk1 = nullptr, e_tiles1 = nullptr;
     bool timed = false, finished = false;
+    // Running ahead of the read-backs (option plan_speculate): a plan of the same shape as the previous one sizes its second
+    // half -- pruning, re-check, flagged tiles -- from THAT plan's counts and does not wait for its own; every kernel reads the
+    // real counts on the device, k_plan_verdict says at the end whether the sizes held (if not, the cell count reads
+    // kPlanStale and the caller runs the plan again: it will not speculate).  The counts come to the host with the next
+    // read-back anybody does: mvs_cells_report's, or plan_resolve's own.
+    bool speculate = false;               // this plan
+    bool pending = false;                 // its counts are still on the device only
+    bool stale = false;                   // (after the counts came in) its sizes did not hold
+    bool hints_valid = false;
+    long long hint_cand = 0, hint_flagged = 0;
+    std::array<int64_t, 8> hint_key{};    // the shape the hints belong to
+    std::array<int64_t, 8> key{};
 };
 
 static void plan_state_free(mvs_ctx* c) {
@@ -3011,6 +3041,32 @@ long long plan_block_tiles(const PlanState& st, const std::array<int64_t, 4>& b)
         t += n_tc - skipped;
     }
     return t;
+}
+
+// the counter block of a finished speculative plan, as read back: its counts become the next plan's hints
+void plan_take_counts(mvs_ctx* c, PlanState& st, const unsigned long long* back) {
+    st.pending = false;
+    st.candidates = (long long)back[2];
+    st.flagged = (long long)back[13];
+    st.stale = back[12] != 0;
+    c->last_candidates = back[2];
+    c->last_flagged_tiles = (long long)back[13];
+    c->last_filter_tiles = st.tiles;
+    st.hints_valid = !st.stale;
+    st.hint_cand = st.candidates;
+    st.hint_flagged = st.flagged;
+    st.hint_key = st.key;
+}
+
+// waits for a speculative plan's counts if nobody has fetched them yet
+int plan_resolve(mvs_ctx* c) {
+    PlanState* st = c->plan;
+    if (!st || !st->pending) return MVS_OK;
+    unsigned long long back[33];
+    const int rc = read_back(c, c->stream, {{back, c->d_counter, sizeof(back)}});
+    if (rc) return rc;
+    plan_take_counts(c, *st, back);
+    return MVS_OK;
 }
 
 int plan_reset_counters(mvs_ctx* c, PlanState& st, bool cells_too) {
@@ -3119,7 +3175,8 @@ int mvs_sketch_set_recode_rows(mvs_ctx* c, mvs_sketch_set* s, const void* sketch
     int8_t* planes = const_cast<int8_t*>(s->planes) + row_first * (int64_t)mvs::planes_of(s->limbs) * s->d_pad;
     if (s->limbs == 2 && s->ext_coarse_fm &&
         mvs::launch_recode_rows(c->stream, sketches, elem_bytes, n_rows, row_count, s->d, s->d_pad, planes,
-                                s->ext_coarse_fm + row_first * (int64_t)s->d_pad, s->ext_rows + row_first, c->opt.coarse_radix))
+                                s->ext_coarse_fm + row_first * (int64_t)s->d_pad, s->ext_rows + row_first, c->opt.coarse_radix,
+                                c->opt.recode_rows_wg))
         return check_kernel("k_recode_rows");
     // other limb codes, longer sketches, no derived data attached: the separate passes
     if (n_rows > 0) {
@@ -3143,6 +3200,10 @@ int mvs_plan_begin(mvs_ctx* c, const mvs_sketch_set* s, const double* norms_sq, 
         if (!c->plan) return fail(MVS_E_NOMEM, "out of host memory");
     }
     PlanState& st = *c->plan;
+    {
+        const int rr = plan_resolve(c);   // (a sync only if the previous plan's counts were never fetched)
+        if (rr) return rr;
+    }
     st.active = false;
     st.finished = false;
     st.set = s;
@@ -3219,6 +3280,9 @@ int mvs_plan_begin(mvs_ctx* c, const mvs_sketch_set* s, const double* norms_sq, 
     if (rc) return rc;
     rc = plan_meta(c, st, f0, std::min<int64_t>(f1, s->n));
     if (rc) return rc;
+    st.key = {f0, f1, s->n, (int64_t)s->d_pad, (int64_t)flags, (int64_t)keep_mode, (int64_t)s->d, capacity};
+    st.speculate = c->opt.plan_speculate != 0 && st.hints_valid && st.key == st.hint_key;
+    st.stale = false;
     st.active = true;
     return MVS_OK;
 }
@@ -3318,6 +3382,58 @@ int mvs_plan_finish(mvs_ctx* c, const uint64_t** d_count) {
         if (rc) return rc;
         HIP_TRY(hipEventRecord(st.e_chk0, c->stream));
     }
+    if (st.speculate) {
+        // sizes from the previous plan of this shape; counts from the device; no host round trip (PlanState::speculate)
+        if (st.regions_next > 0) {
+            mvs::launch_cand_gather(c->stream, st.a, (int64_t)st.regions_next);
+            const int rc = check_kernel("k_cand_gather");
+            if (rc) return rc;
+        }
+        mvs::launch_tile_count(c->stream, st.a.tile_flag, st.n_tr, st.n_tc, (int*)c->pw_trow);
+        int rc = check_kernel("k_tile_count");
+        if (rc) return rc;
+        const bool tiles_pass = st.hint_flagged > 0;
+        const int tile_cap = tiles_pass ? (int)std::min<long long>((long long)st.n_tr * st.n_tc, 2 * st.hint_flagged + 64) : 0;
+        rc = ensure_buf(c, &c->pw_tlist, &c->pw_tlist_bytes, ((size_t)tile_cap + 1) * 4);
+        if (rc) return rc;
+        mvs::PairwiseArgs a = st.a;
+        mvs::launch_tile_list(c->stream, a.tile_flag, st.n_tr, st.n_tc, (const int*)c->pw_trow, (int*)c->pw_tlist, tile_cap);
+        rc = check_kernel("k_tile_list");
+        if (rc) return rc;
+        if (tiles_pass) {
+            rc = ensure_buf(c, &c->pw_cand2, &c->pw_cand2_bytes, c->pw_cand_bytes);      // whatever the list holds fits
+            if (rc) return rc;
+            mvs::launch_cand_prune(c->stream, a, 0, (int2*)c->pw_cand2, c->d_counter + 6, st.hint_cand + st.hint_cand / 4);
+            rc = check_kernel("k_cand_prune");
+            if (rc) return rc;
+            a.cand = (int2*)c->pw_cand2;
+            a.cand_capacity = c->pw_cand2_bytes / sizeof(int2);
+            a.cand_counter = c->d_counter + 6;
+            rc = ensure_buf(c, &c->pw_thr, &c->pw_thr_bytes, (size_t)s->n_alloc * 4);
+            if (rc) return rc;
+            mvs::launch_cand_thr(c->stream, st.d_n2, s->n, s->n_alloc, s->d, a.keep_coeff, (int32_t*)c->pw_thr);
+            rc = check_kernel("k_cand_thr");
+            if (rc) return rc;
+            a.cand_thr = (const int32_t*)c->pw_thr;
+        }
+        rc = mvs::launch_exact_pairs(c->stream, a, c->opt, st.hint_cand + st.hint_cand / 4);
+        if (rc) return fail(rc, "exact re-check launch rejected");
+        rc = check_kernel("k_exact_pairs");
+        if (rc) return rc;
+        if (st.timed) HIP_TRY(hipEventRecord(st.e_chk1, c->stream));
+        if (tiles_pass) {
+            rc = mvs::launch_exact_tiles(c->stream, a, (const int*)c->pw_tlist + 1, tile_cap, c->opt, true);
+            if (rc) return fail(rc, "exact tile launch rejected");
+            rc = check_kernel("k_pairwise_pp(tiles)");
+            if (rc) return rc;
+        }
+        if (st.timed) HIP_TRY(hipEventRecord(st.e_tiles1, c->stream));
+        mvs::launch_plan_verdict(c->stream, c->d_counter, st.a.cand_capacity, (const int*)c->pw_tlist, tile_cap, !tiles_pass);
+        rc = check_kernel("k_plan_verdict");
+        if (rc) return rc;
+        st.pending = true;
+        return MVS_OK;
+    }
     std::vector<int> row_count((size_t)st.n_tr);
     unsigned long long back[33];
     for (int attempt = 0;; ++attempt) {
@@ -3399,12 +3515,20 @@ int mvs_plan_finish(mvs_ctx* c, const uint64_t** d_count) {
         if (rc) return rc;
     }
     if (st.timed) HIP_TRY(hipEventRecord(st.e_tiles1, c->stream));
+    st.hints_valid = true;
+    st.hint_cand = st.candidates;
+    st.hint_flagged = st.flagged;
+    st.hint_key = st.key;
     return MVS_OK;
 }
 
 int mvs_plan_stats(mvs_ctx* c, double ms[4], int64_t counts[6]) {
     if (!c || !c->plan) return fail(MVS_E_INVALID, "no plan has run on this context");
     PlanState& st = *c->plan;
+    {
+        const int rr = plan_resolve(c);
+        if (rr) return rr;
+    }
     if (ms) {
         ms[0] = ms[1] = ms[2] = ms[3] = 0.0;
         if (st.timed && st.two_stage && st.finished && st.ev_used >= 2 && st.e_tiles1) {
@@ -3428,7 +3552,7 @@ int mvs_plan_stats(mvs_ctx* c, double ms[4], int64_t counts[6]) {
         counts[1] = st.flagged;
         counts[2] = st.tiles;
         counts[3] = st.launches;
-        counts[4] = st.two_stage ? 0 : 1;
+        counts[4] = (st.two_stage ? 0 : 1) | (st.speculate ? 2 : 0) | (st.stale ? 4 : 0);
         counts[5] = st.set ? st.set->d_pad : 0;
     }
     return MVS_OK;
@@ -3490,16 +3614,26 @@ int mvs_cells_report(mvs_ctx* c, const void* recv, int world, int64_t foreign_ca
     if (!c || !d_own_count || !out || world < 1 || foreign_capacity < 0 || own_rows < 0 || (world > 1 && !recv))
         return fail(MVS_E_INVALID, "bad argument");
     HIP_TRY(hipSetDevice(c->device));
-    std::vector<unsigned long long> hdr((size_t)world * 8, 0);
-    unsigned long long own[2] = {0, 0};
+    // both read-backs land in the context's pinned buffer (a copy into pageable memory is staged and blocks per copy)
+    const size_t hdr_bytes = (size_t)world * MVS_CELLS_HEADER_BYTES;
+    const int rc = ensure_read_back(c, 64 + hdr_bytes + 33 * 8);
+    if (rc) return rc;
+    unsigned long long* own = static_cast<unsigned long long*>(c->rb_pinned);
+    unsigned long long* hdr = own + 8;
+    unsigned long long* plan_back = hdr + (size_t)world * 8;
+    memset(c->rb_pinned, 0, 64 + hdr_bytes);
+    // a plan that ran ahead of its read-backs: its counts come along with this one
+    const bool with_plan = c->plan && c->plan->pending;
+    if (with_plan) HIP_TRY(hipMemcpyAsync(plan_back, c->d_counter, 33 * 8, hipMemcpyDeviceToHost, c->stream));
     mvs::launch_rows_max(c->stream, reinterpret_cast<unsigned long long*>(d_own_count), (int)own_rows);
     HIP_TRY(hipMemcpyAsync(own, d_own_count, 16, hipMemcpyDeviceToHost, c->stream));
     if (recv) {
         const size_t stride = MVS_CELLS_HEADER_BYTES + (size_t)foreign_capacity * sizeof(mvs_cell);
-        HIP_TRY(hipMemcpy2DAsync(hdr.data(), MVS_CELLS_HEADER_BYTES, recv, stride, MVS_CELLS_HEADER_BYTES, (size_t)world,
+        HIP_TRY(hipMemcpy2DAsync(hdr, MVS_CELLS_HEADER_BYTES, recv, stride, MVS_CELLS_HEADER_BYTES, (size_t)world,
                                  hipMemcpyDeviceToHost, c->stream));
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if (with_plan) plan_take_counts(c, *c->plan, plan_back);
     out[0] = (int64_t)own[0];
     for (int r = 0; r < world; ++r)
         for (int k = 0; k < 5; ++k) out[1 + r * 5 + k] = (int64_t)hdr[(size_t)r * 8 + (size_t)k];
@@ -3526,8 +3660,10 @@ int mvs_search_block(mvs_ctx* c, const mvs_sketch_set* s, const double* norms_sq
                          (mvs_cell*)c->pw_tmp, capacity, 0, &count, jaccard_min / (1.0 + jaccard_min));
     if (rc) return rc;
     if (count == ~0ULL) {
-        HIP_TRY(hipMemcpyAsync(&count, c->d_counter, 8, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
+        {
+            const int rb_rc = read_back(c, c->stream, {{&count, c->d_counter, 8}});
+            if (rb_rc) return rb_rc;
+        }
     }
     *n_cells = (int64_t)count;
     if ((int64_t)count > capacity)

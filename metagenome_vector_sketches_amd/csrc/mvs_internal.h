@@ -78,6 +78,8 @@ struct Options {
     int search_stream = 1;          // blocks of few rows x >= 4096 columns outside the symmetric schedule: 1 = the streaming
                                     // filter (rows resident in LDS, columns streamed into the matrix cores), 0 = the tile kernels
     int stream_trace = 0;           // 1: mvs_pairwise_stream prints the host-side time line of its row blocks to stderr
+    int recode_rows_wg = 8;         // k_recode_rows: rows (= waves) per workgroup, 8 or 16
+    int plan_speculate = 0;         // block plans: second half of a plan sized from the previous plan's counts, no host round trip
     int plan_strip_wgs = 1 << 22;   // block plans: a rectangle whose padded grid holds more workgroups than this is cut into column
                                     // strips (a dispatch holds 2^32 work-items per dimension = 2^23 workgroups; tests lower it)
     int comm_timeout_s = 600;       // file transport: how long a rank waits for a peer's block before it gives up
@@ -229,7 +231,7 @@ int launch_coarse_build(hipStream_t stream, const int8_t* d_planes, int64_t n, i
 // limb split + coarse build + fragment-major copy of a row range in one pass (k_recode_rows); false: no fused kernel for
 // this geometry (the caller takes the three separate launches)
 bool launch_recode_rows(hipStream_t stream, const void* d_sk, int elem_bytes, int64_t n_rows, int64_t count, int d, int d_pad,
-                        int8_t* d_planes, int8_t* d_coarse_fm, CoarseRow* d_rows, int radix_mode);
+                        int8_t* d_planes, int8_t* d_coarse_fm, CoarseRow* d_rows, int radix_mode, int rows_per_wg);
 // fragment-major copy of the coarse plane (PairwiseArgs::coarse_fm) / of the limb planes (planes_fm): `limbs` planes per row
 int launch_coarse_fm(hipStream_t stream, const int8_t* d_coarse, int64_t n_alloc, int d_pad, int8_t* d_fm, int limbs = 1);
 // true when launch_pairwise / launch_exact_tiles run the kernel that reads planes_fm for this set
@@ -256,10 +258,16 @@ bool filter_streams_rows(const PairwiseArgs& a, const Options& opt);
 bool filter_streams(const PairwiseArgs& a, const Options& opt);
 void filter_tile_grid(const PairwiseArgs& a, int* n_tr, int* n_tc);
 int launch_tile_count(hipStream_t stream, const unsigned int* d_flags, int n_tr, int n_tc, int* d_row_count);
-int launch_tile_list(hipStream_t stream, const unsigned int* d_flags, int n_tr, int n_tc, const int* d_row_count, int* d_list);
+int launch_tile_list(hipStream_t stream, const unsigned int* d_flags, int n_tr, int n_tc, const int* d_row_count, int* d_list,
+                     int cap = 0x7fffffff);
 int launch_cand_prune(hipStream_t stream, const PairwiseArgs& a, unsigned long long n_cand, int2* d_out,
-                      unsigned long long* d_out_count);
-int launch_exact_tiles(hipStream_t stream, const PairwiseArgs& a, const int* d_list, int n_list, const Options& opt);
+                      unsigned long long* d_out_count, long long n_hint = -1);
+int launch_exact_tiles(hipStream_t stream, const PairwiseArgs& a, const int* d_list, int n_list, const Options& opt,
+                       bool device_count = false);
+// the cell count of a plan whose speculative second half ran on stale counts (k_plan_verdict)
+constexpr unsigned long long kPlanStale = 1ULL << 62;
+int launch_plan_verdict(hipStream_t stream, unsigned long long* d_counter, unsigned long long cand_capacity, const int* d_tile_total,
+                        int tile_cap, bool tiles_skipped);
 // packed cells of the streamed output: radix sort on the (row, col) bits, then CSR arrays (row_ptr over `rows` rows,
 // col, q as 8 bits -- *d_wide set if some q needs 16 -- or as 16 bits when d_q16 is given)
 int sort_packed(hipStream_t stream, unsigned long long* d_in, unsigned long long* d_out, int64_t n, int begin_bit, int end_bit,

@@ -1278,9 +1278,10 @@ __global__ __launch_bounds__(256) void k_tile_count(const unsigned int* __restri
 
 // row-major list of the flagged tiles' ids (tr * n_tc + tc); workgroup tr sums the counts of the rows before it (the grid
 // has a few thousand rows at most) and writes its own row's ids in column order.  list[-1 .. ] : the caller passes
-// d_list + 1 and gets the total in d_list[0]
+// d_list + 1 and gets the total in d_list[0]; ids beyond `cap` entries are not written (a plan that sized the list from the
+// previous step's count: the total tells it)
 __global__ __launch_bounds__(256) void k_tile_list(const unsigned int* __restrict__ flags, int n_tr, int n_tc,
-                                                   const int* __restrict__ row_count, int* __restrict__ list) {
+                                                   const int* __restrict__ row_count, int* __restrict__ list, int cap) {
     __shared__ int part[4];
     __shared__ int run;
     const int tr = blockIdx.x;
@@ -1305,7 +1306,7 @@ __global__ __launch_bounds__(256) void k_tile_list(const unsigned int* __restric
         __syncthreads();
         int pos = run + __popcll(m & ((1ULL << lane) - 1ULL));
         for (int i = 0; i < w; ++i) pos += part[i];
-        if (f) list[pos] = tr * n_tc + t;
+        if (f && pos < cap) list[pos] = tr * n_tc + t;
         __syncthreads();
         if (threadIdx.x == 0) run += part[0] + part[1] + part[2] + part[3];
         __syncthreads();
@@ -1319,6 +1320,10 @@ __global__ __launch_bounds__(256) void k_cand_prune(const PairwiseArgs a, unsign
     // 100k comparison's list queued on the counter's line for 0.08 ms (k_cand_prune "waiting 0.99 of wave cycles", round 5)
     const int lane = threadIdx.x & 63;
     const unsigned long long waves = (unsigned long long)gridDim.x * 4;
+    if (n_cand == ~0ULL) {                       // the count is on the device (a plan that runs ahead of its read-backs)
+        n_cand = *reinterpret_cast<volatile const unsigned long long*>(a.cand_counter);
+        n_cand = n_cand < a.cand_capacity ? n_cand : a.cand_capacity;
+    }
     for (unsigned long long base = ((unsigned long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 512; base < n_cand; base += waves * 512) {
         int2 pr[8];
         unsigned keep = 0;
@@ -1388,7 +1393,12 @@ __global__ __launch_bounds__(512, 2) void k_pairwise_pp(const PairwiseArgs a, in
         // the flagged tiles of the tile-granular comparison: entry = a 256 x 256 filter tile = four tiles of this kernel,
         // consecutive indices; XCD label x (blockIdx.x % 8) takes the x-th contiguous eighth of the row-major list, so the
         // tiles that share row and column panels meet in one L2
-        const unsigned n4 = 4u * (unsigned)a.tile_list_n, per = (n4 + 7u) / 8u;
+        int n_list = a.tile_list_n;
+        if (n_list < 0) {                        // -(cap + 1): the count is on the device, in front of the list; the grid holds cap
+            const int cap = -(n_list + 1), have = a.tile_list[-1];
+            n_list = have < cap ? have : cap;
+        }
+        const unsigned n4 = 4u * (unsigned)n_list, per = (n4 + 7u) / 8u;
         const unsigned idx = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
         if ((blockIdx.x >> 3) >= per || idx >= n4) return;
         const int entry = a.tile_list[idx >> 2];
@@ -2085,14 +2095,14 @@ __global__ __launch_bounds__(256) void k_coarse_build(const int8_t* __restrict__
 // kernels produce (the statistics are taken from the value the two limbs hold, as k_coarse_build reads it back).
 // Rows [n_rows, count) of the range are written as zero rows (their planes are zero already: never written).
 // ---------------------------------------------------------------------------------------------------
-template <typename T, int CH>
-__global__ __launch_bounds__(CH == 4 ? 512 : 1024) void k_recode_rows(const T* __restrict__ sk, int64_t n_rows, int64_t count, int d, int d_pad,
+template <typename T, int CH, int RW>
+__global__ __launch_bounds__(RW * 64) void k_recode_rows(const T* __restrict__ sk, int64_t n_rows, int64_t count, int d, int d_pad,
                                                       int8_t* __restrict__ planes, int8_t* __restrict__ coarse_fm,
                                                       CoarseRow* __restrict__ rows, int radix_mode) {
     const int lane = threadIdx.x & 63;
-    // relative to the range's first row (a multiple of 16); 16 rows per workgroup (8 where a lane holds 64 entries: the
+    // relative to the range's first row (a multiple of 16); RW rows per workgroup (8 where a lane holds 64 entries: the
     // 128 registers a 1024-thread workgroup leaves per lane spill there)
-    const int64_t row = (int64_t)blockIdx.x * (CH == 4 ? 8 : 16) + (threadIdx.x >> 6);
+    const int64_t row = (int64_t)blockIdx.x * RW + (threadIdx.x >> 6);
     if (row >= count) return;
     const int nk = d_pad / 64;
     int v[CH][16];
@@ -3188,16 +3198,24 @@ int launch_coarse_fm(hipStream_t stream, const int8_t* d_coarse, int64_t n_alloc
 // sketches (n_rows x d, device) -> limb planes, fragment-major coarse plane and statistics of `count` rows (a multiple of 16;
 // rows beyond n_rows: zero rows), all pointers at the range's first row.  false: this sketch length has no fused kernel
 bool launch_recode_rows(hipStream_t stream, const void* d_sk, int elem_bytes, int64_t n_rows, int64_t count, int d, int d_pad,
-                        int8_t* d_planes, int8_t* d_coarse_fm, CoarseRow* d_rows, int radix_mode) {
+                        int8_t* d_planes, int8_t* d_coarse_fm, CoarseRow* d_rows, int radix_mode, int rows_per_wg) {
     if (count <= 0) return true;
     if (d_pad > 4096 || (count & 15)) return false;
     const int ch = d_pad <= 1024 ? 1 : (d_pad <= 2048 ? 2 : 4);
-#define MVS_RECODE(T, CH) hipLaunchKernelGGL((k_recode_rows<T, CH>), dim3((unsigned)(count / (CH == 4 ? 8 : 16))), dim3(CH == 4 ? 512 : 1024), 0, stream, (const T*)d_sk, n_rows, count, d, d_pad, d_planes, d_coarse_fm, d_rows, radix_mode)
-    if (elem_bytes == 4) {
-        if (ch == 1) MVS_RECODE(int32_t, 1); else if (ch == 2) MVS_RECODE(int32_t, 2); else MVS_RECODE(int32_t, 4);
-    } else {
-        if (ch == 1) MVS_RECODE(int16_t, 1); else if (ch == 2) MVS_RECODE(int16_t, 2); else MVS_RECODE(int16_t, 4);
-    }
+    // 8 rows per workgroup: two workgroups share a CU and are in different phases (loads / radix trials / stores), and the
+    // eight 16-byte pieces of a fragment-major run still fill a 128-byte line; 16 rows (one 1024-thread workgroup per CU:
+    // all of its waves load, compute and store in step) only where the option asks for it and the registers allow
+    const bool wide = rows_per_wg == 16 && ch < 4;
+#define MVS_RECODE(T, CH, RW) hipLaunchKernelGGL((k_recode_rows<T, CH, RW>), dim3((unsigned)(count / RW)), dim3(RW * 64), 0, stream, (const T*)d_sk, n_rows, count, d, d_pad, d_planes, d_coarse_fm, d_rows, radix_mode)
+#define MVS_RECODE_T(T)                                                     \
+    do {                                                                    \
+        if (ch == 4) MVS_RECODE(T, 4, 8);                                   \
+        else if (ch == 2) { if (wide) MVS_RECODE(T, 2, 16); else MVS_RECODE(T, 2, 8); } \
+        else { if (wide) MVS_RECODE(T, 1, 16); else MVS_RECODE(T, 1, 8); }  \
+    } while (0)
+    if (elem_bytes == 4) MVS_RECODE_T(int32_t);
+    else MVS_RECODE_T(int16_t);
+#undef MVS_RECODE_T
 #undef MVS_RECODE
     return true;
 }
@@ -3406,23 +3424,29 @@ int launch_tile_count(hipStream_t stream, const unsigned int* d_flags, int n_tr,
     return 0;
 }
 
-int launch_tile_list(hipStream_t stream, const unsigned int* d_flags, int n_tr, int n_tc, const int* d_row_count, int* d_list) {
+int launch_tile_list(hipStream_t stream, const unsigned int* d_flags, int n_tr, int n_tc, const int* d_row_count, int* d_list,
+                     int cap) {
     if (n_tr <= 0) return 0;
-    hipLaunchKernelGGL(k_tile_list, dim3((unsigned)n_tr), dim3(256), 0, stream, d_flags, n_tr, n_tc, d_row_count, d_list + 1);
+    hipLaunchKernelGGL(k_tile_list, dim3((unsigned)n_tr), dim3(256), 0, stream, d_flags, n_tr, n_tc, d_row_count, d_list + 1, cap);
     return 0;
 }
 
+// n_hint < 0: n_cand is the count.  n_hint >= 0: the count is read on the device (a.cand_counter, at most a.cand_capacity)
+// and the grid is sized for about n_hint entries (the kernel strides: any count is handled)
 int launch_cand_prune(hipStream_t stream, const PairwiseArgs& a, unsigned long long n_cand, int2* d_out,
-                      unsigned long long* d_out_count) {
-    if (n_cand == 0) return 0;
-    const unsigned long long blocks = std::min<unsigned long long>(4096ULL, (n_cand + 2047) / 2048);
-    hipLaunchKernelGGL(k_cand_prune, dim3((unsigned)blocks), dim3(256), 0, stream, a, n_cand, d_out, d_out_count);
+                      unsigned long long* d_out_count, long long n_hint) {
+    const unsigned long long size_for = n_hint >= 0 ? (unsigned long long)n_hint : n_cand;
+    if (n_hint < 0 && n_cand == 0) return 0;
+    const unsigned long long blocks = std::max<unsigned long long>(1, std::min<unsigned long long>(4096ULL, (size_for + 2047) / 2048));
+    hipLaunchKernelGGL(k_cand_prune, dim3((unsigned)blocks), dim3(256), 0, stream, a, n_hint >= 0 ? ~0ULL : n_cand, d_out, d_out_count);
     return 0;
 }
 
 // the exact ping-pong kernel on n_list flagged filter tiles (d_list: their ids in the grid of `a`, which is the filter
 // launch's: same row / column origin and ranges, same symmetric square)
-int launch_exact_tiles(hipStream_t stream, const PairwiseArgs& a, const int* d_list, int n_list, const Options& opt) {
+// device_count: n_list is the capacity the list (and this grid) was sized for, the count itself is read from d_list[-1]
+int launch_exact_tiles(hipStream_t stream, const PairwiseArgs& a, const int* d_list, int n_list, const Options& opt,
+                       bool device_count) {
     if (n_list <= 0) return 0;
     if (a.limbs != 2 || a.d_pad > 32768 || pairwise_variant(opt) != 8) return MVS_E_INVALID;
     using G = PpGeom<0>;
@@ -3431,7 +3455,7 @@ int launch_exact_tiles(hipStream_t stream, const PairwiseArgs& a, const int* d_l
     PairwiseArgs b = a;
     if (b.symmetric && !a.plan && ((a.row_begin - a.col_begin) % 256 != 0 || a.mirror_all)) b.symmetric = 0;   // as launch_pp<2> decided
     b.tile_list = d_list;
-    b.tile_list_n = n_list;
+    b.tile_list_n = device_count ? -(n_list + 1) : n_list;
     const size_t lds = (size_t)4 * G::kStage;
     const unsigned per = (4u * (unsigned)n_list + 7u) / 8u;
     if (pp_direct_b(b, 0, opt)) {
@@ -3445,6 +3469,29 @@ int launch_exact_tiles(hipStream_t stream, const PairwiseArgs& a, const int* d_l
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return MVS_E_HIP;
     hipLaunchKernelGGL((k_pairwise_pp<0, 4>), dim3(per * 8u), dim3(512), lds, stream, b, n_tr, n_tc, PlanSegs{});
+    return 0;
+}
+
+// A plan that ran its second half on the previous step's counts (mvs_plan_finish, speculative): did they hold?  counter =
+// the context's counter block: [0] kept cells, [2] candidates, [12] verdict (out), [13] flagged tiles (out).  A plan whose
+// candidate list or flagged-tile list was cut short says so in [12] and puts kPlanStale into the cell count, where every
+// consumer of the cells looks first.
+__global__ void k_plan_verdict(unsigned long long* __restrict__ counter, unsigned long long cand_capacity,
+                               const int* __restrict__ tile_total, int tile_cap, int tiles_skipped) {
+    const unsigned long long cand = counter[2];
+    const long long flagged = tile_total ? (long long)*tile_total : 0;
+    unsigned long long bad = 0;
+    if (cand > cand_capacity) bad |= 1;
+    if (flagged > (long long)tile_cap) bad |= 2;
+    if (tiles_skipped && flagged > 0) bad |= 4;              // no tile was flagged last time: the tile passes were not launched
+    counter[12] = bad;
+    counter[13] = (unsigned long long)flagged;
+    if (bad) counter[0] = kPlanStale;
+}
+
+int launch_plan_verdict(hipStream_t stream, unsigned long long* d_counter, unsigned long long cand_capacity, const int* d_tile_total,
+                        int tile_cap, bool tiles_skipped) {
+    hipLaunchKernelGGL(k_plan_verdict, dim3(1), dim3(1), 0, stream, d_counter, cand_capacity, d_tile_total, tile_cap, tiles_skipped ? 1 : 0);
     return 0;
 }
 

@@ -244,6 +244,7 @@ class GpuOps:
         # buffers here are torch tensors (zero fills, copies and slices run on torch's stream): the library
         # must issue its kernels on that same stream or nothing orders them against each other
         ctx.set_stream(torch.cuda.current_stream(torch.device(device)))
+        self.speculate = os.environ.get("MVS_PLAN_SPECULATE", "1") != "0"
 
     def layout(self, n_total, world):
         return _capi.shard_layout(n_total, world)
@@ -318,7 +319,15 @@ class GpuOps:
         self.ctx.prepare_rows(sset, first, count)
 
     def plan_begin(self, sset, norms_sq, f0, f1, mirror_outside, raw, keep_mode):
-        self.ctx.plan_begin(sset, norms_sq, f0, f1, mirror_outside, raw, keep_mode=keep_mode)
+        # a step of the same shape as the previous one runs its plan ahead of the read-backs (the decision is taken in
+        # mvs_plan_begin; ShardedComparison.finish knows what a stale plan looks like): MVS_PLAN_SPECULATE=0 turns it off
+        if self.speculate:
+            self.ctx.set_option("plan_speculate", 1)
+        try:
+            self.ctx.plan_begin(sset, norms_sq, f0, f1, mirror_outside, raw, keep_mode=keep_mode)
+        finally:
+            if self.speculate:
+                self.ctx.set_option("plan_speculate", 0)
 
     def plan_filter(self, blocks):
         self.ctx.plan_filter(blocks)
@@ -587,6 +596,13 @@ class ShardedComparison:
                 cells, cnt, info2 = self.finish(keep_mode=keep_mode, cells_out=cells_out)
                 info2["overlap"] = "limb guess %d did not hold: step redone with %d" % (limbs, need)
                 return cells, cnt, info2
+            if any(int(h[3]) >= _capi.PLAN_STALE for h in heads):
+                # a rank's plan ran its second half on the previous step's counts and they did not hold (mvs_plan_finish with
+                # option plan_speculate): that rank compares again -- the library will not speculate this time --, the
+                # others exchange again with it
+                need_compute = int(heads[rank][3]) >= _capi.PLAN_STALE
+                info["plan_respeculated"] = info.get("plan_respeculated", 0) + 1
+                continue
             redo = False
             mine = heads[rank]
             need_compute = int(mine[3]) > int(mine[4])      # this rank's raw list overflowed: its blocks again, with room

@@ -228,7 +228,7 @@ def test_recode_rows_equals_the_separate_passes(ctx, d, dtype):
     n_st = 128
     n_alloc, d_pad, nbytes = ctx.limb_geometry(n_st, d, 2)
     out = []
-    for fused in (True, False):
+    for fused in (8, 16, 0):                                    # rows per workgroup of the fused kernel; 0: separate passes
         planes = torch.zeros(nbytes, dtype=torch.int8, device=DEV)
         coarse = torch.full((n_alloc * d_pad,), 0x55, dtype=torch.uint8, device=DEV)
         stats = torch.full((n_alloc * 16,), 0x55, dtype=torch.uint8, device=DEV)
@@ -236,15 +236,17 @@ def test_recode_rows_equals_the_separate_passes(ctx, d, dtype):
         ctx.attach_derived(sset, coarse, stats)
         dev_sk = torch.from_numpy(sk).to(DEV)
         if fused:
-            ctx.recode_rows(sset, dev_sk, 32, rows)
+            with ctx.options(recode_rows_wg=fused):
+                ctx.recode_rows(sset, dev_sk, 32, rows)
         else:
             ctx.limb_split(dev_sk, 2, planes, d_pad, 32)
             ctx.prepare_rows(sset, 32, rows)
         torch.cuda.synchronize()
         out.append((planes.cpu().numpy().copy(), coarse.cpu().numpy().copy(), stats.cpu().numpy().copy()))
         sset.close()
-    for a, b in zip(out[0], out[1]):
-        assert np.array_equal(a, b)
+    for got in out[:2]:
+        for a, b in zip(got, out[2]):
+            assert np.array_equal(a, b)
     assert np.all(out[0][1][:32 * d_pad] == 0x55) and np.all(out[0][1][80 * d_pad:] == 0x55)     # nothing outside the range
     st = out[0][2][32 * 16:80 * 16].view(np.int32).reshape(rows, 4)
     assert np.all(st[n:] == [1, 0, 0, 0]) and st[3].tolist() == [1, 0, 0, 0] and st[5, 0] == 1 and st[7, 0] > 1
@@ -270,3 +272,76 @@ def test_plan_rectangle_beyond_one_dispatch_is_cut_into_strips(ctx):
     assert np.array_equal(got, want) and len(want) > 4 * n
     assert [x[2]["filter_tiles"] for x in per2] == tiles
     assert all(b > a for a, b in zip(launches, [x[2]["filter_launches"] for x in per2]))
+
+
+def _plan_once(ctx, split, cap, speculate):
+    """rank 0's plan of a one-rank split -> (cell count as the plan left it, sorted cells or None, plan statistics)"""
+    raw = torch.empty((cap, 4), dtype=torch.int32, device=DEV)
+    own = torch.empty((cap, 4), dtype=torch.int32, device=DEV)
+    P, n = split.P, split.n
+    d_own = torch.zeros(2 + (n + 2) // 2, dtype=torch.int64, device=DEV)
+    send = torch.zeros(_capi.CELLS_HEADER_BYTES, dtype=torch.uint8, device=DEV)
+    with ctx.options(plan_speculate=1 if speculate else 0):
+        ctx.plan_begin(split.sset, split.n2, 0, P, False, raw)
+    ctx.plan_filter(parallel.block_plan(1, 0, P))
+    d_cnt = ctx.plan_finish()
+    ctx.cells_route(raw, d_cnt, P, split.rps, n, 0, n, own, d_own, send, 0)
+    n_own, heads, _ = ctx.cells_report(send, 1, 0, n, d_own)          # (brings the plan's counts along)
+    count = int(heads[0][3])
+    st = ctx.plan_stats()
+    cells = None
+    if count < _capi.PLAN_STALE:
+        assert n_own == count <= cap
+        cells = own[:n_own]
+        order = torch.argsort(cells[:, 0].to(torch.int64) * (1 << 32) + cells[:, 1].to(torch.int64))
+        cells = cells[order]                                             # (stays on the device: the dense case has 17 M cells)
+    return count, cells, st
+
+
+def test_plan_runs_ahead_of_its_read_backs_and_says_when_its_sizes_were_stale(ctx):
+    """Option plan_speculate: the second plan of a shape takes its sizes from the first and does not synchronise; the same
+    cells.  A third plan of the same shape on data with many more flagged tiles and candidates finds its sizes too small:
+    the cell count reads MVS_PLAN_STALE, the plan after it does not speculate and is right."""
+    n, d = 8192, 1024
+    sparse = synth.make_sketches_numpy(n, d, 3000, seed=3, cluster=2)          # flags its 32 diagonal tiles
+    dense = synth.make_sketches_numpy(n, d, 3000, seed=4, cluster=2048)        # 4 clusters of 8 x 8 tiles: 144 on and above the diagonal
+    ctx.set_option("pairwise_filter", 2)
+    cap = 2500 * n
+    a = Split(ctx, sparse, _n2(sparse), 1)
+    c1, cells1, s1 = _plan_once(ctx, a, cap, True)
+    assert not s1["speculated"] and 0 < c1 < cap
+    c2, cells2, s2 = _plan_once(ctx, a, cap, True)
+    assert s2["speculated"] and not s2["stale"] and c2 == c1 and torch.equal(cells2, cells1)
+    assert (s2["candidates"], s2["flagged_tiles"], s2["filter_tiles"]) == (s1["candidates"], s1["flagged_tiles"], s1["filter_tiles"])
+    b = Split(ctx, dense, _n2(dense), 1)
+    assert (b.P, b.d_pad, b.n_alloc) == (a.P, a.d_pad, a.n_alloc)
+    c3, cells3, s3 = _plan_once(ctx, b, cap, True)
+    assert s3["speculated"] and s3["stale"] and c3 >= _capi.PLAN_STALE and s3["flagged_tiles"] > 2 * s1["flagged_tiles"] + 64
+    c4, cells4, s4 = _plan_once(ctx, b, cap, True)
+    assert not s4["speculated"] and not s4["stale"] and 0 < c4 < cap
+    c5, cells5, s5 = _plan_once(ctx, b, cap, False)
+    assert c5 == c4 and torch.equal(cells5, cells4)
+    c6, cells6, s6 = _plan_once(ctx, b, cap, True)          # and from here on the dense shape speculates on its own counts
+    assert s6["speculated"] and not s6["stale"] and c6 == c4 and torch.equal(cells6, cells4)
+    a.sset.close()
+    b.sset.close()
+
+
+def test_sharded_comparison_repeats_a_step_whose_plan_was_stale(ctx):
+    """parallel.ShardedComparison on one rank: sparse data, then same-shaped dense data -- the second step's plan runs on the
+    first step's sizes, reports MVS_PLAN_STALE in its header, the step is repeated and equals mvs_pairwise_rows"""
+    n, d = 8192, 1024
+    ctx.set_option("pairwise_filter", 2)
+    sc = parallel.ShardedComparison(parallel.GpuOps(ctx, DEV), 0, 1)
+    cells_out = torch.empty((2500 * n, 4), dtype=torch.int32, device=DEV)
+    for rep, (seed, cluster) in enumerate(((3, 2), (3, 2), (4, 2048), (4, 2048))):
+        sk = synth.make_sketches_numpy(n, d, 3000, seed=seed, cluster=cluster)
+        n2 = _n2(sk)
+        plain = ctx.sketch_set(sk)
+        ref, n_want = ctx.pairwise_rows(plain, n2)
+        plain.close()
+        want = np.stack([ref[k] for k in ("row", "col", "dot", "q")], axis=1).astype(np.int32)
+        out, cnt, info = sc.run(torch.from_numpy(sk).to(DEV), n2, n, cells_out=cells_out)
+        torch.cuda.synchronize()
+        assert info.get("plan_respeculated", 0) == (1 if rep == 2 else 0)
+        assert cnt == n_want and np.array_equal(out[:cnt].cpu().numpy(), want)

@@ -45,6 +45,7 @@ def main():
     ap.add_argument("--chunks", type=int, default=2)
     ap.add_argument("--reps", type=int, default=8)
     ap.add_argument("--seed", type=int, default=2345)
+    ap.add_argument("--no-speculate", action="store_true", help="every plan waits for its own counts (two host syncs per step)")
     ap.add_argument("--out", default="")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
@@ -88,7 +89,8 @@ def main():
             ev[0].record()
             ctx.recode_rows(sset, sk[b0:e0], 0, P)              # own rows only
             ev[1].record()
-            ctx.plan_begin(sset, n2_st, 0, P, G > 1, raw)
+            with ctx.options(plan_speculate=0 if args.no_speculate else 1):     # as parallel.GpuOps runs it
+                ctx.plan_begin(sset, n2_st, 0, P, G > 1, raw)
             ctx.plan_filter(plan[:1])
             ev[2].record()
             for (c0, c1) in parallel.chunk_bounds(P, args.chunks):
@@ -115,7 +117,8 @@ def main():
                             "route_report_ms": ev[4].elapsed_time(ev[5]), "sort_ms": ev[5].elapsed_time(ev[6]),
                             "filter_kernels_ms": ps["filter_ms"], "recheck_ms": ps["recheck_ms"], "tiles_ms": ps["tiles_ms"],
                             "filter_tiles": ps["filter_tiles"], "filter_launches": ps["filter_launches"], "candidates": ps["candidates"],
-                            "flagged_tiles": ps["flagged_tiles"], "own_cells": int(n_own), "foreign_cells": int(heads[0][0])})
+                            "flagged_tiles": ps["flagged_tiles"], "own_cells": int(n_own), "foreign_cells": int(heads[0][0]),
+                            "speculated": float(ps["speculated"]), "stale": float(ps["stale"])})
         m = {k: float(np.mean([a[k] for a in acc])) for k in acc[0]}
         m["rows_per_rank_padded"] = P
         m["plan_blocks"] = len(plan)
