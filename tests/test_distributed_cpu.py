@@ -30,6 +30,7 @@ class OracleOps:
         self.orc = pyoracle
         self.log = []
         self.coll = coll                  # lazy collectives: the re-check must not run while exchanges are outstanding
+        self.stale_next = 0               # plans to report as MVS_PLAN_STALE
 
     # ---- geometry / buffers ----
     def layout(self, n_total, world):
@@ -160,6 +161,11 @@ class OracleOps:
         keep = min(len(arr), raw.shape[0])
         raw[:keep] = torch.from_numpy(arr[:keep])
         self.log.append("finish")
+        if self.stale_next:                             # a plan that ran on the previous step's sizes and found them too small
+            self.stale_next -= 1
+            raw[:keep] = torch.from_numpy(arr[:keep][::-1].copy()) // 2          # whatever it appended is not to be used
+            from metagenome_vector_sketches_amd import _capi as capi
+            return [capi.PLAN_STALE + 5]
         return [len(arr)]                               # the count may exceed the capacity, as on the device
 
     # ---- kept cells -> shard ----
@@ -320,6 +326,14 @@ def _worker(rank, world, port, n, d, out_dir):
     _, cnt_s2, info_s2 = sc.run(small[b:e], n2s[b:e], n, cells_out=out_s)
     assert info_s2["limbs"] == 2 and "did not hold" not in info_s2["overlap"], info_s2
     assert cnt_s2 == cnt_s and np.array_equal(out_s[:cnt_s2].numpy(), want_s)
+    # ONE rank's plan ran ahead of its read-backs on sizes that did not hold (mvs_plan_finish, plan_speculate): its header says
+    # so, it compares again, everybody exchanges again
+    ops_st = OracleOps()
+    ops_st.stale_next = 1 if rank == world - 1 else 0
+    sc_st = parallel.ShardedComparison(ops_st, rank, world, dist)
+    _, cnt_st, info_st = sc_st.run(sk[b:e], n2[b:e], n, cells_out=out)
+    assert cnt_st == cnt and np.array_equal(out[:cnt_st].numpy(), plain)
+    assert info_st["plan_respeculated"] == 1 and ops_st.log.count("finish") == (2 if rank == world - 1 else 1)
     # an output buffer that holds exactly this shard: the raw list and the exchange buffers start too small for the mirrored
     # cells in flight and are regrown from what the headers report (every rank goes through the same retries)
     sc_tight = parallel.ShardedComparison(OracleOps(), rank, world, dist)
