@@ -731,7 +731,9 @@ def strong_run(args, ctx, dev, rank, world, dist, coll, config, steps, warmup):
                        "exchanged_cells": info.get("exchanged_cells", 0),
                        "other_ms": ms - prepare_ms - plan_span_ms - cells_ms,
                        "note": "prepare + plan span + cells + other = ms_per_step; spans are the last step's, from events on the "
-                               "step's streams (max over ranks); host synchronisations per step: 2"},
+                               "step's streams (max over ranks); host synchronisations per step: 1 in the steady state (cell "
+                               "counts; a plan of the same shape as the previous step's runs ahead of its own read-backs), 2 on "
+                               "a first step"},
             # rank 0's last step: (what, ms since the step began) from events on the compute stream and on the exchange's
             # stream -- "filter launched" / "gathered" events complete when the work queued before them has
             "timeline": timeline,
