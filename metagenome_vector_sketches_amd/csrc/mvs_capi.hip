@@ -120,6 +120,7 @@ struct mvs_ctx {
     hipEvent_t pinned_ev = nullptr;
     bool pinned_busy = false;
     // block plans (mvs_plan_*): state between begin / filter / finish, scratch of mvs_sketch_set_prepare_rows, events
+    int plan_overlap = 1;                 // block plans: filter launches alternate between the stream and a side stream
     struct PlanState* plan = nullptr;
     void* plan_tmp = nullptr;   size_t plan_tmp_bytes = 0;
 };
@@ -548,6 +549,11 @@ int mvs_ctx_destroy(mvs_ctx* c) {
 
 int mvs_ctx_set_option(mvs_ctx* c, const char* name, int64_t value) {
     if (!c || !name) return fail(MVS_E_INVALID, "NULL argument");
+    if (std::strcmp(name, "plan_overlap") == 0) {            // host-side scheduling only: not one of the kernels' options
+        if (value < 0 || value > 1) return fail(MVS_E_INVALID, "option plan_overlap: 0 or 1");
+        c->plan_overlap = (int)value;
+        return MVS_OK;
+    }
     for (const OptionSpec& sp : kOptions)
         if (std::strcmp(sp.name, name) == 0) return apply_option(c->opt, sp, (long long)value);
     return fail(MVS_E_INVALID, "unknown option '%s'", name);
@@ -555,6 +561,10 @@ int mvs_ctx_set_option(mvs_ctx* c, const char* name, int64_t value) {
 
 int mvs_ctx_get_option(const mvs_ctx* c, const char* name, int64_t* value) {
     if (!c || !name || !value) return fail(MVS_E_INVALID, "NULL argument");
+    if (std::strcmp(name, "plan_overlap") == 0) {
+        *value = c->plan_overlap;
+        return MVS_OK;
+    }
     for (const OptionSpec& sp : kOptions)
         if (std::strcmp(sp.name, name) == 0) {
             *value = sp.ifield ? (int64_t)(c->opt.*(sp.ifield)) : (int64_t)(c->opt.*(sp.dfield));
@@ -3007,6 +3017,12 @@ struct PlanState {
     // real counts on the device, k_plan_verdict says at the end whether the sizes held (if not, the cell count reads
     // kPlanStale and the caller runs the plan again: it will not speculate).  The counts come to the host with the next
     // read-back anybody does: mvs_cells_report's, or plan_resolve's own.
+    // Filter launches alternate between the context's stream and a side stream of the plan (option plan_overlap): the last
+    // round of one launch leaves CUs idle that the first round of the next can use.  A side launch waits for everything the
+    // caller had put on the context's stream when it was issued (the arrival of its columns); mvs_plan_finish joins them.
+    hipStream_t side = nullptr;
+    hipEvent_t e_fork = nullptr, e_join = nullptr;
+    bool side_busy = false;
     bool speculate = false;               // this plan
     bool pending = false;                 // its counts are still on the device only
     bool stale = false;                   // (after the counts came in) its sizes did not hold
@@ -3021,8 +3037,9 @@ static void plan_state_free(mvs_ctx* c) {
     if (!st) return;
     for (hipEvent_t e : st->ev)
         if (e) (void)hipEventDestroy(e);
-    for (hipEvent_t e : {st->e_chk0, st->e_chk1, st->e_tiles1})
+    for (hipEvent_t e : {st->e_chk0, st->e_chk1, st->e_tiles1, st->e_fork, st->e_join})
         if (e) (void)hipEventDestroy(e);
+    if (st->side) (void)hipStreamDestroy(st->side);
     delete st;
     c->plan = nullptr;
 }
@@ -3089,6 +3106,14 @@ int plan_meta(mvs_ctx* c, PlanState& st, int64_t r0, int64_t r1) {
     return check_kernel("k_filter_meta");
 }
 
+// everything the plan put on its side stream is ordered before what follows on the context's stream
+int plan_join(mvs_ctx* c, PlanState& st) {
+    if (!st.side_busy) return MVS_OK;
+    HIP_TRY(hipStreamWaitEvent(c->stream, st.e_join, 0));
+    st.side_busy = false;
+    return MVS_OK;
+}
+
 // blocks [first, first + count) of the plan as ONE filter launch
 int plan_launch(mvs_ctx* c, PlanState& st, size_t first, int count) {
     int64_t rect[mvs::kPlanSegs][4];
@@ -3107,6 +3132,17 @@ int plan_launch(mvs_ctx* c, PlanState& st, size_t first, int count) {
         a.cand_hdr = nullptr;            // this launch's waves append with the atomic
         a.cand_ent = nullptr;
     }
+    hipStream_t on = c->stream;
+    if (c->plan_overlap != 0 && (st.launches & 1) != 0) {          // every second launch of a plan: the side stream
+        if (!st.side) {
+            HIP_TRY(hipStreamCreateWithFlags(&st.side, hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&st.e_fork, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&st.e_join, hipEventDisableTiming));
+        }
+        HIP_TRY(hipEventRecord(st.e_fork, c->stream));
+        HIP_TRY(hipStreamWaitEvent(st.side, st.e_fork, 0));
+        on = st.side;
+    }
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->timing) {
         while (st.ev.size() < st.ev_used + 2) {
@@ -3117,13 +3153,17 @@ int plan_launch(mvs_ctx* c, PlanState& st, size_t first, int count) {
         e0 = st.ev[st.ev_used];
         e1 = st.ev[st.ev_used + 1];
         st.ev_used += 2;
-        HIP_TRY(hipEventRecord(e0, c->stream));
+        HIP_TRY(hipEventRecord(e0, on));
     }
-    const int rc = mvs::launch_filter_plan(c->stream, a, segs, wg);
+    const int rc = mvs::launch_filter_plan(on, a, segs, wg);
     if (rc) return fail(rc, "plan filter launch rejected");
     const int rk = check_kernel("k_pairwise_pp(plan filter)");
     if (rk) return rk;
-    if (e1) HIP_TRY(hipEventRecord(e1, c->stream));
+    if (e1) HIP_TRY(hipEventRecord(e1, on));
+    if (on != c->stream) {
+        HIP_TRY(hipEventRecord(st.e_join, on));
+        st.side_busy = true;
+    }
     ++st.launches;
     return MVS_OK;
 }
@@ -3201,7 +3241,9 @@ int mvs_plan_begin(mvs_ctx* c, const mvs_sketch_set* s, const double* norms_sq, 
     }
     PlanState& st = *c->plan;
     {
-        const int rr = plan_resolve(c);   // (a sync only if the previous plan's counts were never fetched)
+        int rr = plan_resolve(c);         // (a sync only if the previous plan's counts were never fetched)
+        if (rr) return rr;
+        rr = plan_join(c, st);            // (a plan that was begun and never finished)
         if (rr) return rr;
     }
     st.active = false;
@@ -3369,6 +3411,10 @@ int mvs_plan_finish(mvs_ctx* c, const uint64_t** d_count) {
     st.finished = true;
     st.active = false;
     if (!st.two_stage || st.blocks.empty()) return MVS_OK;
+    {
+        const int rj = plan_join(c, st);
+        if (rj) return rj;
+    }
     auto lazy_event = [&](hipEvent_t& e) -> int {
         if (!e) HIP_TRY(hipEventCreate(&e));
         return MVS_OK;
@@ -3466,6 +3512,8 @@ int mvs_plan_finish(mvs_ctx* c, const uint64_t** d_count) {
             if (rc) return rc;
             k += (size_t)count;
         }
+        rc = plan_join(c, st);
+        if (rc) return rc;
     }
     c->last_candidates = (unsigned long long)st.candidates;
     c->last_filter_tiles = st.tiles;
@@ -3533,10 +3581,20 @@ int mvs_plan_stats(mvs_ctx* c, double ms[4], int64_t counts[6]) {
         ms[0] = ms[1] = ms[2] = ms[3] = 0.0;
         if (st.timed && st.two_stage && st.finished && st.ev_used >= 2 && st.e_tiles1) {
             HIP_TRY(hipEventSynchronize(st.e_tiles1));
+            // the time during which at least one filter launch ran (launches on the two streams overlap: plan_launch)
+            std::vector<std::pair<float, float>> iv;
             for (size_t k = 0; k + 1 < st.ev_used; k += 2) {
-                float t = 0.0f;
-                HIP_TRY(hipEventElapsedTime(&t, st.ev[k], st.ev[k + 1]));
-                ms[0] += t;
+                float b = 0.0f, d = 0.0f;
+                if (k) HIP_TRY(hipEventElapsedTime(&b, st.ev[0], st.ev[k]));
+                HIP_TRY(hipEventElapsedTime(&d, st.ev[k], st.ev[k + 1]));
+                iv.emplace_back(b, b + d);
+            }
+            std::sort(iv.begin(), iv.end());
+            float upto = -1e30f;
+            for (const auto& x : iv) {
+                if (x.second <= upto) continue;
+                ms[0] += x.second - std::max(x.first, upto);
+                upto = x.second;
             }
             float t = 0.0f;
             HIP_TRY(hipEventElapsedTime(&t, st.e_chk0, st.e_chk1));
