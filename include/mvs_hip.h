@@ -422,7 +422,7 @@ int mvs_plan_begin(mvs_ctx* ctx, const mvs_sketch_set* set, const double* norms_
 int mvs_plan_filter(mvs_ctx* ctx, const mvs_plan_block* blocks, int n_blocks);
 int mvs_plan_finish(mvs_ctx* ctx, const uint64_t** d_count);
 /* What the last plan did.  ms (timing enabled, else zeros): [0] the time during which a filter launch of the plan was running
- * (consecutive launches alternate between the context's stream and a side stream and overlap: option plan_overlap), [1] re-check (candidate gather,
+ * (with option plan_overlap = 1 consecutive launches alternate between the context's stream and a side stream and overlap), [1] re-check (candidate gather,
  * pruning, k_exact_pairs), [2] exact kernel on the flagged tiles, [3] first filter launch .. end of the plan on the stream.
  * counts: [0] candidates, [1] flagged tiles, [2] 256 x 256 filter tiles computed, [3] filter launches, [4] bit 0: the plan ran
  * the exact kernel block by block (no filter), bit 1: it ran ahead of its read-backs (plan_speculate), bit 2: and its sizes

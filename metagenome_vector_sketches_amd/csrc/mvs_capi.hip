@@ -120,7 +120,9 @@ struct mvs_ctx {
     hipEvent_t pinned_ev = nullptr;
     bool pinned_busy = false;
     // block plans (mvs_plan_*): state between begin / filter / finish, scratch of mvs_sketch_set_prepare_rows, events
-    int plan_overlap = 1;                 // block plans: filter launches alternate between the stream and a side stream
+    int plan_overlap = 0;                 // block plans: 1 = filter launches alternate between the stream and a side stream
+                                          // (measured at the per-rank size of an 8-way split: filters 1.191 -> 1.164 ms, within
+                                          // the box-to-box spread; off by default -- one more queue beside RCCL's for 2 %)
     struct PlanState* plan = nullptr;
     void* plan_tmp = nullptr;   size_t plan_tmp_bytes = 0;
 };

@@ -245,8 +245,8 @@ class GpuOps:
         # must issue its kernels on that same stream or nothing orders them against each other
         ctx.set_stream(torch.cuda.current_stream(torch.device(device)))
         self.speculate = os.environ.get("MVS_PLAN_SPECULATE", "1") != "0"
-        if os.environ.get("MVS_PLAN_OVERLAP", "1") == "0":      # A/B: every filter launch of a plan on the one stream
-            ctx.set_option("plan_overlap", 0)
+        if os.environ.get("MVS_PLAN_OVERLAP", "0") == "1":      # A/B: filter launches of a plan alternate between two streams
+            ctx.set_option("plan_overlap", 1)
 
     def layout(self, n_total, world):
         return _capi.shard_layout(n_total, world)

@@ -46,15 +46,15 @@ def main():
     ap.add_argument("--reps", type=int, default=8)
     ap.add_argument("--seed", type=int, default=2345)
     ap.add_argument("--no-speculate", action="store_true", help="every plan waits for its own counts (two host syncs per step)")
-    ap.add_argument("--no-overlap", action="store_true", help="every filter launch of a plan on the one stream")
+    ap.add_argument("--overlap", action="store_true", help="filter launches of a plan alternate between two streams (plan_overlap)")
     ap.add_argument("--out", default="")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     ctx = pkg.Context(0)
     ctx.set_stream(torch.cuda.current_stream())
     ctx.set_timing(True)
-    if args.no_overlap:
-        ctx.set_option("plan_overlap", 0)
+    if args.overlap:
+        ctx.set_option("plan_overlap", 1)
     n, d = args.n, args.d
     sk = synth.make_sketches_torch(n, d, 50_000, seed=args.seed, device=dev)
     ss = torch.empty(n, dtype=torch.int64, device=dev)
