@@ -417,6 +417,17 @@ int mvs_sketch_set_prepare_rows(mvs_ctx* ctx, mvs_sketch_set* set, int64_t row_f
  * passes, same result.  Asynchronous. */
 int mvs_sketch_set_recode_rows(mvs_ctx* ctx, mvs_sketch_set* set, const void* sketches, int elem_bytes, int64_t n_rows,
                                int64_t row_first, int64_t row_count);
+/* The exchange without the high limb.  The coarse plane c, its radix m (in the row statistics) and the LOW limb of a row pin
+ * the row's values (v is the one value congruent to the low limb mod 256 near m * c: the radix search only admits radices for
+ * which that holds, csrc/mvs_pairwise.hip "The high limb on the wire"), so ranks exchange 2 bytes per entry -- coarse plane
+ * and low limbs -- instead of 3 and rebuild the other ranks' limb planes here: rows [row_first, row_first + row_count)
+ * (multiples of 16) of the set's plane buffer from lo_wire[row * d_pad + k] (DEVICE; indexed like the set's rows) and the
+ * attached coarse plane / statistics of those rows.  Valid for rows whose radix is <= MVS_WIRE_RADIX_MAX, i.e. max|v| <=
+ * MVS_WIRE_MAX_ABS: the caller checks the largest |v| of all ranks (it travels in the cells header) and falls back to
+ * exchanging the limb planes otherwise.  Asynchronous. */
+#define MVS_WIRE_RADIX_MAX 252
+#define MVS_WIRE_MAX_ABS 32004
+int mvs_sketch_set_planes_from_wire(mvs_ctx* ctx, mvs_sketch_set* set, const int8_t* lo_wire, int64_t row_first, int64_t row_count);
 int mvs_plan_begin(mvs_ctx* ctx, const mvs_sketch_set* set, const double* norms_sq, int keep_mode, int64_t frame_row_begin,
                    int64_t frame_row_end, int flags, mvs_cell* cells, int64_t capacity);
 int mvs_plan_filter(mvs_ctx* ctx, const mvs_plan_block* blocks, int n_blocks);

@@ -116,6 +116,7 @@ SYMBOLS = [
     ("mvs_sketch_set_attach_derived", _c.c_int, [_P, _P, _P]),
     ("mvs_sketch_set_prepare_rows", _c.c_int, [_P, _P, _c.c_int64, _c.c_int64]),
     ("mvs_sketch_set_recode_rows", _c.c_int, [_P, _P, _P, _c.c_int, _c.c_int64, _c.c_int64, _c.c_int64]),
+    ("mvs_sketch_set_planes_from_wire", _c.c_int, [_P, _P, _P, _c.c_int64, _c.c_int64]),
     ("mvs_plan_begin", _c.c_int, [_P, _P, _P, _c.c_int, _c.c_int64, _c.c_int64, _c.c_int, _P, _c.c_int64]),
     ("mvs_plan_filter", _c.c_int, [_P, _P, _c.c_int]),
     ("mvs_plan_finish", _c.c_int, [_P, _c.POINTER(_P)]),
@@ -231,6 +232,7 @@ class SketchSet:
 COMM_ID_BYTES = 128
 PLAN_MIRROR_OUTSIDE = 1
 CELLS_HEADER_BYTES = 64
+WIRE_MAX_ABS = 32004          # mvs_sketch_set_planes_from_wire: largest |v| for which the low limb pins the value
 PLAN_STALE = 1 << 62          # mvs_plan_finish under option plan_speculate: the cell count of a plan that must run again
 
 
@@ -724,6 +726,14 @@ class Context:
             raise ValueError("sketches must be a device buffer")
         _check(self.lib.mvs_sketch_set_recode_rows(self._h, sset._h, sp, self._elem_bytes(sketches) if n else 4, n, int(row_first),
                                                    int(row_count)))
+
+    def planes_from_wire(self, sset, lo_wire, row_first, row_count):
+        """limb planes of rows [row_first, row_first + row_count) from their low limbs (lo_wire: device bytes, row r at
+        r * d_pad) and the attached coarse plane / statistics (mvs_sketch_set_planes_from_wire)"""
+        lp, lm, lk = _buf(lo_wire)
+        if lm != MEM_DEVICE:
+            raise ValueError("the wire buffer must be a device buffer")
+        _check(self.lib.mvs_sketch_set_planes_from_wire(self._h, sset._h, lp, int(row_first), int(row_count)))
 
     def plan_begin(self, sset, norms_sq, frame_begin, frame_end, mirror_outside, cells, keep_mode=KEEP_INT32):
         np_, nm, nk = _buf(norms_sq)

@@ -3229,6 +3229,22 @@ int mvs_sketch_set_recode_rows(mvs_ctx* c, mvs_sketch_set* s, const void* sketch
     return mvs_sketch_set_prepare_rows(c, s, row_first, row_count);
 }
 
+int mvs_sketch_set_planes_from_wire(mvs_ctx* c, mvs_sketch_set* s, const int8_t* lo_wire, int64_t row_first, int64_t row_count) {
+    if (!c || !s) return fail(MVS_E_INVALID, "NULL argument");
+    if (row_first < 0 || row_count < 0 || row_first + row_count > s->n_alloc || (row_first & 15) || (row_count & 15))
+        return fail(MVS_E_INVALID, "rows [%lld, +%lld): multiples of 16 inside the %lld allocated rows", (long long)row_first,
+                    (long long)row_count, (long long)s->n_alloc);
+    if (s->limbs != 2 || !s->ext_coarse_fm || !s->ext_rows)
+        return fail(MVS_E_INVALID, "a two-limb set with derived data attached (mvs_sketch_set_attach_derived)");
+    if (row_count == 0) return MVS_OK;
+    if (!lo_wire) return fail(MVS_E_INVALID, "NULL wire buffer");
+    HIP_TRY(hipSetDevice(c->device));
+    mvs::launch_planes_from_wire(c->stream, lo_wire + row_first * (int64_t)s->d_pad, s->ext_coarse_fm + row_first * (int64_t)s->d_pad,
+                                 s->ext_rows + row_first, row_count, s->d_pad,
+                                 const_cast<int8_t*>(s->planes) + row_first * 2 * (int64_t)s->d_pad);
+    return check_kernel("k_planes_from_wire");
+}
+
 int mvs_plan_begin(mvs_ctx* c, const mvs_sketch_set* s, const double* norms_sq, int keep_mode, int64_t f0, int64_t f1, int flags,
                    mvs_cell* cells, int64_t capacity) {
     if (!c || !s) return fail(MVS_E_INVALID, "NULL argument");

@@ -1959,6 +1959,17 @@ __global__ __launch_bounds__(256) void k_cand_thr(const double* __restrict__ n2,
 // planes and applies the reference's keep test and quantisation.  On typical sketches (d = 2048) B is
 // about a fifth of the threshold and ~1e-4 of the unrelated pairs pass.
 // ---------------------------------------------------------------------------------------------------
+// The high limb on the wire (multi-rank steps: mvs_sketch_set_planes_from_wire).  A rank that holds a row's coarse plane c,
+// its radix m and its LOW limb l0 can rebuild the high limb: v is the one value congruent to l0 mod 256 near m c --
+//   |c| < 127 :  |v - m c| <= ceil(m / 2) <= 126 for m <= 252, so v = t + wrap8(l0 - t) with t = m c;
+//   |c| = 127 :  v lies beyond: s v in [L, max|v|] with L = 127 m - ceil(m / 2), s = sign(c) -- one value mod 256 as long as
+//                max|v| <= L + 254, and then v = t' + wrap8(l0 - t') with t' = s (L + 127)
+// (wrap8 = the representative in [-128, 127]; checked exhaustively for every m <= 252 and every v the rule admits:
+// tests/test_oracle_golden.py).  The radix search therefore only tries radices with max|v| <= L + 254 -- the radix that
+// just avoids clamping, ceil(max|v| / 127), always qualifies -- and the exchange carries 2 bytes per entry instead of 3.
+__device__ __forceinline__ bool radix_keeps_high_limb(int mc, int mx) { return mx <= 127 * mc - (mc + 1) / 2 + 254; }
+static_assert(MVS_WIRE_RADIX_MAX == 252 && MVS_WIRE_MAX_ABS == 127 * 252, "the bounds the header states");
+
 // One entry of a radix trial: the squared residual of v under radix mc (ic = 1.0f / mc).  Two-limb values only:
 // |v| <= 32896 = 128 * 256 + 128, so the radix that just avoids clamping is m <= 260, a trial radix is mc >= m - 15 * step
 // with step <= 8, and |r| is at most mc / 2 where the coarse value is not clamped and |v| - 127 mc <= 127 (m - mc) <= 15240
@@ -2028,7 +2039,7 @@ __global__ __launch_bounds__(256) void k_coarse_build(const int8_t* __restrict__
         int best_m = m;
         for (int t = 0; t < 16; ++t) {
             const int mc = m - t * step;
-            if (mc < 1) break;
+            if (mc < 1 || !radix_keeps_high_limb(mc, mx)) break;
             const float ic = 1.0f / (float)mc;
             unsigned long long r2c = 0;
             for (int k = lane; k < chunks; k += 64) {
@@ -2181,7 +2192,7 @@ __global__ __launch_bounds__(RW * 64) void k_recode_rows(const T* __restrict__ s
         int best_m = m;
         for (int t = 0; t < 16; ++t) {
             const int mc = m - t * step;
-            if (mc < 1) break;
+            if (mc < 1 || !radix_keeps_high_limb(mc, mx)) break;
             const float ic = 1.0f / (float)mc;
             unsigned long long r2c = 0;
 #pragma unroll
@@ -2230,6 +2241,43 @@ __global__ __launch_bounds__(RW * 64) void k_recode_rows(const T* __restrict__ s
         r2 += __shfl_xor(r2, o, 64);
     }
     if (lane == 0) rows[row] = real ? CoarseRow{m, (int32_t)c2, (int32_t)r2, ss >= (1ULL << 31) ? 1 : 0} : CoarseRow{1, 0, 0, 0};
+}
+
+// k_planes_from_wire: limb planes of rows whose LOW limb arrived in a wire buffer (lo[row * d_pad + k]) and whose coarse
+// plane and statistics are in place (fragment-major, as the filter reads them): both limb rows are written -- the rule is
+// at radix_keeps_high_limb.  One workgroup per group of 16 rows (one KiB of the fragment-major plane holds 16 rows x 64 k):
+// a lane takes 16 consecutive k of one row, reads its 16 coarse bytes where k_recode_rows put them and 16 bytes of the wire.
+__global__ __launch_bounds__(256) void k_planes_from_wire(const int8_t* __restrict__ lo_wire, const int8_t* __restrict__ coarse_fm,
+                                                          const CoarseRow* __restrict__ rows, int64_t count, int d_pad,
+                                                          int8_t* __restrict__ planes) {
+    const int nk = d_pad / 64;
+    const int64_t grp = blockIdx.x;                        // 16 rows
+    const int chunks = 16 * (d_pad / 16);                  // (row, 16-entry chunk) pairs of the group
+    for (int idx = threadIdx.x; idx < chunks; idx += 256) {
+        const int r = idx & 15, kc = idx >> 4;             // consecutive lanes: the 16 rows of one chunk = 256 contiguous bytes of the plane
+        const int64_t row = grp * 16 + r;
+        if (row >= count) continue;
+        const int m = rows[row].radix;
+        const v4i c4 = *reinterpret_cast<const v4i*>(coarse_fm + (grp * nk + (kc >> 2)) * 1024 + (((kc & 3) << 4) + r) * 16);
+        const v4i l4 = *reinterpret_cast<const v4i*>(lo_wire + row * (int64_t)d_pad + kc * 16);
+        const int h = (m + 1) >> 1, edge = 127 * m - h + 127;
+        v4i h4;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            uint32_t ph = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int c = (int)(int8_t)((uint32_t)c4[w] >> (8 * e));
+                const int l0 = (int)(int8_t)((uint32_t)l4[w] >> (8 * e));
+                const int t = c == 127 ? edge : (c == -127 ? -edge : m * c);
+                const int v = t + (int)(int8_t)(l0 - t);
+                ph |= (uint32_t)(uint8_t)(int8_t)((v - l0) >> 8) << (8 * e);
+            }
+            h4[w] = (int)ph;
+        }
+        *reinterpret_cast<v4i*>(planes + row * 2 * (int64_t)d_pad + kc * 16) = l4;
+        *reinterpret_cast<v4i*>(planes + (row * 2 + 1) * (int64_t)d_pad + kc * 16) = h4;
+    }
 }
 
 // per-call filter constants {s, w, a, p} (see above); padding rows never pass (s = +inf)
@@ -3192,6 +3240,15 @@ int launch_coarse_fm(hipStream_t stream, const int8_t* d_coarse, int64_t n_alloc
     const long long chunks = (long long)(n_alloc / 16) * limbs * nk;
     const unsigned grid = (unsigned)std::min<long long>((chunks + 3) / 4, 65536);
     hipLaunchKernelGGL(k_coarse_fm, dim3(grid), dim3(256), 0, stream, d_coarse, chunks, nk, d_pad, limbs, d_fm);
+    return 0;
+}
+
+// rows [0, count) (count a multiple of 16; all pointers at the range's first row, which is a multiple of 16)
+int launch_planes_from_wire(hipStream_t stream, const int8_t* d_lo_wire, const int8_t* d_coarse_fm, const CoarseRow* d_rows,
+                            int64_t count, int d_pad, int8_t* d_planes) {
+    if (count <= 0) return 0;
+    hipLaunchKernelGGL(k_planes_from_wire, dim3((unsigned)(count / 16)), dim3(256), 0, stream, d_lo_wire, d_coarse_fm, d_rows, count, d_pad,
+                       d_planes);
     return 0;
 }
 

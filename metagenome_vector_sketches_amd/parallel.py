@@ -79,6 +79,12 @@ class _Collectives:
     returns a handle whose wait() orders the compute stream behind them.  Base: synchronous."""
     stream = None
 
+    @property
+    def inline(self):
+        """fn() of submit() runs on the calling thread (it may then queue kernels of the numeric back end behind its
+        collectives, on `stream`); False: on a worker thread, where only the collectives themselves belong"""
+        return True
+
     def submit(self, fn):
         fn()
         return _Done()
@@ -140,6 +146,10 @@ class NativeCollectives(_Collectives):
         self.comm, self.rank, self.world, self.stream = comm, comm.rank, comm.world, stream
         self.kind = "libmvs_hip mvs_comm (%s)" % ("RCCL" if comm.is_rccl else "file transport")
         self._pool = None
+
+    @property
+    def inline(self):
+        return self.stream is None or self.comm.is_rccl
 
     def submit(self, fn):
         if self.stream is None:
@@ -243,7 +253,8 @@ class GpuOps:
         self.ctx, self.device = ctx, device
         # buffers here are torch tensors (zero fills, copies and slices run on torch's stream): the library
         # must issue its kernels on that same stream or nothing orders them against each other
-        ctx.set_stream(torch.cuda.current_stream(torch.device(device)))
+        self._main = torch.cuda.current_stream(torch.device(device))
+        ctx.set_stream(self._main)
         self.speculate = os.environ.get("MVS_PLAN_SPECULATE", "1") != "0"
         if os.environ.get("MVS_PLAN_OVERLAP", "0") == "1":      # A/B: filter launches of a plan alternate between two streams
             ctx.set_option("plan_overlap", 1)
@@ -320,6 +331,23 @@ class GpuOps:
             self.ctx.limb_split(sketches, limbs, planes, d_pad, first)
         self.ctx.prepare_rows(sset, first, count)
 
+    def wire_rows(self, planes, lo_wire, d_pad, first, count):
+        """the LOW limbs of rows [first, first + count) of two-limb planes into the wire buffer (row r at r * d_pad)"""
+        rows = planes[:(first + count) * 2 * d_pad].view(-1, 2, d_pad)
+        lo_wire[first * d_pad:(first + count) * d_pad].view(count, d_pad).copy_(rows[first:first + count, 0, :])
+
+    def planes_from_wire(self, sset, lo_wire, first, count, stream=None):
+        """both limb planes of rows [first, first + count) from their low limbs + the coarse plane / statistics that are in
+        place (mvs_sketch_set_planes_from_wire); stream: queue the kernel there (the exchange's stream: it then runs as
+        soon as the bytes have landed, beside the compute stream's filter kernels)"""
+        if stream is None:
+            return self.ctx.planes_from_wire(sset, lo_wire, first, count)
+        self.ctx.set_stream(stream)
+        try:
+            self.ctx.planes_from_wire(sset, lo_wire, first, count)
+        finally:
+            self.ctx.set_stream(self._main)
+
     def plan_begin(self, sset, norms_sq, f0, f1, mirror_outside, raw, keep_mode):
         # a step of the same shape as the previous one runs its plan ahead of the read-backs (the decision is taken in
         # mvs_plan_begin; ShardedComparison.finish knows what a stale plan looks like): MVS_PLAN_SPECULATE=0 turns it off
@@ -381,10 +409,13 @@ class ShardedComparison:
             raise ValueError("world > 1 needs torch.distributed or a communicator")
         self.symmetric = os.environ.get("MVS_SHARDED_SYMMETRIC", "1") != "0"
         self.gather_chunks = max(1, int(os.environ.get("MVS_GATHER_CHUNKS", "2")))   # pieces the peers' coarse rows arrive in
+        # two-limb sets: the exchange carries coarse plane + LOW limbs, the receiver rebuilds the high limbs (2 bytes per entry
+        # on the links instead of 3); switched off for good once a rank reports |v| beyond what the rule covers
+        self.wire = os.environ.get("MVS_WIRE_LOW_LIMB", "1") != "0" and hasattr(ops, "planes_from_wire")
         self.time_gather = False         # bench: events around the exchange (read with last_gather_ms())
         self.trace = None                # a list: (label, torch event) pairs of the last step (tools/exp/r05_overlap_trace.py)
         self._key = None
-        self._planes = self._coarse = self._stats = self._n2 = self._sset = None
+        self._planes = self._coarse = self._stats = self._n2 = self._sset = self._lo = None
         self._raw = self._own = self._xbuf = self._d_own = None
         self._d_own_rows = 0
         self._cap_f = 1 << 14
@@ -437,6 +468,7 @@ class ShardedComparison:
             self._coarse = ops.new_bytes(n_alloc * d_pad)          # fragment-major coarse plane (two-limb sets)
             self._stats = ops.new_bytes(n_alloc * 16)              # 16 bytes of row statistics
             self._n2 = ops.to_device(np.zeros(n_alloc, dtype=np.float64))
+            self._lo = ops.new_planes(n_alloc * d_pad) if (limbs == 2 and world > 1 and self.wire) else None
             self._sset = ops.open_set(self._planes, n_st, n_alloc, d, d_pad, limbs, self._coarse, self._stats)
             self._key = key
         return rps, P, n_alloc, d_pad
@@ -482,7 +514,8 @@ class ShardedComparison:
             self._trace("step begin")
         self._step = {"sk": sketches_local, "n2": norms_sq_local, "n_total": n_total, "limbs": limbs_guess, "rps": rps, "P": P,
                       "n_alloc": n_alloc, "d_pad": d_pad, "max_abs": 0, "fed": 0, "parts": 0, "small": [], "coarse": [], "planes": [],
-                      "rows": (rb, re)}
+                      "rows": (rb, re), "wire": bool(self.wire and limbs_guess == 2 and self.world > 1 and self._lo is not None),
+                      "rebuilt": False}
 
     def part_bounds(self, n_total, parts):
         """[(row_begin, row_end)] cutting a rank's block (STORAGE rows 0 .. block_pad, the same bounds on every rank: a
@@ -532,11 +565,32 @@ class ShardedComparison:
                 self._trace("coarse rows [%d,%d) gathered" % (a, b), getattr(coll, "stream", None))
             st["coarse"].append((a, b, coll.submit(coarse)))
 
+        if st["wire"]:
+            ops.wire_rows(self._planes, self._lo, d_pad, base + row_begin, row_end - row_begin)
+
         def planes():
-            coll.allgather_rows(self._planes, P, row_begin, row_end - row_begin, nl * d_pad)
+            if not st["wire"]:
+                coll.allgather_rows(self._planes, P, row_begin, row_end - row_begin, nl * d_pad)
+                self._mark(1)
+                self._trace("limb planes [%d,%d) gathered" % (row_begin, row_end), getattr(coll, "stream", None))
+                return
+            coll.allgather_rows(self._lo, P, row_begin, row_end - row_begin, d_pad)
             self._mark(1)
-            self._trace("limb planes [%d,%d) gathered" % (row_begin, row_end), getattr(coll, "stream", None))
+            self._trace("low limbs [%d,%d) gathered" % (row_begin, row_end), getattr(coll, "stream", None))
+            if last and coll.inline:
+                # every part's low limbs, the coarse plane and the statistics are queued in front of this on the exchange's
+                # stream: the other ranks' limb planes are rebuilt there, beside the compute stream's filter kernels
+                self._rebuild(st, getattr(coll, "stream", None))
         st["planes"].append(coll.submit(planes))
+
+    def _rebuild(self, st, stream):
+        P = st["P"]
+        for p in range(self.world):
+            if p != self.rank:
+                self.ops.planes_from_wire(self._sset, self._lo, p * P, P, stream=stream)
+        self._mark(1)
+        self._trace("limb planes rebuilt", stream)
+        st["rebuilt"] = True
 
     def finish(self, keep_mode=_capi.KEEP_INT32, cells_out=None):
         st, self._step = self._step, None
@@ -546,7 +600,8 @@ class ShardedComparison:
         P, rps, limbs, n_total = st["P"], st["rps"], st["limbs"], st["n_total"]
         rb, re = st["rows"]
         info = {"limbs": limbs, "rows": (rb, re), "collectives": self.coll.kind if world > 1 else "none",
-                "allgather_bytes_per_rank": P * ((limbs & 0xff) + 1) * st["d_pad"] + P * 24 if world > 1 else 0,
+                "allgather_bytes_per_rank": P * ((2 if st["wire"] else (limbs & 0xff) + 1)) * st["d_pad"] + P * 24 if world > 1 else 0,
+                "wire": "coarse plane + low limbs (high limbs rebuilt by the receiver)" if st["wire"] else "coarse plane + limb planes",
                 "schedule": "symmetric" if (self.symmetric and world > 1) else "rows x all columns",
                 "overlap": "none" if world == 1 else
                            "diagonal block beside the exchange; peers' blocks per arrived chunk of coarse rows" +
@@ -589,6 +644,15 @@ class ShardedComparison:
             worst = max(int(h[1]) for h in heads)
             if worst:
                 raise err if err is not None else _capi.MvsError(worst, "another rank failed in its block comparisons")
+            if st["wire"] and max(int(h[2]) for h in heads) > _capi.WIRE_MAX_ABS:
+                # some rank's values are beyond what the low limb pins: the rebuilt planes are not to be trusted.  Every rank
+                # sees the same headers: the step is redone with the limb planes themselves on the wire, from now on
+                self.wire = False
+                self.begin(st["sk"], st["n2"], n_total, limbs_guess=limbs)
+                self.feed(0, P, st["max_abs"])
+                cells, cnt, info2 = self.finish(keep_mode=keep_mode, cells_out=cells_out)
+                info2["overlap"] = "|v| beyond %d: step redone with the limb planes on the wire" % _capi.WIRE_MAX_ABS
+                return cells, cnt, info2
             need = ops.limbs_for(max(int(h[2]) for h in heads))
             plain = need <= 4 and limbs <= 4
             if (need > limbs) if plain else (need != limbs):
@@ -664,6 +728,8 @@ class ShardedComparison:
             # needs nothing from anybody (rank 1 of 2): the next step rewrites the buffers the collectives read
             for h in st["planes"]:
                 h.wait()
+            if st["wire"] and not st["rebuilt"]:           # (an exchange that ran on a worker thread: rebuilt here)
+                self._rebuild(st, None)
         d_cnt = ops.plan_finish()
         self._trace("plan finished")
         return d_cnt

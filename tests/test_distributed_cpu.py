@@ -98,10 +98,38 @@ class OracleOps:
         sset["stats"].zero_()
 
     def prepare_rows(self, sset, first, count):
+        """the filter's inputs of these rows.  The stand-in keeps a real coarse plane (row-major, c + 128 so that a byte that has
+        landed is never 0) with the radix that just avoids clamping in the first four statistics bytes: what the receiver of
+        a low limb needs to rebuild the high one (csrc/mvs_pairwise.hip "The high limb on the wire")"""
         assert first % 16 == 0 and count % 16 == 0
+        d_pad, limbs = sset["d_pad"], sset["limbs"]
+        view = sset["planes"].numpy().reshape(-1, limbs, d_pad).astype(np.int64)[first:first + count]
+        v = sum(view[:, l, :] * (256 ** l) for l in range(limbs))
+        mx = np.abs(v).max(axis=1)
+        m = np.maximum(1, (mx + 126) // 127)
+        c = np.clip(np.rint(v.astype(np.float32) * (np.float32(1.0) / m.astype(np.float32))[:, None]), -127, 127).astype(np.int64)
+        sset["coarse"].numpy()[first * d_pad:(first + count) * d_pad] = (c + 128).astype(np.uint8).reshape(-1)
+        stats = sset["stats"].numpy()[first * 16:(first + count) * 16].reshape(count, 16)
+        stats[:, :4] = m.astype("<i4").view(np.uint8).reshape(count, 4)
+        stats[:, 4:] = 7
+
+    def wire_rows(self, planes, lo_wire, d_pad, first, count):
+        lo_wire.numpy().reshape(-1, d_pad)[first:first + count] = planes.numpy().reshape(-1, 2, d_pad)[first:first + count, 0, :]
+
+    def planes_from_wire(self, sset, lo_wire, first, count, stream=None):
+        """numpy restatement of k_planes_from_wire: v = the value congruent to the low limb mod 256 near m c"""
+        assert sset["limbs"] == 2 and self._landed(sset, first, first + count), "low limbs rebuilt before coarse plane / statistics arrived"
         d_pad = sset["d_pad"]
-        sset["coarse"][first * d_pad:(first + count) * d_pad] = 1
-        sset["stats"][first * 16:(first + count) * 16] = 7
+        l0 = lo_wire.numpy().reshape(-1, d_pad)[first:first + count].astype(np.int64)
+        c = sset["coarse"].numpy()[first * d_pad:(first + count) * d_pad].reshape(count, d_pad).astype(np.int64) - 128
+        m = sset["stats"].numpy()[first * 16:(first + count) * 16].reshape(count, 16)[:, :4].copy().view("<i4").reshape(count).astype(np.int64)
+        edge = (127 * m - (m + 1) // 2 + 127)[:, None]
+        t = np.where(c == 127, edge, np.where(c == -127, -edge, m[:, None] * c))
+        v = t + (((l0 - t) + 128) % 256 - 128)
+        planes = sset["planes"].numpy().reshape(-1, 2, d_pad)
+        planes[first:first + count, 0, :] = l0.astype(np.int8)
+        planes[first:first + count, 1, :] = ((v - l0) // 256).astype(np.int8)
+        self.log.append("rebuilt %d" % first)
 
     def recode_rows(self, sset, sketches, limbs, planes, d_pad, first, count):
         if sketches.shape[0]:
@@ -111,8 +139,8 @@ class OracleOps:
     def _landed(self, sset, r0, r1):
         d_pad = sset["d_pad"]
         c = sset["coarse"].numpy()[r0 * d_pad:r1 * d_pad].reshape(r1 - r0, d_pad)
-        s = sset["stats"].numpy()[r0 * 16:r1 * 16]
-        return bool(np.all(c[:, 0] == 1) and np.all(c[:, -1] == 1) and np.all(s == 7))
+        s = sset["stats"].numpy()[r0 * 16:r1 * 16].reshape(r1 - r0, 16)
+        return bool(np.all(c[:, 0] != 0) and np.all(c[:, -1] != 0) and np.all(s[:, 4:] == 7))
 
     def _sketches(self, sset):
         planes, n, d, d_pad, limbs = sset["planes"], sset["n"], sset["d"], sset["d_pad"], sset["limbs"]
@@ -273,7 +301,11 @@ def _worker(rank, world, port, n, d, out_dir):
     cells, cnt, info = sc.run(sk[b:e], n2[b:e], n)          # no output buffer -> the shard comes back as a host array
     assert info["schedule"] == ("symmetric" if world > 1 else "rows x all columns")
     # the order of the step: the diagonal block's filter first, then one launch per arrived chunk, then the rest
-    assert ops.log[0] == "begin" and ops.log[1] == "filter 1" and ops.log[-1] == "finish"
+    steps = [x for x in ops.log if not x.startswith("rebuilt")]
+    assert steps[0] == "begin" and steps[1] == "filter 1" and steps[-1] == "finish"
+    # two bytes per entry on the wire: the other ranks' limb planes were rebuilt from low limbs + coarse plane, once per peer
+    assert info["wire"].startswith("coarse plane + low limbs") == (world > 1)
+    assert len([x for x in ops.log if x.startswith("rebuilt")]) == world - 1
     if len(parallel.block_plan(world, rank, ops.layout(n, world)[1])) > 1:
         assert len([x for x in ops.log if x.startswith("filter")]) >= 2
     cells2, cnt2, _ = sc.run(sk[b:e], n2[b:e], n)           # second step reuses the gathered buffers
@@ -326,6 +358,21 @@ def _worker(rank, world, port, n, d, out_dir):
     _, cnt_s2, info_s2 = sc.run(small[b:e], n2s[b:e], n, cells_out=out_s)
     assert info_s2["limbs"] == 2 and "did not hold" not in info_s2["overlap"], info_s2
     assert cnt_s2 == cnt_s and np.array_equal(out_s[:cnt_s2].numpy(), want_s)
+    # values beyond what a low limb pins (|v| > 32 004, still two limbs) on ONE rank: the rebuilt planes are not trusted, every
+    # rank learns it from the headers, the step is redone with the limb planes themselves on the wire -- for good
+    big = sk.copy()
+    big[n - 1, 1] = 32500
+    n2b = np.array([orc_mod.norm_sq_from_text(orc_mod.format_norm(orc_mod.norm(r))) for r in big])
+    sc_ref = parallel.ShardedComparison(OracleOps(), rank, world, dist)
+    sc_ref.wire = False
+    out_b = torch.empty((n * n, 4), dtype=torch.int32)
+    _, cnt_ref, info_ref = sc_ref.run(big[b:e], n2b[b:e], n, cells_out=out_b)
+    want_b = out_b[:cnt_ref].numpy().copy()
+    assert info_ref["wire"] == "coarse plane + limb planes"
+    sc_b = parallel.ShardedComparison(OracleOps(), rank, world, dist)
+    _, cnt_b, info_b = sc_b.run(big[b:e], n2b[b:e], n, cells_out=out_b)
+    assert cnt_b == cnt_ref and np.array_equal(out_b[:cnt_b].numpy(), want_b)
+    assert ("beyond" in info_b["overlap"]) == (world > 1) and sc_b.wire == (world == 1)
     # ONE rank's plan ran ahead of its read-backs on sizes that did not hold (mvs_plan_finish, plan_speculate): its header says
     # so, it compares again, everybody exchanges again
     ops_st = OracleOps()

@@ -262,3 +262,26 @@ def test_toy_cell_fixture_carries_reference_provenance(gold):
     for rname, pin in gold.kat["survey_pairwise_pins"].items():
         for cname, q in zip(pin["cols"], pin["q"]):
             assert by_name[(rname, cname)] == q
+
+
+def test_low_limb_and_coarse_value_pin_every_value_the_radix_rule_admits():
+    """csrc/mvs_pairwise.hip "The high limb on the wire": for every radix m <= 252 and every v with |v| <= 127 m - ceil(m / 2) + 254
+    (what radix_keeps_high_limb admits; |v| <= 32 896 = two signed base-256 digits), the coarse value c = clamp(rint(v / m)) and
+    the low digit of v give v back -- exhaustively, with the float arithmetic the kernels use."""
+    def wrap8(x):
+        return ((x + 128) % 256) - 128
+    for m in range(1, 253):
+        h = (m + 1) // 2
+        edge = 127 * m - h
+        top = min(edge + 254, 32896)
+        v = np.arange(-top, top + 1, dtype=np.int64)
+        c = np.clip(np.rint(v.astype(np.float32) * (np.float32(1.0) / np.float32(m))).astype(np.int64), -127, 127)
+        l0 = wrap8(v)
+        t = np.where(c == 127, edge + 127, np.where(c == -127, -(edge + 127), m * c))
+        assert np.array_equal(t + wrap8(l0 - t), v), m
+        hi = (v - l0) // 256
+        assert hi.min() >= -128 and hi.max() <= 127
+    # the radix that just avoids clamping always qualifies, whatever the row's largest |v|
+    mx = np.arange(1, 32005, dtype=np.int64)
+    m = np.maximum(1, (mx + 126) // 127)
+    assert np.all(mx <= 127 * m - (m + 1) // 2 + 254) and m.max() == 252

@@ -345,3 +345,48 @@ def test_sharded_comparison_repeats_a_step_whose_plan_was_stale(ctx):
         torch.cuda.synchronize()
         assert info.get("plan_respeculated", 0) == (1 if rep == 2 else 0)
         assert cnt == n_want and np.array_equal(out[:cnt].cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("d", [64, 100, 512, 2048, 2100, 4096, 5000])
+@pytest.mark.parametrize("dtype", [np.int32, np.int16])
+def test_limb_planes_rebuilt_from_low_limbs_and_the_coarse_plane(ctx, d, dtype):
+    """mvs_sketch_set_planes_from_wire: what a rank receives in a multi-rank step -- low limbs, fragment-major coarse plane,
+    row statistics -- gives back both limb planes byte for byte, for rows at the largest |v| the rule covers (32 004), rows whose
+    radix search settled below the clamping-free radix (bell-shaped entries with a few outliers), one-limb rows, zero rows and
+    the padding rows behind the samples; rows outside the range are not touched"""
+    rng = np.random.default_rng(1000 + d)
+    n, rows = 150, 160                                           # 150 samples in a range of 160 rows starting at row 32
+    sk = np.rint(rng.normal(0.0, 220.0, size=(n, d))).astype(np.int64)
+    sk[np.arange(0, n, 7), rng.integers(0, d, size=len(range(0, n, 7)))] = 1500          # outliers: the radix search clamps them
+    sk[3] = 0
+    sk[5] = rng.integers(-100, 101, size=d)
+    sk[7] = rng.integers(-_capi.WIRE_MAX_ABS, _capi.WIRE_MAX_ABS + 1, size=d)
+    sk[7, 0] = _capi.WIRE_MAX_ABS
+    sk[8] = -sk[7]
+    sk[9] = rng.integers(-4000, 4001, size=d)
+    sk[9, d // 2] = 31000                                        # one far outlier in a small row
+    sk = np.clip(sk, -32004, 32004).astype(dtype)
+    n_st = 256
+    n_alloc, d_pad, nbytes = ctx.limb_geometry(n_st, d, 2)
+    planes = torch.zeros(nbytes, dtype=torch.int8, device=DEV)
+    coarse = torch.zeros(n_alloc * d_pad, dtype=torch.uint8, device=DEV)
+    stats = torch.zeros(n_alloc * 16, dtype=torch.uint8, device=DEV)
+    sset = ctx.sketch_set_from_planes(planes, n_st, n_alloc, d, d_pad, 2)
+    ctx.attach_derived(sset, coarse, stats)
+    ctx.recode_rows(sset, torch.from_numpy(sk).to(DEV), 32, rows)
+    lo = torch.zeros(n_alloc * d_pad, dtype=torch.int8, device=DEV)
+    parallel.GpuOps(ctx, DEV).wire_rows(planes, lo, d_pad, 32, rows)
+    rebuilt = torch.full((nbytes,), 0x33, dtype=torch.int8, device=DEV)
+    other = ctx.sketch_set_from_planes(rebuilt, n_st, n_alloc, d, d_pad, 2)
+    ctx.attach_derived(other, coarse, stats)
+    ctx.planes_from_wire(other, lo, 32, rows)
+    torch.cuda.synchronize()
+    a = planes.cpu().numpy().reshape(-1, 2, d_pad)
+    b = rebuilt.cpu().numpy().reshape(-1, 2, d_pad)
+    assert np.array_equal(b[32:32 + rows], a[32:32 + rows])
+    assert np.all(b[:32] == 0x33) and np.all(b[32 + rows:] == 0x33)
+    radix = stats.cpu().numpy().reshape(-1, 16)[32:32 + n, :4].copy().view("<i4").reshape(n)
+    clampfree = np.maximum(1, (np.abs(sk.astype(np.int64)).max(axis=1) + 126) // 127)
+    assert np.all(radix <= clampfree) and np.any(radix < clampfree)          # the search did go below it somewhere
+    sset.close()
+    other.close()

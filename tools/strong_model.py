@@ -9,7 +9,8 @@ rows (k_recode_rows), its block plan of the symmetric schedule (diagonal block, 
 mvs_plan_begin / _filter / _finish), kept cells routed and sorted -- with every byte the exchange would have delivered
 already in place.  What is measured: the device time of every stage for the per-rank problem size (events on the stream),
 and the host-visible step time without any exchange.  What is modelled: the exchange.  Per rank and peer the all-gathers move
-P * 24 bytes (statistics + norms), P * d_pad bytes (coarse plane, in `chunks` pieces) and P * 2 * d_pad bytes (limb planes),
+P * 24 bytes (statistics + norms), P * d_pad bytes (coarse plane, in `chunks` pieces) and P * d_pad bytes (low limbs; the
+receiver rebuilds the high limbs from them and the coarse plane: mvs_sketch_set_planes_from_wire, timed here; --no-wire: both limb planes),
 P = padded rows per rank; on the fully connected xGMI mesh every peer's block arrives over its own link, so a gather takes
 block bytes / link rate (+ a latency per collective).  The filter of the diagonal block starts at once; the peers' chunk c
 can start when chunk c of the coarse plane has landed; the re-check needs the limb planes.  The model walks that timeline.
@@ -46,6 +47,7 @@ def main():
     ap.add_argument("--reps", type=int, default=8)
     ap.add_argument("--seed", type=int, default=2345)
     ap.add_argument("--no-speculate", action="store_true", help="every plan waits for its own counts (two host syncs per step)")
+    ap.add_argument("--no-wire", action="store_true", help="limb planes on the wire (3 bytes per entry) instead of low limbs (2)")
     ap.add_argument("--overlap", action="store_true", help="filter launches of a plan alternate between two streams (plan_overlap)")
     ap.add_argument("--out", default="")
     args = ap.parse_args()
@@ -84,8 +86,11 @@ def main():
         d_own = torch.zeros(2 + (e0 - b0 + 2) // 2, dtype=torch.int64, device=dev)      # the shard's state block
         send = torch.zeros(_capi.CELLS_HEADER_BYTES + 16 * cap, dtype=torch.uint8, device=dev)
         plan = parallel.block_plan(G, 0, P)
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(8)]
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(10)]
         acc = []
+        lo = torch.zeros(n_alloc * d_pad, dtype=torch.int8, device=dev)
+        gops = parallel.GpuOps(ctx, dev)
+        gops.wire_rows(planes, lo, d_pad, 0, n_st)                 # what the exchange of low limbs would have delivered
         for rep in range(args.reps + 2):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -113,6 +118,14 @@ def main():
             ev[6].record()
             torch.cuda.synchronize()
             wall = (time.perf_counter() - t0) * 1e3
+            # rebuilding the other ranks' limb planes from low limbs + coarse plane: on the exchange's stream in a real step
+            # (beside the filter kernels), timed here alone
+            ev[7].record()
+            if G > 1 and not args.no_wire:
+                for p in range(1, G):
+                    ctx.planes_from_wire(sset, lo, p * P, P)
+            ev[8].record()
+            torch.cuda.synchronize()
             if rep >= 2:
                 ps = ctx.plan_stats()
                 acc.append({"wall_ms": wall, "prepare_ms": ev[0].elapsed_time(ev[1]), "diag_filter_ms": ev[1].elapsed_time(ev[2]),
@@ -121,6 +134,7 @@ def main():
                             "filter_kernels_ms": ps["filter_ms"], "recheck_ms": ps["recheck_ms"], "tiles_ms": ps["tiles_ms"],
                             "filter_tiles": ps["filter_tiles"], "filter_launches": ps["filter_launches"], "candidates": ps["candidates"],
                             "flagged_tiles": ps["flagged_tiles"], "own_cells": int(n_own), "foreign_cells": int(heads[0][0]),
+                            "rebuild_ms": ev[7].elapsed_time(ev[8]),
                             "speculated": float(ps["speculated"]), "stale": float(ps["stale"])})
         m = {k: float(np.mean([a[k] for a in acc])) for k in acc[0]}
         m["rows_per_rank_padded"] = P
@@ -137,7 +151,8 @@ def main():
             for (c0, c1) in chunks:
                 t_comm += (lat + (c1 - c0) * d_pad / (rate * 1e6)) if G > 1 else 0.0
                 arrive.append(t_comm)
-            planes_at = t_comm + ((lat + P * 2 * d_pad / (rate * 1e6)) if G > 1 else 0.0)
+            wire_bytes = (2 if args.no_wire else 1) * d_pad            # limb planes, or low limbs + the rebuild behind them
+            planes_at = t_comm + ((lat + P * wire_bytes / (rate * 1e6) + m["rebuild_ms"]) if G > 1 else 0.0)
             # compute stream: prepare, diagonal filter, then the chunk launches (each waits for its chunk), finish waits for the planes
             t = m["prepare_ms"] + m["diag_filter_ms"]
             per_chunk = m["peer_filters_ms"] / max(1, len(chunks))
@@ -161,14 +176,14 @@ def main():
         m["model"] = models
         out["ranks"][str(G)] = m
         print("G=%d  P=%d  wall %.3f ms (no exchange)  prepare %.3f  diag %.3f  peers %.3f  finish %.3f  route %.3f  sort %.3f | "
-              "filter kernels %.3f (%d tiles, %d launches)  re-check %.3f  tiles %.3f" %
+              "filter kernels %.3f (%d tiles, %d launches)  re-check %.3f  tiles %.3f | rebuild of the peers' limb planes %.3f" %
               (G, P, m["wall_ms"], m["prepare_ms"], m["diag_filter_ms"], m["peer_filters_ms"], m["finish_ms"], m["route_report_ms"],
-               m["sort_ms"], m["filter_kernels_ms"], m["filter_tiles"], m["filter_launches"], m["recheck_ms"], m["tiles_ms"]))
+               m["sort_ms"], m["filter_kernels_ms"], m["filter_tiles"], m["filter_launches"], m["recheck_ms"], m["tiles_ms"], m["rebuild_ms"]))
         for k, v in models.items():
             print("      %s: step %.3f ms (exchange exposed %.3f) -> %.2f x the measured 1-GPU step" %
                   (k, v["step_ms"], v["exposed_exchange_ms"], v["speedup_vs_1gpu_measured"]))
         sset.close()
-        del planes, coarse, stats, n2_st, raw, own, outc, send
+        del planes, coarse, stats, n2_st, raw, own, outc, send, lo
         torch.cuda.empty_cache()
     if args.out:
         with open(args.out, "w") as f:
