@@ -574,23 +574,33 @@ class ShardedComparison:
                 self._mark(1)
                 self._trace("limb planes [%d,%d) gathered" % (row_begin, row_end), getattr(coll, "stream", None))
                 return
-            coll.allgather_rows(self._lo, P, row_begin, row_end - row_begin, d_pad)
-            self._mark(1)
-            self._trace("low limbs [%d,%d) gathered" % (row_begin, row_end), getattr(coll, "stream", None))
-            if last and coll.inline:
-                # every part's low limbs, the coarse plane and the statistics are queued in front of this on the exchange's
-                # stream: the other ranks' limb planes are rebuilt there, beside the compute stream's filter kernels
-                self._rebuild(st, getattr(coll, "stream", None))
+            # Every part's coarse plane and -- with the last part -- the statistics are queued in front of this on the
+            # exchange's stream, so the other ranks' limb planes can be rebuilt there, beside the compute stream's filter
+            # kernels: the last part's low limbs travel in pieces, and a piece is rebuilt while the next one is on the links
+            # (the earlier parts' rows are rebuilt in front of the first piece)
+            stream = getattr(coll, "stream", None)
+            pieces = chunk_bounds(row_end - row_begin, self.gather_chunks) if (last and coll.inline) else [(0, row_end - row_begin)]
+            done = 0 if last else None
+            for (c0, c1) in pieces:
+                coll.allgather_rows(self._lo, P, row_begin + c0, c1 - c0, d_pad)
+                self._mark(1)
+                self._trace("low limbs [%d,%d) gathered" % (row_begin + c0, row_begin + c1), stream)
+                if last and coll.inline:
+                    self._rebuild(st, done, row_begin + c1, stream)
+                    done = row_begin + c1
         st["planes"].append(coll.submit(planes))
 
-    def _rebuild(self, st, stream):
+    def _rebuild(self, st, r0, r1, stream):
+        """the other ranks' limb planes of block rows [r0, r1) from their low limbs, coarse plane and statistics"""
         P = st["P"]
-        for p in range(self.world):
-            if p != self.rank:
-                self.ops.planes_from_wire(self._sset, self._lo, p * P, P, stream=stream)
-        self._mark(1)
-        self._trace("limb planes rebuilt", stream)
-        st["rebuilt"] = True
+        if r1 > r0:
+            for p in range(self.world):
+                if p != self.rank:
+                    self.ops.planes_from_wire(self._sset, self._lo, p * P + r0, r1 - r0, stream=stream)
+            self._mark(1)
+            self._trace("limb planes [%d,%d) rebuilt" % (r0, r1), stream)
+        if r1 == P:
+            st["rebuilt"] = True
 
     def finish(self, keep_mode=_capi.KEEP_INT32, cells_out=None):
         st, self._step = self._step, None
@@ -729,7 +739,7 @@ class ShardedComparison:
             for h in st["planes"]:
                 h.wait()
             if st["wire"] and not st["rebuilt"]:           # (an exchange that ran on a worker thread: rebuilt here)
-                self._rebuild(st, None)
+                self._rebuild(st, 0, P, None)
         d_cnt = ops.plan_finish()
         self._trace("plan finished")
         return d_cnt

@@ -305,7 +305,8 @@ def _worker(rank, world, port, n, d, out_dir):
     assert steps[0] == "begin" and steps[1] == "filter 1" and steps[-1] == "finish"
     # two bytes per entry on the wire: the other ranks' limb planes were rebuilt from low limbs + coarse plane, once per peer
     assert info["wire"].startswith("coarse plane + low limbs") == (world > 1)
-    assert len([x for x in ops.log if x.startswith("rebuilt")]) == world - 1
+    rebuilt = [int(x.split()[1]) for x in ops.log if x.startswith("rebuilt")]
+    assert sorted(set(r // ops.layout(n, world)[1] for r in rebuilt)) == [p for p in range(world) if p != rank]
     if len(parallel.block_plan(world, rank, ops.layout(n, world)[1])) > 1:
         assert len([x for x in ops.log if x.startswith("filter")]) >= 2
     cells2, cnt2, _ = sc.run(sk[b:e], n2[b:e], n)           # second step reuses the gathered buffers

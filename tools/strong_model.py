@@ -151,8 +151,12 @@ def main():
             for (c0, c1) in chunks:
                 t_comm += (lat + (c1 - c0) * d_pad / (rate * 1e6)) if G > 1 else 0.0
                 arrive.append(t_comm)
-            wire_bytes = (2 if args.no_wire else 1) * d_pad            # limb planes, or low limbs + the rebuild behind them
-            planes_at = t_comm + ((lat + P * wire_bytes / (rate * 1e6) + m["rebuild_ms"]) if G > 1 else 0.0)
+            # limb planes; or low limbs in `chunks` pieces, a piece rebuilt while the next one is on the links: the last piece's
+            # rebuild is what remains behind the transfer
+            if args.no_wire:
+                planes_at = t_comm + ((lat + P * 2 * d_pad / (rate * 1e6)) if G > 1 else 0.0)
+            else:
+                planes_at = t_comm + ((lat * len(chunks) + P * d_pad / (rate * 1e6) + m["rebuild_ms"] / len(chunks)) if G > 1 else 0.0)
             # compute stream: prepare, diagonal filter, then the chunk launches (each waits for its chunk), finish waits for the planes
             t = m["prepare_ms"] + m["diag_filter_ms"]
             per_chunk = m["peer_filters_ms"] / max(1, len(chunks))
