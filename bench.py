@@ -714,6 +714,7 @@ def strong_run(args, ctx, dev, rank, world, dist, coll, config, steps, warmup):
                                    (config - 1, n_total, d, world),
                        "total_samples": n_total, "d": d, "limbs": info["limbs"], "kept_cells": kept, "cells_checksum": digest,
                        "schedule": info.get("schedule"), "overlap": info.get("overlap"), "gather_chunks": sc.gather_chunks,
+                       "wire": info.get("wire"),
                        "collectives": info.get("collectives"), **comm_facts(coll, world)},
             "stages": {"prepare_own_rows_ms": prepare_ms,
                        "comparison_kernels_ms_max_over_ranks": k2_max,
