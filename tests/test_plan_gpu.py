@@ -356,8 +356,13 @@ def test_limb_planes_rebuilt_from_low_limbs_and_the_coarse_plane(ctx, d, dtype):
     the padding rows behind the samples; rows outside the range are not touched"""
     rng = np.random.default_rng(1000 + d)
     n, rows = 150, 160                                           # 150 samples in a range of 160 rows starting at row 32
-    sk = np.rint(rng.normal(0.0, 220.0, size=(n, d))).astype(np.int64)
-    sk[np.arange(0, n, 7), rng.integers(0, d, size=len(range(0, n, 7)))] = 1500          # outliers: the radix search clamps them
+    scale = 10.0 ** rng.uniform(0.0, 3.9, size=(n, 1))           # rows of every magnitude: radices from 1 to 252
+    sk = np.rint(rng.normal(0.0, 1.0, size=(n, d)) * scale).astype(np.int64)
+    for r in range(0, n, 3):                                     # outliers of 1.5 .. 12 sigma: the radix search clamps some of them
+        k = rng.integers(0, d, size=3)
+        sk[r, k] = (np.rint(scale[r, 0] * rng.uniform(1.5, 12.0, size=3)) * rng.choice([-1, 1], size=3)).astype(np.int64)
+    sk[1] = np.rint(rng.normal(0.0, 220.0, size=d))
+    sk[1, rng.integers(0, d)] = 1500
     sk[3] = 0
     sk[5] = rng.integers(-100, 101, size=d)
     sk[7] = rng.integers(-_capi.WIRE_MAX_ABS, _capi.WIRE_MAX_ABS + 1, size=d)
