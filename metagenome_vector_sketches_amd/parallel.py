@@ -410,8 +410,14 @@ class ShardedComparison:
         self.symmetric = os.environ.get("MVS_SHARDED_SYMMETRIC", "1") != "0"
         self.gather_chunks = max(1, int(os.environ.get("MVS_GATHER_CHUNKS", "2")))   # pieces the peers' coarse rows arrive in
         # two-limb sets: the exchange carries coarse plane + LOW limbs, the receiver rebuilds the high limbs (2 bytes per entry
-        # on the links instead of 3); switched off for good once a rank reports |v| beyond what the rule covers
-        self.wire = os.environ.get("MVS_WIRE_LOW_LIMB", "1") != "0" and hasattr(ops, "planes_from_wire")
+        # on the links instead of 3); switched off for good once a rank reports |v| beyond what the rule covers.  The rebuild
+        # costs device time (0.22 ms for the 87.8k x 2048 foreign rows of an 8-way split, and running it beside the filter
+        # launches hides little of it: tools/strong_model.py), the bytes it saves only matter where the links are the
+        # bottleneck: up to 4 ranks, where a rank's block travels over one to three links (1.65 -> 1.84 x and 3.15 -> 3.33 x
+        # predicted at 61 GB/s per link; at 8 ranks seven links share the work and the limb planes travel as they are).
+        # MVS_WIRE_LOW_LIMB=0 / 1 forces it off / on for every world size.
+        force = os.environ.get("MVS_WIRE_LOW_LIMB", "")
+        self.wire = force != "0" and hasattr(ops, "planes_from_wire") and (force == "1" or world <= 4)
         self.time_gather = False         # bench: events around the exchange (read with last_gather_ms())
         self.trace = None                # a list: (label, torch event) pairs of the last step (tools/exp/r05_overlap_trace.py)
         self._key = None

@@ -47,7 +47,8 @@ def main():
     ap.add_argument("--reps", type=int, default=8)
     ap.add_argument("--seed", type=int, default=2345)
     ap.add_argument("--no-speculate", action="store_true", help="every plan waits for its own counts (two host syncs per step)")
-    ap.add_argument("--no-wire", action="store_true", help="limb planes on the wire (3 bytes per entry) instead of low limbs (2)")
+    ap.add_argument("--no-wire", action="store_true", help="limb planes on the wire (3 bytes per entry) for every G")
+    ap.add_argument("--wire", action="store_true", help="low limbs on the wire (2 bytes per entry) for every G (default: up to 4 ranks, as parallel.py)")
     ap.add_argument("--rebuild-alone", action="store_true", help="do not run the rebuild of the peers' limb planes beside the filters")
     ap.add_argument("--overlap", action="store_true", help="filter launches of a plan alternate between two streams (plan_overlap)")
     ap.add_argument("--out", default="")
@@ -67,6 +68,7 @@ def main():
     base_ms = None
     for G in [int(x) for x in args.ranks.split(",")]:
         rps, P = _capi.shard_layout(n, G)
+        no_wire = args.no_wire or (G > 4 and not args.wire)        # parallel.ShardedComparison's rule
         n_st = P * G
         n_alloc, d_pad, nbytes = ctx.limb_geometry(n_st, d, 2)
         planes = torch.zeros(nbytes, dtype=torch.int8, device=dev)
@@ -103,7 +105,7 @@ def main():
                 ctx.plan_begin(sset, n2_st, 0, P, G > 1, raw)
             ctx.plan_filter(plan[:1])
             ev[2].record()
-            if G > 1 and not args.no_wire and not args.rebuild_alone:
+            if G > 1 and not no_wire and not args.rebuild_alone:
                 # the other ranks' limb planes are rebuilt on the exchange's stream while the filter launches run: here a side
                 # stream, started behind the diagonal block's launch, joined in front of the re-check -- the measured step
                 # carries whatever the two cost each other
@@ -115,7 +117,7 @@ def main():
                 if blocks:
                     ctx.plan_filter(blocks)
             ev[3].record()
-            if G > 1 and not args.no_wire and not args.rebuild_alone:
+            if G > 1 and not no_wire and not args.rebuild_alone:
                 torch.cuda.current_stream().wait_stream(side)
             d_cnt = ctx.plan_finish()
             ev[4].record()
@@ -131,7 +133,7 @@ def main():
             wall = (time.perf_counter() - t0) * 1e3
             # the same rebuild once more, alone (its own time: what stays behind the last piece of the exchange in the model)
             ev[7].record()
-            if G > 1 and not args.no_wire:
+            if G > 1 and not no_wire:
                 for p in range(1, G):
                     ctx.planes_from_wire(sset, lo, p * P, P)
             ev[8].record()
@@ -148,6 +150,7 @@ def main():
                             "speculated": float(ps["speculated"]), "stale": float(ps["stale"])})
         m = {k: float(np.mean([a[k] for a in acc])) for k in acc[0]}
         m["rows_per_rank_padded"] = P
+        m["wire"] = "coarse plane + limb planes" if no_wire else "coarse plane + low limbs (peers' limb planes rebuilt beside the filters)"
         m["plan_blocks"] = len(plan)
         if base_ms is None:
             base_ms = m["wall_ms"]
@@ -163,7 +166,7 @@ def main():
                 arrive.append(t_comm)
             # limb planes; or low limbs in `chunks` pieces, a piece rebuilt while the next one is on the links: the last piece's
             # rebuild is what remains behind the transfer
-            if args.no_wire:
+            if no_wire:
                 planes_at = t_comm + ((lat + P * 2 * d_pad / (rate * 1e6)) if G > 1 else 0.0)
             else:
                 planes_at = t_comm + ((lat * len(chunks) + P * d_pad / (rate * 1e6) + m["rebuild_ms"] / len(chunks)) if G > 1 else 0.0)
@@ -189,9 +192,9 @@ def main():
                                                                "speedup_vs_1gpu_measured": base_ms / t}
         m["model"] = models
         out["ranks"][str(G)] = m
-        print("G=%d  P=%d  wall %.3f ms (no exchange)  prepare %.3f  diag %.3f  peers %.3f  finish %.3f  route %.3f  sort %.3f | "
+        print("G=%d  [%s]  P=%d  wall %.3f ms (no exchange)  prepare %.3f  diag %.3f  peers %.3f  finish %.3f  route %.3f  sort %.3f | "
               "filter kernels %.3f (%d tiles, %d launches)  re-check %.3f  tiles %.3f | rebuild of the peers' limb planes %.3f" %
-              (G, P, m["wall_ms"], m["prepare_ms"], m["diag_filter_ms"], m["peer_filters_ms"], m["finish_ms"], m["route_report_ms"],
+              (G, "3 B/entry on the wire" if no_wire else "2 B/entry on the wire", P, m["wall_ms"], m["prepare_ms"], m["diag_filter_ms"], m["peer_filters_ms"], m["finish_ms"], m["route_report_ms"],
                m["sort_ms"], m["filter_kernels_ms"], m["filter_tiles"], m["filter_launches"], m["recheck_ms"], m["tiles_ms"], m["rebuild_ms"]))
         for k, v in models.items():
             print("      %s: step %.3f ms (exchange exposed %.3f) -> %.2f x the measured 1-GPU step" %
