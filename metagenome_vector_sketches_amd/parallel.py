@@ -79,12 +79,6 @@ class _Collectives:
     returns a handle whose wait() orders the compute stream behind them.  Base: synchronous."""
     stream = None
 
-    @property
-    def inline(self):
-        """fn() of submit() runs on the calling thread (it may then queue kernels of the numeric back end behind its
-        collectives, on `stream`); False: on a worker thread, where only the collectives themselves belong"""
-        return True
-
     def submit(self, fn):
         fn()
         return _Done()
@@ -146,10 +140,6 @@ class NativeCollectives(_Collectives):
         self.comm, self.rank, self.world, self.stream = comm, comm.rank, comm.world, stream
         self.kind = "libmvs_hip mvs_comm (%s)" % ("RCCL" if comm.is_rccl else "file transport")
         self._pool = None
-
-    @property
-    def inline(self):
-        return self.stream is None or self.comm.is_rccl
 
     def submit(self, fn):
         if self.stream is None:
@@ -336,17 +326,10 @@ class GpuOps:
         rows = planes[:(first + count) * 2 * d_pad].view(-1, 2, d_pad)
         lo_wire[first * d_pad:(first + count) * d_pad].view(count, d_pad).copy_(rows[first:first + count, 0, :])
 
-    def planes_from_wire(self, sset, lo_wire, first, count, stream=None):
+    def planes_from_wire(self, sset, lo_wire, first, count):
         """both limb planes of rows [first, first + count) from their low limbs + the coarse plane / statistics that are in
-        place (mvs_sketch_set_planes_from_wire); stream: queue the kernel there (the exchange's stream: it then runs as
-        soon as the bytes have landed, beside the compute stream's filter kernels)"""
-        if stream is None:
-            return self.ctx.planes_from_wire(sset, lo_wire, first, count)
-        self.ctx.set_stream(stream)
-        try:
-            self.ctx.planes_from_wire(sset, lo_wire, first, count)
-        finally:
-            self.ctx.set_stream(self._main)
+        place (mvs_sketch_set_planes_from_wire)"""
+        self.ctx.planes_from_wire(sset, lo_wire, first, count)
 
     def plan_begin(self, sset, norms_sq, f0, f1, mirror_outside, raw, keep_mode):
         # a step of the same shape as the previous one runs its plan ahead of the read-backs (the decision is taken in
@@ -411,8 +394,7 @@ class ShardedComparison:
         self.gather_chunks = max(1, int(os.environ.get("MVS_GATHER_CHUNKS", "2")))   # pieces the peers' coarse rows arrive in
         # two-limb sets: the exchange carries coarse plane + LOW limbs, the receiver rebuilds the high limbs (2 bytes per entry
         # on the links instead of 3); switched off for good once a rank reports |v| beyond what the rule covers.  The rebuild
-        # costs device time (0.22 ms for the 87.8k x 2048 foreign rows of an 8-way split, and running it beside the filter
-        # launches hides little of it: tools/strong_model.py), the bytes it saves only matter where the links are the
+        # costs device time (0.22 ms for the 87.8k x 2048 foreign rows of an 8-way split), the bytes it saves only matter where the links are the
         # bottleneck: up to 4 ranks, where a rank's block travels over one to three links (1.65 -> 1.84 x and 3.15 -> 3.33 x
         # predicted at 61 GB/s per link; at 8 ranks seven links share the work and the limb planes travel as they are).
         # MVS_WIRE_LOW_LIMB=0 / 1 forces it off / on for every world size.
@@ -580,33 +562,21 @@ class ShardedComparison:
                 self._mark(1)
                 self._trace("limb planes [%d,%d) gathered" % (row_begin, row_end), getattr(coll, "stream", None))
                 return
-            # Every part's coarse plane and -- with the last part -- the statistics are queued in front of this on the
-            # exchange's stream, so the other ranks' limb planes can be rebuilt there, beside the compute stream's filter
-            # kernels: the last part's low limbs travel in pieces, and a piece is rebuilt while the next one is on the links
-            # (the earlier parts' rows are rebuilt in front of the first piece)
-            stream = getattr(coll, "stream", None)
-            pieces = chunk_bounds(row_end - row_begin, self.gather_chunks) if (last and coll.inline) else [(0, row_end - row_begin)]
-            done = 0 if last else None
-            for (c0, c1) in pieces:
-                coll.allgather_rows(self._lo, P, row_begin + c0, c1 - c0, d_pad)
-                self._mark(1)
-                self._trace("low limbs [%d,%d) gathered" % (row_begin + c0, row_begin + c1), stream)
-                if last and coll.inline:
-                    self._rebuild(st, done, row_begin + c1, stream)
-                    done = row_begin + c1
+            coll.allgather_rows(self._lo, P, row_begin, row_end - row_begin, d_pad)
+            self._mark(1)
+            self._trace("low limbs [%d,%d) gathered" % (row_begin, row_end), getattr(coll, "stream", None))
         st["planes"].append(coll.submit(planes))
 
-    def _rebuild(self, st, r0, r1, stream):
-        """the other ranks' limb planes of block rows [r0, r1) from their low limbs, coarse plane and statistics"""
+    def _rebuild(self, st):
+        """the other ranks' limb planes from their low limbs, coarse plane and statistics, on the compute stream in front of
+        the re-check that reads them.  (Queued on the exchange's stream instead -- as soon as the bytes have landed, beside
+        the filter launches -- it cost the filters 1.3 x its own time: tools/strong_model.py, round 5.)"""
         P = st["P"]
-        if r1 > r0:
-            for p in range(self.world):
-                if p != self.rank:
-                    self.ops.planes_from_wire(self._sset, self._lo, p * P + r0, r1 - r0, stream=stream)
-            self._mark(1)
-            self._trace("limb planes [%d,%d) rebuilt" % (r0, r1), stream)
-        if r1 == P:
-            st["rebuilt"] = True
+        for p in range(self.world):
+            if p != self.rank:
+                self.ops.planes_from_wire(self._sset, self._lo, p * P, P)
+        self._trace("limb planes rebuilt")
+        st["rebuilt"] = True
 
     def finish(self, keep_mode=_capi.KEEP_INT32, cells_out=None):
         st, self._step = self._step, None
@@ -744,8 +714,8 @@ class ShardedComparison:
             # needs nothing from anybody (rank 1 of 2): the next step rewrites the buffers the collectives read
             for h in st["planes"]:
                 h.wait()
-            if st["wire"] and not st["rebuilt"]:           # (an exchange that ran on a worker thread: rebuilt here)
-                self._rebuild(st, 0, P, None)
+            if st["wire"] and not st["rebuilt"]:
+                self._rebuild(st)
         d_cnt = ops.plan_finish()
         self._trace("plan finished")
         return d_cnt

@@ -116,7 +116,7 @@ class OracleOps:
     def wire_rows(self, planes, lo_wire, d_pad, first, count):
         lo_wire.numpy().reshape(-1, d_pad)[first:first + count] = planes.numpy().reshape(-1, 2, d_pad)[first:first + count, 0, :]
 
-    def planes_from_wire(self, sset, lo_wire, first, count, stream=None):
+    def planes_from_wire(self, sset, lo_wire, first, count):
         """numpy restatement of k_planes_from_wire: v = the value congruent to the low limb mod 256 near m c"""
         assert sset["limbs"] == 2 and self._landed(sset, first, first + count), "low limbs rebuilt before coarse plane / statistics arrived"
         d_pad = sset["d_pad"]

@@ -49,7 +49,6 @@ def main():
     ap.add_argument("--no-speculate", action="store_true", help="every plan waits for its own counts (two host syncs per step)")
     ap.add_argument("--no-wire", action="store_true", help="limb planes on the wire (3 bytes per entry) for every G")
     ap.add_argument("--wire", action="store_true", help="low limbs on the wire (2 bytes per entry) for every G (default: up to 4 ranks, as parallel.py)")
-    ap.add_argument("--rebuild-alone", action="store_true", help="do not run the rebuild of the peers' limb planes beside the filters")
     ap.add_argument("--overlap", action="store_true", help="filter launches of a plan alternate between two streams (plan_overlap)")
     ap.add_argument("--out", default="")
     args = ap.parse_args()
@@ -91,7 +90,6 @@ def main():
         plan = parallel.block_plan(G, 0, P)
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(10)]
         acc = []
-        side = torch.cuda.Stream()
         lo = torch.zeros(n_alloc * d_pad, dtype=torch.int8, device=dev)
         gops = parallel.GpuOps(ctx, dev)
         gops.wire_rows(planes, lo, d_pad, 0, n_st)                 # what the exchange of low limbs would have delivered
@@ -105,20 +103,15 @@ def main():
                 ctx.plan_begin(sset, n2_st, 0, P, G > 1, raw)
             ctx.plan_filter(plan[:1])
             ev[2].record()
-            if G > 1 and not no_wire and not args.rebuild_alone:
-                # the other ranks' limb planes are rebuilt on the exchange's stream while the filter launches run: here a side
-                # stream, started behind the diagonal block's launch, joined in front of the re-check -- the measured step
-                # carries whatever the two cost each other
-                side.wait_stream(torch.cuda.current_stream())
-                for p in range(1, G):
-                    gops.planes_from_wire(sset, lo, p * P, P, stream=side)
             for (c0, c1) in parallel.chunk_bounds(P, args.chunks):
                 blocks = parallel.clip_blocks(plan[1:], P, c0, c1)
                 if blocks:
                     ctx.plan_filter(blocks)
             ev[3].record()
-            if G > 1 and not no_wire and not args.rebuild_alone:
-                torch.cuda.current_stream().wait_stream(side)
+            if G > 1 and not no_wire:                           # the other ranks' limb planes, in front of the re-check that reads them
+                for p in range(1, G):
+                    ctx.planes_from_wire(sset, lo, p * P, P)
+            ev[9].record()
             d_cnt = ctx.plan_finish()
             ev[4].record()
             ctx.cells_route(raw, d_cnt, P, rps, n, b0, e0, own, d_own, send, cap)
@@ -131,26 +124,19 @@ def main():
             ev[6].record()
             torch.cuda.synchronize()
             wall = (time.perf_counter() - t0) * 1e3
-            # the same rebuild once more, alone (its own time: what stays behind the last piece of the exchange in the model)
-            ev[7].record()
-            if G > 1 and not no_wire:
-                for p in range(1, G):
-                    ctx.planes_from_wire(sset, lo, p * P, P)
-            ev[8].record()
-            torch.cuda.synchronize()
             if rep >= 2:
                 ps = ctx.plan_stats()
                 acc.append({"wall_ms": wall, "prepare_ms": ev[0].elapsed_time(ev[1]), "diag_filter_ms": ev[1].elapsed_time(ev[2]),
-                            "peer_filters_ms": ev[2].elapsed_time(ev[3]), "finish_ms": ev[3].elapsed_time(ev[4]),
+                            "peer_filters_ms": ev[2].elapsed_time(ev[3]), "finish_ms": ev[9].elapsed_time(ev[4]),
                             "route_report_ms": ev[4].elapsed_time(ev[5]), "sort_ms": ev[5].elapsed_time(ev[6]),
                             "filter_kernels_ms": ps["filter_ms"], "recheck_ms": ps["recheck_ms"], "tiles_ms": ps["tiles_ms"],
                             "filter_tiles": ps["filter_tiles"], "filter_launches": ps["filter_launches"], "candidates": ps["candidates"],
                             "flagged_tiles": ps["flagged_tiles"], "own_cells": int(n_own), "foreign_cells": int(heads[0][0]),
-                            "rebuild_ms": ev[7].elapsed_time(ev[8]),
+                            "rebuild_ms": ev[3].elapsed_time(ev[9]),
                             "speculated": float(ps["speculated"]), "stale": float(ps["stale"])})
         m = {k: float(np.mean([a[k] for a in acc])) for k in acc[0]}
         m["rows_per_rank_padded"] = P
-        m["wire"] = "coarse plane + limb planes" if no_wire else "coarse plane + low limbs (peers' limb planes rebuilt beside the filters)"
+        m["wire"] = "coarse plane + limb planes" if no_wire else "coarse plane + low limbs (peers' limb planes rebuilt in front of the re-check)"
         m["plan_blocks"] = len(plan)
         if base_ms is None:
             base_ms = m["wall_ms"]
@@ -164,12 +150,11 @@ def main():
             for (c0, c1) in chunks:
                 t_comm += (lat + (c1 - c0) * d_pad / (rate * 1e6)) if G > 1 else 0.0
                 arrive.append(t_comm)
-            # limb planes; or low limbs in `chunks` pieces, a piece rebuilt while the next one is on the links: the last piece's
-            # rebuild is what remains behind the transfer
+            # what the re-check waits for: the limb planes, or the low limbs (their rebuild is a stage of the compute stream)
             if no_wire:
                 planes_at = t_comm + ((lat + P * 2 * d_pad / (rate * 1e6)) if G > 1 else 0.0)
             else:
-                planes_at = t_comm + ((lat * len(chunks) + P * d_pad / (rate * 1e6) + m["rebuild_ms"] / len(chunks)) if G > 1 else 0.0)
+                planes_at = t_comm + ((lat + P * d_pad / (rate * 1e6)) if G > 1 else 0.0)      # the low limbs
             # compute stream: prepare, diagonal filter, then the chunk launches (each waits for its chunk), finish waits for the planes
             t = m["prepare_ms"] + m["diag_filter_ms"]
             per_chunk = m["peer_filters_ms"] / max(1, len(chunks))
@@ -182,10 +167,10 @@ def main():
             if G > 1 and planes_at > t:
                 waited += planes_at - t
                 t = planes_at
-            t += m["finish_ms"] + m["route_report_ms"]
+            t += m["rebuild_ms"] + m["finish_ms"] + m["route_report_ms"]
             exch = (lat + (64 + 16 * m["foreign_cells"] * 1.25) / (rate * 1e6)) if G > 1 else 0.0   # the mirrored cells
             t += exch + m["sort_ms"]
-            host_gap = max(0.0, m["wall_ms"] - (m["prepare_ms"] + m["diag_filter_ms"] + m["peer_filters_ms"] + m["finish_ms"] +
+            host_gap = max(0.0, m["wall_ms"] - (m["prepare_ms"] + m["diag_filter_ms"] + m["peer_filters_ms"] + m["rebuild_ms"] + m["finish_ms"] +
                                                 m["route_report_ms"] + m["sort_ms"]))
             t += host_gap
             models["%g GB/s per link and direction" % rate] = {"step_ms": t, "exposed_exchange_ms": waited + exch,
