@@ -345,6 +345,10 @@ class GpuOps:
     def plan_filter(self, blocks):
         self.ctx.plan_filter(blocks)
 
+    def plan_exact_mode(self):
+        """the plan that has just begun runs without a filter: its blocks are compared by the exact kernel when handed over"""
+        return self.ctx.plan_stats()["exact_mode"]
+
     def plan_finish(self):
         return self.ctx.plan_finish()
 
@@ -700,7 +704,18 @@ class ShardedComparison:
         if first:
             for h in st["small"]:
                 h.wait()                                   # row statistics + norms of every rank
-        if first and st["coarse"]:
+        if first and others and getattr(ops, "plan_exact_mode", lambda: False)():
+            # no filter in this plan (filter switched off, another limb code): mvs_plan_filter runs the exact kernel on a block
+            # at once, and that reads the other ranks' LIMB planes -- they have to be there (and rebuilt) before the call
+            for (_, _, h) in st["coarse"]:
+                h.wait()
+            for h in st["planes"]:
+                h.wait()
+            if st["wire"] and not st["rebuilt"]:
+                self._rebuild(st)
+            ops.plan_filter(others)
+            self._trace("exact kernel launched: peers' blocks")
+        elif first and st["coarse"]:
             for (a, b, h) in st["coarse"]:
                 h.wait()
                 blocks = clip_blocks(others, P, a, b)
@@ -714,7 +729,7 @@ class ShardedComparison:
             # needs nothing from anybody (rank 1 of 2): the next step rewrites the buffers the collectives read
             for h in st["planes"]:
                 h.wait()
-            if st["wire"] and not st["rebuilt"]:
+            if st["wire"] and not st["rebuilt"] and others:    # (a plan without peer blocks reads nobody's limb planes)
                 self._rebuild(st)
         d_cnt = ops.plan_finish()
         self._trace("plan finished")

@@ -31,6 +31,7 @@ class OracleOps:
         self.log = []
         self.coll = coll                  # lazy collectives: the re-check must not run while exchanges are outstanding
         self.stale_next = 0               # plans to report as MVS_PLAN_STALE
+        self.exact = False                # True: a plan without a filter -- its blocks are compared when they are handed over
 
     # ---- geometry / buffers ----
     def layout(self, n_total, world):
@@ -154,9 +155,14 @@ class OracleOps:
         self.plan = {"sset": sset, "n2": norms_sq, "f0": f0, "f1": f1, "mirror": mirror_outside, "raw": raw, "blocks": []}
         self.log.append("begin")
 
+    def plan_exact_mode(self):
+        return self.exact
+
     def plan_filter(self, blocks):
         p = self.plan
         for (rb, re, cb, ce) in blocks:
+            if self.exact and self.coll is not None and not (cb >= p["f0"] and ce <= p["f1"]):
+                assert self.coll.outstanding() == 0, "exact kernel on a peer's block while its limb planes are still on the way"
             assert p["f0"] <= rb <= re <= p["f1"] and rb % 256 == 0 and cb % 256 == 0
             inside = cb >= p["f0"] and ce <= p["f1"]
             assert inside or ce <= p["f0"] or cb >= p["f1"]
@@ -306,7 +312,8 @@ def _worker(rank, world, port, n, d, out_dir):
     # two bytes per entry on the wire: the other ranks' limb planes were rebuilt from low limbs + coarse plane, once per peer
     assert info["wire"].startswith("coarse plane + low limbs") == (world > 1)
     rebuilt = [int(x.split()[1]) for x in ops.log if x.startswith("rebuilt")]
-    assert sorted(set(r // ops.layout(n, world)[1] for r in rebuilt)) == [p for p in range(world) if p != rank]
+    has_peers = len(parallel.block_plan(world, rank, ops.layout(n, world)[1])) > 1      # (else nobody's limb planes are read)
+    assert sorted(set(r // ops.layout(n, world)[1] for r in rebuilt)) == ([p for p in range(world) if p != rank] if has_peers else [])
     if len(parallel.block_plan(world, rank, ops.layout(n, world)[1])) > 1:
         assert len([x for x in ops.log if x.startswith("filter")]) >= 2
     cells2, cnt2, _ = sc.run(sk[b:e], n2[b:e], n)           # second step reuses the gathered buffers
@@ -327,6 +334,11 @@ def _worker(rank, world, port, n, d, out_dir):
     sc_lazy = parallel.ShardedComparison(OracleOps(lazy), rank, world, collectives=lazy)
     _, cnt_l, _ = sc_lazy.run(sk[b:e], n2[b:e], n, cells_out=out)
     assert cnt_l == cnt and np.array_equal(out[:cnt_l].numpy(), plain)
+    ops_x = OracleOps(lazy)
+    ops_x.exact = True                    # a plan without a filter reads the peers' limb planes when a block is handed over
+    sc_x = parallel.ShardedComparison(ops_x, rank, world, collectives=lazy)
+    _, cnt_x, _ = sc_x.run(sk[b:e], n2[b:e], n, cells_out=out)
+    assert cnt_x == cnt and np.array_equal(out[:cnt_x].numpy(), plain)
     sc_lazy.begin(torch.from_numpy(sk[b:e].copy()), n2[b:e], n)
     for (p0, p1) in sc_lazy.part_bounds(n, 2):
         q0, q1 = min(p0, e - b), min(p1, e - b)
