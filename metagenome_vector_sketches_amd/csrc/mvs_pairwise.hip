@@ -2245,18 +2245,21 @@ __global__ __launch_bounds__(RW * 64) void k_recode_rows(const T* __restrict__ s
 
 // k_planes_from_wire: limb planes of rows whose LOW limb arrived in a wire buffer (lo[row * d_pad + k]) and whose coarse
 // plane and statistics are in place (fragment-major, as the filter reads them): both limb rows are written -- the rule is
-// at radix_keeps_high_limb.  One workgroup per group of 16 rows (one KiB of the fragment-major plane holds 16 rows x 64 k):
-// a lane takes 16 consecutive k of one row, reads its 16 coarse bytes where k_recode_rows put them and 16 bytes of the wire.
+// at radix_keeps_high_limb.  A workgroup takes 16 rows (one KiB of the fragment-major plane holds 16 rows x 64 k) x 256 k: a lane
+// takes 16 consecutive k of one row, reads its 16 coarse bytes where k_recode_rows put them and 16 bytes of the wire.  (One
+// workgroup per 16 rows looping over k moved 3.4 TB/s: eight dependent rounds of loads per workgroup.)
 __global__ __launch_bounds__(256) void k_planes_from_wire(const int8_t* __restrict__ lo_wire, const int8_t* __restrict__ coarse_fm,
                                                           const CoarseRow* __restrict__ rows, int64_t count, int d_pad,
                                                           int8_t* __restrict__ planes) {
     const int nk = d_pad / 64;
     const int64_t grp = blockIdx.x;                        // 16 rows
     const int chunks = 16 * (d_pad / 16);                  // (row, 16-entry chunk) pairs of the group
-    for (int idx = threadIdx.x; idx < chunks; idx += 256) {
+    {
+        const int idx = (int)blockIdx.y * 256 + (int)threadIdx.x;
+        if (idx >= chunks) return;
         const int r = idx & 15, kc = idx >> 4;             // consecutive lanes: the 16 rows of one chunk = 256 contiguous bytes of the plane
         const int64_t row = grp * 16 + r;
-        if (row >= count) continue;
+        if (row >= count) return;
         const int m = rows[row].radix;
         const v4i c4 = *reinterpret_cast<const v4i*>(coarse_fm + (grp * nk + (kc >> 2)) * 1024 + (((kc & 3) << 4) + r) * 16);
         const v4i l4 = *reinterpret_cast<const v4i*>(lo_wire + row * (int64_t)d_pad + kc * 16);
@@ -3247,8 +3250,8 @@ int launch_coarse_fm(hipStream_t stream, const int8_t* d_coarse, int64_t n_alloc
 int launch_planes_from_wire(hipStream_t stream, const int8_t* d_lo_wire, const int8_t* d_coarse_fm, const CoarseRow* d_rows,
                             int64_t count, int d_pad, int8_t* d_planes) {
     if (count <= 0) return 0;
-    hipLaunchKernelGGL(k_planes_from_wire, dim3((unsigned)(count / 16)), dim3(256), 0, stream, d_lo_wire, d_coarse_fm, d_rows, count, d_pad,
-                       d_planes);
+    hipLaunchKernelGGL(k_planes_from_wire, dim3((unsigned)(count / 16), (unsigned)((d_pad / 16 * 16 + 255) / 256)), dim3(256), 0, stream,
+                       d_lo_wire, d_coarse_fm, d_rows, count, d_pad, d_planes);
     return 0;
 }
 
