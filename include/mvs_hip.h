@@ -467,6 +467,12 @@ int mvs_cells_report(mvs_ctx* ctx, const void* recv, int world, int64_t foreign_
                      int64_t* out);
 int mvs_cells_sort_rows(mvs_ctx* ctx, const mvs_cell* cells_in, int64_t n, int64_t own_begin, int64_t own_end,
                         const uint64_t* d_own_count, mvs_cell* cells_out);
+/* mvs_cells_sort_rows queued IN FRONT of mvs_cells_report's read-back: the number of cells is the one in the state block (at
+ * most in_capacity of them are in cells_in), cells whose place lies beyond out_capacity are dropped.  For a caller that knows
+ * from its previous step that no row holds more than 64 cells and that the buffers suffice; what the report then says -- cell
+ * count, largest row -- tells it whether that held (if not: sort again with what the report says).  Asynchronous. */
+int mvs_cells_sort_rows_ahead(mvs_ctx* ctx, const mvs_cell* cells_in, int64_t in_capacity, int64_t own_begin, int64_t own_end,
+                              const uint64_t* d_own_count, mvs_cell* cells_out, int64_t out_capacity);
 #define MVS_CELLS_HEADER_BYTES 64
 
 /* Sort n cells by (row, col) from one DEVICE buffer into another (asynchronous on the context's stream). */

@@ -126,6 +126,7 @@ SYMBOLS = [
     ("mvs_cells_collect", _c.c_int, [_P, _P, _c.c_int, _c.c_int, _c.c_int64, _c.c_int64, _c.c_int64, _P, _c.c_int64, _P]),
     ("mvs_cells_report", _c.c_int, [_P, _P, _c.c_int, _c.c_int64, _c.c_int64, _P, _c.POINTER(_c.c_int64)]),
     ("mvs_cells_sort_rows", _c.c_int, [_P, _P, _c.c_int64, _c.c_int64, _c.c_int64, _P, _P]),
+    ("mvs_cells_sort_rows_ahead", _c.c_int, [_P, _P, _c.c_int64, _c.c_int64, _c.c_int64, _P, _P, _c.c_int64]),
     ("mvs_chunk_size", _c.c_int64, [_c.c_double, _c.c_int]),
     ("mvs_shard_rows", None, [_c.c_int64, _c.c_int, _c.c_int, _c.POINTER(_c.c_int64), _c.POINTER(_c.c_int64)]),
 ]
@@ -796,6 +797,14 @@ class Context:
         op, om, ok = _buf(cells_out)
         cp, cm, ck = _buf(d_own_count)
         _check(self.lib.mvs_cells_sort_rows(self._h, ip, int(n), int(own_begin), int(own_end), cp, op))
+
+    def cells_sort_rows_ahead(self, cells_in, own_begin, own_end, d_own_count, cells_out):
+        """the row-bucket sort queued before the report's read-back: the count is the one on the device, both buffers' sizes bound it"""
+        ip, im, ik = _buf(cells_in)
+        op, om, ok = _buf(cells_out)
+        cp, cm, ck = _buf(d_own_count)
+        _check(self.lib.mvs_cells_sort_rows_ahead(self._h, ip, int(cells_in.shape[0]), int(own_begin), int(own_end), cp, op,
+                                                  int(cells_out.shape[0])))
 
     def cells_sort(self, cells_in, n, cells_out):
         ip, im, ik = _buf(cells_in)

@@ -3685,6 +3685,28 @@ int mvs_cells_sort_rows(mvs_ctx* c, const mvs_cell* cells_in, int64_t n, int64_t
     return check_kernel("k_rows_sort");
 }
 
+int mvs_cells_sort_rows_ahead(mvs_ctx* c, const mvs_cell* cells_in, int64_t in_capacity, int64_t own_begin, int64_t own_end,
+                              const uint64_t* d_own_state, mvs_cell* cells_out, int64_t out_capacity) {
+    if (!c || !d_own_state) return fail(MVS_E_INVALID, "NULL argument");
+    if (in_capacity < 0 || out_capacity < 0 || own_begin < 0 || own_end < own_begin || own_end - own_begin >= (1LL << 30) ||
+        in_capacity >= (1LL << 32) || out_capacity >= (1LL << 32))
+        return fail(MVS_E_INVALID, "bad argument");
+    if (in_capacity == 0 || out_capacity == 0) return MVS_OK;
+    if (!cells_in || !cells_out || cells_in == cells_out) return fail(MVS_E_INVALID, "need two distinct device buffers");
+    HIP_TRY(hipSetDevice(c->device));
+    size_t need = 0;
+    int rc = mvs::sort_cells_rows(c->stream, cells_in, cells_out, 0, (int)own_begin, (int)(own_end - own_begin),
+                                  reinterpret_cast<const unsigned long long*>(d_own_state), nullptr, 0, &need, in_capacity, out_capacity);
+    if (rc) return fail(rc, "row sort sizing failed");
+    rc = ensure_buf(c, &c->pw_sort, &c->pw_sort_bytes, need);
+    if (rc) return rc;
+    rc = mvs::sort_cells_rows(c->stream, cells_in, cells_out, 0, (int)own_begin, (int)(own_end - own_begin),
+                              reinterpret_cast<const unsigned long long*>(d_own_state), c->pw_sort, c->pw_sort_bytes, nullptr, in_capacity,
+                              out_capacity);
+    if (rc) return fail(rc, "row sort failed");
+    return check_kernel("k_rows_sort");
+}
+
 int mvs_cells_report(mvs_ctx* c, const void* recv, int world, int64_t foreign_capacity, int64_t own_rows, uint64_t* d_own_count,
                      int64_t* out) {
     if (!c || !d_own_count || !out || world < 1 || foreign_capacity < 0 || own_rows < 0 || (world > 1 && !recv))

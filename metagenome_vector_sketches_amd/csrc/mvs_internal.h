@@ -308,7 +308,8 @@ int launch_cells_collect(hipStream_t stream, const unsigned long long* d_recv, i
 // the shard's cells by row buckets (rows of <= 64 cells): state block as the route / collect kernels fill it
 int launch_rows_max(hipStream_t stream, unsigned long long* d_state, int rows);
 int sort_cells_rows(hipStream_t stream, const mvs_cell* d_in, mvs_cell* d_out, int64_t n, int row0, int rows,
-                    const unsigned long long* d_state, void* d_scratch, size_t scratch_bytes, size_t* scratch_needed);
+                    const unsigned long long* d_state, void* d_scratch, size_t scratch_bytes, size_t* scratch_needed,
+                    int64_t in_cap = -1, int64_t out_cap = -1);
 // sort cells by (row, col); tmp buffers owned by the caller
 int sort_cells(hipStream_t stream, mvs_cell* d_cells, mvs_cell* d_tmp, int64_t n, void* d_scratch,
                size_t scratch_bytes, size_t* scratch_needed, const Options& opt);

@@ -2991,12 +2991,20 @@ __global__ __launch_bounds__(1024) void k_rows_max(unsigned long long* __restric
     }
 }
 
-__global__ __launch_bounds__(256) void k_rows_scatter(const mvs_cell* __restrict__ in, unsigned long long n, int row0,
-                                                      unsigned* __restrict__ cursor, mvs_cell* __restrict__ out) {
+// d_count != NULL: the number of cells is read there (a sort queued in front of the read-back that would have told the host) and
+// bounded by in_cap; positions beyond out_cap are not written (the row counts include cells a full buffer dropped)
+__global__ __launch_bounds__(256) void k_rows_scatter(const mvs_cell* __restrict__ in, unsigned long long n,
+                                                      const unsigned long long* __restrict__ d_count, unsigned long long in_cap, int row0,
+                                                      unsigned* __restrict__ cursor, mvs_cell* __restrict__ out, unsigned long long out_cap) {
+    if (d_count) {
+        n = *d_count;
+        n = n < in_cap ? n : in_cap;
+    }
     const unsigned long long stride = (unsigned long long)gridDim.x * 256;
     for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
         const mvs_cell c = in[i];
-        out[atomicAdd(cursor + (c.row - row0), 1u)] = c;
+        const unsigned pos = atomicAdd(cursor + (c.row - row0), 1u);
+        if (pos < out_cap) out[pos] = c;
     }
 }
 
@@ -3019,14 +3027,16 @@ __device__ __forceinline__ void bitonic_by_col(mvs_cell& c, int lane) {
         }
 }
 
-__global__ __launch_bounds__(256) void k_rows_sort(mvs_cell* __restrict__ cells, const unsigned* __restrict__ row_ptr, int rows) {
+__global__ __launch_bounds__(256) void k_rows_sort(mvs_cell* __restrict__ cells, const unsigned* __restrict__ row_ptr, int rows,
+                                                   unsigned long long out_cap) {
     const int lane = threadIdx.x & 63;
     const int waves = gridDim.x * 4;
     // a wave takes four consecutive rows: when none of them holds more than 16 cells (the usual shard: clusters of 16) each
     // quarter of the wave sorts one row, 10 exchange steps instead of 21 on a quarter of the lanes; otherwise row by row
     for (int r0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4; r0 < rows; r0 += waves * 4) {
         const int rq = r0 + (lane >> 4);
-        const unsigned bq = rq < rows ? row_ptr[rq] : 0u, cq = rq < rows ? row_ptr[rq + 1] - bq : 0u;
+        const unsigned bq = rq < rows ? row_ptr[rq] : 0u;
+        const unsigned cq = rq < rows && row_ptr[rq + 1] <= out_cap ? row_ptr[rq + 1] - bq : 0u;      // (rows beyond the buffer: not there)
         if (__ballot(cq > 16u) == 0ULL) {
             mvs_cell c{0, 0x7fffffff, 0, 0};
             const unsigned l16 = (unsigned)lane & 15u;
@@ -3037,7 +3047,7 @@ __global__ __launch_bounds__(256) void k_rows_sort(mvs_cell* __restrict__ cells,
         }
         for (int r = r0; r < r0 + 4 && r < rows; ++r) {
             const unsigned b = row_ptr[r], cnt = row_ptr[r + 1] - b;
-            if (cnt < 2) continue;
+            if (cnt < 2 || row_ptr[r + 1] > out_cap) continue;
             mvs_cell c{0, 0x7fffffff, 0, 0};
             if ((unsigned)lane < cnt) c = cells[b + lane];
             bitonic_by_col<64>(c, lane);
@@ -3684,7 +3694,8 @@ int launch_rows_max(hipStream_t stream, unsigned long long* d_state, int rows) {
 }
 
 int sort_cells_rows(hipStream_t stream, const mvs_cell* d_in, mvs_cell* d_out, int64_t n, int row0, int rows,
-                    const unsigned long long* d_state, void* d_scratch, size_t scratch_bytes, size_t* scratch_needed) {
+                    const unsigned long long* d_state, void* d_scratch, size_t scratch_bytes, size_t* scratch_needed,
+                    int64_t in_cap, int64_t out_cap) {
     const unsigned* counts = reinterpret_cast<const unsigned*>(d_state + 2);
     const size_t tab = ((size_t)rows + 1) * sizeof(unsigned);
     const size_t tab_al = (tab + 255) / 256 * 256;
@@ -3700,9 +3711,14 @@ int sort_cells_rows(hipStream_t stream, const mvs_cell* d_in, mvs_cell* d_out, i
     e = rocprim::exclusive_scan(scan_tmp, need, counts, row_ptr, 0u, (size_t)rows + 1, rocprim::plus<unsigned>(), stream);
     if (e != hipSuccess) return MVS_E_HIP;
     if (hipMemcpyAsync(cursor, row_ptr, tab, hipMemcpyDeviceToDevice, stream) != hipSuccess) return MVS_E_HIP;
-    const unsigned blocks = (unsigned)std::min<int64_t>(2048, std::max<int64_t>(1, (n + 255) / 256));
-    hipLaunchKernelGGL(k_rows_scatter, dim3(blocks), dim3(256), 0, stream, d_in, (unsigned long long)n, row0, cursor, d_out);
-    hipLaunchKernelGGL(k_rows_sort, dim3((unsigned)std::min(4096, (rows + 15) / 16)), dim3(256), 0, stream, d_out, row_ptr, rows);
+    // in_cap >= 0: the count is d_state[0] on the device, at most in_cap cells are there; the grid is sized for the buffer
+    const bool ahead = in_cap >= 0;
+    const int64_t size_for = ahead ? in_cap : n;
+    const unsigned blocks = (unsigned)std::min<int64_t>(ahead ? 1024 : 2048, std::max<int64_t>(1, (size_for + 255) / 256));
+    hipLaunchKernelGGL(k_rows_scatter, dim3(blocks), dim3(256), 0, stream, d_in, (unsigned long long)(ahead ? 0 : n), ahead ? d_state : nullptr,
+                       (unsigned long long)(ahead ? in_cap : 0), row0, cursor, d_out, out_cap >= 0 ? (unsigned long long)out_cap : ~0ULL);
+    hipLaunchKernelGGL(k_rows_sort, dim3((unsigned)std::min(4096, (rows + 15) / 16)), dim3(256), 0, stream, d_out, row_ptr, rows,
+                       out_cap >= 0 ? (unsigned long long)out_cap : ~0ULL);
     return 0;
 }
 

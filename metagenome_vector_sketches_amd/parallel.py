@@ -365,6 +365,10 @@ class GpuOps:
     def cells_report(self, recv, world, cap_f, own, d_own):
         return self.ctx.cells_report(recv, world, cap_f, own[1] - own[0], d_own)
 
+    def sort_cells_ahead(self, cells_in, cells_out, own, d_own):
+        """the row-bucket sort before the host knows the count (mvs_cells_sort_rows_ahead)"""
+        self.ctx.cells_sort_rows_ahead(cells_in, own[0], own[1], d_own, cells_out)
+
     def sort_cells(self, cells_in, n, cells_out, own=None, d_own=None, max_row=None):
         """(row, col) order: by row buckets when no row holds more than 64 cells (the usual shard), else the general sort"""
         if own is not None and max_row is not None and max_row <= 64:
@@ -411,6 +415,7 @@ class ShardedComparison:
         self._raw = self._own = self._xbuf = self._d_own = None
         self._d_own_rows = 0
         self._cap_f = 1 << 14
+        self._sort_ahead = False         # the previous step's shard had no row beyond 64 cells and fitted its buffers
         self._step = None
         self._ev = None
 
@@ -630,7 +635,13 @@ class ShardedComparison:
                 self.coll.submit(lambda: self.coll.allgather_blocks(xb, stride)).wait()
                 if mirror:
                     ops.cells_collect(xb, world, rank, cap_f, (rb, re), self._own, self._d_own)
-            n_out, heads, max_row = ops.cells_report(xb, world, cap_f, (rb, re), self._d_own)   # the step's second (last) host sync
+            # the sort, queued in front of the step's host synchronisation when the previous step says the row buckets will do:
+            # the device then runs from the plan's first kernel to the sorted shard without waiting for the host
+            ahead = bool(self._sort_ahead and cells_out is not None and d_cnt is not None and hasattr(ops, "sort_cells_ahead"))
+            if ahead:
+                ops.sort_cells_ahead(self._own, cells_out, (rb, re), self._d_own)
+                self._trace("cells sorted")
+            n_out, heads, max_row = ops.cells_report(xb, world, cap_f, (rb, re), self._d_own)   # the step's host synchronisation
             worst = max(int(h[1]) for h in heads)
             if worst:
                 raise err if err is not None else _capi.MvsError(worst, "another rank failed in its block comparisons")
@@ -683,9 +694,13 @@ class ShardedComparison:
             raise _capi.MvsError(_capi.MVS_E_CAPACITY, "%d cells for this shard but capacity is %d" % (n_out, cells_out.shape[0]),
                                  needed=n_out)
         out = cells_out if cells_out is not None else ops.new_cells(max(n_out, 1))
-        if n_out:
+        sorted_ahead = ahead and max_row <= 64            # (the buffers held: checked above)
+        if n_out and not sorted_ahead:
             ops.sort_cells(self._own, n_out, out, (rb, re), self._d_own, max_row)
-        self._trace("cells sorted")
+        if not sorted_ahead:
+            self._trace("cells sorted")
+        self._sort_ahead = max_row <= 64
+        info["sorted_ahead"] = sorted_ahead
         info["exchanged_cells"] = int(heads[rank][0]) if mirror else 0
         info["blocks"] = len(plan)
         if cells_out is None:

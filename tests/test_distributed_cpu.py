@@ -216,6 +216,7 @@ class OracleOps:
         keep = min(len(mc), own_out.shape[0])
         own_out[:keep] = torch.from_numpy(mc[:keep])
         d_own[0] = len(mc)
+        self._own_rows = own_out         # (the report looks at it for the widest row)
         fc = g[valid & ~mine]
         hdr = np.zeros(8, dtype=np.int64)
         hdr[:5] = [len(fc), status, max_abs, total, raw.shape[0]]
@@ -240,13 +241,24 @@ class OracleOps:
             n_own += len(got)
         d_own[0] = n_own
 
+    def sort_cells_ahead(self, cells_in, cells_out, own, d_own):
+        """the sort before the report: the count is the one the route / collect left in the state block"""
+        n = min(int(d_own[0]), cells_in.shape[0])
+        a = cells_in[:n].numpy()
+        a = a[np.lexsort((a[:, 1], a[:, 0]))]
+        k = min(n, cells_out.shape[0])
+        cells_out[:k] = torch.from_numpy(a[:k].copy())
+        self.log.append("sorted ahead")
+
     def cells_report(self, recv, world, cap_f, own, d_own):
         stride = 64 + 16 * cap_f
         heads = []
         for p in range(world):
             h = recv[p * stride:p * stride + 64].numpy().view(np.int64)
             heads.append(tuple(int(x) for x in h[:5]))
-        return int(d_own[0]), heads, 1 << 30
+        n_own = min(int(d_own[0]), self._own_rows.shape[0]) if getattr(self, "_own_rows", None) is not None else 0
+        widest = int(np.bincount(self._own_rows[:n_own, 0].numpy() - own[0]).max()) if n_own else 0
+        return int(d_own[0]), heads, widest
 
     def sort_cells(self, cells_in, n, cells_out, own=None, d_own=None, max_row=None):
         a = cells_in[:n].numpy()
@@ -316,14 +328,17 @@ def _worker(rank, world, port, n, d, out_dir):
     assert sorted(set(r // ops.layout(n, world)[1] for r in rebuilt)) == ([p for p in range(world) if p != rank] if has_peers else [])
     if len(parallel.block_plan(world, rank, ops.layout(n, world)[1])) > 1:
         assert len([x for x in ops.log if x.startswith("filter")]) >= 2
-    cells2, cnt2, _ = sc.run(sk[b:e], n2[b:e], n)           # second step reuses the gathered buffers
-    assert cnt == cnt2 and np.array_equal(cells, cells2)
+    cells2, cnt2, info_2 = sc.run(sk[b:e], n2[b:e], n)      # second step reuses the gathered buffers
+    assert cnt == cnt2 and np.array_equal(cells, cells2) and not info_2["sorted_ahead"]      # (no caller's buffer to sort into)
     np.save(os.path.join(out_dir, "cells_%d.npy" % rank), cells)
     plain = _plain(cells)
     # into a caller's buffer; the plain rows x all-columns schedule (no mirroring, no cell exchange) gives the same shard
     out = torch.empty((n * n, 4), dtype=torch.int32)
     _, cnt3, info3 = sc.run(sk[b:e], n2[b:e], n, cells_out=out)
     assert cnt3 == cnt and np.array_equal(out[:cnt3].numpy(), plain), (rank, cnt3, cnt)
+    # the previous steps' rows held at most 64 cells: this one sorted in front of its host synchronisation
+    widest = int(np.bincount(plain[:, 0] - b).max()) if cnt else 0
+    assert info3["sorted_ahead"] == (widest <= 64) and ("sorted ahead" in ops.log) == (widest <= 64), (widest, info3["sorted_ahead"], ops.log[-6:])
     sc_rows = parallel.ShardedComparison(OracleOps(), rank, world, dist)
     sc_rows.symmetric = False
     _, cnt3b, info3b = sc_rows.run(sk[b:e], n2[b:e], n, cells_out=out)

@@ -106,6 +106,16 @@ def _union(split, symmetric=True, chunks=1, keep_mode=_capi.KEEP_INT32):
                 out2 = torch.zeros_like(out)
                 ctx.cells_sort_rows(own, n_out, b, e, d_own, out2)
                 assert torch.equal(out2[:n_out], out[:n_out])
+                # ... and queued before the host knows the count (the count is read on the device, the buffers' sizes bound it)
+                out3 = torch.zeros_like(out)
+                ctx.cells_sort_rows_ahead(own, b, e, d_own, out3)
+                assert torch.equal(out3[:n_out], out[:n_out])
+                if n_out > 8:                                            # an output buffer that is too small: whole rows or nothing
+                    small = torch.full((n_out // 2, 4), -7, dtype=torch.int32, device=DEV)
+                    ctx.cells_sort_rows_ahead(own, b, e, d_own, small)
+                    ends = np.cumsum(np.bincount(out[:n_out, 0].cpu().numpy() - b, minlength=e - b))
+                    fit = int(ends[ends <= n_out // 2].max()) if np.any(ends <= n_out // 2) else 0
+                    assert torch.equal(small[:fit], out[:fit])
         shards.append(out[:n_out].cpu().numpy())
     return np.concatenate(shards), per_rank
 

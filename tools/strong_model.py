@@ -90,6 +90,7 @@ def main():
         plan = parallel.block_plan(G, 0, P)
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(10)]
         acc = []
+        last_max_row = 1 << 30
         lo = torch.zeros(n_alloc * d_pad, dtype=torch.int8, device=dev)
         gops = parallel.GpuOps(ctx, dev)
         gops.wire_rows(planes, lo, d_pad, 0, n_st)                 # what the exchange of low limbs would have delivered
@@ -115,12 +116,17 @@ def main():
             d_cnt = ctx.plan_finish()
             ev[4].record()
             ctx.cells_route(raw, d_cnt, P, rps, n, b0, e0, own, d_own, send, cap)
-            n_own, heads, max_row = ctx.cells_report(send, 1, cap, e0 - b0, d_own)
             ev[5].record()
-            if n_own and max_row <= 64:
-                ctx.cells_sort_rows(own, n_own, b0, e0, d_own, outc)
-            elif n_own:
-                ctx.cells_sort(own, n_own, outc)
+            ahead = rep > 0 and last_max_row <= 64              # as parallel.ShardedComparison: the sort in front of the step's host sync
+            if ahead:
+                ctx.cells_sort_rows_ahead(own, b0, e0, d_own, outc)
+            n_own, heads, max_row = ctx.cells_report(send, 1, cap, e0 - b0, d_own)
+            if n_own and not (ahead and max_row <= 64):
+                if max_row <= 64:
+                    ctx.cells_sort_rows(own, n_own, b0, e0, d_own, outc)
+                else:
+                    ctx.cells_sort(own, n_own, outc)
+            last_max_row = max_row
             ev[6].record()
             torch.cuda.synchronize()
             wall = (time.perf_counter() - t0) * 1e3
@@ -128,7 +134,7 @@ def main():
                 ps = ctx.plan_stats()
                 acc.append({"wall_ms": wall, "prepare_ms": ev[0].elapsed_time(ev[1]), "diag_filter_ms": ev[1].elapsed_time(ev[2]),
                             "peer_filters_ms": ev[2].elapsed_time(ev[3]), "finish_ms": ev[9].elapsed_time(ev[4]),
-                            "route_report_ms": ev[4].elapsed_time(ev[5]), "sort_ms": ev[5].elapsed_time(ev[6]),
+                            "route_report_ms": ev[4].elapsed_time(ev[5]), "sort_ms": ev[5].elapsed_time(ev[6]),      # route | sort + report
                             "filter_kernels_ms": ps["filter_ms"], "recheck_ms": ps["recheck_ms"], "tiles_ms": ps["tiles_ms"],
                             "filter_tiles": ps["filter_tiles"], "filter_launches": ps["filter_launches"], "candidates": ps["candidates"],
                             "flagged_tiles": ps["flagged_tiles"], "own_cells": int(n_own), "foreign_cells": int(heads[0][0]),
