@@ -428,6 +428,12 @@ int mvs_sketch_set_recode_rows(mvs_ctx* ctx, mvs_sketch_set* set, const void* sk
 #define MVS_WIRE_RADIX_MAX 252
 #define MVS_WIRE_MAX_ABS 32004
 int mvs_sketch_set_planes_from_wire(mvs_ctx* ctx, mvs_sketch_set* set, const int8_t* lo_wire, int64_t row_first, int64_t row_count);
+/* The same for a plan, ROW BY ROW AS NEEDED: after mvs_plan_wire, mvs_plan_finish rebuilds -- between gathering the candidates
+ * and the re-check -- exactly the rows outside the frame that its second half reads (the columns of the candidates and of the
+ * flagged tiles; lo_wire as above, valid until the plan has finished).  A plan whose filter leaves few candidates touches few
+ * rows; the others' limb planes keep whatever an earlier step left there.  Plans with a filter only (others read every row of
+ * their blocks: mvs_sketch_set_planes_from_wire before mvs_plan_filter). */
+int mvs_plan_wire(mvs_ctx* ctx, const int8_t* lo_wire);
 int mvs_plan_begin(mvs_ctx* ctx, const mvs_sketch_set* set, const double* norms_sq, int keep_mode, int64_t frame_row_begin,
                    int64_t frame_row_end, int flags, mvs_cell* cells, int64_t capacity);
 int mvs_plan_filter(mvs_ctx* ctx, const mvs_plan_block* blocks, int n_blocks);

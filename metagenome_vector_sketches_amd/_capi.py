@@ -118,6 +118,7 @@ SYMBOLS = [
     ("mvs_sketch_set_recode_rows", _c.c_int, [_P, _P, _P, _c.c_int, _c.c_int64, _c.c_int64, _c.c_int64]),
     ("mvs_sketch_set_planes_from_wire", _c.c_int, [_P, _P, _P, _c.c_int64, _c.c_int64]),
     ("mvs_plan_begin", _c.c_int, [_P, _P, _P, _c.c_int, _c.c_int64, _c.c_int64, _c.c_int, _P, _c.c_int64]),
+    ("mvs_plan_wire", _c.c_int, [_P, _P]),
     ("mvs_plan_filter", _c.c_int, [_P, _P, _c.c_int]),
     ("mvs_plan_finish", _c.c_int, [_P, _c.POINTER(_P)]),
     ("mvs_plan_stats", _c.c_int, [_P, _c.POINTER(_c.c_double), _c.POINTER(_c.c_int64)]),
@@ -735,6 +736,13 @@ class Context:
         if lm != MEM_DEVICE:
             raise ValueError("the wire buffer must be a device buffer")
         _check(self.lib.mvs_sketch_set_planes_from_wire(self._h, sset._h, lp, int(row_first), int(row_count)))
+
+    def plan_wire(self, lo_wire):
+        """the plan in progress rebuilds the limb planes of the foreign rows its second half reads from lo_wire (mvs_plan_wire)"""
+        lp, lm, lk = _buf(lo_wire)
+        if lm != MEM_DEVICE:
+            raise ValueError("the wire buffer must be a device buffer")
+        _check(self.lib.mvs_plan_wire(self._h, lp))
 
     def plan_begin(self, sset, norms_sq, frame_begin, frame_end, mirror_outside, cells, keep_mode=KEEP_INT32):
         np_, nm, nk = _buf(norms_sq)

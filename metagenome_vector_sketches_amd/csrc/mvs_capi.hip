@@ -51,6 +51,7 @@ struct mvs_ctx {
     void* st_tlist = nullptr;  size_t st_tlist_bytes = 0;    // dense row passes: active tiles per tile row of the block, their counts,
     void* st_tlist_n = nullptr;  size_t st_tlist_n_bytes = 0;  // and every row's first / last kept column
     void* st_ends = nullptr;  size_t st_ends_bytes = 0;
+    void* pw_need = nullptr;  size_t pw_need_bytes = 0;             // block plans: rows whose limb planes are to be rebuilt (mvs_plan_wire)
     void* pw_planes_fm = nullptr;  size_t pw_planes_fm_bytes = 0;   // fragment-major copy of the limb planes of set planes_fm_id
     unsigned long long planes_fm_id = 0, planes_fm_gen = 0;         // (generation planes_fm_gen), for the ping-pong exact kernel
     bool coarse_fm_valid = false;           // ... of the cached plane
@@ -510,6 +511,7 @@ int mvs_ctx_destroy(mvs_ctx* c) {
     if (c->pw_coarse) (void)hipFree(c->pw_coarse);
     if (c->pw_coarse_fm) (void)hipFree(c->pw_coarse_fm);
     if (c->pw_planes_fm) (void)hipFree(c->pw_planes_fm);
+    if (c->pw_need) (void)hipFree(c->pw_need);
     if (c->st_tlist) (void)hipFree(c->st_tlist);
     if (c->st_tlist_n) (void)hipFree(c->st_tlist_n);
     if (c->st_ends) (void)hipFree(c->st_ends);
@@ -3025,6 +3027,7 @@ struct PlanState {
     hipStream_t side = nullptr;
     hipEvent_t e_fork = nullptr, e_join = nullptr;
     bool side_busy = false;
+    const int8_t* lo_wire = nullptr;      // mvs_plan_wire: the other ranks' limb planes are rebuilt from it, row by row, as needed
     bool speculate = false;               // this plan
     bool pending = false;                 // its counts are still on the device only
     bool stale = false;                   // (after the counts came in) its sizes did not hold
@@ -3113,6 +3116,31 @@ int plan_join(mvs_ctx* c, PlanState& st) {
     if (!st.side_busy) return MVS_OK;
     HIP_TRY(hipStreamWaitEvent(c->stream, st.e_join, 0));
     st.side_busy = false;
+    return MVS_OK;
+}
+
+// mvs_plan_wire: the limb planes of the rows outside the frame that the re-check and the flagged tiles are about to read --
+// the columns of the gathered candidates and of the flagged tiles -- are rebuilt from low limbs + coarse plane; the others
+// keep whatever an earlier step left there (nobody reads them)
+int plan_rebuild_needed(mvs_ctx* c, PlanState& st) {
+    if (!st.lo_wire) return MVS_OK;
+    const mvs_sketch_set* s = st.set;
+    int rc = ensure_buf(c, &c->pw_need, &c->pw_need_bytes, (size_t)s->n_alloc);
+    if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(c->pw_need, 0, (size_t)s->n_alloc, c->stream));
+    mvs::launch_rows_needed(c->stream, st.a, st.n_tr, st.n_tc, st.f0, st.f1, s->n, (unsigned char*)c->pw_need);
+    rc = check_kernel("k_rows_needed");
+    if (rc) return rc;
+    const int64_t dp = s->d_pad;
+    const int64_t lo_end = st.f0 & ~(int64_t)15, hi_begin = (st.f1 + 15) & ~(int64_t)15, hi_end = (s->n + 15) & ~(int64_t)15;
+    for (int half = 0; half < 2; ++half) {
+        const int64_t r0 = half ? hi_begin : 0, r1 = half ? std::min<int64_t>(hi_end, s->n_alloc) : lo_end;
+        if (r1 <= r0) continue;
+        mvs::launch_planes_from_wire(c->stream, st.lo_wire + r0 * dp, s->ext_coarse_fm + r0 * dp, s->ext_rows + r0, r1 - r0, s->d_pad,
+                                     const_cast<int8_t*>(s->planes) + r0 * 2 * dp, (const unsigned char*)c->pw_need + r0);
+        rc = check_kernel("k_planes_from_wire(needed rows)");
+        if (rc) return rc;
+    }
     return MVS_OK;
 }
 
@@ -3266,6 +3294,7 @@ int mvs_plan_begin(mvs_ctx* c, const mvs_sketch_set* s, const double* norms_sq, 
     }
     st.active = false;
     st.finished = false;
+    st.lo_wire = nullptr;
     st.set = s;
     st.d_n2 = norms_sq;
     st.keep_mode = keep_mode;
@@ -3420,6 +3449,15 @@ int mvs_plan_filter(mvs_ctx* c, const mvs_plan_block* blocks, int n_blocks) {
     return MVS_OK;
 }
 
+int mvs_plan_wire(mvs_ctx* c, const int8_t* lo_wire) {
+    if (!c || !c->plan || !c->plan->active || c->plan->finished) return fail(MVS_E_INVALID, "no plan in progress (mvs_plan_begin)");
+    PlanState& st = *c->plan;
+    if (lo_wire && (!st.two_stage || !st.set->ext_coarse_fm || !st.set->ext_rows))
+        return fail(MVS_E_INVALID, "a plan with a filter on a two-limb set with derived data attached (others: mvs_sketch_set_planes_from_wire)");
+    st.lo_wire = lo_wire;
+    return MVS_OK;
+}
+
 int mvs_plan_finish(mvs_ctx* c, const uint64_t** d_count) {
     if (!c || !c->plan || !c->plan->active || c->plan->finished) return fail(MVS_E_INVALID, "no plan in progress (mvs_plan_begin)");
     PlanState& st = *c->plan;
@@ -3455,6 +3493,8 @@ int mvs_plan_finish(mvs_ctx* c, const uint64_t** d_count) {
         }
         mvs::launch_tile_count(c->stream, st.a.tile_flag, st.n_tr, st.n_tc, (int*)c->pw_trow);
         int rc = check_kernel("k_tile_count");
+        if (rc) return rc;
+        rc = plan_rebuild_needed(c, st);
         if (rc) return rc;
         const bool tiles_pass = st.hint_flagged > 0;
         const int tile_cap = tiles_pass ? (int)std::min<long long>((long long)st.n_tr * st.n_tc, 2 * st.hint_flagged + 64) : 0;
@@ -3535,6 +3575,10 @@ int mvs_plan_finish(mvs_ctx* c, const uint64_t** d_count) {
     }
     c->last_candidates = (unsigned long long)st.candidates;
     c->last_filter_tiles = st.tiles;
+    {
+        const int rw = plan_rebuild_needed(c, st);
+        if (rw) return rw;
+    }
     int n_flagged = 0;
     std::vector<int> row_first((size_t)st.n_tr + 1, 0);
     for (int t = 0; t < st.n_tr; ++t) row_first[(size_t)t + 1] = row_first[(size_t)t] + row_count[(size_t)t];

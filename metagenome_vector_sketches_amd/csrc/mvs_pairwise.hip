@@ -2243,14 +2243,32 @@ __global__ __launch_bounds__(RW * 64) void k_recode_rows(const T* __restrict__ s
     if (lane == 0) rows[row] = real ? CoarseRow{m, (int32_t)c2, (int32_t)r2, ss >= (1ULL << 31) ? 1 : 0} : CoarseRow{1, 0, 0, 0};
 }
 
+__global__ __launch_bounds__(256) void k_rows_needed(const PairwiseArgs a, int n_tr, int n_tc, long long f0, long long f1, long long n_rows,
+                                                     unsigned char* __restrict__ need) {
+    unsigned long long n_cand = *reinterpret_cast<volatile const unsigned long long*>(a.cand_counter);
+    n_cand = n_cand < a.cand_capacity ? n_cand : a.cand_capacity;
+    const unsigned long long stride = (unsigned long long)gridDim.x * 256;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < n_cand; i += stride) {
+        const long long col = a.cand[i].y & 0x7fffffff;
+        if ((col < f0 || col >= f1) && col < n_rows) need[col] = 1;
+    }
+    // flagged tiles (a workgroup per tile it finds flagged: one thread per column)
+    for (int t = blockIdx.x; t < n_tr * n_tc; t += gridDim.x) {
+        if (a.tile_flag[t] == 0u) continue;
+        const long long col = a.col_begin + (long long)(t % n_tc) * 256 + threadIdx.x;
+        if ((col < f0 || col >= f1) && col < n_rows) need[col] = 1;
+    }
+}
+
 // k_planes_from_wire: limb planes of rows whose LOW limb arrived in a wire buffer (lo[row * d_pad + k]) and whose coarse
 // plane and statistics are in place (fragment-major, as the filter reads them): both limb rows are written -- the rule is
 // at radix_keeps_high_limb.  A workgroup takes 16 rows (one KiB of the fragment-major plane holds 16 rows x 64 k) x 256 k: a lane
 // takes 16 consecutive k of one row, reads its 16 coarse bytes where k_recode_rows put them and 16 bytes of the wire.  (One
 // workgroup per 16 rows looping over k moved 3.4 TB/s: eight dependent rounds of loads per workgroup.)
+// need != NULL: only the rows marked there (k_rows_needed: what a plan's re-check and flagged tiles will read).
 __global__ __launch_bounds__(256) void k_planes_from_wire(const int8_t* __restrict__ lo_wire, const int8_t* __restrict__ coarse_fm,
                                                           const CoarseRow* __restrict__ rows, int64_t count, int d_pad,
-                                                          int8_t* __restrict__ planes) {
+                                                          int8_t* __restrict__ planes, const unsigned char* __restrict__ need) {
     const int nk = d_pad / 64;
     const int64_t grp = blockIdx.x;                        // 16 rows
     const int chunks = 16 * (d_pad / 16);                  // (row, 16-entry chunk) pairs of the group
@@ -2259,7 +2277,7 @@ __global__ __launch_bounds__(256) void k_planes_from_wire(const int8_t* __restri
         if (idx >= chunks) return;
         const int r = idx & 15, kc = idx >> 4;             // consecutive lanes: the 16 rows of one chunk = 256 contiguous bytes of the plane
         const int64_t row = grp * 16 + r;
-        if (row >= count) return;
+        if (row >= count || (need && need[row] == 0)) return;
         const int m = rows[row].radix;
         const v4i c4 = *reinterpret_cast<const v4i*>(coarse_fm + (grp * nk + (kc >> 2)) * 1024 + (((kc & 3) << 4) + r) * 16);
         const v4i l4 = *reinterpret_cast<const v4i*>(lo_wire + row * (int64_t)d_pad + kc * 16);
@@ -3258,10 +3276,18 @@ int launch_coarse_fm(hipStream_t stream, const int8_t* d_coarse, int64_t n_alloc
 
 // rows [0, count) (count a multiple of 16; all pointers at the range's first row, which is a multiple of 16)
 int launch_planes_from_wire(hipStream_t stream, const int8_t* d_lo_wire, const int8_t* d_coarse_fm, const CoarseRow* d_rows,
-                            int64_t count, int d_pad, int8_t* d_planes) {
+                            int64_t count, int d_pad, int8_t* d_planes, const unsigned char* d_need) {
     if (count <= 0) return 0;
     hipLaunchKernelGGL(k_planes_from_wire, dim3((unsigned)(count / 16), (unsigned)((d_pad / 16 * 16 + 255) / 256)), dim3(256), 0, stream,
-                       d_lo_wire, d_coarse_fm, d_rows, count, d_pad, d_planes);
+                       d_lo_wire, d_coarse_fm, d_rows, count, d_pad, d_planes, d_need);
+    return 0;
+}
+
+// need[row] = 1 for the storage rows OUTSIDE the frame [f0, f1) that a plan's second half reads: the columns of its candidates
+// (count on the device, as the filter launches left it) and the 256 columns of every flagged tile; need is zero on entry
+int launch_rows_needed(hipStream_t stream, const PairwiseArgs& a, int n_tr, int n_tc, int64_t f0, int64_t f1, int64_t n_rows,
+                       unsigned char* d_need) {
+    hipLaunchKernelGGL(k_rows_needed, dim3(512), dim3(256), 0, stream, a, n_tr, n_tc, (long long)f0, (long long)f1, (long long)n_rows, d_need);
     return 0;
 }
 

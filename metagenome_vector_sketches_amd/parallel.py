@@ -345,6 +345,10 @@ class GpuOps:
     def plan_filter(self, blocks):
         self.ctx.plan_filter(blocks)
 
+    def plan_wire(self, lo_wire):
+        """the plan in progress rebuilds, inside its finish, the limb planes of exactly the foreign rows it reads"""
+        self.ctx.plan_wire(lo_wire)
+
     def plan_exact_mode(self):
         """the plan that has just begun runs without a filter: its blocks are compared by the exact kernel when handed over"""
         return self.ctx.plan_stats()["exact_mode"]
@@ -744,8 +748,9 @@ class ShardedComparison:
             # needs nothing from anybody (rank 1 of 2): the next step rewrites the buffers the collectives read
             for h in st["planes"]:
                 h.wait()
-            if st["wire"] and not st["rebuilt"] and others:    # (a plan without peer blocks reads nobody's limb planes)
-                self._rebuild(st)
+        if st["wire"] and not st["rebuilt"] and others:        # (a plan without peer blocks reads nobody's limb planes)
+            # the plan rebuilds the rows its re-check and flagged tiles read -- the columns of its candidates -- and no others
+            ops.plan_wire(self._lo)
         d_cnt = ops.plan_finish()
         self._trace("plan finished")
         return d_cnt

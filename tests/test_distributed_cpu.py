@@ -158,6 +158,15 @@ class OracleOps:
     def plan_exact_mode(self):
         return self.exact
 
+    def plan_wire(self, lo_wire):
+        """the device rebuilds the rows its candidates name, inside mvs_plan_finish; the stand-in, which compares everything
+        with everything, rebuilds every peer's rows (after the exchanges have been waited for: finish checks)"""
+        p = self.plan
+        P = p["f1"] - p["f0"]
+        for q in range(p["sset"]["n"] // P):
+            if q * P != p["f0"]:
+                self.planes_from_wire(p["sset"], lo_wire, q * P, P)
+
     def plan_filter(self, blocks):
         p = self.plan
         for (rb, re, cb, ce) in blocks:

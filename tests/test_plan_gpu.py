@@ -58,9 +58,18 @@ class Split:
                 self.n2[r * self.P:r * self.P + (e - b)] = torch.from_numpy(n2[b:e].copy()).to(DEV)
             ctx.prepare_rows(self.sset, r * self.P, self.P)
 
-    def rank_cells(self, rank, symmetric=True, chunks=1, keep_mode=_capi.KEEP_INT32, cap=None, cap_f=None):
-        """-> (own cells [k, 4] in sample indices, the send buffer as the exchange would carry it, plan statistics)"""
+    def rank_cells(self, rank, symmetric=True, chunks=1, keep_mode=_capi.KEEP_INT32, cap=None, cap_f=None, wire=False):
+        """-> (own cells [k, 4] in sample indices, the send buffer as the exchange would carry it, plan statistics).
+        wire: the other ranks' limb planes are NOT there (poisoned) -- the plan rebuilds the rows it reads from their low limbs"""
         ctx, P, world = self.ctx, self.P, self.world
+        saved = None
+        if wire:
+            lo = torch.zeros(self.n_alloc * self.d_pad, dtype=torch.int8, device=DEV)
+            parallel.GpuOps(ctx, DEV).wire_rows(self.planes, lo, self.d_pad, 0, P * world)
+            saved = self.planes.clone()
+            rows = self.planes.view(-1, 2, self.d_pad)
+            rows[:rank * P] = 0x55
+            rows[(rank + 1) * P:] = 0x55
         cap = cap or max(4096, 400 * self.n)
         raw = torch.empty((2 * cap, 4), dtype=torch.int32, device=DEV)
         own = torch.empty((cap, 4), dtype=torch.int32, device=DEV)
@@ -69,6 +78,8 @@ class Split:
         plan = parallel.block_plan(world, rank, P, symmetric=symmetric)
         mirror = symmetric and world > 1
         ctx.plan_begin(self.sset, self.n2, rank * P, (rank + 1) * P, mirror, raw, keep_mode=keep_mode)
+        if wire:
+            ctx.plan_wire(lo)
         ctx.plan_filter(plan[:1])
         for (c0, c1) in parallel.chunk_bounds(P, chunks):
             blocks = parallel.clip_blocks(plan[1:], P, c0, c1)
@@ -79,14 +90,16 @@ class Split:
         send = torch.zeros(_capi.CELLS_HEADER_BYTES + 16 * cap_f, dtype=torch.uint8, device=DEV)
         ctx.cells_route(raw, d_cnt, P, self.rps, self.n, b, e, own, d_own, send, cap_f, status=0, max_abs=123 + rank)
         n_own, heads = ctx.cells_report(send, 1, cap_f, e - b, d_own)[:2]
+        if saved is not None:
+            self.planes.copy_(saved)
         assert heads[0][1] == 0 and heads[0][2] == 123 + rank and (heads[0][3] <= heads[0][4] or cap < 4096)
         return own[:n_own].cpu().numpy(), send, ctx.plan_stats(), heads[0], own, d_own
 
 
-def _union(split, symmetric=True, chunks=1, keep_mode=_capi.KEEP_INT32):
+def _union(split, symmetric=True, chunks=1, keep_mode=_capi.KEEP_INT32, wire=False):
     """every rank's shard = its own cells + what the other ranks' send buffers hold for its rows (mvs_cells_collect)"""
     ctx, world = split.ctx, split.world
-    per_rank = [split.rank_cells(r, symmetric, chunks, keep_mode) for r in range(world)]
+    per_rank = [split.rank_cells(r, symmetric, chunks, keep_mode, wire=wire) for r in range(world)]
     cap_f = (per_rank[0][1].numel() - _capi.CELLS_HEADER_BYTES) // 16
     recv = torch.cat([x[1] for x in per_rank])
     shards = []
@@ -405,3 +418,22 @@ def test_limb_planes_rebuilt_from_low_limbs_and_the_coarse_plane(ctx, d, dtype):
     assert np.all(radix <= clampfree) and np.any(radix < clampfree)          # the search did go below it somewhere
     sset.close()
     other.close()
+
+
+@pytest.mark.parametrize("world,cluster", [(2, 8), (4, 8), (4, 600), (3, 300)])
+def test_plan_rebuilds_the_rows_it_reads_from_their_low_limbs(ctx, world, cluster):
+    """mvs_plan_wire: with the other ranks' limb planes poisoned, a plan still finds every cell -- its finish rebuilds the
+    columns of its candidates and of its flagged tiles (dense clusters that span ranks) from low limbs + coarse plane, both when it
+    waits for its counts and when it runs ahead of them"""
+    n, d = 3000, 512
+    sk = synth.make_sketches_numpy(n, d, 3000, seed=world + cluster, cluster=cluster)
+    ctx.set_option("pairwise_filter", 2)
+    split = Split(ctx, sk, _n2(sk), world)
+    want, per = _union(split)
+    assert len(want) > 4 * n
+    for speculate in (0, 1, 1):
+        ctx.set_option("plan_speculate", speculate)
+        got, per_w = _union(split, wire=True)
+        assert np.array_equal(got, want)
+    assert any(x[2]["flagged_tiles"] > 0 for x in per_w) or cluster < 100
+    split.sset.close()

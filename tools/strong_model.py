@@ -109,9 +109,8 @@ def main():
                 if blocks:
                     ctx.plan_filter(blocks)
             ev[3].record()
-            if G > 1 and not no_wire:                           # the other ranks' limb planes, in front of the re-check that reads them
-                for p in range(1, G):
-                    ctx.planes_from_wire(sset, lo, p * P, P)
+            if G > 1 and not no_wire:                           # the plan rebuilds the foreign rows its second half reads (inside finish)
+                ctx.plan_wire(lo)
             ev[9].record()
             d_cnt = ctx.plan_finish()
             ev[4].record()
