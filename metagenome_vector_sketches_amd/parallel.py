@@ -404,14 +404,14 @@ class ShardedComparison:
             raise ValueError("world > 1 needs torch.distributed or a communicator")
         self.symmetric = os.environ.get("MVS_SHARDED_SYMMETRIC", "1") != "0"
         self.gather_chunks = max(1, int(os.environ.get("MVS_GATHER_CHUNKS", "2")))   # pieces the peers' coarse rows arrive in
-        # two-limb sets: the exchange carries coarse plane + LOW limbs, the receiver rebuilds the high limbs (2 bytes per entry
-        # on the links instead of 3); switched off for good once a rank reports |v| beyond what the rule covers.  The rebuild
-        # costs device time (0.22 ms for the 87.8k x 2048 foreign rows of an 8-way split), the bytes it saves only matter where the links are the
-        # bottleneck: up to 4 ranks, where a rank's block travels over one to three links (1.65 -> 1.84 x and 3.15 -> 3.33 x
-        # predicted at 61 GB/s per link; at 8 ranks seven links share the work and the limb planes travel as they are).
-        # MVS_WIRE_LOW_LIMB=0 / 1 forces it off / on for every world size.
-        force = os.environ.get("MVS_WIRE_LOW_LIMB", "")
-        self.wire = force != "0" and hasattr(ops, "planes_from_wire") and (force == "1" or world <= 4)
+        # two-limb sets: the exchange carries coarse plane + LOW limbs and the receiver rebuilds the high limbs -- 2 bytes per
+        # entry on the links instead of 3.  The plan rebuilds, inside its finish, only the rows its re-check and flagged tiles
+        # read (mvs_plan_wire: the columns of its candidates), so the cost follows the candidates: 0.10 ms at the per-rank size
+        # of an 8-way split of configs[2] (52k candidates over 87.8k foreign rows), 0.03 ms for configs[3] (365 candidates).
+        # Predicted at 61 GB/s per link: 2 ranks 1.67 -> 1.84 x, 4 ranks 3.14 -> 3.3 x, 8 ranks 5.58 -> 5.61 x (configs[3]: 5.6 ->
+        # 6.2 x); at twice that rate it costs 1-2 % (tools/strong_model.py --wire / --no-wire).  Switched off for good once a
+        # rank reports |v| beyond what the rule covers; MVS_WIRE_LOW_LIMB=0 switches it off from the start.
+        self.wire = os.environ.get("MVS_WIRE_LOW_LIMB", "1") != "0" and hasattr(ops, "planes_from_wire")
         self.time_gather = False         # bench: events around the exchange (read with last_gather_ms())
         self.trace = None                # a list: (label, torch event) pairs of the last step (tools/exp/r05_overlap_trace.py)
         self._key = None

@@ -47,8 +47,8 @@ def main():
     ap.add_argument("--reps", type=int, default=8)
     ap.add_argument("--seed", type=int, default=2345)
     ap.add_argument("--no-speculate", action="store_true", help="every plan waits for its own counts (two host syncs per step)")
-    ap.add_argument("--no-wire", action="store_true", help="limb planes on the wire (3 bytes per entry) for every G")
-    ap.add_argument("--wire", action="store_true", help="low limbs on the wire (2 bytes per entry) for every G (default: up to 4 ranks, as parallel.py)")
+    ap.add_argument("--no-wire", action="store_true", help="limb planes on the wire (3 bytes per entry)")
+    ap.add_argument("--wire", action="store_true", help="(default) low limbs on the wire, 2 bytes per entry; the plan rebuilds the rows it reads")
     ap.add_argument("--overlap", action="store_true", help="filter launches of a plan alternate between two streams (plan_overlap)")
     ap.add_argument("--out", default="")
     args = ap.parse_args()
@@ -67,7 +67,7 @@ def main():
     base_ms = None
     for G in [int(x) for x in args.ranks.split(",")]:
         rps, P = _capi.shard_layout(n, G)
-        no_wire = args.no_wire or (G > 4 and not args.wire)        # parallel.ShardedComparison's rule
+        no_wire = args.no_wire                                     # (default: low limbs on the wire, as parallel.ShardedComparison)
         n_st = P * G
         n_alloc, d_pad, nbytes = ctx.limb_geometry(n_st, d, 2)
         planes = torch.zeros(nbytes, dtype=torch.int8, device=dev)
@@ -183,7 +183,7 @@ def main():
         m["model"] = models
         out["ranks"][str(G)] = m
         print("G=%d  [%s]  P=%d  wall %.3f ms (no exchange)  prepare %.3f  diag %.3f  peers %.3f  finish %.3f  route %.3f  sort %.3f | "
-              "filter kernels %.3f (%d tiles, %d launches)  re-check %.3f  tiles %.3f | rebuild of the peers' limb planes %.3f" %
+              "filter kernels %.3f (%d tiles, %d launches)  re-check %.3f  tiles %.3f | (rebuild of the rows the plan reads: inside finish) %.3f" %
               (G, "3 B/entry on the wire" if no_wire else "2 B/entry on the wire", P, m["wall_ms"], m["prepare_ms"], m["diag_filter_ms"], m["peer_filters_ms"], m["finish_ms"], m["route_report_ms"],
                m["sort_ms"], m["filter_kernels_ms"], m["filter_tiles"], m["filter_launches"], m["recheck_ms"], m["tiles_ms"], m["rebuild_ms"]))
         for k, v in models.items():
