@@ -213,11 +213,17 @@ def block_plan(world, rank, block_pad, symmetric=True):
     return plan
 
 
-def chunk_bounds(block_pad, chunks):
-    """[(c0, c1)] cutting a block of block_pad rows into at most `chunks` pieces on multiples of 256 rows"""
+def chunk_bounds(block_pad, chunks, first=None):
+    """[(c0, c1)] cutting a block of block_pad rows into at most `chunks` pieces on multiples of 256 rows; first (0 < first < 1):
+    the share of the first piece, the others split the rest evenly"""
     tiles = block_pad // 256
     chunks = max(1, min(chunks, tiles))
-    cuts = [(tiles * k // chunks) * 256 for k in range(chunks + 1)]
+    if first is not None and chunks > 1:
+        t0 = max(1, min(tiles - (chunks - 1), int(round(tiles * first))))
+        rest = tiles - t0
+        cuts = [0] + [(t0 + rest * k // (chunks - 1)) * 256 for k in range(chunks)]
+    else:
+        cuts = [(tiles * k // chunks) * 256 for k in range(chunks + 1)]
     return [(cuts[k], cuts[k + 1]) for k in range(chunks) if cuts[k + 1] > cuts[k]]
 
 
@@ -404,6 +410,7 @@ class ShardedComparison:
             raise ValueError("world > 1 needs torch.distributed or a communicator")
         self.symmetric = os.environ.get("MVS_SHARDED_SYMMETRIC", "1") != "0"
         self.gather_chunks = max(1, int(os.environ.get("MVS_GATHER_CHUNKS", "2")))   # pieces the peers' coarse rows arrive in
+        self.gather_first = float(os.environ.get("MVS_GATHER_FIRST", "0.25"))        # share of the first piece
         # two-limb sets: the exchange carries coarse plane + LOW limbs and the receiver rebuilds the high limbs -- 2 bytes per
         # entry on the links instead of 3.  The plan rebuilds, inside its finish, only the rows its re-check and flagged tiles
         # read (mvs_plan_wire: the columns of its candidates), so the cost follows the candidates: 0.10 ms at the per-rank size
@@ -557,7 +564,9 @@ class ShardedComparison:
         if last:
             st["small"].append(coll.submit(small))
         # the coarse plane of the part in row chunks (units of 16 rows = d_pad * 16 contiguous bytes), then its limb planes
-        for (c0, c1) in chunk_bounds(row_end - row_begin, self.gather_chunks):
+        # (the first piece is the small one: it has to land while the diagonal block's filter runs, and that takes about as
+        # long as a quarter of the coarse plane takes on a link)
+        for (c0, c1) in chunk_bounds(row_end - row_begin, self.gather_chunks, self.gather_first):
             a, b = row_begin + c0, row_begin + c1
 
             def coarse(a=a, b=b):

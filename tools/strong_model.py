@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--link-GBps", default="61,122")
     ap.add_argument("--latency-us", type=float, default=20.0, help="per collective")
     ap.add_argument("--chunks", type=int, default=2)
+    ap.add_argument("--first", type=float, default=0.25, help="share of the first piece of the coarse plane (parallel.py: MVS_GATHER_FIRST)")
     ap.add_argument("--reps", type=int, default=8)
     ap.add_argument("--seed", type=int, default=2345)
     ap.add_argument("--no-speculate", action="store_true", help="every plan waits for its own counts (two host syncs per step)")
@@ -104,7 +105,7 @@ def main():
                 ctx.plan_begin(sset, n2_st, 0, P, G > 1, raw)
             ctx.plan_filter(plan[:1])
             ev[2].record()
-            for (c0, c1) in parallel.chunk_bounds(P, args.chunks):
+            for (c0, c1) in parallel.chunk_bounds(P, args.chunks, args.first):
                 blocks = parallel.clip_blocks(plan[1:], P, c0, c1)
                 if blocks:
                     ctx.plan_filter(blocks)
@@ -150,7 +151,7 @@ def main():
         for rate in [float(x) for x in args.link_GBps.split(",")]:
             lat = args.latency_us * 1e-3
             small = lat + P * 24 / (rate * 1e6) if G > 1 else 0.0                       # ms
-            chunks = parallel.chunk_bounds(P, args.chunks)
+            chunks = parallel.chunk_bounds(P, args.chunks, args.first)
             t_comm, arrive = m["prepare_ms"] + small, []
             for (c0, c1) in chunks:
                 t_comm += (lat + (c1 - c0) * d_pad / (rate * 1e6)) if G > 1 else 0.0
@@ -162,13 +163,12 @@ def main():
                 planes_at = t_comm + ((lat + P * d_pad / (rate * 1e6)) if G > 1 else 0.0)      # the low limbs
             # compute stream: prepare, diagonal filter, then the chunk launches (each waits for its chunk), finish waits for the planes
             t = m["prepare_ms"] + m["diag_filter_ms"]
-            per_chunk = m["peer_filters_ms"] / max(1, len(chunks))
             waited = 0.0
-            for a in arrive:
+            for a, (c0, c1) in zip(arrive, chunks):
                 if G > 1 and a > t:
                     waited += a - t
                     t = a
-                t += per_chunk if len(plan) > 1 else 0.0
+                t += m["peer_filters_ms"] * (c1 - c0) / P if len(plan) > 1 else 0.0      # a piece's share of the peers' filter time
             if G > 1 and planes_at > t:
                 waited += planes_at - t
                 t = planes_at
