@@ -410,7 +410,7 @@ class ShardedComparison:
             raise ValueError("world > 1 needs torch.distributed or a communicator")
         self.symmetric = os.environ.get("MVS_SHARDED_SYMMETRIC", "1") != "0"
         self.gather_chunks = max(1, int(os.environ.get("MVS_GATHER_CHUNKS", "2")))   # pieces the peers' coarse rows arrive in
-        self.gather_first = float(os.environ.get("MVS_GATHER_FIRST", "0.25"))        # share of the first piece
+        self.gather_first = float(os.environ.get("MVS_GATHER_FIRST", "0.33"))        # share of the first piece
         # two-limb sets: the exchange carries coarse plane + LOW limbs and the receiver rebuilds the high limbs -- 2 bytes per
         # entry on the links instead of 3.  The plan rebuilds, inside its finish, only the rows its re-check and flagged tiles
         # read (mvs_plan_wire: the columns of its candidates), so the cost follows the candidates: 0.10 ms at the per-rank size
@@ -565,7 +565,8 @@ class ShardedComparison:
             st["small"].append(coll.submit(small))
         # the coarse plane of the part in row chunks (units of 16 rows = d_pad * 16 contiguous bytes), then its limb planes
         # (the first piece is the small one: it has to land while the diagonal block's filter runs, and that takes about as
-        # long as a quarter of the coarse plane takes on a link)
+        # long as a third of the coarse plane takes on a link; and the second piece must not take longer on the links than the first takes
+        # to filter: transfer is about twice as fast as filtering per row, hence 1 : 2)
         for (c0, c1) in chunk_bounds(row_end - row_begin, self.gather_chunks, self.gather_first):
             a, b = row_begin + c0, row_begin + c1
 

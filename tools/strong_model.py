@@ -44,7 +44,7 @@ def main():
     ap.add_argument("--link-GBps", default="61,122")
     ap.add_argument("--latency-us", type=float, default=20.0, help="per collective")
     ap.add_argument("--chunks", type=int, default=2)
-    ap.add_argument("--first", type=float, default=0.25, help="share of the first piece of the coarse plane (parallel.py: MVS_GATHER_FIRST)")
+    ap.add_argument("--first", type=float, default=0.33, help="share of the first piece of the coarse plane (parallel.py: MVS_GATHER_FIRST)")
     ap.add_argument("--reps", type=int, default=8)
     ap.add_argument("--seed", type=int, default=2345)
     ap.add_argument("--no-speculate", action="store_true", help="every plan waits for its own counts (two host syncs per step)")
