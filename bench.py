@@ -226,6 +226,9 @@ def main():
     ap.add_argument("--strong-steps", type=int, default=10,
                     help="default mode: timed steps of the strong-scaled pairwise legs (configs[2] 100k x 2048 and configs[3] "
                          "100k x 4096 split over the N ranks, reported as `strong`); 0 skips them")
+    ap.add_argument("--strong-timeout", type=int, default=300,
+                    help="N > 1: seconds the strong legs may take before every rank gives up on them (the line is printed "
+                         "without them, `strong.error` says why)")
     ap.add_argument("--overlap-parts", type=int, default=2,
                     help="N > 1: pieces the rank's samples are projected in; the all-gather of a finished piece's limb "
                          "planes runs beside the projection of the next (1: no overlap)")
@@ -429,10 +432,41 @@ def main():
                                                  "roofline": rec["roofline"]}
         return strong
 
+    def run_strong_guarded(res):
+        """N > 1: the strong legs behind a guard.  The headline of this line is complete when they start; a leg that raises
+        or hangs on a node this build could never try (RCCL with more than one rank has not run anywhere yet) must not
+        cost it.  A rank that raises reports and leaves; the ranks left waiting in a collective leave when the timer
+        fires; rank 0 prints the line either way, with the reason in `strong.error`."""
+        import threading
+        done = threading.Event()
+
+        def leave(why):
+            if rank == 0:
+                res["strong"] = {"error": why}
+                print(json.dumps(res), flush=True)
+            else:
+                print("bench.py rank %d: strong legs: %s" % (rank, why), file=sys.stderr, flush=True)
+            os._exit(0)                                    # no collective teardown: the peers may be gone or stuck
+
+        def fire():
+            if not done.is_set():
+                leave("the strong legs did not finish within %d s (--strong-timeout); headline unaffected" % args.strong_timeout)
+        timer = threading.Timer(args.strong_timeout, fire)
+        timer.daemon = True
+        timer.start()
+        try:
+            out = run_strong()
+        except BaseException as e:      # noqa: BLE001 -- reported in the line
+            done.set()
+            leave("%s: %s" % (type(e).__name__, e))
+        done.set()
+        timer.cancel()
+        return out
+
     strong = {}
-    if args.strong_steps > 0 and world > 1:                # every rank takes part; with one rank the legs run last (below)
+    if args.strong_steps > 0 and world > 1 and rank != 0:  # every rank takes part (rank 0: below, once its headline is assembled)
         del hashes, sketches, cells, sc
-        strong = run_strong()
+        run_strong_guarded(None)
 
     if rank != 0:
         shutdown()
@@ -508,6 +542,10 @@ def main():
                                 "int32_lane_op_peak_T": VALU_INT_PEAK_TOPS},
         "roofline_pairwise_step": step_pairwise_roofline(state, S, N_total, D, k2, k2_flops, traffic),
     }
+
+    if args.strong_steps > 0 and world > 1:
+        del sketches, cells, sc
+        strong = run_strong_guarded(res)
 
     if args.pairwise_samples and world == 1:
         pw = pairwise_leg(ctx, dev, args.pairwise_samples, args.pairwise_dim, NH, args.pairwise_reps)
