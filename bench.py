@@ -683,10 +683,28 @@ def strong_run(args, ctx, dev, rank, world, dist, coll, config, steps, warmup):
 
     for _ in range(warmup):
         step()
+    # The K timed steps run WITHOUT instrumentation: every event recorded between two kernels costs the stream ~6 us
+    # (profiles/r05_g8_step_kernels.txt: 14 records = 82 us of the 1.7 ms a rank of an 8-way split spends on its step).
+    # The stage breakdown comes from `probe` instrumented steps behind the timed region.
+    timing_was = True
+    ctx.set_timing(False)
+    sc.time_gather, sc.trace = False, None
+    for _ in range(2):
+        step()
     sync_all()
-    acc = {k: [] for k in ("filter", "recheck", "tiles", "prepare", "plan_span", "cells", "gather")}
     t0 = time.perf_counter()
     for _ in range(steps):
+        step()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    ctx.set_timing(timing_was)
+    sc.time_gather, sc.trace = True, []
+    acc = {k: [] for k in ("filter", "recheck", "tiles", "prepare", "plan_span", "cells", "gather")}
+    probe = max(2, min(5, steps))
+    sync_all()
+    t1 = time.perf_counter()
+    for _ in range(probe):
+        sc.trace = []
         step()
         ps = ctx.plan_stats()                          # waits for the plan's last kernel, not for the sort behind it
         acc["filter"].append(ps["filter_ms"])
@@ -695,7 +713,7 @@ def strong_run(args, ctx, dev, rank, world, dist, coll, config, steps, warmup):
         acc["gather"].append(sc.last_gather_ms())
         state["plan"] = ps
     sync_all()
-    elapsed = time.perf_counter() - t0
+    instrumented_ms = (time.perf_counter() - t1) / probe * 1e3
     if os.environ.get("MVS_BENCH_STEP_TIMES") and rank == 0:       # per-step kernel times of the leg (diagnosis)
         print("strong_run config %d: per-step ms %s" % (config, {k: [round(x, 3) for x in v] for k, v in acc.items()}), file=sys.stderr)
     # stage spans of the LAST step from the events the step left on its streams
@@ -769,10 +787,13 @@ def strong_run(args, ctx, dev, rank, world, dist, coll, config, steps, warmup):
                        "cells_route_exchange_sort_ms": cells_ms,
                        "exchanged_cells": info.get("exchanged_cells", 0),
                        "other_ms": ms - prepare_ms - plan_span_ms - cells_ms,
-                       "note": "prepare + plan span + cells + other = ms_per_step; spans are the last step's, from events on the "
-                               "step's streams (max over ranks); host synchronisations per step: 1 in the steady state (cell "
-                               "counts; a plan of the same shape as the previous step's runs ahead of its own read-backs), 2 on "
-                               "a first step"},
+                       "instrumented_ms_per_step": instrumented_ms, "instrumented_steps": probe,
+                       "note": "ms_per_step: K steps without instrumentation; the stage spans are from `instrumented_steps` more "
+                               "steps behind the timed region with events on the step's streams (the last one's spans, max over "
+                               "ranks; an event between two kernels costs the stream ~6 us, so instrumented_ms_per_step is the "
+                               "larger and `other_ms` = ms_per_step - prepare - plan span - cells may come out negative); host "
+                               "synchronisations per step: 1 in the steady state (cell counts; a plan of the same shape as the "
+                               "previous step's runs ahead of its own read-backs), 2 on a first step"},
             # rank 0's last step: (what, ms since the step began) from events on the compute stream and on the exchange's
             # stream -- "filter launched" / "gathered" events complete when the work queued before them has
             "timeline": timeline,

@@ -434,6 +434,13 @@ int mvs_sketch_set_planes_from_wire(mvs_ctx* ctx, mvs_sketch_set* set, const int
  * rows; the others' limb planes keep whatever an earlier step left there.  Plans with a filter only (others read every row of
  * their blocks: mvs_sketch_set_planes_from_wire before mvs_plan_filter). */
 int mvs_plan_wire(mvs_ctx* ctx, const int8_t* lo_wire);
+/* The caller announces that the row statistics (mvs_sketch_set_attach_derived) and squared norms of rows [row_begin, row_end) are
+ * in place on the context's stream -- in a multi-rank step: the small exchange has been joined.  The plan derives the filter's
+ * per-row constants of those rows in ONE launch (the part of the range inside the frame is skipped: derived at mvs_plan_begin),
+ * and mvs_plan_filter no longer derives them block by block (eight 4-us launches per step of an 8-way split).  Optional: blocks
+ * whose columns were never announced are handled as before.  Replaces nothing of the reference by itself -- part of the tile
+ * loop's set-up (src/pairwise_comp_optimized.cpp:949-958: norms of the column tile). */
+int mvs_plan_rows_ready(mvs_ctx* ctx, int64_t row_begin, int64_t row_end);
 int mvs_plan_begin(mvs_ctx* ctx, const mvs_sketch_set* set, const double* norms_sq, int keep_mode, int64_t frame_row_begin,
                    int64_t frame_row_end, int flags, mvs_cell* cells, int64_t capacity);
 int mvs_plan_filter(mvs_ctx* ctx, const mvs_plan_block* blocks, int n_blocks);

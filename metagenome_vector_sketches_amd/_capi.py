@@ -119,6 +119,7 @@ SYMBOLS = [
     ("mvs_sketch_set_planes_from_wire", _c.c_int, [_P, _P, _P, _c.c_int64, _c.c_int64]),
     ("mvs_plan_begin", _c.c_int, [_P, _P, _P, _c.c_int, _c.c_int64, _c.c_int64, _c.c_int, _P, _c.c_int64]),
     ("mvs_plan_wire", _c.c_int, [_P, _P]),
+    ("mvs_plan_rows_ready", _c.c_int, [_P, _c.c_int64, _c.c_int64]),
     ("mvs_plan_filter", _c.c_int, [_P, _P, _c.c_int]),
     ("mvs_plan_finish", _c.c_int, [_P, _c.POINTER(_P)]),
     ("mvs_plan_stats", _c.c_int, [_P, _c.POINTER(_c.c_double), _c.POINTER(_c.c_int64)]),
@@ -736,6 +737,10 @@ class Context:
         if lm != MEM_DEVICE:
             raise ValueError("the wire buffer must be a device buffer")
         _check(self.lib.mvs_sketch_set_planes_from_wire(self._h, sset._h, lp, int(row_first), int(row_count)))
+
+    def plan_rows_ready(self, row_begin, row_end):
+        """statistics and norms of these rows are in place: their filter constants in one launch (mvs_plan_rows_ready)"""
+        _check(self.lib.mvs_plan_rows_ready(self._h, int(row_begin), int(row_end)))
 
     def plan_wire(self, lo_wire):
         """the plan in progress rebuilds the limb planes of the foreign rows its second half reads from lo_wire (mvs_plan_wire)"""

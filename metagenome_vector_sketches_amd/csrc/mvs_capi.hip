@@ -122,10 +122,12 @@ struct mvs_ctx {
     bool pinned_busy = false;
     // block plans (mvs_plan_*): state between begin / filter / finish, scratch of mvs_sketch_set_prepare_rows, events
     int plan_overlap = 0;                 // block plans: 1 = filter launches alternate between the stream and a side stream
+    int report_spin = 0;                  // mvs_cells_report: microseconds to poll the stream before blocking on it (0: block at once)
                                           // (measured at the per-rank size of an 8-way split: filters 1.191 -> 1.164 ms, within
                                           // the box-to-box spread; off by default -- one more queue beside RCCL's for 2 %)
     struct PlanState* plan = nullptr;
     void* plan_tmp = nullptr;   size_t plan_tmp_bytes = 0;
+    const void* rows_max_done = nullptr;   // state block whose widest row mvs_cells_sort_rows_ahead has already computed
 };
 
 struct mvs_sketch_set {
@@ -558,6 +560,11 @@ int mvs_ctx_set_option(mvs_ctx* c, const char* name, int64_t value) {
         c->plan_overlap = (int)value;
         return MVS_OK;
     }
+    if (std::strcmp(name, "report_spin") == 0) {             // host-side waiting only
+        if (value < 0 || value > 1000000) return fail(MVS_E_INVALID, "option report_spin: 0 .. 1000000 microseconds");
+        c->report_spin = (int)value;
+        return MVS_OK;
+    }
     for (const OptionSpec& sp : kOptions)
         if (std::strcmp(sp.name, name) == 0) return apply_option(c->opt, sp, (long long)value);
     return fail(MVS_E_INVALID, "unknown option '%s'", name);
@@ -567,6 +574,10 @@ int mvs_ctx_get_option(const mvs_ctx* c, const char* name, int64_t* value) {
     if (!c || !name || !value) return fail(MVS_E_INVALID, "NULL argument");
     if (std::strcmp(name, "plan_overlap") == 0) {
         *value = c->plan_overlap;
+        return MVS_OK;
+    }
+    if (std::strcmp(name, "report_spin") == 0) {
+        *value = c->report_spin;
         return MVS_OK;
     }
     for (const OptionSpec& sp : kOptions)
@@ -3028,6 +3039,8 @@ struct PlanState {
     hipEvent_t e_fork = nullptr, e_join = nullptr;
     bool side_busy = false;
     const int8_t* lo_wire = nullptr;      // mvs_plan_wire: the other ranks' limb planes are rebuilt from it, row by row, as needed
+    bool need_clean = false;              // the row marks (pw_need) were cleared by this plan's reset and not written since
+    std::vector<std::pair<int64_t, int64_t>> meta_done;   // rows whose filter constants are in place (mvs_plan_rows_ready, the frame)
     bool speculate = false;               // this plan
     bool pending = false;                 // its counts are still on the device only
     bool stale = false;                   // (after the counts came in) its sizes did not hold
@@ -3091,13 +3104,17 @@ int plan_resolve(mvs_ctx* c) {
     return MVS_OK;
 }
 
+// counters, candidate-region headers, tile flags and the row marks of mvs_plan_wire cleared by ONE launch (six memsets were
+// nine fill kernels of 5 us each in front of every plan: 45 us of the 1.7 ms a rank of an 8-way split spends on its step)
 int plan_reset_counters(mvs_ctx* c, PlanState& st, bool cells_too) {
-    if (cells_too) HIP_TRY(hipMemsetAsync(c->d_counter, 0, 8, c->stream));
-    HIP_TRY(hipMemsetAsync(c->d_counter + 1, 0, 16, c->stream));
-    HIP_TRY(hipMemsetAsync(c->d_counter + 5, 0, 224, c->stream));
-    HIP_TRY(hipMemsetAsync(st.a.recheck_queue, 0, 512, c->stream));
-    if (st.regions_cap) HIP_TRY(hipMemsetAsync(c->pw_chdr, 0, (size_t)st.regions_cap * 4, c->stream));
-    HIP_TRY(hipMemsetAsync(st.a.tile_flag, 0, (size_t)st.n_tr * (size_t)st.n_tc * 4, c->stream));
+    void* ptrs[7] = {cells_too ? (void*)c->d_counter : nullptr, c->d_counter + 1, c->d_counter + 5, st.a.recheck_queue,
+                     st.regions_cap ? c->pw_chdr : nullptr, st.a.tile_flag, c->pw_need};
+    const size_t bytes[7] = {8, 16, 224, 512, (size_t)st.regions_cap * 4, (size_t)st.n_tr * (size_t)st.n_tc * 4,
+                             c->pw_need ? (size_t)st.set->n_alloc / 4 * 4 : 0};
+    if (mvs::launch_zero_ranges(c->stream, ptrs, bytes, 7) != 0) return fail(MVS_E_INVALID, "plan reset: misaligned buffer");
+    const int rc = check_kernel("k_zero_ranges");
+    if (rc) return rc;
+    st.need_clean = c->pw_need != nullptr && st.set->n_alloc % 4 == 0 && c->pw_need_bytes >= (size_t)st.set->n_alloc;
     st.regions_next = 0;
     return MVS_OK;
 }
@@ -3127,7 +3144,8 @@ int plan_rebuild_needed(mvs_ctx* c, PlanState& st) {
     const mvs_sketch_set* s = st.set;
     int rc = ensure_buf(c, &c->pw_need, &c->pw_need_bytes, (size_t)s->n_alloc);
     if (rc) return rc;
-    HIP_TRY(hipMemsetAsync(c->pw_need, 0, (size_t)s->n_alloc, c->stream));
+    if (!st.need_clean) HIP_TRY(hipMemsetAsync(c->pw_need, 0, (size_t)s->n_alloc, c->stream));   // (the plan's reset cleared it)
+    st.need_clean = false;
     mvs::launch_rows_needed(c->stream, st.a, st.n_tr, st.n_tc, st.f0, st.f1, s->n, (unsigned char*)c->pw_need);
     rc = check_kernel("k_rows_needed");
     if (rc) return rc;
@@ -3365,10 +3383,16 @@ int mvs_plan_begin(mvs_ctx* c, const mvs_sketch_set* s, const double* norms_sq, 
     a.tile_dense_thr = c->opt.tile_dense_thr > 0 ? (unsigned)c->opt.tile_dense_thr : 0xffffffffu;
     a.tile_flag_count = reinterpret_cast<unsigned int*>(c->d_counter + 8);
     a.tile_flag_limit = 0xffffffffu;      // a plan never gives up on its filter: dense tiles go to the exact kernel one by one
+    if (s->n_alloc % 4 == 0) {            // the row marks of mvs_plan_wire: cleared with the counters (one launch)
+        rc = ensure_buf(c, &c->pw_need, &c->pw_need_bytes, (size_t)s->n_alloc);
+        if (rc) return rc;
+    }
     rc = plan_reset_counters(c, st, true);
     if (rc) return rc;
     rc = plan_meta(c, st, f0, std::min<int64_t>(f1, s->n));
     if (rc) return rc;
+    st.meta_done.clear();
+    st.meta_done.emplace_back(f0, f1);
     st.key = {f0, f1, s->n, (int64_t)s->d_pad, (int64_t)flags, (int64_t)keep_mode, (int64_t)s->d, capacity};
     st.speculate = c->opt.plan_speculate != 0 && st.hints_valid && st.key == st.hint_key;
     st.stale = false;
@@ -3423,7 +3447,9 @@ int mvs_plan_filter(mvs_ctx* c, const mvs_plan_block* blocks, int n_blocks) {
     }
     for (size_t k = first; k < st.blocks.size(); ++k) {
         const auto& b = st.blocks[k];
-        if (!(b[2] >= st.f0 && b[3] <= st.f1)) {          // columns outside the frame's rows: their constants are not there yet
+        bool have = false;                                 // the frame's rows; rows announced by mvs_plan_rows_ready
+        for (const auto& r : st.meta_done) have = have || (b[2] >= r.first && b[3] <= r.second);
+        if (!have) {                                        // columns outside: their constants are not there yet
             const int rc = plan_meta(c, st, b[2], b[3]);
             if (rc) return rc;
         }
@@ -3455,6 +3481,23 @@ int mvs_plan_wire(mvs_ctx* c, const int8_t* lo_wire) {
     if (lo_wire && (!st.two_stage || !st.set->ext_coarse_fm || !st.set->ext_rows))
         return fail(MVS_E_INVALID, "a plan with a filter on a two-limb set with derived data attached (others: mvs_sketch_set_planes_from_wire)");
     st.lo_wire = lo_wire;
+    return MVS_OK;
+}
+
+int mvs_plan_rows_ready(mvs_ctx* c, int64_t row_begin, int64_t row_end) {
+    if (!c || !c->plan || !c->plan->active || c->plan->finished) return fail(MVS_E_INVALID, "no plan in progress (mvs_plan_begin)");
+    PlanState& st = *c->plan;
+    if (row_begin < 0 || row_end < row_begin || row_end > st.set->n) return fail(MVS_E_INVALID, "rows outside the sketch set");
+    if (!st.two_stage || row_begin == row_end) return MVS_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    // the part below and the part above the frame (the frame's own constants are in place and its filter may be reading them)
+    const int64_t parts[2][2] = {{row_begin, std::min(row_end, st.f0)}, {std::max(row_begin, st.f1), row_end}};
+    for (const auto& p : parts) {
+        if (p[1] <= p[0]) continue;
+        const int rc = plan_meta(c, st, p[0], p[1]);
+        if (rc) return rc;
+        st.meta_done.emplace_back(p[0], p[1]);
+    }
     return MVS_OK;
 }
 
@@ -3687,8 +3730,14 @@ int mvs_cells_route(mvs_ctx* c, const mvs_cell* raw, const uint64_t* d_n_raw, in
         n_total >= (1LL << 31) - 256 || (raw_capacity > 0 && !raw) || (own_capacity > 0 && !own_out))
         return fail(MVS_E_INVALID, "bad argument");
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipMemsetAsync(d_own_count, 0, 16 + 4 * (size_t)(own_end - own_begin + 1), c->stream));   // count, max, per-row counts
-    if (send) HIP_TRY(hipMemsetAsync(send, 0, MVS_CELLS_HEADER_BYTES, c->stream));
+    {   // count, max, per-row counts; the header of the send buffer -- one launch
+        void* ptrs[2] = {d_own_count, send};
+        const size_t bytes[2] = {16 + 4 * (size_t)(own_end - own_begin + 1), send ? (size_t)MVS_CELLS_HEADER_BYTES : 0};
+        if (mvs::launch_zero_ranges(c->stream, ptrs, bytes, 2) != 0) return fail(MVS_E_INVALID, "state block / send buffer not 4-byte aligned");
+        const int rz = check_kernel("k_zero_ranges");
+        if (rz) return rz;
+    }
+    c->rows_max_done = nullptr;
     mvs::launch_cells_route(c->stream, raw, reinterpret_cast<const unsigned long long*>(d_n_raw), (unsigned long long)raw_capacity,
                             block_rows_padded, block_rows, n_total, (int)own_begin, (int)own_end, own_out,
                             (unsigned long long)own_capacity, reinterpret_cast<unsigned long long*>(d_own_count),
@@ -3704,6 +3753,7 @@ int mvs_cells_collect(mvs_ctx* c, const void* recv, int world, int rank, int64_t
         return fail(MVS_E_INVALID, "bad argument");
     if (world == 1) return MVS_OK;
     HIP_TRY(hipSetDevice(c->device));
+    c->rows_max_done = nullptr;
     mvs::launch_cells_collect(c->stream, static_cast<const unsigned long long*>(recv), world, rank, (unsigned long long)foreign_capacity,
                               (int)own_begin, (int)own_end, own_out, (unsigned long long)own_capacity,
                               reinterpret_cast<unsigned long long*>(d_own_count));
@@ -3748,6 +3798,7 @@ int mvs_cells_sort_rows_ahead(mvs_ctx* c, const mvs_cell* cells_in, int64_t in_c
                               reinterpret_cast<const unsigned long long*>(d_own_state), c->pw_sort, c->pw_sort_bytes, nullptr, in_capacity,
                               out_capacity);
     if (rc) return fail(rc, "row sort failed");
+    c->rows_max_done = d_own_state;        // the scan left the widest row in the state block: the report need not look again
     return check_kernel("k_rows_sort");
 }
 
@@ -3767,12 +3818,21 @@ int mvs_cells_report(mvs_ctx* c, const void* recv, int world, int64_t foreign_ca
     // a plan that ran ahead of its read-backs: its counts come along with this one
     const bool with_plan = c->plan && c->plan->pending;
     if (with_plan) HIP_TRY(hipMemcpyAsync(plan_back, c->d_counter, 33 * 8, hipMemcpyDeviceToHost, c->stream));
-    mvs::launch_rows_max(c->stream, reinterpret_cast<unsigned long long*>(d_own_count), (int)own_rows);
+    if (c->rows_max_done != d_own_count)
+        mvs::launch_rows_max(c->stream, reinterpret_cast<unsigned long long*>(d_own_count), (int)own_rows);
     HIP_TRY(hipMemcpyAsync(own, d_own_count, 16, hipMemcpyDeviceToHost, c->stream));
     if (recv) {
         const size_t stride = MVS_CELLS_HEADER_BYTES + (size_t)foreign_capacity * sizeof(mvs_cell);
         HIP_TRY(hipMemcpy2DAsync(hdr, MVS_CELLS_HEADER_BYTES, recv, stride, MVS_CELLS_HEADER_BYTES, (size_t)world,
                                  hipMemcpyDeviceToHost, c->stream));
+    }
+    if (c->report_spin > 0) {
+        // the step's one host synchronisation: the device is typically a fraction of a millisecond from done, and a blocked
+        // thread is woken by an interrupt tens of microseconds after the stream drained -- poll first, block if it takes long
+        const auto t0 = std::chrono::steady_clock::now();
+        while (hipStreamQuery(c->stream) == hipErrorNotReady &&
+               std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() < (double)c->report_spin) {
+        }
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (with_plan) plan_take_counts(c, *c->plan, plan_back);

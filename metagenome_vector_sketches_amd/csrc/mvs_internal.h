@@ -309,6 +309,9 @@ int launch_cells_collect(hipStream_t stream, const unsigned long long* d_recv, i
                          int own_begin, int own_end, mvs_cell* d_own, unsigned long long own_capacity, unsigned long long* d_own_count);
 // the shard's cells by row buckets (rows of <= 64 cells): state block as the route / collect kernels fill it
 int launch_rows_max(hipStream_t stream, unsigned long long* d_state, int rows);
+// up to 8 device ranges (4-byte aligned, sizes multiples of 4; NULL / empty ones are skipped) zeroed by ONE launch
+int launch_zero_ranges(hipStream_t stream, void* const* ptrs, const size_t* bytes, int n);
+// sort_cells_rows also leaves the widest row in d_state[1] (what launch_rows_max computes)
 int sort_cells_rows(hipStream_t stream, const mvs_cell* d_in, mvs_cell* d_out, int64_t n, int row0, int rows,
                     const unsigned long long* d_state, void* d_scratch, size_t scratch_bytes, size_t* scratch_needed,
                     int64_t in_cap = -1, int64_t out_cap = -1);

@@ -3009,6 +3009,80 @@ __global__ __launch_bounds__(1024) void k_rows_max(unsigned long long* __restric
     }
 }
 
+// The scan of the row counts, the copy that becomes the scatter's cursors and the widest row in ONE workgroup (rows + 1 <=
+// kRowsScanMax: a rank's shard of a split; 12 500 rows of an 8-way split took rocprim's two kernels + a device copy + k_rows_max
+// 25 us of a 1.7 ms step): thread t owns a contiguous run of <= 16 counts, all loaded before the first is used, the 1024 sums
+// are scanned over the lanes and through the LDS.  counts holds rows + 1 entries (the last one zero), row_ptr / cursor likewise.
+constexpr int kRowsScanPer = 16, kRowsScanMax = kRowsScanPer * 1024;
+__global__ __launch_bounds__(1024) void k_rows_scan(unsigned long long* __restrict__ state, int rows, unsigned* __restrict__ row_ptr,
+                                                    unsigned* __restrict__ cursor) {
+    __shared__ unsigned wsum[16], wmax[16];
+    const unsigned* cnt = reinterpret_cast<const unsigned*>(state + 2);
+    const int n = rows + 1, t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int per = (n + 1023) / 1024;                     // <= kRowsScanPer
+    const int b = t * per;
+    unsigned v[kRowsScanPer];
+#pragma unroll
+    for (int k = 0; k < kRowsScanPer; ++k) v[k] = (k < per && b + k < n) ? cnt[b + k] : 0u;
+    unsigned sum = 0, m = 0;
+#pragma unroll
+    for (int k = 0; k < kRowsScanPer; ++k) {
+        sum += v[k];
+        m = v[k] > m ? v[k] : m;
+    }
+    unsigned incl = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned x = (unsigned)__shfl_up((int)incl, o, 64);
+        if (lane >= o) incl += x;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned x = (unsigned)__shfl_xor((int)m, o, 64);
+        m = x > m ? x : m;
+    }
+    if (lane == 63) wsum[w] = incl;
+    if (lane == 0) wmax[w] = m;
+    __syncthreads();
+    unsigned base = incl - sum;
+    for (int k = 0; k < w; ++k) base += wsum[k];
+#pragma unroll
+    for (int k = 0; k < kRowsScanPer; ++k) {
+        if (k < per && b + k < n) {
+            row_ptr[b + k] = base;
+            cursor[b + k] = base;
+        }
+        base += v[k];
+    }
+    if (t == 0) {
+        for (int k = 1; k < 16; ++k) m = wmax[k] > m ? wmax[k] : m;
+        state[1] = m;
+    }
+}
+
+// up to 8 device ranges cleared by one launch (a plan's counters, candidate headers, tile flags, row marks: six memsets became
+// nine fill kernels of 5 us each in front of every plan); bytes are multiples of 4
+struct ZeroRanges {
+    unsigned* p[8];
+    unsigned long long words[8];
+    int n;
+};
+__global__ __launch_bounds__(256) void k_zero_ranges(const ZeroRanges z) {
+    const unsigned long long stride = (unsigned long long)gridDim.x * 256;
+    for (int r = 0; r < z.n; ++r) {
+        unsigned* __restrict__ p = z.p[r];
+        const unsigned long long nw = z.words[r];
+        if ((reinterpret_cast<unsigned long long>(p) & 15) == 0) {           // whole 16-byte stores, then the tail
+            const unsigned long long n4 = nw >> 2;
+            uint4* p4 = reinterpret_cast<uint4*>(p);
+            for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) p4[i] = uint4{0, 0, 0, 0};
+            for (unsigned long long i = (n4 << 2) + (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < nw; i += stride) p[i] = 0u;
+        } else {
+            for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < nw; i += stride) p[i] = 0u;
+        }
+    }
+}
+
 // d_count != NULL: the number of cells is read there (a sort queued in front of the read-back that would have told the host) and
 // bounded by in_cap; positions beyond out_cap are not written (the row counts include cells a full buffer dropped)
 __global__ __launch_bounds__(256) void k_rows_scatter(const mvs_cell* __restrict__ in, unsigned long long n,
@@ -3719,6 +3793,23 @@ int launch_rows_max(hipStream_t stream, unsigned long long* d_state, int rows) {
     return 0;
 }
 
+int launch_zero_ranges(hipStream_t stream, void* const* ptrs, const size_t* bytes, int n) {
+    ZeroRanges z{};
+    unsigned long long total = 0;
+    for (int k = 0; k < n; ++k) {
+        if (!ptrs[k] || bytes[k] == 0) continue;
+        if (z.n == 8 || (bytes[k] & 3) != 0 || (reinterpret_cast<unsigned long long>(ptrs[k]) & 3) != 0) return MVS_E_INVALID;
+        z.p[z.n] = static_cast<unsigned*>(ptrs[k]);
+        z.words[z.n] = bytes[k] / 4;
+        total += z.words[z.n];
+        ++z.n;
+    }
+    if (z.n == 0) return 0;
+    const unsigned blocks = (unsigned)std::min<unsigned long long>(1024, std::max<unsigned long long>(1, (total / 4 + 255) / 256));
+    hipLaunchKernelGGL(k_zero_ranges, dim3(blocks), dim3(256), 0, stream, z);
+    return 0;
+}
+
 int sort_cells_rows(hipStream_t stream, const mvs_cell* d_in, mvs_cell* d_out, int64_t n, int row0, int rows,
                     const unsigned long long* d_state, void* d_scratch, size_t scratch_bytes, size_t* scratch_needed,
                     int64_t in_cap, int64_t out_cap) {
@@ -3734,9 +3825,14 @@ int sort_cells_rows(hipStream_t stream, const mvs_cell* d_in, mvs_cell* d_out, i
     unsigned* row_ptr = reinterpret_cast<unsigned*>(d_scratch);
     unsigned* cursor = reinterpret_cast<unsigned*>(static_cast<char*>(d_scratch) + tab_al);
     void* scan_tmp = static_cast<char*>(d_scratch) + 2 * tab_al;
-    e = rocprim::exclusive_scan(scan_tmp, need, counts, row_ptr, 0u, (size_t)rows + 1, rocprim::plus<unsigned>(), stream);
-    if (e != hipSuccess) return MVS_E_HIP;
-    if (hipMemcpyAsync(cursor, row_ptr, tab, hipMemcpyDeviceToDevice, stream) != hipSuccess) return MVS_E_HIP;
+    if (rows < kRowsScanMax) {      // scan, cursors and the widest row (state[1], what k_rows_max would write) in one launch
+        hipLaunchKernelGGL(k_rows_scan, dim3(1), dim3(1024), 0, stream, const_cast<unsigned long long*>(d_state), rows, row_ptr, cursor);
+    } else {
+        e = rocprim::exclusive_scan(scan_tmp, need, counts, row_ptr, 0u, (size_t)rows + 1, rocprim::plus<unsigned>(), stream);
+        if (e != hipSuccess) return MVS_E_HIP;
+        if (hipMemcpyAsync(cursor, row_ptr, tab, hipMemcpyDeviceToDevice, stream) != hipSuccess) return MVS_E_HIP;
+        hipLaunchKernelGGL(k_rows_max, dim3(1), dim3(1024), 0, stream, const_cast<unsigned long long*>(d_state), rows);
+    }
     // in_cap >= 0: the count is d_state[0] on the device, at most in_cap cells are there; the grid is sized for the buffer
     const bool ahead = in_cap >= 0;
     const int64_t size_for = ahead ? in_cap : n;

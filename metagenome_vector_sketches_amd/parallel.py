@@ -351,6 +351,9 @@ class GpuOps:
     def plan_filter(self, blocks):
         self.ctx.plan_filter(blocks)
 
+    def plan_rows_ready(self, row_begin, row_end):
+        self.ctx.plan_rows_ready(row_begin, row_end)
+
     def plan_wire(self, lo_wire):
         """the plan in progress rebuilds, inside its finish, the limb planes of exactly the foreign rows it reads"""
         self.ctx.plan_wire(lo_wire)
@@ -733,6 +736,8 @@ class ShardedComparison:
         if first:
             for h in st["small"]:
                 h.wait()                                   # row statistics + norms of every rank
+        if others and hasattr(ops, "plan_rows_ready"):
+            ops.plan_rows_ready(0, self.world * P)         # every peer's filter constants in one launch, not block by block
         if first and others and getattr(ops, "plan_exact_mode", lambda: False)():
             # no filter in this plan (filter switched off, another limb code): mvs_plan_filter runs the exact kernel on a block
             # at once, and that reads the other ranks' LIMB planes -- they have to be there (and rebuilt) before the call

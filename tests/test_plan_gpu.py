@@ -81,6 +81,8 @@ class Split:
         if wire:
             ctx.plan_wire(lo)
         ctx.plan_filter(plan[:1])
+        if rank % 2 == 1:                   # odd ranks announce every row at once (one launch derives the peers' filter constants:
+            ctx.plan_rows_ready(0, P * world)   # mvs_plan_rows_ready), even ranks leave it to mvs_plan_filter, block by block
         for (c0, c1) in parallel.chunk_bounds(P, chunks):
             blocks = parallel.clip_blocks(plan[1:], P, c0, c1)
             if blocks:

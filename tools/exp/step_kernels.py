@@ -19,7 +19,7 @@ end = t0
 busy = 0
 print("step of %d kernels, %.3f ms from its first kernel to the next step's first" % (len(sel), (ev[hi][0] - t0) / 1e6))
 for s, e, n in sel:
-    name = n.split("(")[0].replace("void ", "").replace("mvs::(anonymous namespace)::", "").replace("mvs::", "")[:44]
+    name = n.replace("(anonymous namespace)::", "").replace("void ", "").replace("mvs::", "").split("(")[0][:44]
     gap = (s - end) / 1e3
     print("  %9.1f us  %8.1f us  gap %7.1f  %s" % ((s - t0) / 1e3, (e - s) / 1e3, gap, name))
     busy += max(0, e - max(s, end))

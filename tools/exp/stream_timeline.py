@@ -9,7 +9,7 @@ import sys
 kr = list(csv.DictReader(open(sys.argv[1])))
 cr = list(csv.DictReader(open(sys.argv[2])))
 def short(n):
-    return n.split("(")[0].replace("void ", "").replace("mvs::(anonymous namespace)::", "").replace("mvs::", "").split("<")[0][:28]
+    return n.replace("(anonymous namespace)::", "").replace("void ", "").replace("mvs::", "").split("(")[0].split("<")[0][:28]
 K = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"])) for r in kr)
 C = []
 for r in cr:

@@ -51,6 +51,7 @@ def main():
     ap.add_argument("--no-wire", action="store_true", help="limb planes on the wire (3 bytes per entry)")
     ap.add_argument("--wire", action="store_true", help="(default) low limbs on the wire, 2 bytes per entry; the plan rebuilds the rows it reads")
     ap.add_argument("--overlap", action="store_true", help="filter launches of a plan alternate between two streams (plan_overlap)")
+    ap.add_argument("--report-spin", type=int, default=-1, help="option report_spin: microseconds mvs_cells_report polls before it blocks")
     ap.add_argument("--out", default="")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
@@ -59,6 +60,8 @@ def main():
     ctx.set_timing(True)
     if args.overlap:
         ctx.set_option("plan_overlap", 1)
+    if args.report_spin >= 0:
+        ctx.set_option("report_spin", args.report_spin)
     n, d = args.n, args.d
     sk = synth.make_sketches_torch(n, d, 50_000, seed=args.seed, device=dev)
     ss = torch.empty(n, dtype=torch.int64, device=dev)
@@ -91,13 +94,17 @@ def main():
         plan = parallel.block_plan(G, 0, P)
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(10)]
         acc = []
-        last_max_row = 1 << 30
         lo = torch.zeros(n_alloc * d_pad, dtype=torch.int8, device=dev)
         gops = parallel.GpuOps(ctx, dev)
         gops.wire_rows(planes, lo, d_pad, 0, n_st)                 # what the exchange of low limbs would have delivered
-        for rep in range(args.reps + 2):
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
+        class _NoEvent:
+            def record(self):
+                pass
+        state = {"last_max_row": 1 << 30, "rep": 0}
+
+        def one_step(ev):
+            """rank 0's step as parallel.ShardedComparison runs it; ev: ten events recorded between the stages, or stand-ins that
+            record nothing (an event between two kernels costs the stream ~6 us: the wall is measured without them)"""
             ev[0].record()
             ctx.recode_rows(sset, sk[b0:e0], 0, P)              # own rows only
             ev[1].record()
@@ -105,6 +112,8 @@ def main():
                 ctx.plan_begin(sset, n2_st, 0, P, G > 1, raw)
             ctx.plan_filter(plan[:1])
             ev[2].record()
+            if len(plan) > 1:
+                ctx.plan_rows_ready(0, n_st)                    # as parallel.ShardedComparison: statistics + norms have arrived
             for (c0, c1) in parallel.chunk_bounds(P, args.chunks, args.first):
                 blocks = parallel.clip_blocks(plan[1:], P, c0, c1)
                 if blocks:
@@ -117,7 +126,7 @@ def main():
             ev[4].record()
             ctx.cells_route(raw, d_cnt, P, rps, n, b0, e0, own, d_own, send, cap)
             ev[5].record()
-            ahead = rep > 0 and last_max_row <= 64              # as parallel.ShardedComparison: the sort in front of the step's host sync
+            ahead = state["rep"] > 0 and state["last_max_row"] <= 64    # as parallel.ShardedComparison: the sort in front of the step's host sync
             if ahead:
                 ctx.cells_sort_rows_ahead(own, b0, e0, d_own, outc)
             n_own, heads, max_row = ctx.cells_report(send, 1, cap, e0 - b0, d_own)
@@ -126,13 +135,20 @@ def main():
                     ctx.cells_sort_rows(own, n_own, b0, e0, d_own, outc)
                 else:
                     ctx.cells_sort(own, n_own, outc)
-            last_max_row = max_row
+            state["last_max_row"] = max_row
+            state["rep"] += 1
             ev[6].record()
+            return n_own, heads
+
+        for rep in range(args.reps + 2):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            n_own, heads = one_step(ev)
             torch.cuda.synchronize()
             wall = (time.perf_counter() - t0) * 1e3
             if rep >= 2:
                 ps = ctx.plan_stats()
-                acc.append({"wall_ms": wall, "prepare_ms": ev[0].elapsed_time(ev[1]), "diag_filter_ms": ev[1].elapsed_time(ev[2]),
+                acc.append({"wall_instrumented_ms": wall, "prepare_ms": ev[0].elapsed_time(ev[1]), "diag_filter_ms": ev[1].elapsed_time(ev[2]),
                             "peer_filters_ms": ev[2].elapsed_time(ev[3]), "finish_ms": ev[9].elapsed_time(ev[4]),
                             "route_report_ms": ev[4].elapsed_time(ev[5]), "sort_ms": ev[5].elapsed_time(ev[6]),      # route | sort + report
                             "filter_kernels_ms": ps["filter_ms"], "recheck_ms": ps["recheck_ms"], "tiles_ms": ps["tiles_ms"],
@@ -140,6 +156,20 @@ def main():
                             "flagged_tiles": ps["flagged_tiles"], "own_cells": int(n_own), "foreign_cells": int(heads[0][0]),
                             "rebuild_ms": ev[3].elapsed_time(ev[9]),
                             "speculated": float(ps["speculated"]), "stale": float(ps["stale"])})
+        # the wall of the step as production runs it: no timing events in the library, none between the stages
+        ctx.set_timing(False)
+        none = [_NoEvent() for _ in range(10)]
+        walls = []
+        for rep in range(args.reps + 2):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            one_step(none)
+            torch.cuda.synchronize()
+            if rep >= 2:
+                walls.append((time.perf_counter() - t0) * 1e3)
+        ctx.set_timing(True)
+        for a in acc:
+            a["wall_ms"] = float(np.mean(walls))
         m = {k: float(np.mean([a[k] for a in acc])) for k in acc[0]}
         m["rows_per_rank_padded"] = P
         m["wire"] = "coarse plane + limb planes" if no_wire else "coarse plane + low limbs (peers' limb planes rebuilt in front of the re-check)"
@@ -161,30 +191,37 @@ def main():
                 planes_at = t_comm + ((lat + P * 2 * d_pad / (rate * 1e6)) if G > 1 else 0.0)
             else:
                 planes_at = t_comm + ((lat + P * d_pad / (rate * 1e6)) if G > 1 else 0.0)      # the low limbs
-            # compute stream: prepare, diagonal filter, then the chunk launches (each waits for its chunk), finish waits for the planes
-            t = m["prepare_ms"] + m["diag_filter_ms"]
+            # compute stream: prepare, diagonal filter, then the chunk launches (each waits for its chunk), finish waits for the planes.
+            # The stage spans were measured with events between the stages (each costs the stream ~6 us); the step's wall without
+            # them.  The walk uses the spans scaled to the uninstrumented wall -- compute reaches its wait points EARLIER than the
+            # instrumented spans say, so waits come out longer, not shorter.
+            stages = ("prepare_ms", "diag_filter_ms", "peer_filters_ms", "rebuild_ms", "finish_ms", "route_report_ms", "sort_ms")
+            scale = min(1.0, m["wall_ms"] / sum(m[k] for k in stages))
+            sp = {k: m[k] * scale for k in stages}
+            t_comm_scaled_shift = m["prepare_ms"] - sp["prepare_ms"]         # the exchange starts when the own rows are ready
+            t = sp["prepare_ms"] + sp["diag_filter_ms"]
             waited = 0.0
             for a, (c0, c1) in zip(arrive, chunks):
+                a -= t_comm_scaled_shift
                 if G > 1 and a > t:
                     waited += a - t
                     t = a
-                t += m["peer_filters_ms"] * (c1 - c0) / P if len(plan) > 1 else 0.0      # a piece's share of the peers' filter time
-            if G > 1 and planes_at > t:
-                waited += planes_at - t
-                t = planes_at
-            t += m["rebuild_ms"] + m["finish_ms"] + m["route_report_ms"]
+                t += sp["peer_filters_ms"] * (c1 - c0) / P if len(plan) > 1 else 0.0      # a piece's share of the peers' filter time
+            if G > 1 and planes_at - t_comm_scaled_shift > t:
+                waited += planes_at - t_comm_scaled_shift - t
+                t = planes_at - t_comm_scaled_shift
+            t += sp["rebuild_ms"] + sp["finish_ms"] + sp["route_report_ms"]
             exch = (lat + (64 + 16 * m["foreign_cells"] * 1.25) / (rate * 1e6)) if G > 1 else 0.0   # the mirrored cells
-            t += exch + m["sort_ms"]
-            host_gap = max(0.0, m["wall_ms"] - (m["prepare_ms"] + m["diag_filter_ms"] + m["peer_filters_ms"] + m["rebuild_ms"] + m["finish_ms"] +
-                                                m["route_report_ms"] + m["sort_ms"]))
+            t += exch + sp["sort_ms"]
+            host_gap = max(0.0, m["wall_ms"] - sum(sp.values()))
             t += host_gap
             models["%g GB/s per link and direction" % rate] = {"step_ms": t, "exposed_exchange_ms": waited + exch,
                                                                "speedup_vs_1gpu_measured": base_ms / t}
         m["model"] = models
         out["ranks"][str(G)] = m
-        print("G=%d  [%s]  P=%d  wall %.3f ms (no exchange)  prepare %.3f  diag %.3f  peers %.3f  finish %.3f  route %.3f  sort %.3f | "
+        print("G=%d  [%s]  P=%d  wall %.3f ms (no exchange, no events; %.3f with the events the stage spans come from)  prepare %.3f  diag %.3f  peers %.3f  finish %.3f  route %.3f  sort %.3f | "
               "filter kernels %.3f (%d tiles, %d launches)  re-check %.3f  tiles %.3f | (rebuild of the rows the plan reads: inside finish) %.3f" %
-              (G, "3 B/entry on the wire" if no_wire else "2 B/entry on the wire", P, m["wall_ms"], m["prepare_ms"], m["diag_filter_ms"], m["peer_filters_ms"], m["finish_ms"], m["route_report_ms"],
+              (G, "3 B/entry on the wire" if no_wire else "2 B/entry on the wire", P, m["wall_ms"], m["wall_instrumented_ms"], m["prepare_ms"], m["diag_filter_ms"], m["peer_filters_ms"], m["finish_ms"], m["route_report_ms"],
                m["sort_ms"], m["filter_kernels_ms"], m["filter_tiles"], m["filter_launches"], m["recheck_ms"], m["tiles_ms"], m["rebuild_ms"]))
         for k, v in models.items():
             print("      %s: step %.3f ms (exchange exposed %.3f) -> %.2f x the measured 1-GPU step" %
