@@ -338,6 +338,7 @@ const OptionSpec kOptions[] = {
     {"stream_pipeline", &mvs::Options::stream_pipeline, nullptr, 0, 1},
     {"stream_trace", &mvs::Options::stream_trace, nullptr, 0, 1},
     {"search_stream", &mvs::Options::search_stream, nullptr, 0, 1},
+    {"search_depth", &mvs::Options::search_depth, nullptr, 3, 6},
     {"fragment_major", &mvs::Options::fragment_major, nullptr, 0, 1},
     {"pairwise_bdirect", &mvs::Options::pairwise_bdirect, nullptr, 0, 1},
     {"plan_strip_wgs", &mvs::Options::plan_strip_wgs, nullptr, 256, 1 << 22},

@@ -77,6 +77,8 @@ struct Options {
                                     // (PairwiseArgs::coarse_fm, planes_fm), built once per set; 0: the row-major planes (A/B, tests)
     int search_stream = 1;          // blocks of few rows x >= 4096 columns outside the symmetric schedule: 1 = the streaming
                                     // filter (rows resident in LDS, columns streamed into the matrix cores), 0 = the tile kernels
+    int search_depth = 5;           // k_search_filter: register buffers of one k-slice x 64 columns per wave (3 .. 6); all but one
+                                    // are in flight (10^6 x 2048: 256 queries 0.654 -> 0.622 ms, 512 queries 1.146 -> 1.034 from 3 to 5)
     int stream_trace = 0;           // 1: mvs_pairwise_stream prints the host-side time line of its row blocks to stderr
     int recode_rows_wg = 8;         // k_recode_rows: rows (= waves) per workgroup, 8 or 16
     int plan_speculate = 0;         // block plans: second half of a plan sized from the previous plan's counts, no host round trip
