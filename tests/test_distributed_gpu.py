@@ -235,6 +235,15 @@ def test_bare_bench_gpus2_launches_itself():
     assert d["stages"]["allgather_bytes_per_rank"] == 2048 * 2 * 2048 + 2048 * 24 and d["stages"]["allgather_ms"] > 0
 
 
+def test_bare_bench_gpus2_keeps_its_headline_when_the_strong_legs_do_not_finish():
+    """the strong legs of a multi-GPU line run behind a guard (bench.py: run_strong_guarded): with a limit they cannot meet
+    every rank gives up on them, rank 0 still prints the ONE line with the configs[1] headline, `strong.error` says why,
+    and the exit code is 0 -- RCCL with more than one rank has never run anywhere: a failure there must not cost the line"""
+    d = _bare_bench(["--samples", "2000", "--hashes", "4000", "--strong-timeout", "1"])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["kept_cells"] >= 4000 * 10
+    assert "did not finish within 1 s" in d["strong"]["error"]
+
+
 def test_bare_bench_gpus2_config4_launches_itself():
     d = _bare_bench(["--config", "4"])
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["total_samples"] == 100_000
