@@ -21,7 +21,7 @@ reps = int(sys.argv[4]) if len(sys.argv) > 4 else 3
 encoded = len(sys.argv) > 5 and sys.argv[5] == "encoded"     # rows encoded in the shard codec on the device
 ctx = pkg.Context(0)
 ctx.set_stream(torch.cuda.current_stream())
-ctx.set_timing(True)
+ctx.set_timing(os.environ.get("MVS_BENCH_TIMING", "1") != "0")     # 0: no events in the library (kernels_ms reads 0)
 sk = synth.make_sketches_torch(n, d, 50_000, seed=2345, device="cuda", cluster=cluster)
 ss = torch.empty(n, dtype=torch.int64, device="cuda")
 ctx.sumsq(sk, out=ss)
