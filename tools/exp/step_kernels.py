@@ -10,9 +10,10 @@ marker = sys.argv[2] if len(sys.argv) > 2 else "k_recode_rows"
 back = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows)
 starts = [i for i, e in enumerate(ev) if marker in e[2]]
-if len(starts) < back + 1:
+if len(starts) < back + 1 or back < 0:
     sys.exit("fewer than %d steps in the trace" % (back + 1))
-lo, hi = starts[-back - 1], starts[-back]
+lo = starts[-back - 1]
+hi = starts[-back] if back > 0 else len(ev) - 1          # back = 0: from the last marker to the end of the trace
 sel = ev[lo:hi]
 t0 = sel[0][0]
 end = t0
