@@ -205,7 +205,15 @@ def test_plan_rejects_what_it_cannot_run(ctx):
     raw = torch.empty((1024, 4), dtype=torch.int32, device=DEV)
     with pytest.raises(_capi.MvsError):
         ctx.plan_filter([(0, 256, 0, 256)])                            # no plan in progress
+    with pytest.raises(_capi.MvsError):
+        ctx.plan_rows_ready(0, split.P)                                # likewise
     ctx.plan_begin(split.sset, split.n2, 0, split.P, True, raw)
+    with pytest.raises(_capi.MvsError):
+        ctx.plan_rows_ready(0, 2 * split.P + 1)                        # rows beyond the sketch set
+    with pytest.raises(_capi.MvsError):
+        ctx.plan_rows_ready(split.P, 0)                                # an inverted range
+    ctx.plan_rows_ready(0, 2 * split.P)                                # every row (the frame's own part is skipped); twice is fine
+    ctx.plan_rows_ready(split.P, 2 * split.P)
     with pytest.raises(_capi.MvsError):
         ctx.plan_filter([(0, split.P, 128, split.P)])                  # not on the tile grid
     with pytest.raises(_capi.MvsError):
