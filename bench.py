@@ -363,9 +363,14 @@ def main():
             q0, q1 = min(p0, S), min(p1, S)
             m = 0
             if q1 > q0:
-                # K1; the sums of squares and max |v| come out of the same kernel
+                # K1; the sums of squares and max |v| come out of the same kernel.  The library's events around K1 are recorded
+                # in EVERY step (the roofline's kernel time is measured live over the timed region); the block plan's own five
+                # events -- each costs the stream ~6 us -- only in the probe steps behind the timed region (state["probe"])
+                ctx.set_timing(True)
                 m = ctx.project_csr_stats(hashes, o_host[q0:q1 + 1], D, sketches[q0:q1], sumsq[q0:q1])
                 k1 += ctx.kernel_ms(0)
+                if not state.get("probe"):
+                    ctx.set_timing(False)
                 # text round trip of the norms (vector_norms.txt), on the device
                 ctx.norms_sq_text(sumsq[q0:q1], D, out=n2_local[q0:q1])
             # limb split of these rows, [all-gather of exactly these rows of every rank's block, on the side stream]
@@ -388,17 +393,26 @@ def main():
         step()
     sync_all()
     k1_ms, k2_ms, gather_ms = [], [], []
+    if os.environ.get("MVS_BENCH_PLAN_EVENTS") == "1":      # A/B: the plan's events in the timed steps too (as up to round 5's first session)
+        state["probe"] = True
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
         k1_ms.append(state["k1_ms"])
-        gather_ms.append(sc.last_gather_ms())    # events recorded before the comparison's end: already complete
-        # the comparison kernels of the rank's block plan: filter launches + re-check + exact kernel on flagged tiles
+        if world > 1:
+            gather_ms.append(sc.last_gather_ms())    # events recorded before the comparison's end: already complete
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    # probe steps behind the timed region: the comparison kernels of the rank's block plan (filter launches + re-check + exact
+    # kernel on flagged tiles) from the plan's own events, which the timed steps do without
+    state["probe"] = True
+    for _ in range(3):
+        step()
         ps = ctx.plan_stats()
         k2_ms.append(ps["filter_ms"] + ps["recheck_ms"] + ps["tiles_ms"])
         state["plan"] = ps
     sync_all()
-    elapsed = time.perf_counter() - t0
+    ctx.set_timing(True)
     ps = state["plan"]
     state["candidates"] = ps["candidates"]
     state["filter_ms"] = ps["filter_ms"] if not ps["exact_mode"] else None
