@@ -3111,7 +3111,7 @@ int plan_reset_counters(mvs_ctx* c, PlanState& st, bool cells_too) {
     void* ptrs[7] = {cells_too ? (void*)c->d_counter : nullptr, c->d_counter + 1, c->d_counter + 5, st.a.recheck_queue,
                      st.regions_cap ? c->pw_chdr : nullptr, st.a.tile_flag, c->pw_need};
     const size_t bytes[7] = {8, 16, 224, 512, (size_t)st.regions_cap * 4, (size_t)st.n_tr * (size_t)st.n_tc * 4,
-                             c->pw_need ? (size_t)st.set->n_alloc / 4 * 4 : 0};
+                             c->pw_need ? std::min((size_t)st.set->n_alloc, c->pw_need_bytes) / 4 * 4 : 0};   // (a buffer sized for an earlier, smaller set: never beyond it)
     if (mvs::launch_zero_ranges(c->stream, ptrs, bytes, 7) != 0) return fail(MVS_E_INVALID, "plan reset: misaligned buffer");
     const int rc = check_kernel("k_zero_ranges");
     if (rc) return rc;
@@ -3765,7 +3765,7 @@ int mvs_cells_sort_rows(mvs_ctx* c, const mvs_cell* cells_in, int64_t n, int64_t
                         mvs_cell* cells_out) {
     if (!c || !d_own_state) return fail(MVS_E_INVALID, "NULL argument");
     if (n < 0 || own_begin < 0 || own_end < own_begin || own_end - own_begin >= (1LL << 30)) return fail(MVS_E_INVALID, "bad argument");
-    if (n == 0) return MVS_OK;
+    if (n == 0 || own_end == own_begin) return MVS_OK;
     if (!cells_in || !cells_out || cells_in == cells_out) return fail(MVS_E_INVALID, "need two distinct device buffers");
     HIP_TRY(hipSetDevice(c->device));
     size_t need = 0;
@@ -3786,7 +3786,7 @@ int mvs_cells_sort_rows_ahead(mvs_ctx* c, const mvs_cell* cells_in, int64_t in_c
     if (in_capacity < 0 || out_capacity < 0 || own_begin < 0 || own_end < own_begin || own_end - own_begin >= (1LL << 30) ||
         in_capacity >= (1LL << 32) || out_capacity >= (1LL << 32))
         return fail(MVS_E_INVALID, "bad argument");
-    if (in_capacity == 0 || out_capacity == 0) return MVS_OK;
+    if (in_capacity == 0 || out_capacity == 0 || own_end == own_begin) return MVS_OK;   // (a shard without rows has nothing to order)
     if (!cells_in || !cells_out || cells_in == cells_out) return fail(MVS_E_INVALID, "need two distinct device buffers");
     HIP_TRY(hipSetDevice(c->device));
     size_t need = 0;

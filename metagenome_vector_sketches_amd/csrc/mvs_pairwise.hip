@@ -3855,7 +3855,8 @@ int sort_cells_rows(hipStream_t stream, const mvs_cell* d_in, mvs_cell* d_out, i
     const unsigned blocks = (unsigned)std::min<int64_t>(ahead ? 1024 : 2048, std::max<int64_t>(1, (size_for + 255) / 256));
     hipLaunchKernelGGL(k_rows_scatter, dim3(blocks), dim3(256), 0, stream, d_in, (unsigned long long)(ahead ? 0 : n), ahead ? d_state : nullptr,
                        (unsigned long long)(ahead ? in_cap : 0), row0, cursor, d_out, out_cap >= 0 ? (unsigned long long)out_cap : ~0ULL);
-    hipLaunchKernelGGL(k_rows_sort, dim3((unsigned)std::min(4096, (rows + 15) / 16)), dim3(256), 0, stream, d_out, row_ptr, rows,
+    // (a shard without rows -- a rank behind the last sample -- still gets a valid grid)
+    hipLaunchKernelGGL(k_rows_sort, dim3((unsigned)std::max(1, std::min(4096, (rows + 15) / 16))), dim3(256), 0, stream, d_out, row_ptr, rows,
                        out_cap >= 0 ? (unsigned long long)out_cap : ~0ULL);
     return 0;
 }

@@ -429,6 +429,10 @@ class ShardedComparison:
         self._raw = self._own = self._xbuf = self._d_own = None
         self._d_own_rows = 0
         self._cap_f = 1 << 14
+        # capacities of a step that was given no output buffer, as functions of the shard's rows (tests shrink them): the
+        # shard itself, and what the rank's blocks may produce per direction (None: as the shard)
+        self.own_capacity_default = lambda rows: max(1 << 16, 64 * max(rows, 1))
+        self.raw_capacity_default = None
         self._sort_ahead = False         # the previous step's shard had no row beyond 64 cells and fitted its buffers
         self._step = None
         self._ev = None
@@ -618,18 +622,25 @@ class ShardedComparison:
                 "overlap": "none" if world == 1 else
                            "diagonal block beside the exchange; peers' blocks per arrived chunk of coarse rows" +
                            ("; exchange of a part beside the projection of the next" if st["parts"] > 1 else "")}
-        cap = cells_out.shape[0] if cells_out is not None else max(1 << 16, 64 * max(re - rb, 1))
+        # two capacities: cap_own = what this rank's shard may hold (the caller's buffer, if given), cap_raw = what its blocks
+        # may produce per direction (own cells + as many mirror images).  They grow for different reasons: a raw list that
+        # overflowed is a COLLECTIVE matter (that rank compares again, everybody exchanges again -- every rank reads it in the
+        # headers), a shard that overflowed is a LOCAL one (the kept cells are still in the raw list, the other ranks' mirror
+        # images still in the exchange buffer: route + collect again into a larger buffer, no collective).
+        cap_own = cells_out.shape[0] if cells_out is not None else int(self.own_capacity_default(re - rb))
+        cap_raw = cap_own if (cells_out is not None or self.raw_capacity_default is None) else int(self.raw_capacity_default(re - rb))
         plan = block_plan(world, rank, P, symmetric=self.symmetric)
         mirror = self.symmetric and world > 1
         status, err, d_cnt = 0, None, None
-        need_compute = True
-        for attempt in range(5):
-            # raw: what this rank's blocks produce -- its own cells AND the mirror images on their way to other ranks
-            want_raw = (2 if mirror else 1) * cap + 1024
-            if self._raw is None or self._raw.shape[0] < want_raw:
+        need_compute, local_only = True, False
+        for attempt in range(8):
+            # raw: what this rank's blocks produce -- its own cells AND the mirror images on their way to other ranks.  The
+            # buffer is only ever replaced in front of a comparison: between a plan and the routing of its cells it IS the result
+            want_raw = (2 if mirror else 1) * cap_raw + 1024
+            if need_compute and (self._raw is None or self._raw.shape[0] < want_raw):
                 self._raw = ops.new_cells(want_raw)
-            if self._own is None or self._own.shape[0] < cap:
-                self._own = ops.new_cells(cap)
+            if self._own is None or self._own.shape[0] < cap_own:
+                self._own = ops.new_cells(cap_own)
             if self._d_own is None or self._d_own_rows < re - rb:
                 self._d_own, self._d_own_rows = ops.new_counter(re - rb), re - rb
             if need_compute and status == 0:
@@ -642,6 +653,8 @@ class ShardedComparison:
             cap_f = self._cap_f if mirror else 0
             stride = _capi.CELLS_HEADER_BYTES + 16 * cap_f
             if self._xbuf is None or self._xbuf.shape[0] < world * stride:
+                if local_only:
+                    raise RuntimeError("internal: the exchange buffer of a local repeat must be the one the peers' cells are in")
                 self._xbuf = ops.new_bytes(world * stride)
             xb = self._xbuf[:world * stride]
             send = xb[rank * stride:(rank + 1) * stride]
@@ -649,7 +662,8 @@ class ShardedComparison:
                             self._d_own, send, cap_f, status, st["max_abs"])
             self._trace("cells routed")
             if world > 1:
-                self.coll.submit(lambda: self.coll.allgather_blocks(xb, stride)).wait()
+                if not local_only:                # (a local repeat rewrote this rank's own block with the same cells)
+                    self.coll.submit(lambda: self.coll.allgather_blocks(xb, stride)).wait()
                 if mirror:
                     ops.cells_collect(xb, world, rank, cap_f, (rb, re), self._own, self._d_own)
             # the sort, queued in front of the step's host synchronisation when the previous step says the row buckets will do:
@@ -659,6 +673,7 @@ class ShardedComparison:
                 ops.sort_cells_ahead(self._own, cells_out, (rb, re), self._d_own)
                 self._trace("cells sorted")
             n_out, heads, max_row = ops.cells_report(xb, world, cap_f, (rb, re), self._d_own)   # the step's host synchronisation
+            local_only = False
             worst = max(int(h[1]) for h in heads)
             if worst:
                 raise err if err is not None else _capi.MvsError(worst, "another rank failed in its block comparisons")
@@ -687,24 +702,31 @@ class ShardedComparison:
                 need_compute = int(heads[rank][3]) >= _capi.PLAN_STALE
                 info["plan_respeculated"] = info.get("plan_respeculated", 0) + 1
                 continue
+            # ---- decisions every rank takes alike: they read nothing but the exchanged headers ----
             redo = False
             mine = heads[rank]
             need_compute = int(mine[3]) > int(mine[4])      # this rank's raw list overflowed: its blocks again, with room
             if any(int(h[3]) > int(h[4]) for h in heads):   # ... and the others exchange again with it
                 redo = True
                 if need_compute:
-                    cap = max(cap, int(mine[3]) // (2 if mirror else 1) + 1)
+                    cap_raw = max(cap_raw, int(mine[3]) // (2 if mirror else 1) + 1)
             if mirror and max(int(h[0]) for h in heads) > cap_f:
                 self._cap_f = max(int(h[0]) for h in heads) * 5 // 4 + 1024
                 redo = True
+            if redo:
+                if cells_out is None and n_out > cap_own:   # (a lower bound while lists overflow: the repeat will tell)
+                    cap_own = n_out + n_out // 4
+                continue
+            # ---- this rank's own business: its shard did not fit.  No other rank knows, and none needs to ----
             if n_out > self._own.shape[0]:
                 if cells_out is not None:
                     raise _capi.MvsError(_capi.MVS_E_CAPACITY, "%d cells for this shard but capacity is %d" %
                                          (n_out, cells_out.shape[0]), needed=n_out)
-                cap = n_out + n_out // 4
-                redo = True
-            if not redo:
-                break
+                cap_own = n_out + n_out // 4
+                need_compute, local_only = False, True
+                info["own_regrown"] = info.get("own_regrown", 0) + 1
+                continue
+            break
         else:
             raise _capi.MvsError(_capi.MVS_E_CAPACITY, "the step's buffers kept overflowing")
         if cells_out is not None and n_out > cells_out.shape[0]:

@@ -430,6 +430,21 @@ def _worker(rank, world, port, n, d, out_dir):
         with pytest.raises(_capi.MvsError) as ei:
             sc_tight.run(sk[b:e], n2[b:e], n, cells_out=torch.empty((cnt - 1, 4), dtype=torch.int32))
         assert ei.value.code == _capi.MVS_E_CAPACITY and ei.value.needed == cnt
+    # no output buffer, and ONE rank's default shard capacity is too small while its raw list fits: that rank
+    # routes and collects again into a larger buffer on its own -- the kept cells are still in the raw list, the peers'
+    # mirror images still in the exchange buffer -- and no peer takes part (a collective repeat only one rank knows about would
+    # hang); with every capacity too small on one rank the collective regrowth and the local one follow each other
+    for raw_small in (False, True):
+        ops_o = OracleOps()
+        sc_o = parallel.ShardedComparison(ops_o, rank, world, dist)
+        if rank == world - 1:
+            sc_o.own_capacity_default = lambda rows: 3
+        sc_o.raw_capacity_default = (lambda rows: 3) if (raw_small and rank == world - 1) else (lambda rows: n * n)
+        cells_o, cnt_o, info_o = sc_o.run(sk[b:e], n2[b:e], n)
+        assert cnt_o == cnt and np.array_equal(cells_o, cells), (rank, cnt_o, cnt, info_o)
+        assert info_o.get("own_regrown", 0) == (1 if (rank == world - 1 and cnt > 3) else 0), info_o
+        # (the raw list keeps 1024 cells of slack: whether it overflows as well depends on the shard)
+        assert ops_o.log.count("finish") in ((1, 2) if (raw_small and rank == world - 1) else (1,)), ops_o.log
     # a second, larger problem: other geometry, other buffers
     n_big = n + 3
     sk2, n22 = _make(n_big, d, seed=99)
@@ -506,6 +521,15 @@ def test_single_rank_goes_through_the_same_step():
     want = orc.pairwise_rows(sk, n2, chunk=192)
     want = want[np.lexsort((want["col"], want["row"]))]
     assert cnt == len(want) and np.array_equal(cells, want) and info["collectives"] == "none"
+    # a default shard capacity that is too small while the raw list fits: the raw buffer -- which holds the plan's kept cells --
+    # must survive the regrowth of the shard buffer (it was replaced by an uninitialised one without a new comparison)
+    for own_cap in (5, cnt - 1):
+        ops = OracleOps()
+        sc2 = parallel.ShardedComparison(ops, 0, 1)
+        sc2.own_capacity_default = lambda rows, c=own_cap: c
+        sc2.raw_capacity_default = lambda rows: cnt
+        cells2, cnt2, info2 = sc2.run(sk, n2, n)
+        assert cnt2 == cnt and np.array_equal(cells2, want) and info2["own_regrown"] == 1 and ops.log.count("finish") == 1
 
 
 def test_shard_rows_matches_reference_formula():
