@@ -48,7 +48,9 @@ def disassemble(path, is_dis=False):
     out = []
     with tempfile.TemporaryDirectory() as tmp:
         fat = os.path.join(tmp, "fat.bin")
-        run([os.path.join(LLVM, "llvm-objcopy"), "--dump-section", ".hip_fatbin=" + fat, path])
+        # (with an explicit output file: objcopy otherwise rewrites its INPUT in place -- the library that ships came out with
+        # a fresh mtime and `make -q` saw every host tool stale against it)
+        run([os.path.join(LLVM, "llvm-objcopy"), "--dump-section", ".hip_fatbin=" + fat, path, os.path.join(tmp, "copy.so")])
         blob = open(fat, "rb").read()
         starts = [m.start() for m in re.finditer(re.escape(MAGIC), blob)]
         if not starts:

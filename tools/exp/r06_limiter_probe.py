@@ -26,14 +26,15 @@ cells = torch.empty((max(1 << 22, 64 * n), 4), dtype=torch.int32, device="cuda")
 CMDS = {
     "rocm-smi": ["rocm-smi", "--showpower", "--showclocks", "--showtemp", "--showperflevel", "--showvoltage", "--showmaxpower",
                  "--showuse", "--json"],
-    "amd-smi-metric": ["amd-smi", "metric", "-g", "0", "--json"],
+    "amd-smi-metric": ["amd-smi", "metric", "-g", "0", "--power", "--clock", "--temperature", "--json"],
+    "amd-smi-throttle": ["amd-smi", "metric", "-g", "0", "--throttle", "--json"],
 }
 
 
 def run_cmd(cmd):
     try:
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=30)
-        return (r.stdout.strip() or r.stderr.strip())[:20000]
+        return (r.stdout.strip() or r.stderr.strip())[:60000]
     except Exception as e:   # noqa: BLE001
         return "%s failed: %s" % (cmd[0], e)
 
