@@ -147,6 +147,31 @@ int mvs_ctx_pairwise_candidates(mvs_ctx* ctx, int64_t* candidates);
  * falling off a cliff between "sparse" and "dense").  Any pointer may be NULL. */
 int mvs_ctx_pairwise_stats(mvs_ctx* ctx, int64_t* candidates, int64_t* flagged_tiles, int64_t* filter_tiles);
 
+/* ---- device memory and events for hosts above the ABI -------------------------------------------------
+ * The host drivers are plain C++ above this header (no HIP runtime of their own): the buffers a multi-rank step keeps between
+ * its calls (limb planes, coarse plane, statistics, kept cells -- INTEGRATION.md B5) and the ordering between the context
+ * that compares and the context the communicator exchanges on come from here.  Replaces nothing of the reference by
+ * itself: its tiles live in Eigen matrices on the host (src/pairwise_comp_optimized.cpp:33-54).
+ * mvs_device_alloc : bytes of HBM on the context's device (zero != 0: cleared, on the context's stream).
+ * mvs_device_free  : waits for the context's stream first.
+ * mvs_device_zero  : asynchronous on the context's stream.
+ * mvs_device_copy  : dst / src each MVS_MEM_HOST or MVS_MEM_DEVICE; device-to-device copies are asynchronous on the
+ *                    context's stream, copies that touch host memory return when the host buffer may be reused / read.
+ * Events order two contexts of one device without the host waiting: mvs_event_record puts the event on the context's
+ * stream, mvs_ctx_wait_event makes everything queued LATER on a context's stream wait for it (an event that was never
+ * recorded counts as complete).  timing != 0 at creation: mvs_event_elapsed_ms between two recorded events. */
+typedef struct mvs_event mvs_event;
+int mvs_device_alloc(mvs_ctx* ctx, size_t bytes, int zero, void** ptr);
+int mvs_device_free(mvs_ctx* ctx, void* ptr);
+int mvs_device_zero(mvs_ctx* ctx, void* ptr, size_t bytes);
+int mvs_device_copy(mvs_ctx* ctx, void* dst, int mem_dst, const void* src, int mem_src, size_t bytes);
+int mvs_event_create(mvs_ctx* ctx, int timing, mvs_event** event);
+int mvs_event_record(mvs_ctx* ctx, mvs_event* event);
+int mvs_ctx_wait_event(mvs_ctx* ctx, mvs_event* event);
+int mvs_event_synchronize(mvs_event* event);
+int mvs_event_elapsed_ms(mvs_event* begin, mvs_event* end, float* ms);
+int mvs_event_destroy(mvs_event* event);
+
 /* ---- projection ----------------------------------------------------------------------------------
  * Replaces transform_set_into_vector() (src/random_projection.cpp:9-26) called once per sample from
  * the OpenMP loop of sketch() (src/project_everything.cpp:289-298) and from standalone_projection
@@ -428,6 +453,10 @@ int mvs_sketch_set_recode_rows(mvs_ctx* ctx, mvs_sketch_set* set, const void* sk
 #define MVS_WIRE_RADIX_MAX 252
 #define MVS_WIRE_MAX_ABS 32004
 int mvs_sketch_set_planes_from_wire(mvs_ctx* ctx, mvs_sketch_set* set, const int8_t* lo_wire, int64_t row_first, int64_t row_count);
+/* The sender's side of that exchange: the LOW limbs of rows [row_first, row_first + row_count) of a two-limb set's planes into
+ * lo_wire[row * d_pad + k] (DEVICE, indexed like the set's rows) -- a rank calls it for its own row block before the all-gather
+ * of the wire buffer.  Asynchronous. */
+int mvs_sketch_set_wire_rows(mvs_ctx* ctx, const mvs_sketch_set* set, int8_t* lo_wire, int64_t row_first, int64_t row_count);
 /* The same for a plan, ROW BY ROW AS NEEDED: after mvs_plan_wire, mvs_plan_finish rebuilds -- between gathering the candidates
  * and the re-check -- exactly the rows outside the frame that its second half reads (the columns of the candidates and of the
  * flagged tiles; lo_wire as above, valid until the plan has finished).  A plan whose filter leaves few candidates touches few
@@ -487,6 +516,18 @@ int mvs_cells_sort_rows(mvs_ctx* ctx, const mvs_cell* cells_in, int64_t n, int64
 int mvs_cells_sort_rows_ahead(mvs_ctx* ctx, const mvs_cell* cells_in, int64_t in_capacity, int64_t own_begin, int64_t own_end,
                               const uint64_t* d_own_count, mvs_cell* cells_out, int64_t out_capacity);
 #define MVS_CELLS_HEADER_BYTES 64
+
+/* A shard's kept cells -> the writer.  `cells` (DEVICE) holds n_cells cells ordered by (row, col) -- what a step leaves behind
+ * (mvs_cells_sort_rows / mvs_cells_sort) --, rows [row_begin, row_end) of them are delivered exactly as mvs_pairwise_stream /
+ * mvs_pairwise_stream_encoded deliver their result: CSR pieces of whole rows in ascending order, or the rows' finished shard
+ * records, through the same callbacks under the same rules (pinned buffers of the library, a worker thread, a non-zero return
+ * aborts).  A process that owns several shards (src/pairwise_comp_optimized.cpp:937-940: one row range each) compares the union
+ * of their rows ONCE and calls this per shard folder with that shard's row range; cells outside the range are skipped.
+ * *n_delivered (optional): the cells handed over.  Synchronous.  Writer loop replaced: src/pairwise_comp_optimized.cpp:700-790. */
+int mvs_cells_stream(mvs_ctx* ctx, const mvs_cell* cells, int64_t n_cells, int64_t row_begin, int64_t row_end,
+                     mvs_row_block_cb cb, void* user, int64_t* n_delivered);
+int mvs_cells_stream_encoded(mvs_ctx* ctx, const mvs_cell* cells, int64_t n_cells, int64_t row_begin, int64_t row_end,
+                             mvs_encoded_rows_cb cb, void* user, int64_t* n_delivered);
 
 /* Sort n cells by (row, col) from one DEVICE buffer into another (asynchronous on the context's stream). */
 int mvs_cells_sort(mvs_ctx* ctx, const mvs_cell* cells_in, int64_t n, mvs_cell* cells_out);

@@ -129,6 +129,19 @@ SYMBOLS = [
     ("mvs_cells_report", _c.c_int, [_P, _P, _c.c_int, _c.c_int64, _c.c_int64, _P, _c.POINTER(_c.c_int64)]),
     ("mvs_cells_sort_rows", _c.c_int, [_P, _P, _c.c_int64, _c.c_int64, _c.c_int64, _P, _P]),
     ("mvs_cells_sort_rows_ahead", _c.c_int, [_P, _P, _c.c_int64, _c.c_int64, _c.c_int64, _P, _P, _c.c_int64]),
+    ("mvs_sketch_set_wire_rows", _c.c_int, [_P, _P, _P, _c.c_int64, _c.c_int64]),
+    ("mvs_device_alloc", _c.c_int, [_P, _c.c_size_t, _c.c_int, _c.POINTER(_P)]),
+    ("mvs_device_free", _c.c_int, [_P, _P]),
+    ("mvs_device_zero", _c.c_int, [_P, _P, _c.c_size_t]),
+    ("mvs_device_copy", _c.c_int, [_P, _P, _c.c_int, _P, _c.c_int, _c.c_size_t]),
+    ("mvs_event_create", _c.c_int, [_P, _c.c_int, _c.POINTER(_P)]),
+    ("mvs_event_record", _c.c_int, [_P, _P]),
+    ("mvs_ctx_wait_event", _c.c_int, [_P, _P]),
+    ("mvs_event_synchronize", _c.c_int, [_P]),
+    ("mvs_event_elapsed_ms", _c.c_int, [_P, _P, _c.POINTER(_c.c_float)]),
+    ("mvs_event_destroy", _c.c_int, [_P]),
+    ("mvs_cells_stream", _c.c_int, [_P, _P, _c.c_int64, _c.c_int64, _c.c_int64, ROW_BLOCK_CB, _P, _c.POINTER(_c.c_int64)]),
+    ("mvs_cells_stream_encoded", _c.c_int, [_P, _P, _c.c_int64, _c.c_int64, _c.c_int64, ENCODED_ROWS_CB, _P, _c.POINTER(_c.c_int64)]),
     ("mvs_chunk_size", _c.c_int64, [_c.c_double, _c.c_int]),
     ("mvs_shard_rows", None, [_c.c_int64, _c.c_int, _c.c_int, _c.POINTER(_c.c_int64), _c.POINTER(_c.c_int64)]),
 ]

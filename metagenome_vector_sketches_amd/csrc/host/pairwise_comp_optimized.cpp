@@ -6,12 +6,17 @@
 //                           --num_shards S --shard_idx k [--start_shard a] [--end_shard b] [--help]
 //   (extension: --shard_idx -1 computes ALL S shards from this one process on all visible GPUs)
 //
-// Multi-GPU: the reference runs one process per shard and every process re-reads the whole vectors.bin
-// (src/pairwise_comp_optimized.cpp:953,962).  Started the same way -- one process per shard, --shard_idx k on GPU
-// k % device_count -- with MVS_COLLECTIVE=rccl in the environment, every process loads only the rows of ITS shard,
-// re-codes them into its row block of the plane buffer and one RCCL all-gather (mvs_allgather_planes) gives every
-// GPU all columns; the processes find each other through <output_folder>/.mvs_comm_<MVS_COLLECTIVE_TOKEN>.
-// MVS_COLLECTIVE=files does the exchange through files in the output folder instead (ranks sharing one GPU).
+// Multi-GPU: the reference runs one process per shard and every process re-reads the whole vectors.bin and compares
+// its rows against ALL columns (src/pairwise_comp_optimized.cpp:937-982).  Started the same way -- one process per shard,
+// --shard_idx k on GPU k % device_count -- with MVS_COLLECTIVE=rccl in the environment, the shard processes run ONE
+// strong-scaled step between them (mvs_step.hpp: ShardStep): every process loads only the rows of ITS shard, the filter's
+// inputs and the low limbs travel over RCCL beside the comparison, every unordered pair of row blocks is compared by
+// exactly one process and the mirrored cells are exchanged; the processes find each other through
+// <output_folder>/.mvs_comm_<MVS_COLLECTIVE_TOKEN>.  MVS_COLLECTIVE=files does the exchange through files in the output
+// folder instead (ranks sharing one GPU).  --shard_idx -1 runs the same step from ONE process: a host thread + device
+// context per GPU, each rank owning --num_shards / G consecutive shards whose rows it compares once, as one block.
+// MVS_STEP=0 keeps the round-1 scheme (limb planes gathered whole, rows x all columns per shard); a result too dense for
+// cell lists falls back to it by itself (every rank reads that in the exchanged headers).
 //
 // Differences a user can observe (all listed in DESIGN.md): tiles are sized by the kernel, not by
 // --max_memory_gb (the "Using chunks of size" line still prints the reference's formula; the flag bounds
@@ -23,6 +28,7 @@
 #include <memory>
 
 #include "mvs_host.hpp"
+#include "mvs_step.hpp"
 
 namespace fs = std::filesystem;
 using namespace mvs_host;
@@ -168,9 +174,11 @@ static int load_db(Gpu& g, const std::string& matrix_file, int elem_bytes, int64
 // Rendezvous of the shard processes of one job: they meet under <output_folder>/.mvs_comm_<token> through the
 // library's file handshake (a job nonce all ranks agree on; files an earlier job left there are never taken for this
 // job's), and with MVS_COLLECTIVE=rccl rank 0's RCCL id travels as one verified block of that transport.
-static int open_communicator(Gpu& g, const std::string& kind, const std::string& output_folder, int rank, int world) {
+static std::string comm_base_path(const std::string& output_folder, const std::string& fallback_token) {
     const char* tok = getenv("MVS_COLLECTIVE_TOKEN");
-    const std::string base = output_folder + ".mvs_comm_" + (tok ? tok : "job");
+    return output_folder + ".mvs_comm_" + (tok ? std::string(tok) : fallback_token);
+}
+static int open_communicator(Gpu& g, const std::string& kind, const std::string& base, int rank, int world) {
     if (kind == "files") {
         if (mvs_comm_create_files(g.ctx, base.c_str(), rank, world, &g.comm) != MVS_OK) return gpu_fail("file communicator");
         return 0;
@@ -296,6 +304,37 @@ static int compare_rows(Gpu& g, const std::vector<double>& n2, int keep_mode, in
     return 0;
 }
 
+// what the streamed pieces -- of a comparison (mvs_pairwise_stream*) or of a step's sorted cells (mvs_cells_stream*) -- go into
+struct ShardSink {
+    ShardWriter writer;
+    std::string error;
+    explicit ShardSink(const std::string& folder) : writer(folder) {}
+    static int on_block(void* user, const mvs_row_block* b) {
+        ShardSink* self = static_cast<ShardSink*>(user);
+        try {
+            self->writer.add(*b);
+            return 0;
+        } catch (const std::exception& e) {
+            self->error = e.what();
+            return 1;
+        }
+    }
+    static int on_encoded(void* user, const mvs_encoded_rows* b) {
+        ShardSink* self = static_cast<ShardSink*>(user);
+        try {
+            self->writer.add_encoded(*b);
+            return 0;
+        } catch (const std::exception& e) {
+            self->error = e.what();
+            return 1;
+        }
+    }
+};
+static bool host_encoder_wanted() {
+    const char* enc = getenv("MVS_SHARD_ENCODER");
+    return enc && std::string(enc) == "host";
+}
+
 // One shard: rows [begin_row, end_row) against all columns, streamed into <shard_folder>.  The comparison hands over CSR
 // pieces of whole rows (ascending) -- by default with the rows already encoded in the shard codec ON THE DEVICE (1.4 bytes
 // per kept cell on the link instead of 5, no host thread touches a cell); MVS_SHARD_ENCODER=host takes (column, q) pieces
@@ -304,37 +343,13 @@ static int compare_rows(Gpu& g, const std::vector<double>& n2, int keep_mode, in
 static int stream_shard(Gpu& g, const std::vector<double>& norms_sq, int keep_mode, int64_t begin_row, int64_t end_row,
                         const std::string& shard_folder, bool stage_timing, int64_t* n_kept, ShardStats* stats,
                         const std::function<void(const char*)>& lap) {
-    struct Sink {
-        ShardWriter writer;
-        std::string error;
-        static int on_block(void* user, const mvs_row_block* b) {
-            Sink* self = static_cast<Sink*>(user);
-            try {
-                self->writer.add(*b);
-                return 0;
-            } catch (const std::exception& e) {
-                self->error = e.what();
-                return 1;
-            }
-        }
-        static int on_encoded(void* user, const mvs_encoded_rows* b) {
-            Sink* self = static_cast<Sink*>(user);
-            try {
-                self->writer.add_encoded(*b);
-                return 0;
-            } catch (const std::exception& e) {
-                self->error = e.what();
-                return 1;
-            }
-        }
-    } sink{ShardWriter(shard_folder), std::string()};
-    const char* enc = getenv("MVS_SHARD_ENCODER");
-    const bool host_encoder = enc && std::string(enc) == "host";
+    ShardSink sink(shard_folder);
+    const bool host_encoder = host_encoder_wanted();
     const int stream_rc =
         host_encoder ? mvs_pairwise_stream(g.ctx, g.set, norms_sq.data(), MVS_MEM_HOST, keep_mode, begin_row, end_row, 0,
-                                           &Sink::on_block, &sink, n_kept)
+                                           &ShardSink::on_block, &sink, n_kept)
                      : mvs_pairwise_stream_encoded(g.ctx, g.set, norms_sq.data(), MVS_MEM_HOST, keep_mode, begin_row, end_row, 0,
-                                                   &Sink::on_encoded, &sink, n_kept);
+                                                   &ShardSink::on_encoded, &sink, n_kept);
     if (stream_rc != MVS_OK) {
         if (!sink.error.empty()) std::cerr << "pairwise_comp_optimized: " << sink.error << std::endl;
         return gpu_fail("pairwise comparison");
@@ -359,6 +374,198 @@ static int stream_shard(Gpu& g, const std::vector<double>& norms_sq, int keep_mo
     return 0;
 }
 
+
+// -------------------------------------------------------------------------------------------------------------------
+// the strong-scaled step under the reference's command line (mvs_step.hpp)
+// -------------------------------------------------------------------------------------------------------------------
+// One rank of a job of `world` ranks: it owns shards [shard_begin, shard_end) -- consecutive, the same number on every rank --,
+// loads exactly their rows of vectors.bin, takes part in ONE step and writes its shard folders.
+struct StepRank {
+    int device = 0, rank = 0, world = 1, shard_begin = 0, shard_end = 1;
+};
+struct StepJob {
+    const Options* o = nullptr;
+    std::string output_folder, matrix_file, comm_kind, comm_base;
+    int elem_bytes = 4, dimension = 0, keep_mode = MVS_KEEP_INT32;
+    int64_t total_vectors = 0;
+    const std::vector<double>* norms_sq = nullptr;
+    bool stage_timing = false;
+    std::mutex* out_mu = nullptr;
+};
+
+// rows [b, e) of vectors.bin -> device memory (chunks of the mapping; the file's pages are read once, by this rank only)
+static int upload_rows(mvs_ctx* ctx, const std::string& matrix_file, int elem_bytes, int d, int64_t b, int64_t e, mvs_step::DevMem& out,
+                       int64_t* max_abs) {
+    *max_abs = 0;
+    const int64_t row_bytes = (int64_t)d * elem_bytes;
+    const size_t bytes = (size_t)((e - b) * row_bytes);
+    if (!bytes) return 0;
+    const int fd = ::open(matrix_file.c_str(), O_RDONLY);
+    if (fd < 0) {
+        std::cerr << "Error opening file: " << matrix_file << std::endl;       // :35-38
+        return 1;
+    }
+    const size_t map_off = (size_t)(b * row_bytes) & ~(size_t)4095, map_len = (size_t)(b * row_bytes) - map_off + bytes;
+    void* m = ::mmap(nullptr, map_len, PROT_READ, MAP_PRIVATE, fd, (off_t)map_off);
+    ::close(fd);
+    if (m == MAP_FAILED) {
+        std::cerr << "Error reading file: " << matrix_file << std::endl;
+        return 1;
+    }
+    ::madvise(m, map_len, MADV_SEQUENTIAL);
+    const char* base = (const char*)m + ((size_t)(b * row_bytes) - map_off);
+    int rc = 0;
+    try {
+        out.ensure(ctx, bytes, false);
+        const size_t chunk = (size_t)1 << 28;
+        for (size_t at = 0; at < bytes && !rc; at += chunk)
+            if (mvs_device_copy(ctx, out.as<char>() + at, MVS_MEM_DEVICE, base + at, MVS_MEM_HOST, std::min(chunk, bytes - at)) != MVS_OK)
+                rc = gpu_fail("uploading vectors.bin");
+        if (!rc && mvs_sketch_max_abs(ctx, out.p, elem_bytes, MVS_MEM_DEVICE, (e - b) * (int64_t)d, max_abs) != MVS_OK)
+            rc = gpu_fail("largest |v| of the rank's rows");
+    } catch (const mvs_step::StepError& err) {
+        std::cerr << "pairwise_comp_optimized: " << err.what() << std::endl;
+        rc = 2;
+    }
+    ::munmap(m, map_len);
+    return rc;
+}
+
+// the round-1 scheme for this rank's shards, on the context the communicator lives on: limb planes gathered whole (or the
+// whole file read), rows x all columns per shard through the streamed comparison -- what a dense result needs
+static int legacy_rank(const StepJob& job, const StepRank& r, Gpu& x, bool collective) {
+    int rc = 0;
+    if (collective) {
+        int64_t b = 0, e = 0;
+        mvs_shard_rows(job.total_vectors, job.o->num_shards, r.shard_begin, &b, &e);
+        rc = load_db_collective(x, job.matrix_file, job.elem_bytes, job.total_vectors, job.dimension, b, e, job.o->num_shards);
+    } else {
+        rc = load_db(x, job.matrix_file, job.elem_bytes, job.total_vectors, job.dimension);
+    }
+    for (int shard = r.shard_begin; shard < r.shard_end && !rc; ++shard) {
+        const std::string folder = job.output_folder + "shard_" + std::to_string(shard) + "/";
+        int64_t b = 0, e = 0, kept = 0;
+        mvs_shard_rows(job.total_vectors, job.o->num_shards, shard, &b, &e);
+        ShardStats st;
+        rc = stream_shard(x, *job.norms_sq, job.keep_mode, b, e, folder, job.stage_timing, &kept, &st, [](const char*) {});
+        std::lock_guard<std::mutex> lk(*job.out_mu);
+        if (!rc) std::cout << "Jac space: " << st.jac_space << " ngh space: " << st.ngh_space << std::endl;   // :808
+    }
+    return rc;
+}
+
+static int run_step_rank(const StepJob& job, const StepRank& r) {
+    const Options& o = *job.o;
+    const int64_t N = job.total_vectors;
+    const int64_t rps = (N + o.num_shards - 1) / std::max(1, o.num_shards);                       // :938
+    const int64_t block_rows = (int64_t)(r.shard_end - r.shard_begin) * rps;                      // samples per rank block
+    const auto own = mvs_step::rank_rows(N, block_rows, r.rank);
+    auto t_lap = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        const auto t = std::chrono::steady_clock::now();
+        if (job.stage_timing) {
+            std::lock_guard<std::mutex> lk(*job.out_mu);
+            std::cerr << "[stage] rank " << r.rank << ": " << what << " " << std::chrono::duration<double>(t - t_lap).count() << " s" << std::endl;
+        }
+        t_lap = t;
+    };
+    for (int shard = r.shard_begin; shard < r.shard_end; ++shard) {
+        int64_t b = 0, e = 0;
+        mvs_shard_rows(N, o.num_shards, shard, &b, &e);
+        std::lock_guard<std::mutex> lk(*job.out_mu);
+        std::cout << "Shard " << shard << " processing rows " << b << " to " << e << std::endl;   // :941
+    }
+    Gpu g, x;                       // the comparison's context; the exchange's (its own stream) with the communicator
+    if (mvs_ctx_create(r.device, &g.ctx) != MVS_OK) return gpu_fail("creating context");
+    if (job.stage_timing) mvs_ctx_set_timing(g.ctx, 1);
+    if (r.world > 1) {
+        if (mvs_ctx_create(r.device, &x.ctx) != MVS_OK) return gpu_fail("creating the exchange's context");
+        const int rc = open_communicator(x, job.comm_kind, job.comm_base, r.rank, r.world);
+        if (rc) return rc;
+    }
+    lap(r.world > 1 ? "contexts + communicator" : "context");
+    // own rows; a failure before the first collective is carried into it (agree), not returned
+    mvs_step::DevMem sketches;
+    int64_t max_abs = 0;
+    int rc = upload_rows(g.ctx, job.matrix_file, job.elem_bytes, job.dimension, own.first, own.second, sketches, &max_abs);
+    int64_t max_abs_all = max_abs;
+    if (r.world > 1) rc = agree(x, rc, &max_abs_all);
+    if (rc) return rc;
+    lap("own rows of vectors.bin on the device");
+    bool too_dense = false;
+    try {
+        mvs_step::StepOptions so = mvs_step::StepOptions::from_env();
+        so.timing = job.stage_timing;
+        std::unique_ptr<mvs_step::Exchange> ex;
+        if (r.world > 1) ex.reset(new mvs_step::Exchange(x.ctx, x.comm));
+        mvs_step::ShardStep step(g.ctx, ex.get(), r.rank, r.world, so);
+        step.run(N, block_rows, job.dimension, sketches.p, job.elem_bytes, own.second - own.first, max_abs, job.norms_sq->data(), nullptr,
+                 job.keep_mode, mvs_limbs_for_max_abs(max_abs_all));
+        too_dense = step.info.too_dense;
+        lap("step: own rows re-coded, exchange, block plan, cells routed and sorted");
+        if (job.stage_timing) {
+            const mvs_step::StepInfo& si = step.info;
+            std::lock_guard<std::mutex> lk(*job.out_mu);
+            std::cerr << "[step] rank " << r.rank << "/" << r.world << ": prepare_own_rows_ms " << si.prepare_own_rows_ms << " plan_span_ms "
+                      << si.plan_span_ms << " (filter_ms " << si.filter_ms << " recheck_ms " << si.recheck_ms << " flagged_tiles_ms "
+                      << si.flagged_tiles_ms << "; " << si.filter_launches << " filter launch(es), " << si.filter_tiles << " tiles, "
+                      << si.candidates << " candidates, " << si.flagged_tiles << " flagged tiles) cells_route_exchange_sort_ms "
+                      << si.cells_route_exchange_sort_ms << " | " << step.n_cells() << " cells in this rank's rows, " << si.exchanged_cells
+                      << " mirrored to other ranks, " << si.allgather_bytes_per_rank << " bytes gathered per rank ("
+                      << (si.wire ? "coarse plane + low limbs" : "coarse plane + limb planes") << "), limbs " << si.limbs << ", " << si.blocks
+                      << " block(s), " << si.attempts << " attempt(s)" << (si.note.empty() ? "" : "; ") << si.note << std::endl;
+        }
+        // the rank's sorted cells, shard by shard, through the device encoder into the shard folders
+        for (int shard = r.shard_begin; shard < r.shard_end && !too_dense; ++shard) {
+            const std::string folder = job.output_folder + "shard_" + std::to_string(shard) + "/";
+            int64_t b = 0, e = 0, delivered = 0;
+            mvs_shard_rows(N, o.num_shards, shard, &b, &e);
+            ShardSink sink(folder);
+            const int src = host_encoder_wanted()
+                                ? mvs_cells_stream(g.ctx, step.cells(), step.n_cells(), b, e, &ShardSink::on_block, &sink, &delivered)
+                                : mvs_cells_stream_encoded(g.ctx, step.cells(), step.n_cells(), b, e, &ShardSink::on_encoded, &sink, &delivered);
+            if (src != MVS_OK) {
+                if (!sink.error.empty()) std::cerr << "pairwise_comp_optimized: " << sink.error << std::endl;
+                return gpu_fail("writing a shard's rows");
+            }
+            const ShardStats st = sink.writer.finish();                                           // :990
+            std::lock_guard<std::mutex> lk(*job.out_mu);
+            std::cout << "Jac space: " << st.jac_space << " ngh space: " << st.ngh_space << std::endl;   // :808
+        }
+        if (!too_dense) lap("shard files");
+    } catch (const mvs_step::StepError& e) {
+        std::lock_guard<std::mutex> lk(*job.out_mu);
+        std::cerr << "pairwise_comp_optimized: rank " << r.rank << ": " << e.what() << std::endl;
+        return 2;
+    } catch (const std::exception& e) {
+        std::lock_guard<std::mutex> lk(*job.out_mu);
+        std::cerr << "pairwise_comp_optimized: rank " << r.rank << ": " << e.what() << std::endl;
+        return 2;
+    }
+    if (too_dense) {
+        // every rank read the same headers and is here: the streamed dense path, per shard (the step's buffers are gone)
+        sketches.release();
+        if (job.stage_timing) {
+            std::lock_guard<std::mutex> lk(*job.out_mu);
+            std::cerr << "[step] rank " << r.rank << ": the result is too dense for cell lists: streamed comparison per shard" << std::endl;
+        }
+        const bool per_shard_ranks = r.world > 1 && r.shard_end - r.shard_begin == 1 && r.world == o.num_shards;
+        rc = legacy_rank(job, r, r.world > 1 ? x : g, per_shard_ranks);
+        if (rc) return rc;
+        lap("streamed comparison + shard files");
+    }
+    return 0;
+}
+
+// how many ranks a single process splits --num_shards over: the largest divisor of the shard count that the contexts allow
+// (every rank owns the same number of consecutive shards: the blocks of the exchange have one size)
+static int step_world(int num_shards, int contexts) {
+    int w = 1;
+    for (int k = 1; k <= std::min(num_shards, contexts); ++k)
+        if (num_shards % k == 0) w = k;
+    return w;
+}
+
 // --shard_idx -1 (an extension: the reference needs one process per shard): ALL shards from this one process, on all
 // visible GPUs -- one device context and host thread per GPU, the whole vectors.bin resident on each (what each of the
 // reference's shard processes reads too, :953-962), shard s computed by GPU s mod G.  MVS_DEVICE pins the work to one
@@ -377,8 +584,64 @@ static int run_all_shards(const Options& o, const std::string& output_folder, co
             for (int i = 0; i < want; ++i) devices.push_back(i % ndev);
         }
     }
-    const size_t n_ctx = devices.size();
     std::mutex out_mu;
+    const char* step_env = getenv("MVS_STEP");
+    if (!(step_env && step_env[0] == '0')) {
+        // ONE step over all shards: W ranks (a host thread + contexts each), S / W consecutive shards per rank, every
+        // unordered pair of row blocks compared once -- on one card: the whole frame once, where the round-1 scheme below
+        // compares every shard's rows against all columns (S x the filter tiles of the symmetric schedule / 2)
+        const int world = step_world(o.num_shards, (int)devices.size());
+        bool distinct = true;
+        for (int a = 0; a < world; ++a)
+            for (int b = a + 1; b < world; ++b)
+                if (devices[(size_t)a] == devices[(size_t)b]) distinct = false;
+        StepJob job;
+        job.o = &o;
+        job.output_folder = output_folder;
+        job.matrix_file = matrix_file;
+        const char* coll = getenv("MVS_COLLECTIVE");
+        job.comm_kind = (coll && *coll) ? coll : (distinct ? "rccl" : "files");      // (RCCL refuses two ranks on one device)
+        if (job.comm_kind != "rccl" && job.comm_kind != "files") {
+            std::cerr << "pairwise_comp_optimized: MVS_COLLECTIVE must be rccl or files" << std::endl;
+            return 1;
+        }
+        job.comm_base = comm_base_path(output_folder, "p" + std::to_string((long)::getpid()));
+        job.elem_bytes = elem_bytes;
+        job.dimension = dimension;
+        job.keep_mode = keep_mode;
+        job.total_vectors = total_vectors;
+        job.norms_sq = &norms_sq;
+        job.stage_timing = stage_timing;
+        job.out_mu = &out_mu;
+        for (int shard = 0; shard < o.num_shards; ++shard) {
+            const std::string folder = output_folder + "shard_" + std::to_string(shard) + "/";
+            if (!fs::exists(folder)) fs::create_directories(folder);
+        }
+        std::vector<int> status((size_t)world, 0);
+        auto rank_work = [&](int rk) {
+            StepRank r;
+            r.device = devices[(size_t)rk];
+            r.rank = rk;
+            r.world = world;
+            r.shard_begin = rk * (o.num_shards / world);
+            r.shard_end = (rk + 1) * (o.num_shards / world);
+            status[(size_t)rk] = run_step_rank(job, r);
+        };
+        if (world == 1) {
+            rank_work(0);
+        } else {
+            std::vector<std::thread> pool;
+            for (int rk = 0; rk < world; ++rk) pool.emplace_back(rank_work, rk);
+            for (auto& th : pool) th.join();
+        }
+        if (stage_timing)
+            std::cerr << "[stage] " << o.num_shards << " shards in one step of " << world << " rank(s) (" << (world > 1 ? job.comm_kind : "no exchange")
+                      << ")" << std::endl;
+        for (int rc : status)
+            if (rc) return rc;
+        return 0;
+    }
+    const size_t n_ctx = devices.size();
     std::vector<int> status(n_ctx, 0);
     auto work = [&](size_t gi) {
         Gpu g;
@@ -527,7 +790,40 @@ int main(int argc, char* argv[]) {
             std::cerr << "pairwise_comp_optimized: collective mode needs 0 <= shard_idx < num_shards" << std::endl;
             return 1;
         }
-        rc = open_communicator(g, coll, output_folder, o.shard_idx, o.num_shards);
+        const char* step_env = getenv("MVS_STEP");
+        if (!(step_env && step_env[0] == '0') && !(int16 && legacy16_output())) {
+            // the strong-scaled step: this process is rank shard_idx of num_shards (mvs_step.hpp)
+            std::mutex out_mu;
+            StepJob job;
+            job.o = &o;
+            job.output_folder = output_folder;
+            job.matrix_file = matrix_file;
+            job.comm_kind = coll;
+            job.comm_base = comm_base_path(output_folder, "job");
+            job.elem_bytes = elem_bytes;
+            job.dimension = dimension;
+            job.keep_mode = int16 ? MVS_KEEP_INT16 : MVS_KEEP_INT32;
+            job.total_vectors = total_vectors;
+            db.norms_sq.resize((size_t)total_vectors);
+            job.norms_sq = &db.norms_sq;
+            job.stage_timing = stage_timing;
+            job.out_mu = &out_mu;
+            StepRank r;
+            r.device = device;
+            r.rank = o.shard_idx;
+            r.world = o.num_shards;
+            r.shard_begin = o.shard_idx;
+            r.shard_end = o.shard_idx + 1;
+            mvs_ctx_destroy(g.ctx);                  // (the rank creates its own pair of contexts)
+            g.ctx = nullptr;
+            rc = run_step_rank(job, r);
+            if (rc) return rc;
+            auto end_time = std::chrono::high_resolution_clock::now();
+            auto duration = std::chrono::duration_cast<std::chrono::milliseconds>(end_time - start_time);
+            std::cout << "Total computation time: " << duration.count() << " ms" << std::endl;     // :993-996
+            return 0;
+        }
+        rc = open_communicator(g, coll, comm_base_path(output_folder, "job"), o.shard_idx, o.num_shards);
         if (rc) return rc;
         lap("communicator");
         rc = load_db_collective(g, matrix_file, elem_bytes, total_vectors, dimension, begin_row, end_row, o.num_shards);

@@ -472,4 +472,124 @@ int mvs_ctx_kernel_ms(mvs_ctx* c, int which, float* ms) {
     return MVS_OK;
 }
 
+
+// -------------------------------------------------------------------------------------------------
+// device memory and events for hosts above the ABI (csrc/host/mvs_step.hpp)
+// -------------------------------------------------------------------------------------------------
+struct mvs_event {
+    int device = 0;
+    hipEvent_t ev = nullptr;
+    bool timing = false, recorded = false;
+};
+
+int mvs_device_alloc(mvs_ctx* c, size_t bytes, int zero, void** ptr) {
+    if (!c || !ptr) return fail(MVS_E_INVALID, "NULL argument");
+    *ptr = nullptr;
+    HIP_TRY(hipSetDevice(c->device));
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) return fail(MVS_E_NOMEM, "hipMalloc of %zu bytes failed", bytes);
+    if (zero && bytes) {
+        const hipError_t e = hipMemsetAsync(p, 0, bytes, c->stream);
+        if (e != hipSuccess) {
+            (void)hipFree(p);
+            return fail(MVS_E_HIP, "hipMemsetAsync: %s", hipGetErrorString(e));
+        }
+    }
+    *ptr = p;
+    return MVS_OK;
+}
+
+int mvs_device_free(mvs_ctx* c, void* ptr) {
+    if (!c) return fail(MVS_E_INVALID, "ctx is NULL");
+    if (!ptr) return MVS_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipFree(ptr));
+    return MVS_OK;
+}
+
+int mvs_device_zero(mvs_ctx* c, void* ptr, size_t bytes) {
+    if (!c || (!ptr && bytes)) return fail(MVS_E_INVALID, "NULL argument");
+    if (bytes == 0) return MVS_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemsetAsync(ptr, 0, bytes, c->stream));
+    return MVS_OK;
+}
+
+int mvs_device_copy(mvs_ctx* c, void* dst, int mem_dst, const void* src, int mem_src, size_t bytes) {
+    if (!c || !mem_ok(mem_dst) || !mem_ok(mem_src)) return fail(MVS_E_INVALID, "bad argument");
+    if (bytes == 0) return MVS_OK;
+    if (!dst || !src) return fail(MVS_E_INVALID, "NULL buffer");
+    HIP_TRY(hipSetDevice(c->device));
+    if (mem_dst == MVS_MEM_HOST && mem_src == MVS_MEM_HOST) {
+        memcpy(dst, src, bytes);
+        return MVS_OK;
+    }
+    const hipMemcpyKind kind = mem_dst == MVS_MEM_DEVICE ? (mem_src == MVS_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice)
+                                                         : hipMemcpyDeviceToHost;
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, kind, c->stream));
+    if (kind != hipMemcpyDeviceToDevice) HIP_TRY(hipStreamSynchronize(c->stream));
+    return MVS_OK;
+}
+
+int mvs_event_create(mvs_ctx* c, int timing, mvs_event** out) {
+    if (!c || !out) return fail(MVS_E_INVALID, "NULL argument");
+    *out = nullptr;
+    HIP_TRY(hipSetDevice(c->device));
+    mvs_event* e = new (std::nothrow) mvs_event();
+    if (!e) return fail(MVS_E_NOMEM, "out of host memory");
+    e->device = c->device;
+    e->timing = timing != 0;
+    const hipError_t rc = hipEventCreateWithFlags(&e->ev, timing ? hipEventDefault : hipEventDisableTiming);
+    if (rc != hipSuccess) {
+        delete e;
+        return fail(MVS_E_HIP, "hipEventCreate: %s", hipGetErrorString(rc));
+    }
+    *out = e;
+    return MVS_OK;
+}
+
+int mvs_event_record(mvs_ctx* c, mvs_event* e) {
+    if (!c || !e) return fail(MVS_E_INVALID, "NULL argument");
+    if (c->device != e->device) return fail(MVS_E_INVALID, "the event belongs to device %d, the context to device %d", e->device, c->device);
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipEventRecord(e->ev, c->stream));
+    e->recorded = true;
+    return MVS_OK;
+}
+
+int mvs_ctx_wait_event(mvs_ctx* c, mvs_event* e) {
+    if (!c || !e) return fail(MVS_E_INVALID, "NULL argument");
+    if (!e->recorded) return MVS_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamWaitEvent(c->stream, e->ev, 0));
+    return MVS_OK;
+}
+
+int mvs_event_synchronize(mvs_event* e) {
+    if (!e) return fail(MVS_E_INVALID, "event is NULL");
+    if (!e->recorded) return MVS_OK;
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipEventSynchronize(e->ev));
+    return MVS_OK;
+}
+
+int mvs_event_elapsed_ms(mvs_event* b, mvs_event* e, float* ms) {
+    if (!b || !e || !ms) return fail(MVS_E_INVALID, "NULL argument");
+    *ms = 0.0f;
+    if (!b->timing || !e->timing || !b->recorded || !e->recorded) return fail(MVS_E_INVALID, "both events must have been created with timing and recorded");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipEventSynchronize(e->ev));
+    HIP_TRY(hipEventElapsedTime(ms, b->ev, e->ev));
+    return MVS_OK;
+}
+
+int mvs_event_destroy(mvs_event* e) {
+    if (!e) return MVS_OK;
+    (void)hipSetDevice(e->device);
+    if (e->ev) (void)hipEventDestroy(e->ev);
+    delete e;
+    return MVS_OK;
+}
+
 }  // extern "C"

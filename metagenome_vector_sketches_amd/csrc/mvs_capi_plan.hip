@@ -277,6 +277,36 @@ int mvs_sketch_set_recode_rows(mvs_ctx* c, mvs_sketch_set* s, const void* sketch
     return mvs_sketch_set_prepare_rows(c, s, row_first, row_count);
 }
 
+}  // extern "C"
+
+namespace mvs_capi {
+// planes[(row * 2 + 0) * d_pad + k] -> lo_wire[row * d_pad + k], 16 bytes per lane
+__global__ void k_wire_rows(const int4* __restrict__ planes, int4* __restrict__ lo, long long row_first, long long rows, int vec_per_row) {
+    const long long total = rows * vec_per_row;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long r = row_first + i / vec_per_row;
+        const int v = (int)(i % vec_per_row);
+        lo[r * vec_per_row + v] = planes[r * 2 * vec_per_row + v];
+    }
+}
+}  // namespace mvs_capi
+
+extern "C" {
+
+int mvs_sketch_set_wire_rows(mvs_ctx* c, const mvs_sketch_set* s, int8_t* lo_wire, int64_t row_first, int64_t row_count) {
+    if (!c || !s || !lo_wire) return fail(MVS_E_INVALID, "NULL argument");
+    if (s->limbs != 2) return fail(MVS_E_INVALID, "the low-limb wire format is defined for two-limb sets");
+    if (row_first < 0 || row_count < 0 || row_first + row_count > s->n_alloc) return fail(MVS_E_INVALID, "rows outside the set");
+    if (row_count == 0) return MVS_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    const int vec = s->d_pad / 16;
+    const long long total = (long long)row_count * vec;
+    const unsigned blocks = (unsigned)std::min<long long>(4096, (total + 255) / 256);
+    hipLaunchKernelGGL(k_wire_rows, dim3(blocks), dim3(256), 0, c->stream, reinterpret_cast<const int4*>(s->planes),
+                       reinterpret_cast<int4*>(lo_wire), (long long)row_first, (long long)row_count, vec);
+    return check_kernel("k_wire_rows");
+}
+
 int mvs_sketch_set_planes_from_wire(mvs_ctx* c, mvs_sketch_set* s, const int8_t* lo_wire, int64_t row_first, int64_t row_count) {
     if (!c || !s) return fail(MVS_E_INVALID, "NULL argument");
     if (row_first < 0 || row_count < 0 || row_first + row_count > s->n_alloc || (row_first & 15) || (row_count & 15))

@@ -1127,3 +1127,102 @@ int mvs_ctx_stream_stats(const mvs_ctx* c, double* kernel_ms, int64_t* bytes_out
 
 
 }  // extern "C"
+
+// -------------------------------------------------------------------------------------------------
+// a shard's sorted cell list -> the same pieces (mvs_cells_stream / mvs_cells_stream_encoded)
+// -------------------------------------------------------------------------------------------------
+namespace mvs_capi {
+int cells_stream_impl(mvs_ctx* c, const mvs_cell* cells, int64_t n, int64_t rb, int64_t re, mvs_row_block_cb cb, mvs_encoded_rows_cb ecb,
+                      void* user, int64_t* n_delivered) {
+    if (!c || (!cb && !ecb)) return fail(MVS_E_INVALID, "NULL argument");
+    if (n_delivered) *n_delivered = 0;
+    if (n < 0 || rb < 0 || re < rb || re >= (1LL << 31) || (n > 0 && !cells)) return fail(MVS_E_INVALID, "bad argument");
+    if (re == rb) return MVS_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = ensure_download_side(c);
+    if (rc) return rc;
+    c->st_kernel_ms = 0.0;
+    c->st_bytes = c->st_blocks = c->st_pieces = c->st_two_stage = 0;
+    const int64_t rows = re - rb;
+    const size_t piece_bytes = 32u << 20;
+    BlockCsr blk;
+    blk.rb = rb;
+    blk.re = re;
+    blk.set = 0;
+    blk.row_ptr.assign((size_t)rows + 1, 0);
+    // the arrays of set 0 may still be on their way out of an earlier call's last block: that call drained its download stream
+    // before it returned (finish / below), so nothing is in flight here
+    if (n > 0) {
+        rc = ensure_buf(c, &c->st_rowptr, &c->st_rowptr_bytes, (size_t)(rows + 1) * 8);
+        if (rc == MVS_OK) rc = ensure_buf(c, &c->st_counts, &c->st_counts_bytes, (size_t)(rows + 2) * 8);   // index into the list + the "wide q" flag
+        if (rc == MVS_OK) rc = claim_csr_set(c, 0, 0, n, false, c->stream);
+        if (rc) return rc;
+        unsigned int* d_wide = reinterpret_cast<unsigned int*>((long long*)c->st_counts + rows + 1);
+        HIP_TRY(hipMemsetAsync(d_wide, 0, 8, c->stream));
+        mvs::launch_cells_rowptr(c->stream, cells, n, rb, rows, (long long*)c->st_counts);
+        rc = check_kernel("k_cells_rowptr");
+        if (rc) return rc;
+        mvs::launch_cells_split(c->stream, cells, (const long long*)c->st_counts, rows, n, (long long*)c->st_rowptr, (int32_t*)c->st_col[0],
+                                c->st_q[0], 1, d_wide);
+        rc = check_kernel("k_cells_split");
+        if (rc) return rc;
+        unsigned int h_wide = 0;
+        rc = read_back(c, c->stream, {{blk.row_ptr.data(), c->st_rowptr, (size_t)(rows + 1) * 8}, {&h_wide, d_wide, 4}});
+        if (rc) return rc;
+        blk.n = blk.row_ptr[(size_t)rows];
+        if (blk.n < 0 || blk.n > n) return fail(MVS_E_INVALID, "the cell list is not ordered by row");
+        if (h_wide) {                      // some q needs 16 bits (norms that do not belong to the vectors): the q array again
+            blk.wide = true;
+            rc = ensure_buf(c, &c->st_q[0], &c->st_q_bytes[0], (size_t)n * 2);
+            if (rc) return rc;
+            mvs::launch_cells_split(c->stream, cells, (const long long*)c->st_counts, rows, n, nullptr, (int32_t*)c->st_col[0], c->st_q[0], 2,
+                                    nullptr);
+            rc = check_kernel("k_cells_split(16-bit q)");
+            if (rc) return rc;
+        }
+    }
+    HIP_TRY(hipEventRecord(c->dl_ready[0], c->stream));
+    c->st_blocks = 1;
+    StreamOut out;
+    out.c = c;
+    out.cb = cb;
+    out.ecb = ecb;
+    out.user = user;
+    out.worker = std::thread([&out] { out.run(); });
+    if (ecb) rc = encode_block(c, blk, c->stream);
+    if (rc == MVS_OK) rc = ecb ? feed_encoded(c, out, blk, piece_bytes) : feed_block(c, out, blk, piece_bytes);
+    out.close();
+    (void)hipStreamSynchronize(c->dl_stream);
+    if (rc) return rc;
+    if (!out.error.empty()) return fail(MVS_E_HIP, "%s", out.error.c_str());
+    if (out.cb_status != 0) return fail(MVS_E_ABORTED, "the row-block callback returned %d", out.cb_status);
+    if (n_delivered) *n_delivered = blk.n;
+    return MVS_OK;
+}
+}  // namespace mvs_capi
+
+extern "C" {
+
+int mvs_cells_stream(mvs_ctx* c, const mvs_cell* cells, int64_t n_cells, int64_t row_begin, int64_t row_end, mvs_row_block_cb cb,
+                     void* user, int64_t* n_delivered) {
+    try {
+        return cells_stream_impl(c, cells, n_cells, row_begin, row_end, cb, nullptr, user, n_delivered);
+    } catch (const std::bad_alloc&) {
+        return fail(MVS_E_NOMEM, "out of host memory while streaming a shard's cells");
+    } catch (const std::exception& e) {
+        return fail(MVS_E_HIP, "mvs_cells_stream: %s", e.what());
+    }
+}
+
+int mvs_cells_stream_encoded(mvs_ctx* c, const mvs_cell* cells, int64_t n_cells, int64_t row_begin, int64_t row_end,
+                             mvs_encoded_rows_cb cb, void* user, int64_t* n_delivered) {
+    try {
+        return cells_stream_impl(c, cells, n_cells, row_begin, row_end, nullptr, cb, user, n_delivered);
+    } catch (const std::bad_alloc&) {
+        return fail(MVS_E_NOMEM, "out of host memory while streaming a shard's cells");
+    } catch (const std::exception& e) {
+        return fail(MVS_E_HIP, "mvs_cells_stream_encoded: %s", e.what());
+    }
+}
+
+}  // extern "C"

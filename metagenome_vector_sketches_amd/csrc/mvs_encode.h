@@ -5,6 +5,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "../../include/mvs_hip.h"
+
 namespace mvs {
 
 // what the size pass leaves per row for the fill pass
@@ -27,6 +29,14 @@ int encode_offsets(hipStream_t stream, unsigned long long* d_size, unsigned long
 // lower it to exercise the fallback)
 int launch_encode_fill(hipStream_t stream, const long long* d_row_ptr, const int32_t* d_col, const void* d_q, int q_bytes,
                        int64_t rows, const unsigned long long* d_offset, const EncRow* d_par, unsigned char* d_out, int stage_words);
+
+// A list of kept cells ordered by (row, col) -> the CSR arrays above for rows [row0, row0 + rows) (mvs_cells_stream*):
+// d_abs_ptr[r] = index of the first cell of row row0 + r in the list (rows + 1 entries), then the columns / q of those cells
+// into arrays that start at 0 with the row index rebased (d_rel_ptr, may be NULL); n_upper bounds the cells (grid size);
+// *d_wide is set when a q does not fit q_bytes == 1.
+int launch_cells_rowptr(hipStream_t stream, const mvs_cell* d_cells, int64_t n, int64_t row0, int64_t rows, long long* d_abs_ptr);
+int launch_cells_split(hipStream_t stream, const mvs_cell* d_cells, const long long* d_abs_ptr, int64_t rows, int64_t n_upper,
+                       long long* d_rel_ptr, int32_t* d_col, void* d_q, int q_bytes, unsigned int* d_wide);
 
 }  // namespace mvs
 

@@ -21,6 +21,8 @@
 // 0.1 s of comparison + download), and the encoded rows are 1.4 bytes per cell on the link instead of 5.
 #include "mvs_encode.h"
 
+#include <algorithm>
+
 #include <rocprim/device/device_scan.hpp>
 
 #include "../../include/mvs_hip.h"
@@ -431,6 +433,42 @@ __global__ __launch_bounds__(64) void k_enc_fill(const long long* __restrict__ r
     if (lane == 0 && carry) high[base >> 6] = carry;
 }
 
+
+// ---- a sorted cell list -> the CSR arrays the encoder reads (mvs_cells_stream[_encoded]) ----
+// cells are ordered by (row, col); rows [row0, row0 + rows) of them leave.  abs_ptr[r] = index of the first cell whose row is
+// >= row0 + r (r = 0 .. rows): one binary search per row -- rows without cells cost nothing else, and no per-row counts are
+// needed from whoever produced the list.
+__global__ void k_cells_rowptr(const mvs_cell* __restrict__ cells, long long n, int row0, long long rows, long long* __restrict__ abs_ptr) {
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r > rows) return;
+    const long long want = (long long)row0 + r;
+    long long lo = 0, hi = n;
+    while (lo < hi) {
+        const long long mid = (lo + hi) >> 1;
+        if ((long long)cells[mid].row < want) lo = mid + 1;
+        else hi = mid;
+    }
+    abs_ptr[r] = lo;
+}
+
+// columns and q of the cells [abs_ptr[0], abs_ptr[rows]) into arrays that start at 0, the row index rebased likewise; *wide is
+// set when some q does not fit a byte (then the caller runs the pass again with q16)
+template <typename Q>
+__global__ void k_cells_split(const mvs_cell* __restrict__ cells, const long long* __restrict__ abs_ptr, long long rows,
+                              long long* __restrict__ rel_ptr, int32_t* __restrict__ col, Q* __restrict__ q, unsigned int* __restrict__ wide) {
+    const long long base = abs_ptr[0], end = abs_ptr[rows];
+    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x, step = (long long)gridDim.x * blockDim.x;
+    if (rel_ptr)
+        for (long long r = tid; r <= rows; r += step) rel_ptr[r] = abs_ptr[r] - base;
+    bool odd = false;
+    for (long long i = base + tid; i < end; i += step) {
+        const mvs_cell c = cells[i];
+        col[i - base] = c.col;
+        q[i - base] = (Q)c.q;
+        odd |= sizeof(Q) == 1 && ((unsigned)c.q > 255u);
+    }
+    if (odd && wide) atomicOr(wide, 1u);
+}
 }  // namespace
 
 int launch_encode_sizes(hipStream_t stream, const long long* d_row_ptr, const int32_t* d_col, const void* d_q, int q_bytes,
@@ -470,6 +508,24 @@ int launch_encode_fill(hipStream_t stream, const long long* d_row_ptr, const int
     else
         hipLaunchKernelGGL(k_enc_fill<uint8_t>, dim3((unsigned)rows), dim3(64), 0, stream, d_row_ptr, d_col, (const uint8_t*)d_q,
                            d_offset, d_par, d_out, sw, fast);
+    return 0;
+}
+
+int launch_cells_rowptr(hipStream_t stream, const mvs_cell* d_cells, int64_t n, int64_t row0, int64_t rows, long long* d_abs_ptr) {
+    hipLaunchKernelGGL(k_cells_rowptr, dim3((unsigned)((rows + 1 + 255) / 256)), dim3(256), 0, stream, d_cells, (long long)n, (int)row0,
+                       (long long)rows, d_abs_ptr);
+    return 0;
+}
+
+int launch_cells_split(hipStream_t stream, const mvs_cell* d_cells, const long long* d_abs_ptr, int64_t rows, int64_t n_upper,
+                       long long* d_rel_ptr, int32_t* d_col, void* d_q, int q_bytes, unsigned int* d_wide) {
+    const unsigned blocks = (unsigned)std::min<int64_t>(2048, std::max<int64_t>(1, (std::max(n_upper, rows + 1) + 255) / 256));
+    if (q_bytes == 2)
+        hipLaunchKernelGGL(k_cells_split<uint16_t>, dim3(blocks), dim3(256), 0, stream, d_cells, d_abs_ptr, (long long)rows, d_rel_ptr,
+                           d_col, (uint16_t*)d_q, d_wide);
+    else
+        hipLaunchKernelGGL(k_cells_split<uint8_t>, dim3(blocks), dim3(256), 0, stream, d_cells, d_abs_ptr, (long long)rows, d_rel_ptr,
+                           d_col, (uint8_t*)d_q, d_wide);
     return 0;
 }
 

@@ -168,3 +168,32 @@ def test_text_parser_against_reference_standalone_projection(tmp_path):
             for v, line in zip(sets, want_lines):
                 got = " ".join("%g" % float(np.float32(x)) for x in orc.project(v, d))
                 assert got == line, (key, simd)
+
+
+def test_cpp_step_partition_equals_the_python_mirror():
+    """csrc/host/mvs_step.hpp (the C++ host of the strong-scaled step) and parallel.py cut the work the same way: rank rows
+    (src/pairwise_comp_optimized.cpp:938-940), padded blocks, the symmetric block plan, the chunks the coarse plane travels in
+    and the peers' rectangles clipped to a chunk -- mvs_step_plan prints the C++ side's arithmetic"""
+    import json
+    from metagenome_vector_sketches_amd import parallel, _capi
+    exe = os.path.join(BIN, "mvs_step_plan")
+    cases = [(1, 61, 61, 2, 0.33, 1), (2, 31, 61, 2, 0.33, 1), (3, 21, 61, 3, 0.5, 1), (4, 25000, 100000, 2, 0.33, 1),
+             (8, 12500, 100000, 2, 0.33, 1), (8, 12500, 100000, 4, 0.25, 0), (7, 143, 1000, 2, 0.33, 1), (8, 8, 61, 2, 0.33, 1),
+             (5, 2560, 12800, 3, 0.0, 1), (6, 1000, 5001, 2, 0.33, 1), (8, 125000, 1000000, 2, 0.33, 1)]
+    for world, block_rows, n_total, chunks, first, sym in cases:
+        r = run(exe, str(world), str(block_rows), str(n_total), str(chunks), str(first), str(sym))
+        assert r.returncode == 0, r.stderr
+        got = json.loads(r.stdout)
+        if block_rows == (n_total + world - 1) // world:
+            assert (block_rows, got["P"]) == _capi.shard_layout(n_total, world)
+        P = got["P"]
+        assert got["half_split"] == parallel.half_split(P)
+        want_chunks = parallel.chunk_bounds(P, chunks, first if first > 0 else None)
+        assert [tuple(c) for c in got["chunks"]] == want_chunks, (world, block_rows, chunks, first)
+        for rank, rec in enumerate(got["ranks"]):
+            if block_rows == (n_total + world - 1) // world:
+                assert tuple(rec["rows"]) == parallel.shard_rows(n_total, world, rank)
+            plan = parallel.block_plan(world, rank, P, symmetric=bool(sym))
+            assert [tuple(b) for b in rec["plan"]] == plan, (world, rank)
+            for (c0, c1), cl in zip(want_chunks, rec["clipped"]):
+                assert [tuple(b) for b in cl] == parallel.clip_blocks(plan[1:], P, c0, c1), (world, rank, c0, c1)
