@@ -306,6 +306,9 @@ struct StepOptions {
     bool wire = true;               // MVS_WIRE_LOW_LIMB=0: limb planes on the wire instead of low limbs
     bool speculate = true;          // MVS_PLAN_SPECULATE=0: every plan waits for its own counts
     bool timing = false;            // stage spans from events on the step's streams (an event costs the stream ~6 us)
+    bool exchange_in_place = false; // MEASUREMENT ONLY (mvs_step_bench, as tools/strong_model.py): a rank of `world` > 1 without a
+                                    // communicator -- every byte the exchange would deliver has been put in place
+                                    // (ShardStep::model_fill_peer), the collectives are skipped, the mirrored cells stay home
     int64_t dense_limit_cells = (int64_t)1 << 27;   // a rank whose blocks keep more than this (2 GiB of cells): the step reports
                                                     // too_dense on every rank and the caller takes the streamed dense path
     static StepOptions from_env() {
@@ -339,12 +342,18 @@ class ShardStep {
  public:
     ShardStep(mvs_ctx* ctx, Exchange* exchange, int rank, int world, StepOptions opt = StepOptions::from_env())
         : ctx_(ctx), ex_(exchange), rank_(rank), world_(world), opt_(opt) {
-        if (world > 1 && !exchange) throw StepError(MVS_E_INVALID, "world > 1 needs a communicator");
+        if (world > 1 && !exchange && !opt.exchange_in_place) throw StepError(MVS_E_INVALID, "world > 1 needs a communicator");
+        if (exchange && opt.exchange_in_place) throw StepError(MVS_E_INVALID, "exchange_in_place is for a step without a communicator");
         if (exchange && (exchange->rank() != rank || exchange->world() != world))
             throw StepError(MVS_E_INVALID, "the communicator's rank / world differ from the step's");
         wire_ok_ = opt.wire;
-        if (opt_.timing)
-            for (mvs_event*& e : ev_) check(mvs_event_create(ctx, 1, &e), "event");
+        set_timing(opt.timing);
+    }
+    // stage spans from events on the step's stream (an event between two kernels costs the stream ~6 us: off for timed steps)
+    void set_timing(bool on) {
+        opt_.timing = on;
+        if (on && !ev_[0])
+            for (mvs_event*& e : ev_) check(mvs_event_create(ctx_, 1, &e), "event");
     }
     ~ShardStep() {
         if (set_) (void)mvs_sketch_set_destroy(set_);
@@ -379,6 +388,16 @@ class ShardStep {
     const mvs_cell* cells() const { return sorted_.as<mvs_cell>(); }
     int64_t n_cells() const { return n_out_; }
     std::pair<int64_t, int64_t> rows() const { return rank_rows(src_.n_total, src_.block_rows, rank_); }
+    // Measurement aid (tools/strong_model.py, csrc/host/mvs_step_bench.cpp): what the exchange WOULD have delivered for rank p's
+    // block -- planes, filter inputs, low limbs -- built here from p's sketches, so that one rank's step can be timed on one
+    // card with every byte of the exchange in place.  Call after a first run() (the buffers exist then); the data survives
+    // later steps (a step rewrites its own block only).
+    void model_fill_peer(int p, const void* d_sketches_p, int elem_bytes, int64_t n_rows_p) {
+        if (!set_ || p == rank_) return;
+        check(mvs_sketch_set_recode_rows(ctx_, set_, n_rows_p ? d_sketches_p : nullptr, elem_bytes, n_rows_p, (int64_t)p * P_, P_),
+              "mvs_sketch_set_recode_rows (peer block)");
+        if (lo_.p) check(mvs_sketch_set_wire_rows(ctx_, set_, lo_.as<int8_t>(), (int64_t)p * P_, P_), "mvs_sketch_set_wire_rows (peer block)");
+    }
     int64_t block_pad() const { return P_; }
     const double* norms_sq_storage() const { return n2_.as<double>(); }     // DEVICE, indexed by storage row
     StepInfo info;
@@ -466,6 +485,11 @@ class ShardStep {
               "mvs_sketch_set_recode_rows");
         mark(1);
         if (world_ == 1) return;
+        if (!ex_) {                         // exchange_in_place: only what this rank itself contributes to the wire buffer
+            if (wire_) copy_low_limbs(base, P_);
+            for (const auto& ch : chunk_bounds(P_, opt_.gather_chunks, opt_.gather_first)) coarse_h_.push_back({ch.first, ch.second, Exchange::Handle()});
+            return;
+        }
         const int64_t P = P_;
         const int d_pad = d_pad_, nl = limbs_ & 0xff;
         const bool gather_norms = s.n2_all == nullptr;
@@ -512,7 +536,7 @@ class ShardStep {
         mark(2);
         check(mvs_plan_filter(ctx_, plan.data(), 1), "mvs_plan_filter (diagonal block)");     // nothing of it comes from another rank
         const bool others = plan.size() > 1;
-        if (first && world_ > 1) ex_->wait(ctx_, small_);        // row statistics (+ norms) of every rank
+        if (first && ex_) ex_->wait(ctx_, small_);               // row statistics (+ norms) of every rank
         if (others) check(mvs_plan_rows_ready(ctx_, 0, (int64_t)world_ * P), "mvs_plan_rows_ready");
         int64_t counts[6] = {0, 0, 0, 0, 0, 0};
         bool exact_mode = false;
@@ -524,13 +548,15 @@ class ShardStep {
         if (first && others && exact_mode) {
             // no filter in this plan (filter switched off, another limb code): mvs_plan_filter runs the exact kernel on a block at
             // once, and that reads the other ranks' LIMB planes -- they have to be there (and rebuilt) before the call
-            for (auto& c : coarse_h_) ex_->wait(ctx_, c.h);
-            ex_->wait(ctx_, planes_h_);
+            if (ex_) {
+                for (auto& c : coarse_h_) ex_->wait(ctx_, c.h);
+                ex_->wait(ctx_, planes_h_);
+            }
             if (wire_ && !rebuilt_) rebuild_all();
             check(mvs_plan_filter(ctx_, plan.data() + 1, (int)plan.size() - 1), "mvs_plan_filter (peers' blocks, exact kernel)");
         } else if (first && !coarse_h_.empty()) {
             for (auto& c : coarse_h_) {
-                ex_->wait(ctx_, c.h);
+                if (ex_) ex_->wait(ctx_, c.h);
                 const std::vector<mvs_plan_block> blocks = clip_blocks(plan, 1, P, c.a, c.b);
                 if (!blocks.empty()) check(mvs_plan_filter(ctx_, blocks.data(), (int)blocks.size()), "mvs_plan_filter (peers' rows)");
             }
@@ -539,7 +565,7 @@ class ShardStep {
         }
         // the limb planes: the re-check reads them.  Every exchange of the step is joined here even if this rank's plan needs
         // nothing from anybody (rank 1 of 2): the next step rewrites the buffers the collectives read
-        if (first && world_ > 1) ex_->wait(ctx_, planes_h_);
+        if (first && ex_) ex_->wait(ctx_, planes_h_);
         // the plan rebuilds the rows its re-check and flagged tiles read -- the columns of its candidates -- and no others
         if (wire_ && !rebuilt_ && others) check(mvs_plan_wire(ctx_, lo_.as<int8_t>()), "mvs_plan_wire");
         const uint64_t* d_cnt = nullptr;
@@ -606,7 +632,7 @@ class ShardStep {
                                   state_.as<uint64_t>(), send, cap_f, status, s.max_abs),
                   "mvs_cells_route");
             if (world_ > 1) {
-                if (!local_only) {                 // (a local repeat rewrote this rank's own block with the same cells)
+                if (!local_only && ex_) {          // (a local repeat rewrote this rank's own block with the same cells)
                     const Exchange::Handle h = ex_->submit(ctx_, [this, stride](mvs_ctx* x, mvs_comm* cm) {
                         check(mvs_allgather_bytes(x, cm, xbuf_.p, stride), "all-gather of the mirrored cells");
                     });

@@ -515,6 +515,26 @@ static int run_step_rank(const StepJob& job, const StepRank& r) {
                       << (si.wire ? "coarse plane + low limbs" : "coarse plane + limb planes") << "), limbs " << si.limbs << ", " << si.blocks
                       << " block(s), " << si.attempts << " attempt(s)" << (si.note.empty() ? "" : "; ") << si.note << std::endl;
         }
+        if (getenv("MVS_STEP_CHECKSUM")) {
+            // bench.py's order-independent checksum of a shard (--config 3: `cells_checksum`): sum and sum of squares, mod 2^64, of
+            // a 64-bit mix of (row, col, dot, q); summed over the ranks it is the same whatever the rank count
+            std::vector<mvs_cell> host((size_t)step.n_cells());
+            if (!host.empty() &&
+                mvs_device_copy(g.ctx, host.data(), MVS_MEM_HOST, step.cells(), MVS_MEM_DEVICE, host.size() * sizeof(mvs_cell)) != MVS_OK)
+                return gpu_fail("downloading the rank's cells");
+            uint64_t s1 = 0, s2 = 0;
+            for (const mvs_cell& c : host) {
+                const uint64_t mix = ((uint64_t)(int64_t)c.row * 1000003ull + (uint64_t)(int64_t)c.col) * 2654435761ull +
+                                     (uint64_t)(int64_t)c.dot * 40503ull + (uint64_t)(int64_t)c.q;
+                s1 += mix;
+                s2 += mix * mix;
+            }
+            char buf[160];
+            snprintf(buf, sizeof buf, "[checksum] rank %d kept %lld sum %016llx sum2 %016llx", r.rank, (long long)step.n_cells(),
+                     (unsigned long long)s1, (unsigned long long)s2);
+            std::lock_guard<std::mutex> lk(*job.out_mu);
+            std::cerr << buf << std::endl;
+        }
         // the rank's sorted cells, shard by shard, through the device encoder into the shard folders
         for (int shard = r.shard_begin; shard < r.shard_end && !too_dense; ++shard) {
             const std::string folder = job.output_folder + "shard_" + std::to_string(shard) + "/";

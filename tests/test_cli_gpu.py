@@ -357,14 +357,14 @@ def test_step_mode_falls_back_when_the_result_is_dense(tmp_path):
             r = subprocess.run([exe, *base, "--output_folder", out, "--num_shards", "2", "--shard_idx", "-1"], capture_output=True, text=True,
                                env=env)
             assert r.returncode == 0, r.stderr
-            assert r.stderr.count("too dense for cell lists") == 2, r.stderr
+            assert r.stderr.count("too dense for cell lists: streamed comparison per shard") == 2, r.stderr
         else:
             env["MVS_DEVICE"] = "0"
             procs = [subprocess.Popen([exe, *base, "--output_folder", out, "--num_shards", "2", "--shard_idx", str(k)], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for k in range(2)]
             outs = [p.communicate(timeout=300) for p in procs]
             assert all(p.returncode == 0 for p in procs), outs
-            assert all("too dense for cell lists" in o[1] for o in outs), outs
+            assert all("too dense for cell lists: streamed comparison per shard" in o[1] for o in outs), outs
         assert _shard_bytes(out, 2) == _shard_bytes(ref, 2), mode
 
 
