@@ -334,6 +334,9 @@ struct StepInfo {
     std::string note;
     // stage spans of the step (StepOptions::timing), as bench.py's `strong` record names them
     double prepare_own_rows_ms = 0, plan_span_ms = 0, cells_route_exchange_sort_ms = 0;
+    // the plan's span cut where the exchange's arrivals matter (tools/strong_model.py walks these): own rows ready -> diagonal
+    // block's filter queued and run; the peers' filter launches; low-limb rebuild + re-check + flagged tiles
+    double diag_filter_ms = 0, peer_filters_ms = 0, finish_ms = 0;
     double filter_ms = 0, recheck_ms = 0, flagged_tiles_ms = 0;
     int64_t filter_launches = 0, filter_tiles = 0, candidates = 0, flagged_tiles = 0;
 };
@@ -535,6 +538,7 @@ class ShardStep {
         check(rc_begin, "mvs_plan_begin");
         mark(2);
         check(mvs_plan_filter(ctx_, plan.data(), 1), "mvs_plan_filter (diagonal block)");     // nothing of it comes from another rank
+        mark(5);
         const bool others = plan.size() > 1;
         if (first && ex_) ex_->wait(ctx_, small_);               // row statistics (+ norms) of every rank
         if (others) check(mvs_plan_rows_ready(ctx_, 0, (int64_t)world_ * P), "mvs_plan_rows_ready");
@@ -563,6 +567,7 @@ class ShardStep {
         } else if (others) {
             check(mvs_plan_filter(ctx_, plan.data() + 1, (int)plan.size() - 1), "mvs_plan_filter (peers' blocks)");
         }
+        mark(6);
         // the limb planes: the re-check reads them.  Every exchange of the step is joined here even if this rank's plan needs
         // nothing from anybody (rank 1 of 2): the next step rewrites the buffers the collectives read
         if (first && ex_) ex_->wait(ctx_, planes_h_);
@@ -746,6 +751,9 @@ class ShardStep {
         if (mvs_event_elapsed_ms(ev_[0], ev_[1], &ms) == MVS_OK) info.prepare_own_rows_ms = ms;
         if (mvs_event_elapsed_ms(ev_[2], ev_[3], &ms) == MVS_OK) info.plan_span_ms = ms;
         if (mvs_event_elapsed_ms(ev_[3], ev_[4], &ms) == MVS_OK) info.cells_route_exchange_sort_ms = ms;
+        if (mvs_event_elapsed_ms(ev_[1], ev_[5], &ms) == MVS_OK) info.diag_filter_ms = ms;
+        if (mvs_event_elapsed_ms(ev_[5], ev_[6], &ms) == MVS_OK) info.peer_filters_ms = ms;
+        if (mvs_event_elapsed_ms(ev_[6], ev_[3], &ms) == MVS_OK) info.finish_ms = ms;
         double pms[4] = {0, 0, 0, 0};
         int64_t counts[6] = {0, 0, 0, 0, 0, 0};
         if (mvs_plan_stats(ctx_, pms, counts) == MVS_OK) {
@@ -776,7 +784,7 @@ class ShardStep {
         Exchange::Handle h;
     };
     std::vector<CoarseChunk> coarse_h_;
-    mvs_event* ev_[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    mvs_event* ev_[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 
 }  // namespace mvs_step

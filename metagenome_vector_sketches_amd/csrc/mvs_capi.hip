@@ -191,6 +191,7 @@ const OptionSpec kOptions[] = {
     {"plan_strip_wgs", &mvs::Options::plan_strip_wgs, nullptr, 256, 1 << 22},
     {"recode_rows_wg", &mvs::Options::recode_rows_wg, nullptr, 8, 16},
     {"plan_speculate", &mvs::Options::plan_speculate, nullptr, 0, 1},
+    {"plan_order", &mvs::Options::plan_order, nullptr, 0, 1},
     {"pairwise_block_cells", nullptr, &mvs::Options::pairwise_block_cells, 1, (1LL << 62)},
 };
 

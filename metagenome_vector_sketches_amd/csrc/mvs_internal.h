@@ -5,6 +5,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <vector>
+
 #include "../../include/mvs_hip.h"
 
 namespace mvs {
@@ -81,6 +83,8 @@ struct Options {
                                     // are in flight (10^6 x 2048: 256 queries 0.654 -> 0.622 ms, 512 queries 1.146 -> 1.034 from 3 to 5)
     int stream_trace = 0;           // 1: mvs_pairwise_stream prints the host-side time line of its row blocks to stderr
     int recode_rows_wg = 8;         // k_recode_rows: rows (= waves) per workgroup, 8 or 16
+    int plan_order = 1;             // block plans: 1 = filter launches of up to 2^20 tiles take the balanced tile order (PlanSegs::order),
+                                    // 0 = the static super-patch map (A/B, tests)
     int plan_speculate = 0;         // block plans: second half of a plan sized from the previous plan's counts, no host round trip
     int plan_strip_wgs = 1 << 22;   // block plans: a rectangle whose padded grid holds more workgroups than this is cut into column
                                     // strips (a dispatch holds 2^32 work-items per dimension = 2^23 workgroups; tests lower it)
@@ -186,6 +190,14 @@ struct PlanSegs {
     unsigned wg_begin[kPlanSegs + 1];
     int n_tr[kPlanSegs], n_tc[kPlanSegs], n_spc[kPlanSegs];
     long long i_begin[kPlanSegs], j_begin[kPlanSegs];
+    // Balanced order (plan_tile_order; NULL: the static map above): the tiles the launch really computes, XCD label x
+    // (blockIdx.x % 8) takes entries [x * order_per, (x + 1) * order_per) -- its share of every super-patch, in sub-patch
+    // order, so that the XCDs still walk the same super-patch at the same time (panels shared through the memory-side cache)
+    // but no XCD carries more tiles than another: a triangle's static sub-patches hold 32, 26, 10 or 0 tiles, and a launch
+    // of a few rounds (1225 tiles of a rank's diagonal block, 820 of a 10k x 10k comparison) waited for its fullest XCD --
+    // 174 tiles where 154 would do.  Entry = segment << 28 | tile row << 14 | tile column; ~0u = no tile.
+    const unsigned* order;
+    unsigned order_per;
 };
 
 // Which 256 x 256 tiles of the dense byte matrix can hold a kept cell (tile-granular comparison feeding the matrix): the
@@ -249,6 +261,9 @@ int launch_filter(hipStream_t stream, const PairwiseArgs& a, const Options& opt)
 // 1-D grid in workgroups, 0: empty, -1: too many rectangles / too large for one launch), and that launch of the ping-pong filter
 long long plan_segments(const int64_t (*blocks)[4], int n, PlanSegs* segs);
 int launch_filter_plan(hipStream_t stream, const PairwiseArgs& a, const PlanSegs& segs, long long workgroups);
+// the balanced order of a plan launch (host): per XCD label the tiles it computes, order_per entries each (padded with ~0u);
+// false when a coordinate does not fit an entry or the launch is too large for a list to pay (the static map is used then)
+bool plan_tile_order(const PairwiseArgs& a, const PlanSegs& segs, std::vector<unsigned>* order, unsigned* per);
 int launch_exact_pairs(hipStream_t stream, const PairwiseArgs& a, const Options& opt, long long n_hint = -1);
 // candidate regions of the ping-pong filter: how many (workgroups x 8 waves) launch_filter's grid has for this block, 0 if
 // the variant it would pick appends with atomics only; k_cand_gather moves the regions' contents into the candidate list

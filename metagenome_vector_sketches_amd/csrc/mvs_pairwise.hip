@@ -1421,10 +1421,20 @@ __global__ __launch_bounds__(512, 2) void k_pairwise_pp(const PairwiseArgs a, in
         // a block plan: the workgroup's segment (uniform: scalar compares on the kernel arguments), then the single-block
         // map inside it -- a segment starts on a multiple of 256 workgroups, so blockIdx.x % 8 is the XCD label there too
         int sg = 0;
-        for (int k = 1; k < segs.n; ++k) sg += blockIdx.x >= segs.wg_begin[k] ? 1 : 0;
-        const unsigned local = blockIdx.x - segs.wg_begin[sg];
-        const unsigned per_row = (unsigned)segs.n_spc[sg] * 256u;
-        tc = map_tile(local % per_row, local / per_row, segs.n_tr[sg], segs.n_tc[sg], a.map_mode);
+        if (segs.order != nullptr) {
+            // the balanced order: this XCD label's next tile (uniform: a scalar load)
+            const unsigned e = segs.order[(blockIdx.x & 7u) * segs.order_per + (blockIdx.x >> 3)];
+            if (e == ~0u) return;
+            sg = (int)(e >> 28);
+            tc.tr = (int)((e >> 14) & 0x3fffu);
+            tc.tc = (int)(e & 0x3fffu);
+            tc.valid = true;
+        } else {
+            for (int k = 1; k < segs.n; ++k) sg += blockIdx.x >= segs.wg_begin[k] ? 1 : 0;
+            const unsigned local = blockIdx.x - segs.wg_begin[sg];
+            const unsigned per_row = (unsigned)segs.n_spc[sg] * 256u;
+            tc = map_tile(local % per_row, local / per_row, segs.n_tr[sg], segs.n_tc[sg], a.map_mode);
+        }
         org_i = segs.i_begin[sg];
         org_j = segs.j_begin[sg];
     } else {
@@ -3477,10 +3487,67 @@ long long plan_segments(const int64_t (*blocks)[4], int n, PlanSegs* segs) {
     return (long long)wg;
 }
 
+// The tiles a plan launch computes, dealt out evenly: super-patch by super-patch (segment, patch row, patch column -- the order
+// the static map's workgroups are dispatched in), the valid tiles of a super-patch in sub-patch order (4 x 8 tiles: 12 operand
+// panels per 32 tiles) are cut into eight contiguous runs, one per XCD label, of equal length but for a remainder that rotates
+// from super-patch to super-patch.  A tile is valid by the kernel's own rule: inside the segment's grid and not strictly below
+// the diagonal of the symmetric square.
+bool plan_tile_order(const PairwiseArgs& a, const PlanSegs& segs, std::vector<unsigned>* order, unsigned* per) {
+    std::vector<unsigned> lists[8];
+    std::vector<unsigned> patch;
+    unsigned long long total = 0;
+    unsigned rot = 0;
+    for (int sg = 0; sg < segs.n; ++sg) {
+        const int n_tr = segs.n_tr[sg], n_tc = segs.n_tc[sg];
+        if (n_tr > 0x3fff || n_tc > 0x3fff || sg > 15) return false;
+        total += (unsigned long long)n_tr * (unsigned long long)n_tc;
+        if (total > (1ull << 20)) return false;
+        const int n_spr = (n_tr + 15) / 16, n_spc = (n_tc + 15) / 16;
+        for (int spr = 0; spr < n_spr; ++spr)
+            for (int spc = 0; spc < n_spc; ++spc) {
+                patch.clear();
+                for (int sub = 0; sub < 8; ++sub)
+                    for (int ql = 0; ql < 32; ++ql) {
+                        int tr, tc;
+                        if (a.map_mode == 1) {          // (the sub-patch shapes of map_tile)
+                            tr = spr * 16 + (sub >> 2) * 8 + (ql >> 2);
+                            tc = spc * 16 + (sub & 3) * 4 + (ql & 3);
+                        } else if (a.map_mode == 2) {
+                            tr = spr * 16 + sub * 2 + (ql >> 4);
+                            tc = spc * 16 + (ql & 15);
+                        } else {
+                            tr = spr * 16 + (sub >> 1) * 4 + (ql >> 3);
+                            tc = spc * 16 + (sub & 1) * 8 + (ql & 7);
+                        }
+                        if (tr >= n_tr || tc >= n_tc) continue;
+                        const long long i0 = segs.i_begin[sg] + (long long)tr * 256, j0 = segs.j_begin[sg] + (long long)tc * 256;
+                        if (a.symmetric && j0 >= a.sym_begin && j0 + 256 <= i0) continue;      // k_pairwise_pp: produced by mirroring
+                        patch.push_back((unsigned)sg << 28 | (unsigned)tr << 14 | (unsigned)tc);
+                    }
+                const unsigned n = (unsigned)patch.size(), base = n / 8, extra = n % 8;
+                unsigned at = 0;
+                for (unsigned j = 0; j < 8; ++j) {
+                    const unsigned x = (rot + j) & 7u, take = base + (j < extra ? 1u : 0u);
+                    lists[x].insert(lists[x].end(), patch.begin() + at, patch.begin() + at + take);
+                    at += take;
+                }
+                rot = (rot + extra) & 7u;
+            }
+    }
+    size_t longest = 0;
+    for (const auto& l : lists) longest = std::max(longest, l.size());
+    if (longest == 0) return false;
+    order->assign(longest * 8, ~0u);
+    for (int x = 0; x < 8; ++x) std::copy(lists[x].begin(), lists[x].end(), order->begin() + (size_t)x * longest);
+    *per = (unsigned)longest;
+    return true;
+}
+
 // the ping-pong filter (4-stage ring, B operand direct) over the segments of a plan; `a` carries the frame (PairwiseArgs::plan)
 int launch_filter_plan(hipStream_t stream, const PairwiseArgs& a, const PlanSegs& segs, long long workgroups) {
     if (a.limbs != 2 || a.d_pad > 32768 || !a.plan || a.coarse_fm == nullptr || ((a.row_begin | a.col_begin) & 255) != 0) return MVS_E_INVALID;
     if (workgroups <= 0 || segs.n <= 0) return 0;
+    if (segs.order != nullptr) workgroups = (long long)segs.order_per * 8;
     using G = PpGeom<2>;
     const size_t lds = (size_t)4 * G::kStage;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pairwise_pp<2, 4, 0, 0, 1, 0, 1>),

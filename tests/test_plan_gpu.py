@@ -156,6 +156,13 @@ def test_plans_of_all_ranks_give_the_whole_matrix(ctx, n, d, world, mode):
     got3, per3 = _union(split, symmetric=False, chunks=2)
     assert np.array_equal(got3, want)
     assert all(x[3][0] == 0 for x in per3)                       # nothing to send anywhere
+    # the static super-patch map instead of the balanced tile order (option plan_order, default 1): placement only -- the same
+    # tiles, candidates and cells
+    with ctx.options(plan_order=0):
+        got4, per4 = _union(split, symmetric=True, chunks=1)
+    assert np.array_equal(got4, want)
+    for a, b in zip(per_rank, per4):
+        assert (a[2]["filter_tiles"], a[2]["candidates"], a[2]["flagged_tiles"]) == (b[2]["filter_tiles"], b[2]["candidates"], b[2]["flagged_tiles"])
 
 
 def test_plan_on_dense_clusters_goes_through_flagged_tiles(ctx):

@@ -22,7 +22,8 @@ def main():
         out += "/"
     os.makedirs(out, exist_ok=True)
     dev = torch.device("cuda", 0)
-    sk = synth.make_sketches_torch(n, d, hashes, seed=seed, device=dev, cluster=cluster)
+    # slab by slab, as bench.py's strong_run synthesises a rank's rows: the same matrix whichever rank count asks
+    sk = synth.make_sketches_torch_rows(n, d, hashes, seed=seed, device=dev, row_begin=0, row_end=n, cluster=cluster)
     ctx = pkg.Context(0)
     ctx.set_stream(torch.cuda.current_stream())
     ss = torch.empty(n, dtype=torch.int64, device=dev)

@@ -36,6 +36,108 @@ def fast_norm_sq(sumsq, d):
     return np.array([float("%g" % v) for v in x]) ** 2
 
 
+STAGES = ("prepare_ms", "diag_filter_ms", "peer_filters_ms", "rebuild_ms", "finish_ms", "route_report_ms", "sort_ms")
+
+
+def model_step(m, G, P, d_pad, plan_blocks, rate_GBps, latency_us, chunks, first, no_wire=False, clock=1.0):
+    """One rank's step on the timeline of the exchange.  m: measured stage spans (STAGES), wall_ms (no events on the stream),
+    foreign_cells.  rate_GBps per link and direction, latency_us per collective, clock: the shader clock relative to the
+    measurement (0.95 = every compute span 1 / 0.95 longer: eight cards under load in one chassis).  Returns (step_ms, exposed)."""
+    lat = latency_us * 1e-3
+    small = lat + P * 24 / (rate_GBps * 1e6) if G > 1 else 0.0                       # ms
+    bounds = parallel.chunk_bounds(P, chunks, first)
+    scale = min(1.0, m["wall_ms"] / sum(m[k] for k in STAGES)) / clock
+    sp = {k: m[k] * scale for k in STAGES}
+    # the exchange starts when the own rows are ready
+    t_comm, arrive = sp["prepare_ms"] + small, []
+    for (c0, c1) in bounds:
+        t_comm += (lat + (c1 - c0) * d_pad / (rate_GBps * 1e6)) if G > 1 else 0.0
+        arrive.append(t_comm)
+    # what the re-check waits for: the limb planes, or the low limbs (their rebuild is a stage of the compute stream)
+    planes_at = t_comm + ((lat + P * (2 if no_wire else 1) * d_pad / (rate_GBps * 1e6)) if G > 1 else 0.0)
+    t = sp["prepare_ms"] + sp["diag_filter_ms"]
+    waited = 0.0
+    for a, (c0, c1) in zip(arrive, bounds):
+        if G > 1 and a > t:
+            waited += a - t
+            t = a
+        t += sp["peer_filters_ms"] * (c1 - c0) / P if plan_blocks > 1 else 0.0      # a piece's share of the peers' filter time
+    if G > 1 and planes_at > t:
+        waited += planes_at - t
+        t = planes_at
+    t += sp["rebuild_ms"] + sp["finish_ms"] + sp["route_report_ms"]
+    exch = (lat + (64 + 16 * m["foreign_cells"] * 1.25) / (rate_GBps * 1e6)) if G > 1 else 0.0   # the mirrored cells
+    t += exch + sp["sort_ms"]
+    t += max(0.0, m["wall_ms"] / clock - sum(sp.values()))                            # host gaps
+    return t, waited + exch
+
+
+def median(xs):
+    xs = sorted(xs)
+    return xs[len(xs) // 2]
+
+
+def from_cpp(paths, args):
+    """mvs_step_bench JSONs (csrc/host/mvs_step_bench.cpp: every rank of a G-way split timed alone, exchange bytes in place; several
+    runs per G) -> per G: every rank's median over the runs, the slowest rank, the modelled step and speed-up"""
+    runs = {}
+    for pth in paths:
+        with open(pth) as f:
+            rec = json.load(f)
+        runs.setdefault(rec["ranks"], []).append(rec)
+    out = {"host": "csrc/host/mvs_step.hpp (C++), mvs_step_bench", "runs_per_G": {str(g): len(v) for g, v in runs.items()}, "ranks": {}}
+    n, d = next(iter(runs.values()))[0]["n"], next(iter(runs.values()))[0]["d"]
+    d_pad = (d + 127) // 128 * 128
+    out["n"], out["d"] = n, d
+    keys = ("wall_ms_median", "prepare_own_rows_ms", "diag_filter_ms", "peer_filters_ms", "finish_ms", "cells_route_exchange_sort_ms",
+            "filter_ms", "recheck_ms", "flagged_tiles_ms", "foreign_cells", "filter_tiles", "candidates", "own_cells", "plan_blocks")
+    base = None
+    for G in sorted(runs):
+        per_rank = {}
+        for rec in runs[G]:
+            for pr in rec["per_rank"]:
+                per_rank.setdefault(pr["rank"], []).append(pr)
+        ranks = {}
+        for r, lst in sorted(per_rank.items()):
+            ranks[r] = {k: median([x[k] for x in lst]) for k in keys if k in lst[0]}
+            ranks[r]["wall_ms_runs"] = [x["wall_ms_median"] for x in lst]
+            ranks[r]["P"] = lst[0]["rows_per_rank_padded"]
+        slow = max(ranks, key=lambda r: ranks[r]["wall_ms_median"])
+        if base is None:
+            base = ranks[slow]["wall_ms_median"]
+        rec_out = {"per_rank_wall_ms_median": {str(r): v["wall_ms_median"] for r, v in ranks.items()}, "slowest_rank": slow,
+                   "slowest_rank_wall_ms_median": ranks[slow]["wall_ms_median"], "slowest_rank_wall_ms_runs": ranks[slow]["wall_ms_runs"],
+                   "slowest_rank_stages": {k: v for k, v in ranks[slow].items() if k != "wall_ms_runs"}, "model": {}, "sensitivity": []}
+        def m_of(v):
+            return {"wall_ms": v["wall_ms_median"], "prepare_ms": v["prepare_own_rows_ms"], "diag_filter_ms": v.get("diag_filter_ms", 0.0),
+                    "peer_filters_ms": v.get("peer_filters_ms", 0.0), "rebuild_ms": 0.0, "finish_ms": v.get("finish_ms", 0.0),
+                    "route_report_ms": v["cells_route_exchange_sort_ms"], "sort_ms": 0.0, "foreign_cells": v["foreign_cells"]}
+        for rate in [float(x) for x in args.link_GBps.split(",")]:
+            # every rank walks its own timeline; the step ends when the slowest one does
+            worst = max(model_step(m_of(v), G, v["P"], d_pad, v["plan_blocks"], rate, args.latency_us, args.chunks, args.first)[0]
+                        for v in ranks.values())
+            rec_out["model"]["%g GB/s per link and direction" % rate] = {"step_ms": worst, "speedup_vs_1gpu_measured": base / worst}
+        for lat in (20.0, 50.0, 100.0):
+            for rate in (45.0, 61.0):
+                for clock in (1.0, 0.95):
+                    worst = max(model_step(m_of(v), G, v["P"], d_pad, v["plan_blocks"], rate, lat, args.chunks, args.first, clock=clock)[0]
+                                for v in ranks.values())
+                    rec_out["sensitivity"].append({"latency_us": lat, "link_GBps": rate, "clock": clock, "step_ms": worst,
+                                                   "speedup_vs_1gpu_measured": base / worst})
+        out["ranks"][str(G)] = rec_out
+        print("G=%d  slowest rank %d: wall %.3f ms (median of %d runs: %s); per rank %s" %
+              (G, slow, ranks[slow]["wall_ms_median"], len(ranks[slow]["wall_ms_runs"]), " ".join("%.3f" % x for x in ranks[slow]["wall_ms_runs"]),
+               " ".join("%.3f" % v["wall_ms_median"] for v in ranks.values())))
+        for k, v in rec_out["model"].items():
+            print("      %s: step %.3f ms -> %.2f x the measured 1-GPU step" % (k, v["step_ms"], v["speedup_vs_1gpu_measured"]))
+        if G > 1:
+            print("      sensitivity (speed-up): " + "  ".join("%gus/%gGB/s/clk%.2f=%.2f" % (x["latency_us"], x["link_GBps"], x["clock"],
+                                                                                           x["speedup_vs_1gpu_measured"]) for x in rec_out["sensitivity"]))
+    if args.out:
+        with open(args.out, "w") as f:
+            json.dump(out, f, indent=1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("n", nargs="?", type=int, default=100_000)
@@ -53,7 +155,12 @@ def main():
     ap.add_argument("--overlap", action="store_true", help="filter launches of a plan alternate between two streams (plan_overlap)")
     ap.add_argument("--report-spin", type=int, default=-1, help="option report_spin: microseconds mvs_cells_report polls before it blocks")
     ap.add_argument("--out", default="")
+    ap.add_argument("--from-cpp", nargs="+", default=None,
+                    help="mvs_step_bench JSON files (the C++ step, every rank, several runs): model only, nothing is measured here")
+    ap.add_argument("--rank", type=int, default=0, help="the rank whose step is measured (clamped to G - 1)")
     args = ap.parse_args()
+    if args.from_cpp:
+        return from_cpp(args.from_cpp, args)
     dev = torch.device("cuda", 0)
     ctx = pkg.Context(0)
     ctx.set_stream(torch.cuda.current_stream())
@@ -84,14 +191,16 @@ def main():
             b, e = parallel.shard_rows(n, G, r)
             ctx.recode_rows(sset, sk[b:e] if e > b else None, r * P, P)
             n2_st[r * P:r * P + (e - b)] = n2[b:e]
-        b0, e0 = parallel.shard_rows(n, G, 0)
+        rank = min(args.rank, G - 1)                               # whose step is measured (the C++ tool measures all of them)
+        b0, e0 = parallel.shard_rows(n, G, rank)
+        f0 = rank * P                                              # the rank's frame in storage rows
         cap = max(1 << 21, 40 * (e0 - b0) + (1 << 20))
         raw = torch.empty((2 * cap, 4), dtype=torch.int32, device=dev)
         own = torch.empty((cap, 4), dtype=torch.int32, device=dev)
         outc = torch.empty((cap, 4), dtype=torch.int32, device=dev)
         d_own = torch.zeros(2 + (e0 - b0 + 2) // 2, dtype=torch.int64, device=dev)      # the shard's state block
         send = torch.zeros(_capi.CELLS_HEADER_BYTES + 16 * cap, dtype=torch.uint8, device=dev)
-        plan = parallel.block_plan(G, 0, P)
+        plan = parallel.block_plan(G, rank, P)
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(10)]
         acc = []
         lo = torch.zeros(n_alloc * d_pad, dtype=torch.int8, device=dev)
@@ -106,10 +215,10 @@ def main():
             """rank 0's step as parallel.ShardedComparison runs it; ev: ten events recorded between the stages, or stand-ins that
             record nothing (an event between two kernels costs the stream ~6 us: the wall is measured without them)"""
             ev[0].record()
-            ctx.recode_rows(sset, sk[b0:e0], 0, P)              # own rows only
+            ctx.recode_rows(sset, sk[b0:e0] if e0 > b0 else None, f0, P)      # own rows only
             ev[1].record()
             with ctx.options(plan_speculate=0 if args.no_speculate else 1):     # as parallel.GpuOps runs it
-                ctx.plan_begin(sset, n2_st, 0, P, G > 1, raw)
+                ctx.plan_begin(sset, n2_st, f0, f0 + P, G > 1, raw)
             ctx.plan_filter(plan[:1])
             ev[2].record()
             if len(plan) > 1:
