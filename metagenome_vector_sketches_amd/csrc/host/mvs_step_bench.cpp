@@ -24,7 +24,7 @@ static int fail(const char* what) {
 
 int main(int argc, char** argv) {
     std::string db;
-    int G = 1, only = -1, steps = 20, warmup = 5, probe = 3;
+    int G = 1, only = -1, steps = 20, warmup = 5, probe = 3, report_spin = -1;
     for (int i = 1; i + 1 < argc; i += 2) {
         const std::string a = argv[i];
         if (a == "--db") db = argv[i + 1];
@@ -33,6 +33,7 @@ int main(int argc, char** argv) {
         else if (a == "--steps") steps = atoi(argv[i + 1]);
         else if (a == "--warmup") warmup = atoi(argv[i + 1]);
         else if (a == "--probe") probe = atoi(argv[i + 1]);
+        else if (a == "--report-spin") report_spin = atoi(argv[i + 1]);      // microseconds mvs_cells_report polls before it blocks
         else {
             fprintf(stderr, "unknown flag %s\n", a.c_str());
             return 1;
@@ -57,6 +58,7 @@ int main(int argc, char** argv) {
     info.norms_sq.resize((size_t)N);
     mvs_ctx* ctx = nullptr;
     if (mvs_ctx_create(pick_device(), &ctx) != MVS_OK) return fail("creating context");
+    if (report_spin >= 0 && mvs_ctx_set_option(ctx, "report_spin", report_spin) != MVS_OK) return fail("report_spin");
     // the whole DB on the device: a rank's own rows and -- once -- what the exchange would have delivered of the others'
     mvs_step::DevMem all;
     {

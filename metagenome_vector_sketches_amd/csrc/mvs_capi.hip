@@ -192,6 +192,7 @@ const OptionSpec kOptions[] = {
     {"recode_rows_wg", &mvs::Options::recode_rows_wg, nullptr, 8, 16},
     {"plan_speculate", &mvs::Options::plan_speculate, nullptr, 0, 1},
     {"plan_order", &mvs::Options::plan_order, nullptr, 0, 1},
+    {"stream_piece_mib", &mvs::Options::stream_piece_mib, nullptr, 1, 1024},
     {"pairwise_block_cells", nullptr, &mvs::Options::pairwise_block_cells, 1, (1LL << 62)},
 };
 

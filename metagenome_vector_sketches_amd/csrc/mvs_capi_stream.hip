@@ -622,7 +622,7 @@ int pairwise_stream_impl(mvs_ctx* c, const mvs_sketch_set* s, const double* norm
         HIP_TRY(hipMemGetInfo(&free_b, &total_b));
         dense_budget = free_b / 3;
     }
-    const size_t piece_bytes = 32u << 20;                       // pinned buffer size: pinning costs ~0.3 ms per MiB
+    const size_t piece_bytes = (size_t)c->opt.stream_piece_mib << 20;   // pinned buffer size (32 MiB): pinning costs ~0.3 ms per MiB
     const int col_bits = bits_for(std::max<int64_t>(s->n - 1, 1));
     const int shift = 16 + col_bits;
     int rc = ensure_download_side(c);
@@ -650,7 +650,7 @@ int pairwise_stream_impl(mvs_ctx* c, const mvs_sketch_set* s, const double* norm
         auto sp = std::make_shared<BlockCsr>(std::move(blk));
         const bool enc = ecb != nullptr;
         StreamOut* o = &out;
-        out.enqueue_feed([c, o, sp, enc]() -> int {
+        out.enqueue_feed([c, o, sp, enc, piece_bytes]() -> int {
             return enc ? feed_encoded(c, *o, *sp, piece_bytes) : feed_block(c, *o, *sp, piece_bytes);
         });
         return MVS_OK;
@@ -1144,7 +1144,7 @@ int cells_stream_impl(mvs_ctx* c, const mvs_cell* cells, int64_t n, int64_t rb, 
     c->st_kernel_ms = 0.0;
     c->st_bytes = c->st_blocks = c->st_pieces = c->st_two_stage = 0;
     const int64_t rows = re - rb;
-    const size_t piece_bytes = 32u << 20;
+    const size_t piece_bytes = (size_t)c->opt.stream_piece_mib << 20;
     BlockCsr blk;
     blk.rb = rb;
     blk.re = re;

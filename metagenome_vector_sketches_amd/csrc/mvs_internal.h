@@ -83,6 +83,8 @@ struct Options {
                                     // are in flight (10^6 x 2048: 256 queries 0.654 -> 0.622 ms, 512 queries 1.146 -> 1.034 from 3 to 5)
     int stream_trace = 0;           // 1: mvs_pairwise_stream prints the host-side time line of its row blocks to stderr
     int recode_rows_wg = 8;         // k_recode_rows: rows (= waves) per workgroup, 8 or 16
+    int stream_piece_mib = 32;      // mvs_pairwise_stream / mvs_cells_stream: MiB per pinned buffer = per device-to-host copy (a copy is a
+                                    // blit kernel that fills the card while the link drains it: kernels that start beside one end with it)
     int plan_order = 1;             // block plans: 1 = filter launches of up to 2^20 tiles take the balanced tile order (PlanSegs::order),
                                     // 0 = the static super-patch map (A/B, tests)
     int plan_speculate = 0;         // block plans: second half of a plan sized from the previous plan's counts, no host round trip
