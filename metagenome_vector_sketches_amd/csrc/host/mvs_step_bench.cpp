@@ -136,12 +136,14 @@ int main(int argc, char** argv) {
                    "\"wall_instrumented_ms\": %.4f, \"prepare_own_rows_ms\": %.4f, \"plan_span_ms\": %.4f, \"cells_route_exchange_sort_ms\": %.4f, "
                    "\"diag_filter_ms\": %.4f, \"peer_filters_ms\": %.4f, \"finish_ms\": %.4f, \"filter_ms\": %.4f, \"recheck_ms\": %.4f, \"flagged_tiles_ms\": %.4f, \"filter_launches\": %lld, \"filter_tiles\": %lld, "
                    "\"candidates\": %lld, \"flagged_tiles\": %lld, \"own_cells\": %lld, \"foreign_cells\": %lld, \"plan_blocks\": %d, "
-                   "\"attempts_per_step\": %d, \"sorted_ahead\": %s, \"wire\": %s}",
+                   "\"attempts_per_step\": %d, \"sorted_ahead\": %s, \"wire\": %s, \"walls_ms\": [",
                    first_out ? "" : ", ", r, (long long)own.first, (long long)own.second, (long long)step.block_pad(), mean, median, sorted.front(),
                    inst.empty() ? 0.0 : inst.back(), si.prepare_own_rows_ms, si.plan_span_ms, si.cells_route_exchange_sort_ms, si.diag_filter_ms, si.peer_filters_ms, si.finish_ms, si.filter_ms, si.recheck_ms,
                    si.flagged_tiles_ms, (long long)si.filter_launches, (long long)si.filter_tiles, (long long)si.candidates, (long long)si.flagged_tiles,
                    (long long)step.n_cells(), (long long)si.exchanged_cells, si.blocks, plain.attempts, plain.sorted_ahead ? "true" : "false",
                    si.wire ? "true" : "false");
+            for (size_t k = 0; k < walls.size(); ++k) printf("%s%.4f", k ? ", " : "", walls[k]);
+            printf("]}");
             first_out = false;
             fflush(stdout);
         }

@@ -1025,8 +1025,10 @@ int pairwise_stream_impl(mvs_ctx* c, const mvs_sketch_set* s, const double* norm
     // launch k + 1 already runs on the context's stream -- memory-bound passes beside a matrix-core-bound kernel instead
     // of between two of them.  (stream_dense = 2: everything on the context's stream, one after the other.)
     side = dense && whole && blocks.size() > 1 &&
-           (lopt.stream_dense == 3 || (lopt.stream_dense == 1 && matrix_mode != kM2));
-    if (side) ps = c->post_stream;
+           (lopt.stream_dense >= 3 || (lopt.stream_dense == 1 && matrix_mode != kM2));
+    // stream_dense = 4 (experiment): the row passes on the DOWNLOAD stream itself -- between two pieces' copies instead of beside
+    // one (a device-to-host copy is a blit kernel that fills the card; a kernel that starts beside it ends with it)
+    if (side) ps = lopt.stream_dense == 4 ? c->dl_stream : c->post_stream;
     mark("setup", -1);
     if (!blocks.empty()) {
         rc = launch(0, dense);

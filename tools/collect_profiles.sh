@@ -10,6 +10,8 @@
 #             srch = 64 query sketches against 10^6 resident sketches (tools/search_bench.py: k_search_filter + re-check)
 #             c3s = the strong-scaled pairwise step on one rank (bench.py --config 3 --gpus 1: k_recode_rows, the block plan's
 #                   filter launch, re-check, flagged tiles, k_cells_route, the row-bucket sort)
+#             g8  = ONE rank's step of an 8-way split of configs[2] through the C++ host (bin/mvs_step_bench --ranks 8 --rank 1,
+#                   exchange bytes in place; needs the DB of tools/make_synth_db.py 100000 2048 2345 /tmp/mvs_r06_db_100000_2048/)
 # The profiled program itself follows `--` (no env / sh wrapper); counters are collected in their own passes.
 set -u
 TAG=${1:-r05}
@@ -44,9 +46,10 @@ if want c2x; then export MVS_PAIRWISE_FILTER=0; run_set c2x python3 "$REPO/tools
 if want c2d; then run_set c2d python3 "$REPO/tools/stream_bench.py" 100000 2048 10000 2 encoded || exit 1; fi
 if want srch; then run_set srch python3 "$REPO/tools/search_bench.py" 1000000 2048 64 6 || exit 1; fi
 if want c3s; then run_set c3s python3 "$REPO/bench.py" --config 3 --gpus 1 --steps 3 --warmup 2 || exit 1; fi
+if want g8; then run_set g8 "$REPO/metagenome_vector_sketches_amd/bin/mvs_step_bench" --db /tmp/mvs_r06_db_100000_2048/ --ranks 8 --rank 1 --steps 10 --warmup 3 --probe 0 || exit 1; fi
 
 cd "$REPO"
-for w in c1 c2 c2x c2d srch c3s; do
+for w in c1 c2 c2x c2d srch c3s g8; do
     [ -d "$OUT/${w}_stats" ] || continue
     python3 tools/pmc_summary.py --stats "$OUT/${w}_stats" > "$OUT/${w}_kernel_stats.txt"
     python3 tools/pmc_summary.py "$OUT/${w}_pmc" > "$OUT/${w}_pmc_summary.txt"
@@ -59,6 +62,7 @@ SPECS=""
 [ -d "$OUT/c2d_pmc" ] && SPECS="$SPECS dense-100k=$OUT/c2d_pmc"
 [ -d "$OUT/srch_pmc" ] && SPECS="$SPECS search-64x1M=$OUT/srch_pmc"
 [ -d "$OUT/c3s_pmc" ] && SPECS="$SPECS strong-configs[2]-1rank=$OUT/c3s_pmc"
+[ -d "$OUT/g8_pmc" ] && SPECS="$SPECS strong-configs[2]-rank1of8-cpp=$OUT/g8_pmc"
 python3 tools/pmc_summary.py --traffic "$OUT/pmc_traffic.json" $SPECS
 # keep the merged-back payload small: the raw per-dispatch CSVs of the PMC passes are summarised above
 find "$OUT" -name "*_counter_collection.csv" -size +4M -delete

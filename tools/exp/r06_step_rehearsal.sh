@@ -59,10 +59,12 @@ for tag in ("step8_1rank", "step8_8ranks", "step8_4ranks", "step8_2ranks", "proc
     print("%s: kept %d cells_checksum %016x%016x" % (tag, kept, s1 % 2**64, s2 % 2**64))
 PY
 } | tee "$OUT/summary.txt"
-# every rank's step of the G-way split timed alone on the card, exchange bytes in place (the C++ host): five runs
+# every rank's step of the G-way split timed alone on the card, exchange bytes in place (the C++ host): five runs.  60 warm-up
+# steps per rank: the card's power controller needs ~0.1 s to settle after the set-up phase (with 5 warm-up steps single
+# ranks of single runs measured 0.1 ms -- 7 % -- slower than the same rank in the next run)
 for rep in 1 2 3 4 5; do
   for G in 1 2 4 8; do
-    $B/mvs_step_bench --db $DB --ranks $G --steps 20 --warmup 5 > "$OUT/step_bench_G${G}_run${rep}.json" 2> "$OUT/step_bench_G${G}_run${rep}.stderr"
+    $B/mvs_step_bench --db $DB --ranks $G --steps ${STEPS:-60} --warmup ${WARMUP:-60} > "$OUT/step_bench_G${G}_run${rep}.json" 2> "$OUT/step_bench_G${G}_run${rep}.stderr"
   done
   echo "step_bench run $rep done" | tee -a "$OUT/progress.log"
 done

@@ -4,7 +4,7 @@
 set -e
 TAG=${1:-r05}
 SRC=gpurun_out/$TAG
-for w in c1 c2 c2x c2d srch c3s; do
+for w in c1 c2 c2x c2d srch c3s g8; do
     [ -f $SRC/${w}_kernel_stats.txt ] || continue
     grep "^k_" $SRC/${w}_kernel_stats.txt > profiles/${TAG}_${w}_kernel_stats.txt
     cp $SRC/${w}_pmc_summary.txt profiles/${TAG}_${w}_pmc_summary.txt
