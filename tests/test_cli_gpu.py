@@ -335,6 +335,55 @@ def test_step_mode_shard_folders_are_byte_identical_20k(tmp_path):
     _step_runs(exe, db, tmp_path, "c4", 4, 2, 4)
 
 
+def test_step_mode_edge_cases(gold, tmp_path):
+    """the strong-scaled step where its geometry degenerates or its defaults do not apply: fewer samples than shards (ranks
+    without a single row), an empty DB, an int16 DB (elem_bytes 2, the floating keep test of _16bits.cpp:218), a DB whose values
+    need three limbs (no filter: the exact kernel block by block, limb planes on the wire) -- `--shard_idx -1` as one rank and
+    as one rank per shard, byte-identical to the per-shard runs"""
+    from oracle import pyoracle as orc
+    from metagenome_vector_sketches_amd import synth
+    exe = os.path.join(BIN, "pairwise_comp_optimized")
+
+    def check(db, tag, shards, ranks_list):
+        base = ["--db", db, "--max_memory_gb", "1", "--num_threads", "4"]
+        ref = str(tmp_path / (tag + "_ref"))
+        for k in range(shards):
+            r = run(exe, *base, "--output_folder", ref, "--num_shards", str(shards), "--shard_idx", str(k))
+            assert r.returncode == 0, (tag, k, r.stderr)
+        want = _shard_bytes(ref, shards)
+        for ranks in ranks_list:
+            out = str(tmp_path / ("%s_r%d" % (tag, ranks)))
+            env = dict(os.environ, MVS_PAIRWISE_CONTEXTS=str(ranks), MVS_STAGE_TIMING="1")
+            env.pop("MVS_DEVICE", None)
+            r = subprocess.run([exe, *base, "--output_folder", out, "--num_shards", str(shards), "--shard_idx", "-1"], capture_output=True,
+                               text=True, env=env)
+            assert r.returncode == 0, (tag, ranks, r.stderr)
+            assert "%d shards in one step of %d rank(s)" % (shards, ranks) in r.stderr, r.stderr
+            assert _shard_bytes(out, shards) == want, (tag, ranks)
+        return ref
+
+    # five samples over eight shards: ceil(5 / 8) = 1 row per shard, shards 5..7 (and their ranks) own nothing
+    sk5 = synth.make_sketches_numpy(5, 256, 3000, seed=3, cluster=2)
+    db5 = str(tmp_path / "db5") + "/"
+    _write_db(db5, sk5)
+    ref5 = check(db5, "five", 8, [1, 8])
+    assert sum(len(_dump(os.path.join(ref5, "shard_%d" % k))) for k in range(8)) >= 5
+    # an empty DB
+    db0 = str(tmp_path / "db0") + "/"
+    _write_db(db0, np.zeros((0, 64), dtype=np.int32))
+    check(db0, "empty", 2, [1, 2])
+    # the reference's toy set as an int16 DB
+    db16 = str(tmp_path / "db16") + "/"
+    _write_ref_db(db16, gold, dtype="int16")
+    check(db16, "int16", 4, [1, 4])
+    # values beyond two limbs in ONE shard only
+    sk3 = synth.make_sketches_numpy(1500, 256, 3000, seed=11, cluster=8)
+    sk3[1400, 3] = 40000
+    db3 = str(tmp_path / "db3") + "/"
+    _write_db(db3, sk3)
+    check(db3, "limbs3", 3, [1, 3])
+
+
 def test_step_mode_falls_back_when_the_result_is_dense(tmp_path):
     """a result too dense for cell lists (here: the limit lowered to 1000 cells): every rank reads it in the exchanged headers
     and all of them take the streamed comparison of the round-1 scheme instead -- same files"""
