@@ -47,7 +47,7 @@ def source_sha():
     import hashlib
     h = hashlib.sha256()
     base = os.path.join(ROOT, "metagenome_vector_sketches_amd", "csrc")
-    for fn in ("mvs_project.hip", "mvs_pairwise.hip", "mvs_internal.h"):
+    for fn in ("mvs_project.hip", "mvs_pairwise.hip", "mvs_pairwise_dev.h", "mvs_recode.hip", "mvs_cells.hip", "mvs_internal.h"):
         with open(os.path.join(base, fn), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]
@@ -460,7 +460,10 @@ def main():
                 print(json.dumps(res), flush=True)
             else:
                 print("bench.py rank %d: strong legs: %s" % (rank, why), file=sys.stderr, flush=True)
-            os._exit(0)                                    # no collective teardown: the peers may be gone or stuck
+            # no collective teardown: the peers may be gone or stuck.  Exit code: 0 by default -- the headline of a launcher-run
+            # multi-GPU bench is complete and printed, an optional leg must not void it --, 3 with MVS_BENCH_STRICT=1 (CI that
+            # wants a failed or hung strong leg to show in the status)
+            os._exit(3 if os.environ.get("MVS_BENCH_STRICT") == "1" else 0)
 
         def fire():
             if not done.is_set():

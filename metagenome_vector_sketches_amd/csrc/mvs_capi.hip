@@ -193,6 +193,7 @@ const OptionSpec kOptions[] = {
     {"plan_speculate", &mvs::Options::plan_speculate, nullptr, 0, 1},
     {"plan_order", &mvs::Options::plan_order, nullptr, 0, 1},
     {"stream_piece_mib", &mvs::Options::stream_piece_mib, nullptr, 1, 1024},
+    {"stream_spec", &mvs::Options::stream_spec, nullptr, 0, 1},
     {"pairwise_block_cells", nullptr, &mvs::Options::pairwise_block_cells, 1, (1LL << 62)},
 };
 

@@ -415,6 +415,90 @@ int csr_from_dense(mvs_ctx* c, int64_t rb, int64_t re, int64_t n_cols, int64_t d
     return MVS_OK;
 }
 
+// The row passes of a dense block WITHOUT a host round trip in their middle (rows delivered encoded): csr_from_dense reads the
+// block's cell count back before it sizes the CSR arrays, encode_block the record sizes before it sizes the record buffer -- two
+// host round trips per block, each of them a bubble in front of kernels that then queue behind the link's copy kernels.  Here the
+// arrays are sized from what the blocks before this one held (cap_cells, cap_bytes: the caller's estimate with head room), all
+// passes are queued in one go -- the kernels drop what would not fit --, and ONE read-back at the end brings the row index, the
+// record directory and the totals: *held says whether the sizes held (if not, nothing of this block has been delivered and the
+// caller does it again the careful way).
+int rows_from_dense_spec(mvs_ctx* c, int64_t rb, int64_t re, int64_t n_cols, int64_t dense_row0, int64_t ld, int64_t block_index,
+                         BlockCsr& out, bool* odd, hipStream_t ps, mvs::DenseActive active, int64_t cap_cells, size_t cap_bytes,
+                         int stage_words, bool* held) {
+    *held = false;
+    *odd = false;
+    active.row_rel0 = rb - dense_row0;
+    const int64_t rows = re - rb;
+    out.rb = rb;
+    out.re = re;
+    out.wide = false;
+    out.set = (int)(block_index & 1);
+    out.row_ptr.assign((size_t)rows + 1, 0);
+    int rc = ensure_buf(c, &c->st_rowptr, &c->st_rowptr_bytes, (size_t)(rows + 1) * 8);
+    if (rc == MVS_OK) rc = ensure_buf(c, &c->st_counts, &c->st_counts_bytes, (size_t)(rows + 1) * 8);
+    if (rc) return rc;
+    int tr0 = 0, n_trows = 0, n_tc = 0;
+    mvs::dense_tile_rows(active, rows, n_cols, &tr0, &n_trows, &n_tc);
+    rc = ensure_buf(c, &c->st_tlist, &c->st_tlist_bytes, std::max<size_t>((size_t)n_trows * (size_t)n_tc * 4, 4));
+    if (rc == MVS_OK) rc = ensure_buf(c, &c->st_tlist_n, &c->st_tlist_n_bytes, std::max<size_t>((size_t)n_trows * 4, 4));
+    if (rc == MVS_OK) rc = ensure_buf(c, &c->st_ends, &c->st_ends_bytes, std::max<size_t>((size_t)rows * sizeof(int2), 8));
+    if (rc == MVS_OK) rc = ensure_buf(c, &c->en_size, &c->en_size_bytes, (size_t)(rows + 1) * 8);
+    if (rc == MVS_OK) rc = ensure_buf(c, &c->en_off, &c->en_off_bytes, (size_t)(rows + 1) * 8);
+    if (rc == MVS_OK) rc = ensure_buf(c, &c->en_jac, &c->en_jac_bytes, (size_t)rows * 4);
+    if (rc == MVS_OK) rc = ensure_buf(c, &c->en_first, &c->en_first_bytes, (size_t)rows * 4);
+    if (rc == MVS_OK) rc = ensure_buf(c, &c->en_par, &c->en_par_bytes, (size_t)rows * sizeof(mvs::EncRow));
+    if (rc == MVS_OK) rc = claim_csr_set(c, out.set, block_index, cap_cells, false, ps);
+    if (rc == MVS_OK) rc = ensure_buf(c, &c->st_enc[out.set], &c->st_enc_bytes[out.set], std::max<size_t>(cap_bytes, 8));
+    if (rc) return rc;
+    size_t need = 0, need2 = 0;
+    rc = mvs::dense_row_ptr(ps, (long long*)c->st_counts, (long long*)c->st_rowptr, rows, nullptr, 0, &need);
+    if (rc == MVS_OK) rc = mvs::encode_offsets(ps, (unsigned long long*)c->en_size, (unsigned long long*)c->en_off, rows, nullptr, 0, &need2);
+    if (rc) return fail(rc, "scan sizing failed");
+    rc = ensure_buf(c, &c->pw_sort, &c->pw_sort_bytes, std::max(need, need2));
+    if (rc) return rc;
+    const uint8_t* first = (const uint8_t*)c->st_dense + (size_t)(rb - dense_row0) * (size_t)ld;
+    HIP_TRY(hipMemsetAsync((char*)c->st_counts + (size_t)rows * 8, 0, 8, ps));
+    mvs::launch_dense_count(ps, first, ld, n_cols, rows, (long long*)c->st_counts, (int2*)c->st_ends, active, (int*)c->st_tlist,
+                            (int*)c->st_tlist_n);
+    rc = check_kernel("k_dense_count");
+    if (rc) return rc;
+    rc = mvs::dense_row_ptr(ps, (long long*)c->st_counts, (long long*)c->st_rowptr, rows, c->pw_sort, c->pw_sort_bytes, nullptr);
+    if (rc) return fail(rc, "scan of the row counts failed");
+    HIP_TRY(hipMemsetAsync((char*)c->en_size + (size_t)rows * 8, 0, 8, ps));
+    mvs::launch_dense_fill(ps, first, ld, n_cols, rows, (const long long*)c->st_rowptr, (int32_t*)c->st_col[out.set],
+                           (uint8_t*)c->st_q[out.set], active, (const int*)c->st_tlist, (const int*)c->st_tlist_n,
+                           (const int2*)c->st_ends, (unsigned long long*)c->en_size, (unsigned int*)c->en_jac, (unsigned int*)c->en_first,
+                           (mvs::EncRow*)c->en_par, (long long)cap_cells);
+    rc = check_kernel("k_dense_fill");
+    if (rc) return rc;
+    rc = mvs::encode_offsets(ps, (unsigned long long*)c->en_size, (unsigned long long*)c->en_off, rows, c->pw_sort, c->pw_sort_bytes, nullptr);
+    if (rc) return fail(rc, "scan of the record sizes failed");
+    HIP_TRY(hipMemsetAsync(c->st_enc[out.set], 0, cap_bytes, ps));        // the unary parts are OR-ed into zeroed words
+    mvs::launch_encode_fill(ps, (const long long*)c->st_rowptr, (const int32_t*)c->st_col[out.set], c->st_q[out.set], 1, rows,
+                            (const unsigned long long*)c->en_off, (const mvs::EncRow*)c->en_par, (unsigned char*)c->st_enc[out.set],
+                            stage_words, (unsigned long long)cap_cells, (unsigned long long)cap_bytes);
+    rc = check_kernel("k_enc_fill");
+    if (rc) return rc;
+    out.enc_off.assign((size_t)rows + 1, 0);
+    out.enc_jac.assign((size_t)rows, 0);
+    out.enc_first.assign((size_t)rows, 0);
+    unsigned int h_odd = 0;
+    rc = read_back(c, ps, {{out.row_ptr.data(), c->st_rowptr, (size_t)(rows + 1) * 8},
+                           {out.enc_off.data(), c->en_off, (size_t)(rows + 1) * 8},
+                           {out.enc_jac.data(), c->en_jac, (size_t)rows * 4},
+                           {out.enc_first.data(), c->en_first, (size_t)rows * 4},
+                           {&h_odd, c->d_counter + 4, 4}});
+    if (rc) return rc;
+    *odd = h_odd != 0;
+    out.n = out.row_ptr[(size_t)rows];
+    if (*odd || out.n > cap_cells || out.enc_off[(size_t)rows] > (uint64_t)cap_bytes) return MVS_OK;     // (*held stays false)
+    out.sizes_ready = true;
+    out.encoded = true;
+    *held = true;
+    HIP_TRY(hipEventRecord(c->dl_ready[out.set], ps));
+    return MVS_OK;
+}
+
 // the block's CSR arrays out through the two pinned buffers, in pieces of whole rows; the host blocks here only on the
 // pinned buffers (the device is free to run the next block's comparison meanwhile)
 int feed_block(mvs_ctx* c, StreamOut& out, const BlockCsr& b, size_t piece_bytes) {
@@ -645,7 +729,10 @@ int pairwise_stream_impl(mvs_ctx* c, const mvs_sketch_set* s, const double* norm
     // device-side work that is left (encoding the rows, where the caller asked for that), deliver = pieces to the link
     hipStream_t ps = c->stream;                                // where a block is turned into CSR / encoded rows (see `side`)
     bool side = false;
-    auto prepare = [&](BlockCsr& blk) -> int { return ecb ? encode_block(c, blk, ps) : MVS_OK; };
+    auto prepare = [&](BlockCsr& blk) -> int { return (ecb && !blk.encoded) ? encode_block(c, blk, ps) : MVS_OK; };
+    // what the dense blocks so far held per row (cells, record bytes): sizes the next block's buffers when its row passes are
+    // queued without reading its own totals first (rows_from_dense_spec, option stream_spec)
+    double spec_cells_per_row = -1.0, spec_bytes_per_row = -1.0;
     auto deliver = [&](BlockCsr& blk) -> int {
         auto sp = std::make_shared<BlockCsr>(std::move(blk));
         const bool enc = ecb != nullptr;
@@ -1053,8 +1140,17 @@ int pairwise_stream_impl(mvs_ctx* c, const mvs_sketch_set* s, const double* norm
         }
         wait_for_set((int64_t)k);
         if (dense) {
-            bool odd = false;
-            rc = csr_from_dense(c, rb, re, s->n, whole ? row_begin : rb, ld, (int64_t)k, blk, &odd, ps, active, ecb != nullptr);
+            bool odd = false, held = false;
+            if (ecb && lopt.stream_spec != 0 && spec_cells_per_row >= 0.0) {
+                const double rows_k = (double)(re - rb);
+                const int64_t cap_cells = (int64_t)(rows_k * spec_cells_per_row * 1.3) + 65536;
+                const size_t cap_bytes = ((size_t)(rows_k * spec_bytes_per_row * 1.3) + ((size_t)1 << 20) + 7) & ~(size_t)7;
+                rc = rows_from_dense_spec(c, rb, re, s->n, whole ? row_begin : rb, ld, (int64_t)k, blk, &odd, ps, active, cap_cells, cap_bytes,
+                                          lopt.encode_stage_words, &held);
+                if (rc) return finish(rc);
+                if (!held) blk = BlockCsr();          // the sizes did not hold (or a 16-bit q): the careful way below
+            }
+            if (!held) rc = csr_from_dense(c, rb, re, s->n, whole ? row_begin : rb, ld, (int64_t)k, blk, &odd, ps, active, ecb != nullptr);
             if (rc) return finish(rc);
             mark("csr", (long)k);
             if (!side) add_kernel_ms();
@@ -1097,6 +1193,10 @@ int pairwise_stream_impl(mvs_ctx* c, const mvs_sketch_set* s, const double* norm
         ++c->st_blocks;
         rc = prepare(blk);
         if (rc) return finish(rc);
+        if (dense && ecb && blk.encoded && re > rb) {
+            spec_cells_per_row = std::max(spec_cells_per_row, (double)blk.n / (double)(re - rb));
+            spec_bytes_per_row = std::max(spec_bytes_per_row, (double)blk.enc_off[(size_t)(re - rb)] / (double)(re - rb));
+        }
         mark("enc", (long)k);
         if (!next_launched && k + 1 < blocks.size() && !out.failed()) {   // the next block computes while this one is fed to the link
             rc = launch(k + 1, dense);

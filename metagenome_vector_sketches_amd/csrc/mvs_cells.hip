@@ -173,7 +173,9 @@ __global__ __launch_bounds__(256) void k_dense_fill(const uint8_t* __restrict__ 
                                                     const long long* __restrict__ row_ptr, int32_t* __restrict__ col,
                                                     uint8_t* __restrict__ q, long long row_rel0, int tr0, int n_tc,
                                                     const int* __restrict__ list, const int* __restrict__ list_n,
-                                                    const int2* __restrict__ ends, const DenseSizes out) {
+                                                    const int2* __restrict__ ends, const DenseSizes out, long long capacity) {
+    // capacity: entries col / q hold (a caller that sized them from the PREVIOUS row block, without reading this block's count
+    // back first; stores beyond it are dropped and the caller, who learns the count afterwards, does the block again)
     // A lane scatters a RUN of up to 16 entries starting at its prefix position; in a dense row those positions are 16 apart,
     // i.e. 16 words (columns) or 4 words (q bytes) apart: a 16-way / 4-way bank conflict on every store of the loop
     // (SQ_LDS_BANK_CONFLICT 2.8e7 cycles per launch, round 4).  One pad word per 16 entries (columns: index i lives at
@@ -257,8 +259,10 @@ __global__ __launch_bounds__(256) void k_dense_fill(const uint8_t* __restrict__ 
         for (unsigned i = threadIdx.x; i < total; i += 256) {
             const int32_t cv = s_col[ci(i)];
             const unsigned qv = s_q[qi(i)];
-            col[base + i] = cv;
-            q[base + i] = (uint8_t)qv;
+            if (base + i < capacity) {
+                col[base + i] = cv;
+                q[base + i] = (uint8_t)qv;
+            }
             if (SIZES) {
                 qmax = qv > qmax ? qv : qmax;
                 if (i > 0) quot += (unsigned long long)(unsigned)(cv - s_col[ci(i - 1)]) >> rice_k;
@@ -770,17 +774,18 @@ int dense_row_ptr(hipStream_t stream, long long* d_counts, long long* d_row_ptr,
 // d_size non-NULL: the shard encoder's per-row sizes as well (size / jac / first_col / par of launch_encode_sizes)
 int launch_dense_fill(hipStream_t stream, const uint8_t* d_dense, int64_t ld, int64_t n_cols, int64_t rows, const long long* d_row_ptr,
                       int32_t* d_col, uint8_t* d_q, const DenseActive& active, const int* d_list, const int* d_list_n,
-                      const int2* d_ends, unsigned long long* d_size, unsigned int* d_jac, unsigned int* d_first_col, EncRow* d_par) {
+                      const int2* d_ends, unsigned long long* d_size, unsigned int* d_jac, unsigned int* d_first_col, EncRow* d_par,
+                      long long capacity) {
     if (rows <= 0) return 0;
     int tr0, n_trows, n_tc;
     dense_tile_rows(active, rows, n_cols, &tr0, &n_trows, &n_tc);
     const DenseSizes out{d_size, d_jac, d_first_col, d_par};
     if (d_size)
         hipLaunchKernelGGL(k_dense_fill<true>, dim3((unsigned)rows), dim3(256), 0, stream, d_dense, (long long)ld, (long long)n_cols,
-                           d_row_ptr, d_col, d_q, (long long)active.row_rel0, tr0, n_tc, d_list, d_list_n, d_ends, out);
+                           d_row_ptr, d_col, d_q, (long long)active.row_rel0, tr0, n_tc, d_list, d_list_n, d_ends, out, capacity);
     else
         hipLaunchKernelGGL(k_dense_fill<false>, dim3((unsigned)rows), dim3(256), 0, stream, d_dense, (long long)ld, (long long)n_cols,
-                           d_row_ptr, d_col, d_q, (long long)active.row_rel0, tr0, n_tc, d_list, d_list_n, d_ends, out);
+                           d_row_ptr, d_col, d_q, (long long)active.row_rel0, tr0, n_tc, d_list, d_list_n, d_ends, out, capacity);
     return 0;
 }
 

@@ -28,7 +28,8 @@ int encode_offsets(hipStream_t stream, unsigned long long* d_size, unsigned long
 // stage_words (1..64): words of LDS a chunk of 64 unary codes may span before the kernel falls back to atomics (64; tests
 // lower it to exercise the fallback)
 int launch_encode_fill(hipStream_t stream, const long long* d_row_ptr, const int32_t* d_col, const void* d_q, int q_bytes,
-                       int64_t rows, const unsigned long long* d_offset, const EncRow* d_par, unsigned char* d_out, int stage_words);
+                       int64_t rows, const unsigned long long* d_offset, const EncRow* d_par, unsigned char* d_out, int stage_words,
+                       unsigned long long cap_cells = ~0ULL, unsigned long long cap_bytes = ~0ULL);
 
 // A list of kept cells ordered by (row, col) -> the CSR arrays above for rows [row0, row0 + rows) (mvs_cells_stream*):
 // d_abs_ptr[r] = index of the first cell of row row0 + r in the list (rows + 1 entries), then the columns / q of those cells

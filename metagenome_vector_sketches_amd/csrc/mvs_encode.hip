@@ -296,13 +296,16 @@ template <typename Q>
 __global__ __launch_bounds__(64) void k_enc_fill(const long long* __restrict__ row_ptr, const int32_t* __restrict__ col,
                                                  const Q* __restrict__ q, const u64* __restrict__ offset,
                                                  const EncRow* __restrict__ par, unsigned char* __restrict__ out, unsigned stage_words,
-                                                 int fast_rows) {
+                                                 int fast_rows, u64 cap_cells, u64 cap_bytes) {
     __shared__ u64 st_q[2][64], st_l[2][64], st_h[2][64];
     const long long r = blockIdx.x;
     const int lane = threadIdx.x;
     const long long b = row_ptr[r], e = row_ptr[r + 1];
     const u64 n = (u64)(e - b);
     if (n == 0) return;
+    // buffers sized from the previous row block (no read-back of this block's totals in front of the launch): a row whose cells or
+    // record lie beyond them is skipped -- the caller reads the totals afterwards and does the block again
+    if ((u64)e > cap_cells || offset[r + 1] > cap_bytes) return;
     const EncRow pr = par[r];
     const unsigned wq = pr.wq, k = pr.k;
     u64* w = reinterpret_cast<u64*>(out + offset[r]);
@@ -496,7 +499,8 @@ int encode_offsets(hipStream_t stream, unsigned long long* d_size, unsigned long
 }
 
 int launch_encode_fill(hipStream_t stream, const long long* d_row_ptr, const int32_t* d_col, const void* d_q, int q_bytes,
-                       int64_t rows, const unsigned long long* d_offset, const EncRow* d_par, unsigned char* d_out, int stage_words) {
+                       int64_t rows, const unsigned long long* d_offset, const EncRow* d_par, unsigned char* d_out, int stage_words,
+                       unsigned long long cap_cells, unsigned long long cap_bytes) {
     if (rows <= 0) return 0;
     const unsigned sw = stage_words < 1 ? 1u : (stage_words > 64 ? 64u : (unsigned)stage_words);
     // stage_words = 64 (the default): common rows (8-bit q, Rice parameter <= 16) take the four-cells-per-lane loop; a lower
@@ -504,10 +508,10 @@ int launch_encode_fill(hipStream_t stream, const long long* d_row_ptr, const int
     const int fast = stage_words == 64 ? 1 : 0;
     if (q_bytes == 2)
         hipLaunchKernelGGL(k_enc_fill<uint16_t>, dim3((unsigned)rows), dim3(64), 0, stream, d_row_ptr, d_col, (const uint16_t*)d_q,
-                           d_offset, d_par, d_out, sw, fast);
+                           d_offset, d_par, d_out, sw, fast, cap_cells, cap_bytes);
     else
         hipLaunchKernelGGL(k_enc_fill<uint8_t>, dim3((unsigned)rows), dim3(64), 0, stream, d_row_ptr, d_col, (const uint8_t*)d_q,
-                           d_offset, d_par, d_out, sw, fast);
+                           d_offset, d_par, d_out, sw, fast, cap_cells, cap_bytes);
     return 0;
 }
 

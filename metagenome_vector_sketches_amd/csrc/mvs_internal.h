@@ -83,6 +83,10 @@ struct Options {
                                     // are in flight (10^6 x 2048: 256 queries 0.654 -> 0.622 ms, 512 queries 1.146 -> 1.034 from 3 to 5)
     int stream_trace = 0;           // 1: mvs_pairwise_stream prints the host-side time line of its row blocks to stderr
     int recode_rows_wg = 8;         // k_recode_rows: rows (= waves) per workgroup, 8 or 16
+    int stream_spec = 1;            // mvs_pairwise_stream_encoded, dense row blocks: 1 = a block's row passes (count, scan, fill, scan, encode)
+                                    // are queued in one go with buffers sized from the blocks before it and ONE read-back at the end says
+                                    // whether the sizes held (else the block is done again the careful way); 0 = read the count back before
+                                    // the fill and the record sizes before the encode (two host round trips per block)
     int stream_piece_mib = 32;      // mvs_pairwise_stream / mvs_cells_stream: MiB per pinned buffer = per device-to-host copy (a copy is a
                                     // blit kernel that fills the card while the link drains it: kernels that start beside one end with it)
     int plan_order = 1;             // block plans: 1 = filter launches of up to 2^20 tiles take the balanced tile order (PlanSegs::order),
@@ -308,7 +312,8 @@ int dense_row_ptr(hipStream_t stream, long long* d_counts, long long* d_row_ptr,
 struct EncRow;
 int launch_dense_fill(hipStream_t stream, const uint8_t* d_dense, int64_t ld, int64_t n_cols, int64_t rows, const long long* d_row_ptr,
                       int32_t* d_col, uint8_t* d_q, const DenseActive& active, const int* d_list, const int* d_list_n,
-                      const int2* d_ends, unsigned long long* d_size, unsigned int* d_jac, unsigned int* d_first_col, EncRow* d_par);
+                      const int2* d_ends, unsigned long long* d_size, unsigned int* d_jac, unsigned int* d_first_col, EncRow* d_par,
+                      long long capacity = 0x7fffffffffffffffLL);
 // the re-check's kept cells (packed words, *d_n of them, rows relative to pack_row0 = the matrix's first row) into the dense
 // byte matrix: mark the tiles they fall into (newly touched ones are listed in d_new, count in d_new[-1] .. i.e. d_new_count),
 // clear those tiles, then write the bytes; *d_odd is set when a q is not in 1..255

@@ -96,18 +96,28 @@ def _cells(cells, rb=0, re=1 << 62):
     return [(int(c["row"]), int(c["col"]), int(c["q"])) for c in cells if rb <= c["row"] < re]
 
 
-@pytest.mark.parametrize("case", ["sparse", "dense-blocks", "dense-small-stage", "one-limb-packed", "wide-q", "toy"])
+@pytest.mark.parametrize("case", ["sparse", "dense-blocks", "dense-blocks-careful", "dense-rising", "dense-small-stage", "one-limb-packed",
+                                  "wide-q", "toy"])
 def test_encoded_rows_decode_to_the_cell_list(ctx, gold, case):
     budget, rb, re = 0, 0, None
     if case == "sparse":
         sk = synth.make_sketches_numpy(700, 512, 3000, seed=5, cluster=8)
         ctx.set_option("pairwise_filter", 2)
         rb, re = 100, 650
-    elif case in ("dense-blocks", "dense-small-stage"):   # rows of ~500 cells: several 64-value chunks per row
+    elif case in ("dense-blocks", "dense-blocks-careful", "dense-small-stage"):   # rows of ~500 cells: several 64-value chunks per row
         sk = synth.make_sketches_numpy(1500, 256, 3000, seed=77, cluster=500, shared=0.6)
         ctx.set_option("stream_block_rows", 256)
         if case == "dense-small-stage":    # a stage of one word: most chunks of unary codes take the atomics fall-back
             ctx.set_option("encode_stage_words", 1)
+        if case == "dense-blocks-careful":  # the row passes with a read-back in front of the fill and of the encode (option stream_spec)
+            ctx.set_option("stream_spec", 0)
+    elif case == "dense-rising":
+        # rows that get denser block by block: the buffers a block's row passes were given -- sized from the blocks before it,
+        # without reading this block's totals first -- do not hold, and the block is done again the careful way
+        sk = np.concatenate([synth.make_sketches_numpy(512, 256, 3000, seed=5, cluster=8),
+                             synth.make_sketches_numpy(400, 256, 3000, seed=6, cluster=100, shared=0.6),
+                             synth.make_sketches_numpy(1100, 256, 3000, seed=7, cluster=550, shared=0.6)])
+        ctx.set_option("stream_block_rows", 256)
     elif case == "one-limb-packed":    # |v| <= 127: the 32x32x32 kernel, packed list, blocks sized for the worst case
         sk = np.clip(synth.make_sketches_numpy(600, 256, 300, seed=3, cluster=50, shared=0.6), -127, 127).astype(np.int32)
         budget = 1 << 20
@@ -134,6 +144,7 @@ def test_encoded_rows_decode_to_the_cell_list(ctx, gold, case):
     finally:
         ctx.set_option("stream_block_rows", 0)
         ctx.set_option("encode_stage_words", 64)
+        ctx.set_option("stream_spec", 1)
 
 
 @pytest.mark.parametrize("cluster", [2, 3, 4, 5, 63, 64, 65, 128, 129, 193, 255, 256, 257, 511, 513])
