@@ -63,7 +63,7 @@ def kernel_stats(d):
 def source_sha():
     h = hashlib.sha256()
     base = os.path.join(ROOT, "metagenome_vector_sketches_amd", "csrc")
-    for fn in ("mvs_project.hip", "mvs_pairwise.hip", "mvs_internal.h"):
+    for fn in ("mvs_project.hip", "mvs_pairwise.hip", "mvs_pairwise_dev.h", "mvs_recode.hip", "mvs_cells.hip", "mvs_internal.h"):
         with open(os.path.join(base, fn), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]
