@@ -83,10 +83,12 @@ struct Options {
                                     // are in flight (10^6 x 2048: 256 queries 0.654 -> 0.622 ms, 512 queries 1.146 -> 1.034 from 3 to 5)
     int stream_trace = 0;           // 1: mvs_pairwise_stream prints the host-side time line of its row blocks to stderr
     int recode_rows_wg = 8;         // k_recode_rows: rows (= waves) per workgroup, 8 or 16
-    int stream_spec = 1;            // mvs_pairwise_stream_encoded, dense row blocks: 1 = a block's row passes (count, scan, fill, scan, encode)
+    int stream_spec = 0;            // mvs_pairwise_stream_encoded, dense row blocks: 1 = a block's row passes (count, scan, fill, scan, encode)
                                     // are queued in one go with buffers sized from the blocks before it and ONE read-back at the end says
-                                    // whether the sizes held (else the block is done again the careful way); 0 = read the count back before
-                                    // the fill and the record sizes before the encode (two host round trips per block)
+                                    // whether the sizes held (else the block is done again the careful way); 0 (default) = read the count
+                                    // back before the fill and the record sizes before the encode (two host round trips per block).
+                                    // Measured (10 % dense 100k): 33.5 against 33.0 ms -- the producer is not bound by its host round
+                                    // trips but by the link's copy kernels on the CUs (profiles/r06_exp_dense_output.log)
     int stream_piece_mib = 32;      // mvs_pairwise_stream / mvs_cells_stream: MiB per pinned buffer = per device-to-host copy (a copy is a
                                     // blit kernel that fills the card while the link drains it: kernels that start beside one end with it)
     int plan_order = 1;             // block plans: 1 = filter launches of up to 2^20 tiles take the balanced tile order (PlanSegs::order),

@@ -109,8 +109,10 @@ def test_encoded_rows_decode_to_the_cell_list(ctx, gold, case):
         ctx.set_option("stream_block_rows", 256)
         if case == "dense-small-stage":    # a stage of one word: most chunks of unary codes take the atomics fall-back
             ctx.set_option("encode_stage_words", 1)
-        if case == "dense-blocks-careful":  # the row passes with a read-back in front of the fill and of the encode (option stream_spec)
+        if case == "dense-blocks-careful":  # the row passes with a read-back in front of the fill and of the encode (the default)
             ctx.set_option("stream_spec", 0)
+        else:                               # ... queued in one go with buffers sized from the blocks before (option stream_spec)
+            ctx.set_option("stream_spec", 1)
     elif case == "dense-rising":
         # rows that get denser block by block: the buffers a block's row passes were given -- sized from the blocks before it,
         # without reading this block's totals first -- do not hold, and the block is done again the careful way
@@ -118,6 +120,7 @@ def test_encoded_rows_decode_to_the_cell_list(ctx, gold, case):
                              synth.make_sketches_numpy(400, 256, 3000, seed=6, cluster=100, shared=0.6),
                              synth.make_sketches_numpy(1100, 256, 3000, seed=7, cluster=550, shared=0.6)])
         ctx.set_option("stream_block_rows", 256)
+        ctx.set_option("stream_spec", 1)
     elif case == "one-limb-packed":    # |v| <= 127: the 32x32x32 kernel, packed list, blocks sized for the worst case
         sk = np.clip(synth.make_sketches_numpy(600, 256, 300, seed=3, cluster=50, shared=0.6), -127, 127).astype(np.int32)
         budget = 1 << 20
@@ -144,7 +147,7 @@ def test_encoded_rows_decode_to_the_cell_list(ctx, gold, case):
     finally:
         ctx.set_option("stream_block_rows", 0)
         ctx.set_option("encode_stage_words", 64)
-        ctx.set_option("stream_spec", 1)
+        ctx.set_option("stream_spec", 0)
 
 
 @pytest.mark.parametrize("cluster", [2, 3, 4, 5, 63, 64, 65, 128, 129, 193, 255, 256, 257, 511, 513])
