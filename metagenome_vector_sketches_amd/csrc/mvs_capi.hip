@@ -194,6 +194,7 @@ const OptionSpec kOptions[] = {
     {"plan_order", &mvs::Options::plan_order, nullptr, 0, 1},
     {"stream_piece_mib", &mvs::Options::stream_piece_mib, nullptr, 1, 1024},
     {"stream_spec", &mvs::Options::stream_spec, nullptr, 0, 1},
+    {"stream_copy", &mvs::Options::stream_copy, nullptr, 0, 1},
     {"pairwise_block_cells", nullptr, &mvs::Options::pairwise_block_cells, 1, (1LL << 62)},
 };
 
@@ -365,6 +366,7 @@ int mvs_ctx_destroy(mvs_ctx* c) {
     }
     for (hipEvent_t ev : c->dl_ready) if (ev) (void)hipEventDestroy(ev);
     if (c->dl_stream) (void)hipStreamDestroy(c->dl_stream);
+    if (c->dl_hsa && c->dl_hsa_free) c->dl_hsa_free(c->dl_hsa);
     if (c->post_stream) (void)hipStreamDestroy(c->post_stream);
     if (c->cmp_done) (void)hipEventDestroy(c->cmp_done);
     if (c->pw_chdr) (void)hipFree(c->pw_chdr);

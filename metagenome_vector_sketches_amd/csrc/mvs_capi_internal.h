@@ -89,6 +89,8 @@ struct mvs_ctx {
     hipEvent_t dl_done[2] = {nullptr, nullptr};   // download into pinned buffer i has completed
     hipEvent_t dl_block[2] = {nullptr, nullptr};  // the downloads out of CSR array set i have completed
     hipEvent_t dl_ready[2] = {nullptr, nullptr};  // the arrays of the row block in set i are final on the compute stream
+    void* dl_hsa = nullptr;                       // option stream_copy = 1: agents + completion signals of the DMA copies
+    void (*dl_hsa_free)(void*) = nullptr;         // (mvs_capi_stream.hip owns the type)
     hipStream_t post_stream = nullptr;            // dense row blocks -> CSR / encoded rows beside the next block's comparison
     hipEvent_t cmp_done = nullptr;                // the comparison launch of the block about to be post-processed is through
     // what the last mvs_pairwise_stream did (mvs_ctx_stream_stats)

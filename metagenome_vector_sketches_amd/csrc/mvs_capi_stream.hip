@@ -1,6 +1,9 @@
 // mvs_capi_stream.hip -- C ABI: the comparison with its result streamed out in row blocks (mvs_pairwise_stream[_encoded])
 #include "mvs_capi_internal.h"
 
+#include <hsa/hsa.h>
+#include <hsa/hsa_ext_amd.h>
+
 using namespace mvs_capi;
 
 extern "C" {
@@ -18,6 +21,78 @@ int bits_for(int64_t max_value) {          // bits that hold 0 .. max_value
     return b;
 }
 
+// Device -> host copies on a DMA engine instead of the runtime's copy kernel (option stream_copy = 1).  hipMemcpyAsync into pinned
+// memory is a blit KERNEL on this stack (__amd_rocclr_copyBuffer in the traces): it reaches the link's rate but holds compute units
+// while the link drains it.  hsa_amd_memory_async_copy moves the same bytes at the same 56 GB/s with no CU involved
+// (tools/microbench/sdma_copy.hip).  ROCr is the layer HIP itself sits on: same process, same address space, pointers of hipMalloc /
+// hipHostMalloc are valid as they are.  The copies are not on a HIP stream any more, so their ordering is the host's: the feeder
+// waits for the block's arrays (dl_ready) before the first copy, the callback thread waits for a piece's completion signal, and
+// the driving thread re-uses a set of arrays once the callback thread has seen the last piece of the block that used it.
+struct HsaCopy {
+    hsa_agent_t gpu{}, cpu{};
+    hsa_signal_t sig[2]{};
+    bool ok = false;
+};
+struct HsaAgents {
+    std::vector<hsa_agent_t> gpus;
+    hsa_agent_t cpu{};
+    bool have_cpu = false;
+};
+hsa_status_t hsa_on_agent(hsa_agent_t a, void* data) {
+    HsaAgents* ag = static_cast<HsaAgents*>(data);
+    hsa_device_type_t t;
+    if (hsa_agent_get_info(a, HSA_AGENT_INFO_DEVICE, &t) != HSA_STATUS_SUCCESS) return HSA_STATUS_SUCCESS;
+    if (t == HSA_DEVICE_TYPE_GPU) ag->gpus.push_back(a);
+    if (t == HSA_DEVICE_TYPE_CPU && !ag->have_cpu) {
+        ag->cpu = a;
+        ag->have_cpu = true;
+    }
+    return HSA_STATUS_SUCCESS;
+}
+void hsa_copy_free(void* p) {
+    HsaCopy* h = static_cast<HsaCopy*>(p);
+    if (h->ok) {
+        for (hsa_signal_t& s : h->sig) (void)hsa_signal_destroy(s);
+        (void)hsa_shut_down();
+    }
+    delete h;
+}
+int ensure_hsa_copy(mvs_ctx* c) {
+    if (c->dl_hsa) return static_cast<HsaCopy*>(c->dl_hsa)->ok ? MVS_OK : fail(MVS_E_HIP, "the DMA copy path is not available");
+    HsaCopy* h = new (std::nothrow) HsaCopy();
+    if (!h) return fail(MVS_E_NOMEM, "out of host memory");
+    c->dl_hsa = h;
+    c->dl_hsa_free = hsa_copy_free;
+    if (hsa_init() != HSA_STATUS_SUCCESS) return fail(MVS_E_HIP, "hsa_init failed");
+    HsaAgents ag;
+    if (hsa_iterate_agents(hsa_on_agent, &ag) != HSA_STATUS_SUCCESS || ag.gpus.empty() || !ag.have_cpu) {
+        (void)hsa_shut_down();
+        return fail(MVS_E_HIP, "no HSA agents");
+    }
+    // the context's device among the GPU agents: by PCI bus / device / function, by index if that cannot be read
+    size_t pick = (size_t)c->device < ag.gpus.size() ? (size_t)c->device : 0;
+    char bus[32] = {0};
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, c->device) == hipSuccess) {
+        unsigned dom = 0, b = 0, d = 0, f = 0;
+        if (sscanf(bus, "%x:%x:%x.%x", &dom, &b, &d, &f) == 4)
+            for (size_t k = 0; k < ag.gpus.size(); ++k) {
+                uint32_t bdf = 0;
+                if (hsa_agent_get_info(ag.gpus[k], (hsa_agent_info_t)HSA_AMD_AGENT_INFO_BDFID, &bdf) == HSA_STATUS_SUCCESS &&
+                    ((bdf >> 8) & 0xff) == b && ((bdf >> 3) & 0x1f) == d && (bdf & 0x7) == f)
+                    pick = k;
+            }
+    }
+    h->gpu = ag.gpus[pick];
+    h->cpu = ag.cpu;
+    for (hsa_signal_t& sg : h->sig)
+        if (hsa_signal_create(0, 0, nullptr, &sg) != HSA_STATUS_SUCCESS) {
+            (void)hsa_shut_down();
+            return fail(MVS_E_HIP, "hsa_signal_create failed");
+        }
+    h->ok = true;
+    return MVS_OK;
+}
+
 // Hand-over between the thread that drives the GPU and the one that runs the caller's callback: two pinned buffers,
 // a queue of filled ones.  The callback therefore runs beside the next block's kernels and downloads.
 struct StreamOut {
@@ -30,6 +105,8 @@ struct StreamOut {
         std::vector<uint32_t> rows, first_col, jac_bytes;
         std::vector<uint64_t> offset;
         int64_t n_bytes = 0;
+        bool dma = false;                  // the piece was copied by a DMA engine: its completion is the slot's HSA signal
+        bool last_of_block = false;        // (DMA copies) the callback thread has seen a block's last piece: its arrays are free again
     };
     mvs_ctx* c;
     mvs_row_block_cb cb = nullptr;
@@ -50,6 +127,7 @@ struct StreamOut {
     std::deque<std::function<int()>> feed_queue;
     bool feed_closing = false;
     int64_t fed_blocks = 0;                // blocks whose pieces have all been queued on the download stream
+    int64_t done_blocks = 0;               // (DMA copies) blocks whose last piece the callback thread has consumed
     int feed_rc = 0;
 
     void feed_run() {
@@ -86,6 +164,10 @@ struct StreamOut {
         std::unique_lock<std::mutex> lk(mu);
         cv.wait(lk, [&] { return fed_blocks >= blocks; });
     }
+    void wait_done(int64_t blocks) {        // (DMA copies) until that many blocks have left the device entirely
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return done_blocks >= blocks || cb_status != 0 || !error.empty() || feed_rc != 0; });
+    }
     void close_feeder() {
         {
             std::lock_guard<std::mutex> lk(mu);
@@ -107,7 +189,14 @@ struct StreamOut {
                 queue.pop_front();
             }
             int status = 0;
-            const hipError_t e = hipEventSynchronize(c->dl_done[it.slot]);
+            hipError_t e = hipSuccess;
+            if (it.dma) {
+                const HsaCopy* h = static_cast<const HsaCopy*>(c->dl_hsa);
+                if (hsa_signal_wait_scacquire(h->sig[it.slot], HSA_SIGNAL_CONDITION_LT, 1, UINT64_MAX, HSA_WAIT_STATE_BLOCKED) != 0)
+                    e = hipErrorUnknown;       // (a negative value: the copy failed)
+            } else {
+                e = hipEventSynchronize(c->dl_done[it.slot]);
+            }
             if (e != hipSuccess) {
                 std::lock_guard<std::mutex> lk(mu);
                 if (error.empty()) error = std::string("download failed: ") + hipGetErrorString(e);
@@ -156,6 +245,7 @@ struct StreamOut {
                 std::lock_guard<std::mutex> lk(mu);
                 if (status != 0 && cb_status == 0) cb_status = status;
                 slot_busy[it.slot] = false;
+                if (it.last_of_block) ++done_blocks;
             }
             cv.notify_all();
         }
@@ -291,7 +381,8 @@ int encode_block(mvs_ctx* c, BlockCsr& b, hipStream_t ps) {
 
 // before the CSR arrays of set `set` are rewritten: the downloads of the block that used them last (two blocks ago) are through
 int claim_csr_set(mvs_ctx* c, int set, int64_t block_index, int64_t n, bool wide, hipStream_t ps) {
-    if (block_index >= 2) HIP_TRY(hipStreamWaitEvent(ps, c->dl_block[set], 0));
+    // (with DMA copies the driving thread has waited for the callback thread to see that block's last piece: StreamOut::wait_done)
+    if (block_index >= 2 && c->opt.stream_copy == 0) HIP_TRY(hipStreamWaitEvent(ps, c->dl_block[set], 0));
     int rc = ensure_buf(c, &c->st_col[set], &c->st_col_bytes[set], (size_t)std::max<int64_t>(n, 1) * 4);
     if (rc) return rc;
     return ensure_buf(c, &c->st_q[set], &c->st_q_bytes[set], (size_t)std::max<int64_t>(n, 1) * (wide ? 2 : 1));
@@ -525,6 +616,12 @@ int feed_block(mvs_ctx* c, StreamOut& out, const BlockCsr& b, size_t piece_bytes
         need_bytes = std::max(need_bytes, (size_t)(row_ptr[(size_t)r1] - row_ptr[(size_t)r0]) * cell_bytes);
         r0 = r1;
     }
+    const bool dma = c->opt.stream_copy != 0;
+    if (dma) {
+        rc = ensure_hsa_copy(c);
+        if (rc) return rc;
+        HIP_TRY(hipEventSynchronize(c->dl_ready[b.set]));      // the block's arrays are final (this thread only feeds)
+    }
     for (int64_t r0 = 0; r0 < rows;) {
         const int64_t r1 = piece_end(r0);
         const int64_t c0 = row_ptr[(size_t)r0];
@@ -544,8 +641,32 @@ int feed_block(mvs_ctx* c, StreamOut& out, const BlockCsr& b, size_t piece_bytes
         it.wide = wide;
         it.row_ptr.resize((size_t)(r1 - r0) + 1);
         for (int64_t r = r0; r <= r1; ++r) it.row_ptr[(size_t)(r - r0)] = row_ptr[(size_t)r] - c0;
-        hipError_t e = hipStreamWaitEvent(c->dl_stream, c->dl_ready[b.set], 0);
+        it.dma = dma;
+        it.last_of_block = dma && r1 == rows;
         char* dst = static_cast<char*>(c->dl_pinned[sl]);
+        if (dma) {
+            const HsaCopy* h = static_cast<const HsaCopy*>(c->dl_hsa);
+            hsa_signal_store_relaxed(h->sig[sl], cells > 0 ? 2 : 0);       // two copies (columns, q) count it down
+            hsa_status_t hs = HSA_STATUS_SUCCESS;
+            if (cells > 0) {
+                hs = hsa_amd_memory_async_copy(dst, h->cpu, (const char*)c->st_col[b.set] + (size_t)c0 * 4, h->gpu, (size_t)cells * 4, 0, nullptr,
+                                               h->sig[sl]);
+                if (hs == HSA_STATUS_SUCCESS)
+                    hs = hsa_amd_memory_async_copy(dst + (size_t)cells * 4, h->cpu, (const char*)c->st_q[b.set] + (size_t)c0 * (wide ? 2 : 1),
+                                                   h->gpu, (size_t)cells * (wide ? 2 : 1), 0, nullptr, h->sig[sl]);
+            }
+            if (hs != HSA_STATUS_SUCCESS) {
+                hsa_signal_store_relaxed(h->sig[sl], 0);
+                out.release_slot(sl);
+                return fail(MVS_E_HIP, "DMA download of a row block failed (hsa status %d)", (int)hs);
+            }
+            out.push(std::move(it));
+            ++c->st_pieces;
+            c->st_bytes += (long long)((size_t)cells * cell_bytes);
+            r0 = r1;
+            continue;
+        }
+        hipError_t e = hipStreamWaitEvent(c->dl_stream, c->dl_ready[b.set], 0);
         if (e == hipSuccess && cells > 0) {
             e = hipMemcpyAsync(dst, (const char*)c->st_col[b.set] + (size_t)c0 * 4, (size_t)cells * 4, hipMemcpyDeviceToHost,
                                c->dl_stream);
@@ -563,7 +684,7 @@ int feed_block(mvs_ctx* c, StreamOut& out, const BlockCsr& b, size_t piece_bytes
         c->st_bytes += (long long)((size_t)cells * cell_bytes);
         r0 = r1;
     }
-    HIP_TRY(hipEventRecord(c->dl_block[b.set], c->dl_stream));
+    if (!dma) HIP_TRY(hipEventRecord(c->dl_block[b.set], c->dl_stream));
     return MVS_OK;
 }
 
@@ -587,6 +708,12 @@ int feed_encoded(mvs_ctx* c, StreamOut& out, const BlockCsr& b, size_t piece_byt
         r0 = r1;
     }
     int rc = MVS_OK;
+    const bool dma = c->opt.stream_copy != 0;
+    if (dma) {
+        rc = ensure_hsa_copy(c);
+        if (rc) return rc;
+        HIP_TRY(hipEventSynchronize(c->dl_ready[b.set]));
+    }
     for (int64_t r0 = 0; r0 < rows;) {
         const int64_t r1 = piece_end(r0);
         const uint64_t o0 = off[(size_t)r0], bytes = off[(size_t)r1] - o0;
@@ -611,6 +738,25 @@ int feed_encoded(mvs_ctx* c, StreamOut& out, const BlockCsr& b, size_t piece_byt
                 it.jac_bytes.push_back(b.enc_jac[(size_t)r]);
                 it.offset.push_back(off[(size_t)r] - o0);
             }
+        it.dma = dma;
+        it.last_of_block = dma && r1 == rows;
+        if (dma) {
+            const HsaCopy* h = static_cast<const HsaCopy*>(c->dl_hsa);
+            hsa_signal_store_relaxed(h->sig[sl], bytes > 0 ? 1 : 0);
+            const hsa_status_t hs = bytes > 0 ? hsa_amd_memory_async_copy(c->dl_pinned[sl], h->cpu, (const char*)c->st_enc[b.set] + o0, h->gpu,
+                                                                          (size_t)bytes, 0, nullptr, h->sig[sl])
+                                              : HSA_STATUS_SUCCESS;
+            if (hs != HSA_STATUS_SUCCESS) {
+                hsa_signal_store_relaxed(h->sig[sl], 0);
+                out.release_slot(sl);
+                return fail(MVS_E_HIP, "DMA download of encoded rows failed (hsa status %d)", (int)hs);
+            }
+            out.push(std::move(it));
+            ++c->st_pieces;
+            c->st_bytes += (long long)bytes;
+            r0 = r1;
+            continue;
+        }
         hipError_t e = hipStreamWaitEvent(c->dl_stream, c->dl_ready[b.set], 0);
         if (e == hipSuccess && bytes > 0)
             e = hipMemcpyAsync(c->dl_pinned[sl], (const char*)c->st_enc[b.set] + o0, (size_t)bytes, hipMemcpyDeviceToHost, c->dl_stream);
@@ -624,7 +770,7 @@ int feed_encoded(mvs_ctx* c, StreamOut& out, const BlockCsr& b, size_t piece_byt
         c->st_bytes += (long long)bytes;
         r0 = r1;
     }
-    HIP_TRY(hipEventRecord(c->dl_block[b.set], c->dl_stream));
+    if (!dma) HIP_TRY(hipEventRecord(c->dl_block[b.set], c->dl_stream));
     return MVS_OK;
 }
 
@@ -745,6 +891,7 @@ int pairwise_stream_impl(mvs_ctx* c, const mvs_sketch_set* s, const double* norm
     // the arrays of block k live in set k & 1: before block k is built the feeder must be through with block k - 2
     auto wait_for_set = [&](int64_t k) {
         if (k >= 2) out.wait_fed(k - 1);
+        if (k >= 2 && c->opt.stream_copy != 0) out.wait_done(k - 1);      // (DMA copies: block k - 2 has left the device)
     };
     out.worker = std::thread([&out] { out.run(); });
     out.feeder = std::thread([&out] { out.feed_run(); });

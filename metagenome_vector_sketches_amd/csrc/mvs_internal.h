@@ -83,6 +83,9 @@ struct Options {
                                     // are in flight (10^6 x 2048: 256 queries 0.654 -> 0.622 ms, 512 queries 1.146 -> 1.034 from 3 to 5)
     int stream_trace = 0;           // 1: mvs_pairwise_stream prints the host-side time line of its row blocks to stderr
     int recode_rows_wg = 8;         // k_recode_rows: rows (= waves) per workgroup, 8 or 16
+    int stream_copy = 0;            // streamed output, device -> host copies of the pieces: 0 = hipMemcpyAsync on the download stream (a blit
+                                    // KERNEL on this stack: it holds CUs while the link drains it), 1 = hsa_amd_memory_async_copy (a DMA engine:
+                                    // no CU involved; the copies' ordering then lives on the host threads of the streamed output)
     int stream_spec = 0;            // mvs_pairwise_stream_encoded, dense row blocks: 1 = a block's row passes (count, scan, fill, scan, encode)
                                     // are queued in one go with buffers sized from the blocks before it and ONE read-back at the end says
                                     // whether the sizes held (else the block is done again the careful way); 0 (default) = read the count

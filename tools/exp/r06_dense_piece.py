@@ -57,12 +57,13 @@ def stream():
     return wall, st["kernel_ms"], st["bytes"], st["row_blocks"], seen["pieces"], int(st["two_stage"]), int(cnt.value)
 
 
-sweep = [(32, 1, 0), (32, 1, 1), (64, 1, 1), (32, 3, 1), (32, 2, 1), (32, 1, 0), (32, 1, 1)]
-for mib, dense_mode, spec in sweep:
+sweep = [(32, 1, 0, 0), (32, 1, 0, 1), (32, 1, 1, 1), (64, 1, 0, 1), (16, 1, 0, 1), (32, 2, 0, 1), (32, 3, 0, 1), (32, 1, 0, 0), (32, 1, 0, 1)]
+for mib, dense_mode, spec, copy in sweep:
     ctx.set_option("stream_piece_mib", mib)
     ctx.set_option("stream_dense", dense_mode)
     ctx.set_option("stream_spec", spec)
-    print("stream_spec %d stream_dense %d " % (spec, dense_mode), end="")
+    ctx.set_option("stream_copy", copy)
+    print("stream_copy %d stream_spec %d stream_dense %d " % (copy, spec, dense_mode), end="")
     runs = [stream() for _ in range(4)][1:]
     w = sorted(r[0] for r in runs)
     print("piece %3d MiB: wall %s ms (median %.2f)  kernels %.2f ms  %d bytes = %.2f ms of a 55 GB/s link  %d row blocks  %d pieces  path %d  %d cells"
