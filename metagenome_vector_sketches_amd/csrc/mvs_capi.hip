@@ -177,7 +177,7 @@ const OptionSpec kOptions[] = {
     {"cand_regions", &mvs::Options::cand_regions, nullptr, 0, 1},
     {"recheck_mode", &mvs::Options::recheck_mode, nullptr, 0, 3},
     {"recheck_blocks", &mvs::Options::recheck_blocks, nullptr, 1, 64},
-    {"stream_dense", &mvs::Options::stream_dense, nullptr, 0, 4},
+    {"stream_dense", &mvs::Options::stream_dense, nullptr, 0, 5},
     {"encode_stage_words", &mvs::Options::encode_stage_words, nullptr, 1, 64},
     {"stream_block_rows", &mvs::Options::stream_block_rows, nullptr, 0, 1 << 30},
     {"tile_dense_thr", &mvs::Options::tile_dense_thr, nullptr, 0, 8192},

@@ -1262,7 +1262,11 @@ int pairwise_stream_impl(mvs_ctx* c, const mvs_sketch_set* s, const double* norm
            (lopt.stream_dense >= 3 || (lopt.stream_dense == 1 && matrix_mode != kM2));
     // stream_dense = 4 (experiment): the row passes on the DOWNLOAD stream itself -- between two pieces' copies instead of beside
     // one (a device-to-host copy is a blit kernel that fills the card; a kernel that starts beside it ends with it)
-    if (side) ps = lopt.stream_dense == 4 ? c->dl_stream : c->post_stream;
+    // stream_dense = 5 (experiment): ONE stream, but launch k + 1 is queued IN FRONT of block k's row passes (as with the side stream):
+    // exact(k + 1), row passes(k), exact(k + 2), ... run one after the other at their un-contended speed and the host's read-backs of
+    // block k fall into the shadow of a launch that is already queued -- the row passes beside an exact kernel wait for its
+    // workgroups to leave the CUs one kernel after the other (a 49-us count took 659 us there)
+    if (side) ps = lopt.stream_dense == 4 ? c->dl_stream : (lopt.stream_dense == 5 ? c->stream : c->post_stream);
     mark("setup", -1);
     if (!blocks.empty()) {
         rc = launch(0, dense);

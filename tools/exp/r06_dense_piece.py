@@ -57,7 +57,7 @@ def stream():
     return wall, st["kernel_ms"], st["bytes"], st["row_blocks"], seen["pieces"], int(st["two_stage"]), int(cnt.value)
 
 
-sweep = [(32, 1, 0, 0), (32, 1, 0, 1), (32, 1, 1, 1), (64, 1, 0, 1), (16, 1, 0, 1), (32, 2, 0, 1), (32, 3, 0, 1), (32, 1, 0, 0), (32, 1, 0, 1)]
+sweep = [(32, 1, 0, 0), (32, 5, 0, 0), (32, 5, 1, 0), (32, 5, 0, 1), (32, 5, 1, 1), (64, 5, 1, 1), (32, 2, 1, 1), (32, 1, 0, 0), (32, 5, 1, 1)]
 for mib, dense_mode, spec, copy in sweep:
     ctx.set_option("stream_piece_mib", mib)
     ctx.set_option("stream_dense", dense_mode)
