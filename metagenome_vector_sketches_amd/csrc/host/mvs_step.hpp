@@ -471,7 +471,7 @@ class ShardStep {
         // norms: everybody has the file -> one upload into storage order (block p at p * P), once per geometry; else own norms
         // into this rank's block and the all-gather below brings the others'
         if (s.n2_all) {
-            if (!norms_in_place_) {
+            if (!norms_in_place_ || norms_src_ != s.n2_all) {     // (the same array again: its contents are taken as unchanged)
                 std::vector<double> st((size_t)(P_ * world_), 0.0);
                 for (int p = 0; p < world_; ++p) {
                     const auto r = rank_rows(s.n_total, s.block_rows, p);
@@ -479,6 +479,7 @@ class ShardStep {
                 }
                 check(mvs_device_copy(ctx_, n2_.p, MVS_MEM_DEVICE, st.data(), MVS_MEM_HOST, st.size() * 8), "uploading the norms");
                 norms_in_place_ = true;
+                norms_src_ = s.n2_all;
             }
         } else if (s.n_local) {
             check(mvs_device_copy(ctx_, n2_.as<double>() + base, MVS_MEM_DEVICE, s.d_n2_local, MVS_MEM_DEVICE, (size_t)s.n_local * 8),
@@ -772,6 +773,7 @@ class ShardStep {
     int rank_, world_;
     StepOptions opt_;
     Source src_;
+    const double* norms_src_ = nullptr;      // the host norms that are in place on the device
     bool wire_ok_ = true, wire_ = false, rebuilt_ = false, norms_in_place_ = false, sort_ahead_ = false;
     int limbs_ = 2, d_pad_ = 0, key_limbs_ = 0, key_d_ = 0;
     int64_t P_ = 0, n_alloc_ = 0, key_n_st_ = 0, n_out_ = 0;
