@@ -367,6 +367,8 @@ int mvs_ctx_destroy(mvs_ctx* c) {
     for (hipEvent_t ev : c->dl_ready) if (ev) (void)hipEventDestroy(ev);
     if (c->dl_stream) (void)hipStreamDestroy(c->dl_stream);
     if (c->dl_hsa && c->dl_hsa_free) c->dl_hsa_free(c->dl_hsa);
+    for (mvs_tile_order& o : c->tile_orders)
+        if (o.d) (void)hipFree(o.d);
     if (c->post_stream) (void)hipStreamDestroy(c->post_stream);
     if (c->cmp_done) (void)hipEventDestroy(c->cmp_done);
     if (c->pw_chdr) (void)hipFree(c->pw_chdr);

@@ -123,6 +123,45 @@ int attach_planes_fm(mvs_ctx* c, const mvs_sketch_set* s, mvs::PairwiseArgs& a, 
 // grow-only buffer of the context that the launch sizes itself, so that a comparison never has to be repeated because its
 // output did not fit: the two-stage comparison sizes it from the candidate count between the filter and the re-check
 // (a kept cell is a candidate or the mirror image of one), the exact kernel's caller sizes the row block for the worst case.
+int tile_order_for(mvs_ctx* c, const mvs::PairwiseArgs& a, const mvs::PlanSegs& segs, const unsigned** d, unsigned* per) {
+    *d = nullptr;
+    *per = 0;
+    std::vector<long long> key{segs.n, a.symmetric, a.sym_begin, a.sym_end, a.map_mode};
+    for (int k = 0; k < segs.n; ++k) {
+        key.push_back(segs.n_tr[k]);
+        key.push_back(segs.n_tc[k]);
+        key.push_back(segs.i_begin[k]);
+        key.push_back(segs.j_begin[k]);
+    }
+    const mvs_tile_order* hit = nullptr;
+    for (const mvs_tile_order& o : c->tile_orders)
+        if (o.key == key) hit = &o;
+    if (!hit) {
+        if (c->tile_orders.size() >= 64) {                         // (other shapes every time: start over)
+            HIP_TRY(hipDeviceSynchronize());
+            for (mvs_tile_order& o : c->tile_orders)
+                if (o.d) (void)hipFree(o.d);
+            c->tile_orders.clear();
+        }
+        mvs_tile_order o;
+        o.key = key;
+        std::vector<unsigned> list;
+        if (mvs::plan_tile_order(a, segs, &list, &o.per)) {
+            if (hipMalloc((void**)&o.d, list.size() * 4) != hipSuccess) return fail(MVS_E_NOMEM, "hipMalloc of a tile order failed");
+            const hipError_t e = hipMemcpy(o.d, list.data(), list.size() * 4, hipMemcpyHostToDevice);
+            if (e != hipSuccess) {
+                (void)hipFree(o.d);
+                return fail(MVS_E_HIP, "uploading a tile order: %s", hipGetErrorString(e));
+            }
+        }
+        c->tile_orders.push_back(std::move(o));
+        hit = &c->tile_orders.back();
+    }
+    *d = hit->d;
+    *per = hit->per;
+    return MVS_OK;
+}
+
 void fill_args(mvs_ctx* c, const mvs_sketch_set* s, const double* d_n2, int keep_mode, int64_t rb, int64_t re, int64_t cb,
                int64_t ce, bool symmetric, bool mirror_all, double keep_coeff, mvs::PairwiseArgs& a, const mvs::Options* o) {
     const mvs::Options& opt = o ? *o : c->opt;     // (a caller that forces a variant passes its own copy: the context is not written)
@@ -263,7 +302,18 @@ int two_stage_filter(mvs_ctx* c, const mvs_sketch_set* s, const double* d_n2, do
         if (n_regions > 0) HIP_TRY(hipMemsetAsync(a.cand_hdr, 0, (size_t)n_regions * 4, c->stream));
         if (ts.tiles) HIP_TRY(hipMemsetAsync(a.tile_flag, 0, n_tiles * 4, c->stream));
         if (c->timing) HIP_TRY(hipEventRecord(c->ev[2], c->stream));
-        rc = mvs::launch_filter(c->stream, a, opt);
+        {
+            // the one-block launch of the default ping-pong filter with a balanced tile order (option plan_order, as the plans)
+            const unsigned* order = nullptr;
+            unsigned order_per = 0;
+            mvs::PairwiseArgs kb{};
+            mvs::PlanSegs segs{};
+            if (opt.plan_order != 0 && mvs::filter_order_geometry(a, opt, &kb, &segs)) {
+                rc = tile_order_for(c, kb, segs, &order, &order_per);
+                if (rc) return rc;
+            }
+            rc = mvs::launch_filter(c->stream, a, opt, order, order_per);
+        }
         if (rc) return fail(rc, "filter launch rejected");
         rc = check_kernel("k_pairwise_mfma(filter)");
         if (rc) return rc;

@@ -27,8 +27,17 @@
 #include "mvs_encode.h"
 #include "mvs_internal.h"
 
+// a balanced tile order of a filter launch (mvs::plan_tile_order), cached by launch geometry: the comparisons of a job repeat
+// the same few shapes, so a list is built and uploaded once
+struct mvs_tile_order {
+    std::vector<long long> key;
+    unsigned* d = nullptr;            // NULL: the static map serves this shape
+    unsigned per = 0;
+};
+
 struct mvs_ctx {
     int device = 0;
+    std::vector<mvs_tile_order> tile_orders;
     mvs::Options opt;   // tuning switches: environment defaults read once at creation, then mvs_ctx_set_option
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
@@ -202,6 +211,8 @@ void note_rows_rewritten(mvs_sketch_set* s, int64_t lo, int64_t hi);
 
 // ---- mvs_capi_compare.hip ----
 int refresh_derived(mvs_ctx* c, const mvs_sketch_set* cs);
+// the balanced order of the launch `segs` describes with the kernel arguments `a` (option plan_order; *d == NULL: use the static map)
+int tile_order_for(mvs_ctx* c, const mvs::PairwiseArgs& a, const mvs::PlanSegs& segs, const unsigned** d, unsigned* per);
 struct PackedOut {
     void** buf;
     size_t* bytes;

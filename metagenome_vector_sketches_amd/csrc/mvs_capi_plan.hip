@@ -48,14 +48,6 @@ struct PlanState {
     long long hint_cand = 0, hint_flagged = 0;
     std::array<int64_t, 8> hint_key{};    // the shape the hints belong to
     std::array<int64_t, 8> key{};
-    // balanced tile orders of the filter launches (mvs::plan_tile_order), by launch geometry: a step's plans repeat the same few
-    // shapes, so the lists are built and uploaded once
-    struct TileOrder {
-        std::vector<long long> key;
-        unsigned* d = nullptr;            // NULL: the static map serves this shape
-        unsigned per = 0;
-    };
-    std::vector<TileOrder> orders;
 };
 
 void mvs_capi::plan_state_free(mvs_ctx* c) {
@@ -66,8 +58,6 @@ void mvs_capi::plan_state_free(mvs_ctx* c) {
     for (hipEvent_t e : {st->e_chk0, st->e_chk1, st->e_tiles1, st->e_fork, st->e_join})
         if (e) (void)hipEventDestroy(e);
     if (st->side) (void)hipStreamDestroy(st->side);
-    for (PlanState::TileOrder& o : st->orders)
-        if (o.d) (void)hipFree(o.d);
     delete st;
     c->plan = nullptr;
 }
@@ -191,40 +181,12 @@ int plan_launch(mvs_ctx* c, PlanState& st, size_t first, int count) {
         a.cand_ent = nullptr;
     }
     if (c->opt.plan_order != 0) {
-        std::vector<long long> key{segs.n, a.symmetric, a.sym_begin, a.sym_end, a.map_mode};
-        for (int k = 0; k < segs.n; ++k) {
-            key.push_back(segs.n_tr[k]);
-            key.push_back(segs.n_tc[k]);
-            key.push_back(segs.i_begin[k]);
-            key.push_back(segs.j_begin[k]);
-        }
-        const PlanState::TileOrder* hit = nullptr;
-        for (const PlanState::TileOrder& o : st.orders)
-            if (o.key == key) hit = &o;
-        if (!hit) {
-            if (st.orders.size() >= 64) {                          // (other shapes every time: start over)
-                HIP_TRY(hipStreamSynchronize(c->stream));
-                if (st.side) HIP_TRY(hipStreamSynchronize(st.side));
-                for (PlanState::TileOrder& o : st.orders)
-                    if (o.d) (void)hipFree(o.d);
-                st.orders.clear();
-            }
-            PlanState::TileOrder o;
-            o.key = key;
-            std::vector<unsigned> list;
-            if (mvs::plan_tile_order(a, segs, &list, &o.per)) {
-                if (hipMalloc((void**)&o.d, list.size() * 4) != hipSuccess) return fail(MVS_E_NOMEM, "hipMalloc of a tile order failed");
-                const hipError_t e = hipMemcpy(o.d, list.data(), list.size() * 4, hipMemcpyHostToDevice);
-                if (e != hipSuccess) {
-                    (void)hipFree(o.d);
-                    return fail(MVS_E_HIP, "uploading a tile order: %s", hipGetErrorString(e));
-                }
-            }
-            st.orders.push_back(std::move(o));
-            hit = &st.orders.back();
-        }
-        segs.order = hit->d;
-        segs.order_per = hit->per;
+        const unsigned* order = nullptr;
+        unsigned per = 0;
+        const int ro = tile_order_for(c, a, segs, &order, &per);
+        if (ro) return ro;
+        segs.order = order;
+        segs.order_per = per;
     }
     hipStream_t on = c->stream;
     if (c->plan_overlap != 0 && (st.launches & 1) != 0) {          // every second launch of a plan: the side stream

@@ -267,7 +267,9 @@ int launch_coarse_fm(hipStream_t stream, const int8_t* d_coarse, int64_t n_alloc
 bool exact_reads_fm(const PairwiseArgs& a, const Options& opt);
 int launch_filter_meta(hipStream_t stream, const CoarseRow* d_rows, const double* d_norms_sq, int64_t n,
                        int64_t n_alloc, int d, double coeff, float4* d_meta);
-int launch_filter(hipStream_t stream, const PairwiseArgs& a, const Options& opt);
+int launch_filter(hipStream_t stream, const PairwiseArgs& a, const Options& opt, const unsigned* order = nullptr, unsigned order_per = 0);
+struct PlanSegs;
+bool filter_order_geometry(const PairwiseArgs& a, const Options& opt, PairwiseArgs* b, PlanSegs* segs);
 // block plans (mvs_plan_*): rectangles {row_begin, row_end, col_begin, col_end} -> the segments of one launch (returns its
 // 1-D grid in workgroups, 0: empty, -1: too many rectangles / too large for one launch), and that launch of the ping-pong filter
 long long plan_segments(const int64_t (*blocks)[4], int n, PlanSegs* segs);

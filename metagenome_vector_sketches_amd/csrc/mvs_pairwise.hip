@@ -2027,8 +2027,23 @@ static bool pp_direct_b(const PairwiseArgs& a, int mode, const Options& opt) {
            ((a.row_begin | a.col_begin) & 15) == 0;
 }
 
+// what launch_pp makes of a block before it launches: the tile grid and the arguments the kernel gets (symmetric schedule only
+// with aligned grids, the skinny map for grids of less than a patch row)
+template <int MODE>
+static bool pp_geometry(const PairwiseArgs& a, PairwiseArgs* b, int* n_tr, int* n_tc) {
+    using G = PpGeom<MODE>;
+    const int64_t rows = a.row_end - a.row_begin, cols = a.col_end - a.col_begin;
+    if (rows <= 0 || cols <= 0) return false;
+    *n_tr = (int)((rows + G::TM - 1) / G::TM);
+    *n_tc = (int)((cols + G::TN - 1) / G::TN);
+    *b = a;
+    if (b->symmetric && ((a.row_begin - a.col_begin) % G::TM != 0 || a.mirror_all)) b->symmetric = 0;
+    skinny_map(*b, *n_tr);
+    return true;
+}
+
 template <int MODE, int NST, int ORDER = 0, int ABL = 0, int PH = 1, int NT = 0, int BD = 0>
-int launch_pp(hipStream_t stream, const PairwiseArgs& a) {
+int launch_pp(hipStream_t stream, const PairwiseArgs& a, const unsigned* order = nullptr, unsigned order_per = 0) {
     using G = PpGeom<MODE>;
     const int64_t rows = a.row_end - a.row_begin, cols = a.col_end - a.col_begin;
     if (rows <= 0 || cols <= 0) return 0;
@@ -2042,6 +2057,22 @@ int launch_pp(hipStream_t stream, const PairwiseArgs& a) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pairwise_pp<MODE, NST, ORDER, ABL, PH, NT, BD>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return MVS_E_HIP;
+    if (order != nullptr && order_per > 0 && b.map_mode != 3) {
+        // the block as ONE segment of a balanced tile order (filter_order_geometry + plan_tile_order built the list for exactly
+        // these arguments): a 1-D grid of order_per workgroups per XCD label
+        PlanSegs segs{};
+        segs.n = 1;
+        segs.n_tr[0] = n_tr;
+        segs.n_tc[0] = n_tc;
+        segs.n_spc[0] = n_spc;
+        segs.i_begin[0] = a.row_begin;
+        segs.j_begin[0] = a.col_begin;
+        for (int k = 1; k <= kPlanSegs; ++k) segs.wg_begin[k] = order_per * 8u;
+        segs.order = order;
+        segs.order_per = order_per;
+        hipLaunchKernelGGL((k_pairwise_pp<MODE, NST, ORDER, ABL, PH, NT, BD>), dim3(order_per * 8u), dim3(512), lds, stream, b, n_tr, n_tc, segs);
+        return 0;
+    }
     hipLaunchKernelGGL((k_pairwise_pp<MODE, NST, ORDER, ABL, PH, NT, BD>), dim3((unsigned)n_spc * 256u, (unsigned)n_spr), dim3(512), lds, stream,
                        b, n_tr, n_tc, PlanSegs{});
     return 0;
@@ -2049,9 +2080,9 @@ int launch_pp(hipStream_t stream, const PairwiseArgs& a) {
 
 // the default ping-pong kernel (4-stage ring), with the B operand straight from the fragment-major plane when that exists
 template <int MODE>
-int launch_pp_default(hipStream_t stream, const PairwiseArgs& a, const Options& opt) {
-    if (pp_direct_b(a, MODE, opt)) return launch_pp<MODE, 4, 0, 0, 1, 0, 1>(stream, a);
-    return launch_pp<MODE, 4>(stream, a);
+int launch_pp_default(hipStream_t stream, const PairwiseArgs& a, const Options& opt, const unsigned* order = nullptr, unsigned order_per = 0) {
+    if (pp_direct_b(a, MODE, opt)) return launch_pp<MODE, 4, 0, 0, 1, 0, 1>(stream, a, order, order_per);
+    return launch_pp<MODE, 4>(stream, a, order, order_per);
 }
 
 template <int L, bool KARA, int MODE>
@@ -2086,7 +2117,23 @@ int launch_mfma(hipStream_t stream, const PairwiseArgs& a, const Options& opt) {
 static int filter_variant_for(const PairwiseArgs& a, const Options& opt);
 static int launch_search_filter(hipStream_t stream, const PairwiseArgs& a, const Options& opt);
 
-int launch_filter(hipStream_t stream, const PairwiseArgs& a, const Options& opt) {
+// The one-block filter launch with a balanced tile order (the default ping-pong kernel only): the segment the launch will be and
+// the arguments its kernel will get, for plan_tile_order -- false where the launch takes another kernel or map.
+bool filter_order_geometry(const PairwiseArgs& a, const Options& opt, PairwiseArgs* b, PlanSegs* segs) {
+    if (a.limbs != 2 || a.d_pad > 32768 || filter_variant_for(a, opt) != 8) return false;
+    int n_tr = 0, n_tc = 0;
+    if (!pp_geometry<2>(a, b, &n_tr, &n_tc) || b->map_mode == 3) return false;
+    *segs = PlanSegs{};
+    segs->n = 1;
+    segs->n_tr[0] = n_tr;
+    segs->n_tc[0] = n_tc;
+    segs->n_spc[0] = (n_tc + 15) / 16;
+    segs->i_begin[0] = a.row_begin;
+    segs->j_begin[0] = a.col_begin;
+    return true;
+}
+
+int launch_filter(hipStream_t stream, const PairwiseArgs& a, const Options& opt, const unsigned* order, unsigned order_per) {
     if (a.limbs != 2 || a.d_pad > 32768) return MVS_E_INVALID;
     // opt.filter_variant: tile shape / ring depth of the one-pass filter.
     // Default (-1): the ping-pong kernel on 256 x 256 tiles (half the L2 -> LDS bytes per cell of 128 x 128 tiles; its
@@ -2096,7 +2143,7 @@ int launch_filter(hipStream_t stream, const PairwiseArgs& a, const Options& opt)
     switch (v) {
         case 50: return launch_search_filter(stream, a, opt);
         case 7: return launch_pp<2, 5>(stream, a);   // ping-pong wave groups, 256 x 256, 5-stage ring (all 160 KiB of LDS)
-        case 8: return launch_pp_default<2>(stream, a, opt);   // the same on a 4-stage ring (B operand direct when the fragment-major plane exists)
+        case 8: return launch_pp_default<2>(stream, a, opt, order, order_per);   // the same on a 4-stage ring (B operand direct when the fragment-major plane exists)
         case 9: return launch_pp<2, 4, 0, 0, 2>(stream, a);    // two phases per slice
         case 10: return launch_pp<2, 4, 2, 0, 2>(stream, a);   // two phases, copy / read order by wave parity
         case 40: return launch_pp<2, 4, 0, 0, 1, 1>(stream, a);   // variant 8 with non-temporal column-panel copies
