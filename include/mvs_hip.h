@@ -124,9 +124,10 @@ int mvs_ctx_kernel_ms(mvs_ctx* ctx, int which, float* ms);
  *                         registers and LDS carries the A operand only; 0: both operands through LDS
  *   search_stream         1 (default): blocks of up to 640 rows x at least 4096 columns outside the symmetric schedule (a
  *                         search) take the streaming filter (rows resident in LDS, columns streamed); 0: the tile kernels
- *   plan_order            block plans: 1 (default) the filter launches of a plan take a balanced tile order -- every XCD the same
- *                         number of tiles of every 16 x 16-tile super-patch --, 0 the static super-patch map (a triangle's static
- *                         sub-patches hold 32, 26, 10 or 0 tiles: launches of a few rounds waited for their fullest XCD)
+ *   plan_order            1 (default) the launches of the ping-pong filter -- of a block plan, and the one-block launch of
+ *                         mvs_pairwise_rows / _stream -- take a balanced tile order: every XCD the same number of tiles of every
+ *                         16 x 16-tile super-patch; 0 the static super-patch map (a triangle's static sub-patches hold 32, 26, 10
+ *                         or 0 tiles: launches of a few rounds waited for their fullest XCD)
  *   stream_block_rows, encode_stage_words, pairwise_map, coarse_radix, cand_regions, recheck_mode, recheck_blocks
  *                         test / experiment switches (DESIGN.md, appendix "switches"; encode_stage_words below 64 also keeps
  *                         every row on the device encoder's general loop)
