@@ -226,6 +226,10 @@ def main():
     ap.add_argument("--strong-steps", type=int, default=10,
                     help="default mode: timed steps of the strong-scaled pairwise legs (configs[2] 100k x 2048 and configs[3] "
                          "100k x 4096 split over the N ranks, reported as `strong`); 0 skips them")
+    ap.add_argument("--cpp-step-ranks", type=int, default=8,
+                    help="N=1: `strong_cpp` record -- every rank's step of a split of configs[2] into this many ranks through the "
+                         "C++ host of the step (csrc/host/mvs_step.hpp, bin/mvs_step_bench: the code pairwise_comp_optimized runs), "
+                         "each rank timed alone with the exchange's bytes in place, beside the one-GPU step; 0 skips it")
     ap.add_argument("--strong-timeout", type=int, default=300,
                     help="N > 1: seconds the strong legs may take before every rank gives up on them (the line is printed "
                          "without them, `strong.error` says why)")
@@ -611,6 +615,8 @@ def main():
         strong = run_strong()
     if strong:
         res["strong"] = strong
+    if args.cpp_step_ranks > 1 and args.strong_steps > 0 and world == 1:
+        res["strong_cpp"] = cpp_step_leg(dev, args.cpp_step_ranks, args.hashes)
 
     if not args.no_cpu_baseline and world == 1:
         res["cpu_baseline"] = cpu_baseline(hashes, offsets, S, NH, D, dev)
@@ -618,6 +624,64 @@ def main():
             res["pairwise"]["vs_cpu_port_all_cores"] = res["pairwise"]["cells_per_s"] / res["cpu_baseline"]["pairwise_cells_per_s"]
     print(json.dumps(res))
     shutdown()
+
+
+def cpp_step_leg(dev, ranks, nh):
+    """The strong-scaled step through its C++ host (csrc/host/mvs_step.hpp: what `pairwise_comp_optimized` runs with
+    MVS_COLLECTIVE=rccl or --shard_idx -1; src/pairwise_comp_optimized.cpp:937-982 is what it replaces): configs[2]'s sketches are
+    written as a DB folder, `bin/mvs_step_bench` times the one-GPU step and EVERY rank's step of a `ranks`-way split alone on this
+    card, every byte of the exchange in place (40 warm-up + 40 timed steps per rank, no events on the stream).  The exchange itself
+    is not in these numbers (tools/strong_model.py --from-cpp models it); `speedup_before_exchange` = one-GPU step / slowest rank."""
+    import shutil
+    import subprocess
+    import tempfile
+    import torch
+    from metagenome_vector_sketches_amd import synth
+    exe = os.path.join(ROOT, "metagenome_vector_sketches_amd", "bin", "mvs_step_bench")
+    if not os.path.exists(exe):
+        return {"error": "bin/mvs_step_bench is not built"}
+    n, d, seed = STRONG[3]
+    tmp = tempfile.mkdtemp(prefix="mvs_bench_db_")
+    try:
+        db = tmp + "/"
+        sk = synth.make_sketches_torch_rows(n, d, nh, seed=seed, device=dev, row_begin=0, row_end=n)
+        ss = (sk.to(torch.int64) ** 2).sum(dim=1)
+        norms = np.sqrt(ss.cpu().numpy().astype(np.float64) / d)
+        sk.cpu().numpy().astype("<i4").tofile(db + "vectors.bin")
+        del sk
+        torch.cuda.empty_cache()
+        with open(db + "vector_norms.txt", "w") as f:
+            f.write("".join("s%d %s\n" % (i, "%g" % v) for i, v in enumerate(norms)))
+        with open(db + "dimension.txt", "w") as f:
+            f.write("%d\n" % d)
+        with open(db + "dtype.txt", "w") as f:
+            f.write("int32\n")
+        out = {}
+        for g in (1, ranks):
+            r = subprocess.run([exe, "--db", db, "--ranks", str(g), "--steps", "40", "--warmup", "40"], capture_output=True, text=True,
+                               timeout=240)
+            if r.returncode != 0:
+                return {"error": "mvs_step_bench --ranks %d: rc %d: %s" % (g, r.returncode, r.stderr.strip()[-300:])}
+            out[g] = json.loads(r.stdout.strip().split("\n")[-1])
+        one, split = out[1]["per_rank"][0], out[ranks]
+        slow = max(split["per_rank"], key=lambda p: p["wall_ms_median"])
+        return {"workload": "configs[2]: %d synthetic samples, d=%d, the step of `pairwise_comp_optimized` (C++ host), 1 rank and every "
+                            "rank of a %d-way split timed alone on one GPU, exchange bytes in place" % (n, d, ranks),
+                "one_gpu_step_ms": one["wall_ms_median"], "ranks": ranks,
+                "per_rank_step_ms": [p["wall_ms_median"] for p in split["per_rank"]],
+                "slowest_rank": slow["rank"], "slowest_rank_step_ms": slow["wall_ms_median"],
+                "speedup_before_exchange": one["wall_ms_median"] / slow["wall_ms_median"],
+                "slowest_rank_stages": {k: slow[k] for k in ("prepare_own_rows_ms", "diag_filter_ms", "peer_filters_ms", "finish_ms",
+                                                             "cells_route_exchange_sort_ms", "filter_ms", "recheck_ms", "flagged_tiles_ms",
+                                                             "filter_launches", "filter_tiles", "candidates", "flagged_tiles",
+                                                             "own_cells", "foreign_cells") if k in slow},
+                "kept_cells_one_gpu": one["own_cells"],
+                "note": "not a multi-GPU measurement: per-rank compute of the C++ step on ONE card; the exchange is modelled in "
+                        "tools/strong_model.py --from-cpp (DESIGN.md section 7: 6.3-6.6 x at 61 GB/s per link and 20 us per collective)"}
+    except Exception as e:      # noqa: BLE001 -- a leg beside the headline: reported, never fatal
+        return {"error": "%s: %s" % (type(e).__name__, e)}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def step_pairwise_roofline(state, S, N_total, D, k2_ms, k2_flops, traffic):
