@@ -236,11 +236,13 @@ def main():
     ap.add_argument("--overlap-parts", type=int, default=2,
                     help="N > 1: pieces the rank's samples are projected in; the all-gather of a finished piece's limb "
                          "planes runs beside the projection of the next (1: no overlap)")
-    ap.add_argument("--allow-torch-collectives", action="store_true",
-                    help="N > 1: if the library's own RCCL communicator cannot be created, let torch.distributed's collectives "
-                         "carry the exchange (the line then says so) instead of exiting non-zero.  Without this flag a "
-                         "multi-GPU line is always a measurement of the library's communicator (mvs_comm); rehearsals "
-                         "(MVS_BENCH_REHEARSAL=1: all ranks on one card, file transport) do not need it")
+    ap.add_argument("--require-native-collectives", action="store_true",
+                    help="N > 1: exit 3 on every rank if the library's own RCCL communicator (mvs_comm) cannot be created.  Default: "
+                         "torch.distributed's nccl backend -- the same RCCL -- then carries the exchange, and the line says so in "
+                         "config.collectives / collectives_note (a driver-launched scaling run must not lose its line to the set-up of a "
+                         "node this build could never try).  Rehearsals (MVS_BENCH_REHEARSAL=1: all ranks on one card, file transport) "
+                         "are not affected")
+    ap.add_argument("--allow-torch-collectives", action="store_true", help="accepted for older scripts: this is the default now")
     ap.add_argument("--host-input", action="store_true",
                     help="also time the step with the hash lists handed over as host buffers (PCIe inclusive; "
                          "reported as pcie_inclusive, never as value)")
@@ -319,13 +321,13 @@ def main():
             if coll is not None:
                 coll.comm.close()
                 coll_note = "another rank could not create the native communicator"
-            if not args.allow_torch_collectives:
-                # a scaling line must not silently measure another communicator: fail, loudly, on every rank
-                print("bench.py rank %d: %s -- not falling back (pass --allow-torch-collectives to measure with "
-                      "torch.distributed's collectives instead)" % (rank, coll_note), file=sys.stderr)
+            if args.require_native_collectives:
+                print("bench.py rank %d: %s -- not falling back (--require-native-collectives)" % (rank, coll_note), file=sys.stderr)
                 dist.destroy_process_group()
                 sys.exit(3)
-            coll_note += "; torch.distributed carries the exchange (--allow-torch-collectives)"
+            # never silently: the line names the communicator that carried the exchange (config.collectives) and why
+            coll_note += "; torch.distributed's nccl backend (RCCL) carries the exchange instead of the library's communicator"
+            print("bench.py rank %d: %s" % (rank, coll_note), file=sys.stderr, flush=True)
             coll = parallel.TorchCollectives(dist, rank, world, stream=side)
 
     if args.config != 2:
