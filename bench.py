@@ -301,32 +301,58 @@ def main():
         side = torch.cuda.Stream(device=dev)
         ctx_comm = pkg.Context(dev_index)
         ctx_comm.set_stream(side)
+
+        def agree(ok):
+            """True if every rank says ok (a collective over torch.distributed: every rank must call it the same number of times)"""
+            t = torch.tensor([1 if ok else 0], device=dev if not rehearsal else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return int(t.item()) == 1
+        # (1) what a rank can find out ALONE, agreed on before anything collective: does the library bind an RCCL here, and can
+        # rank 0 draw the id?  Creating a communicator is itself a collective (ncclCommInitRank, the file transport's hand-shake): a
+        # rank that gave up before it would leave the others waiting in it for ever -- RCCL has no timeout.
+        uid_bytes = None
         try:
-            if rehearsal:
-                comm = ctx_comm.comm_files(os.path.join(os.environ.get("TMPDIR", "/tmp"), "mvs_bench_%s" %
-                                                        os.environ.get("MASTER_PORT", "0")), rank, world)
-            else:
-                uid = torch.zeros(_capi.COMM_ID_BYTES, dtype=torch.uint8, device=dev)
+            if os.environ.get("MVS_BENCH_FAIL_NATIVE_COMM") == str(rank):      # test hook: this rank's library "finds no RCCL"
+                raise RuntimeError("MVS_BENCH_FAIL_NATIVE_COMM")
+            if not rehearsal:
+                _capi.comm_library()
                 if rank == 0:
-                    uid.copy_(torch.frombuffer(bytearray(_capi.comm_unique_id()), dtype=torch.uint8))
-                dist.broadcast(uid, src=0)
-                comm = ctx_comm.comm_rccl(bytes(uid.cpu().numpy().tobytes()), rank, world)
-            coll = parallel.NativeCollectives(comm, stream=side)
-        except Exception as e:      # noqa: BLE001 -- reported below: every rank must reach the agreement first
-            coll_note = "native communicator failed (%s: %s)" % (type(e).__name__, e)
-            coll = None
-        ok = torch.tensor([1 if coll is not None else 0], device=dev)
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        if int(ok.item()) == 0:   # all ranks use the same transport
+                    uid_bytes = _capi.comm_unique_id()
+        except Exception as e:      # noqa: BLE001 -- reported below, after the agreement every rank takes part in
+            coll_note = "native communicator unavailable (%s: %s)" % (type(e).__name__, e)
+        local_ok = coll_note is None
+        all_ok = agree(local_ok)
+        if all_ok:
+            # (2) the collective creation.  An error return is reported by the library on every rank (bad id, mismatched world);
+            # the agreement behind it covers the case where only some ranks see one
+            try:
+                if rehearsal:
+                    comm = ctx_comm.comm_files(os.path.join(os.environ.get("TMPDIR", "/tmp"), "mvs_bench_%s" %
+                                                            os.environ.get("MASTER_PORT", "0")), rank, world)
+                else:
+                    uid = torch.zeros(_capi.COMM_ID_BYTES, dtype=torch.uint8, device=dev)
+                    if rank == 0:
+                        uid.copy_(torch.frombuffer(bytearray(uid_bytes), dtype=torch.uint8))
+                    dist.broadcast(uid, src=0)
+                    comm = ctx_comm.comm_rccl(bytes(uid.cpu().numpy().tobytes()), rank, world)
+                coll = parallel.NativeCollectives(comm, stream=side)
+            except Exception as e:      # noqa: BLE001
+                coll_note = "native communicator failed (%s: %s)" % (type(e).__name__, e)
+                coll = None
+            all_ok = agree(coll is not None)
+        if not all_ok:   # all ranks use the same transport
             if coll is not None:
                 coll.comm.close()
+                coll = None
+            if coll_note is None:
                 coll_note = "another rank could not create the native communicator"
             if args.require_native_collectives:
                 print("bench.py rank %d: %s -- not falling back (--require-native-collectives)" % (rank, coll_note), file=sys.stderr)
                 dist.destroy_process_group()
                 sys.exit(3)
             # never silently: the line names the communicator that carried the exchange (config.collectives) and why
-            coll_note += "; torch.distributed's nccl backend (RCCL) carries the exchange instead of the library's communicator"
+            coll_note += "; torch.distributed's %s backend carries the exchange instead of the library's communicator" % (
+                "gloo" if rehearsal else "nccl (RCCL)")
             print("bench.py rank %d: %s" % (rank, coll_note), file=sys.stderr, flush=True)
             coll = parallel.TorchCollectives(dist, rank, world, stream=side)
 
