@@ -149,17 +149,14 @@ int plan_rebuild_needed(mvs_ctx* c, PlanState& st) {
     mvs::launch_rows_needed(c->stream, st.a, st.n_tr, st.n_tc, st.f0, st.f1, s->n, (unsigned char*)c->pw_need);
     rc = check_kernel("k_rows_needed");
     if (rc) return rc;
-    const int64_t dp = s->d_pad;
-    const int64_t lo_end = st.f0 & ~(int64_t)15, hi_begin = (st.f1 + 15) & ~(int64_t)15, hi_end = (s->n + 15) & ~(int64_t)15;
-    for (int half = 0; half < 2; ++half) {
-        const int64_t r0 = half ? hi_begin : 0, r1 = half ? std::min<int64_t>(hi_end, s->n_alloc) : lo_end;
-        if (r1 <= r0) continue;
-        mvs::launch_planes_from_wire(c->stream, st.lo_wire + r0 * dp, s->ext_coarse_fm + r0 * dp, s->ext_rows + r0, r1 - r0, s->d_pad,
-                                     const_cast<int8_t*>(s->planes) + r0 * 2 * dp, (const unsigned char*)c->pw_need + r0);
-        rc = check_kernel("k_planes_from_wire(needed rows)");
-        if (rc) return rc;
-    }
-    return MVS_OK;
+    // ONE launch over the rows on both sides of the frame (its 16-row groups are skipped inside the kernel)
+    const int64_t lo_end = st.f0 & ~(int64_t)15, hi_begin = std::min<int64_t>((st.f1 + 15) & ~(int64_t)15, s->n_alloc);
+    const int64_t hi_end = std::min<int64_t>((s->n + 15) & ~(int64_t)15, s->n_alloc);
+    const int64_t count = std::max(hi_end, lo_end);                                             // rows [0, count) but [lo_end, hi_begin)
+    const int64_t skip_first = lo_end, skip_count = std::max<int64_t>(0, std::min(hi_begin, count) - lo_end);
+    mvs::launch_planes_from_wire(c->stream, st.lo_wire, s->ext_coarse_fm, s->ext_rows, count, s->d_pad, const_cast<int8_t*>(s->planes),
+                                 (const unsigned char*)c->pw_need, skip_first, skip_count);
+    return check_kernel("k_planes_from_wire(needed rows)");
 }
 
 // blocks [first, first + count) of the plan as ONE filter launch

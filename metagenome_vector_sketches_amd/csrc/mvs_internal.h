@@ -256,7 +256,8 @@ int launch_coarse_build(hipStream_t stream, const int8_t* d_planes, int64_t n, i
 // limb split + coarse build + fragment-major copy of a row range in one pass (k_recode_rows); false: no fused kernel for
 // this geometry (the caller takes the three separate launches)
 int launch_planes_from_wire(hipStream_t stream, const int8_t* d_lo_wire, const int8_t* d_coarse_fm, const CoarseRow* d_rows,
-                            int64_t count, int d_pad, int8_t* d_planes, const unsigned char* d_need = nullptr);
+                            int64_t count, int d_pad, int8_t* d_planes, const unsigned char* d_need = nullptr, int64_t skip_first = 0,
+                            int64_t skip_count = 0);
 int launch_rows_needed(hipStream_t stream, const PairwiseArgs& a, int n_tr, int n_tc, int64_t f0, int64_t f1, int64_t n_rows,
                        unsigned char* d_need);
 bool launch_recode_rows(hipStream_t stream, const void* d_sk, int elem_bytes, int64_t n_rows, int64_t count, int d, int d_pad,

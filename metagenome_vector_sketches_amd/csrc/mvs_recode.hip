@@ -425,43 +425,46 @@ __global__ __launch_bounds__(256) void k_rows_needed(const PairwiseArgs a, int n
 
 // k_planes_from_wire: limb planes of rows whose LOW limb arrived in a wire buffer (lo[row * d_pad + k]) and whose coarse
 // plane and statistics are in place (fragment-major, as the filter reads them): both limb rows are written -- the rule is
-// at radix_keeps_high_limb.  A workgroup takes 16 rows (one KiB of the fragment-major plane holds 16 rows x 64 k) x 256 k: a lane
-// takes 16 consecutive k of one row, reads its 16 coarse bytes where k_recode_rows put them and 16 bytes of the wire.  (One
-// workgroup per 16 rows looping over k moved 3.4 TB/s: eight dependent rounds of loads per workgroup.)
+// at radix_keeps_high_limb.  A workgroup takes 16 rows (one KiB of the fragment-major plane holds 16 rows x 64 k) x 256 k.
+// [r6] A WAVE takes 4 rows x 16 chunks of 16 k: per row 256 contiguous bytes of the wire and of either limb row (whole cache
+// lines; the first mapping, 16 rows x 4 chunks per wave, touched 64-byte halves of 16 lines per instruction and moved
+// 3.1 TB/s), and of the coarse plane the four adjacent 16-byte pieces of its rows in each of 16 sub-blocks -- the workgroup's
+// four waves use every line of its 4 KiB whole, and a wave none of whose rows is wanted reads nothing.
 // need != NULL: only the rows marked there (k_rows_needed: what a plan's re-check and flagged tiles will read).
+// Groups [skip0, skip1) (units of 16 rows) are left alone: a plan's own frame, so that ONE launch covers the rows on both sides.
 __global__ __launch_bounds__(256) void k_planes_from_wire(const int8_t* __restrict__ lo_wire, const int8_t* __restrict__ coarse_fm,
                                                           const CoarseRow* __restrict__ rows, int64_t count, int d_pad,
-                                                          int8_t* __restrict__ planes, const unsigned char* __restrict__ need) {
+                                                          int8_t* __restrict__ planes, const unsigned char* __restrict__ need,
+                                                          int64_t skip0, int64_t skip1) {
     const int nk = d_pad / 64;
-    const int64_t grp = blockIdx.x;                        // 16 rows
-    const int chunks = 16 * (d_pad / 16);                  // (row, 16-entry chunk) pairs of the group
-    {
-        const int idx = (int)blockIdx.y * 256 + (int)threadIdx.x;
-        if (idx >= chunks) return;
-        const int r = idx & 15, kc = idx >> 4;             // consecutive lanes: the 16 rows of one chunk = 256 contiguous bytes of the plane
-        const int64_t row = grp * 16 + r;
-        if (row >= count || (need && need[row] == 0)) return;
-        const int m = rows[row].radix;
-        const v4i c4 = *reinterpret_cast<const v4i*>(coarse_fm + (grp * nk + (kc >> 2)) * 1024 + (((kc & 3) << 4) + r) * 16);
-        const v4i l4 = *reinterpret_cast<const v4i*>(lo_wire + row * (int64_t)d_pad + kc * 16);
-        const int h = (m + 1) >> 1, edge = 127 * m - h + 127;
-        v4i h4;
+    int64_t grp = blockIdx.x;                              // 16 rows
+    if (grp >= skip0) grp += skip1 - skip0;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = wave * 4 + (lane >> 4);
+    const int kc = (int)blockIdx.y * 16 + (lane & 15);     // 16-entry chunk of the row
+    if (kc >= d_pad / 16) return;
+    const int64_t row = grp * 16 + r;
+    if (row >= count || (need && need[row] == 0)) return;
+    const int m = rows[row].radix;
+    const v4i c4 = *reinterpret_cast<const v4i*>(coarse_fm + (grp * nk + (kc >> 2)) * 1024 + (((kc & 3) << 4) + r) * 16);
+    const v4i l4 = *reinterpret_cast<const v4i*>(lo_wire + row * (int64_t)d_pad + kc * 16);
+    const int h = (m + 1) >> 1, edge = 127 * m - h + 127;
+    v4i h4;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            uint32_t ph = 0;
+    for (int w = 0; w < 4; ++w) {
+        uint32_t ph = 0;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int c = (int)(int8_t)((uint32_t)c4[w] >> (8 * e));
-                const int l0 = (int)(int8_t)((uint32_t)l4[w] >> (8 * e));
-                const int t = c == 127 ? edge : (c == -127 ? -edge : m * c);
-                const int v = t + (int)(int8_t)(l0 - t);
-                ph |= (uint32_t)(uint8_t)(int8_t)((v - l0) >> 8) << (8 * e);
-            }
-            h4[w] = (int)ph;
+        for (int e = 0; e < 4; ++e) {
+            const int c = (int)(int8_t)((uint32_t)c4[w] >> (8 * e));
+            const int l0 = (int)(int8_t)((uint32_t)l4[w] >> (8 * e));
+            const int t = c == 127 ? edge : (c == -127 ? -edge : m * c);
+            const int v = t + (int)(int8_t)(l0 - t);
+            ph |= (uint32_t)(uint8_t)(int8_t)((v - l0) >> 8) << (8 * e);
         }
-        *reinterpret_cast<v4i*>(planes + row * 2 * (int64_t)d_pad + kc * 16) = l4;
-        *reinterpret_cast<v4i*>(planes + (row * 2 + 1) * (int64_t)d_pad + kc * 16) = h4;
+        h4[w] = (int)ph;
     }
+    *reinterpret_cast<v4i*>(planes + row * 2 * (int64_t)d_pad + kc * 16) = l4;
+    *reinterpret_cast<v4i*>(planes + (row * 2 + 1) * (int64_t)d_pad + kc * 16) = h4;
 }
 
 // per-call filter constants {s, w, a, p} (see above); padding rows never pass (s = +inf)
@@ -558,12 +561,15 @@ int launch_coarse_fm(hipStream_t stream, const int8_t* d_coarse, int64_t n_alloc
     return 0;
 }
 
-// rows [0, count) (count a multiple of 16; all pointers at the range's first row, which is a multiple of 16)
+// rows [0, count) (count a multiple of 16; all pointers at the range's first row, which is a multiple of 16) except rows
+// [skip_first, skip_first + skip_count) (multiples of 16 too; 0, 0: none)
 int launch_planes_from_wire(hipStream_t stream, const int8_t* d_lo_wire, const int8_t* d_coarse_fm, const CoarseRow* d_rows,
-                            int64_t count, int d_pad, int8_t* d_planes, const unsigned char* d_need) {
-    if (count <= 0) return 0;
-    hipLaunchKernelGGL(k_planes_from_wire, dim3((unsigned)(count / 16), (unsigned)((d_pad / 16 * 16 + 255) / 256)), dim3(256), 0, stream,
-                       d_lo_wire, d_coarse_fm, d_rows, count, d_pad, d_planes, d_need);
+                            int64_t count, int d_pad, int8_t* d_planes, const unsigned char* d_need, int64_t skip_first,
+                            int64_t skip_count) {
+    const int64_t groups = count / 16 - skip_count / 16;
+    if (groups <= 0) return 0;
+    hipLaunchKernelGGL(k_planes_from_wire, dim3((unsigned)groups, (unsigned)((d_pad / 16 + 15) / 16)), dim3(256), 0, stream,
+                       d_lo_wire, d_coarse_fm, d_rows, count, d_pad, d_planes, d_need, skip_first / 16, (skip_first + skip_count) / 16);
     return 0;
 }
 
