@@ -425,29 +425,16 @@ __global__ __launch_bounds__(256) void k_rows_needed(const PairwiseArgs a, int n
 
 // k_planes_from_wire: limb planes of rows whose LOW limb arrived in a wire buffer (lo[row * d_pad + k]) and whose coarse
 // plane and statistics are in place (fragment-major, as the filter reads them): both limb rows are written -- the rule is
-// at radix_keeps_high_limb.  A workgroup takes 16 rows (one KiB of the fragment-major plane holds 16 rows x 64 k) x 256 k.
-// [r6] A WAVE takes 4 rows x 16 chunks of 16 k: per row 256 contiguous bytes of the wire and of either limb row (whole cache
-// lines; the first mapping, 16 rows x 4 chunks per wave, touched 64-byte halves of 16 lines per instruction and moved
-// 3.1 TB/s), and of the coarse plane the four adjacent 16-byte pieces of its rows in each of 16 sub-blocks -- the workgroup's
-// four waves use every line of its 4 KiB whole, and a wave none of whose rows is wanted reads nothing.
+// at radix_keeps_high_limb.  A workgroup takes 16 rows (one KiB of the fragment-major plane holds 16 rows x 64 k), a wave
+// 8 rows x 8 chunks of 16 k: whole 128-byte lines of the wire, of either limb row and of the coarse plane (the eight
+// adjacent 16-byte pieces of its rows in a 256-byte sub-block).
 // need != NULL: only the rows marked there (k_rows_needed: what a plan's re-check and flagged tiles will read).
 // Groups [skip0, skip1) (units of 16 rows) are left alone: a plan's own frame, so that ONE launch covers the rows on both sides.
-__global__ __launch_bounds__(256) void k_planes_from_wire(const int8_t* __restrict__ lo_wire, const int8_t* __restrict__ coarse_fm,
-                                                          const CoarseRow* __restrict__ rows, int64_t count, int d_pad,
-                                                          int8_t* __restrict__ planes, const unsigned char* __restrict__ need,
-                                                          int64_t skip0, int64_t skip1) {
-    const int nk = d_pad / 64;
-    int64_t grp = blockIdx.x;                              // 16 rows
-    if (grp >= skip0) grp += skip1 - skip0;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r = wave * 4 + (lane >> 4);
-    const int kc = (int)blockIdx.y * 16 + (lane & 15);     // 16-entry chunk of the row
-    if (kc >= d_pad / 16) return;
-    const int64_t row = grp * 16 + r;
-    if (row >= count || (need && need[row] == 0)) return;
-    const int m = rows[row].radix;
-    const v4i c4 = *reinterpret_cast<const v4i*>(coarse_fm + (grp * nk + (kc >> 2)) * 1024 + (((kc & 3) << 4) + r) * 16);
-    const v4i l4 = *reinterpret_cast<const v4i*>(lo_wire + row * (int64_t)d_pad + kc * 16);
+// [r6] Measured on one rank's step of an 8-way split of 100k x 2048 (~36 000 wanted rows of 75 000: ~375 MB -- the coarse
+// plane's lines hold 8 rows each, so nearly all of it is read): 16 rows x 4 chunks per wave, one launch per side and per
+// 256 k: 4.6 + 83.3 us; 4 x 16 or 8 x 8 per wave: 86; a thread walking its row with all loads in flight (KB below): 77-79 us
+// = 4.9 TB/s of mixed reads and writes.  It is bound by the bytes, not by how they are asked for.
+__device__ __forceinline__ v4i high_limbs_from_wire(const v4i c4, const v4i l4, int m) {
     const int h = (m + 1) >> 1, edge = 127 * m - h + 127;
     v4i h4;
 #pragma unroll
@@ -463,8 +450,49 @@ __global__ __launch_bounds__(256) void k_planes_from_wire(const int8_t* __restri
         }
         h4[w] = (int)ph;
     }
-    *reinterpret_cast<v4i*>(planes + row * 2 * (int64_t)d_pad + kc * 16) = l4;
-    *reinterpret_cast<v4i*>(planes + (row * 2 + 1) * (int64_t)d_pad + kc * 16) = h4;
+    return h4;
+}
+
+// KB: 16-chunk blocks (256 k) a thread walks with ALL their loads in flight before the first is used (8 = a row of 2048 k
+// in one go: 16 loads of 16 bytes per lane, two rounds of memory latency per wave -- the row marks and radices, then the
+// data -- instead of two rounds per 256 k)
+template <int KB>
+__global__ __launch_bounds__(256) void k_planes_from_wire(const int8_t* __restrict__ lo_wire, const int8_t* __restrict__ coarse_fm,
+                                                          const CoarseRow* __restrict__ rows, int64_t count, int d_pad,
+                                                          int8_t* __restrict__ planes, const unsigned char* __restrict__ need,
+                                                          int64_t skip0, int64_t skip1) {
+    const int nk = d_pad / 64;
+    int64_t grp = blockIdx.x;                              // 16 rows
+    if (grp >= skip0) grp += skip1 - skip0;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = (wave & 1) * 8 + (lane >> 3);            // a wave: 8 rows x 8 chunks = whole 128-byte lines of all three arrays
+    const int64_t row = grp * 16 + r;
+    if (row >= count || (need && need[row] == 0)) return;
+    const int m = rows[row].radix;
+    const int chunks = d_pad / 16;
+    const int8_t* cbase = coarse_fm + grp * nk * 1024 + r * 16;
+    const int8_t* lbase = lo_wire + row * (int64_t)d_pad;
+    int8_t* p0 = planes + row * 2 * (int64_t)d_pad;
+    int8_t* p1 = p0 + d_pad;
+    for (int kc0 = (int)blockIdx.y * 16 * KB + (wave >> 1) * 8 + (lane & 7); kc0 < chunks; kc0 += (int)gridDim.y * 16 * KB) {
+        v4i c4[KB], l4[KB];
+#pragma unroll
+        for (int j = 0; j < KB; ++j) {
+            const int kc = kc0 + 16 * j;
+            if (kc < chunks) {
+                c4[j] = *reinterpret_cast<const v4i*>(cbase + (kc >> 2) * 1024 + ((kc & 3) << 8));
+                l4[j] = *reinterpret_cast<const v4i*>(lbase + kc * 16);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < KB; ++j) {
+            const int kc = kc0 + 16 * j;
+            if (kc < chunks) {
+                *reinterpret_cast<v4i*>(p0 + kc * 16) = l4[j];
+                *reinterpret_cast<v4i*>(p1 + kc * 16) = high_limbs_from_wire(c4[j], l4[j], m);
+            }
+        }
+    }
 }
 
 // per-call filter constants {s, w, a, p} (see above); padding rows never pass (s = +inf)
@@ -568,8 +596,13 @@ int launch_planes_from_wire(hipStream_t stream, const int8_t* d_lo_wire, const i
                             int64_t skip_count) {
     const int64_t groups = count / 16 - skip_count / 16;
     if (groups <= 0) return 0;
-    hipLaunchKernelGGL(k_planes_from_wire, dim3((unsigned)groups, (unsigned)((d_pad / 16 + 15) / 16)), dim3(256), 0, stream,
-                       d_lo_wire, d_coarse_fm, d_rows, count, d_pad, d_planes, d_need, skip_first / 16, (skip_first + skip_count) / 16);
+    const int blocks16 = (d_pad / 16 + 15) / 16;                          // 16-chunk blocks per row
+    if (d_pad % 256 == 0 && blocks16 >= 8)
+        hipLaunchKernelGGL(k_planes_from_wire<8>, dim3((unsigned)groups, (unsigned)((blocks16 + 7) / 8)), dim3(256), 0, stream, d_lo_wire,
+                           d_coarse_fm, d_rows, count, d_pad, d_planes, d_need, skip_first / 16, (skip_first + skip_count) / 16);
+    else
+        hipLaunchKernelGGL(k_planes_from_wire<1>, dim3((unsigned)groups, (unsigned)blocks16), dim3(256), 0, stream, d_lo_wire,
+                           d_coarse_fm, d_rows, count, d_pad, d_planes, d_need, skip_first / 16, (skip_first + skip_count) / 16);
     return 0;
 }
 
