@@ -425,15 +425,13 @@ __global__ __launch_bounds__(256) void k_rows_needed(const PairwiseArgs a, int n
 
 // k_planes_from_wire: limb planes of rows whose LOW limb arrived in a wire buffer (lo[row * d_pad + k]) and whose coarse
 // plane and statistics are in place (fragment-major, as the filter reads them): both limb rows are written -- the rule is
-// at radix_keeps_high_limb.  A workgroup takes 16 rows (one KiB of the fragment-major plane holds 16 rows x 64 k), a wave
-// 8 rows x 8 chunks of 16 k: whole 128-byte lines of the wire, of either limb row and of the coarse plane (the eight
-// adjacent 16-byte pieces of its rows in a 256-byte sub-block).
+// at radix_keeps_high_limb.  A workgroup takes 16 rows (one KiB of the fragment-major plane holds 16 rows x 64 k), a wave one.
 // need != NULL: only the rows marked there (k_rows_needed: what a plan's re-check and flagged tiles will read).
 // Groups [skip0, skip1) (units of 16 rows) are left alone: a plan's own frame, so that ONE launch covers the rows on both sides.
-// [r6] Measured on one rank's step of an 8-way split of 100k x 2048 (~36 000 wanted rows of 75 000: ~375 MB -- the coarse
-// plane's lines hold 8 rows each, so nearly all of it is read): 16 rows x 4 chunks per wave, one launch per side and per
-// 256 k: 4.6 + 83.3 us; 4 x 16 or 8 x 8 per wave: 86; a thread walking its row with all loads in flight (KB below): 77-79 us
-// = 4.9 TB/s of mixed reads and writes.  It is bound by the bytes, not by how they are asked for.
+// [r6] Measured on one rank's step of an 8-way split of 100k x 2048 (about a quarter of the 75 000 foreign rows wanted; a 128-byte
+// line of the coarse plane holds 8 rows, so nearly all 154 MB of it are read; 256 MB in all by the counters): 16 rows x 4 chunks
+// per wave, one launch per side of the frame and per 256 k: 4.6 + 83.3 us; 4 x 16 or 8 x 8 per wave in one launch: 86; the same with
+// a thread walking its whole row, all loads in flight: 77-79; a wave per row (below): 66 us = 3.9 TB/s.
 __device__ __forceinline__ v4i high_limbs_from_wire(const v4i c4, const v4i l4, int m) {
     const int h = (m + 1) >> 1, edge = 127 * m - h + 127;
     v4i h4;
@@ -445,27 +443,30 @@ __device__ __forceinline__ v4i high_limbs_from_wire(const v4i c4, const v4i l4, 
             const int c = (int)(int8_t)((uint32_t)c4[w] >> (8 * e));
             const int l0 = (int)(int8_t)((uint32_t)l4[w] >> (8 * e));
             const int t = c == 127 ? edge : (c == -127 ? -edge : m * c);
-            const int v = t + (int)(int8_t)(l0 - t);
-            ph |= (uint32_t)(uint8_t)(int8_t)((v - l0) >> 8) << (8 * e);
+            // v = t + wrap8(l0 - t) is the value congruent to l0 near t, and (v - l0) / 256 = floor((t - l0 + 127) / 256)
+            ph |= (uint32_t)(uint8_t)((t - l0 + 127) >> 8) << (8 * e);
         }
         h4[w] = (int)ph;
     }
     return h4;
 }
 
-// KB: 16-chunk blocks (256 k) a thread walks with ALL their loads in flight before the first is used (8 = a row of 2048 k
-// in one go: 16 loads of 16 bytes per lane, two rounds of memory latency per wave -- the row marks and radices, then the
-// data -- instead of two rounds per 256 k)
-template <int KB>
-__global__ __launch_bounds__(256) void k_planes_from_wire(const int8_t* __restrict__ lo_wire, const int8_t* __restrict__ coarse_fm,
-                                                          const CoarseRow* __restrict__ rows, int64_t count, int d_pad,
-                                                          int8_t* __restrict__ planes, const unsigned char* __restrict__ need,
-                                                          int64_t skip0, int64_t skip1) {
+// A WAVE PER ROW (16 waves = the 16 rows of a group per workgroup), a lane per 16-k chunk, KJ rounds of 64 chunks with all their
+// loads in flight: a wave either has its row wanted -- then all 64 lanes work -- or leaves at once.  With several rows per wave
+// (8 x 8, 4 x 16, 16 x 4 were all tried) three lanes of four idle through the ~12 instructions per entry of the rule whenever
+// one row of the wave is wanted (a quarter to a half of the rows are), and the counters showed the kernel busy, not waiting
+// (SQ_WAIT_ANY 0.27 of the wave cycles, 256 MB at 3.4 TB/s).  The coarse pieces of one row are 16 bytes in every 256: the
+// wanted rows of a group run on ONE CU at the same time and meet in its L1 / the XCD's L2 on the lines they share.
+template <int KJ>
+__global__ __launch_bounds__(1024) void k_planes_from_wire(const int8_t* __restrict__ lo_wire, const int8_t* __restrict__ coarse_fm,
+                                                           const CoarseRow* __restrict__ rows, int64_t count, int d_pad,
+                                                           int8_t* __restrict__ planes, const unsigned char* __restrict__ need,
+                                                           int64_t skip0, int64_t skip1) {
     const int nk = d_pad / 64;
     int64_t grp = blockIdx.x;                              // 16 rows
     if (grp >= skip0) grp += skip1 - skip0;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r = (wave & 1) * 8 + (lane >> 3);            // a wave: 8 rows x 8 chunks = whole 128-byte lines of all three arrays
+    const int lane = threadIdx.x & 63;
+    const int r = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t row = grp * 16 + r;
     if (row >= count || (need && need[row] == 0)) return;
     const int m = rows[row].radix;
@@ -474,19 +475,19 @@ __global__ __launch_bounds__(256) void k_planes_from_wire(const int8_t* __restri
     const int8_t* lbase = lo_wire + row * (int64_t)d_pad;
     int8_t* p0 = planes + row * 2 * (int64_t)d_pad;
     int8_t* p1 = p0 + d_pad;
-    for (int kc0 = (int)blockIdx.y * 16 * KB + (wave >> 1) * 8 + (lane & 7); kc0 < chunks; kc0 += (int)gridDim.y * 16 * KB) {
-        v4i c4[KB], l4[KB];
+    for (int kc0 = lane; kc0 < chunks; kc0 += 64 * KJ) {
+        v4i c4[KJ], l4[KJ];
 #pragma unroll
-        for (int j = 0; j < KB; ++j) {
-            const int kc = kc0 + 16 * j;
+        for (int j = 0; j < KJ; ++j) {
+            const int kc = kc0 + 64 * j;
             if (kc < chunks) {
                 c4[j] = *reinterpret_cast<const v4i*>(cbase + (kc >> 2) * 1024 + ((kc & 3) << 8));
                 l4[j] = *reinterpret_cast<const v4i*>(lbase + kc * 16);
             }
         }
 #pragma unroll
-        for (int j = 0; j < KB; ++j) {
-            const int kc = kc0 + 16 * j;
+        for (int j = 0; j < KJ; ++j) {
+            const int kc = kc0 + 64 * j;
             if (kc < chunks) {
                 *reinterpret_cast<v4i*>(p0 + kc * 16) = l4[j];
                 *reinterpret_cast<v4i*>(p1 + kc * 16) = high_limbs_from_wire(c4[j], l4[j], m);
@@ -596,13 +597,8 @@ int launch_planes_from_wire(hipStream_t stream, const int8_t* d_lo_wire, const i
                             int64_t skip_count) {
     const int64_t groups = count / 16 - skip_count / 16;
     if (groups <= 0) return 0;
-    const int blocks16 = (d_pad / 16 + 15) / 16;                          // 16-chunk blocks per row
-    if (d_pad % 256 == 0 && blocks16 >= 8)
-        hipLaunchKernelGGL(k_planes_from_wire<8>, dim3((unsigned)groups, (unsigned)((blocks16 + 7) / 8)), dim3(256), 0, stream, d_lo_wire,
-                           d_coarse_fm, d_rows, count, d_pad, d_planes, d_need, skip_first / 16, (skip_first + skip_count) / 16);
-    else
-        hipLaunchKernelGGL(k_planes_from_wire<1>, dim3((unsigned)groups, (unsigned)blocks16), dim3(256), 0, stream, d_lo_wire,
-                           d_coarse_fm, d_rows, count, d_pad, d_planes, d_need, skip_first / 16, (skip_first + skip_count) / 16);
+    hipLaunchKernelGGL(k_planes_from_wire<2>, dim3((unsigned)groups), dim3(1024), 0, stream, d_lo_wire, d_coarse_fm, d_rows, count, d_pad,
+                       d_planes, d_need, skip_first / 16, (skip_first + skip_count) / 16);
     return 0;
 }
 
