@@ -40,9 +40,9 @@ run_set() {   # name, command...
     echo "$*" > "$OUT/${name}_pmc/command.txt"
 }
 
-if want c1; then run_set c1 python3 "$REPO/bench.py" --steps 3 --warmup 2 --no-cpu-baseline --pairwise-samples 0 --stream-samples 0 --search-samples 0 --density-samples 0 --strong-steps 0 || exit 1; fi
-if want c2; then export MVS_PAIRWISE_FILTER=1; run_set c2 python3 "$REPO/tools/run_pairwise.py" 100000 2048 4 || exit 1; unset MVS_PAIRWISE_FILTER; fi
-if want c2x; then export MVS_PAIRWISE_FILTER=0; run_set c2x python3 "$REPO/tools/run_pairwise.py" 100000 2048 3 || exit 1; unset MVS_PAIRWISE_FILTER; fi
+if want c1; then run_set c1 python3 "$REPO/bench.py" --steps 20 --warmup 10 --no-cpu-baseline --pairwise-samples 0 --stream-samples 0 --search-samples 0 --density-samples 0 --strong-steps 0 || exit 1; fi
+if want c2; then export MVS_PAIRWISE_FILTER=1; run_set c2 python3 "$REPO/tools/run_pairwise.py" 100000 2048 12 || exit 1; unset MVS_PAIRWISE_FILTER; fi
+if want c2x; then export MVS_PAIRWISE_FILTER=0; run_set c2x python3 "$REPO/tools/run_pairwise.py" 100000 2048 6 || exit 1; unset MVS_PAIRWISE_FILTER; fi
 if want c2d; then run_set c2d python3 "$REPO/tools/stream_bench.py" 100000 2048 10000 2 encoded || exit 1; fi
 if want srch; then run_set srch python3 "$REPO/tools/search_bench.py" 1000000 2048 64 6 || exit 1; fi
 if want c3s; then run_set c3s python3 "$REPO/bench.py" --config 3 --gpus 1 --steps 3 --warmup 2 || exit 1; fi
