@@ -244,6 +244,31 @@ def test_bare_bench_gpus2_keeps_its_headline_when_the_strong_legs_do_not_finish(
     assert "did not finish within 1 s" in d["strong"]["error"]
 
 
+def test_bare_bench_gpus2_moves_to_torchs_collectives_when_one_rank_finds_no_native_communicator():
+    """bench.py's communicator set-up agrees in two phases (what a rank finds out alone, then the collective creation): a rank
+    whose library binds no RCCL (test hook MVS_BENCH_FAIL_NATIVE_COMM=<rank>) takes every rank to torch.distributed's collectives
+    -- before the change the other rank waited inside the communicator's creation for ever --, the line says so, the cells are the
+    same; with --require-native-collectives every rank exits 3 instead"""
+    import subprocess
+    want = _bare_bench(["--samples", "2000", "--hashes", "4000", "--strong-steps", "0"])
+    os.environ["MVS_BENCH_FAIL_NATIVE_COMM"] = "1"
+    try:
+        d = _bare_bench(["--samples", "2000", "--hashes", "4000", "--strong-steps", "0"])
+        env = {k: v for k, v in os.environ.items()
+               if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "MVS_PAIRWISE_FILTER")}
+        env["MVS_BENCH_REHEARSAL"] = "1"
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                            "--no-cpu-baseline", "--samples", "2000", "--hashes", "4000", "--strong-steps", "0",
+                            "--require-native-collectives"], env=env, capture_output=True, text=True, timeout=300)
+    finally:
+        del os.environ["MVS_BENCH_FAIL_NATIVE_COMM"]
+    assert d["config"]["collectives"] == "torch.distributed" and d["config"]["rccl_ranks"] == 0
+    assert "carries the exchange instead of the library's communicator" in d["config"]["collectives_note"]
+    assert d["config"]["kept_cells"] == want["config"]["kept_cells"] and want["config"]["collectives"].startswith("libmvs_hip mvs_comm")
+    assert r.returncode == 3 and not [l for l in r.stdout.splitlines() if l.startswith("{")], (r.returncode, r.stderr[-1500:])
+    assert "not falling back (--require-native-collectives)" in r.stderr
+
+
 def test_bare_bench_gpus2_config4_launches_itself():
     d = _bare_bench(["--config", "4"])
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["total_samples"] == 100_000
